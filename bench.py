@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config.
+
+metric  : inferences/sec at batch 256 (Model-A = embedding_47_krnl tables + FC 352-1024-512-256-1, fp32 FC),
+          all tables resident in one GPU's HBM (BASELINE configs[1]); plus the embedding-gather HBM GB/s
+          against peak on the largest model (Model-C, batch 4096) as the extra "gather" object.
+step    : one pass of the hot path (index rows -> gather+pack -> 4-GEMM FC chain -> scores) over one batch
+          of 256 synthetic requests whose index rows are already resident in HBM.
+N > 1   : the path shards by independent request batches -> one replica per GPU, no data-path collective
+          ("scaling": "weak"); value = batches all ranks processed / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3   # dense f32-input MFMA peak (same guide)
+SEED_TABLES, SEED_IDX, SEED_WEIGHTS = 0xF1EE7, 1234, 99
+N_IDX_BUFFERS = 32         # distinct index buffers rotated through, so caches are not re-hit artificially
+
+
+def gather_bytes_per_inference(model, fr):
+    """row reads + index reads + dense read + record write."""
+    rows = sum(s.len * 4 for s in model.segments() if s.kind != fr.SEG_DENSE)
+    idx = 4 * model.n_tables
+    dense = 4 * model.dense_len
+    write = 4 * model.record_len
+    return rows + idx + dense + write
+
+
+def fc_flops_per_inference(fc):
+    return 2 * sum(fc[i] * fc[i + 1] for i in range(4))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--workers", type=int, default=4, help="host workers/streams in flight (reference THREAD_NUM = 4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-model-c", action="store_true", help="skip the Model-C batch-4096 gather roofline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    fr = graft.load_package()
+    if fr.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+
+    B = args.batch
+    model = fr.Model.builtin(fr.MODEL_A)
+    ctx = fr.Context(model, device=local_rank)
+    ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    rng = np.random.default_rng(SEED_IDX + rank)
+    rows = model.rows()
+    idx_host = [(rng.random((B, model.n_tables)) * rows[None, :]).astype(np.int32) for _ in range(N_IDX_BUFFERS)]
+    d_idx = [fr.DeviceBuffer.from_numpy(ctx, a) for a in idx_host]
+    workers = [fr.Worker(ctx, B) for _ in range(args.workers)]
+    d_scores = [fr.DeviceBuffer(ctx, B * 4) for _ in range(args.workers)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    def run_steps(n):
+        """n batches round-robin over the workers; a worker is synced before it is reused."""
+        W = len(workers)
+        for i in range(n):
+            w = i % W
+            if i >= W:
+                workers[w].sync()
+            workers[w].submit_device(B, d_idx[i % N_IDX_BUFFERS], None, d_scores[w])
+        for w in range(min(W, n)):
+            workers[w].sync()
+
+    run_steps(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    result = None
+    if rank == 0:
+        value = world * args.steps * B / dt
+        result = {
+            "metric": "inferences/sec at batch 256", "value": value, "unit": "inferences/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Model-A (embedding_47_krnl: 47 tables, 1.415 GB) batch=%d, fp32 FC 352-1024-512-256-1, "
+                                   "all tables resident in one GPU's HBM; hash-filled tables, uniform indices, "
+                                   "index rows resident in HBM" % B,
+                       "batch": B, "workers_in_flight": args.workers, "parallelism": "replicas x%d" % world},
+        }
+        # ---- roofline of the dominant kernel: measured live with HIP events on the worker's stream ----
+        wk = workers[0]
+        rec = wk.records_dptr()
+        reps = 200
+        # FC chain (the dominant part at batch 256: 0.52 GFLOP vs 0.77 MB of gather traffic)
+        for _ in range(20):
+            wk.fc_only(B, rec, d_scores[0])
+        wk.sync()
+        wk.timer_start()
+        for _ in range(reps):
+            wk.fc_only(B, rec, d_scores[0])
+        fc_ms = wk.timer_stop_ms() / reps
+        wk.sync()
+        flops = fc_flops_per_inference(model.fc) * B
+        ach = flops / (fc_ms * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                              "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+                              "kernel": "fc chain (3x fc_f32_kernel + fc_out_kernel), avg per batch",
+                              "avg_launch_ms": fc_ms, "algorithmic_flops_per_launch": flops}
+        # gather kernel at the bench batch
+        for _ in range(20):
+            wk.gather_only(B, d_idx[0], None, rec)
+        wk.sync()
+        wk.timer_start()
+        for i in range(reps):
+            wk.gather_only(B, d_idx[i % N_IDX_BUFFERS], None, rec)
+        g_ms = wk.timer_stop_ms() / reps
+        wk.sync()
+        gb = gather_bytes_per_inference(model, fr) * B
+        result["gather_roofline_bench_batch"] = {"bound": "hbm", "achieved": gb / (g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                                 "unit": "GB/s", "frac": gb / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                 "avg_launch_ms": g_ms, "algorithmic_bytes_per_launch": gb}
+
+        # ---- CPU baseline: the oracle ("port") on this node's host cores, bounded sample -------------
+        if not args.no_cpu_baseline:
+            O = graft.load_oracle()
+            om = O.OracleModel("A")
+            ws = [ctx.get_weights(l) for l in range(4)]
+            nthreads = O.lib().oracle_num_threads()
+            n_done, t_cpu = 0, 0.0
+            t_start = time.perf_counter()
+            while time.perf_counter() - t_start < 10.0:
+                a = idx_host[n_done % N_IDX_BUFFERS]
+                t1 = time.perf_counter()
+                r = om.gather(a, content_mode=O.FILL_HASH, seed=SEED_TABLES)
+                om.fc_chain(r.view(np.float32), ws, acc64=False)
+                t_cpu += time.perf_counter() - t1
+                n_done += 1
+            result["cpu_baseline"] = {"value": n_done * B / t_cpu, "unit": "inferences/s", "cores": nthreads, "kind": "port",
+                                      "sample": "%d batches of %d (Model-A, same seeded indices; oracle C port: OpenMP gather with "
+                                                "on-the-fly hash tables + fp32 4-GEMM chain)" % (n_done, B)}
+
+    for w in workers:
+        w.close()
+    for b in d_idx + d_scores:
+        b.free()
+    ctx.close()
+
+    # ---- the headline gather measurement: Model-C, batch 4096 (rank 0, N=1 only) -------------------------
+    if rank == 0 and world == 1 and not args.no_model_c:
+        try:
+            mc = fr.Model.builtin(fr.MODEL_C)
+            cc = fr.Context(mc, device=local_rank)
+            cc.fill_tables(fr.FILL_HASH, SEED_TABLES)
+            BC = 4096
+            rng = np.random.default_rng(SEED_IDX)
+            rows = mc.rows()
+            nbuf = 8
+            idxs = [fr.DeviceBuffer.from_numpy(cc, (rng.random((BC, mc.n_tables)) * rows[None, :]).astype(np.int32)) for _ in range(nbuf)]
+            dns = [fr.DeviceBuffer.from_numpy(cc, rng.uniform(-1, 1, (BC, mc.dense_len)).astype(np.float32)) for _ in range(nbuf)]
+            wk = fr.Worker(cc, BC)
+            rec = wk.records_dptr()
+            for i in range(10):
+                wk.gather_only(BC, idxs[i % nbuf], dns[i % nbuf], rec)
+            wk.sync()
+            reps = 100
+            wk.timer_start()
+            for i in range(reps):
+                wk.gather_only(BC, idxs[i % nbuf], dns[i % nbuf], rec)
+            ms = wk.timer_stop_ms() / reps
+            wk.sync()
+            gb = gather_bytes_per_inference(mc, fr) * BC
+            result["gather"] = {"workload": "Model-C (2x embedding_377_krnl + 64 dense: 376 tables, 63.2 GB) batch=4096, uniform indices",
+                                "bound": "hbm", "achieved": gb / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": gb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
+                                "algorithmic_bytes_per_launch": gb, "inferences_per_s": BC / (ms * 1e-3),
+                                "kernel": "gather_pack_kernel<8>"}
+            wk.close()
+            cc.close()
+        except Exception as ex:  # the main metric must still be reported
+            result["gather"] = {"error": str(ex)}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

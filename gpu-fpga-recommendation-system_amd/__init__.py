@@ -1,0 +1,384 @@
+"""fleetrec_amd -- Python host binding of the MI355X-native FleetRec hot path.
+
+A thin ctypes mirror of include/fleetrec.h (the C-ABI in libfleetrec.so).  It exists for the test
+harness and bench.py; the production host is the C++ driver (the counterpart of the reference's
+GPU/final_network_cublasLt_1_node_no_FIFO_scatter/cuda_server.c).  There is no CPU fallback: if the
+HIP library is missing or no gfx950 device is visible, calls raise FleetRecError.
+
+Vocabulary follows the reference: tables, banks, rounds, records (the per-item concatenated
+feature vector the FPGA sends), workers (thread_consume), batches.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfleetrec.so")
+
+FR_OK, FR_ERR_INVALID, FR_ERR_NO_DEVICE, FR_ERR_OOM, FR_ERR_HIP, FR_ERR_INDEX_RANGE, FR_ERR_STATE, FR_ERR_COMM = 0, -1, -2, -3, -4, -5, -6, -7
+MODEL_A, MODEL_B, MODEL_C = 0, 1, 2
+FILL_EVEN_ODD, FILL_HASH, FILL_TAGGED = 0, 1, 2
+WEIGHTS_ONES, WEIGHTS_UNIFORM = 0, 1
+FC_FP32, FC_BF16 = 0, 1
+LAYOUT_SEMANTIC, LAYOUT_BLOCKED = 0, 1
+INDEX_PER_TABLE, INDEX_PER_ITEM = 0, 1
+SEG_TABLE, SEG_COPY, SEG_DENSE = 0, 1, 2
+MEM_CLASS_NAMES = {0: "HBM", 1: "DDR", 2: "PLRAM"}
+
+
+class TableDesc(ctypes.Structure):
+    _fields_ = [("mem_class", ctypes.c_int32), ("table_id", ctypes.c_int32), ("source", ctypes.c_int32),
+                ("dim", ctypes.c_int32), ("rows", ctypes.c_int64), ("bank", ctypes.c_int32),
+                ("round", ctypes.c_int32), ("addr_axi", ctypes.c_int64)]
+
+
+class Segment(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("src", ctypes.c_int32), ("src_col", ctypes.c_int32),
+                ("rec_offset", ctypes.c_int32), ("len", ctypes.c_int32), ("source", ctypes.c_int32)]
+
+
+class ModelDesc(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 32), ("n_tables", ctypes.c_int32), ("n_segments", ctypes.c_int32),
+                ("tables", ctypes.POINTER(TableDesc)), ("segments", ctypes.POINTER(Segment)),
+                ("record_len", ctypes.c_int32), ("dense_len", ctypes.c_int32), ("fc", ctypes.c_int32 * 5),
+                ("layout", ctypes.c_int32), ("index_mode", ctypes.c_int32)]
+
+
+class FleetRecError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("fleetrec status %d: %s" % (status, message))
+        self.status = status
+
+
+_lib = None
+
+# every symbol include/fleetrec.h declares (the not-gpu test checks the .so exports all of them)
+ABI_SYMBOLS = [
+    "fr_abi_version", "fr_last_error", "fr_device_count", "fr_model_builtin", "fr_model_clone_scaled", "fr_model_free",
+    "fr_model_table_bytes", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
+    "fr_ctx_fill_tables", "fr_ctx_upload_table", "fr_ctx_download_table", "fr_ctx_set_weights", "fr_ctx_fill_weights",
+    "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
+    "fr_worker_dense_ptr", "fr_worker_score_ptr", "fr_worker_submit", "fr_worker_submit_device", "fr_worker_sync",
+    "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_records_dptr", "fr_worker_timer_start",
+    "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
+    "fr_device_synchronize", "fr_ctx_shard_info",
+]
+
+
+def lib():
+    """Load libfleetrec.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FleetRecError(FR_ERR_STATE, "HIP library %s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "or `make -C gpu-fpga-recommendation-system_amd/csrc`" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, u32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint32, ctypes.c_size_t
+    pf, pi = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)
+    sig = {
+        "fr_abi_version": (i32, []), "fr_last_error": (ctypes.c_char_p, []), "fr_device_count": (i32, []),
+        "fr_model_builtin": (ctypes.POINTER(ModelDesc), [i32]),
+        "fr_model_clone_scaled": (i32, [ctypes.POINTER(ModelDesc), ctypes.c_double, i64, i64, ctypes.POINTER(ctypes.POINTER(ModelDesc))]),
+        "fr_model_free": (None, [ctypes.POINTER(ModelDesc)]),
+        "fr_model_table_bytes": (i64, [ctypes.POINTER(ModelDesc)]),
+        "fr_ctx_create": (i32, [ctypes.POINTER(ModelDesc), i32, ctypes.POINTER(vp)]),
+        "fr_ctx_create_sharded": (i32, [ctypes.POINTER(ModelDesc), i32, i32, i32, ctypes.POINTER(vp)]),
+        "fr_ctx_destroy": (None, [vp]), "fr_ctx_model": (ctypes.POINTER(ModelDesc), [vp]),
+        "fr_ctx_fill_tables": (i32, [vp, i32, u32]),
+        "fr_ctx_upload_table": (i32, [vp, i32, i64, i64, vp]), "fr_ctx_download_table": (i32, [vp, i32, i64, i64, vp]),
+        "fr_ctx_set_weights": (i32, [vp, i32, vp, sz]), "fr_ctx_fill_weights": (i32, [vp, i32, u32]),
+        "fr_ctx_get_weights": (i32, [vp, i32, vp, sz]), "fr_ctx_set_fc_precision": (i32, [vp, i32]),
+        "fr_worker_create": (i32, [vp, i32, ctypes.POINTER(vp)]), "fr_worker_destroy": (None, [vp]),
+        "fr_worker_idx_ptr": (pi, [vp]), "fr_worker_dense_ptr": (pf, [vp]), "fr_worker_score_ptr": (pf, [vp]),
+        "fr_worker_submit": (i32, [vp, i32]), "fr_worker_submit_device": (i32, [vp, i32, vp, vp, vp]),
+        "fr_worker_sync": (i32, [vp]), "fr_worker_gather_only": (i32, [vp, i32, vp, vp, vp]),
+        "fr_worker_fc_only": (i32, [vp, i32, vp, vp]), "fr_worker_records_dptr": (vp, [vp]),
+        "fr_worker_timer_start": (i32, [vp]), "fr_worker_timer_stop_ms": (i32, [vp, pf]),
+        "fr_device_malloc": (i32, [vp, sz, ctypes.POINTER(vp)]), "fr_device_free": (i32, [vp, vp]),
+        "fr_memcpy_h2d": (i32, [vp, vp, vp, sz]), "fr_memcpy_d2h": (i32, [vp, vp, vp, sz]),
+        "fr_device_synchronize": (i32, [vp]),
+        "fr_ctx_shard_info": (i32, [vp] + [ctypes.POINTER(ctypes.c_int)] * 5),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def _check(status):
+    if status != FR_OK:
+        raise FleetRecError(status, lib().fr_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return lib().fr_device_count()
+
+
+class Model:
+    """A model description (built-in A/B/C, or a row-scaled clone)."""
+
+    def __init__(self, ptr, owned=False, keepalive=None):
+        self._ptr, self._owned, self._keep = ptr, owned, keepalive
+
+    @classmethod
+    def builtin(cls, which):
+        p = lib().fr_model_builtin(which)
+        if not p:
+            _check(FR_ERR_INVALID)
+        return cls(p)
+
+    def clone(self, row_scale=1.0, min_rows=1, max_rows=0, layout=None, index_mode=None):
+        out = ctypes.POINTER(ModelDesc)()
+        _check(lib().fr_model_clone_scaled(self._ptr, row_scale, min_rows, max_rows, ctypes.byref(out)))
+        m = Model(out, owned=True)
+        if layout is not None:
+            out.contents.layout = layout
+        if index_mode is not None:
+            out.contents.index_mode = index_mode
+        return m
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and self._ptr:
+            lib().fr_model_free(self._ptr)
+            self._ptr = None
+
+    @property
+    def desc(self):
+        return self._ptr.contents
+
+    @property
+    def name(self):
+        return self.desc.name.decode()
+
+    @property
+    def n_tables(self):
+        return self.desc.n_tables
+
+    @property
+    def record_len(self):
+        return self.desc.record_len
+
+    @property
+    def dense_len(self):
+        return self.desc.dense_len
+
+    @property
+    def fc(self):
+        return list(self.desc.fc)
+
+    @property
+    def idx_cols(self):
+        return self.desc.n_tables if self.desc.index_mode == INDEX_PER_TABLE else 1
+
+    def tables(self):
+        d = self.desc
+        return [d.tables[i] for i in range(d.n_tables)]
+
+    def segments(self):
+        d = self.desc
+        return [d.segments[i] for i in range(d.n_segments)]
+
+    def rows(self):
+        return np.array([t.rows for t in self.tables()], dtype=np.int64)
+
+    def table_bytes(self):
+        return lib().fr_model_table_bytes(self._ptr)
+
+
+class DeviceBuffer:
+    """Raw HBM allocation made through the C-ABI (no torch involved)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = ctypes.c_void_p()
+        _check(lib().fr_device_malloc(ctx._h, self.nbytes, ctypes.byref(p)))
+        self.ptr = p
+
+    @classmethod
+    def from_numpy(cls, ctx, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(ctx, arr.nbytes)
+        b.upload(arr)
+        return b
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        _check(lib().fr_memcpy_h2d(self.ctx._h, self.ptr, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes))
+
+    def download(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        _check(lib().fr_memcpy_d2h(self.ctx._h, out.ctypes.data_as(ctypes.c_void_p), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().fr_device_free(self.ctx._h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """Device + model + tables + weights; shared by all workers (one per GPU)."""
+
+    def __init__(self, model, device=0, shard_rank=0, n_shards=1):
+        self.model = model
+        h = ctypes.c_void_p()
+        _check(lib().fr_ctx_create_sharded(model._ptr, device, shard_rank, n_shards, ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().fr_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def fill_tables(self, mode, seed=0):
+        _check(lib().fr_ctx_fill_tables(self._h, mode, seed))
+
+    def upload_table(self, table, rows_f32, row0=0):
+        a = np.ascontiguousarray(rows_f32)
+        assert a.dtype in (np.float32, np.uint32)
+        nrows = a.shape[0]
+        _check(lib().fr_ctx_upload_table(self._h, table, row0, nrows, a.ctypes.data_as(ctypes.c_void_p)))
+
+    def download_table(self, table, row0, nrows, dtype=np.uint32):
+        dim = self.model.desc.tables[table].dim
+        out = np.empty((nrows, dim), dtype=dtype)
+        _check(lib().fr_ctx_download_table(self._h, table, row0, nrows, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def set_weights(self, layer, w_colmajor):
+        w = np.ascontiguousarray(w_colmajor, dtype=np.float32).ravel()
+        _check(lib().fr_ctx_set_weights(self._h, layer, w.ctypes.data_as(ctypes.c_void_p), w.size))
+
+    def fill_weights(self, mode, seed=0):
+        _check(lib().fr_ctx_fill_weights(self._h, mode, seed))
+
+    def get_weights(self, layer):
+        fc = self.model.fc
+        w = np.empty(fc[layer] * fc[layer + 1], dtype=np.float32)
+        _check(lib().fr_ctx_get_weights(self._h, layer, w.ctypes.data_as(ctypes.c_void_p), w.size))
+        return w
+
+    def set_fc_precision(self, precision):
+        _check(lib().fr_ctx_set_fc_precision(self._h, precision))
+
+    def shard_info(self):
+        v = [ctypes.c_int() for _ in range(5)]
+        _check(lib().fr_ctx_shard_info(self._h, *[ctypes.byref(x) for x in v]))
+        return dict(zip(["shard_rank", "n_shards", "slice_offset", "slice_len", "slice_padded"], [x.value for x in v]))
+
+    def synchronize(self):
+        _check(lib().fr_device_synchronize(self._h))
+
+    def buffer(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+
+class Worker:
+    """One stream + staging buffers = one thread_consume() of the reference server."""
+
+    def __init__(self, ctx, max_batch):
+        self.ctx, self.max_batch = ctx, max_batch
+        h = ctypes.c_void_p()
+        _check(lib().fr_worker_create(ctx._h, max_batch, ctypes.byref(h)))
+        self._h = h
+        m = ctx.model
+        self.idx = np.ctypeslib.as_array(lib().fr_worker_idx_ptr(h), shape=(max_batch, m.idx_cols))
+        self.score = np.ctypeslib.as_array(lib().fr_worker_score_ptr(h), shape=(max_batch,))
+        self.dense = (np.ctypeslib.as_array(lib().fr_worker_dense_ptr(h), shape=(max_batch, m.dense_len))
+                      if m.dense_len else None)
+
+    def close(self):
+        if self._h:
+            lib().fr_worker_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, batch):
+        _check(lib().fr_worker_submit(self._h, batch))
+
+    def sync(self):
+        _check(lib().fr_worker_sync(self._h))
+
+    def infer(self, idx, dense=None):
+        """Host-buffer path: idx int32 [B][idx_cols] (+ dense float32 [B][dense_len]) -> scores float32 [B]."""
+        idx = np.asarray(idx, dtype=np.int32).reshape(len(idx), -1)
+        B = idx.shape[0]
+        self.idx[:B] = idx
+        if self.dense is not None:
+            self.dense[:B] = np.asarray(dense, dtype=np.float32).reshape(B, -1)
+        self.submit(B)
+        self.sync()
+        return self.score[:B].copy()
+
+    @staticmethod
+    def _ptr(x):
+        if x is None:
+            return None
+        return x.ptr if isinstance(x, DeviceBuffer) else ctypes.c_void_p(x)
+
+    def submit_device(self, batch, d_idx, d_dense, d_scores):
+        _check(lib().fr_worker_submit_device(self._h, batch, self._ptr(d_idx), self._ptr(d_dense), self._ptr(d_scores)))
+
+    def gather_only(self, batch, d_idx, d_dense, d_records):
+        _check(lib().fr_worker_gather_only(self._h, batch, self._ptr(d_idx), self._ptr(d_dense), self._ptr(d_records)))
+
+    def fc_only(self, batch, d_records, d_scores):
+        _check(lib().fr_worker_fc_only(self._h, batch, self._ptr(d_records), self._ptr(d_scores)))
+
+    def records_dptr(self):
+        return lib().fr_worker_records_dptr(self._h)
+
+    def timer_start(self):
+        _check(lib().fr_worker_timer_start(self._h))
+
+    def timer_stop_ms(self):
+        ms = ctypes.c_float()
+        _check(lib().fr_worker_timer_stop_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    # convenience used by the parity tests --------------------------------------------------------
+    def gather_records(self, idx, dense=None):
+        """-> uint32 [flat B*K] record buffer in the model's layout (bit copy of what the kernel wrote)."""
+        ctx, m = self.ctx, self.ctx.model
+        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.int32).reshape(len(idx), -1))
+        B = idx.shape[0]
+        d_idx = DeviceBuffer.from_numpy(ctx, idx)
+        d_dense = DeviceBuffer.from_numpy(ctx, np.asarray(dense, dtype=np.float32)) if m.dense_len else None
+        info = ctx.shard_info()
+        n = B * info["slice_padded"]
+        d_rec = DeviceBuffer(ctx, n * 4)
+        self.gather_only(B, d_idx, d_dense, d_rec)
+        self.sync()
+        return d_rec.download(np.uint32, n)
+
+    def fc_scores(self, records_f32):
+        ctx = self.ctx
+        rec = np.ascontiguousarray(records_f32, dtype=np.float32)
+        B = rec.size // ctx.model.record_len
+        d_rec = DeviceBuffer.from_numpy(ctx, rec)
+        d_sc = DeviceBuffer(ctx, B * 4)
+        self.fc_only(B, d_rec, d_sc)
+        self.sync()
+        return d_sc.download(np.float32, B)

@@ -1,0 +1,559 @@
+// Host side of the C-ABI (include/fleetrec.h): context = device + model + tables + weights,
+// worker = stream + staging buffers, submit/sync = the hot-loop body of the reference's
+// thread_consume() (GPU/final_network_cublasLt_1_node_no_FIFO_scatter/cuda_server.c:101-503) with
+// the FPGA embedding stage (FPGA/kernel/user_krnl/embedding_*_krnl) pulled in front of the FC chain.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "fr_internal.h"
+
+// ---- errors -------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void fr_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *fr_last_error(void) { return g_err; }
+extern "C" int fr_abi_version(void) { return FR_ABI_VERSION; }
+
+extern "C" int fr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+static int select_device(int device) {
+    int n = fr_device_count();
+    if (n <= 0) FR_FAIL(FR_ERR_NO_DEVICE, "no HIP device visible: the FleetRec hot path has no CPU back-end");
+    if (device < 0 || device >= n) FR_FAIL(FR_ERR_NO_DEVICE, "device %d not available (%d visible)", device, n);
+    hipDeviceProp_t prop;
+    FR_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        FR_FAIL(FR_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+    FR_HIP(hipSetDevice(device));
+    return FR_OK;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- context --------------------------------------------------------------------------------------
+static void ctx_free(fr_ctx *c) {
+    if (!c) return;
+    if (c->device >= 0) (void)hipSetDevice(c->device);
+    if (c->table_arena) (void)hipFree(c->table_arena);
+    if (c->d_words) (void)hipFree(c->d_words);
+    for (int i = 0; i < 4; i++) {
+        if (c->d_w[i]) (void)hipFree(c->d_w[i]);
+        if (c->d_w_bf16[i]) (void)hipFree(c->d_w_bf16[i]);
+    }
+    if (c->setup_stream) (void)hipStreamDestroy(c->setup_stream);
+    delete c;
+}
+
+// Contiguous, float-balanced split of the record's segments over n_shards (SURVEY section 8(e):
+// "partition tables by table-ID ... balancing floats-per-item ... slices are whole segments").
+static void shard_bounds(const fr_model_desc &m, int n_shards, std::vector<int> &seg_begin) {
+    seg_begin.assign(n_shards + 1, m.n_segments);
+    seg_begin[0] = 0;
+    int s = 0;
+    for (int g = 1; g < n_shards; g++) {
+        const double target = (double)m.record_len * g / n_shards;
+        // advance while the end of segment s is closer to (or before) the target than its start
+        while (s < m.n_segments && m.segments[s].rec_offset + m.segments[s].len / 2.0 <= target) s++;
+        // a COPY segment must stay with the table segment it duplicates only for locality, not correctness
+        if (s < g) s = g;  // at least one segment per shard
+        if (s > m.n_segments - (n_shards - g)) s = m.n_segments - (n_shards - g);
+        seg_begin[g] = s;
+    }
+}
+
+static int build_words(fr_ctx *c) {
+    const fr_model_desc &m = c->model;
+    std::vector<int> seg_begin;
+    int s0 = 0, s1 = m.n_segments;
+    if (c->n_shards > 1) {
+        shard_bounds(m, c->n_shards, seg_begin);
+        s0 = seg_begin[c->shard_rank];
+        s1 = seg_begin[c->shard_rank + 1];
+        int maxlen = 0;
+        for (int g = 0; g < c->n_shards; g++) {
+            int b = seg_begin[g], e = seg_begin[g + 1];
+            int len = (e > b) ? (m.segments[e - 1].rec_offset + m.segments[e - 1].len - m.segments[b].rec_offset) : 0;
+            if (len > maxlen) maxlen = len;
+        }
+        c->slice_offset = m.segments[s0].rec_offset;
+        c->slice_len = m.segments[s1 - 1].rec_offset + m.segments[s1 - 1].len - c->slice_offset;
+        c->slice_padded = maxlen;
+    } else {
+        c->slice_offset = 0;
+        c->slice_len = m.record_len;
+        c->slice_padded = m.record_len;
+    }
+    // which tables are resident on this shard: those referenced by its segments
+    for (auto &tm : c->table_mem) tm.resident = false;
+    for (int s = s0; s < s1; s++)
+        if (m.segments[s].kind != FR_SEG_DENSE) c->table_mem[m.segments[s].src].resident = true;
+    // arena layout
+    size_t off = 0;
+    for (int t = 0; t < m.n_tables; t++) {
+        if (!c->table_mem[t].resident) continue;
+        c->table_mem[t].byte_offset = off;
+        off = align_up(off + (size_t)m.tables[t].rows * m.tables[t].dim * 4, 256);
+    }
+    c->table_arena_bytes = off;
+    if (off) FR_HIP(hipMalloc((void **)&c->table_arena, off));
+
+    // source runs (for the BLOCKED layout)
+    int src_start[3] = {0, 0, 0}, src_len[3] = {0, 0, 0};
+    for (int s = 0; s < m.n_segments; s++) {
+        const fr_segment &g = m.segments[s];
+        if (src_len[g.source] == 0) src_start[g.source] = g.rec_offset;
+        src_len[g.source] += g.len;
+    }
+    c->h_words.clear();
+    for (int s = s0; s < s1; s++) {
+        const fr_segment &g = m.segments[s];
+        for (int j = 0; j < g.len / 4; j++) {
+            FrWordDesc w{};
+            if (g.kind == FR_SEG_DENSE) {
+                w.src = (uint64_t)(g.src_col + 4 * j) * 4;
+                w.stride = (uint32_t)m.dense_len * 4;
+                w.idx_col = FR_DESC_DENSE;
+                w.rows = 0xFFFFFFFFu;
+            } else {
+                const fr_table_desc &t = m.tables[g.src];
+                w.src = (uint64_t)(uintptr_t)(c->table_arena + c->table_mem[g.src].byte_offset) + (uint64_t)(g.src_col + 4 * j) * 4;
+                w.stride = (uint32_t)t.dim * 4;
+                w.idx_col = (m.index_mode == FR_INDEX_PER_TABLE) ? (uint32_t)g.src : 0u;
+                w.rows = (uint32_t)t.rows;
+            }
+            const int rec_pos = g.rec_offset + 4 * j;
+            if (c->n_shards > 1) {
+                w.dst_off = (uint32_t)(rec_pos - c->slice_offset) / 4;
+                w.dst_stride = (uint32_t)c->slice_padded / 4;
+                w.dst_blk = 0;
+            } else if (m.layout == FR_LAYOUT_BLOCKED) {
+                w.dst_off = (uint32_t)(rec_pos - src_start[g.source]) / 4;
+                w.dst_stride = (uint32_t)src_len[g.source] / 4;
+                w.dst_blk = (uint32_t)src_start[g.source] / 4;
+            } else {
+                w.dst_off = (uint32_t)rec_pos / 4;
+                w.dst_stride = (uint32_t)m.record_len / 4;
+                w.dst_blk = 0;
+            }
+            c->h_words.push_back(w);
+        }
+    }
+    c->n_words = (int)c->h_words.size();
+    FR_HIP(hipMalloc((void **)&c->d_words, sizeof(FrWordDesc) * c->n_words));
+    FR_HIP(hipMemcpy(c->d_words, c->h_words.data(), sizeof(FrWordDesc) * c->n_words, hipMemcpyHostToDevice));
+    return FR_OK;
+}
+
+extern "C" int fr_ctx_create_sharded(const fr_model_desc *m, int device, int shard_rank, int n_shards, fr_ctx **out) {
+    if (!out) FR_FAIL(FR_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int rc = fr_model_validate(m);
+    if (rc) return rc;
+    if (n_shards < 1 || shard_rank < 0 || shard_rank >= n_shards) FR_FAIL(FR_ERR_INVALID, "bad shard %d of %d", shard_rank, n_shards);
+    if (n_shards > m->n_segments) FR_FAIL(FR_ERR_INVALID, "more shards (%d) than record segments (%d)", n_shards, m->n_segments);
+    if (n_shards > 1 && m->layout != FR_LAYOUT_SEMANTIC) FR_FAIL(FR_ERR_INVALID, "table sharding requires the SEMANTIC layout");
+    rc = select_device(device);
+    if (rc) return rc;
+    fr_ctx *c = new (std::nothrow) fr_ctx();
+    if (!c) FR_FAIL(FR_ERR_OOM, "out of host memory");
+    c->device = device;
+    c->tables.assign(m->tables, m->tables + m->n_tables);
+    c->segments.assign(m->segments, m->segments + m->n_segments);
+    c->model = *m;
+    c->model.tables = c->tables.data();
+    c->model.segments = c->segments.data();
+    c->table_mem.assign(m->n_tables, FrTableMem{0, false});
+    c->shard_rank = shard_rank;
+    c->n_shards = n_shards;
+    hipError_t e = hipStreamCreateWithFlags(&c->setup_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        fr_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        ctx_free(c);
+        return FR_ERR_HIP;
+    }
+    rc = build_words(c);
+    if (rc) {
+        ctx_free(c);
+        return rc;
+    }
+    for (int l = 0; l < 4; l++) {
+        size_t n = (size_t)m->fc[l] * m->fc[l + 1];
+        e = hipMalloc((void **)&c->d_w[l], n * sizeof(float));
+        if (e != hipSuccess) {
+            fr_set_error("hipMalloc(weights layer %d) failed: %s", l, hipGetErrorString(e));
+            ctx_free(c);
+            return FR_ERR_OOM;
+        }
+    }
+    *out = c;
+    return FR_OK;
+}
+
+extern "C" int fr_ctx_create(const fr_model_desc *m, int device, fr_ctx **out) { return fr_ctx_create_sharded(m, device, 0, 1, out); }
+extern "C" void fr_ctx_destroy(fr_ctx *ctx) { ctx_free(ctx); }
+extern "C" const fr_model_desc *fr_ctx_model(const fr_ctx *ctx) { return ctx ? &ctx->model : nullptr; }
+
+extern "C" int fr_ctx_shard_info(const fr_ctx *ctx, int *shard_rank, int *n_shards, int *slice_offset, int *slice_len,
+                                 int *slice_padded_len) {
+    if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
+    if (shard_rank) *shard_rank = ctx->shard_rank;
+    if (n_shards) *n_shards = ctx->n_shards;
+    if (slice_offset) *slice_offset = ctx->slice_offset;
+    if (slice_len) *slice_len = ctx->slice_len;
+    if (slice_padded_len) *slice_padded_len = ctx->slice_padded;
+    return FR_OK;
+}
+
+extern "C" int fr_ctx_fill_tables(fr_ctx *ctx, int mode, uint32_t seed) {
+    if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
+    if (mode < FR_FILL_EVEN_ODD || mode > FR_FILL_TAGGED) FR_FAIL(FR_ERR_INVALID, "bad fill mode %d", mode);
+    FR_HIP(hipSetDevice(ctx->device));
+    for (int t = 0; t < ctx->model.n_tables; t++) {
+        if (!ctx->table_mem[t].resident) continue;
+        const fr_table_desc &d = ctx->tables[t];
+        int rc = frk_fill_table((float *)(ctx->table_arena + ctx->table_mem[t].byte_offset), d.rows, d.dim, mode, seed,
+                                fr_table_uid(d), ctx->setup_stream);
+        if (rc) return rc;
+    }
+    FR_HIP(hipStreamSynchronize(ctx->setup_stream));
+    ctx->tables_filled = true;
+    return FR_OK;
+}
+
+static int table_span(fr_ctx *ctx, int table, int64_t row0, int64_t nrows, char **p, size_t *bytes) {
+    if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
+    if (table < 0 || table >= ctx->model.n_tables) FR_FAIL(FR_ERR_INVALID, "table %d out of range", table);
+    if (!ctx->table_mem[table].resident) FR_FAIL(FR_ERR_STATE, "table %d is not resident on shard %d", table, ctx->shard_rank);
+    const fr_table_desc &d = ctx->tables[table];
+    if (row0 < 0 || nrows < 0 || row0 + nrows > d.rows) FR_FAIL(FR_ERR_INVALID, "rows [%lld,+%lld) outside table %d", (long long)row0, (long long)nrows, table);
+    *p = ctx->table_arena + ctx->table_mem[table].byte_offset + (size_t)row0 * d.dim * 4;
+    *bytes = (size_t)nrows * d.dim * 4;
+    return FR_OK;
+}
+
+extern "C" int fr_ctx_upload_table(fr_ctx *ctx, int table, int64_t row0, int64_t nrows, const float *host_rows) {
+    char *p;
+    size_t bytes;
+    int rc = table_span(ctx, table, row0, nrows, &p, &bytes);
+    if (rc) return rc;
+    if (!host_rows && bytes) FR_FAIL(FR_ERR_INVALID, "host_rows is NULL");
+    FR_HIP(hipSetDevice(ctx->device));
+    if (bytes) FR_HIP(hipMemcpy(p, host_rows, bytes, hipMemcpyHostToDevice));
+    ctx->tables_filled = true;
+    return FR_OK;
+}
+
+extern "C" int fr_ctx_download_table(fr_ctx *ctx, int table, int64_t row0, int64_t nrows, float *host_rows) {
+    char *p;
+    size_t bytes;
+    int rc = table_span(ctx, table, row0, nrows, &p, &bytes);
+    if (rc) return rc;
+    if (!host_rows && bytes) FR_FAIL(FR_ERR_INVALID, "host_rows is NULL");
+    FR_HIP(hipSetDevice(ctx->device));
+    if (bytes) FR_HIP(hipMemcpy(host_rows, p, bytes, hipMemcpyDeviceToHost));
+    return FR_OK;
+}
+
+// ---- weights ----------------------------------------------------------------------------------------
+static int refresh_bf16(fr_ctx *ctx, int layer) {
+    if (ctx->fc_precision != FR_FC_BF16) return FR_OK;
+    size_t n = (size_t)ctx->model.fc[layer] * ctx->model.fc[layer + 1];
+    if (!ctx->d_w_bf16[layer]) FR_HIP(hipMalloc((void **)&ctx->d_w_bf16[layer], n * sizeof(uint16_t)));
+    return frk_f32_to_bf16(ctx->d_w[layer], ctx->d_w_bf16[layer], n, ctx->setup_stream);
+}
+
+extern "C" int fr_ctx_set_weights(fr_ctx *ctx, int layer, const float *w, size_t count) {
+    if (!ctx || !w) FR_FAIL(FR_ERR_INVALID, "NULL argument");
+    if (layer < 0 || layer > 3) FR_FAIL(FR_ERR_INVALID, "layer %d out of range", layer);
+    size_t n = (size_t)ctx->model.fc[layer] * ctx->model.fc[layer + 1];
+    if (count != n) FR_FAIL(FR_ERR_INVALID, "layer %d expects %zu weights (H=%d x K=%d), got %zu", layer, n, ctx->model.fc[layer + 1], ctx->model.fc[layer], count);
+    FR_HIP(hipSetDevice(ctx->device));
+    FR_HIP(hipMemcpy(ctx->d_w[layer], w, n * sizeof(float), hipMemcpyHostToDevice));
+    int rc = refresh_bf16(ctx, layer);
+    if (rc) return rc;
+    FR_HIP(hipStreamSynchronize(ctx->setup_stream));
+    ctx->weights_set = true;
+    return FR_OK;
+}
+
+extern "C" int fr_ctx_fill_weights(fr_ctx *ctx, int mode, uint32_t seed) {
+    if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
+    if (mode != FR_WEIGHTS_ONES && mode != FR_WEIGHTS_UNIFORM) FR_FAIL(FR_ERR_INVALID, "bad weight mode %d", mode);
+    FR_HIP(hipSetDevice(ctx->device));
+    for (int l = 0; l < 4; l++) {
+        size_t n = (size_t)ctx->model.fc[l] * ctx->model.fc[l + 1];
+        float scale = 1.0f / std::sqrt((float)ctx->model.fc[l]);
+        int rc = frk_fill_weights(ctx->d_w[l], n, mode, seed, (uint32_t)l, scale, ctx->setup_stream);
+        if (rc) return rc;
+        rc = refresh_bf16(ctx, l);
+        if (rc) return rc;
+    }
+    FR_HIP(hipStreamSynchronize(ctx->setup_stream));
+    ctx->weights_set = true;
+    return FR_OK;
+}
+
+extern "C" int fr_ctx_get_weights(fr_ctx *ctx, int layer, float *w, size_t count) {
+    if (!ctx || !w) FR_FAIL(FR_ERR_INVALID, "NULL argument");
+    if (layer < 0 || layer > 3) FR_FAIL(FR_ERR_INVALID, "layer %d out of range", layer);
+    size_t n = (size_t)ctx->model.fc[layer] * ctx->model.fc[layer + 1];
+    if (count != n) FR_FAIL(FR_ERR_INVALID, "layer %d holds %zu weights, got %zu", layer, n, count);
+    FR_HIP(hipSetDevice(ctx->device));
+    FR_HIP(hipMemcpy(w, ctx->d_w[layer], n * sizeof(float), hipMemcpyDeviceToHost));
+    return FR_OK;
+}
+
+extern "C" int fr_ctx_set_fc_precision(fr_ctx *ctx, int precision) {
+    if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
+    if (precision != FR_FC_FP32 && precision != FR_FC_BF16) FR_FAIL(FR_ERR_INVALID, "bad precision %d", precision);
+    FR_HIP(hipSetDevice(ctx->device));
+    ctx->fc_precision = precision;
+    if (precision == FR_FC_BF16 && ctx->weights_set) {
+        for (int l = 0; l < 4; l++) {
+            int rc = refresh_bf16(ctx, l);
+            if (rc) return rc;
+        }
+        FR_HIP(hipStreamSynchronize(ctx->setup_stream));
+    }
+    return FR_OK;
+}
+
+// ---- worker -----------------------------------------------------------------------------------------
+extern "C" void fr_worker_destroy(fr_worker *w) {
+    if (!w) return;
+    if (w->ctx) (void)hipSetDevice(w->ctx->device);
+    if (w->stream) (void)hipStreamSynchronize(w->stream);
+    if (w->h_idx) (void)hipHostFree(w->h_idx);
+    if (w->h_dense) (void)hipHostFree(w->h_dense);
+    if (w->h_score) (void)hipHostFree(w->h_score);
+    if (w->h_err) (void)hipHostFree(w->h_err);
+    void *dev[] = {w->d_idx, w->d_dense, w->d_records, w->d_r1, w->d_r2, w->d_r3, w->d_score, w->d_err};
+    for (void *p : dev)
+        if (p) (void)hipFree(p);
+    if (w->ev_start) (void)hipEventDestroy(w->ev_start);
+    if (w->ev_stop) (void)hipEventDestroy(w->ev_stop);
+    if (w->stream) (void)hipStreamDestroy(w->stream);
+    delete w;
+}
+
+static size_t idx_cols(const fr_ctx *c) { return c->model.index_mode == FR_INDEX_PER_TABLE ? (size_t)c->model.n_tables : 1; }
+
+#define W_HIP(call)                                                                       \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            fr_set_error("%s failed: %s", #call, hipGetErrorString(e_));                  \
+            fr_worker_destroy(w);                                                         \
+            return (e_ == hipErrorOutOfMemory) ? FR_ERR_OOM : FR_ERR_HIP;                 \
+        }                                                                                 \
+    } while (0)
+
+extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
+    if (!ctx || !out) FR_FAIL(FR_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (max_batch <= 0 || max_batch > (1 << 24)) FR_FAIL(FR_ERR_INVALID, "max_batch %d out of range", max_batch);
+    FR_HIP(hipSetDevice(ctx->device));
+    fr_worker *w = new (std::nothrow) fr_worker();
+    if (!w) FR_FAIL(FR_ERR_OOM, "out of host memory");
+    w->ctx = ctx;
+    w->max_batch = max_batch;
+    const fr_model_desc &m = ctx->model;
+    const size_t B = (size_t)max_batch;
+    W_HIP(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
+    W_HIP(hipHostMalloc((void **)&w->h_idx, B * idx_cols(ctx) * sizeof(int32_t), hipHostMallocDefault));
+    if (m.dense_len) W_HIP(hipHostMalloc((void **)&w->h_dense, B * m.dense_len * sizeof(float), hipHostMallocDefault));
+    W_HIP(hipHostMalloc((void **)&w->h_score, B * sizeof(float), hipHostMallocDefault));
+    W_HIP(hipHostMalloc((void **)&w->h_err, sizeof(int), hipHostMallocDefault));
+    *w->h_err = 0;
+    W_HIP(hipMalloc((void **)&w->d_idx, B * idx_cols(ctx) * sizeof(int32_t)));
+    if (m.dense_len) W_HIP(hipMalloc((void **)&w->d_dense, B * m.dense_len * sizeof(float)));
+    W_HIP(hipMalloc((void **)&w->d_records, B * (size_t)ctx->slice_padded * sizeof(float) * (ctx->n_shards > 1 ? 1 : 1)));
+    if (ctx->n_shards == 1 && ctx->slice_padded != m.record_len) {
+        fr_worker_destroy(w);
+        FR_FAIL(FR_ERR_STATE, "internal: unsharded ctx with a partial slice");
+    }
+    W_HIP(hipMalloc((void **)&w->d_r1, B * m.fc[1] * sizeof(float)));
+    W_HIP(hipMalloc((void **)&w->d_r2, B * m.fc[2] * sizeof(float)));
+    W_HIP(hipMalloc((void **)&w->d_r3, B * m.fc[3] * sizeof(float)));
+    W_HIP(hipMalloc((void **)&w->d_score, B * sizeof(float)));
+    W_HIP(hipMalloc((void **)&w->d_err, sizeof(int)));
+    W_HIP(hipMemset(w->d_err, 0, sizeof(int)));
+    W_HIP(hipEventCreate(&w->ev_start));
+    W_HIP(hipEventCreate(&w->ev_stop));
+    *out = w;
+    return FR_OK;
+}
+
+extern "C" int32_t *fr_worker_idx_ptr(fr_worker *w) { return w ? w->h_idx : nullptr; }
+extern "C" float *fr_worker_dense_ptr(fr_worker *w) { return w ? w->h_dense : nullptr; }
+extern "C" float *fr_worker_score_ptr(fr_worker *w) { return w ? w->h_score : nullptr; }
+extern "C" float *fr_worker_records_dptr(fr_worker *w) { return w ? w->d_records : nullptr; }
+
+static int check_ready(fr_worker *w, int batch, bool need_tables, bool need_weights) {
+    if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
+    if (batch <= 0 || batch > w->max_batch) FR_FAIL(FR_ERR_INVALID, "batch %d outside (0, max_batch=%d]", batch, w->max_batch);
+    if (need_tables && !w->ctx->tables_filled) FR_FAIL(FR_ERR_STATE, "tables have not been filled or uploaded");
+    if (need_weights && !w->ctx->weights_set) FR_FAIL(FR_ERR_STATE, "FC weights have not been set");
+    return FR_OK;
+}
+
+static int launch_gather(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_records) {
+    fr_ctx *c = w->ctx;
+    if (!d_idx) FR_FAIL(FR_ERR_INVALID, "d_idx is NULL");
+    if (c->model.dense_len && !d_dense) {
+        bool needs = false;
+        for (const FrWordDesc &wd : c->h_words) needs |= (wd.idx_col & FR_DESC_DENSE) != 0;
+        if (needs) FR_FAIL(FR_ERR_INVALID, "model has dense features but d_dense is NULL");
+    }
+    return frk_gather(c->d_words, c->n_words, d_idx, (int)idx_cols(c), d_dense, d_records, batch, w->d_err, w->stream);
+}
+
+static int launch_fc(fr_worker *w, int batch, const float *d_records, float *d_scores) {
+    fr_ctx *c = w->ctx;
+    const int32_t *fc = c->model.fc;
+    if (c->n_shards > 1) FR_FAIL(FR_ERR_STATE, "fc on a sharded ctx needs the all-gathered records (use the sharded driver)");
+    if (c->fc_precision != FR_FC_FP32) FR_FAIL(FR_ERR_STATE, "bf16 FC path not built yet");
+    int rc = frk_fc_f32(d_records, c->d_w[0], w->d_r1, batch, fc[0], fc[1], w->stream);
+    if (rc) return rc;
+    rc = frk_fc_f32(w->d_r1, c->d_w[1], w->d_r2, batch, fc[1], fc[2], w->stream);
+    if (rc) return rc;
+    rc = frk_fc_f32(w->d_r2, c->d_w[2], w->d_r3, batch, fc[2], fc[3], w->stream);
+    if (rc) return rc;
+    return frk_fc_out(w->d_r3, c->d_w[3], d_scores, batch, fc[3], w->stream);
+}
+
+extern "C" int fr_worker_gather_only(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_records) {
+    int rc = check_ready(w, batch, true, false);
+    if (rc) return rc;
+    if (!d_records) FR_FAIL(FR_ERR_INVALID, "d_records is NULL");
+    FR_HIP(hipSetDevice(w->ctx->device));
+    rc = launch_gather(w, batch, d_idx, d_dense, d_records);
+    if (rc) return rc;
+    w->in_flight = true;
+    return FR_OK;
+}
+
+extern "C" int fr_worker_fc_only(fr_worker *w, int batch, const float *d_records, float *d_scores) {
+    int rc = check_ready(w, batch, false, true);
+    if (rc) return rc;
+    if (!d_records || !d_scores) FR_FAIL(FR_ERR_INVALID, "NULL device pointer");
+    FR_HIP(hipSetDevice(w->ctx->device));
+    rc = launch_fc(w, batch, d_records, d_scores);
+    if (rc) return rc;
+    w->in_flight = true;
+    return FR_OK;
+}
+
+extern "C" int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores) {
+    int rc = check_ready(w, batch, true, true);
+    if (rc) return rc;
+    if (!d_scores) FR_FAIL(FR_ERR_INVALID, "d_scores is NULL");
+    FR_HIP(hipSetDevice(w->ctx->device));
+    rc = launch_gather(w, batch, d_idx, d_dense, w->d_records);
+    if (rc) return rc;
+    rc = launch_fc(w, batch, w->d_records, d_scores);
+    if (rc) return rc;
+    w->in_flight = true;
+    return FR_OK;
+}
+
+extern "C" int fr_worker_submit(fr_worker *w, int batch) {
+    int rc = check_ready(w, batch, true, true);
+    if (rc) return rc;
+    if (w->in_flight) FR_FAIL(FR_ERR_STATE, "a batch is already in flight on this worker: call fr_worker_sync first");
+    fr_ctx *c = w->ctx;
+    FR_HIP(hipSetDevice(c->device));
+    // input H2D (cuda_server.c:460-461) -- indices instead of the already-gathered features
+    FR_HIP(hipMemcpyAsync(w->d_idx, w->h_idx, (size_t)batch * idx_cols(c) * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
+    if (c->model.dense_len)
+        FR_HIP(hipMemcpyAsync(w->d_dense, w->h_dense, (size_t)batch * c->model.dense_len * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    rc = launch_gather(w, batch, w->d_idx, w->d_dense, w->d_records);
+    if (rc) return rc;
+    rc = launch_fc(w, batch, w->d_records, w->d_score);
+    if (rc) return rc;
+    // output D2H (cuda_server.c:494-495)
+    FR_HIP(hipMemcpyAsync(w->h_score, w->d_score, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+    w->in_flight = true;
+    return FR_OK;
+}
+
+extern "C" int fr_worker_sync(fr_worker *w) {
+    if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
+    FR_HIP(hipSetDevice(w->ctx->device));
+    // the error flag travels behind the batch on the same stream
+    FR_HIP(hipMemcpyAsync(w->h_err, w->d_err, sizeof(int), hipMemcpyDeviceToHost, w->stream));
+    FR_HIP(hipStreamSynchronize(w->stream));
+    w->in_flight = false;
+    if (*w->h_err) {
+        *w->h_err = 0;
+        FR_HIP(hipMemsetAsync(w->d_err, 0, sizeof(int), w->stream));
+        FR_HIP(hipStreamSynchronize(w->stream));
+        FR_FAIL(FR_ERR_INDEX_RANGE, "a lookup index was outside its table (row 0 was read instead)");
+    }
+    return FR_OK;
+}
+
+extern "C" int fr_worker_timer_start(fr_worker *w) {
+    if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
+    FR_HIP(hipSetDevice(w->ctx->device));
+    FR_HIP(hipEventRecord(w->ev_start, w->stream));
+    return FR_OK;
+}
+
+extern "C" int fr_worker_timer_stop_ms(fr_worker *w, float *ms) {
+    if (!w || !ms) FR_FAIL(FR_ERR_INVALID, "NULL argument");
+    FR_HIP(hipSetDevice(w->ctx->device));
+    FR_HIP(hipEventRecord(w->ev_stop, w->stream));
+    FR_HIP(hipEventSynchronize(w->ev_stop));
+    FR_HIP(hipEventElapsedTime(ms, w->ev_start, w->ev_stop));
+    return FR_OK;
+}
+
+// ---- device memory helpers ------------------------------------------------------------------------------
+extern "C" int fr_device_malloc(fr_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) FR_FAIL(FR_ERR_INVALID, "NULL argument");
+    FR_HIP(hipSetDevice(ctx->device));
+    FR_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return FR_OK;
+}
+extern "C" int fr_device_free(fr_ctx *ctx, void *dptr) {
+    if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
+    FR_HIP(hipSetDevice(ctx->device));
+    if (dptr) FR_HIP(hipFree(dptr));
+    return FR_OK;
+}
+extern "C" int fr_memcpy_h2d(fr_ctx *ctx, void *dptr, const void *host, size_t bytes) {
+    if (!ctx || (bytes && (!dptr || !host))) FR_FAIL(FR_ERR_INVALID, "NULL argument");
+    FR_HIP(hipSetDevice(ctx->device));
+    if (bytes) FR_HIP(hipMemcpy(dptr, host, bytes, hipMemcpyHostToDevice));
+    return FR_OK;
+}
+extern "C" int fr_memcpy_d2h(fr_ctx *ctx, void *host, const void *dptr, size_t bytes) {
+    if (!ctx || (bytes && (!dptr || !host))) FR_FAIL(FR_ERR_INVALID, "NULL argument");
+    FR_HIP(hipSetDevice(ctx->device));
+    if (bytes) FR_HIP(hipMemcpy(host, dptr, bytes, hipMemcpyDeviceToHost));
+    return FR_OK;
+}
+extern "C" int fr_device_synchronize(fr_ctx *ctx) {
+    if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
+    FR_HIP(hipSetDevice(ctx->device));
+    FR_HIP(hipDeviceSynchronize());
+    return FR_OK;
+}

@@ -1,0 +1,113 @@
+// Internal declarations shared by the host-side C-ABI (fr_api.cpp, fr_registry.cpp) and the
+// gfx950 kernels (fr_kernels.hip).  Not installed; the public surface is include/fleetrec.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "fleetrec.h"
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void fr_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define FR_FAIL(code, ...)         \
+    do {                           \
+        fr_set_error(__VA_ARGS__); \
+        return (code);             \
+    } while (0)
+
+#define FR_HIP(call)                                                                                 \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            fr_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (e_ == hipErrorOutOfMemory) ? FR_ERR_OOM : FR_ERR_HIP;                            \
+        }                                                                                            \
+    } while (0)
+
+// ---- device-side descriptors --------------------------------------------------------------------
+// One per 16-byte word of the per-item record (the unit the reference's packers move:
+// `typedef ap_uint<128> axi_t`, constants.hpp:4).  32 bytes = two dwordx4 loads, read once per thread.
+struct FrWordDesc {
+    uint64_t src;        // TABLE/COPY: device address of (table base + 16*word_in_row); DENSE: byte offset in the item's dense row
+    uint32_t stride;     // bytes between consecutive rows of the source (dim*4; DENSE: dense_len*4)
+    uint32_t idx_col;    // column of the item's index row feeding this word (0 in PER_ITEM mode); bit 31 set = DENSE
+    uint32_t rows;       // row count for the range check (DENSE: unused)
+    uint32_t dst_off;    // word offset inside the item's destination row
+    uint32_t dst_stride; // words per item of the destination block (SEMANTIC: K/4; BLOCKED: source_len/4)
+    uint32_t dst_blk;    // BLOCKED: words-per-item of all preceding source blocks (x batch at run time); SEMANTIC: 0
+};
+static_assert(sizeof(FrWordDesc) == 32, "FrWordDesc must be 32 bytes");
+#define FR_DESC_DENSE 0x80000000u
+
+// ---- host objects -------------------------------------------------------------------------------
+struct FrTableMem {
+    uint64_t byte_offset; // inside ctx->table_arena
+    bool resident;        // false when the table belongs to another shard
+};
+
+struct fr_ctx {
+    int device = -1;
+    fr_model_desc model{};                 // deep copy (tables/segments point into the vectors below)
+    std::vector<fr_table_desc> tables;
+    std::vector<fr_segment> segments;
+    std::vector<FrTableMem> table_mem;
+    char *table_arena = nullptr;           // one allocation holding every resident table, 256-B aligned starts
+    size_t table_arena_bytes = 0;
+    bool tables_filled = false;
+    // record geometry
+    int n_words = 0;                       // words this ctx gathers per item (whole record, or the shard's slice)
+    FrWordDesc *d_words = nullptr;         // [n_words]
+    std::vector<FrWordDesc> h_words;
+    // FC weights: fp32 master copies in the reference's column-major H x K layout
+    // (= K-major "Wt[k][h]", cuda_server.c:215) and optional bf16 copies.
+    float *d_w[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint16_t *d_w_bf16[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool weights_set = false;
+    int fc_precision = FR_FC_FP32;
+    // sharding
+    int shard_rank = 0, n_shards = 1;
+    int slice_offset = 0, slice_len = 0, slice_padded = 0;
+    hipStream_t setup_stream = nullptr;
+};
+
+struct fr_worker {
+    fr_ctx *ctx = nullptr;
+    int max_batch = 0;
+    hipStream_t stream = nullptr;
+    // pinned host staging (cudaMallocHost in the reference, cuda_server.c:136-160)
+    int32_t *h_idx = nullptr;
+    float *h_dense = nullptr;
+    float *h_score = nullptr;
+    // device buffers (cudaMalloc in the reference, cuda_server.c:170-183)
+    int32_t *d_idx = nullptr;
+    float *d_dense = nullptr;
+    float *d_records = nullptr; // [max_batch][K]
+    float *d_r1 = nullptr, *d_r2 = nullptr, *d_r3 = nullptr;
+    float *d_score = nullptr;
+    int *d_err = nullptr;  // sticky index-range flag (device)
+    int *h_err = nullptr;  // pinned mirror
+    bool in_flight = false;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+};
+
+// ---- registry (fr_registry.cpp) -------------------------------------------------------------------
+int fr_model_validate(const fr_model_desc *m);
+
+// ---- kernel launchers (fr_kernels.hip) --------------------------------------------------------------
+// uid used by the procedural fills: source*1024 + class*256 + table_id
+static inline uint32_t fr_table_uid(const fr_table_desc &t) {
+    return (uint32_t)t.source * 1024u + (uint32_t)t.mem_class * 256u + (uint32_t)t.table_id;
+}
+int frk_fill_table(float *base, int64_t rows, int dim, int mode, uint32_t seed, uint32_t uid, hipStream_t s);
+int frk_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t layer, float scale, hipStream_t s);
+int frk_f32_to_bf16(const float *src, uint16_t *dst, size_t count, hipStream_t s);
+int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense,
+               float *out, int batch, int *err_flag, hipStream_t s);
+// Y[B][N] = X[B][K] * Wt[K][N]  (fp32, exact-f32 MFMA)
+int frk_fc_f32(const float *X, const float *Wt, float *Y, int B, int K, int N, hipStream_t s);
+// score[b] = sum_h R[b][h] * w[h]   (the OUT == 1 layer, cuda_server.c:486-491)
+int frk_fc_out(const float *R, const float *w, float *score, int B, int H, hipStream_t s);

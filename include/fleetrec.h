@@ -1,0 +1,247 @@
+/*
+ * fleetrec.h -- C-ABI of the MI355X-native FleetRec inference hot path.
+ *
+ * The reference (fpgasystems/GPU-FPGA-Recommendation-System) has no plugin/FFI interface: its GPU
+ * server calls CUDA/cuBLASLt inline from thread_consume(), and the embedding lookup runs on an FPGA
+ * behind a TCP hop.  This header is the boundary a maintainer of the reference would bind to in
+ * order to replace BOTH stages (FPGA user_krnl gather/concat + GPU cublasLt FC chain) by one MI355X.
+ * Every entry point cites the reference span it replaces.  Citations are path:line under the
+ * reference tree; "cuda_server.c" = GPU/final_network_cublasLt_1_node_no_FIFO_scatter/cuda_server.c,
+ * "3-node" = the same file under GPU/final_network_cublasLt_3_nodes_no_FIFO_scatter/,
+ * "embedding_N_krnl.cpp" = FPGA/kernel/user_krnl/embedding_N_krnl/src/hls/embedding_N_krnl.cpp,
+ * "host.cpp" = FPGA/host/embedding_47_krnl/host.cpp.
+ *
+ * Plain C: opaque handles, plain pointers and sizes, no C++/torch types.  All functions return
+ * FR_OK (0) or a negative fr_status; fr_last_error() gives a thread-local message.  Nothing here
+ * ever exit()s or prints-and-continues (contrast checkCudaStatus, cuda_server.c:27-32).
+ *
+ * There is NO CPU fallback: every compute entry point needs a gfx950 device and fails with
+ * FR_ERR_NO_DEVICE otherwise.
+ */
+#ifndef FLEETREC_H
+#define FLEETREC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
+#endif
+
+#define FR_ABI_VERSION 1
+
+typedef enum fr_status {
+    FR_OK = 0,
+    FR_ERR_INVALID = -1,     /* bad argument / malformed model description */
+    FR_ERR_NO_DEVICE = -2,   /* no usable gfx950 device (there is no CPU back-end) */
+    FR_ERR_OOM = -3,         /* device or pinned-host allocation failed */
+    FR_ERR_HIP = -4,         /* HIP runtime error; see fr_last_error() */
+    FR_ERR_INDEX_RANGE = -5, /* a lookup index was >= the table's row count (reference: silent OOB,
+                                embedding_47_krnl.cpp:927-933) */
+    FR_ERR_STATE = -6,       /* call sequence error (e.g. sync without submit, tables not filled) */
+    FR_ERR_COMM = -7         /* RCCL error in the table-sharded mode */
+} fr_status;
+
+/* Memory class a table lived in on the FPGA card.  Purely descriptive on MI355X (everything is in
+ * HBM3E; small tables end up L2/Infinity-Cache resident), kept so reference table names map 1:1.
+ * constants.hpp:30-38 (47), :29-41 (98), :31-43 (377). */
+typedef enum fr_mem_class { FR_MEM_HBM = 0, FR_MEM_DDR = 1, FR_MEM_PLRAM = 2 } fr_mem_class;
+
+/* One embedding table.  Row r of the table is `dim` consecutive fp32 (dim in {4,8,16,32}: whole
+ * 128-bit AXI words, constants.hpp:4 `typedef ap_uint<128> axi_t`).  DATA_SIZE/PADDED_SIZE/
+ * AXI_PADDED_SIZE/TABLE_SIZE/ADDR_AXI of the reference's generated constants.hpp. */
+typedef struct fr_table_desc {
+    int32_t mem_class; /* fr_mem_class */
+    int32_t table_id;  /* N of DATA_SIZE_<CLASS>_N */
+    int32_t source;    /* 0 for Models A/B; 0/1 = FPGA0/FPGA1 for Model C (3-node constant.h:25-27) */
+    int32_t dim;       /* floats per row = 4 * AXI_PADDED_SIZE */
+    int64_t rows;      /* TABLE_SIZE */
+    int32_t bank;      /* memory bank on the card the table sat in */
+    int32_t round;     /* position inside that bank's load_single_embedding_K_tables call */
+    int64_t addr_axi;  /* ADDR_AXI_*: start address inside the bank, in 128-bit words */
+} fr_table_desc;
+
+typedef enum fr_segment_kind {
+    FR_SEG_TABLE = 0, /* one table row: record[rec_offset .. +len) = table[src].row(idx)             */
+    FR_SEG_COPY = 1,  /* pad: record[rec_offset .. +len) = table[src].row(idx)[src_col .. +len)
+                         (Model-B floats [220,224) = first AXI word of PLRAM16's row,
+                         embedding_98_krnl.cpp:1078,1099)                                            */
+    FR_SEG_DENSE = 2  /* dense features from the request: record[..] = dense[item][src_col .. +len)
+                         (Model-C: 64 floats from the CPU node, 3-node constant.h:27)                */
+} fr_segment_kind;
+
+/* One contiguous run of the per-item record ("wire order" = what gather_embeddings emits,
+ * embedding_47_krnl.cpp:1097-1217, embedding_98_krnl.cpp:1331-1605, embedding_377_krnl.cpp:1665-1873). */
+typedef struct fr_segment {
+    int32_t kind;       /* fr_segment_kind */
+    int32_t src;        /* table index (TABLE/COPY); unused for DENSE */
+    int32_t src_col;    /* first float inside the source row / dense vector */
+    int32_t rec_offset; /* first float inside the item's record */
+    int32_t len;        /* floats, multiple of 4 */
+    int32_t source;     /* which sender the segment came from: 0 = FPGA0 (A/B: the only one),
+                           1 = FPGA1, 2 = CPU dense node */
+} fr_segment;
+
+/* Record layout switch.
+ *  SEMANTIC: item b's record is K contiguous floats at records[b*K]; Model-C = [dense64|half0|half1].
+ *  BLOCKED : the 3-node server's literal receive buffer (3-node cuda_server.c:515,541,566):
+ *            [CPU: B x 64][FPGA0: B x 1952][FPGA1: B x 1952], then read by the GEMM as if it were
+ *            B x 3968 item-major (3-node cuda_server.c:216-217).  Only differs for multi-source models. */
+typedef enum fr_layout { FR_LAYOUT_SEMANTIC = 0, FR_LAYOUT_BLOCKED = 1 } fr_layout;
+
+/* Index mode.
+ *  PER_TABLE: idx[B][n_tables], column t = table t of the model (tables are listed in wire order).
+ *  PER_ITEM : idx[B], one index per item reused for every table -- what the reference actually does
+ *             (load_access_idx feeds the same stream to every bank and each bank reuses it for all its
+ *             rounds: embedding_47_krnl.cpp:580-628,899-914; embedding_98_krnl.cpp:1026-1040). */
+typedef enum fr_index_mode { FR_INDEX_PER_TABLE = 0, FR_INDEX_PER_ITEM = 1 } fr_index_mode;
+
+typedef struct fr_model_desc {
+    char name[32];
+    int32_t n_tables;
+    int32_t n_segments;
+    const fr_table_desc *tables; /* in wire order (order of first appearance in the record) */
+    const fr_segment *segments;  /* in record order; must tile [0, record_len) exactly */
+    int32_t record_len;          /* K: floats per item = FC input length (352 / 880 / 3968) */
+    int32_t dense_len;           /* floats per item supplied by the request (0 / 0 / 64) */
+    int32_t fc[5];               /* K, H1, H2, H3, OUT (constant.h:21-27; 3-node constant.h:25-33) */
+    int32_t layout;              /* fr_layout */
+    int32_t index_mode;          /* fr_index_mode */
+} fr_model_desc;
+
+typedef enum fr_builtin_model {
+    FR_MODEL_A = 0, /* embedding_47_krnl : 47 tables -> 352 floats,  FC 352-1024-512-256-1            */
+    FR_MODEL_B = 1, /* embedding_98_krnl : 98 tables -> 876(+4 pad) floats, FC 880-1024-512-256-1     */
+    FR_MODEL_C = 2  /* 2 x embedding_377_krnl (188 tables, 1952 floats each) + 64 dense floats,
+                       FC 3968-2048-512-256-1                                                        */
+} fr_builtin_model;
+
+/* Table / weight contents. */
+typedef enum fr_fill_mode {
+    FR_FILL_EVEN_ODD = 0, /* reference pattern: even rows 1.0f, odd rows 0.0f
+                             (host.cpp:66-88 init_vectors; embedding_47_krnl.cpp:869-897 init_plram_t_1_table).
+                             The reference only initialises the first 200 rows of HBM/DDR tables
+                             (`#define DEBUG`, host.cpp:75-80); here every row follows the pattern. */
+    FR_FILL_HASH = 1,     /* v = hash32(seed, table, row, col) mapped to [-1,1): the roofline workload  */
+    FR_FILL_TAGGED = 2    /* u32 bit pattern (source<<30 | class<<28 | table_id<<20 | (row&0xffff)<<4 | (col&15)):
+                             every float identifies where it came from -- pins the wire order          */
+} fr_fill_mode;
+
+typedef enum fr_weight_mode {
+    FR_WEIGHTS_ONES = 0,   /* init_array(w, n, 1.0f), cuda_server.c:152-160 */
+    FR_WEIGHTS_UNIFORM = 1 /* U(-1,1)/sqrt(K_layer) by hash32(seed, layer, element) */
+} fr_weight_mode;
+
+typedef enum fr_fc_precision {
+    FR_FC_FP32 = 0, /* fp32 in, fp32 accumulate: CUBLAS_COMPUTE_32F + CUDA_R_32F (cuda_server.c:211) */
+    FR_FC_BF16 = 1  /* bf16 operands on MFMA, fp32 accumulate (BASELINE configs 3/4) */
+} fr_fc_precision;
+
+typedef struct fr_ctx fr_ctx;       /* device + model + tables + weights; shared by all workers,
+                                       like the single ltHandle (cuda_server.c:547-551) */
+typedef struct fr_worker fr_worker; /* one stream + pinned/device buffers = one thread_consume()
+                                       (cuda_server.c:101-354) */
+
+/* ---- library ------------------------------------------------------------------------------- */
+int fr_abi_version(void);
+const char *fr_last_error(void); /* thread-local, never NULL */
+/* Number of visible HIP devices (0 when none; never fails).  cuda_server.c:508-522 device probe. */
+int fr_device_count(void);
+
+/* ---- model descriptions ---------------------------------------------------------------------- */
+/* Built-in reference models; returned pointer is static, never freed. */
+const fr_model_desc *fr_model_builtin(int which /* fr_builtin_model */);
+/* Heap copy of `src` with every table's row count replaced by
+ *   rows' = clamp(round(rows * row_scale), min_rows, max_rows)   (max_rows <= 0: no upper clamp)
+ * Used to shrink models for tests and to inflate them past 288 GB (BASELINE config 5). */
+int fr_model_clone_scaled(const fr_model_desc *src, double row_scale, int64_t min_rows, int64_t max_rows,
+                          fr_model_desc **out);
+void fr_model_free(fr_model_desc *m); /* only for fr_model_clone_scaled results */
+/* Σ rows*dim*4 over the model's tables. */
+int64_t fr_model_table_bytes(const fr_model_desc *m);
+
+/* ---- context: replaces main()'s device probe + cublasLtCreate (cuda_server.c:508-522,547-551)
+ *      plus the FPGA host's table set-up (host.cpp:264-423,691-731) ----------------------------- */
+/* Validates `m`, selects `device`, allocates every table and the FC weights in HBM.
+ * Shard [shard_rank, n_shards): n_shards == 1 keeps all tables; n_shards > 1 keeps only the tables of
+ * segments assigned to this shard (table-ID sharding); see fr_ctx_shard_info. */
+int fr_ctx_create(const fr_model_desc *m, int device, fr_ctx **out);
+int fr_ctx_create_sharded(const fr_model_desc *m, int device, int shard_rank, int n_shards, fr_ctx **out);
+void fr_ctx_destroy(fr_ctx *ctx);
+const fr_model_desc *fr_ctx_model(const fr_ctx *ctx);
+
+/* Fill every resident table on the device (no host staging: Model-C is 63 GB). */
+int fr_ctx_fill_tables(fr_ctx *ctx, int mode /* fr_fill_mode */, uint32_t seed);
+/* Upload / read back rows [row0, row0+nrows) of table t (host arrays of nrows*dim floats).
+ * host.cpp:739-749 enqueueMigrateMemObjects. */
+int fr_ctx_upload_table(fr_ctx *ctx, int table, int64_t row0, int64_t nrows, const float *host_rows);
+int fr_ctx_download_table(fr_ctx *ctx, int table, int64_t row0, int64_t nrows, float *host_rows);
+
+/* FC weights.  layer 0..3 = W1, W2, W3, Wout; `w` is column-major H x K with ld = H
+ * (element (h,k) at w[h + k*H]) exactly as cuda_server.c:215 hands it to cuBLASLt.  No bias and no
+ * activation exist on the reference path (cuda_server.c:403,468-491: alpha=1, beta=0). */
+int fr_ctx_set_weights(fr_ctx *ctx, int layer, const float *w_colmajor, size_t count);
+int fr_ctx_fill_weights(fr_ctx *ctx, int mode /* fr_weight_mode */, uint32_t seed);
+int fr_ctx_get_weights(fr_ctx *ctx, int layer, float *w_colmajor, size_t count);
+int fr_ctx_set_fc_precision(fr_ctx *ctx, int precision /* fr_fc_precision */);
+
+/* ---- worker: replaces thread_consume()'s set-up (cuda_server.c:110-354) --------------------- */
+int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out);
+void fr_worker_destroy(fr_worker *w);
+/* Pinned host staging buffers the driver's socket read() lands in directly (cuda_server.c:437 reads
+ * into pinned input_feature): int32 idx[max_batch][n_tables] (PER_TABLE) or idx[max_batch] (PER_ITEM),
+ * float dense[max_batch][dense_len] (NULL when dense_len == 0), float score[max_batch]. */
+int32_t *fr_worker_idx_ptr(fr_worker *w);
+float *fr_worker_dense_ptr(fr_worker *w);
+float *fr_worker_score_ptr(fr_worker *w);
+
+/* ---- hot loop body (cuda_server.c:460-495) --------------------------------------------------- */
+/* Asynchronous: idx(+dense) H2D -> gather+pack -> 4-GEMM FC chain -> score D2H on the worker's
+ * stream.  Exactly one batch may be in flight per worker: fr_worker_sync() must be called before the
+ * pinned buffers are touched again (this fixes the reference's unsynchronised reuse, cuda_server.c:406-497). */
+int fr_worker_submit(fr_worker *w, int batch);
+/* Same, with inputs/outputs already resident in HBM (device pointers; no PCIe traffic):
+ * d_idx int32 [batch][n_tables] or [batch]; d_dense float [batch][dense_len] or NULL;
+ * d_scores float [batch]. */
+int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense,
+                            float *d_scores);
+/* Waits for the in-flight batch; returns FR_ERR_INDEX_RANGE if any index was out of range. */
+int fr_worker_sync(fr_worker *w);
+
+/* Diagnostic / roofline entry points (same kernels as submit, run alone).
+ * gather_only: d_records receives batch*record_len floats in the model's layout (device pointer).
+ * fc_only    : d_records is read in the model's layout; d_scores receives batch floats.
+ * Both are asynchronous on the worker's stream; follow with fr_worker_sync(). */
+int fr_worker_gather_only(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense,
+                          float *d_records);
+int fr_worker_fc_only(fr_worker *w, int batch, const float *d_records, float *d_scores);
+/* Device pointer of the worker's own record buffer ([max_batch][record_len] floats). */
+float *fr_worker_records_dptr(fr_worker *w);
+
+/* HIP-event timing on the worker's stream (the stream the kernels are launched on). */
+int fr_worker_timer_start(fr_worker *w);
+int fr_worker_timer_stop_ms(fr_worker *w, float *ms); /* records stop, synchronises, returns elapsed */
+
+/* ---- device memory helpers (so hosts/tests need no other GPU runtime binding) ---------------- */
+int fr_device_malloc(fr_ctx *ctx, size_t bytes, void **dptr);
+int fr_device_free(fr_ctx *ctx, void *dptr);
+int fr_memcpy_h2d(fr_ctx *ctx, void *dptr, const void *host, size_t bytes);
+int fr_memcpy_d2h(fr_ctx *ctx, void *host, const void *dptr, size_t bytes);
+int fr_device_synchronize(fr_ctx *ctx);
+
+/* ---- table-sharded mode (BASELINE configs 4/5) --------------------------- */
+/* For a sharded ctx: first record float and float count of this shard's slice, and the padded
+ * per-shard slice length F (equal on all shards; slices are whole segments). */
+int fr_ctx_shard_info(const fr_ctx *ctx, int *shard_rank, int *n_shards, int *slice_offset,
+                      int *slice_len, int *slice_padded_len);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLEETREC_H */

@@ -1,0 +1,225 @@
+/*
+ * fleetrec_oracle.c -- CPU restatement of the FleetRec inference hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this file's shared object; the product library
+ * (gpu-fpga-recommendation-system_amd/csrc) never links, loads or calls it.
+ *
+ * What it restates (citations are path:line under the reference tree):
+ *   gather  : FPGA/kernel/user_krnl/embedding_N_krnl/src/hls/embedding_N_krnl.cpp
+ *             load_single_embedding_{1,2,4,5}_tables (47: 916-962, 98: 1016-1041, 377: 1180-1291)
+ *             = per item ONE index per bank, then for every table ("round") of the bank copy
+ *             AXI_padded_size consecutive 128-bit words from table_RAM[start_addr + idx*AXI_padded_size];
+ *             group_* + gather_N_embedding_streams (47: 964-1095, 98: 1043-1329, 377: 1294-1663)
+ *             = fixed order in which those words are packed 4-at-a-time into 512-bit words.
+ *             The order is passed in as data (rec_bank/rec_k) extracted from the reference text by
+ *             oracle/tools/extract_registry.py.
+ *   tables  : FPGA/host/embedding_47_krnl/host.cpp:66-88 (init_vectors: even rows 1.0f, odd 0.0f at
+ *             bank word ADDR_AXI + row*AXI_PADDED_SIZE + j), embedding_47_krnl.cpp:869-897.
+ *   indices : load_access_idx (47: 899-914): 32 fixed indices, same stream to every bank.
+ *   FC      : GPU/final_network_cublasLt_1_node_no_FIFO_scatter/cuda_server.c:211-217,468-491:
+ *             four chained column-major GEMMs, alpha=1, beta=0, no bias, no activation:
+ *             R1 = W1*X, R2 = W2*R1, R3 = W3*R2, out = Wout*R3 with W (H x K, ld=H), X (K x B, ld=K).
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - FC: pinned by the reference's own known answers (README.md:7-11: K=512 -> 2^36, K=1024 -> 2^37)
+ *     which are exact in fp32 for any summation order.  For arbitrary data cuBLASLt's summation order
+ *     is unknowable (closed library, no version pin) -> tolerance 1e-3 relative (BASELINE.json).
+ *   - gather: the reference holds no golden vector beyond its deterministic data pattern (even/odd
+ *     rows + the 32 fixed indices => all-ones / all-zero records).  The HLS kernels cannot be
+ *     compiled here (ap_int.h / hls_stream.h absent; writing stand-ins is not allowed), so the wire
+ *     order is pinned by static extraction from the reference text, not by execution:
+ *     "wire-order parity pinned by source extraction, unpinned by execution".
+ *
+ * Build: gcc -O3 -march=native -fopenmp -shared -fPIC fleetrec_oracle.c -o liboracle.so
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- procedural table contents (must match the product's device fill kernels bit for bit) ---- */
+enum { ORACLE_CONTENT_MEMORY = -1, ORACLE_FILL_EVEN_ODD = 0, ORACLE_FILL_HASH = 1, ORACLE_FILL_TAGGED = 2 };
+
+static inline uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+/* uid = source*1024 + class*256 + table_id */
+static inline uint32_t content_bits(int mode, uint32_t seed, uint32_t uid, uint64_t row, uint32_t col) {
+    if (mode == ORACLE_FILL_EVEN_ODD) return (row & 1) ? 0u : 0x3F800000u;
+    if (mode == ORACLE_FILL_TAGGED) {
+        uint32_t source = uid >> 10, cls = (uid >> 8) & 3, tid = uid & 255;
+        return (source << 31) | (cls << 29) | (tid << 21) | ((uint32_t)(row & 0xFFFF) << 5) | (col & 31);
+    }
+    /* HASH: 24 random bits -> [-1, 1) */
+    uint32_t h = fmix32(seed ^ (uid * 0x9E3779B1u));
+    h = fmix32(h ^ (uint32_t)row);
+    h = fmix32(h ^ (uint32_t)(row >> 32) ^ (col * 0x27D4EB2Fu));
+    float v = (float)(int32_t)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
+    uint32_t b;
+    memcpy(&b, &v, 4);
+    return b;
+}
+
+uint32_t oracle_content_bits(int mode, uint32_t seed, uint32_t uid, uint64_t row, uint32_t col) {
+    return content_bits(mode, seed, uid, row, col);
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/*
+ * Bank-addressed gather + pack (H3 + H4 of SURVEY section 8(a)).
+ *
+ *  n_banks, bank_ntab[b]            tables ("rounds") per bank, in the order of the bank's
+ *                                   load_single_embedding_K_tables template arguments
+ *  tab_addr / tab_axi / tab_uid     flattened per (bank, round): ADDR_AXI (128-bit words),
+ *                                   AXI_PADDED_SIZE (words per row), content uid
+ *  bank_mem[b]                      content_mode == MEMORY: the bank's memory image (16 B words),
+ *                                   exactly what host.cpp migrates to the card; else ignored
+ *  rec_bank[w], rec_k[w]            for every 128-bit word w of the item record: which bank and which
+ *                                   k-th word of that bank's per-item stream it carries
+ *  idx                              idx_per_round == 0: int32 [n_items][n_banks]  (reference: one index
+ *                                   per bank per item, reused for every round)
+ *                                   idx_per_round == 1: int32 [n_items][total rounds] in flattened
+ *                                   (bank, round) order (per-table generalisation)
+ *  out                              n_items * n_rec_words * 16 bytes, item-major
+ *
+ * No bounds checks, like the reference (embedding_47_krnl.cpp:927-933): in MEMORY mode an index past
+ * the table simply reads whatever follows in the bank image.
+ */
+void oracle_gather_banks(int n_banks, const int32_t *bank_ntab, const int64_t *tab_addr, const int32_t *tab_axi,
+                         const uint32_t *tab_uid, const uint8_t *const *bank_mem, int content_mode, uint32_t seed,
+                         int n_rec_words, const int32_t *rec_bank, const int32_t *rec_k, const int32_t *idx,
+                         int idx_per_round, int64_t n_items, uint8_t *out) {
+    /* per-bank stream geometry */
+    int *first = (int *)malloc(sizeof(int) * (n_banks + 1));
+    int *slen = (int *)malloc(sizeof(int) * n_banks);
+    first[0] = 0;
+    int max_len = 0;
+    for (int b = 0; b < n_banks; b++) {
+        first[b + 1] = first[b] + bank_ntab[b];
+        int l = 0;
+        for (int r = first[b]; r < first[b + 1]; r++) l += tab_axi[r];
+        slen[b] = l;
+        if (l > max_len) max_len = l;
+    }
+    const int n_rounds = first[n_banks];
+    const int idx_cols = idx_per_round ? n_rounds : n_banks;
+
+#pragma omp parallel
+    {
+        /* s_embedding_buffer_X of every bank for ONE item: slen[b] words of 16 B */
+        uint8_t *streams = (uint8_t *)malloc((size_t)n_banks * max_len * 16);
+#pragma omp for schedule(static)
+        for (int64_t item = 0; item < n_items; item++) {
+            const int32_t *irow = idx + item * idx_cols;
+            for (int b = 0; b < n_banks; b++) {
+                uint8_t *s = streams + (size_t)b * max_len * 16;
+                int pos = 0;
+                for (int r = first[b]; r < first[b + 1]; r++) {
+                    /* long idx = s_idx_buffer.read();  (one read per item per bank in the reference) */
+                    int64_t id = idx_per_round ? irow[r] : irow[b];
+                    int64_t base_addr = tab_addr[r] + id * (int64_t)tab_axi[r];
+                    for (int j = 0; j < tab_axi[r]; j++) {
+                        if (content_mode == ORACLE_CONTENT_MEMORY) {
+                            memcpy(s + 16 * pos, bank_mem[b] + 16 * (base_addr + j), 16);
+                        } else {
+                            uint32_t wv[4];
+                            for (int c = 0; c < 4; c++)
+                                wv[c] = content_bits(content_mode, seed, tab_uid[r], (uint64_t)id, (uint32_t)(4 * j + c));
+                            memcpy(s + 16 * pos, wv, 16);
+                        }
+                        pos++;
+                    }
+                }
+            }
+            uint8_t *o = out + (size_t)item * n_rec_words * 16;
+            for (int w = 0; w < n_rec_words; w++)
+                memcpy(o + 16 * w, streams + ((size_t)rec_bank[w] * max_len + rec_k[w]) * 16, 16);
+        }
+        free(streams);
+    }
+    free(first);
+    free(slen);
+}
+
+/*
+ * One column-major GEMM of the chain: Y (H x B, ld=H) = W (H x K, ld=H) * X (K x B, ld=K), fp32 data.
+ * acc64 != 0: accumulate in double (the tolerance reference); else float accumulate in k order
+ * (= an fp32 fmaf-free chain; one of the many orders cuBLASLt may use).
+ */
+void oracle_gemm_colmajor(int H, int K, int64_t B, const float *W, const float *X, float *Y, int acc64) {
+#pragma omp parallel
+    {
+        double *acc = acc64 ? (double *)malloc(sizeof(double) * H) : NULL;
+#pragma omp for schedule(static)
+        for (int64_t b = 0; b < B; b++) {
+            const float *x = X + b * K;
+            float *y = Y + b * H;
+            if (acc64) {
+                for (int h = 0; h < H; h++) acc[h] = 0.0;
+                for (int k = 0; k < K; k++) {
+                    const double xv = x[k];
+                    const float *w = W + (size_t)k * H;
+                    for (int h = 0; h < H; h++) acc[h] += (double)w[h] * xv;
+                }
+                for (int h = 0; h < H; h++) y[h] = (float)acc[h];
+            } else {
+                for (int h = 0; h < H; h++) y[h] = 0.0f;
+                for (int k = 0; k < K; k++) {
+                    const float xv = x[k];
+                    const float *w = W + (size_t)k * H;
+                    for (int h = 0; h < H; h++) y[h] += w[h] * xv;
+                }
+            }
+        }
+        free(acc);
+    }
+}
+
+/* The 4-GEMM chain of cuda_server.c:468-491.  dims = {K, H1, H2, H3, OUT}; X is B records of K floats
+ * (column-major K x B == item-major); out receives OUT*B floats.  scratch: (H1+H2+H3)*B floats.
+ * In acc64 mode intermediates are still rounded to fp32 between layers, as on the reference path
+ * (R1..R3 are fp32 buffers, cuda_server.c:170-175). */
+void oracle_fc_chain(const int32_t *dims, int64_t B, const float *X, const float *W1, const float *W2, const float *W3,
+                     const float *Wout, float *scratch, float *out, int acc64) {
+    float *r1 = scratch;
+    float *r2 = r1 + (size_t)dims[1] * B;
+    float *r3 = r2 + (size_t)dims[2] * B;
+    oracle_gemm_colmajor(dims[1], dims[0], B, W1, X, r1, acc64);
+    oracle_gemm_colmajor(dims[2], dims[1], B, W2, r1, r2, acc64);
+    oracle_gemm_colmajor(dims[3], dims[2], B, W3, r2, r3, acc64);
+    oracle_gemm_colmajor(dims[4], dims[3], B, Wout, r3, out, acc64);
+}
+
+/* 3-node server receive-buffer arithmetic (3-node cuda_server.c:515,541,566): the batch arrives as
+ * concatenated per-source blocks [src0: B x len0][src1: B x len1]...; this re-blocks item-major
+ * records (B x K, sources concatenated per item in the given order) into that literal layout. */
+void oracle_block_records(int n_src, const int32_t *src_len, int64_t B, const float *item_major, float *blocked) {
+    int K = 0;
+    for (int s = 0; s < n_src; s++) K += src_len[s];
+    int64_t blk = 0;
+    int off = 0;
+    for (int s = 0; s < n_src; s++) {
+        for (int64_t b = 0; b < B; b++)
+            memcpy(blocked + blk + b * src_len[s], item_major + b * K + off, sizeof(float) * src_len[s]);
+        blk += B * src_len[s];
+        off += src_len[s];
+    }
+}

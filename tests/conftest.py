@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def fr():
+    """The product package (ctypes binding of libfleetrec.so).  Built on demand when hipcc is present."""
+    import __graft_entry__ as g
+    mod = g.load_package()
+    if not os.path.exists(mod.LIB_PATH):
+        g.build()
+    return mod
+
+
+@pytest.fixture(scope="session")
+def O():
+    """The CPU oracle (test infrastructure)."""
+    import __graft_entry__ as g
+    return g.load_oracle()
+
+
+@pytest.fixture(scope="session")
+def gpu(fr):
+    if fr.device_count() < 1:
+        pytest.fail("gpu-marked test running without a visible HIP device (no CPU fallback exists)")
+    return 0

@@ -1,0 +1,208 @@
+"""Model registry: three independent derivations of the record ("wire") format must agree.
+
+ 1. tests/golden/registry_*.json  -- static extraction from the reference text
+                                     (oracle/tools/extract_registry.py; re-run here when /root/reference exists)
+ 2. the rule-based statement of SURVEY.md section 8(a) H4 (written out below from the survey's prose)
+ 3. the product's built-in models, read back through the C-ABI (fr_model_builtin)
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def load(n):
+    return json.load(open(os.path.join(GOLD, "registry_%d.json" % n)))
+
+
+def wire_segments(reg):
+    """-> list of (bank_name, table_name, first_float, n_floats) in record order (16-byte words merged)."""
+    streams = []
+    for b in reg["banks"]:
+        s = []
+        for t in b["tables"]:
+            s += [(b["name"], t["name"], j) for j in range(t["axi_words"])]
+        streams.append(s)
+    segs = []
+    for w, (bi, k) in enumerate(reg["record"]):
+        bank, tab, j = streams[bi][k]
+        if segs and segs[-1][1] == tab and segs[-1][4] == j and segs[-1][2] + segs[-1][3] == 4 * w:
+            segs[-1][3] += 4
+            segs[-1][4] = j + 1
+        else:
+            segs.append([bank, tab, 4 * w, 4, j + 1])
+    return [tuple(s[:4]) for s in segs]
+
+
+def test_record_sizes():
+    # INPUT_SIZE / INPUT_SIZE_AXI_512 of each kernel's constants.hpp:13,20
+    for n, floats, words in ((47, 352, 22), (98, 880, 55), (377, 1952, 122)):
+        reg = load(n)
+        assert reg["input_size"] in (floats, floats - 4)  # 98: INPUT_SIZE is 876, record is 880
+        assert reg["record_words_512"] == words and len(reg["record"]) == 4 * words
+        ntab = sum(len(b["tables"]) for b in reg["banks"])
+        assert ntab == {47: 47, 98: 98, 377: 188}[n]
+        data = sum(t["axi_words"] * 4 for b in reg["banks"] for t in b["tables"])
+        assert data == {47: 352, 98: 876, 377: 1952}[n]
+        for b in reg["banks"]:
+            for t in b["tables"]:
+                assert t["data_size"] == t["padded_size"] == 4 * t["axi_words"]
+    assert load(47)["idx_random"] == load(98)["idx_random"] == load(377)["idx_random"]
+    assert len(load(47)["idx_random"]) == 32 and max(load(47)["idx_random"]) < 100
+
+
+def _bank_tables(reg, bank):
+    b = next(x for x in reg["banks"] if x["name"] == bank)
+    return [(t["name"], 4 * t["axi_words"]) for t in b["tables"]]
+
+
+def _expect(reg, plan):
+    """plan: list of bank names (or ('pad', offset_floats, len)) in wire order -> expected segments."""
+    out, off = [], 0
+    for item in plan:
+        if isinstance(item, tuple):
+            out.append(("PAD", item[1], off, item[2]))
+            off += item[2]
+            continue
+        for tab, dim in _bank_tables(reg, item):
+            out.append((item, tab, off, dim))
+            off += dim
+    return out, off
+
+
+def test_wire_order_matches_survey_rules():
+    """SURVEY.md section 8(a) H4 'Wire maps' restated as bank sequences; bank Xb contributes its tables
+    T_b, T_{b+NB}, ... in round order."""
+    # Model-A: PLRAM0..16, HBM0..27, DDR0, DDR1
+    r = load(47)
+    plan = ["PLRAM%d" % i for i in range(17)] + ["HBM%d" % i for i in range(28)] + ["DDR0", "DDR1"]
+    exp, total = _expect(r, plan)
+    assert total == 352 and wire_segments(r) == exp
+    assert [s[2] for s in exp if s[0] in ("PLRAM16", "HBM0", "HBM27", "DDR0", "DDR1")] == [64, 72, 288, 304, 320]
+    # Model-B: PLRAM0..18, HBM27, pad(copy of floats [160,164) = PLRAM16 word 0), HBM0..26, DDR0, DDR1
+    r = load(98)
+    plan = ["PLRAM%d" % i for i in range(19)] + ["HBM27", ("pad", "PLRAM_16", 4)] + ["HBM%d" % i for i in range(27)] + ["DDR0", "DDR1"]
+    exp, total = _expect(r, plan)
+    got = wire_segments(r)
+    assert total == 880 and len(got) == len(exp)
+    for g, e in zip(got, exp):
+        if e[0] == "PAD":
+            assert g == ("PLRAM16", "PLRAM_16", 220, 4)  # first AXI word of PLRAM16's stream again
+        else:
+            assert g == e
+    assert [t for t in _bank_tables(r, "PLRAM16")] == [("PLRAM_16", 4), ("PLRAM_35", 8)]
+    assert next(s for s in got if s[1] == "PLRAM_16")[2] == 160
+    assert [s[2] for s in got if s[0] in ("HBM27",)][:1] == [196] and next(s for s in got if s[0] == "HBM0")[2] == 224
+    assert next(s for s in got if s[0] == "HBM11")[2] == 400 and next(s for s in got if s[0] == "DDR0")[2] == 784
+    assert next(s for s in got if s[0] == "DDR1")[2] == 832
+    # Model-C half: PLRAM8..10, HBM0..7, DDR0, DDR1, PLRAM0..7, HBM8..27
+    r = load(377)
+    plan = (["PLRAM%d" % i for i in (8, 9, 10)] + ["HBM%d" % i for i in range(8)] + ["DDR0", "DDR1"]
+            + ["PLRAM%d" % i for i in range(8)] + ["HBM%d" % i for i in range(8, 28)])
+    exp, total = _expect(r, plan)
+    assert total == 1952 and wire_segments(r) == exp
+    first = {}
+    for s in exp:
+        first.setdefault(s[0], s[2])
+    assert (first["PLRAM8"], first["HBM0"], first["DDR0"], first["DDR1"], first["PLRAM0"], first["HBM8"]) == (0, 96, 480, 544, 608, 832)
+    assert [d for _, d in _bank_tables(r, "HBM0")] == [8, 8, 8, 8, 16] and [d for _, d in _bank_tables(r, "HBM8")] == [8, 8, 8, 16, 16]
+    assert [d for _, d in _bank_tables(r, "PLRAM0")] == [4, 8, 8, 8] and [d for _, d in _bank_tables(r, "PLRAM8")] == [8, 8, 8, 8]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/FPGA"), reason="reference tree only exists in the build container")
+def test_extraction_is_reproducible(tmp_path):
+    """Re-run the static extraction against the reference text and compare with the committed fixtures."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "tools"))
+    import extract_registry as ex
+    for n in (47, 98, 377):
+        assert ex.extract("embedding_%d_krnl" % n) == load(n)
+    assert ex.extract_gpu() == json.load(open(os.path.join(GOLD, "registry_gpu.json")))
+
+
+def test_product_registry_matches_extraction(fr, O):
+    """Built-in models read through the C-ABI == the oracle-side view derived from the JSON."""
+    for which, name in ((fr.MODEL_A, "A"), (fr.MODEL_B, "B"), (fr.MODEL_C, "C")):
+        m = fr.Model.builtin(which)
+        om = O.OracleModel(name)
+        assert m.record_len == om.record_len and m.fc == om.fc and m.dense_len == om.dense_len
+        assert m.n_tables == om.n_tables
+        # table order = wire order; rows/dims/ids per table
+        col = 0
+        tabs = m.tables()
+        for hi, h in enumerate(om.halves):
+            for wpos, r in enumerate(h.wire_to_round):
+                bi, tj = h.rounds[r]
+                t = tabs[col + wpos]
+                assert (fr.MEM_CLASS_NAMES[t.mem_class], t.table_id, t.source) == (tj["class"], tj["id"], hi)
+                assert (t.dim, t.rows, t.addr_axi) == (4 * tj["axi_words"], tj["rows"], tj["addr_axi"])
+                assert t.bank == h.reg["banks"][bi]["bank"]
+            col += h.n_tables
+        # segments tile the record; compare with the JSON record word list
+        off = om.dense_len
+        segs = m.segments()
+        pos = 0
+        if om.dense_len:
+            assert (segs[0].kind, segs[0].rec_offset, segs[0].len, segs[0].source) == (fr.SEG_DENSE, 0, om.dense_len, 2)
+            segs = segs[1:]
+            pos = om.dense_len
+        flat = []  # per record word: (table index, word in row)
+        for s in segs:
+            assert s.rec_offset == pos
+            for j in range(s.len // 4):
+                flat.append((s.src, s.src_col // 4 + j))
+            pos += s.len
+        assert pos == m.record_len
+        want = []
+        col = 0
+        for h in om.halves:
+            first = np.concatenate([[0], np.cumsum(h.bank_ntab)])
+            round_to_wire = np.empty(len(h.rounds), dtype=np.int64)
+            round_to_wire[h.wire_to_round] = np.arange(len(h.rounds))
+            for bi, k in h.reg["record"]:
+                acc = 0
+                for r in range(first[bi], first[bi + 1]):
+                    if k < acc + h.tab_axi[r]:
+                        want.append((col + int(round_to_wire[r]), k - acc))
+                        break
+                    acc += h.tab_axi[r]
+            col += h.n_tables
+        assert flat == want
+        assert m.table_bytes() == sum(t.rows * t.dim * 4 for t in tabs)
+    # headline sizes quoted in BASELINE.md
+    assert abs(fr.Model.builtin(fr.MODEL_A).table_bytes() / 1e9 - 1.415) < 1e-3
+    assert abs(fr.Model.builtin(fr.MODEL_B).table_bytes() / 1e9 - 15.107) < 1e-3
+    assert abs(fr.Model.builtin(fr.MODEL_C).table_bytes() / 1e9 - 63.242) < 1e-2
+
+
+def test_generated_registry_is_current():
+    """csrc/registry_data.inc must be what tools/gen_registry.py produces from the committed JSONs."""
+    inc = os.path.join(ROOT, "gpu-fpga-recommendation-system_amd", "csrc", "registry_data.inc")
+    before = open(inc).read()
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "gpu-fpga-recommendation-system_amd", "tools", "gen_registry.py")],
+                          stdout=subprocess.DEVNULL)
+    assert open(inc).read() == before
+
+
+def test_model_clone_and_validation(fr):
+    a = fr.Model.builtin(fr.MODEL_A)
+    small = a.clone(row_scale=1.0, min_rows=1, max_rows=500)
+    assert small.rows().max() == 500 and small.rows().min() == 100 and small.n_tables == 47
+    big = a.clone(row_scale=3.0)
+    assert np.array_equal(big.rows(), a.rows() * 3)
+    with pytest.raises(fr.FleetRecError) as e:
+        a.clone(row_scale=0.0)
+    assert e.value.status == fr.FR_ERR_INVALID
+    with pytest.raises(fr.FleetRecError):
+        a.clone(row_scale=1e9)  # > 2^32-1 rows
+    # a malformed description is rejected (segments no longer tile the record)
+    bad = a.clone()
+    bad.desc.segments[3].len = 8
+    with pytest.raises(fr.FleetRecError) as e:
+        bad.clone()
+    assert "segment" in str(e.value)
