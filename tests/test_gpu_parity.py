@@ -266,7 +266,7 @@ def test_upload_set_weights_roundtrip(fr, O, gpu):
     for l in range(4):
         ctx.set_weights(l, ws[l])
         assert np.array_equal(ctx.get_weights(l), ws[l])
-    assert np.array_equal(ctx.download_table(3, 5, 100, dtype=np.float32), host_tabs[3][5:105])
+    assert np.array_equal(ctx.download_table(3, 5, 90, dtype=np.float32), host_tabs[3][5:95])
     B = 100
     idx = uniform_idx(rng, m.rows(), B)
     wk = fr.Worker(ctx, B)
