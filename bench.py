@@ -48,7 +48,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--workers", type=int, default=4, help="host workers/streams in flight (reference THREAD_NUM = 4)")
+    ap.add_argument("--threads", type=int, default=4, help="host driver threads (reference THREAD_NUM = 4, constant.h:42)")
+    ap.add_argument("--depth", type=int, default=2, help="workers (streams) each driver thread keeps in flight")
+    ap.add_argument("--sweep", action="store_true", help="also print a threads x depth sweep to stderr (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-model-c", action="store_true", help="skip the Model-C batch-4096 gather roofline leg")
     args = ap.parse_args()
@@ -79,8 +81,7 @@ def main():
     rows = model.rows()
     idx_host = [(rng.random((B, model.n_tables)) * rows[None, :]).astype(np.int32) for _ in range(N_IDX_BUFFERS)]
     d_idx = [fr.DeviceBuffer.from_numpy(ctx, a) for a in idx_host]
-    workers = [fr.Worker(ctx, B) for _ in range(args.workers)]
-    d_scores = [fr.DeviceBuffer(ctx, B * 4) for _ in range(args.workers)]
+    driver = fr.Driver(ctx, args.threads, args.depth, B)
 
     def barrier():
         if dist is not None:
@@ -88,21 +89,18 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
-    def run_steps(n):
-        """n batches round-robin over the workers; a worker is synced before it is reused."""
-        W = len(workers)
-        for i in range(n):
-            w = i % W
-            if i >= W:
-                workers[w].sync()
-            workers[w].submit_device(B, d_idx[i % N_IDX_BUFFERS], None, d_scores[w])
-        for w in range(min(W, n)):
-            workers[w].sync()
+    if args.sweep and rank == 0:
+        for th, dp in ((1, 1), (1, 2), (1, 4), (2, 2), (4, 1), (4, 2), (4, 4), (8, 2), (8, 4), (16, 2)):
+            dv = fr.Driver(ctx, th, dp, B)
+            dv.run_resident(B, 200, d_idx)
+            el = dv.run_resident(B, 2000, d_idx)
+            print("sweep threads=%d depth=%d: %.2f us/batch, %.2f M inf/s" % (th, dp, 1e6 * el / 2000, 2000 * B / el / 1e6), file=sys.stderr)
+            dv.close()
 
-    run_steps(args.warmup)
+    driver.run_resident(B, args.warmup, d_idx)
     barrier()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    driver.run_resident(B, args.steps, d_idx)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -120,27 +118,37 @@ def main():
             "config": {"workload": "Model-A (embedding_47_krnl: 47 tables, 1.415 GB) batch=%d, fp32 FC 352-1024-512-256-1, "
                                    "all tables resident in one GPU's HBM; hash-filled tables, uniform indices, "
                                    "index rows resident in HBM" % B,
-                       "batch": B, "workers_in_flight": args.workers, "parallelism": "replicas x%d" % world},
+                       "batch": B, "driver_threads": args.threads, "workers_per_thread": args.depth,
+                       "parallelism": "replicas x%d" % world},
         }
         # ---- roofline of the dominant kernel: measured live with HIP events on the worker's stream ----
-        wk = workers[0]
+        wk = fr.Worker(ctx, B)
+        d_sc = fr.DeviceBuffer(ctx, B * 4)
+        wk.submit_device(B, d_idx[0], None, d_sc)   # leaves real activations resident for the per-layer launches
+        wk.sync()
         rec = wk.records_dptr()
-        reps = 200
-        # FC chain (the dominant part at batch 256: 0.52 GFLOP vs 0.77 MB of gather traffic)
-        for _ in range(20):
-            wk.fc_only(B, rec, d_scores[0])
-        wk.sync()
-        wk.timer_start()
-        for _ in range(reps):
-            wk.fc_only(B, rec, d_scores[0])
-        fc_ms = wk.timer_stop_ms() / reps
-        wk.sync()
-        flops = fc_flops_per_inference(model.fc) * B
-        ach = flops / (fc_ms * 1e-3) / 1e12
+        reps = 300
+        fc = model.fc
+        layer_ms = []
+        for layer in range(4):
+            for _ in range(20):
+                wk.fc_layer_only(B, layer)
+            wk.sync()
+            wk.timer_start()
+            for _ in range(reps):
+                wk.fc_layer_only(B, layer)
+            layer_ms.append(wk.timer_stop_ms() / reps)
+            wk.sync()
+        layer_flops = [2 * fc[i] * fc[i + 1] * B for i in range(4)]
+        dom = max(range(3), key=lambda i: layer_ms[i])
+        ach = layer_flops[dom] / (layer_ms[dom] * 1e-3) / 1e12
+        chain_ms = sum(layer_ms)
         result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                               "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
-                              "kernel": "fc chain (3x fc_f32_kernel + fc_out_kernel), avg per batch",
-                              "avg_launch_ms": fc_ms, "algorithmic_flops_per_launch": flops}
+                              "kernel": "fc_t_kernel (FC%d: %dx%dx%d, back-to-back launches on one stream)" % (dom + 1, fc[dom + 1], B, fc[dom]),
+                              "avg_launch_ms": layer_ms[dom], "algorithmic_flops_per_launch": layer_flops[dom],
+                              "all_layers_avg_launch_ms": layer_ms,
+                              "chain_tflops": sum(layer_flops) / (chain_ms * 1e-3) / 1e12}
         # gather kernel at the bench batch
         for _ in range(20):
             wk.gather_only(B, d_idx[0], None, rec)
@@ -150,6 +158,8 @@ def main():
             wk.gather_only(B, d_idx[i % N_IDX_BUFFERS], None, rec)
         g_ms = wk.timer_stop_ms() / reps
         wk.sync()
+        wk.close()
+        d_sc.free()
         gb = gather_bytes_per_inference(model, fr) * B
         result["gather_roofline_bench_batch"] = {"bound": "hbm", "achieved": gb / (g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                                  "unit": "GB/s", "frac": gb / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -174,9 +184,8 @@ def main():
                                       "sample": "%d batches of %d (Model-A, same seeded indices; oracle C port: OpenMP gather with "
                                                 "on-the-fly hash tables + fp32 4-GEMM chain)" % (n_done, B)}
 
-    for w in workers:
-        w.close()
-    for b in d_idx + d_scores:
+    driver.close()
+    for b in d_idx:
         b.free()
     ctx.close()
 

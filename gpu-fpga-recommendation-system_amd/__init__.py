@@ -60,9 +60,10 @@ ABI_SYMBOLS = [
     "fr_ctx_fill_tables", "fr_ctx_upload_table", "fr_ctx_download_table", "fr_ctx_set_weights", "fr_ctx_fill_weights",
     "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
     "fr_worker_dense_ptr", "fr_worker_score_ptr", "fr_worker_submit", "fr_worker_submit_device", "fr_worker_sync",
-    "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_records_dptr", "fr_worker_timer_start",
+    "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
-    "fr_device_synchronize", "fr_ctx_shard_info",
+    "fr_device_synchronize", "fr_ctx_shard_info", "fr_driver_create", "fr_driver_destroy", "fr_driver_run_resident",
+    "fr_driver_worker",
 ]
 
 
@@ -94,12 +95,16 @@ def lib():
         "fr_worker_idx_ptr": (pi, [vp]), "fr_worker_dense_ptr": (pf, [vp]), "fr_worker_score_ptr": (pf, [vp]),
         "fr_worker_submit": (i32, [vp, i32]), "fr_worker_submit_device": (i32, [vp, i32, vp, vp, vp]),
         "fr_worker_sync": (i32, [vp]), "fr_worker_gather_only": (i32, [vp, i32, vp, vp, vp]),
-        "fr_worker_fc_only": (i32, [vp, i32, vp, vp]), "fr_worker_records_dptr": (vp, [vp]),
+        "fr_worker_fc_only": (i32, [vp, i32, vp, vp]), "fr_worker_fc_layer_only": (i32, [vp, i32, i32]), "fr_worker_records_dptr": (vp, [vp]),
+        "fr_worker_features_dptr": (vp, [vp, ctypes.POINTER(ctypes.c_int)]),
         "fr_worker_timer_start": (i32, [vp]), "fr_worker_timer_stop_ms": (i32, [vp, pf]),
         "fr_device_malloc": (i32, [vp, sz, ctypes.POINTER(vp)]), "fr_device_free": (i32, [vp, vp]),
         "fr_memcpy_h2d": (i32, [vp, vp, vp, sz]), "fr_memcpy_d2h": (i32, [vp, vp, vp, sz]),
         "fr_device_synchronize": (i32, [vp]),
         "fr_ctx_shard_info": (i32, [vp] + [ctypes.POINTER(ctypes.c_int)] * 5),
+        "fr_driver_create": (i32, [vp, i32, i32, i32, ctypes.POINTER(vp)]), "fr_driver_destroy": (None, [vp]),
+        "fr_driver_run_resident": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
+        "fr_driver_worker": (vp, [vp, i32, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -347,8 +352,21 @@ class Worker:
     def fc_only(self, batch, d_records, d_scores):
         _check(lib().fr_worker_fc_only(self._h, batch, self._ptr(d_records), self._ptr(d_scores)))
 
+    def fc_layer_only(self, batch, layer):
+        _check(lib().fr_worker_fc_layer_only(self._h, batch, layer))
+
     def records_dptr(self):
         return lib().fr_worker_records_dptr(self._h)
+
+    def features(self, batch):
+        """Feature-major activations Xt[k][m] of the last submit() -> uint32 [record_len][batch] (debug/parity hook)."""
+        ld_max = ctypes.c_int()
+        p = lib().fr_worker_features_dptr(self._h, ctypes.byref(ld_max))
+        K = self.ctx.model.record_len
+        ld = (batch + 31) // 32 * 32
+        out = np.empty(K * ld, dtype=np.uint32)
+        _check(lib().fr_memcpy_d2h(self.ctx._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p), out.nbytes))
+        return out.reshape(K, ld)[:, :batch]
 
     def timer_start(self):
         _check(lib().fr_worker_timer_start(self._h))
@@ -382,3 +400,33 @@ class Worker:
         self.fc_only(B, d_rec, d_sc)
         self.sync()
         return d_sc.download(np.float32, B)
+
+
+class Driver:
+    """The reference server's main() + thread_consume() batch loop (without sockets), natively threaded."""
+
+    def __init__(self, ctx, n_threads, depth, max_batch):
+        self.ctx, self.n_threads, self.depth = ctx, n_threads, depth
+        h = ctypes.c_void_p()
+        _check(lib().fr_driver_create(ctx._h, n_threads, depth, max_batch, ctypes.byref(h)))
+        self._h = h
+
+    def run_resident(self, batch, total_batches, idx_pool, dense_pool=None):
+        """idx_pool / dense_pool: lists of DeviceBuffer.  -> elapsed seconds."""
+        n = len(idx_pool)
+        ip = (ctypes.c_void_p * n)(*[b.ptr.value for b in idx_pool])
+        dp = (ctypes.c_void_p * n)(*[b.ptr.value for b in dense_pool]) if dense_pool else None
+        el = ctypes.c_double()
+        _check(lib().fr_driver_run_resident(self._h, batch, total_batches, ip, dp, n, ctypes.byref(el)))
+        return el.value
+
+    def close(self):
+        if self._h:
+            lib().fr_driver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

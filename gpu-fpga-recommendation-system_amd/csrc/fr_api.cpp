@@ -46,6 +46,7 @@ static int select_device(int device) {
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
 // ---- context --------------------------------------------------------------------------------------
 static void ctx_free(fr_ctx *c) {
@@ -344,7 +345,7 @@ extern "C" void fr_worker_destroy(fr_worker *w) {
     if (w->h_dense) (void)hipHostFree(w->h_dense);
     if (w->h_score) (void)hipHostFree(w->h_score);
     if (w->h_err) (void)hipHostFree(w->h_err);
-    void *dev[] = {w->d_idx, w->d_dense, w->d_records, w->d_r1, w->d_r2, w->d_r3, w->d_score, w->d_err};
+    void *dev[] = {w->d_idx, w->d_dense, w->d_records, w->d_xt, w->d_score};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (w->ev_start) (void)hipEventDestroy(w->ev_start);
@@ -380,8 +381,11 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
     W_HIP(hipHostMalloc((void **)&w->h_idx, B * idx_cols(ctx) * sizeof(int32_t), hipHostMallocDefault));
     if (m.dense_len) W_HIP(hipHostMalloc((void **)&w->h_dense, B * m.dense_len * sizeof(float), hipHostMallocDefault));
     W_HIP(hipHostMalloc((void **)&w->h_score, B * sizeof(float), hipHostMallocDefault));
-    W_HIP(hipHostMalloc((void **)&w->h_err, sizeof(int), hipHostMallocDefault));
+    // index-range flag: pinned, device-visible host word.  Kernels touch it only on the error path
+    // (system-scope atomicOr), so fr_worker_sync() needs no D2H copy -- it just reads the word after the stream drained.
+    W_HIP(hipHostMalloc((void **)&w->h_err, sizeof(int), hipHostMallocMapped));
     *w->h_err = 0;
+    W_HIP(hipHostGetDevicePointer((void **)&w->d_err, w->h_err, 0));
     W_HIP(hipMalloc((void **)&w->d_idx, B * idx_cols(ctx) * sizeof(int32_t)));
     if (m.dense_len) W_HIP(hipMalloc((void **)&w->d_dense, B * m.dense_len * sizeof(float)));
     W_HIP(hipMalloc((void **)&w->d_records, B * (size_t)ctx->slice_padded * sizeof(float) * (ctx->n_shards > 1 ? 1 : 1)));
@@ -389,12 +393,9 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
         fr_worker_destroy(w);
         FR_FAIL(FR_ERR_STATE, "internal: unsharded ctx with a partial slice");
     }
-    W_HIP(hipMalloc((void **)&w->d_r1, B * m.fc[1] * sizeof(float)));
-    W_HIP(hipMalloc((void **)&w->d_r2, B * m.fc[2] * sizeof(float)));
-    W_HIP(hipMalloc((void **)&w->d_r3, B * m.fc[3] * sizeof(float)));
+    w->ld_max = round_up(max_batch, 64);
+    W_HIP(hipMalloc((void **)&w->d_xt, (size_t)w->ld_max * ((size_t)m.fc[0] + m.fc[1] + m.fc[2] + m.fc[3]) * sizeof(float)));
     W_HIP(hipMalloc((void **)&w->d_score, B * sizeof(float)));
-    W_HIP(hipMalloc((void **)&w->d_err, sizeof(int)));
-    W_HIP(hipMemset(w->d_err, 0, sizeof(int)));
     W_HIP(hipEventCreate(&w->ev_start));
     W_HIP(hipEventCreate(&w->ev_stop));
     *out = w;
@@ -405,6 +406,11 @@ extern "C" int32_t *fr_worker_idx_ptr(fr_worker *w) { return w ? w->h_idx : null
 extern "C" float *fr_worker_dense_ptr(fr_worker *w) { return w ? w->h_dense : nullptr; }
 extern "C" float *fr_worker_score_ptr(fr_worker *w) { return w ? w->h_score : nullptr; }
 extern "C" float *fr_worker_records_dptr(fr_worker *w) { return w ? w->d_records : nullptr; }
+extern "C" float *fr_worker_features_dptr(fr_worker *w, int *ld_max) {
+    if (!w) return nullptr;
+    if (ld_max) *ld_max = w->ld_max;
+    return w->d_xt;
+}
 
 static int check_ready(fr_worker *w, int batch, bool need_tables, bool need_weights) {
     if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
@@ -425,18 +431,59 @@ static int launch_gather(fr_worker *w, int batch, const int32_t *d_idx, const fl
     return frk_gather(c->d_words, c->n_words, d_idx, (int)idx_cols(c), d_dense, d_records, batch, w->d_err, w->stream);
 }
 
-static int launch_fc(fr_worker *w, int batch, const float *d_records, float *d_scores) {
+// Split-K factor of one FC layer: enough waves to cover the chip's 1024 SIMDs, but at least 16 k-pairs per wave.
+static int pick_splitk(int K, int N, int ldm) {
+    const long tiles = (long)(N / 32) * (ldm / 32);
+    int sk = 1;
+    while (sk < 16 && tiles * sk < 1024 && (K / 2) / (sk * 2) >= 16) sk *= 2;
+    return sk;
+}
+
+// The 4-GEMM chain (cuda_server.c:468-491) on feature-major activations held in w->d_xt:
+//   Xt[K][ldm] -> R1t[H1][ldm] -> R2t[H2][ldm] -> R3t[H3][ldm] -> score[batch]
+static int launch_chain_t(fr_worker *w, int batch, int ldm, float *d_scores) {
     fr_ctx *c = w->ctx;
     const int32_t *fc = c->model.fc;
-    if (c->n_shards > 1) FR_FAIL(FR_ERR_STATE, "fc on a sharded ctx needs the all-gathered records (use the sharded driver)");
     if (c->fc_precision != FR_FC_FP32) FR_FAIL(FR_ERR_STATE, "bf16 FC path not built yet");
-    int rc = frk_fc_f32(d_records, c->d_w[0], w->d_r1, batch, fc[0], fc[1], w->stream);
+    float *xt = w->d_xt;
+    float *r1 = xt + (size_t)fc[0] * w->ld_max;
+    float *r2 = r1 + (size_t)fc[1] * w->ld_max;
+    float *r3 = r2 + (size_t)fc[2] * w->ld_max;
+    int rc = frk_fc_t(c->d_w[0], xt, r1, fc[0], fc[1], ldm, pick_splitk(fc[0], fc[1], ldm), w->stream);
     if (rc) return rc;
-    rc = frk_fc_f32(w->d_r1, c->d_w[1], w->d_r2, batch, fc[1], fc[2], w->stream);
+    rc = frk_fc_t(c->d_w[1], r1, r2, fc[1], fc[2], ldm, pick_splitk(fc[1], fc[2], ldm), w->stream);
     if (rc) return rc;
-    rc = frk_fc_f32(w->d_r2, c->d_w[2], w->d_r3, batch, fc[2], fc[3], w->stream);
+    rc = frk_fc_t(c->d_w[2], r2, r3, fc[2], fc[3], ldm, pick_splitk(fc[2], fc[3], ldm), w->stream);
     if (rc) return rc;
-    return frk_fc_out(w->d_r3, c->d_w[3], d_scores, batch, fc[3], w->stream);
+    return frk_fc_out_t(r3, c->d_w[3], d_scores, batch, fc[3], ldm, w->stream);
+}
+
+// fc_only diagnostic: item-major records in the model's layout -> scores
+static int launch_fc(fr_worker *w, int batch, const float *d_records, float *d_scores) {
+    fr_ctx *c = w->ctx;
+    if (c->n_shards > 1) FR_FAIL(FR_ERR_STATE, "fc on a sharded ctx needs the all-gathered records (use the sharded driver)");
+    const int ldm = round_up(batch, 32);
+    int rc = frk_transpose_records(d_records, w->d_xt, batch, c->model.fc[0], ldm, w->stream);
+    if (rc) return rc;
+    return launch_chain_t(w, batch, ldm, d_scores);
+}
+
+// whole hot path: index rows -> scores
+static int launch_pipeline(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores) {
+    fr_ctx *c = w->ctx;
+    if (c->n_shards > 1) FR_FAIL(FR_ERR_STATE, "submit on a sharded ctx: use the sharded driver (gather_only + all-gather + fc_only)");
+    if (c->model.layout != FR_LAYOUT_SEMANTIC) {
+        // literal 3-node buffer arithmetic (F8): materialise the blocked records, then read them as B x K item-major
+        int rc = launch_gather(w, batch, d_idx, d_dense, w->d_records);
+        if (rc) return rc;
+        return launch_fc(w, batch, w->d_records, d_scores);
+    }
+    if (!d_idx) FR_FAIL(FR_ERR_INVALID, "d_idx is NULL");
+    if (c->model.dense_len && !d_dense) FR_FAIL(FR_ERR_INVALID, "model has dense features but d_dense is NULL");
+    const int ldm = round_up(batch, 32);
+    int rc = frk_gather_t(c->d_words, c->n_words, d_idx, (int)idx_cols(c), d_dense, w->d_xt, batch, ldm, w->d_err, w->stream);
+    if (rc) return rc;
+    return launch_chain_t(w, batch, ldm, d_scores);
 }
 
 extern "C" int fr_worker_gather_only(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_records) {
@@ -461,14 +508,34 @@ extern "C" int fr_worker_fc_only(fr_worker *w, int batch, const float *d_records
     return FR_OK;
 }
 
+// Roofline hook: launch ONE layer of the chain on the worker's resident activations (contents are whatever the
+// last submit left there); layer 0..2 = fc_t of FC1..FC3, 3 = the output dot product.
+extern "C" int fr_worker_fc_layer_only(fr_worker *w, int batch, int layer) {
+    int rc = check_ready(w, batch, false, true);
+    if (rc) return rc;
+    if (layer < 0 || layer > 3) FR_FAIL(FR_ERR_INVALID, "layer %d out of range", layer);
+    fr_ctx *c = w->ctx;
+    FR_HIP(hipSetDevice(c->device));
+    const int32_t *fc = c->model.fc;
+    const int ldm = round_up(batch, 32);
+    float *act[4];
+    act[0] = w->d_xt;
+    for (int l = 1; l < 4; l++) act[l] = act[l - 1] + (size_t)fc[l - 1] * w->ld_max;
+    if (layer < 3)
+        rc = frk_fc_t(c->d_w[layer], act[layer], act[layer + 1], fc[layer], fc[layer + 1], ldm, pick_splitk(fc[layer], fc[layer + 1], ldm), w->stream);
+    else
+        rc = frk_fc_out_t(act[3], c->d_w[3], w->d_score, batch, fc[3], ldm, w->stream);
+    if (rc) return rc;
+    w->in_flight = true;
+    return FR_OK;
+}
+
 extern "C" int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores) {
     int rc = check_ready(w, batch, true, true);
     if (rc) return rc;
     if (!d_scores) FR_FAIL(FR_ERR_INVALID, "d_scores is NULL");
     FR_HIP(hipSetDevice(w->ctx->device));
-    rc = launch_gather(w, batch, d_idx, d_dense, w->d_records);
-    if (rc) return rc;
-    rc = launch_fc(w, batch, w->d_records, d_scores);
+    rc = launch_pipeline(w, batch, d_idx, d_dense, d_scores);
     if (rc) return rc;
     w->in_flight = true;
     return FR_OK;
@@ -484,9 +551,7 @@ extern "C" int fr_worker_submit(fr_worker *w, int batch) {
     FR_HIP(hipMemcpyAsync(w->d_idx, w->h_idx, (size_t)batch * idx_cols(c) * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
     if (c->model.dense_len)
         FR_HIP(hipMemcpyAsync(w->d_dense, w->h_dense, (size_t)batch * c->model.dense_len * sizeof(float), hipMemcpyHostToDevice, w->stream));
-    rc = launch_gather(w, batch, w->d_idx, w->d_dense, w->d_records);
-    if (rc) return rc;
-    rc = launch_fc(w, batch, w->d_records, w->d_score);
+    rc = launch_pipeline(w, batch, w->d_idx, w->d_dense, w->d_score);
     if (rc) return rc;
     // output D2H (cuda_server.c:494-495)
     FR_HIP(hipMemcpyAsync(w->h_score, w->d_score, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, w->stream));
@@ -497,14 +562,10 @@ extern "C" int fr_worker_submit(fr_worker *w, int batch) {
 extern "C" int fr_worker_sync(fr_worker *w) {
     if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
     FR_HIP(hipSetDevice(w->ctx->device));
-    // the error flag travels behind the batch on the same stream
-    FR_HIP(hipMemcpyAsync(w->h_err, w->d_err, sizeof(int), hipMemcpyDeviceToHost, w->stream));
     FR_HIP(hipStreamSynchronize(w->stream));
     w->in_flight = false;
-    if (*w->h_err) {
-        *w->h_err = 0;
-        FR_HIP(hipMemsetAsync(w->d_err, 0, sizeof(int), w->stream));
-        FR_HIP(hipStreamSynchronize(w->stream));
+    if (__atomic_load_n(w->h_err, __ATOMIC_ACQUIRE)) {
+        __atomic_store_n(w->h_err, 0, __ATOMIC_RELEASE);
         FR_FAIL(FR_ERR_INDEX_RANGE, "a lookup index was outside its table (row 0 was read instead)");
     }
     return FR_OK;

@@ -1,0 +1,109 @@
+// Request-driver core: the batch loop of the reference server without its sockets.
+//
+// Reference shape (GPU/final_network_cublasLt_1_node_no_FIFO_scatter/cuda_server.c):
+//   main() spawns THREAD_NUM pthreads running thread_consume() (:554-556); each owns a stream and its
+//   buffers (:136-187) and loops { lock; id = global_batch_count++; unlock (:408-417); receive the
+//   batch (:425-450); H2D; 4 GEMMs; D2H (:460-495) } until TOTAL_BATCH_NUM batches are done.
+// Here the "receive" step is replaced by picking a device-resident index buffer from a pool (the
+// synthetic request stream of bench.py); the TCP front-end in host/ feeds the same loop through
+// the pinned fr_worker buffers instead.  Each thread keeps `depth` workers in flight so that its
+// stream(s) never drain while the host prepares the next submit.
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "fr_internal.h"
+
+struct fr_driver {
+    fr_ctx *ctx = nullptr;
+    int n_threads = 0, depth = 0, max_batch = 0;
+    std::vector<fr_worker *> workers;  // [n_threads * depth]
+};
+
+extern "C" void fr_driver_destroy(fr_driver *d) {
+    if (!d) return;
+    for (fr_worker *w : d->workers) fr_worker_destroy(w);
+    delete d;
+}
+
+extern "C" int fr_driver_create(fr_ctx *ctx, int n_threads, int depth, int max_batch, fr_driver **out) {
+    if (!ctx || !out) FR_FAIL(FR_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (n_threads < 1 || n_threads > 256 || depth < 1 || depth > 64) FR_FAIL(FR_ERR_INVALID, "n_threads %d / depth %d out of range", n_threads, depth);
+    fr_driver *d = new (std::nothrow) fr_driver();
+    if (!d) FR_FAIL(FR_ERR_OOM, "out of host memory");
+    d->ctx = ctx;
+    d->n_threads = n_threads;
+    d->depth = depth;
+    d->max_batch = max_batch;
+    for (int i = 0; i < n_threads * depth; i++) {
+        fr_worker *w = nullptr;
+        int rc = fr_worker_create(ctx, max_batch, &w);
+        if (rc) {
+            fr_driver_destroy(d);
+            return rc;
+        }
+        d->workers.push_back(w);
+    }
+    *out = d;
+    return FR_OK;
+}
+
+extern "C" int fr_driver_run_resident(fr_driver *d, int batch, int64_t total_batches, const int32_t *const *d_idx_pool,
+                                      const float *const *d_dense_pool, int n_pool, double *elapsed_s) {
+    if (!d || !d_idx_pool || n_pool < 1 || !elapsed_s) FR_FAIL(FR_ERR_INVALID, "bad argument");
+    if (batch < 1 || batch > d->max_batch || total_batches < 0) FR_FAIL(FR_ERR_INVALID, "batch %d / total %lld out of range", batch, (long long)total_batches);
+    std::mutex mtx;               // pthread_mutex_t mtx (cuda_server.c:25)
+    int64_t global_batch_count = 0;  // cuda_server.c:23
+    std::vector<int> status(d->n_threads, FR_OK);
+    std::vector<std::string> messages(d->n_threads);
+    std::vector<std::thread> threads;
+    FR_HIP(hipSetDevice(d->ctx->device));
+    FR_HIP(hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < d->n_threads; t++) {
+        threads.emplace_back([&, t]() {
+            fr_worker **wk = &d->workers[(size_t)t * d->depth];
+            std::vector<char> busy(d->depth, 0);
+            int64_t local = 0;
+            int rc = FR_OK;
+            while (rc == FR_OK) {
+                int64_t id;
+                {
+                    std::lock_guard<std::mutex> g(mtx);
+                    if (global_batch_count >= total_batches) break;
+                    id = global_batch_count++;
+                }
+                const int slot = (int)(local++ % d->depth);
+                if (busy[slot]) {
+                    rc = fr_worker_sync(wk[slot]);
+                    busy[slot] = 0;
+                    if (rc) break;
+                }
+                const int p = (int)(id % n_pool);
+                rc = fr_worker_submit_device(wk[slot], batch, d_idx_pool[p], d_dense_pool ? d_dense_pool[p] : nullptr, wk[slot]->d_score);
+                if (rc == FR_OK) busy[slot] = 1;
+            }
+            for (int s = 0; s < d->depth; s++)
+                if (busy[s]) {
+                    int r2 = fr_worker_sync(wk[s]);
+                    if (rc == FR_OK) rc = r2;
+                }
+            status[t] = rc;
+            if (rc) messages[t] = fr_last_error();
+        });
+    }
+    for (auto &th : threads) th.join();
+    FR_HIP(hipDeviceSynchronize());
+    *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int t = 0; t < d->n_threads; t++)
+        if (status[t]) FR_FAIL(status[t], "driver thread %d: %s", t, messages[t].c_str());
+    return FR_OK;
+}
+
+extern "C" fr_worker *fr_driver_worker(fr_driver *d, int thread, int slot) {
+    if (!d || thread < 0 || thread >= d->n_threads || slot < 0 || slot >= d->depth) return nullptr;
+    return d->workers[(size_t)thread * d->depth + slot];
+}

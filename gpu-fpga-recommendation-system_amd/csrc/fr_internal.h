@@ -86,10 +86,11 @@ struct fr_worker {
     int32_t *d_idx = nullptr;
     float *d_dense = nullptr;
     float *d_records = nullptr; // [max_batch][K]
-    float *d_r1 = nullptr, *d_r2 = nullptr, *d_r3 = nullptr;
+    float *d_xt = nullptr;      // feature-major pipeline: Xt[K][ld], R1t[H1][ld], R2t[H2][ld], R3t[H3][ld] in one allocation
+    int ld_max = 0;             // round_up(max_batch, 64)
     float *d_score = nullptr;
-    int *d_err = nullptr;  // sticky index-range flag (device)
-    int *h_err = nullptr;  // pinned mirror
+    int *h_err = nullptr;  // sticky index-range flag: pinned host word ...
+    int *d_err = nullptr;  // ... and its device-side alias
     bool in_flight = false;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
@@ -107,7 +108,9 @@ int frk_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t l
 int frk_f32_to_bf16(const float *src, uint16_t *dst, size_t count, hipStream_t s);
 int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense,
                float *out, int batch, int *err_flag, hipStream_t s);
-// Y[B][N] = X[B][K] * Wt[K][N]  (fp32, exact-f32 MFMA)
-int frk_fc_f32(const float *X, const float *Wt, float *Y, int B, int K, int N, hipStream_t s);
-// score[b] = sum_h R[b][h] * w[h]   (the OUT == 1 layer, cuda_server.c:486-491)
-int frk_fc_out(const float *R, const float *w, float *score, int B, int H, hipStream_t s);
+// feature-major small-batch pipeline (see fr_kernels.hip)
+int frk_gather_t(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, float *Xt,
+                 int batch, int ldm, int *err_flag, hipStream_t s);
+int frk_transpose_records(const float *X, float *Xt, int batch, int K, int ldm, hipStream_t s);
+int frk_fc_t(const float *Wt, const float *Xt, float *Yt, int K, int N, int ldm, int splitk, hipStream_t s);
+int frk_fc_out_t(const float *Rt, const float *w, float *score, int batch, int H, int ldm, hipStream_t s);

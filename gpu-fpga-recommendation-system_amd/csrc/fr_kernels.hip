@@ -5,9 +5,10 @@
 //   gather_pack   per-table embedding row gather + bit-copy concat into the per-item record
 //                 (load_single_embedding_*_tables + group_* + gather_embeddings of
 //                 FPGA/kernel/user_krnl/embedding_{47,98,377}_krnl/src/hls/embedding_*_krnl.cpp)
-//   fc_f32        one column-major GEMM of the chain R = W * X on the exact-f32 MFMA
-//                 (cublasLtMatmul, GPU/final_network_cublasLt_1_node_no_FIFO_scatter/cuda_server.c:468-485)
-//   fc_out        the OUT == 1 layer (cuda_server.c:486-491), a per-item dot product
+//   gather_t      the same gather, written feature-major (Xt[k][item]) for the FC chain
+//   fc_t          one column-major GEMM of the chain R = W * X on the exact-f32 MFMA, split-K inside the
+//                 workgroup (cublasLtMatmul, GPU/final_network_cublasLt_1_node_no_FIFO_scatter/cuda_server.c:468-485)
+//   fc_out_t      the OUT == 1 layer (cuda_server.c:486-491), a per-item dot product
 //
 // Wavefront = 64 lanes everywhere; no CUDA-compat shims.
 #include <hip/hip_bf16.h>
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(256) gather_pack_kernel(const FrWordDesc *__re
         const int b = b0 + i;
         if (b < batch) out[blk + (size_t)b * dst_stride] = v[i];
     }
-    if (bad) atomicOr(err_flag, 1);
+    if (bad) atomicOr_system(err_flag, 1);  // pinned host word; error path only
 }
 
 int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, float *out,
@@ -187,120 +188,260 @@ int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx
     return FR_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// fc_f32: Y[B][N] = X[B][K] * Wt[K][N], all fp32.
-//
-// The reference's column-major operands map onto row-major ones without any transpose:
-//   X  (K x B, ld=K)  == item-major records X[b][k]                      (cuda_server.c:216)
-//   W  (H x K, ld=H)  == K-major weights   Wt[k][h] = W[h + k*H]         (cuda_server.c:215)
-//   R  (H x B, ld=H)  == item-major        Y[b][h]                       (cuda_server.c:217)
-// Arithmetic: v_mfma_f32_32x32x2_f32 -- f32 in / f32 accumulate, bit-for-bit a k-ordered fmaf chain
-// (no TF32-like shortcut exists on gfx950), i.e. CUBLAS_COMPUTE_32F semantics (cuda_server.c:211).
-//
-// Block = 256 threads = 4 waves (2 x 2), block tile 64 items x 64 outputs, wave tile 32 x 32
-// (one 16-register accumulator), K step 16, two LDS buffers, one barrier per K step.
-// LDS images are k-major ([k][m] and [k][n]) so that the A and B fragment reads
-// (lane l -> element [k + (l>>5)][base + (l&31)]) are conflict-free ds_read_b32.
-// ---------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int FC_BM = 64, FC_BN = 64, FC_BK = 16;
+// ===================================================================================================
+// Small-batch pipeline: feature-major activations + split-K inside the workgroup.
+//
+// At batch 256 one FC layer is only 64-128 output tiles of 32x32: a classic LDS-tiled GEMM leaves
+// most of the 1024 SIMDs idle and walks K serially (measured: 20 us per layer).  Here every
+// activation matrix is kept FEATURE-major, Xt[k][m] (m = item, leading dimension ldm), so that both
+// MFMA operands are plain coalesced 128-byte row segments that go straight from L2 to registers:
+//     A fragment: Wt[k + (lane>>5)][n0 + (lane&31)]     (the reference's column-major W, cuda_server.c:215)
+//     B fragment: Xt[k + (lane>>5)][m0 + (lane&31)]
+//     D[n][m] accumulates in the 32x32 MFMA; its store Yt[n][m0 + (lane&31)] is coalesced again.
+// The SPLITK waves of a workgroup each own one slice of K for the SAME 32x32 output tile and are
+// summed through LDS in a fixed order (deterministic, no atomics).  Item columns m >= batch are
+// padding: every output column depends only on the same input column, so they never mix with real items.
+// ===================================================================================================
 
-__global__ void __launch_bounds__(256) fc_f32_kernel(const float *__restrict__ X, const float *__restrict__ Wt,
-                                                     float *__restrict__ Y, int B, int K, int N) {
-    __shared__ float lds[2][2][FC_BK][FC_BM];  // [buf][A|B][k][m or n]  = 16 KiB
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * FC_BM, n0 = blockIdx.x * FC_BN;
+// gather_t: per-table rows -> Xt[k][m].  Lanes = 64 consecutive items, one record word per wave step
+// (its descriptor is wave-uniform -> scalar loads); each lane reads its item's 16-byte row word and
+// writes 4 floats to 4 feature rows (256-byte coalesced stores).
+__global__ void __launch_bounds__(256) gather_t_kernel(const FrWordDesc *__restrict__ words, int n_words,
+                                                       const int32_t *__restrict__ idx, int idx_stride,
+                                                       const float *__restrict__ dense, float *__restrict__ Xt,
+                                                       int batch, int ldm, int words_per_wave, int *__restrict__ err_flag) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = blockIdx.x * 64 + lane;
+    const int w_begin = (blockIdx.y * 4 + wave) * words_per_wave;
+    const bool live = m < batch;
+    bool bad = false;
+    for (int i = 0; i < words_per_wave; i++) {
+        const int w = w_begin + i;
+        if (w >= n_words) break;
+        const FrWordDesc d = words[w];  // wave-uniform
+        const bool is_dense = (d.idx_col & FR_DESC_DENSE) != 0;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (live) {
+            uint32_t id = is_dense ? (uint32_t)m : (uint32_t)idx[(size_t)m * idx_stride + d.idx_col];
+            if (!is_dense && id >= d.rows) {
+                bad = true;
+                id = 0;
+            }
+            const char *base = is_dense ? reinterpret_cast<const char *>(dense) + d.src : reinterpret_cast<const char *>(d.src);
+            v = *reinterpret_cast<const uint4 *>(base + (uint64_t)id * d.stride);
+        }
+        // feature index of this word inside the record (SEMANTIC layout only on this path)
+        float *o = Xt + (size_t)(4 * d.dst_off) * ldm + m;
+        if (m < ldm) {
+            o[0] = __uint_as_float(v.x);
+            o[(size_t)ldm] = __uint_as_float(v.y);
+            o[(size_t)2 * ldm] = __uint_as_float(v.z);
+            o[(size_t)3 * ldm] = __uint_as_float(v.w);
+        }
+    }
+    if (bad) atomicOr_system(err_flag, 1);  // pinned host word; error path only
+}
 
-    // staging roles
-    const int a_m = tid & 63, a_kq = tid >> 6;   // A: row m0+a_m, floats k0+4*a_kq .. +3
-    const int b_k = tid >> 4, b_nq = tid & 15;   // B: row k0+b_k, floats n0+4*b_nq .. +3
-    const bool a_row_ok = (m0 + a_m) < B;
-    const float *a_ptr = X + (size_t)(a_row_ok ? (m0 + a_m) : 0) * K + 4 * a_kq;
-    const bool b_col_ok = (n0 + 4 * b_nq) < N;  // N % 4 == 0 is required by the launcher
-    const float *b_ptr = Wt + (size_t)b_k * N + (b_col_ok ? (n0 + 4 * b_nq) : 0);
+int frk_gather_t(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, float *Xt,
+                 int batch, int ldm, int *err_flag, hipStream_t s) {
+    if (n_words <= 0 || batch <= 0) return FR_OK;
+    const int words_per_wave = 2;
+    dim3 grid((ldm + 63) / 64, (n_words + 4 * words_per_wave - 1) / (4 * words_per_wave));
+    gather_t_kernel<<<grid, dim3(256), 0, s>>>(words, n_words, idx, idx_stride, dense, Xt, batch, ldm, words_per_wave, err_flag);
+    KCHECK();
+    return FR_OK;
+}
+
+// item-major records [B][K] -> Xt[K][ldm] (only used by the fc_only diagnostic entry point)
+__global__ void __launch_bounds__(256) transpose_records_kernel(const float *__restrict__ X, float *__restrict__ Xt, int batch, int K, int ldm) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int m = m0 + r, k = k0 + tx;
+        tile[r][tx] = (m < batch && k < K) ? X[(size_t)m * K + k] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, m = m0 + tx;
+        if (k < K && m < ldm) Xt[(size_t)k * ldm + m] = tile[tx][r];
+    }
+}
+
+int frk_transpose_records(const float *X, float *Xt, int batch, int K, int ldm, hipStream_t s) {
+    dim3 grid((K + 31) / 32, (ldm + 31) / 32);
+    transpose_records_kernel<<<grid, dim3(256), 0, s>>>(X, Xt, batch, K, ldm);
+    KCHECK();
+    return FR_OK;
+}
+
+// fc_t: Yt[N][ldm] = W * X with Wt[K][N], Xt[K][ldm]; one 32(n) x 32(m) tile per workgroup, SPLITK waves.
+//
+// NP > 0 : the wave's K slice is exactly NP k-pairs, known at compile time.  The body is straight-line: all
+//          2*NP operand loads are issued up front (row base in SGPRs + one per-lane VGPR offset), then NP MFMAs
+//          consume them behind counted vmcnt waits -- one L2 round trip per wave instead of one per k-group.
+// NP == 0: generic shapes; double-buffered groups of 8 k-pairs, branch-free inside the loop.
+template <int SPLITK, int NP>
+__global__ void __launch_bounds__(64 * SPLITK) fc_t_kernel(const float *__restrict__ Wt, const float *__restrict__ Xt,
+                                                           float *__restrict__ Yt, int K, int N, int ldm) {
+    __shared__ float red[SPLITK > 1 ? SPLITK : 1][16][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int hk = lane >> 5, lm = lane & 31;
+    const int a_off = hk * N + n0 + lm;    // per-lane, loop-invariant
+    const int b_off = hk * ldm + m0 + lm;
 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
 
-    const int n_kt = (K + FC_BK - 1) / FC_BK;
-    float4 ra, rb;
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * FC_BK;
-        ra = make_float4(0.f, 0.f, 0.f, 0.f);
-        rb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a_row_ok && (k0 + 4 * a_kq) < K) ra = *reinterpret_cast<const float4 *>(a_ptr + k0);  // K % 4 == 0
-        if (b_col_ok && (k0 + b_k) < K) rb = *reinterpret_cast<const float4 *>(b_ptr + (size_t)k0 * N);
-    };
-    load_tile(0);
-    for (int kt = 0; kt < n_kt; kt++) {
-        const int buf = kt & 1;
-        lds[buf][0][4 * a_kq + 0][a_m] = ra.x;
-        lds[buf][0][4 * a_kq + 1][a_m] = ra.y;
-        lds[buf][0][4 * a_kq + 2][a_m] = ra.z;
-        lds[buf][0][4 * a_kq + 3][a_m] = ra.w;
-        *reinterpret_cast<float4 *>(&lds[buf][1][b_k][4 * b_nq]) = rb;
-        __syncthreads();
-        if (kt + 1 < n_kt) load_tile(kt + 1);
-        const int hk = lane >> 5, lm = lane & 31;
+    if constexpr (NP > 0) {
+        const float *a_row = Wt + (size_t)(2 * NP * wave) * N;   // wave-uniform
+        const float *b_row = Xt + (size_t)(2 * NP * wave) * ldm;
+        float ra[NP], rb[NP];
 #pragma unroll
-        for (int kk = 0; kk < FC_BK; kk += 2) {
-            const float a = lds[buf][0][kk + hk][wm * 32 + lm];
-            const float b = lds[buf][1][kk + hk][wn * 32 + lm];
+        for (int i = 0; i < NP; i++) {
+            ra[i] = a_row[(size_t)(2 * i) * N + a_off];
+            rb[i] = b_row[(size_t)(2 * i) * ldm + b_off];
+        }
+        // keep the scheduler from sinking the loads back next to their MFMAs (it would, to save VGPRs)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NP; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i], rb[i], acc, 0, 0, 0);
+    } else {
+        const int pairs = K / 2;
+        const int per = (pairs + SPLITK - 1) / SPLITK;
+        const int p_begin = wave * per;
+        int np = pairs - p_begin;
+        np = np < 0 ? 0 : (np > per ? per : np);
+        const float *a_row = Wt + (size_t)(2 * p_begin) * N;
+        const float *b_row = Xt + (size_t)(2 * p_begin) * ldm;
+        constexpr int D = 8;
+        const int ng = np / D;
+        float ra[D], rb[D], na[D], nb[D];
+        if (ng > 0) {
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+                ra[i] = a_row[(size_t)(2 * i) * N + a_off];
+                rb[i] = b_row[(size_t)(2 * i) * ldm + b_off];
+            }
+        }
+        for (int g = 0; g < ng; g++) {
+            const int nx = (g + 1 < ng) ? (g + 1) : g;  // the last group re-loads itself (harmless) -> no branch in the body
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+                na[i] = a_row[(size_t)(2 * (nx * D + i)) * N + a_off];
+                nb[i] = b_row[(size_t)(2 * (nx * D + i)) * ldm + b_off];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < D; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i], rb[i], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+                ra[i] = na[i];
+                rb[i] = nb[i];
+            }
+        }
+        for (int p = ng * D; p < np; p++) {  // remainder (< D pairs)
+            const float a = a_row[(size_t)(2 * p) * N + a_off];
+            const float b = b_row[(size_t)(2 * p) * ldm + b_off];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
     }
-    // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col < N) {
+    if constexpr (SPLITK == 1) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row < B) Y[(size_t)row * N + col] = acc[r];
+            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * hk;
+            Yt[(size_t)n * ldm + m0 + lm] = acc[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[wave][r][lane] = acc[r];
+        __syncthreads();
+        // fixed-order sum over the K slices, then the coalesced store of the tile
+        for (int e = threadIdx.x; e < 16 * 64; e += 64 * SPLITK) {
+            const int r = e >> 6, l = e & 63;
+            float s = red[0][r][l];
+#pragma unroll
+            for (int w = 1; w < SPLITK; w++) s += red[w][r][l];
+            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+            Yt[(size_t)n * ldm + m0 + (l & 31)] = s;
         }
     }
 }
 
-int frk_fc_f32(const float *X, const float *Wt, float *Y, int B, int K, int N, hipStream_t s) {
-    if (B <= 0) return FR_OK;
-    if (K % 4 || N % 4) FR_FAIL(FR_ERR_INVALID, "fc_f32 needs K and N multiples of 4 (got K=%d N=%d)", K, N);
-    dim3 grid((N + FC_BN - 1) / FC_BN, (B + FC_BM - 1) / FC_BM);
-    fc_f32_kernel<<<grid, dim3(256), 0, s>>>(X, Wt, Y, B, K, N);
+template <int SPLITK, int NP>
+static void fc_t_launch(dim3 grid, const float *Wt, const float *Xt, float *Yt, int K, int N, int ldm, hipStream_t s) {
+    fc_t_kernel<SPLITK, NP><<<grid, dim3(64 * SPLITK), 0, s>>>(Wt, Xt, Yt, K, N, ldm);
+}
+
+int frk_fc_t(const float *Wt, const float *Xt, float *Yt, int K, int N, int ldm, int splitk, hipStream_t s) {
+    if (K % 4 || N % 32 || ldm % 32) FR_FAIL(FR_ERR_INVALID, "fc_t needs K%%4==0, N%%32==0, ldm%%32==0 (K=%d N=%d ldm=%d)", K, N, ldm);
+    dim3 grid(N / 32, ldm / 32);
+    const int pairs = K / 2;
+    const int np = (pairs % splitk == 0) ? pairs / splitk : -1;
+    // straight-line instantiations for the reference models' small-batch shapes
+    if (splitk == 4 && np == 44) fc_t_launch<4, 44>(grid, Wt, Xt, Yt, K, N, ldm, s);        // A FC1: K=352
+    else if (splitk == 8 && np == 55) fc_t_launch<8, 55>(grid, Wt, Xt, Yt, K, N, ldm, s);   // B FC1: K=880
+    else if (splitk == 8 && np == 64) fc_t_launch<8, 64>(grid, Wt, Xt, Yt, K, N, ldm, s);   // FC2: K=1024
+    else if (splitk == 16 && np == 64) fc_t_launch<16, 64>(grid, Wt, Xt, Yt, K, N, ldm, s); // C FC2: K=2048
+    else if (splitk == 8 && np == 32) fc_t_launch<8, 32>(grid, Wt, Xt, Yt, K, N, ldm, s);   // FC3: K=512
+    else if (splitk == 16 && np == 16) fc_t_launch<16, 16>(grid, Wt, Xt, Yt, K, N, ldm, s); // FC3: K=512
+    else if (splitk == 4 && np == 64) fc_t_launch<4, 64>(grid, Wt, Xt, Yt, K, N, ldm, s);
+    else if (splitk == 2 && np == 64) fc_t_launch<2, 64>(grid, Wt, Xt, Yt, K, N, ldm, s);
+    else {
+        switch (splitk) {
+            case 1: fc_t_launch<1, 0>(grid, Wt, Xt, Yt, K, N, ldm, s); break;
+            case 2: fc_t_launch<2, 0>(grid, Wt, Xt, Yt, K, N, ldm, s); break;
+            case 4: fc_t_launch<4, 0>(grid, Wt, Xt, Yt, K, N, ldm, s); break;
+            case 8: fc_t_launch<8, 0>(grid, Wt, Xt, Yt, K, N, ldm, s); break;
+            case 16: fc_t_launch<16, 0>(grid, Wt, Xt, Yt, K, N, ldm, s); break;
+            default: FR_FAIL(FR_ERR_INVALID, "fc_t: unsupported splitk %d", splitk);
+        }
+    }
     KCHECK();
     return FR_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// fc_out: score[b] = sum_h R[b][h] * w[h]  (OUTPUT_FEATURE_LEN == 1; Wout is 1 x H column-major = w[h]).
-// One wave per item, 16-byte loads, wave-level shuffle reduction.
-// ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) fc_out_kernel(const float *__restrict__ R, const float *__restrict__ w,
-                                                     float *__restrict__ score, int B, int H) {
+// fc_out_t: score[m] = sum_n w[n] * Rt[n][m]; block = 64 items x 16 slices of n (all loads of a slice in flight),
+// LDS reduce in fixed order.
+__global__ void __launch_bounds__(1024) fc_out_t_kernel(const float *__restrict__ Rt, const float *__restrict__ w,
+                                                        float *__restrict__ score, int batch, int H, int ldm) {
+    __shared__ float part[16][64];
     const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= B) return;
-    const float *r = R + (size_t)item * H;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = blockIdx.x * 64 + lane;
+    const int per = (H + 15) / 16;
+    const int h0 = q * per;
     float s = 0.0f;
-    for (int h = 4 * lane; h < H; h += 256) {
-        const float4 a = *reinterpret_cast<const float4 *>(r + h);
-        const float4 b = *reinterpret_cast<const float4 *>(w + h);
-        s = fmaf(a.x, b.x, s);
-        s = fmaf(a.y, b.y, s);
-        s = fmaf(a.z, b.z, s);
-        s = fmaf(a.w, b.w, s);
-    }
+    if (m < ldm) {
+        int h = h0;
+        for (; h + 8 <= h0 + per && h + 8 <= H; h += 8) {
+            float v[8];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) score[item] = s;
+            for (int i = 0; i < 8; i++) v[i] = Rt[(size_t)(h + i) * ldm + m];
+#pragma unroll
+            for (int i = 0; i < 8; i++) s = fmaf(w[h + i], v[i], s);
+        }
+        for (; h < h0 + per && h < H; h++) s = fmaf(w[h], Rt[(size_t)h * ldm + m], s);
+    }
+    part[q][lane] = s;
+    __syncthreads();
+    if (q == 0 && m < batch) {
+        float t = part[0][lane];
+#pragma unroll
+        for (int i = 1; i < 16; i++) t += part[i][lane];
+        score[m] = t;
+    }
 }
 
-int frk_fc_out(const float *R, const float *w, float *score, int B, int H, hipStream_t s) {
-    if (B <= 0) return FR_OK;
-    if (H % 4) FR_FAIL(FR_ERR_INVALID, "fc_out needs H multiple of 4 (got %d)", H);
-    fc_out_kernel<<<dim3((B + 3) / 4), dim3(256), 0, s>>>(R, w, score, B, H);
+int frk_fc_out_t(const float *Rt, const float *w, float *score, int batch, int H, int ldm, hipStream_t s) {
+    fc_out_t_kernel<<<dim3((ldm + 63) / 64), dim3(1024), 0, s>>>(Rt, w, score, batch, H, ldm);
     KCHECK();
     return FR_OK;
 }

@@ -126,7 +126,7 @@ typedef enum fr_fill_mode {
                              The reference only initialises the first 200 rows of HBM/DDR tables
                              (`#define DEBUG`, host.cpp:75-80); here every row follows the pattern. */
     FR_FILL_HASH = 1,     /* v = hash32(seed, table, row, col) mapped to [-1,1): the roofline workload  */
-    FR_FILL_TAGGED = 2    /* u32 bit pattern (source<<30 | class<<28 | table_id<<20 | (row&0xffff)<<4 | (col&15)):
+    FR_FILL_TAGGED = 2    /* u32 bit pattern (source<<31 | class<<29 | table_id<<21 | (row&0xffff)<<5 | (col&31)):
                              every float identifies where it came from -- pins the wire order          */
 } fr_fill_mode;
 
@@ -218,12 +218,33 @@ int fr_worker_sync(fr_worker *w);
 int fr_worker_gather_only(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense,
                           float *d_records);
 int fr_worker_fc_only(fr_worker *w, int batch, const float *d_records, float *d_scores);
+/* Roofline hook: launch ONE layer of the FC chain (0..2 = FC1..FC3, 3 = output layer) on the worker's resident
+ * activations, exactly as submit() launches it. */
+int fr_worker_fc_layer_only(fr_worker *w, int batch, int layer);
 /* Device pointer of the worker's own record buffer ([max_batch][record_len] floats). */
 float *fr_worker_records_dptr(fr_worker *w);
+/* Debug/parity hook: device pointer of the worker's FEATURE-major activation buffer used by submit():
+ * Xt[k][m] at xt[k*ld + m] (k < record_len, m < batch, ld = round_up(batch,32) of the LAST submit; the
+ * allocation's row capacity is returned in *ld_max).  Lets tests check the fused gather bit-exactly. */
+float *fr_worker_features_dptr(fr_worker *w, int *ld_max);
 
 /* HIP-event timing on the worker's stream (the stream the kernels are launched on). */
 int fr_worker_timer_start(fr_worker *w);
 int fr_worker_timer_stop_ms(fr_worker *w, float *ms); /* records stop, synchronises, returns elapsed */
+
+/* ---- request-driver core: main() + the thread_consume() batch loop without sockets
+ *      (cuda_server.c:23-25,406-497,554-560) ------------------------------------------------------- */
+typedef struct fr_driver fr_driver;
+/* n_threads host threads (THREAD_NUM, constant.h:42), each owning `depth` workers/streams. */
+int fr_driver_create(fr_ctx *ctx, int n_threads, int depth, int max_batch, fr_driver **out);
+void fr_driver_destroy(fr_driver *d);
+/* Processes `total_batches` batches of `batch` items: threads draw batch ids from a mutex-guarded global
+ * counter (cuda_server.c:408-417); batch id i reads the HBM-resident index rows d_idx_pool[i % n_pool]
+ * (and d_dense_pool[i % n_pool] when the model has dense features; may be NULL otherwise).
+ * Returns wall time from first submit to last completion (device drained on both sides). */
+int fr_driver_run_resident(fr_driver *d, int batch, int64_t total_batches, const int32_t *const *d_idx_pool,
+                           const float *const *d_dense_pool, int n_pool, double *elapsed_s);
+fr_worker *fr_driver_worker(fr_driver *d, int thread, int slot);
 
 /* ---- device memory helpers (so hosts/tests need no other GPU runtime binding) ---------------- */
 int fr_device_malloc(fr_ctx *ctx, size_t bytes, void **dptr);

@@ -1,0 +1,95 @@
+// Ablation of the record gather (gather_pack_kernel's structure) on a Model-C-like descriptor set, all tables cache-resident.
+// Which of {descriptor load, index load, row load, record store} sets the 40 us?  hipcc --offload-arch=gfx950 -O3
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+struct Desc { unsigned long long src; unsigned stride, idx_col, rows, dst_off, dst_stride, dst_blk; };
+template <int ITEMS, int MODE>  // MODE bit0: skip stores, bit1: skip row loads, bit2: skip idx loads
+__global__ void __launch_bounds__(256) gk(const Desc *__restrict__ words, int n_words, const int *__restrict__ idx, int idx_stride,
+                                          uint4 *__restrict__ out, int batch) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    const uint4 d0 = reinterpret_cast<const uint4 *>(words)[2 * w];
+    const uint4 d1 = reinterpret_cast<const uint4 *>(words)[2 * w + 1];
+    const unsigned long long src = ((unsigned long long)d0.y << 32) | d0.x;
+    const unsigned stride = d0.z, idx_col = d0.w, rows = d1.x, dst_off = d1.y, dst_stride = d1.z;
+    const int b0 = blockIdx.y * ITEMS;
+    unsigned id[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const int b = b0 + i;
+        if (MODE & 4) id[i] = (unsigned)(b * 2654435761u + idx_col * 40503u) % rows;
+        else id[i] = (unsigned)idx[(size_t)b * idx_stride + idx_col];
+    }
+    uint4 v[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        if (MODE & 2) v[i] = make_uint4(id[i], id[i] + 1, id[i] + 2, id[i] + 3);
+        else v[i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(src) + (unsigned long long)id[i] * stride);
+    }
+    if (MODE & 1) {
+        unsigned acc = 0;
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) acc ^= v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+        if (acc == 0x12345678u) out[w] = v[0];
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) out[(size_t)(b0 + i) * dst_stride + dst_off] = v[i];
+    }
+}
+// alternative mapping: one WAVE per item-chunk; lanes sweep the record words (word index varies per lane AND per step)
+template <int MODE>
+__global__ void __launch_bounds__(256) gk_item(const Desc *__restrict__ words, int n_words, const int *__restrict__ idx, int idx_stride,
+                                               uint4 *__restrict__ out, int batch) {
+    const int b = blockIdx.x;  // one block per item
+    for (int w = threadIdx.x; w < n_words; w += 256) {
+        const uint4 d0 = reinterpret_cast<const uint4 *>(words)[2 * w];
+        const uint4 d1 = reinterpret_cast<const uint4 *>(words)[2 * w + 1];
+        const unsigned long long src = ((unsigned long long)d0.y << 32) | d0.x;
+        const unsigned id = (unsigned)idx[(size_t)b * idx_stride + d0.w];
+        const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(src) + (unsigned long long)id * d0.z);
+        out[(size_t)b * d1.z + d1.y] = v;
+    }
+}
+template <typename F> float timeit(F f, int reps) {
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    for (int i = 0; i < 5; i++) f(i);
+    (void)hipEventRecord(a, 0);
+    for (int i = 0; i < reps; i++) f(i);
+    (void)hipEventRecord(b, 0); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b); return ms / reps * 1000.f;
+}
+int main() {
+    const int B = 4096, T = 376, NW = 992;
+    // Model-C-like: per half 8x dim4, 128x dim8, 48x dim16, 4x dim32 (+16 dense words treated as a dim64 table)
+    std::vector<int> dims; for (int h = 0; h < 2; h++) { for (int i = 0; i < 8; i++) dims.push_back(4); for (int i = 0; i < 128; i++) dims.push_back(8);
+        for (int i = 0; i < 48; i++) dims.push_back(16); for (int i = 0; i < 4; i++) dims.push_back(32); }
+    const unsigned rows = 20000;
+    size_t tot = 0; std::vector<size_t> off; for (int d : dims) { off.push_back(tot); tot += (size_t)rows * d * 4; }
+    char *tab; (void)hipMalloc(&tab, tot + 4096 * 256); (void)hipMemset(tab, 1, tot);
+    std::vector<Desc> h; for (int t = 0; t < (int)dims.size(); t++) for (int j = 0; j < dims[t] / 4; j++) {
+        Desc d{}; d.src = (unsigned long long)(tab + off[t] + 16 * j); d.stride = dims[t] * 4; d.idx_col = t; d.rows = rows; d.dst_off = (unsigned)h.size(); d.dst_stride = NW; h.push_back(d); }
+    while ((int)h.size() < NW) { Desc d = h[h.size() - 976]; d.dst_off = (unsigned)h.size(); h.push_back(d); }
+    printf("tables %.1f MB, %zu words\n", tot / 1e6, h.size());
+    Desc *dw; (void)hipMalloc(&dw, sizeof(Desc) * NW); (void)hipMemcpy(dw, h.data(), sizeof(Desc) * NW, hipMemcpyHostToDevice);
+    const int NB = 8; int *idx[NB];
+    std::vector<int> hi((size_t)B * T);
+    for (int n = 0; n < NB; n++) { for (auto &x : hi) x = rand() % rows; (void)hipMalloc(&idx[n], hi.size() * 4); (void)hipMemcpy(idx[n], hi.data(), hi.size() * 4, hipMemcpyHostToDevice); }
+    uint4 *out; (void)hipMalloc(&out, (size_t)B * NW * 16);
+    const double bytes = (double)B * (NW * 16 * 2 + T * 4);
+#define RUN(IT, MODE, name) { float us = timeit([&](int i) { gk<IT, MODE><<<dim3((NW + 255) / 256, (B + IT - 1) / IT), 256>>>(dw, NW, idx[i % NB], T, out, B); }, 50); \
+    printf("%-44s %7.2f us  %6.0f GB/s(alg)\n", name, us, bytes / us / 1e3); }
+    RUN(8, 0, "items=8 full");
+    RUN(8, 1, "items=8 no stores");
+    RUN(8, 2, "items=8 no row loads");
+    RUN(8, 4, "items=8 no idx loads");
+    RUN(8, 6, "items=8 stores only");
+    RUN(8, 5, "items=8 row loads only");
+    RUN(4, 0, "items=4 full");
+    RUN(16, 0, "items=16 full");
+    RUN(2, 0, "items=2 full");
+    { float us = timeit([&](int i) { gk_item<0><<<B, 256>>>(dw, NW, idx[i % NB], T, out, B); }, 50);
+      printf("%-44s %7.2f us  %6.0f GB/s(alg)\n", "block-per-item full", us, bytes / us / 1e3); }
+    return 0;
+}
