@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "fr_model_table_bytes", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
     "fr_ctx_fill_tables", "fr_ctx_upload_table", "fr_ctx_download_table", "fr_ctx_set_weights", "fr_ctx_fill_weights",
     "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
-    "fr_worker_dense_ptr", "fr_worker_score_ptr", "fr_worker_submit", "fr_worker_submit_device", "fr_worker_sync",
+    "fr_worker_dense_ptr", "fr_worker_score_ptr", "fr_worker_submit", "fr_worker_submit_device", "fr_worker_push_device", "fr_worker_sync",
     "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
     "fr_device_synchronize", "fr_ctx_shard_info", "fr_driver_create", "fr_driver_destroy", "fr_driver_run_resident",
@@ -93,7 +93,7 @@ def lib():
         "fr_ctx_get_weights": (i32, [vp, i32, vp, sz]), "fr_ctx_set_fc_precision": (i32, [vp, i32]),
         "fr_worker_create": (i32, [vp, i32, ctypes.POINTER(vp)]), "fr_worker_destroy": (None, [vp]),
         "fr_worker_idx_ptr": (pi, [vp]), "fr_worker_dense_ptr": (pf, [vp]), "fr_worker_score_ptr": (pf, [vp]),
-        "fr_worker_submit": (i32, [vp, i32]), "fr_worker_submit_device": (i32, [vp, i32, vp, vp, vp]),
+        "fr_worker_submit": (i32, [vp, i32]), "fr_worker_submit_device": (i32, [vp, i32, vp, vp, vp]), "fr_worker_push_device": (i32, [vp, i32, vp, vp, vp]),
         "fr_worker_sync": (i32, [vp]), "fr_worker_gather_only": (i32, [vp, i32, vp, vp, vp]),
         "fr_worker_fc_only": (i32, [vp, i32, vp, vp]), "fr_worker_fc_layer_only": (i32, [vp, i32, i32]), "fr_worker_records_dptr": (vp, [vp]),
         "fr_worker_features_dptr": (vp, [vp, ctypes.POINTER(ctypes.c_int)]),
@@ -346,6 +346,9 @@ class Worker:
     def submit_device(self, batch, d_idx, d_dense, d_scores):
         _check(lib().fr_worker_submit_device(self._h, batch, self._ptr(d_idx), self._ptr(d_dense), self._ptr(d_scores)))
 
+    def push_device(self, batch, d_idx, d_dense, d_scores):
+        _check(lib().fr_worker_push_device(self._h, batch, self._ptr(d_idx), self._ptr(d_dense), self._ptr(d_scores)))
+
     def gather_only(self, batch, d_idx, d_dense, d_records):
         _check(lib().fr_worker_gather_only(self._h, batch, self._ptr(d_idx), self._ptr(d_dense), self._ptr(d_records)))
 
@@ -359,14 +362,15 @@ class Worker:
         return lib().fr_worker_records_dptr(self._h)
 
     def features(self, batch):
-        """Feature-major activations Xt[k][m] of the last submit() -> uint32 [record_len][batch] (debug/parity hook)."""
+        """Feature-major activations of the last submit(), un-packed from the device's q4 layout Xq[k/4][m][k%4]
+        -> uint32 [record_len][batch] (debug/parity hook for the pipeline's own gather stage)."""
         ld_max = ctypes.c_int()
         p = lib().fr_worker_features_dptr(self._h, ctypes.byref(ld_max))
         K = self.ctx.model.record_len
         ld = (batch + 31) // 32 * 32
         out = np.empty(K * ld, dtype=np.uint32)
         _check(lib().fr_memcpy_d2h(self.ctx._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p), out.nbytes))
-        return out.reshape(K, ld)[:, :batch]
+        return out.reshape(K // 4, ld, 4).transpose(0, 2, 1).reshape(K, ld)[:, :batch]
 
     def timer_start(self):
         _check(lib().fr_worker_timer_start(self._h))

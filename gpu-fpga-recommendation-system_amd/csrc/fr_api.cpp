@@ -56,6 +56,7 @@ static void ctx_free(fr_ctx *c) {
     if (c->d_words) (void)hipFree(c->d_words);
     for (int i = 0; i < 4; i++) {
         if (c->d_w[i]) (void)hipFree(c->d_w[i]);
+        if (i < 3 && c->d_wq[i]) (void)hipFree(c->d_wq[i]);
         if (c->d_w_bf16[i]) (void)hipFree(c->d_w_bf16[i]);
     }
     if (c->setup_stream) (void)hipStreamDestroy(c->setup_stream);
@@ -197,6 +198,7 @@ extern "C" int fr_ctx_create_sharded(const fr_model_desc *m, int device, int sha
     for (int l = 0; l < 4; l++) {
         size_t n = (size_t)m->fc[l] * m->fc[l + 1];
         e = hipMalloc((void **)&c->d_w[l], n * sizeof(float));
+        if (e == hipSuccess && l < 3) e = hipMalloc((void **)&c->d_wq[l], n * sizeof(float));
         if (e != hipSuccess) {
             fr_set_error("hipMalloc(weights layer %d) failed: %s", l, hipGetErrorString(e));
             ctx_free(c);
@@ -273,7 +275,12 @@ extern "C" int fr_ctx_download_table(fr_ctx *ctx, int table, int64_t row0, int64
 }
 
 // ---- weights ----------------------------------------------------------------------------------------
+// derived copies of one layer's weights: the q4 re-pack for the fp32 chain, the bf16 cast for the MFMA-bf16 chain
 static int refresh_bf16(fr_ctx *ctx, int layer) {
+    if (layer < 3) {
+        int rc = frk_pack_weights_q4(ctx->d_w[layer], ctx->d_wq[layer], ctx->model.fc[layer], ctx->model.fc[layer + 1], ctx->setup_stream);
+        if (rc) return rc;
+    }
     if (ctx->fc_precision != FR_FC_BF16) return FR_OK;
     size_t n = (size_t)ctx->model.fc[layer] * ctx->model.fc[layer + 1];
     if (!ctx->d_w_bf16[layer]) FR_HIP(hipMalloc((void **)&ctx->d_w_bf16[layer], n * sizeof(uint16_t)));
@@ -345,7 +352,7 @@ extern "C" void fr_worker_destroy(fr_worker *w) {
     if (w->h_dense) (void)hipHostFree(w->h_dense);
     if (w->h_score) (void)hipHostFree(w->h_score);
     if (w->h_err) (void)hipHostFree(w->h_err);
-    void *dev[] = {w->d_idx, w->d_dense, w->d_records, w->d_xt, w->d_score};
+    void *dev[] = {w->d_idx, w->d_dense, w->d_records, w->d_act[0], w->d_act[1], w->d_score};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (w->ev_start) (void)hipEventDestroy(w->ev_start);
@@ -394,7 +401,8 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
         FR_FAIL(FR_ERR_STATE, "internal: unsharded ctx with a partial slice");
     }
     w->ld_max = round_up(max_batch, 64);
-    W_HIP(hipMalloc((void **)&w->d_xt, (size_t)w->ld_max * ((size_t)m.fc[0] + m.fc[1] + m.fc[2] + m.fc[3]) * sizeof(float)));
+    for (int p = 0; p < 2; p++)
+        W_HIP(hipMalloc((void **)&w->d_act[p], (size_t)w->ld_max * ((size_t)m.fc[0] + 2 * ((size_t)m.fc[1] + m.fc[2] + m.fc[3])) * sizeof(float)));
     W_HIP(hipMalloc((void **)&w->d_score, B * sizeof(float)));
     W_HIP(hipEventCreate(&w->ev_start));
     W_HIP(hipEventCreate(&w->ev_stop));
@@ -409,7 +417,7 @@ extern "C" float *fr_worker_records_dptr(fr_worker *w) { return w ? w->d_records
 extern "C" float *fr_worker_features_dptr(fr_worker *w, int *ld_max) {
     if (!w) return nullptr;
     if (ld_max) *ld_max = w->ld_max;
-    return w->d_xt;
+    return w->d_act[w->last_x_parity];
 }
 
 static int check_ready(fr_worker *w, int batch, bool need_tables, bool need_weights) {
@@ -431,59 +439,169 @@ static int launch_gather(fr_worker *w, int batch, const int32_t *d_idx, const fl
     return frk_gather(c->d_words, c->n_words, d_idx, (int)idx_cols(c), d_dense, d_records, batch, w->d_err, w->stream);
 }
 
-// Split-K factor of one FC layer: enough waves to cover the chip's 1024 SIMDs, but at least 16 k-pairs per wave.
-static int pick_splitk(int K, int N, int ldm) {
+// ---- the stage pipeline ------------------------------------------------------------------------------
+static unsigned long long *g_stamp_buffer = nullptr;  // diagnostics (tools/experiments): see fr_debug_set_stamp_buffer
+extern "C" __attribute__((visibility("default"))) void fr_debug_set_stamp_buffer(void *dptr) { g_stamp_buffer = (unsigned long long *)dptr; }
+
+// K-split of one FC layer into 2 workgroups per output tile (partials summed by the next stage's loads):
+// only when the layer has fewer tiles than CUs and each wave still gets >= 16 k-pairs.
+static int pick_nsplit(int K, int N, int ldm) {
     const long tiles = (long)(N / 32) * (ldm / 32);
-    int sk = 1;
-    while (sk < 16 && tiles * sk < 1024 && (K / 2) / (sk * 2) >= 16) sk *= 2;
-    return sk;
+    const int groups = K / 8;  // groups of 8 k = one 16-byte operand load per lane
+    return (tiles < 256 && groups % 16 == 0 && groups / 16 >= 4) ? 2 : 1;
 }
 
-// The 4-GEMM chain (cuda_server.c:468-491) on feature-major activations held in w->d_xt:
-//   Xt[K][ldm] -> R1t[H1][ldm] -> R2t[H2][ldm] -> R3t[H3][ldm] -> score[batch]
-static int launch_chain_t(fr_worker *w, int batch, int ldm, float *d_scores) {
+struct ActSet {
+    float *x, *r1, *r2, *r3;
+    size_t p1, p2, p3;  // partial strides
+};
+static ActSet act_set(const fr_worker *w, int parity) {
+    const int32_t *fc = w->ctx->model.fc;
+    const size_t ld = (size_t)w->ld_max;
+    ActSet a;
+    a.x = w->d_act[parity];
+    a.r1 = a.x + (size_t)fc[0] * ld;
+    a.p1 = (size_t)fc[1] * ld;
+    a.r2 = a.r1 + 2 * a.p1;
+    a.p2 = (size_t)fc[2] * ld;
+    a.r3 = a.r2 + 2 * a.p2;
+    a.p3 = (size_t)fc[3] * ld;
+    return a;
+}
+
+// Issue ONE pipeline launch: every in-flight batch advances by one stage; `fresh` (may be NULL) enters at stage 0.
+// only_stage >= 0: debugging/roofline -- run just that stage of the (single) in-flight batch as its own kernel.
+static int pipeline_step(fr_worker *w) {
     fr_ctx *c = w->ctx;
     const int32_t *fc = c->model.fc;
-    if (c->fc_precision != FR_FC_FP32) FR_FAIL(FR_ERR_STATE, "bf16 FC path not built yet");
-    float *xt = w->d_xt;
-    float *r1 = xt + (size_t)fc[0] * w->ld_max;
-    float *r2 = r1 + (size_t)fc[1] * w->ld_max;
-    float *r3 = r2 + (size_t)fc[2] * w->ld_max;
-    int rc = frk_fc_t(c->d_w[0], xt, r1, fc[0], fc[1], ldm, pick_splitk(fc[0], fc[1], ldm), w->stream);
-    if (rc) return rc;
-    rc = frk_fc_t(c->d_w[1], r1, r2, fc[1], fc[2], ldm, pick_splitk(fc[1], fc[2], ldm), w->stream);
-    if (rc) return rc;
-    rc = frk_fc_t(c->d_w[2], r2, r3, fc[2], fc[3], ldm, pick_splitk(fc[2], fc[3], ldm), w->stream);
-    if (rc) return rc;
-    return frk_fc_out_t(r3, c->d_w[3], d_scores, batch, fc[3], ldm, w->stream);
+    const uint64_t L = w->launch_no;
+    const int par = (int)(L & 1);
+    const ActSet wr = act_set(w, par), rd = act_set(w, par ^ 1);
+    FrPipeArgs a{};
+    a.words = c->d_words;
+    a.n_words = c->n_words;
+    a.idx_stride = (int)idx_cols(c);
+    a.err_flag = w->d_err;
+    a.stamps = g_stamp_buffer;
+    int blocks = 0, n_stages = 0, only = -1;
+    for (int s = 0; s < FR_N_STAGES; s++) {
+        FrStageArgs &st = a.st[s];
+        st.block_begin = blocks;
+        if (L < (uint64_t)s) continue;
+        fr_worker::Slot &sl = w->ring[(L - s) % 8];
+        if (!sl.active || sl.launch0 != L - s || s < sl.first_stage) continue;
+        st.batch = sl.batch;
+        st.ldm = sl.ldm;
+        const int ldm = sl.ldm;
+        // K-split plan of the three FC layers of this batch
+        const int ns1 = pick_nsplit(fc[0], fc[1], ldm), ns2 = pick_nsplit(fc[1], fc[2], ldm), ns3 = pick_nsplit(fc[2], fc[3], ldm);
+        switch (s) {
+            case 0:
+                a.idx = sl.d_idx;
+                a.dense = sl.d_dense;
+                st.out = wr.x;
+                w->last_x_parity = par;
+                break;
+            case 1:
+                st.K = fc[0]; st.N = fc[1]; st.nsplit = ns1; st.nparts_in = 1;
+                st.in = rd.x; st.in_part_stride = 0; st.out = wr.r1; st.part_stride = (int)wr.p1; st.w = c->d_wq[0];
+                break;
+            case 2:
+                st.K = fc[1]; st.N = fc[2]; st.nsplit = ns2; st.nparts_in = ns1;
+                st.in = rd.r1; st.in_part_stride = (int)rd.p1; st.out = wr.r2; st.part_stride = (int)wr.p2; st.w = c->d_wq[1];
+                break;
+            case 3:
+                st.K = fc[2]; st.N = fc[3]; st.nsplit = ns3; st.nparts_in = ns2;
+                st.in = rd.r2; st.in_part_stride = (int)rd.p2; st.out = wr.r3; st.part_stride = (int)wr.p3; st.w = c->d_wq[2];
+                break;
+            case 4:
+                st.K = fc[3]; st.N = 1; st.nsplit = 1; st.nparts_in = ns3;
+                st.in = rd.r3; st.in_part_stride = (int)rd.p3; st.out = sl.d_scores; st.w = c->d_w[3];
+                break;
+        }
+        blocks += frk_stage_blocks(s, c->n_words, st.K, st.N, ldm, st.nsplit);
+        n_stages++;
+        only = s;
+        if (s == FR_N_STAGES - 1) {  // the batch leaves the pipeline with this launch
+            sl.active = false;
+            w->n_active--;
+        }
+    }
+    a.n_blocks = blocks;
+    w->launch_no = L + 1;
+    if (n_stages == 0) return FR_OK;
+    if (n_stages == 1) {  // a lone stage runs as its own, separately named kernel (rocprof attribution)
+        const int begin = a.st[only].block_begin;
+        for (int s = 0; s < FR_N_STAGES; s++) a.st[s].block_begin -= (s >= only) ? begin : 0;
+        a.st[only].block_begin = 0;
+        return frk_pipeline_launch(a, only, w->stream);
+    }
+    return frk_pipeline_launch(a, -1, w->stream);
 }
 
-// fc_only diagnostic: item-major records in the model's layout -> scores
+static int pipeline_push(fr_worker *w, int batch, int first_stage, const int32_t *d_idx, const float *d_dense, float *d_scores) {
+    const uint64_t L0 = w->launch_no - (uint64_t)first_stage;  // launch number its (virtual) stage 0 had
+    fr_worker::Slot &sl = w->ring[L0 % 8];
+    if (sl.active) FR_FAIL(FR_ERR_STATE, "internal: pipeline ring slot still busy");
+    sl.active = true;
+    sl.launch0 = L0;
+    sl.first_stage = first_stage;
+    sl.batch = batch;
+    sl.ldm = round_up(batch, 32);
+    sl.d_idx = d_idx;
+    sl.d_dense = d_dense;
+    sl.d_scores = d_scores;
+    w->n_active++;
+    return pipeline_step(w);
+}
+
+static int pipeline_flush(fr_worker *w) {
+    while (w->n_active > 0) {
+        int rc = pipeline_step(w);
+        if (rc) return rc;
+    }
+    return FR_OK;
+}
+
+static int check_gather_args(fr_worker *w, const int32_t *d_idx, const float *d_dense) {
+    fr_ctx *c = w->ctx;
+    if (!d_idx) FR_FAIL(FR_ERR_INVALID, "d_idx is NULL");
+    if (c->model.dense_len && !d_dense) FR_FAIL(FR_ERR_INVALID, "model has dense features but d_dense is NULL");
+    return FR_OK;
+}
+
+// fc_only diagnostic: item-major records in the model's layout -> scores (pipeline must be idle)
 static int launch_fc(fr_worker *w, int batch, const float *d_records, float *d_scores) {
     fr_ctx *c = w->ctx;
     if (c->n_shards > 1) FR_FAIL(FR_ERR_STATE, "fc on a sharded ctx needs the all-gathered records (use the sharded driver)");
+    if (c->fc_precision != FR_FC_FP32) FR_FAIL(FR_ERR_STATE, "bf16 FC path not built yet");
+    if (w->n_active) FR_FAIL(FR_ERR_STATE, "pipeline busy: call fr_worker_sync first");
+    if (w->launch_no == 0) w->launch_no = 1;  // stage 1 of the next launch reads the set the (virtual) previous launch wrote
     const int ldm = round_up(batch, 32);
-    int rc = frk_transpose_records(d_records, w->d_xt, batch, c->model.fc[0], ldm, w->stream);
+    const int par_prev = (int)((w->launch_no - 1) & 1);
+    int rc = frk_transpose_records(d_records, act_set(w, par_prev).x, batch, c->model.fc[0], ldm, w->stream);
     if (rc) return rc;
-    return launch_chain_t(w, batch, ldm, d_scores);
+    rc = pipeline_push(w, batch, 1, nullptr, nullptr, d_scores);
+    if (rc) return rc;
+    return pipeline_flush(w);
 }
 
-// whole hot path: index rows -> scores
+// whole hot path for ONE batch, unpipelined: index rows -> scores (five dependent launches)
 static int launch_pipeline(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores) {
     fr_ctx *c = w->ctx;
     if (c->n_shards > 1) FR_FAIL(FR_ERR_STATE, "submit on a sharded ctx: use the sharded driver (gather_only + all-gather + fc_only)");
+    if (c->fc_precision != FR_FC_FP32) FR_FAIL(FR_ERR_STATE, "bf16 FC path not built yet");
     if (c->model.layout != FR_LAYOUT_SEMANTIC) {
         // literal 3-node buffer arithmetic (F8): materialise the blocked records, then read them as B x K item-major
         int rc = launch_gather(w, batch, d_idx, d_dense, w->d_records);
         if (rc) return rc;
         return launch_fc(w, batch, w->d_records, d_scores);
     }
-    if (!d_idx) FR_FAIL(FR_ERR_INVALID, "d_idx is NULL");
-    if (c->model.dense_len && !d_dense) FR_FAIL(FR_ERR_INVALID, "model has dense features but d_dense is NULL");
-    const int ldm = round_up(batch, 32);
-    int rc = frk_gather_t(c->d_words, c->n_words, d_idx, (int)idx_cols(c), d_dense, w->d_xt, batch, ldm, w->d_err, w->stream);
+    int rc = check_gather_args(w, d_idx, d_dense);
     if (rc) return rc;
-    return launch_chain_t(w, batch, ldm, d_scores);
+    rc = pipeline_push(w, batch, 0, d_idx, d_dense, d_scores);
+    if (rc) return rc;
+    return pipeline_flush(w);
 }
 
 extern "C" int fr_worker_gather_only(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_records) {
@@ -508,23 +626,55 @@ extern "C" int fr_worker_fc_only(fr_worker *w, int batch, const float *d_records
     return FR_OK;
 }
 
-// Roofline hook: launch ONE layer of the chain on the worker's resident activations (contents are whatever the
-// last submit left there); layer 0..2 = fc_t of FC1..FC3, 3 = the output dot product.
+// Roofline hook: launch ONE stage of the chain (1..3 = FC1..FC3, 4 = output layer; 0 is not available here) on the
+// worker's resident activations, exactly as an unpipelined submit launches it.  API layer index = stage - 1.
 extern "C" int fr_worker_fc_layer_only(fr_worker *w, int batch, int layer) {
     int rc = check_ready(w, batch, false, true);
     if (rc) return rc;
     if (layer < 0 || layer > 3) FR_FAIL(FR_ERR_INVALID, "layer %d out of range", layer);
+    if (w->n_active) FR_FAIL(FR_ERR_STATE, "pipeline busy: call fr_worker_sync first");
     fr_ctx *c = w->ctx;
     FR_HIP(hipSetDevice(c->device));
-    const int32_t *fc = c->model.fc;
-    const int ldm = round_up(batch, 32);
-    float *act[4];
-    act[0] = w->d_xt;
-    for (int l = 1; l < 4; l++) act[l] = act[l - 1] + (size_t)fc[l - 1] * w->ld_max;
-    if (layer < 3)
-        rc = frk_fc_t(c->d_w[layer], act[layer], act[layer + 1], fc[layer], fc[layer + 1], ldm, pick_splitk(fc[layer], fc[layer + 1], ldm), w->stream);
-    else
-        rc = frk_fc_out_t(act[3], c->d_w[3], w->d_score, batch, fc[3], ldm, w->stream);
+    // place a virtual batch so that the next launch runs exactly stage layer+1 of it, then drop it again
+    const int stage = layer + 1;
+    if (w->launch_no < (uint64_t)stage) w->launch_no = stage;
+    const uint64_t L0 = w->launch_no - (uint64_t)stage;
+    fr_worker::Slot &sl = w->ring[L0 % 8];
+    sl.active = true;
+    sl.launch0 = L0;
+    sl.first_stage = stage;
+    sl.batch = batch;
+    sl.ldm = round_up(batch, 32);
+    sl.d_idx = nullptr;
+    sl.d_dense = nullptr;
+    sl.d_scores = w->d_score;
+    w->n_active++;
+    rc = pipeline_step(w);
+    if (sl.active) {  // stages 1..3 leave the batch in flight: retire it by hand
+        sl.active = false;
+        w->n_active--;
+    }
+    if (rc) return rc;
+    w->in_flight = true;
+    return FR_OK;
+}
+
+// Streaming form of the hot loop body: enqueue batch after batch without synchronising (cuda_server.c:406-497 does
+// exactly that).  Each call issues ONE launch in which this batch is gathered while the previous four batches of
+// this worker advance through FC1, FC2, FC3 and the output layer.  d_scores of a pushed batch are complete after
+// four more pushes have executed, or after fr_worker_sync() (which drains the pipeline).  The caller keeps
+// d_idx / d_dense / d_scores valid and distinct for every batch still in the pipeline (up to 5).
+extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores) {
+    int rc = check_ready(w, batch, true, true);
+    if (rc) return rc;
+    if (!d_scores) FR_FAIL(FR_ERR_INVALID, "d_scores is NULL");
+    fr_ctx *c = w->ctx;
+    if (c->n_shards > 1 || c->model.layout != FR_LAYOUT_SEMANTIC || c->fc_precision != FR_FC_FP32)
+        FR_FAIL(FR_ERR_STATE, "push_device needs an unsharded SEMANTIC-layout fp32 context");
+    rc = check_gather_args(w, d_idx, d_dense);
+    if (rc) return rc;
+    FR_HIP(hipSetDevice(c->device));
+    rc = pipeline_push(w, batch, 0, d_idx, d_dense, d_scores);
     if (rc) return rc;
     w->in_flight = true;
     return FR_OK;
@@ -535,6 +685,7 @@ extern "C" int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d
     if (rc) return rc;
     if (!d_scores) FR_FAIL(FR_ERR_INVALID, "d_scores is NULL");
     FR_HIP(hipSetDevice(w->ctx->device));
+    if (w->n_active) FR_FAIL(FR_ERR_STATE, "pipeline busy (push_device in flight): call fr_worker_sync first");
     rc = launch_pipeline(w, batch, d_idx, d_dense, d_scores);
     if (rc) return rc;
     w->in_flight = true;
@@ -562,6 +713,8 @@ extern "C" int fr_worker_submit(fr_worker *w, int batch) {
 extern "C" int fr_worker_sync(fr_worker *w) {
     if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
     FR_HIP(hipSetDevice(w->ctx->device));
+    int frc = pipeline_flush(w);  // drain batches enqueued with fr_worker_push_device
+    if (frc) return frc;
     FR_HIP(hipStreamSynchronize(w->stream));
     w->in_flight = false;
     if (__atomic_load_n(w->h_err, __ATOMIC_ACQUIRE)) {

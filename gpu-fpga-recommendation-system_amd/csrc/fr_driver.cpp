@@ -20,11 +20,15 @@ struct fr_driver {
     fr_ctx *ctx = nullptr;
     int n_threads = 0, depth = 0, max_batch = 0;
     std::vector<fr_worker *> workers;  // [n_threads * depth]
+    std::vector<float *> score_rings;  // per worker: 8 x max_batch floats (a pushed batch's scores stay valid 8 pushes)
 };
 
 extern "C" void fr_driver_destroy(fr_driver *d) {
     if (!d) return;
     for (fr_worker *w : d->workers) fr_worker_destroy(w);
+    if (d->ctx) (void)hipSetDevice(d->ctx->device);
+    for (float *p : d->score_rings)
+        if (p) (void)hipFree(p);
     delete d;
 }
 
@@ -46,6 +50,12 @@ extern "C" int fr_driver_create(fr_ctx *ctx, int n_threads, int depth, int max_b
             return rc;
         }
         d->workers.push_back(w);
+        float *ring = nullptr;
+        if (hipMalloc((void **)&ring, (size_t)8 * max_batch * sizeof(float)) != hipSuccess) {
+            fr_driver_destroy(d);
+            FR_FAIL(FR_ERR_OOM, "hipMalloc(score ring) failed");
+        }
+        d->score_rings.push_back(ring);
     }
     *out = d;
     return FR_OK;
@@ -66,7 +76,7 @@ extern "C" int fr_driver_run_resident(fr_driver *d, int batch, int64_t total_bat
     for (int t = 0; t < d->n_threads; t++) {
         threads.emplace_back([&, t]() {
             fr_worker **wk = &d->workers[(size_t)t * d->depth];
-            std::vector<char> busy(d->depth, 0);
+            float **rings = &d->score_rings[(size_t)t * d->depth];
             int64_t local = 0;
             int rc = FR_OK;
             while (rc == FR_OK) {
@@ -76,21 +86,19 @@ extern "C" int fr_driver_run_resident(fr_driver *d, int batch, int64_t total_bat
                     if (global_batch_count >= total_batches) break;
                     id = global_batch_count++;
                 }
-                const int slot = (int)(local++ % d->depth);
-                if (busy[slot]) {
-                    rc = fr_worker_sync(wk[slot]);
-                    busy[slot] = 0;
-                    if (rc) break;
-                }
+                // enqueue without synchronising, like the reference's loop body (cuda_server.c:460-495)
+                const int slot = (int)(local % d->depth);
+                float *scores = rings[slot] + (size_t)((local / d->depth) % 8) * d->max_batch;
+                local++;
                 const int p = (int)(id % n_pool);
-                rc = fr_worker_submit_device(wk[slot], batch, d_idx_pool[p], d_dense_pool ? d_dense_pool[p] : nullptr, wk[slot]->d_score);
-                if (rc == FR_OK) busy[slot] = 1;
+                rc = fr_worker_push_device(wk[slot], batch, d_idx_pool[p], d_dense_pool ? d_dense_pool[p] : nullptr, scores);
+                // bound the host's run-ahead: every 64 batches wait for this worker's stream
+                if (rc == FR_OK && (local % (64 * d->depth)) == 0) rc = fr_worker_sync(wk[slot]);
             }
-            for (int s = 0; s < d->depth; s++)
-                if (busy[s]) {
-                    int r2 = fr_worker_sync(wk[s]);
-                    if (rc == FR_OK) rc = r2;
-                }
+            for (int s = 0; s < d->depth; s++) {
+                int r2 = fr_worker_sync(wk[s]);
+                if (rc == FR_OK) rc = r2;
+            }
             status[t] = rc;
             if (rc) messages[t] = fr_last_error();
         });

@@ -43,6 +43,38 @@ struct FrWordDesc {
 static_assert(sizeof(FrWordDesc) == 32, "FrWordDesc must be 32 bytes");
 #define FR_DESC_DENSE 0x80000000u
 
+// ---- pipelined FC chain: launch arguments (see fr_kernels.hip) -------------------------------------
+constexpr int FR_N_STAGES = 5;  // gather | FC1 | FC2 | FC3 | out
+
+struct FrStageArgs {
+    int block_begin;  // first workgroup of this stage inside the launch; == next stage's begin when inactive
+    int batch;        // real items
+    int ldm;          // padded items (multiple of 32) = leading dimension of every activation matrix of this batch
+    int K, N;         // FC stages: reduction length / outputs; out stage: K = H3
+    int nsplit;       // FC stages: workgroups along K per output tile (partials written to out + p*part_stride);
+                      // K % (8 * nsplit) == 0 is required (groups of 8 k)
+    int nparts_in;    // FC/out stages: partial inputs to add while loading (1 or 2)
+    int part_stride;  // floats between the partial OUTPUT buffers
+    int in_part_stride;  // floats between the partial INPUT buffers
+    const float *in;  // activations in (feature-major)
+    float *out;       // activations out / scores
+    const float *w;   // weights Wt[K][N] (FC) or w[H] (out)
+};
+
+struct FrPipeArgs {
+    FrStageArgs st[FR_N_STAGES];
+    int n_blocks;
+    // gather stage
+    const struct FrWordDesc *words;
+    int n_words;
+    int idx_stride;
+    const int32_t *idx;
+    const float *dense;
+    int *err_flag;
+    // diagnostic build aid (NULL in normal operation): per workgroup {s_memrealtime at entry, at exit, stage, hw id}
+    unsigned long long *stamps;
+};
+
 // ---- host objects -------------------------------------------------------------------------------
 struct FrTableMem {
     uint64_t byte_offset; // inside ctx->table_arena
@@ -65,6 +97,7 @@ struct fr_ctx {
     // FC weights: fp32 master copies in the reference's column-major H x K layout
     // (= K-major "Wt[k][h]", cuda_server.c:215) and optional bf16 copies.
     float *d_w[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *d_wq[3] = {nullptr, nullptr, nullptr};  // FC1..FC3 re-packed as Wq[k/4][h][k%4] for the 16-byte operand loads
     uint16_t *d_w_bf16[4] = {nullptr, nullptr, nullptr, nullptr};
     bool weights_set = false;
     int fc_precision = FR_FC_FP32;
@@ -86,8 +119,23 @@ struct fr_worker {
     int32_t *d_idx = nullptr;
     float *d_dense = nullptr;
     float *d_records = nullptr; // [max_batch][K]
-    float *d_xt = nullptr;      // feature-major pipeline: Xt[K][ld], R1t[H1][ld], R2t[H2][ld], R3t[H3][ld] in one allocation
+    // feature-major activations, two sets alternating by launch parity; per set:
+    //   Xt[K][ld] | R1t[2][H1][ld] | R2t[2][H2][ld] | R3t[2][H3][ld]   ([2] = K-split partials)
+    float *d_act[2] = {nullptr, nullptr};
     int ld_max = 0;             // round_up(max_batch, 64)
+    // software pipeline over consecutive batches: slot of the batch whose gather ran in launch L is ring[L % 8]
+    struct Slot {
+        bool active = false;
+        uint64_t launch0 = 0;   // launch number of its stage 0
+        int first_stage = 0;    // 0 normally; 1 for fc_only (activations supplied by a transpose)
+        int batch = 0, ldm = 0;
+        const int32_t *d_idx = nullptr;
+        const float *d_dense = nullptr;
+        float *d_scores = nullptr;
+    } ring[8];
+    uint64_t launch_no = 0;     // number of pipeline launches issued so far
+    int n_active = 0;
+    int last_x_parity = 0;      // which activation set holds Xt of the most recently pushed batch (debug hook)
     float *d_score = nullptr;
     int *h_err = nullptr;  // sticky index-range flag: pinned host word ...
     int *d_err = nullptr;  // ... and its device-side alias
@@ -108,9 +156,8 @@ int frk_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t l
 int frk_f32_to_bf16(const float *src, uint16_t *dst, size_t count, hipStream_t s);
 int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense,
                float *out, int batch, int *err_flag, hipStream_t s);
-// feature-major small-batch pipeline (see fr_kernels.hip)
-int frk_gather_t(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, float *Xt,
-                 int batch, int ldm, int *err_flag, hipStream_t s);
+// feature-major FC chain, stage-pipelined across batches (see fr_kernels.hip)
+int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, hipStream_t s);
+int frk_pack_weights_q4(const float *W, float *Wq, int K, int H, hipStream_t s);
+int frk_stage_blocks(int stage, int n_words, int K, int N, int ldm, int nsplit);
 int frk_transpose_records(const float *X, float *Xt, int batch, int K, int ldm, hipStream_t s);
-int frk_fc_t(const float *Wt, const float *Xt, float *Yt, int K, int N, int ldm, int splitk, hipStream_t s);
-int frk_fc_out_t(const float *Rt, const float *w, float *score, int batch, int H, int ldm, hipStream_t s);

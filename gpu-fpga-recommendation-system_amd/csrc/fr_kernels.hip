@@ -191,257 +191,358 @@ int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ===================================================================================================
-// Small-batch pipeline: feature-major activations + split-K inside the workgroup.
+// FC chain on k-quad-packed feature-major activations, split-K inside the workgroup, stages
+// software-pipelined across consecutive batches of a worker.
 //
-// At batch 256 one FC layer is only 64-128 output tiles of 32x32: a classic LDS-tiled GEMM leaves
-// most of the 1024 SIMDs idle and walks K serially (measured: 20 us per layer).  Here every
-// activation matrix is kept FEATURE-major, Xt[k][m] (m = item, leading dimension ldm), so that both
-// MFMA operands are plain coalesced 128-byte row segments that go straight from L2 to registers:
-//     A fragment: Wt[k + (lane>>5)][n0 + (lane&31)]     (the reference's column-major W, cuda_server.c:215)
-//     B fragment: Xt[k + (lane>>5)][m0 + (lane&31)]
-//     D[n][m] accumulates in the 32x32 MFMA; its store Yt[n][m0 + (lane&31)] is coalesced again.
-// The SPLITK waves of a workgroup each own one slice of K for the SAME 32x32 output tile and are
-// summed through LDS in a fixed order (deterministic, no atomics).  Item columns m >= batch are
-// padding: every output column depends only on the same input column, so they never mix with real items.
+// Layout ("q4"): every activation matrix and every weight matrix is stored with 4 consecutive k per 16 bytes,
+//     Xq[k/4][m][k%4]   (m = item, leading dimension ldm)         Wq[k/4][n][k%4]   (n = output feature)
+// so that both MFMA operands are ONE coalesced 16-byte load per lane (512 contiguous bytes per half-wave) that goes
+// straight from L2 to registers and feeds FOUR v_mfma_f32_32x32x2_f32:
+//     a4 = Wq[2g + (lane>>5)][n0 + (lane&31)]   b4 = Xq[2g + (lane>>5)][m0 + (lane&31)]      (g = group of 8 k)
+//     MFMA t (0..3) multiplies a4[t] x b4[t]: lane half h carries k = 8g + 4h + t on both operands.
+// (4-byte operand loads cost ~37 cycles of the CU's vector-memory pipeline per wave-instruction and capped the whole
+// chain at 4 TB/s; the 16-byte form moves 4x the bytes in ~25 cycles -- tools/experiments/ta_cost.hip.)
+// The MFMA result D[n][m] has 4 consecutive n per lane in registers 4i..4i+3 (row = 8i + 4(lane>>5) + (r&3)), i.e. it is
+// already a q4 element of the NEXT layer's B operand: the tile is stored as 16-byte elements, no shuffle.
+// The reference's column-major W (cuda_server.c:215) is re-packed once when weights are set.
+//
+// At batch 256 one FC layer is only 64-256 output tiles of 32x32; a classic LDS-tiled GEMM leaves most of the 1024
+// SIMDs idle and walks K serially (measured: 20 us per layer).  Here the 8 waves of a workgroup each own one slice of K
+// for the SAME 32x32 output tile and are summed through LDS in a fixed order (deterministic, no atomics).  A layer may
+// additionally be cut into `nsplit` workgroups along K that write partial tiles; the NEXT layer adds the partials
+// while loading its B operand (launch-boundary reduce).  Item columns m >= batch are padding: every output column
+// depends only on the same input column, so they never mix with real items.
+//
+// Why stage-pipelined launches: MI355X runs at most ~4 kernels of different streams concurrently and a dependent
+// launch costs 2-5 us, so five narrow launches per batch cap throughput.  One launch of fr_pipeline_kernel carries
+// ALL stages at once, each working on a different batch of the same worker:
+//     launch L:  gather(batch L) | FC1(batch L-1) | FC2(batch L-2) | FC3(batch L-3) | out(batch L-4)
+// Stage s reads what stage s-1 wrote in the PREVIOUS launch (activation buffers alternate by launch parity), so
+// in-order execution of a stream's launches is the only synchronisation.  This mirrors the reference's hot loop,
+// which enqueues batch after batch and never synchronises inside the loop (cuda_server.c:406-497).
 // ===================================================================================================
 
-// gather_t: per-table rows -> Xt[k][m].  Lanes = 64 consecutive items, one record word per wave step
-// (its descriptor is wave-uniform -> scalar loads); each lane reads its item's 16-byte row word and
-// writes 4 floats to 4 feature rows (256-byte coalesced stores).
-__global__ void __launch_bounds__(256) gather_t_kernel(const FrWordDesc *__restrict__ words, int n_words,
-                                                       const int32_t *__restrict__ idx, int idx_stride,
-                                                       const float *__restrict__ dense, float *__restrict__ Xt,
-                                                       int batch, int ldm, int words_per_wave, int *__restrict__ err_flag) {
+constexpr int FR_PIPE_THREADS = 512;  // 8 waves per workgroup in every stage
+constexpr int FR_PIPE_WAVES = 8;
+// FrStageArgs / FrPipeArgs: fr_internal.h
+
+// ---- stage 0: gather_q.  Lanes = 64 consecutive items; each wave walks WPW record words (wave-uniform descriptor ->
+// scalar loads); each lane reads its item's 16-byte row word and stores it as ONE q4 element Xq[word][m]
+// (1 KiB coalesced per wave-store).
+__device__ __forceinline__ void gather_q_body(const FrPipeArgs &a, const FrStageArgs &st, int local) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int m = blockIdx.x * 64 + lane;
-    const int w_begin = (blockIdx.y * 4 + wave) * words_per_wave;
-    const bool live = m < batch;
+    const int m_blocks = (st.ldm + 63) / 64;
+    const int mb = local % m_blocks, wb = local / m_blocks;  // padding workgroups land on w >= n_words below
+    const int m = mb * 64 + lane;
+    constexpr int WPW = 2;  // words per wave
+    const int w_begin = (wb * FR_PIPE_WAVES + wave) * WPW;
+    const bool live = m < st.batch;
+    uint4 *Xq = reinterpret_cast<uint4 *>(st.out);
     bool bad = false;
-    for (int i = 0; i < words_per_wave; i++) {
+#pragma unroll
+    for (int i = 0; i < WPW; i++) {
         const int w = w_begin + i;
-        if (w >= n_words) break;
-        const FrWordDesc d = words[w];  // wave-uniform
+        if (w >= a.n_words) break;
+        const FrWordDesc d = a.words[w];  // wave-uniform
         const bool is_dense = (d.idx_col & FR_DESC_DENSE) != 0;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (live) {
-            uint32_t id = is_dense ? (uint32_t)m : (uint32_t)idx[(size_t)m * idx_stride + d.idx_col];
-            if (!is_dense && id >= d.rows) {
+            uint32_t id = is_dense ? (uint32_t)m : (uint32_t)a.idx[(size_t)m * a.idx_stride + d.idx_col];
+            if (!is_dense && id >= d.rows) {  // reference: silent out-of-bounds read (embedding_47_krnl.cpp:927-933)
                 bad = true;
                 id = 0;
             }
-            const char *base = is_dense ? reinterpret_cast<const char *>(dense) + d.src : reinterpret_cast<const char *>(d.src);
+            const char *base = is_dense ? reinterpret_cast<const char *>(a.dense) + d.src : reinterpret_cast<const char *>(d.src);
             v = *reinterpret_cast<const uint4 *>(base + (uint64_t)id * d.stride);
         }
-        // feature index of this word inside the record (SEMANTIC layout only on this path)
-        float *o = Xt + (size_t)(4 * d.dst_off) * ldm + m;
-        if (m < ldm) {
-            o[0] = __uint_as_float(v.x);
-            o[(size_t)ldm] = __uint_as_float(v.y);
-            o[(size_t)2 * ldm] = __uint_as_float(v.z);
-            o[(size_t)3 * ldm] = __uint_as_float(v.w);
-        }
+        if (m < st.ldm) Xq[(size_t)d.dst_off * st.ldm + m] = v;  // SEMANTIC layout: dst_off = record word index = k/4
     }
-    if (bad) atomicOr_system(err_flag, 1);  // pinned host word; error path only
+    if (bad) atomicOr_system(a.err_flag, 1);  // pinned host word; error path only
 }
 
-int frk_gather_t(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, float *Xt,
-                 int batch, int ldm, int *err_flag, hipStream_t s) {
-    if (n_words <= 0 || batch <= 0) return FR_OK;
-    const int words_per_wave = 2;
-    dim3 grid((ldm + 63) / 64, (n_words + 4 * words_per_wave - 1) / (4 * words_per_wave));
-    gather_t_kernel<<<grid, dim3(256), 0, s>>>(words, n_words, idx, idx_stride, dense, Xt, batch, ldm, words_per_wave, err_flag);
-    KCHECK();
-    return FR_OK;
-}
+static int gather_q_blocks(int n_words, int ldm) { return ((ldm + 63) / 64) * ((n_words + FR_PIPE_WAVES * 2 - 1) / (FR_PIPE_WAVES * 2)); }
 
-// item-major records [B][K] -> Xt[K][ldm] (only used by the fc_only diagnostic entry point)
-__global__ void __launch_bounds__(256) transpose_records_kernel(const float *__restrict__ X, float *__restrict__ Xt, int batch, int K, int ldm) {
-    __shared__ float tile[32][33];
-    const int k0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    for (int r = ty; r < 32; r += 8) {
-        const int m = m0 + r, k = k0 + tx;
-        tile[r][tx] = (m < batch && k < K) ? X[(size_t)m * K + k] : 0.0f;
+// ---- stages 1..3: one 32(n) x 32(m) output tile per workgroup, 8 waves split the workgroup's K range in groups of
+// 8 k (one 16-byte load per operand per lane -> 4 MFMAs).
+template <bool TWO_IN>
+__device__ __forceinline__ float4 load_b4(const float4 *bq, const float4 *cq, size_t off) {
+    float4 b = bq[off];
+    if constexpr (TWO_IN) {  // launch-boundary reduce of the previous layer's two K halves
+        const float4 c = cq[off];
+        b.x += c.x;
+        b.y += c.y;
+        b.z += c.z;
+        b.w += c.w;
     }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int k = k0 + r, m = m0 + tx;
-        if (k < K && m < ldm) Xt[(size_t)k * ldm + m] = tile[tx][r];
-    }
+    return b;
 }
 
-int frk_transpose_records(const float *X, float *Xt, int batch, int K, int ldm, hipStream_t s) {
-    dim3 grid((K + 31) / 32, (ldm + 31) / 32);
-    transpose_records_kernel<<<grid, dim3(256), 0, s>>>(X, Xt, batch, K, ldm);
-    KCHECK();
-    return FR_OK;
+__device__ __forceinline__ void mfma4(f32x16 &acc, const float4 &a, const float4 &b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
 }
 
-// fc_t: Yt[N][ldm] = W * X with Wt[K][N], Xt[K][ldm]; one 32(n) x 32(m) tile per workgroup, SPLITK waves.
-//
-// NP > 0 : the wave's K slice is exactly NP k-pairs, known at compile time.  The body is straight-line: all
-//          2*NP operand loads are issued up front (row base in SGPRs + one per-lane VGPR offset), then NP MFMAs
-//          consume them behind counted vmcnt waits -- one L2 round trip per wave instead of one per k-group.
-// NP == 0: generic shapes; double-buffered groups of 8 k-pairs, branch-free inside the loop.
-template <int SPLITK, int NP>
-__global__ void __launch_bounds__(64 * SPLITK) fc_t_kernel(const float *__restrict__ Wt, const float *__restrict__ Xt,
-                                                           float *__restrict__ Yt, int K, int N, int ldm) {
-    __shared__ float red[SPLITK > 1 ? SPLITK : 1][16][64];
+template <bool TWO_IN>
+__device__ __forceinline__ void fc_q_body(const FrStageArgs &st, int local, float *red /* [8][16][64] */) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int N = st.N, ldm = st.ldm;
+    const int tiles_n = N / 32, tiles_m = ldm / 32, tiles = tiles_n * tiles_m;
+    // Workgroup -> (K part, n tile, m tile).  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the
+    // XCD group; a speed assumption only, never correctness) and every stage starts at a multiple of 8, so `local % 8`
+    // is the group.  Each group gets a fixed 1/NG of the weight columns and 1/MG of the items, so its slice of the
+    // weights can stay in that XCD's 4 MiB L2 across launches.
+    int part, n_tile, m_tile;
+    const int MG = (tiles_m % 2 == 0) ? 2 : 1, NG = 8 / MG;
+    if (tiles_n % NG == 0) {
+        const int x = local & 7, j = local >> 3;
+        const int mg = x % MG, ng = x / MG;
+        const int tn_x = tiles_n / NG, tm_x = tiles_m / MG;
+        part = j / (tn_x * tm_x);
+        const int r = j - part * (tn_x * tm_x);
+        n_tile = (r % tn_x) * NG + ng;
+        m_tile = (r / tn_x) * MG + mg;
+    } else {
+        part = local / tiles;
+        const int tile = local - part * tiles;
+        n_tile = tile % tiles_n;
+        m_tile = tile / tiles_n;
+    }
+    if (part >= st.nsplit) return;  // padding workgroup (stage sizes are rounded up to a multiple of 8)
+    const int n0 = n_tile * 32, m0 = m_tile * 32;
     const int hk = lane >> 5, lm = lane & 31;
-    const int a_off = hk * N + n0 + lm;    // per-lane, loop-invariant
-    const int b_off = hk * ldm + m0 + lm;
+    // this workgroup's K range in groups of 8 k, then this wave's slice of it
+    const int groups = st.K / 8;
+    const int wg_groups = (groups + st.nsplit - 1) / st.nsplit;
+    const int wg_begin = part * wg_groups;
+    int wg_ng = groups - wg_begin;
+    wg_ng = wg_ng < 0 ? 0 : (wg_ng > wg_groups ? wg_groups : wg_ng);
+    const int per = (wg_ng + FR_PIPE_WAVES - 1) / FR_PIPE_WAVES;
+    const int g_begin = wg_begin + wave * per;
+    int ng = wg_begin + wg_ng - g_begin;
+    ng = ng < 0 ? 0 : (ng > per ? per : ng);
+
+    // q4 element index of (k-quad 2g + hk, column): quad * ld + column
+    const float4 *aq = reinterpret_cast<const float4 *>(st.w) + (size_t)hk * N + n0 + lm;
+    const float4 *bq = reinterpret_cast<const float4 *>(st.in) + (size_t)hk * ldm + m0 + lm;
+    const float4 *cq = reinterpret_cast<const float4 *>(st.in + st.in_part_stride) + (size_t)hk * ldm + m0 + lm;
 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
 
-    if constexpr (NP > 0) {
-        const float *a_row = Wt + (size_t)(2 * NP * wave) * N;   // wave-uniform
-        const float *b_row = Xt + (size_t)(2 * NP * wave) * ldm;
-        float ra[NP], rb[NP];
+    // Double-buffered loop over blocks of D groups: the next block's 2*D 16-byte loads are in flight while the current
+    // block's 4*D MFMAs issue.  D = 2 keeps the kernel at 68 VGPRs (4 workgroups per CU): these workgroups are bound by
+    // the CU's L2 ingest, not by issue slots, and measured faster than straight-line bodies that hold a whole K slice
+    // in registers (110-165 VGPRs, 1-2 workgroups per CU).
+    constexpr int D = 2;
+    float4 ra[D], rb[D], na[D], nb[D];
+    const int nb_full = ng / D;
+    if (nb_full > 0) {
 #pragma unroll
-        for (int i = 0; i < NP; i++) {
-            ra[i] = a_row[(size_t)(2 * i) * N + a_off];
-            rb[i] = b_row[(size_t)(2 * i) * ldm + b_off];
+        for (int i = 0; i < D; i++) {
+            ra[i] = aq[(size_t)(2 * (g_begin + i)) * N];
+            rb[i] = load_b4<TWO_IN>(bq, cq, (size_t)(2 * (g_begin + i)) * ldm);
         }
-        // keep the scheduler from sinking the loads back next to their MFMAs (it would, to save VGPRs)
+    }
+    for (int blk = 0; blk < nb_full; blk++) {
+        const int nx = (blk + 1 < nb_full) ? (blk + 1) : blk;  // the last block re-loads itself (harmless) -> branch-free body
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            na[i] = aq[(size_t)(2 * (g_begin + nx * D + i)) * N];
+            nb[i] = load_b4<TWO_IN>(bq, cq, (size_t)(2 * (g_begin + nx * D + i)) * ldm);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from sinking the loads next to their consumers
+#pragma unroll
+        for (int i = 0; i < D; i++) mfma4(acc, ra[i], rb[i]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < NP; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i], rb[i], acc, 0, 0, 0);
-    } else {
-        const int pairs = K / 2;
-        const int per = (pairs + SPLITK - 1) / SPLITK;
-        const int p_begin = wave * per;
-        int np = pairs - p_begin;
-        np = np < 0 ? 0 : (np > per ? per : np);
-        const float *a_row = Wt + (size_t)(2 * p_begin) * N;
-        const float *b_row = Xt + (size_t)(2 * p_begin) * ldm;
-        constexpr int D = 8;
-        const int ng = np / D;
-        float ra[D], rb[D], na[D], nb[D];
-        if (ng > 0) {
-#pragma unroll
-            for (int i = 0; i < D; i++) {
-                ra[i] = a_row[(size_t)(2 * i) * N + a_off];
-                rb[i] = b_row[(size_t)(2 * i) * ldm + b_off];
-            }
-        }
-        for (int g = 0; g < ng; g++) {
-            const int nx = (g + 1 < ng) ? (g + 1) : g;  // the last group re-loads itself (harmless) -> no branch in the body
-#pragma unroll
-            for (int i = 0; i < D; i++) {
-                na[i] = a_row[(size_t)(2 * (nx * D + i)) * N + a_off];
-                nb[i] = b_row[(size_t)(2 * (nx * D + i)) * ldm + b_off];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < D; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i], rb[i], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < D; i++) {
-                ra[i] = na[i];
-                rb[i] = nb[i];
-            }
-        }
-        for (int p = ng * D; p < np; p++) {  // remainder (< D pairs)
-            const float a = a_row[(size_t)(2 * p) * N + a_off];
-            const float b = b_row[(size_t)(2 * p) * ldm + b_off];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int i = 0; i < D; i++) {
+            ra[i] = na[i];
+            rb[i] = nb[i];
         }
     }
-    if constexpr (SPLITK == 1) {
+    for (int g = g_begin + nb_full * D; g < g_begin + ng; g++)  // remainder (< D groups)
+        mfma4(acc, aq[(size_t)(2 * g) * N], load_b4<TWO_IN>(bq, cq, (size_t)(2 * g) * ldm));
+    // cross-wave reduction in fixed order, then the tile goes out as q4 elements (registers 4i..4i+3 = 4 consecutive n)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * hk;
-            Yt[(size_t)n * ldm + m0 + lm] = acc[r];
+    for (int r = 0; r < 16; r++) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    float4 *Yq = reinterpret_cast<float4 *>(st.out + (size_t)part * st.part_stride);
+    if (threadIdx.x < 4 * 64) {
+        const int i = threadIdx.x >> 6, l = threadIdx.x & 63;  // accumulator register quad i, lane l
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float s = red[(4 * i + c) * 64 + l];
+#pragma unroll
+            for (int w = 1; w < FR_PIPE_WAVES; w++) s += red[(w * 16 + 4 * i + c) * 64 + l];
+            v[c] = s;
         }
+        const int nq = (n0 >> 2) + 2 * i + (l >> 5);  // n = n0 + 8i + 4(l>>5) + c
+        Yq[(size_t)nq * ldm + m0 + (l & 31)] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+static int fc_q_blocks(int N, int ldm, int nsplit) { return (N / 32) * (ldm / 32) * nsplit; }
+static int pad8(int v) { return (v + 7) / 8 * 8; }
+
+// ---- stage 4: score[m] = sum_n w[n] * (R3q[n/4][m][n%4] (+ second partial)); 64 items x 8 slices of n, one 16-byte
+// load per 4 n, LDS reduce in fixed order.
+__device__ __forceinline__ void fc_out_q_body(const FrStageArgs &st, int local, float *red) {
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = local * 64 + lane;  // padding workgroups have m >= ldm
+    const int HQ = st.K / 4, ldm = st.ldm;
+    const int per = (HQ + FR_PIPE_WAVES - 1) / FR_PIPE_WAVES;
+    const int h0 = q * per;
+    const int h1 = (h0 + per) < HQ ? (h0 + per) : HQ;
+    const float4 *Rq = reinterpret_cast<const float4 *>(st.in);
+    const float4 *Cq = reinterpret_cast<const float4 *>(st.in + st.in_part_stride);
+    const float4 *wq = reinterpret_cast<const float4 *>(st.w);
+    float s = 0.0f;
+    if (m < ldm) {
+        for (int h = h0; h < h1; h += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int hh = (h + i < h1) ? (h + i) : (h1 - 1);
+                v[i] = Rq[(size_t)hh * ldm + m];
+                if (st.nparts_in == 2) {
+                    const float4 c = Cq[(size_t)hh * ldm + m];
+                    v[i].x += c.x;
+                    v[i].y += c.y;
+                    v[i].z += c.z;
+                    v[i].w += c.w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (h + i < h1) {
+                    const float4 w4 = wq[h + i];
+                    s = fmaf(w4.x, v[i].x, s);
+                    s = fmaf(w4.y, v[i].y, s);
+                    s = fmaf(w4.z, v[i].z, s);
+                    s = fmaf(w4.w, v[i].w, s);
+                }
+            }
+        }
+    }
+    red[q * 64 + lane] = s;
+    __syncthreads();
+    if (q == 0 && m < st.batch) {
+        float t = red[lane];
+#pragma unroll
+        for (int i = 1; i < FR_PIPE_WAVES; i++) t += red[i * 64 + lane];
+        st.out[m] = t;
+    }
+}
+
+// STAGE = -1: all stages of one pipelined launch; STAGE = 0..4: that stage alone (separately named kernels so
+// that rocprof attributes time per stage when a batch is run unpipelined).
+template <int STAGE>
+__global__ void __launch_bounds__(FR_PIPE_THREADS) fr_pipeline_kernel(const FrPipeArgs a) {
+    __shared__ float red[FR_PIPE_WAVES * 16 * 64];  // 32 KiB
+    const int b = blockIdx.x;
+    int s = 0;
+    if constexpr (STAGE >= 0) {
+        s = STAGE;
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; r++) red[wave][r][lane] = acc[r];
+        for (int i = 1; i < FR_N_STAGES; i++) s += (b >= a.st[i].block_begin) ? 1 : 0;
+    }
+    const FrStageArgs &st = a.st[s];
+    const int local = b - st.block_begin;
+    unsigned long long t_in = 0;
+    if (a.stamps) t_in = __builtin_amdgcn_s_memrealtime();  // diagnostics only; the values never feed an output
+    if (s == 0) {
+        gather_q_body(a, st, local);
+    } else if (s == 4) {
+        fc_out_q_body(st, local, red);
+    } else if (st.nparts_in == 2) {
+        fc_q_body<true>(st, local, red);
+    } else {
+        fc_q_body<false>(st, local, red);
+    }
+    if (a.stamps) {
         __syncthreads();
-        // fixed-order sum over the K slices, then the coalesced store of the tile
-        for (int e = threadIdx.x; e < 16 * 64; e += 64 * SPLITK) {
-            const int r = e >> 6, l = e & 63;
-            float s = red[0][r][l];
-#pragma unroll
-            for (int w = 1; w < SPLITK; w++) s += red[w][r][l];
-            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-            Yt[(size_t)n * ldm + m0 + (l & 31)] = s;
+        if (threadIdx.x == 0) {
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hwid));
+            unsigned long long *o = a.stamps + 4ull * b;
+            o[0] = t_in;
+            o[1] = __builtin_amdgcn_s_memrealtime();
+            o[2] = (unsigned long long)s;
+            o[3] = hwid;
         }
     }
 }
 
-template <int SPLITK, int NP>
-static void fc_t_launch(dim3 grid, const float *Wt, const float *Xt, float *Yt, int K, int N, int ldm, hipStream_t s) {
-    fc_t_kernel<SPLITK, NP><<<grid, dim3(64 * SPLITK), 0, s>>>(Wt, Xt, Yt, K, N, ldm);
-}
-
-int frk_fc_t(const float *Wt, const float *Xt, float *Yt, int K, int N, int ldm, int splitk, hipStream_t s) {
-    if (K % 4 || N % 32 || ldm % 32) FR_FAIL(FR_ERR_INVALID, "fc_t needs K%%4==0, N%%32==0, ldm%%32==0 (K=%d N=%d ldm=%d)", K, N, ldm);
-    dim3 grid(N / 32, ldm / 32);
-    const int pairs = K / 2;
-    const int np = (pairs % splitk == 0) ? pairs / splitk : -1;
-    // straight-line instantiations for the reference models' small-batch shapes
-    if (splitk == 4 && np == 44) fc_t_launch<4, 44>(grid, Wt, Xt, Yt, K, N, ldm, s);        // A FC1: K=352
-    else if (splitk == 8 && np == 55) fc_t_launch<8, 55>(grid, Wt, Xt, Yt, K, N, ldm, s);   // B FC1: K=880
-    else if (splitk == 8 && np == 64) fc_t_launch<8, 64>(grid, Wt, Xt, Yt, K, N, ldm, s);   // FC2: K=1024
-    else if (splitk == 16 && np == 64) fc_t_launch<16, 64>(grid, Wt, Xt, Yt, K, N, ldm, s); // C FC2: K=2048
-    else if (splitk == 8 && np == 32) fc_t_launch<8, 32>(grid, Wt, Xt, Yt, K, N, ldm, s);   // FC3: K=512
-    else if (splitk == 16 && np == 16) fc_t_launch<16, 16>(grid, Wt, Xt, Yt, K, N, ldm, s); // FC3: K=512
-    else if (splitk == 4 && np == 64) fc_t_launch<4, 64>(grid, Wt, Xt, Yt, K, N, ldm, s);
-    else if (splitk == 2 && np == 64) fc_t_launch<2, 64>(grid, Wt, Xt, Yt, K, N, ldm, s);
-    else {
-        switch (splitk) {
-            case 1: fc_t_launch<1, 0>(grid, Wt, Xt, Yt, K, N, ldm, s); break;
-            case 2: fc_t_launch<2, 0>(grid, Wt, Xt, Yt, K, N, ldm, s); break;
-            case 4: fc_t_launch<4, 0>(grid, Wt, Xt, Yt, K, N, ldm, s); break;
-            case 8: fc_t_launch<8, 0>(grid, Wt, Xt, Yt, K, N, ldm, s); break;
-            case 16: fc_t_launch<16, 0>(grid, Wt, Xt, Yt, K, N, ldm, s); break;
-            default: FR_FAIL(FR_ERR_INVALID, "fc_t: unsupported splitk %d", splitk);
-        }
+// Launch one pipeline step.  `single_stage` >= 0 launches only that stage (its block_begin must be 0).
+int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, hipStream_t s) {
+    if (a.n_blocks <= 0) return FR_OK;
+    dim3 grid(a.n_blocks), block(FR_PIPE_THREADS);
+    switch (single_stage) {
+        case -1: fr_pipeline_kernel<-1><<<grid, block, 0, s>>>(a); break;
+        case 0: fr_pipeline_kernel<0><<<grid, block, 0, s>>>(a); break;
+        case 1: fr_pipeline_kernel<1><<<grid, block, 0, s>>>(a); break;
+        case 2: fr_pipeline_kernel<2><<<grid, block, 0, s>>>(a); break;
+        case 3: fr_pipeline_kernel<3><<<grid, block, 0, s>>>(a); break;
+        case 4: fr_pipeline_kernel<4><<<grid, block, 0, s>>>(a); break;
+        default: FR_FAIL(FR_ERR_INVALID, "bad stage %d", single_stage);
     }
     KCHECK();
     return FR_OK;
 }
 
-// fc_out_t: score[m] = sum_n w[n] * Rt[n][m]; block = 64 items x 16 slices of n (all loads of a slice in flight),
-// LDS reduce in fixed order.
-__global__ void __launch_bounds__(1024) fc_out_t_kernel(const float *__restrict__ Rt, const float *__restrict__ w,
-                                                        float *__restrict__ score, int batch, int H, int ldm) {
-    __shared__ float part[16][64];
-    const int lane = threadIdx.x & 63;
-    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int m = blockIdx.x * 64 + lane;
-    const int per = (H + 15) / 16;
-    const int h0 = q * per;
-    float s = 0.0f;
-    if (m < ldm) {
-        int h = h0;
-        for (; h + 8 <= h0 + per && h + 8 <= H; h += 8) {
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = Rt[(size_t)(h + i) * ldm + m];
-#pragma unroll
-            for (int i = 0; i < 8; i++) s = fmaf(w[h + i], v[i], s);
-        }
-        for (; h < h0 + per && h < H; h++) s = fmaf(w[h], Rt[(size_t)h * ldm + m], s);
-    }
-    part[q][lane] = s;
-    __syncthreads();
-    if (q == 0 && m < batch) {
-        float t = part[0][lane];
-#pragma unroll
-        for (int i = 1; i < 16; i++) t += part[i][lane];
-        score[m] = t;
+int frk_stage_blocks(int stage, int n_words, int K, int N, int ldm, int nsplit) {
+    // every stage is padded to a multiple of 8 workgroups so that the next one starts on XCD group 0
+    if (stage == 0) return pad8(gather_q_blocks(n_words, ldm));
+    if (stage == 4) return pad8((ldm + 63) / 64);
+    return pad8(fc_q_blocks(N, ldm, nsplit));
+}
+
+// Reference weight layout (column-major H x K, W[h + k*H], cuda_server.c:215) -> Wq[k/4][h][k%4]
+__global__ void __launch_bounds__(256) pack_weights_q4_kernel(const float *__restrict__ W, float4 *__restrict__ Wq, int K, int H) {
+    const size_t n = (size_t)(K / 4) * H;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t kq = e / H, h = e - kq * H;
+        Wq[e] = make_float4(W[h + (4 * kq + 0) * H], W[h + (4 * kq + 1) * H], W[h + (4 * kq + 2) * H], W[h + (4 * kq + 3) * H]);
     }
 }
 
-int frk_fc_out_t(const float *Rt, const float *w, float *score, int batch, int H, int ldm, hipStream_t s) {
-    fc_out_t_kernel<<<dim3((ldm + 63) / 64), dim3(1024), 0, s>>>(Rt, w, score, batch, H, ldm);
+int frk_pack_weights_q4(const float *W, float *Wq, int K, int H, hipStream_t s) {
+    if (K % 4) FR_FAIL(FR_ERR_INVALID, "pack_weights_q4 needs K %% 4 == 0 (K=%d)", K);
+    size_t n = (size_t)(K / 4) * H;
+    unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    pack_weights_q4_kernel<<<dim3(blocks), dim3(256), 0, s>>>(W, reinterpret_cast<float4 *>(Wq), K, H);
+    KCHECK();
+    return FR_OK;
+}
+
+// item-major records [B][K] -> Xq[K/4][ldm][4]: a transpose of 16-byte elements (only used by the fc_only diagnostic
+// entry point and the BLOCKED layout)
+__global__ void __launch_bounds__(256) transpose_records_kernel(const float4 *__restrict__ X, float4 *__restrict__ Xq, int batch, int KQ, int ldm) {
+    __shared__ float4 tile[16][17];
+    const int q0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16
+    {
+        const int m = m0 + ty, q = q0 + tx;
+        tile[ty][tx] = (m < batch && q < KQ) ? X[(size_t)m * KQ + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    {
+        const int q = q0 + ty, m = m0 + tx;
+        if (q < KQ && m < ldm) Xq[(size_t)q * ldm + m] = tile[tx][ty];
+    }
+}
+
+int frk_transpose_records(const float *X, float *Xq, int batch, int K, int ldm, hipStream_t s) {
+    dim3 grid((K / 4 + 15) / 16, (ldm + 15) / 16);
+    transpose_records_kernel<<<grid, dim3(256), 0, s>>>(reinterpret_cast<const float4 *>(X), reinterpret_cast<float4 *>(Xq), batch, K / 4, ldm);
     KCHECK();
     return FR_OK;
 }

@@ -29,6 +29,10 @@ int fr_model_validate(const fr_model_desc *m) {
     if (m->fc[0] != m->record_len) FR_FAIL(FR_ERR_INVALID, "fc[0]=%d must equal record_len=%d", m->fc[0], m->record_len);
     for (int i = 1; i < 5; i++)
         if (m->fc[i] <= 0) FR_FAIL(FR_ERR_INVALID, "fc[%d]=%d must be positive", i, m->fc[i]);
+    for (int i = 0; i < 4; i++)
+        if (m->fc[i] % 8) FR_FAIL(FR_ERR_INVALID, "fc[%d]=%d must be a multiple of 8 (operands move in groups of 8 k)", i, m->fc[i]);
+    for (int i = 1; i < 4; i++)
+        if (m->fc[i] % 32) FR_FAIL(FR_ERR_INVALID, "fc[%d]=%d must be a multiple of 32 (32x32 MFMA output tiles)", i, m->fc[i]);
     if (m->fc[4] != 1) FR_FAIL(FR_ERR_INVALID, "only OUTPUT_FEATURE_LEN == 1 is supported (got %d)", m->fc[4]);
     if (m->layout != FR_LAYOUT_SEMANTIC && m->layout != FR_LAYOUT_BLOCKED) FR_FAIL(FR_ERR_INVALID, "bad layout %d", m->layout);
     if (m->index_mode != FR_INDEX_PER_TABLE && m->index_mode != FR_INDEX_PER_ITEM) FR_FAIL(FR_ERR_INVALID, "bad index_mode %d", m->index_mode);

@@ -208,7 +208,14 @@ int fr_worker_submit(fr_worker *w, int batch);
  * d_scores float [batch]. */
 int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense,
                             float *d_scores);
-/* Waits for the in-flight batch; returns FR_ERR_INDEX_RANGE if any index was out of range. */
+/* Streaming form of the hot loop: enqueue batch after batch WITHOUT synchronising, as the reference's loop does
+ * (cuda_server.c:406-497).  Each call issues one launch in which this batch is gathered while the previous four
+ * batches of this worker advance through FC1, FC2, FC3 and the output layer (stage pipeline across batches).
+ * d_scores of a pushed batch are complete once four more pushes have executed, or after fr_worker_sync(), which
+ * drains the pipeline.  The caller keeps d_idx / d_dense / d_scores valid and distinct for every batch still in
+ * the pipeline (up to 5).  Needs an unsharded, SEMANTIC-layout, fp32 context. */
+int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores);
+/* Drains and waits for everything enqueued on the worker; returns FR_ERR_INDEX_RANGE if any index was out of range. */
 int fr_worker_sync(fr_worker *w);
 
 /* Diagnostic / roofline entry points (same kernels as submit, run alone).
@@ -223,9 +230,9 @@ int fr_worker_fc_only(fr_worker *w, int batch, const float *d_records, float *d_
 int fr_worker_fc_layer_only(fr_worker *w, int batch, int layer);
 /* Device pointer of the worker's own record buffer ([max_batch][record_len] floats). */
 float *fr_worker_records_dptr(fr_worker *w);
-/* Debug/parity hook: device pointer of the worker's FEATURE-major activation buffer used by submit():
- * Xt[k][m] at xt[k*ld + m] (k < record_len, m < batch, ld = round_up(batch,32) of the LAST submit; the
- * allocation's row capacity is returned in *ld_max).  Lets tests check the fused gather bit-exactly. */
+/* Debug/parity hook: device pointer of the worker's feature-major activation buffer written by the gather stage
+ * of the LAST submitted/pushed batch, in the chain's q4 layout: feature k of item m at
+ * xq[((k/4)*ld + m)*4 + k%4] with ld = round_up(batch, 32).  Lets tests check the pipeline's own gather bit-exactly. */
 float *fr_worker_features_dptr(fr_worker *w, int *ld_max);
 
 /* HIP-event timing on the worker's stream (the stream the kernels are launched on). */
