@@ -42,6 +42,63 @@ def fc_flops_per_inference(fc):
     return 2 * sum(fc[i] * fc[i + 1] for i in range(4))
 
 
+def main_sharded(args):
+    """BASELINE configs[3]: Model-C, batch 4096, tables sharded by table-ID over the ranks; per step every rank gathers its
+    [B x F] slice, ONE RCCL all-gather over xGMI rebuilds the records on every GPU, rank r runs the FC chain on its B/G items.
+    value = B x steps / max-over-ranks time (one batch per step for the whole job: "scaling": "strong")."""
+    import importlib
+    import torch
+    fr = graft.load_package()
+    dist_mod = importlib.import_module("fleetrec_amd.dist")
+    env = dist_mod.DistEnv("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    G, r = env.world, env.rank
+    B = 4096 if args.batch == 256 else args.batch
+    model = fr.Model.builtin(fr.MODEL_C)
+    ctx = fr.Context(model, device=env.local_rank, shard_rank=r, n_shards=G)
+    ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    offs, lens, F = model.shard_plan(G)
+    dev = torch.device("cuda", env.local_rank)
+    rng = np.random.default_rng(SEED_IDX)             # same request stream on every rank (replicated request)
+    rows = model.rows()
+    nbuf = 8
+    idxs = [fr.DeviceBuffer.from_numpy(ctx, (rng.random((B, model.n_tables)) * rows[None, :]).astype(np.int32)) for _ in range(nbuf)]
+    dns = [fr.DeviceBuffer.from_numpy(ctx, rng.uniform(-1, 1, (B, model.dense_len)).astype(np.float32)) for _ in range(nbuf)]
+    wk = fr.Worker(ctx, B)
+    local = torch.empty((B, F), dtype=torch.float32, device=dev)          # torch owns the exchange buffers (RCCL plumbing)
+    gathered = torch.empty((G, B, F), dtype=torch.float32, device=dev)
+    lo, hi = dist_mod.item_range(r, G, B)
+    scores = torch.empty((max(hi - lo, 1),), dtype=torch.float32, device=dev)
+
+    def step(i):
+        wk.gather_only(B, idxs[i % nbuf], dns[i % nbuf], local.data_ptr())
+        wk.sync()                                      # the slice must be complete before RCCL reads it (different stream)
+        env.all_gather_slices(local, gathered)
+        torch.cuda.synchronize()
+        wk.fc_from_slices(B, lo, hi - lo, gathered.data_ptr(), scores.data_ptr())
+        wk.sync()
+
+    for i in range(args.warmup):
+        step(i)
+    env.barrier(); torch.cuda.synchronize(); ctx.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    env.barrier(); torch.cuda.synchronize(); ctx.synchronize()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    if r == 0:
+        print(json.dumps({
+            "metric": "inferences/sec, Model-C batch 4096, tables sharded by table-ID", "value": B * args.steps / dt, "unit": "inferences/s",
+            "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Model-C batch=%d, %d-way table-ID shards (slice F=%d floats), 1 all-gather of [B x F] per step, "
+                                   "FC on B/G items per rank" % (B, G, F), "parallelism": "table-sharded x%d" % G,
+                       "allgather_bytes_per_rank_per_step": int(G * B * F * 4)}}))
+    wk.close()
+    ctx.close()
+    env.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,10 +108,15 @@ def main():
     ap.add_argument("--threads", type=int, default=4, help="host driver threads (reference THREAD_NUM = 4, constant.h:42)")
     ap.add_argument("--depth", type=int, default=2, help="workers (streams) each driver thread keeps in flight")
     ap.add_argument("--sweep", action="store_true", help="also print a threads x depth sweep to stderr (experiments)")
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
+                    help="replicas: BASELINE configs[1] (default, the headline metric); sharded: Model-C batch 4096 with tables "
+                         "sharded by table-ID over the ranks + one RCCL all-gather of the looked-up slices (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-model-c", action="store_true", help="skip the Model-C batch-4096 gather roofline leg")
     args = ap.parse_args()
 
+    if args.mode == "sharded":
+        return main_sharded(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

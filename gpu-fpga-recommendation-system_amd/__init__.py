@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
     "fr_device_synchronize", "fr_ctx_shard_info", "fr_driver_create", "fr_driver_destroy", "fr_driver_run_resident",
-    "fr_driver_worker",
+    "fr_driver_worker", "fr_model_shard_plan", "fr_worker_fc_from_slices",
 ]
 
 
@@ -105,6 +105,8 @@ def lib():
         "fr_driver_create": (i32, [vp, i32, i32, i32, ctypes.POINTER(vp)]), "fr_driver_destroy": (None, [vp]),
         "fr_driver_run_resident": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
         "fr_driver_worker": (vp, [vp, i32, i32]),
+        "fr_model_shard_plan": (i32, [ctypes.POINTER(ModelDesc), i32, pi, pi, ctypes.POINTER(ctypes.c_int)]),
+        "fr_worker_fc_from_slices": (i32, [vp, i32, i32, i32, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -191,6 +193,14 @@ class Model:
 
     def table_bytes(self):
         return lib().fr_model_table_bytes(self._ptr)
+
+    def shard_plan(self, n_shards):
+        """-> (slice_offsets, slice_lens, padded_len): the table-ID sharding of the record over n_shards GPUs (host only)."""
+        off = (ctypes.c_int32 * n_shards)()
+        ln = (ctypes.c_int32 * n_shards)()
+        pad = ctypes.c_int()
+        _check(lib().fr_model_shard_plan(self._ptr, n_shards, off, ln, ctypes.byref(pad)))
+        return list(off), list(ln), pad.value
 
 
 class DeviceBuffer:
@@ -357,6 +367,9 @@ class Worker:
 
     def fc_layer_only(self, batch, layer):
         _check(lib().fr_worker_fc_layer_only(self._h, batch, layer))
+
+    def fc_from_slices(self, batch_total, item0, n_items, d_gathered, d_scores):
+        _check(lib().fr_worker_fc_from_slices(self._h, batch_total, item0, n_items, self._ptr(d_gathered), self._ptr(d_scores)))
 
     def records_dptr(self):
         return lib().fr_worker_records_dptr(self._h)

@@ -65,7 +65,7 @@ static void ctx_free(fr_ctx *c) {
 
 // Contiguous, float-balanced split of the record's segments over n_shards (SURVEY section 8(e):
 // "partition tables by table-ID ... balancing floats-per-item ... slices are whole segments").
-static void shard_bounds(const fr_model_desc &m, int n_shards, std::vector<int> &seg_begin) {
+void fr_shard_bounds(const fr_model_desc &m, int n_shards, std::vector<int> &seg_begin) {
     seg_begin.assign(n_shards + 1, m.n_segments);
     seg_begin[0] = 0;
     int s = 0;
@@ -85,13 +85,17 @@ static int build_words(fr_ctx *c) {
     std::vector<int> seg_begin;
     int s0 = 0, s1 = m.n_segments;
     if (c->n_shards > 1) {
-        shard_bounds(m, c->n_shards, seg_begin);
+        fr_shard_bounds(m, c->n_shards, seg_begin);
         s0 = seg_begin[c->shard_rank];
         s1 = seg_begin[c->shard_rank + 1];
         int maxlen = 0;
+        c->shard_offset.assign(c->n_shards, 0);
+        c->shard_len.assign(c->n_shards, 0);
         for (int g = 0; g < c->n_shards; g++) {
             int b = seg_begin[g], e = seg_begin[g + 1];
             int len = (e > b) ? (m.segments[e - 1].rec_offset + m.segments[e - 1].len - m.segments[b].rec_offset) : 0;
+            c->shard_offset[g] = (e > b) ? m.segments[b].rec_offset : 0;
+            c->shard_len[g] = len;
             if (len > maxlen) maxlen = len;
         }
         c->slice_offset = m.segments[s0].rec_offset;
@@ -101,6 +105,8 @@ static int build_words(fr_ctx *c) {
         c->slice_offset = 0;
         c->slice_len = m.record_len;
         c->slice_padded = m.record_len;
+        c->shard_offset.assign(1, 0);
+        c->shard_len.assign(1, m.record_len);
     }
     // which tables are resident on this shard: those referenced by its segments
     for (auto &tm : c->table_mem) tm.resident = false;
@@ -206,6 +212,27 @@ extern "C" int fr_ctx_create_sharded(const fr_model_desc *m, int device, int sha
         }
     }
     *out = c;
+    return FR_OK;
+}
+
+// Pure host query: the shard plan fr_ctx_create_sharded would use (no device needed).
+extern "C" int fr_model_shard_plan(const fr_model_desc *m, int n_shards, int *slice_offset, int *slice_len, int *slice_padded_len) {
+    int rc = fr_model_validate(m);
+    if (rc) return rc;
+    if (n_shards < 1 || n_shards > m->n_segments) FR_FAIL(FR_ERR_INVALID, "n_shards %d outside [1, %d segments]", n_shards, m->n_segments);
+    std::vector<int> sb;
+    if (n_shards > 1) fr_shard_bounds(*m, n_shards, sb);
+    else sb = {0, m->n_segments};
+    int maxlen = 0;
+    for (int g = 0; g < n_shards; g++) {
+        const int b = sb[g], e = sb[g + 1];
+        const int off = m->segments[b].rec_offset;
+        const int len = m->segments[e - 1].rec_offset + m->segments[e - 1].len - off;
+        if (slice_offset) slice_offset[g] = off;
+        if (slice_len) slice_len[g] = len;
+        if (len > maxlen) maxlen = len;
+    }
+    if (slice_padded_len) *slice_padded_len = maxlen;
     return FR_OK;
 }
 
@@ -584,6 +611,31 @@ static int launch_fc(fr_worker *w, int batch, const float *d_records, float *d_s
     rc = pipeline_push(w, batch, 1, nullptr, nullptr, d_scores);
     if (rc) return rc;
     return pipeline_flush(w);
+}
+
+// Sharded mode, after the all-gather: d_gathered = [n_shards][batch_total][slice_padded] floats (every shard's padded slice,
+// item-major).  Runs the FC chain for items [item0, item0 + n_items) of the batch; d_scores receives n_items floats.
+extern "C" int fr_worker_fc_from_slices(fr_worker *w, int batch_total, int item0, int n_items, const float *d_gathered, float *d_scores) {
+    int rc = check_ready(w, n_items, false, true);
+    if (rc) return rc;
+    fr_ctx *c = w->ctx;
+    if (!d_gathered || !d_scores) FR_FAIL(FR_ERR_INVALID, "NULL device pointer");
+    if (batch_total < 1 || item0 < 0 || item0 + n_items > batch_total) FR_FAIL(FR_ERR_INVALID, "items [%d,+%d) outside batch %d", item0, n_items, batch_total);
+    if (c->fc_precision != FR_FC_FP32) FR_FAIL(FR_ERR_STATE, "bf16 FC path not built yet");
+    if (w->n_active) FR_FAIL(FR_ERR_STATE, "pipeline busy: call fr_worker_sync first");
+    FR_HIP(hipSetDevice(c->device));
+    if (w->launch_no == 0) w->launch_no = 1;
+    const int ldm = round_up(n_items, 32);
+    const int par_prev = (int)((w->launch_no - 1) & 1);
+    rc = frk_transpose_slices(d_gathered, c->n_shards, batch_total, c->slice_padded, c->shard_offset.data(), c->shard_len.data(), item0,
+                              n_items, act_set(w, par_prev).x, ldm, w->stream);
+    if (rc) return rc;
+    rc = pipeline_push(w, n_items, 1, nullptr, nullptr, d_scores);
+    if (rc) return rc;
+    rc = pipeline_flush(w);
+    if (rc) return rc;
+    w->in_flight = true;
+    return FR_OK;
 }
 
 // whole hot path for ONE batch, unpipelined: index rows -> scores (five dependent launches)

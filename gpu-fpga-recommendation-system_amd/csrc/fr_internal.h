@@ -104,6 +104,7 @@ struct fr_ctx {
     // sharding
     int shard_rank = 0, n_shards = 1;
     int slice_offset = 0, slice_len = 0, slice_padded = 0;
+    std::vector<int> shard_offset, shard_len;  // record range of EVERY shard (floats), for the all-gathered layout
     hipStream_t setup_stream = nullptr;
 };
 
@@ -161,3 +162,6 @@ int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, hipStream_t s);
 int frk_pack_weights_q4(const float *W, float *Wq, int K, int H, hipStream_t s);
 int frk_stage_blocks(int stage, int n_words, int K, int N, int ldm, int nsplit);
 int frk_transpose_records(const float *X, float *Xt, int batch, int K, int ldm, hipStream_t s);
+int frk_transpose_slices(const float *gathered, int n_shards, int batch_total, int slice_padded, const int *h_offsets, const int *h_lens,
+                         int item0, int n_items, float *Xq, int ldm, hipStream_t s);
+void fr_shard_bounds(const fr_model_desc &m, int n_shards, std::vector<int> &seg_begin);

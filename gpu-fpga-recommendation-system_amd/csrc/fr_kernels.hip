@@ -546,3 +546,36 @@ int frk_transpose_records(const float *X, float *Xq, int batch, int K, int ldm, 
     KCHECK();
     return FR_OK;
 }
+
+// Sharded mode: all-gathered padded slices [G][B][F] (item-major per shard) -> Xq[K/4][ldm][4] for items [item0, item0+n).
+// One launch per shard (slice offsets/lengths are host data); a transpose of 16-byte elements like the one above.
+__global__ void __launch_bounds__(256) transpose_slice_kernel(const float4 *__restrict__ S /* [B][F/4] of this shard */, int FQ, int item0,
+                                                              int n_items, int q_off, int q_len, float4 *__restrict__ Xq, int ldm) {
+    __shared__ float4 tile[16][17];
+    const int q0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    {
+        const int m = m0 + ty, q = q0 + tx;
+        tile[ty][tx] = (m < n_items && q < q_len) ? S[(size_t)(item0 + m) * FQ + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    {
+        const int q = q0 + ty, m = m0 + tx;
+        if (q < q_len && m < ldm) Xq[(size_t)(q_off + q) * ldm + m] = tile[tx][ty];
+    }
+}
+
+int frk_transpose_slices(const float *gathered, int n_shards, int batch_total, int slice_padded, const int *h_offsets, const int *h_lens,
+                         int item0, int n_items, float *Xq, int ldm, hipStream_t s) {
+    if (slice_padded % 4) FR_FAIL(FR_ERR_INVALID, "slice_padded %d must be a multiple of 4", slice_padded);
+    const int FQ = slice_padded / 4;
+    for (int g = 0; g < n_shards; g++) {
+        const int q_len = h_lens[g] / 4;
+        if (q_len == 0) continue;
+        dim3 grid((q_len + 15) / 16, (ldm + 15) / 16);
+        transpose_slice_kernel<<<grid, dim3(256), 0, s>>>(reinterpret_cast<const float4 *>(gathered) + (size_t)g * batch_total * FQ, FQ, item0,
+                                                         n_items, h_offsets[g] / 4, q_len, reinterpret_cast<float4 *>(Xq), ldm);
+    }
+    KCHECK();
+    return FR_OK;
+}

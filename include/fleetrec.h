@@ -265,6 +265,14 @@ int fr_device_synchronize(fr_ctx *ctx);
  * per-shard slice length F (equal on all shards; slices are whole segments). */
 int fr_ctx_shard_info(const fr_ctx *ctx, int *shard_rank, int *n_shards, int *slice_offset,
                       int *slice_len, int *slice_padded_len);
+/* Pure host query (no device): the plan fr_ctx_create_sharded uses -- per shard the first record float and the float
+ * count of its slice (arrays of n_shards ints), and the common padded slice length F. */
+int fr_model_shard_plan(const fr_model_desc *m, int n_shards, int *slice_offset, int *slice_len, int *slice_padded_len);
+/* After the all-gather: d_gathered = [n_shards][batch_total][F] floats (every shard's padded slice, as
+ * fr_worker_gather_only wrote it on that shard, concatenated in shard order = what ncclAllGather delivers).
+ * Runs the FC chain for items [item0, item0+n_items) of the batch on this GPU (FC weights are replicated);
+ * d_scores receives n_items floats.  Asynchronous on the worker's stream; follow with fr_worker_sync(). */
+int fr_worker_fc_from_slices(fr_worker *w, int batch_total, int item0, int n_items, const float *d_gathered, float *d_scores);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

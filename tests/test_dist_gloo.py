@@ -1,0 +1,103 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU plumbing: the replica mode's timing rule and the table-sharded mode's
+ONE exchange step (all-gather of [B x F] slices) + item partition.  The oracle stands in for the per-rank kernels here;
+the same orchestration runs on RCCL in bench.py --mode sharded."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys, json, time
+    import numpy as np
+    sys.path.insert(0, %(root)r)
+    import __graft_entry__ as g
+    fr = g.load_package()
+    O = g.load_oracle()
+    import importlib
+    dist_mod = importlib.import_module("fleetrec_amd.dist")
+    env = dist_mod.DistEnv("gloo")
+    assert env.world == 2 and env.backend == "gloo"
+    import torch
+    # --- replica mode: barrier + max-over-ranks timing, whole-job aggregation --------------------------------------
+    env.barrier()
+    mine = 0.5 + 0.25 * env.rank
+    mx = env.max_over_ranks(mine)
+    assert abs(mx - 0.75) < 1e-12, mx
+    assert dist_mod.replica_seed(1234, 0) != dist_mod.replica_seed(1234, 1)
+    assert dist_mod.aggregate_throughput(1000, mx, env.world) == 2 * 1000 / 0.75
+    assert abs(env.sum_over_ranks(env.rank + 1) - 3.0) < 1e-12
+    # --- sharded mode: every rank sees the whole request, gathers only its slice, one all-gather --------------------
+    which, name = %(which)d, %(name)r
+    model = fr.Model.builtin(which)
+    om = O.OracleModel(name)
+    offs, lens, F = model.shard_plan(env.world)
+    B = 24
+    rng = np.random.default_rng(99)                      # same seed on both ranks = replicated request
+    rows = model.rows()
+    idx = (rng.random((B, model.n_tables)) * np.minimum(rows, 5000)[None, :]).astype(np.int32)
+    dense = rng.uniform(-1, 1, (B, model.dense_len)).astype(np.float32) if model.dense_len else None
+    full = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=5)      # [B][K] uint32
+    local = np.zeros((B, F), np.uint32)
+    local[:, :lens[env.rank]] = full[:, offs[env.rank]:offs[env.rank] + lens[env.rank]]   # what gather_only writes on this shard
+    gathered = env.all_gather_slices(torch.from_numpy(local.view(np.int32))).numpy().view(np.uint32)
+    assert gathered.shape == (2, B, F)
+    rec = dist_mod.assemble_records(gathered, offs, lens, model.record_len)
+    assert np.array_equal(rec, full)
+    lo, hi = dist_mod.item_range(env.rank, env.world, B)
+    ws = [np.full(om.fc[i] * om.fc[i + 1], 1.0 / om.fc[i], np.float32) for i in range(4)]
+    mine_scores = om.fc_chain(rec[lo:hi].view(np.float32), ws)
+    pad = np.zeros(B, np.float32); pad[lo:hi] = mine_scores
+    tot = torch.from_numpy(pad.copy()); env.dist.all_reduce(tot)
+    ref = om.fc_chain(full.view(np.float32), ws)
+    assert np.array_equal(tot.numpy(), ref)
+    cover = [dist_mod.item_range(r, 2, B) for r in range(2)]
+    assert cover[0][0] == 0 and cover[0][1] == cover[1][0] and cover[1][1] == B
+    env.close()
+    print("rank %%d ok" %% env.rank)
+''')
+
+
+@pytest.mark.parametrize("which,name", [(0, "A"), (2, "C")])
+def test_two_rank_gloo(tmp_path, which, name, fr, O):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "which": which, "name": name})
+    port = 29600 + which
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode())
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, out)
+        assert "rank %d ok" % r in out
+
+
+def test_shard_plan_properties(fr):
+    for which in (fr.MODEL_A, fr.MODEL_B, fr.MODEL_C):
+        m = fr.Model.builtin(which)
+        segs = m.segments()
+        starts = {s.rec_offset for s in segs}
+        for G in (1, 2, 3, 4, 8):
+            offs, lens, F = m.shard_plan(G)
+            assert offs[0] == 0 and sum(lens) == m.record_len and F == max(lens) and F % 4 == 0
+            for g in range(G):
+                assert offs[g] in starts                      # slices are whole segments
+                if g:
+                    assert offs[g] == offs[g - 1] + lens[g - 1]
+            assert max(lens) - min(lens) <= 64                # float-balanced (largest row is 32 floats, dense block 64)
+    with pytest.raises(fr.FleetRecError):
+        fr.Model.builtin(fr.MODEL_A).shard_plan(48)           # more shards than segments

@@ -394,3 +394,56 @@ def test_driver_loop(fr, ctxs):
     assert el > 0
     el = drv.run_resident(256, 0, pool)  # empty run is fine
     drv.close()
+
+
+@pytest.mark.parametrize("which,G", [(0, 2), (1, 4), (2, 8)])
+def test_table_sharded_mode_single_device_emulation(fr, O, gpu, which, G):
+    """BASELINE config 4 on one GPU: G table-sharded contexts (each holds only its tables), every shard gathers its
+    [B x F] slice, the all-gather is emulated by concatenating the slices in shard order, then 'rank' r runs the FC chain on
+    its B/G items from the gathered layout.  Must equal the oracle (records bit-exact, scores 1e-3) and the unsharded path."""
+    import importlib
+    dist_mod = importlib.import_module("fleetrec_amd.dist")
+    m = fr.Model.builtin(which).clone(max_rows=20000)
+    om = O.OracleModel(NAMES[which])
+    offs, lens, F = m.shard_plan(G)
+    rng = np.random.default_rng(100 + G)
+    B = 200
+    idx = uniform_idx(rng, m.rows(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32) if m.dense_len else None
+    full = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES)
+    ctxs_, slices = [], []
+    for r in range(G):
+        c = fr.Context(m, device=gpu, shard_rank=r, n_shards=G)
+        info = c.shard_info()
+        assert (info["slice_offset"], info["slice_len"], info["slice_padded"]) == (offs[r], lens[r], F)
+        c.fill_tables(fr.FILL_HASH, SEED_TABLES)
+        c.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+        wk = fr.Worker(c, B)
+        sl = wk.gather_records(idx, dense).reshape(B, F)
+        assert np.array_equal(sl[:, :lens[r]], full[:, offs[r]:offs[r] + lens[r]])   # the shard's slice, bit-exact
+        with pytest.raises(fr.FleetRecError):                                         # a shard cannot run the whole path alone
+            wk.submit_device(B, None, None, None)
+        ctxs_.append((c, wk))
+        slices.append(sl)
+    gathered = np.stack(slices)                                                       # == ncclAllGather of the G slices
+    assert np.array_equal(dist_mod.assemble_records(gathered, offs, lens, m.record_len), full)
+    ws = [ctxs_[0][0].get_weights(l) for l in range(4)]
+    ref = om.fc_chain(full.view(np.float32), ws, acc64=True)
+    scores = np.empty(B, np.float32)
+    for r, (c, wk) in enumerate(ctxs_):
+        lo, hi = dist_mod.item_range(r, G, B)
+        d_g = fr.DeviceBuffer.from_numpy(c, gathered)
+        d_s = fr.DeviceBuffer(c, max(hi - lo, 1) * 4)
+        wk.fc_from_slices(B, lo, hi - lo, d_g, d_s)
+        wk.sync()
+        scores[lo:hi] = d_s.download(np.float32, hi - lo)
+    assert rel_err(scores, ref) <= 1e-3
+    # unsharded context on the same inputs: same records, scores equal up to the split-K order of a different batch size
+    c0 = fr.Context(m, device=gpu)
+    c0.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    c0.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    w0 = fr.Worker(c0, B)
+    assert np.abs(w0.infer(idx, dense) - scores).max() <= 1e-5 * np.abs(ref).max()
+    for c, wk in ctxs_ + [(c0, w0)]:
+        wk.close()
+        c.close()
