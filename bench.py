@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
                     help="replicas: BASELINE configs[1] (default, the headline metric); sharded: Model-C batch 4096 with tables "
                          "sharded by table-ID over the ranks + one RCCL all-gather of the looked-up slices (BASELINE configs[3])")
+    ap.add_argument("--model", choices=["A", "B", "C"], default="A", help="A = BASELINE configs[1] (default headline); B/C: other configs")
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32", help="FC chain arithmetic (bf16 = BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-model-c", action="store_true", help="skip the Model-C batch-4096 gather roofline leg")
     args = ap.parse_args()
@@ -135,14 +137,32 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
 
     B = args.batch
-    model = fr.Model.builtin(fr.MODEL_A)
+    model = fr.Model.builtin({"A": fr.MODEL_A, "B": fr.MODEL_B, "C": fr.MODEL_C}[args.model])
     ctx = fr.Context(model, device=local_rank)
     ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
     ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    if args.precision == "bf16":
+        ctx.set_fc_precision(fr.FC_BF16)
     rng = np.random.default_rng(SEED_IDX + rank)
     rows = model.rows()
-    idx_host = [(rng.random((B, model.n_tables)) * rows[None, :]).astype(np.int32) for _ in range(N_IDX_BUFFERS)]
+    n_bufs = N_IDX_BUFFERS if args.model == "A" else 8
+    idx_host = [(rng.random((B, model.n_tables)) * rows[None, :]).astype(np.int32) for _ in range(n_bufs)]
     d_idx = [fr.DeviceBuffer.from_numpy(ctx, a) for a in idx_host]
+    d_dense = ([fr.DeviceBuffer.from_numpy(ctx, rng.uniform(-1, 1, (B, model.dense_len)).astype(np.float32)) for _ in range(n_bufs)]
+               if model.dense_len else None)
+    if args.model != "A" or args.precision != "f32":
+        # non-headline configurations: throughput line only
+        driver = fr.Driver(ctx, args.threads, args.depth, B)
+        driver.run_resident(B, args.warmup, d_idx, d_dense)
+        ctx.synchronize()
+        el = driver.run_resident(B, args.steps, d_idx, d_dense)
+        print(json.dumps({"metric": "inferences/sec", "value": args.steps * B / el, "unit": "inferences/s", "n_gpus": 1, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "dtype": args.precision,
+                          "data": "synthetic", "config": {"workload": "Model-%s batch=%d %s FC chain, index rows resident in HBM" % (
+                              args.model, B, args.precision), "fc_tflops": fc_flops_per_inference(model.fc) * B * args.steps / el / 1e12}}))
+        driver.close()
+        ctx.close()
+        return
     driver = fr.Driver(ctx, args.threads, args.depth, B)
 
     def barrier():

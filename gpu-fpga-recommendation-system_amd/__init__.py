@@ -374,13 +374,17 @@ class Worker:
     def records_dptr(self):
         return lib().fr_worker_records_dptr(self._h)
 
-    def features(self, batch):
+    def features(self, batch, bf16=False):
         """Feature-major activations of the last submit(), un-packed from the device's q4 layout Xq[k/4][m][k%4]
         -> uint32 [record_len][batch] (debug/parity hook for the pipeline's own gather stage)."""
         ld_max = ctypes.c_int()
         p = lib().fr_worker_features_dptr(self._h, ctypes.byref(ld_max))
         K = self.ctx.model.record_len
         ld = (batch + 31) // 32 * 32
+        if bf16:  # q8 layout Xh[k/8][m][k%8] of bf16 -> uint16 [record_len][batch]
+            out = np.empty(K * ld, dtype=np.uint16)
+            _check(lib().fr_memcpy_d2h(self.ctx._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p), out.nbytes))
+            return out.reshape(K // 8, ld, 8).transpose(0, 2, 1).reshape(K, ld)[:, :batch]
         out = np.empty(K * ld, dtype=np.uint32)
         _check(lib().fr_memcpy_d2h(self.ctx._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p), out.nbytes))
         return out.reshape(K // 4, ld, 4).transpose(0, 2, 1).reshape(K, ld)[:, :batch]

@@ -311,7 +311,8 @@ static int refresh_bf16(fr_ctx *ctx, int layer) {
     if (ctx->fc_precision != FR_FC_BF16) return FR_OK;
     size_t n = (size_t)ctx->model.fc[layer] * ctx->model.fc[layer + 1];
     if (!ctx->d_w_bf16[layer]) FR_HIP(hipMalloc((void **)&ctx->d_w_bf16[layer], n * sizeof(uint16_t)));
-    return frk_f32_to_bf16(ctx->d_w[layer], ctx->d_w_bf16[layer], n, ctx->setup_stream);
+    // Wh[k/8][h][k%8]; for the output layer (H == 1) this is simply the bf16 vector w[k]
+    return frk_pack_weights_q8_bf16(ctx->d_w[layer], ctx->d_w_bf16[layer], ctx->model.fc[layer], ctx->model.fc[layer + 1], ctx->setup_stream);
 }
 
 extern "C" int fr_ctx_set_weights(fr_ctx *ctx, int layer, const float *w, size_t count) {
@@ -360,6 +361,10 @@ extern "C" int fr_ctx_set_fc_precision(fr_ctx *ctx, int precision) {
     if (precision != FR_FC_FP32 && precision != FR_FC_BF16) FR_FAIL(FR_ERR_INVALID, "bad precision %d", precision);
     FR_HIP(hipSetDevice(ctx->device));
     ctx->fc_precision = precision;
+    if (precision == FR_FC_BF16) {
+        for (int l = 0; l < 4; l++)
+            if (ctx->model.fc[l] % 16) FR_FAIL(FR_ERR_INVALID, "bf16 chain needs fc[%d]=%d to be a multiple of 16", l, ctx->model.fc[l]);
+    }
     if (precision == FR_FC_BF16 && ctx->weights_set) {
         for (int l = 0; l < 4; l++) {
             int rc = refresh_bf16(ctx, l);
@@ -521,7 +526,12 @@ static int pipeline_step(fr_worker *w) {
         st.ldm = sl.ldm;
         const int ldm = sl.ldm;
         // K-split plan of the three FC layers of this batch
-        const int ns1 = pick_nsplit(fc[0], fc[1], ldm), ns2 = pick_nsplit(fc[1], fc[2], ldm), ns3 = pick_nsplit(fc[2], fc[3], ldm);
+        const bool bf16 = c->fc_precision == FR_FC_BF16;  // no K-split partials in the bf16 chain
+        const int ns1 = bf16 ? 1 : pick_nsplit(fc[0], fc[1], ldm), ns2 = bf16 ? 1 : pick_nsplit(fc[1], fc[2], ldm),
+                  ns3 = bf16 ? 1 : pick_nsplit(fc[2], fc[3], ldm);
+        const float *wl[4];
+        for (int l = 0; l < 4; l++)
+            wl[l] = bf16 ? reinterpret_cast<const float *>(c->d_w_bf16[l]) : (l < 3 ? c->d_wq[l] : c->d_w[3]);
         switch (s) {
             case 0:
                 a.idx = sl.d_idx;
@@ -531,19 +541,19 @@ static int pipeline_step(fr_worker *w) {
                 break;
             case 1:
                 st.K = fc[0]; st.N = fc[1]; st.nsplit = ns1; st.nparts_in = 1;
-                st.in = rd.x; st.in_part_stride = 0; st.out = wr.r1; st.part_stride = (int)wr.p1; st.w = c->d_wq[0];
+                st.in = rd.x; st.in_part_stride = 0; st.out = wr.r1; st.part_stride = (int)wr.p1; st.w = wl[0];
                 break;
             case 2:
                 st.K = fc[1]; st.N = fc[2]; st.nsplit = ns2; st.nparts_in = ns1;
-                st.in = rd.r1; st.in_part_stride = (int)rd.p1; st.out = wr.r2; st.part_stride = (int)wr.p2; st.w = c->d_wq[1];
+                st.in = rd.r1; st.in_part_stride = (int)rd.p1; st.out = wr.r2; st.part_stride = (int)wr.p2; st.w = wl[1];
                 break;
             case 3:
                 st.K = fc[2]; st.N = fc[3]; st.nsplit = ns3; st.nparts_in = ns2;
-                st.in = rd.r2; st.in_part_stride = (int)rd.p2; st.out = wr.r3; st.part_stride = (int)wr.p3; st.w = c->d_wq[2];
+                st.in = rd.r2; st.in_part_stride = (int)rd.p2; st.out = wr.r3; st.part_stride = (int)wr.p3; st.w = wl[2];
                 break;
             case 4:
                 st.K = fc[3]; st.N = 1; st.nsplit = 1; st.nparts_in = ns3;
-                st.in = rd.r3; st.in_part_stride = (int)rd.p3; st.out = sl.d_scores; st.w = c->d_w[3];
+                st.in = rd.r3; st.in_part_stride = (int)rd.p3; st.out = sl.d_scores; st.w = wl[3];
                 break;
         }
         blocks += frk_stage_blocks(s, c->n_words, st.K, st.N, ldm, st.nsplit);
@@ -561,9 +571,9 @@ static int pipeline_step(fr_worker *w) {
         const int begin = a.st[only].block_begin;
         for (int s = 0; s < FR_N_STAGES; s++) a.st[s].block_begin -= (s >= only) ? begin : 0;
         a.st[only].block_begin = 0;
-        return frk_pipeline_launch(a, only, w->stream);
+        return frk_pipeline_launch(a, only, c->fc_precision, w->stream);
     }
-    return frk_pipeline_launch(a, -1, w->stream);
+    return frk_pipeline_launch(a, -1, c->fc_precision, w->stream);
 }
 
 static int pipeline_push(fr_worker *w, int batch, int first_stage, const int32_t *d_idx, const float *d_dense, float *d_scores) {
@@ -601,12 +611,13 @@ static int check_gather_args(fr_worker *w, const int32_t *d_idx, const float *d_
 static int launch_fc(fr_worker *w, int batch, const float *d_records, float *d_scores) {
     fr_ctx *c = w->ctx;
     if (c->n_shards > 1) FR_FAIL(FR_ERR_STATE, "fc on a sharded ctx needs the all-gathered records (use the sharded driver)");
-    if (c->fc_precision != FR_FC_FP32) FR_FAIL(FR_ERR_STATE, "bf16 FC path not built yet");
     if (w->n_active) FR_FAIL(FR_ERR_STATE, "pipeline busy: call fr_worker_sync first");
     if (w->launch_no == 0) w->launch_no = 1;  // stage 1 of the next launch reads the set the (virtual) previous launch wrote
     const int ldm = round_up(batch, 32);
     const int par_prev = (int)((w->launch_no - 1) & 1);
-    int rc = frk_transpose_records(d_records, act_set(w, par_prev).x, batch, c->model.fc[0], ldm, w->stream);
+    int rc = (c->fc_precision == FR_FC_BF16)
+                 ? frk_records_to_q8_bf16(d_records, act_set(w, par_prev).x, batch, c->model.fc[0], ldm, w->stream)
+                 : frk_transpose_records(d_records, act_set(w, par_prev).x, batch, c->model.fc[0], ldm, w->stream);
     if (rc) return rc;
     rc = pipeline_push(w, batch, 1, nullptr, nullptr, d_scores);
     if (rc) return rc;
@@ -621,7 +632,7 @@ extern "C" int fr_worker_fc_from_slices(fr_worker *w, int batch_total, int item0
     fr_ctx *c = w->ctx;
     if (!d_gathered || !d_scores) FR_FAIL(FR_ERR_INVALID, "NULL device pointer");
     if (batch_total < 1 || item0 < 0 || item0 + n_items > batch_total) FR_FAIL(FR_ERR_INVALID, "items [%d,+%d) outside batch %d", item0, n_items, batch_total);
-    if (c->fc_precision != FR_FC_FP32) FR_FAIL(FR_ERR_STATE, "bf16 FC path not built yet");
+    if (c->fc_precision != FR_FC_FP32) FR_FAIL(FR_ERR_STATE, "fc_from_slices: fp32 chain only (bf16 slice transport not built yet)");
     if (w->n_active) FR_FAIL(FR_ERR_STATE, "pipeline busy: call fr_worker_sync first");
     FR_HIP(hipSetDevice(c->device));
     if (w->launch_no == 0) w->launch_no = 1;
@@ -642,7 +653,6 @@ extern "C" int fr_worker_fc_from_slices(fr_worker *w, int batch_total, int item0
 static int launch_pipeline(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores) {
     fr_ctx *c = w->ctx;
     if (c->n_shards > 1) FR_FAIL(FR_ERR_STATE, "submit on a sharded ctx: use the sharded driver (gather_only + all-gather + fc_only)");
-    if (c->fc_precision != FR_FC_FP32) FR_FAIL(FR_ERR_STATE, "bf16 FC path not built yet");
     if (c->model.layout != FR_LAYOUT_SEMANTIC) {
         // literal 3-node buffer arithmetic (F8): materialise the blocked records, then read them as B x K item-major
         int rc = launch_gather(w, batch, d_idx, d_dense, w->d_records);
@@ -721,8 +731,8 @@ extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_i
     if (rc) return rc;
     if (!d_scores) FR_FAIL(FR_ERR_INVALID, "d_scores is NULL");
     fr_ctx *c = w->ctx;
-    if (c->n_shards > 1 || c->model.layout != FR_LAYOUT_SEMANTIC || c->fc_precision != FR_FC_FP32)
-        FR_FAIL(FR_ERR_STATE, "push_device needs an unsharded SEMANTIC-layout fp32 context");
+    if (c->n_shards > 1 || c->model.layout != FR_LAYOUT_SEMANTIC)
+        FR_FAIL(FR_ERR_STATE, "push_device needs an unsharded SEMANTIC-layout context");
     rc = check_gather_args(w, d_idx, d_dense);
     if (rc) return rc;
     FR_HIP(hipSetDevice(c->device));

@@ -158,7 +158,9 @@ int frk_f32_to_bf16(const float *src, uint16_t *dst, size_t count, hipStream_t s
 int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense,
                float *out, int batch, int *err_flag, hipStream_t s);
 // feature-major FC chain, stage-pipelined across batches (see fr_kernels.hip)
-int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, hipStream_t s);
+int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, int precision, hipStream_t s);
+int frk_pack_weights_q8_bf16(const float *W, uint16_t *Wh, int K, int H, hipStream_t s);
+int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, hipStream_t s);
 int frk_pack_weights_q4(const float *W, float *Wq, int K, int H, hipStream_t s);
 int frk_stage_blocks(int stage, int n_words, int K, int N, int ldm, int nsplit);
 int frk_transpose_records(const float *X, float *Xt, int batch, int K, int ldm, hipStream_t s);

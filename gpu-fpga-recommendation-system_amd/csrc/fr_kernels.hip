@@ -441,9 +441,185 @@ __device__ __forceinline__ void fc_out_q_body(const FrStageArgs &st, int local, 
     }
 }
 
+// ===================================================================================================
+// bf16 variant of the chain (BASELINE configs 3/4: "bf16 MFMA FC, fused concat + first FC").
+// Same structure, "q8" layout: 8 consecutive k per 16 bytes, Xh[k/8][m][k%8] / Wh[k/8][n][k%8] (bf16), so one 16-byte load
+// per lane is exactly one v_mfma_f32_32x32x16_bf16 operand (lane half h carries k = 16g + 8h + j, j = 0..7).  fp32
+// accumulation; activations are rounded to bf16 (RNE) once per layer when the tile is stored.  The gather stage converts
+// the fp32 table rows to bf16 while concatenating -- the record never exists in fp32 (fused concat + FC1 operand).
+// No K-split partials here (nsplit == 1): a bf16 layer is 16x cheaper than its fp32 form and partial sums would have to be
+// rounded twice.
+// ===================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const __bf16 a = (__bf16)lo, b = (__bf16)hi;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+    return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+__device__ __forceinline__ void gather_h_body(const FrPipeArgs &a, const FrStageArgs &st, int local) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m_blocks = (st.ldm + 63) / 64;
+    const int mb = local % m_blocks, wb = local / m_blocks;
+    const int m = mb * 64 + lane;
+    constexpr int WPW = 2;
+    const int w_begin = (wb * FR_PIPE_WAVES + wave) * WPW;
+    const bool live = m < st.batch;
+    uint2 *Xh = reinterpret_cast<uint2 *>(st.out);  // 8-byte halves of the q8 elements
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < WPW; i++) {
+        const int w = w_begin + i;
+        if (w >= a.n_words) break;
+        const FrWordDesc d = a.words[w];
+        const bool is_dense = (d.idx_col & FR_DESC_DENSE) != 0;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (live) {
+            uint32_t id = is_dense ? (uint32_t)m : (uint32_t)a.idx[(size_t)m * a.idx_stride + d.idx_col];
+            if (!is_dense && id >= d.rows) {
+                bad = true;
+                id = 0;
+            }
+            const char *base = is_dense ? reinterpret_cast<const char *>(a.dense) + d.src : reinterpret_cast<const char *>(d.src);
+            v = *reinterpret_cast<const uint4 *>(base + (uint64_t)id * d.stride);
+        }
+        if (m < st.ldm) {
+            uint2 h;
+            h.x = pack_bf16x2(__uint_as_float(v.x), __uint_as_float(v.y));
+            h.y = pack_bf16x2(__uint_as_float(v.z), __uint_as_float(v.w));
+            // record word w = floats 4w..4w+3 = half (w & 1) of q8 element w / 2
+            Xh[((size_t)(d.dst_off >> 1) * st.ldm + m) * 2 + (d.dst_off & 1)] = h;
+        }
+    }
+    if (bad) atomicOr_system(a.err_flag, 1);
+}
+
+__device__ __forceinline__ void fc_h_body(const FrStageArgs &st, int local, float *red) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = st.N, ldm = st.ldm;
+    const int tiles_n = N / 32, tiles_m = ldm / 32, tiles = tiles_n * tiles_m;
+    int n_tile, m_tile;
+    const int MG = (tiles_m % 2 == 0) ? 2 : 1, NG = 8 / MG;
+    if (tiles_n % NG == 0) {  // same XCD-aware map as the fp32 body
+        const int x = local & 7, j = local >> 3;
+        const int mg = x % MG, ng = x / MG;
+        const int tn_x = tiles_n / NG;
+        if (j >= tn_x * (tiles_m / MG)) return;
+        n_tile = (j % tn_x) * NG + ng;
+        m_tile = (j / tn_x) * MG + mg;
+    } else {
+        if (local >= tiles) return;
+        n_tile = local % tiles_n;
+        m_tile = local / tiles_n;
+    }
+    const int n0 = n_tile * 32, m0 = m_tile * 32;
+    const int hk = lane >> 5, lm = lane & 31;
+    const int groups = st.K / 16;  // one MFMA (16 k) per group
+    const int per = (groups + FR_PIPE_WAVES - 1) / FR_PIPE_WAVES;
+    const int g_begin = wave * per;
+    int ng_ = groups - g_begin;
+    ng_ = ng_ < 0 ? 0 : (ng_ > per ? per : ng_);
+    const uint4 *aq = reinterpret_cast<const uint4 *>(st.w) + (size_t)hk * N + n0 + lm;
+    const uint4 *bq = reinterpret_cast<const uint4 *>(st.in) + (size_t)hk * ldm + m0 + lm;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+    constexpr int D = 4;
+    uint4 ra[D], rb[D], na[D], nb[D];
+    const int nb_full = ng_ / D;
+    if (nb_full > 0) {
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            ra[i] = aq[(size_t)(2 * (g_begin + i)) * N];
+            rb[i] = bq[(size_t)(2 * (g_begin + i)) * ldm];
+        }
+    }
+    for (int blk = 0; blk < nb_full; blk++) {
+        const int nx = (blk + 1 < nb_full) ? (blk + 1) : blk;
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            na[i] = aq[(size_t)(2 * (g_begin + nx * D + i)) * N];
+            nb[i] = bq[(size_t)(2 * (g_begin + nx * D + i)) * ldm];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < D; i++)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[i]), __builtin_bit_cast(bf16x8, rb[i]), acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            ra[i] = na[i];
+            rb[i] = nb[i];
+        }
+    }
+    for (int g = g_begin + nb_full * D; g < g_begin + ng_; g++) {
+        const uint4 a8 = aq[(size_t)(2 * g) * N], b8 = bq[(size_t)(2 * g) * ldm];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, b8), acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    // fixed-order fp32 sum, ONE rounding to bf16, stored as the 8-byte half (4 consecutive n) of a q8 element
+    uint2 *Yh = reinterpret_cast<uint2 *>(st.out);
+    if (threadIdx.x < 4 * 64) {
+        const int i = threadIdx.x >> 6, l = threadIdx.x & 63;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float s = red[(4 * i + c) * 64 + l];
+#pragma unroll
+            for (int w = 1; w < FR_PIPE_WAVES; w++) s += red[(w * 16 + 4 * i + c) * 64 + l];
+            v[c] = s;
+        }
+        uint2 h;
+        h.x = pack_bf16x2(v[0], v[1]);
+        h.y = pack_bf16x2(v[2], v[3]);
+        // n = n0 + 8i + 4(l>>5) + c  ->  q8 element (n0/8 + i), half (l>>5)
+        Yh[((size_t)((n0 >> 3) + i) * ldm + m0 + (l & 31)) * 2 + (l >> 5)] = h;
+    }
+}
+
+// score[m] = sum_n w[n] * R3h[n/8][m][n%8]; weights for this layer stay fp32 values rounded to bf16 (st.w = bf16 array)
+__device__ __forceinline__ void fc_out_h_body(const FrStageArgs &st, int local, float *red) {
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = local * 64 + lane;
+    const int HO = st.K / 8, ldm = st.ldm;
+    const int per = (HO + FR_PIPE_WAVES - 1) / FR_PIPE_WAVES;
+    const int h0 = q * per;
+    const int h1 = (h0 + per) < HO ? (h0 + per) : HO;
+    const uint4 *Rh = reinterpret_cast<const uint4 *>(st.in);
+    const uint4 *wh = reinterpret_cast<const uint4 *>(st.w);
+    float s = 0.0f;
+    if (m < ldm) {
+        for (int h = h0; h < h1; h++) {
+            const uint4 r = Rh[(size_t)h * ldm + m];
+            const uint4 w = wh[h];
+            const uint32_t rr[4] = {r.x, r.y, r.z, r.w}, ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                s = fmaf(__uint_as_float(ww[c] << 16), __uint_as_float(rr[c] << 16), s);
+                s = fmaf(__uint_as_float(ww[c] & 0xFFFF0000u), __uint_as_float(rr[c] & 0xFFFF0000u), s);
+            }
+        }
+    }
+    red[q * 64 + lane] = s;
+    __syncthreads();
+    if (q == 0 && m < st.batch) {
+        float t = red[lane];
+#pragma unroll
+        for (int i = 1; i < FR_PIPE_WAVES; i++) t += red[i * 64 + lane];
+        st.out[m] = t;
+    }
+}
+
 // STAGE = -1: all stages of one pipelined launch; STAGE = 0..4: that stage alone (separately named kernels so
 // that rocprof attributes time per stage when a batch is run unpipelined).
-template <int STAGE>
+// PREC: 0 = fp32 chain (q4 operands, exact-f32 MFMA), 1 = bf16 chain (q8 operands, bf16 MFMA, fp32 accumulate).
+template <int STAGE, int PREC>
 __global__ void __launch_bounds__(FR_PIPE_THREADS) fr_pipeline_kernel(const FrPipeArgs a) {
     __shared__ float red[FR_PIPE_WAVES * 16 * 64];  // 32 KiB
     const int b = blockIdx.x;
@@ -458,14 +634,20 @@ __global__ void __launch_bounds__(FR_PIPE_THREADS) fr_pipeline_kernel(const FrPi
     const int local = b - st.block_begin;
     unsigned long long t_in = 0;
     if (a.stamps) t_in = __builtin_amdgcn_s_memrealtime();  // diagnostics only; the values never feed an output
-    if (s == 0) {
-        gather_q_body(a, st, local);
-    } else if (s == 4) {
-        fc_out_q_body(st, local, red);
-    } else if (st.nparts_in == 2) {
-        fc_q_body<true>(st, local, red);
+    if constexpr (PREC == 1) {
+        if (s == 0) gather_h_body(a, st, local);
+        else if (s == 4) fc_out_h_body(st, local, red);
+        else fc_h_body(st, local, red);
     } else {
-        fc_q_body<false>(st, local, red);
+        if (s == 0) {
+            gather_q_body(a, st, local);
+        } else if (s == 4) {
+            fc_out_q_body(st, local, red);
+        } else if (st.nparts_in == 2) {
+            fc_q_body<true>(st, local, red);
+        } else {
+            fc_q_body<false>(st, local, red);
+        }
     }
     if (a.stamps) {
         __syncthreads();
@@ -482,20 +664,25 @@ __global__ void __launch_bounds__(FR_PIPE_THREADS) fr_pipeline_kernel(const FrPi
 }
 
 // Launch one pipeline step.  `single_stage` >= 0 launches only that stage (its block_begin must be 0).
-int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, hipStream_t s) {
-    if (a.n_blocks <= 0) return FR_OK;
+template <int PREC>
+static int pipeline_launch_prec(const FrPipeArgs &a, int single_stage, hipStream_t s) {
     dim3 grid(a.n_blocks), block(FR_PIPE_THREADS);
     switch (single_stage) {
-        case -1: fr_pipeline_kernel<-1><<<grid, block, 0, s>>>(a); break;
-        case 0: fr_pipeline_kernel<0><<<grid, block, 0, s>>>(a); break;
-        case 1: fr_pipeline_kernel<1><<<grid, block, 0, s>>>(a); break;
-        case 2: fr_pipeline_kernel<2><<<grid, block, 0, s>>>(a); break;
-        case 3: fr_pipeline_kernel<3><<<grid, block, 0, s>>>(a); break;
-        case 4: fr_pipeline_kernel<4><<<grid, block, 0, s>>>(a); break;
+        case -1: fr_pipeline_kernel<-1, PREC><<<grid, block, 0, s>>>(a); break;
+        case 0: fr_pipeline_kernel<0, PREC><<<grid, block, 0, s>>>(a); break;
+        case 1: fr_pipeline_kernel<1, PREC><<<grid, block, 0, s>>>(a); break;
+        case 2: fr_pipeline_kernel<2, PREC><<<grid, block, 0, s>>>(a); break;
+        case 3: fr_pipeline_kernel<3, PREC><<<grid, block, 0, s>>>(a); break;
+        case 4: fr_pipeline_kernel<4, PREC><<<grid, block, 0, s>>>(a); break;
         default: FR_FAIL(FR_ERR_INVALID, "bad stage %d", single_stage);
     }
     KCHECK();
     return FR_OK;
+}
+
+int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, int precision, hipStream_t s) {
+    if (a.n_blocks <= 0) return FR_OK;
+    return precision == FR_FC_BF16 ? pipeline_launch_prec<1>(a, single_stage, s) : pipeline_launch_prec<0>(a, single_stage, s);
 }
 
 int frk_stage_blocks(int stage, int n_words, int K, int N, int ldm, int nsplit) {
@@ -576,6 +763,54 @@ int frk_transpose_slices(const float *gathered, int n_shards, int batch_total, i
         transpose_slice_kernel<<<grid, dim3(256), 0, s>>>(reinterpret_cast<const float4 *>(gathered) + (size_t)g * batch_total * FQ, FQ, item0,
                                                          n_items, h_offsets[g] / 4, q_len, reinterpret_cast<float4 *>(Xq), ldm);
     }
+    KCHECK();
+    return FR_OK;
+}
+
+// fp32 master weights (column-major H x K) -> Wh[k/8][h][k%8] bf16 (RNE)
+__global__ void __launch_bounds__(256) pack_weights_q8_bf16_kernel(const float *__restrict__ W, uint4 *__restrict__ Wh, int K, int H) {
+    const size_t n = (size_t)(K / 8) * H;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t ko = e / H, h = e - ko * H;
+        uint4 o;
+        o.x = pack_bf16x2(W[h + (8 * ko + 0) * H], W[h + (8 * ko + 1) * H]);
+        o.y = pack_bf16x2(W[h + (8 * ko + 2) * H], W[h + (8 * ko + 3) * H]);
+        o.z = pack_bf16x2(W[h + (8 * ko + 4) * H], W[h + (8 * ko + 5) * H]);
+        o.w = pack_bf16x2(W[h + (8 * ko + 6) * H], W[h + (8 * ko + 7) * H]);
+        Wh[e] = o;
+    }
+}
+
+int frk_pack_weights_q8_bf16(const float *W, uint16_t *Wh, int K, int H, hipStream_t s) {
+    if (K % 8) FR_FAIL(FR_ERR_INVALID, "pack_weights_q8 needs K %% 8 == 0 (K=%d)", K);
+    size_t n = (size_t)(K / 8) * H;
+    unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    pack_weights_q8_bf16_kernel<<<dim3(blocks ? blocks : 1), dim3(256), 0, s>>>(W, reinterpret_cast<uint4 *>(Wh), K, H);
+    KCHECK();
+    return FR_OK;
+}
+
+// item-major fp32 records [B][K] -> Xh[K/8][ldm][8] bf16 (fc_only diagnostic / BLOCKED layout in bf16 mode)
+__global__ void __launch_bounds__(256) records_to_q8_bf16_kernel(const float *__restrict__ X, uint4 *__restrict__ Xh, int batch, int KO, int ldm) {
+    const size_t n = (size_t)KO * ldm;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t ko = e / ldm, m = e - ko * ldm;
+        uint4 o = make_uint4(0u, 0u, 0u, 0u);
+        if ((int)m < batch) {
+            const float *x = X + m * (size_t)KO * 8 + ko * 8;
+            o.x = pack_bf16x2(x[0], x[1]);
+            o.y = pack_bf16x2(x[2], x[3]);
+            o.z = pack_bf16x2(x[4], x[5]);
+            o.w = pack_bf16x2(x[6], x[7]);
+        }
+        Xh[e] = o;
+    }
+}
+
+int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, hipStream_t s) {
+    size_t n = (size_t)(K / 8) * ldm;
+    unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    records_to_q8_bf16_kernel<<<dim3(blocks ? blocks : 1), dim3(256), 0, s>>>(X, reinterpret_cast<uint4 *>(Xh), batch, K / 8, ldm);
     KCHECK();
     return FR_OK;
 }

