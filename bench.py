@@ -38,6 +38,19 @@ def gather_bytes_per_inference(model, fr):
     return rows + idx + dense + write
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM/fabric bytes per launch from the committed PMC summary (tools/pmc_traffic.sh: separate rocprofv3 --pmc passes over
+    this same bench command, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md) -- or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        for k, v in d.items():
+            if k.startswith(kernel_prefix) and "traffic_bytes_per_launch" in v:
+                return v["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def fc_flops_per_inference(fc):
     return 2 * sum(fc[i] * fc[i + 1] for i in range(4))
 
@@ -223,8 +236,10 @@ def main():
         flops = fc_flops_per_inference(fc) * B
         ach = flops / (pipe_ms * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
-                              "kernel": "fr_pipeline_kernel<-1> (one launch = gather|FC1|FC2|FC3|out of 5 consecutive batches = one "
+                              "frac": ach / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("fr_pipeline_kernel<-1, 0>"),
+                              "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
+                                                "FETCH_SIZE x2 gfx950 correction), bytes per launch",
+                              "kernel": "fr_pipeline_kernel<-1, 0> (one launch = gather|FC1|FC2|FC3|out of 5 consecutive batches = one "
                                         "batch worth of the 4-GEMM chain), back-to-back on ONE stream",
                               "avg_launch_ms": pipe_ms, "algorithmic_flops_per_launch": flops,
                               "note": "value above runs %d such streams concurrently" % (args.threads * args.depth)}
@@ -317,9 +332,10 @@ def main():
             gb = gather_bytes_per_inference(mc, fr) * BC
             result["gather"] = {"workload": "Model-C (2x embedding_377_krnl + 64 dense: 376 tables, 63.2 GB) batch=4096, uniform indices",
                                 "bound": "hbm", "achieved": gb / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": gb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
+                                "frac": gb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("gather_pack_xcd_kernel<8>"),
+                                "traffic_source": "profiles/r01_pmc_traffic.json (PMC, FETCH_SIZE x2 correction), bytes per launch", "avg_launch_ms": ms,
                                 "algorithmic_bytes_per_launch": gb, "inferences_per_s": BC / (ms * 1e-3),
-                                "kernel": "gather_pack_kernel<8>"}
+                                "kernel": "gather_pack_xcd_kernel<8>"}
             wk.close()
             cc.close()
         except Exception as ex:  # the main metric must still be reported

@@ -65,7 +65,7 @@ int main() {
     // Model-C-like: per half 8x dim4, 128x dim8, 48x dim16, 4x dim32 (+16 dense words treated as a dim64 table)
     std::vector<int> dims; for (int h = 0; h < 2; h++) { for (int i = 0; i < 8; i++) dims.push_back(4); for (int i = 0; i < 128; i++) dims.push_back(8);
         for (int i = 0; i < 48; i++) dims.push_back(16); for (int i = 0; i < 4; i++) dims.push_back(32); }
-    const unsigned rows = 20000;
+    const unsigned rows = getenv("ROWS") ? (unsigned)atoi(getenv("ROWS")) : 20000;
     size_t tot = 0; std::vector<size_t> off; for (int d : dims) { off.push_back(tot); tot += (size_t)rows * d * 4; }
     char *tab; (void)hipMalloc(&tab, tot + 4096 * 256); (void)hipMemset(tab, 1, tot);
     std::vector<Desc> h; for (int t = 0; t < (int)dims.size(); t++) for (int j = 0; j < dims[t] / 4; j++) {

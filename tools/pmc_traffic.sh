@@ -1,0 +1,16 @@
+#!/bin/bash
+# HBM/fabric traffic of the two roofline kernels from PMC counters, as MI355X_MICROARCH.md "HBM" prescribes:
+# separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), kernel-trace only, program directly after `--`.
+# Run on the GPU box from the repo root:  bash tools/pmc_traffic.sh   -> gpurun_out/pmc_traffic/*.csv + summary JSON
+set -e
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/pmc_traffic
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum"; do
+  tag=$(echo $pass | tr ' ' '_')
+  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/$tag -- python3 $ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline > $OUT/$tag.log 2>&1
+done
+cd $ROOT
+python3 tools/pmc_summarize.py $OUT > $OUT/summary.json
+cat $OUT/summary.json
