@@ -1,0 +1,104 @@
+// fleetrec_sender -- synthetic request stream; counterpart of the reference's FPGA/CPU simulators
+// (GPU/final_network_cublasLt_1_node_no_FIFO_scatter/multiple_connections_network_client_sender.c): THREAD_NUM threads,
+// each connect()s to SERVER:PORT+i and sends fixed-size blocks back to back.  The reference oversends 2x because sender
+// and receiver threads progress unevenly (README.md:23-25); here every thread simply sends until the server closes
+// the connection.  A block is B x T int32 indices (+ B x 64 dense floats for Model-C).
+//
+// Usage: fleetrec_sender --model A|B|C [--batch 256] [--threads 4] [--port 8080] [--host 127.0.0.1]
+//                        [--indices reference|uniform] [--per-item] [--row-cap N] [--max-blocks N] [--reply]
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "fleetrec.h"
+
+// load_access_idx's 32 fixed indices (embedding_47_krnl.cpp:899-914; identical in the 98/377 kernels)
+static const int kIdxRandom[32] = {3, 99, 38, 72, 29, 57, 1, 72, 36, 76, 35, 50, 37, 57, 13, 66,
+                                   26, 70, 41, 93, 48, 82, 44, 78, 25, 52, 3, 92, 36, 56, 46, 88};
+
+int main(int argc, char **argv) {
+    int which = FR_MODEL_A, batch = 256, threads = 4, port = 8080;
+    long row_cap = 0, max_blocks = 1L << 40;
+    std::string host = "127.0.0.1", indices = "reference";
+    bool per_item = false, reply = false;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char * { return (i + 1 < argc) ? argv[++i] : ""; };
+        if (a == "--model") { std::string v = next(); which = v == "A" ? FR_MODEL_A : v == "B" ? FR_MODEL_B : FR_MODEL_C; }
+        else if (a == "--batch") batch = atoi(next());
+        else if (a == "--threads") threads = atoi(next());
+        else if (a == "--port") port = atoi(next());
+        else if (a == "--host") host = next();
+        else if (a == "--indices") indices = next();
+        else if (a == "--per-item") per_item = true;
+        else if (a == "--reply") reply = true;
+        else if (a == "--row-cap") row_cap = atol(next());
+        else if (a == "--max-blocks") max_blocks = atol(next());
+        else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+    }
+    fr_model_desc *m = nullptr;
+    if (fr_model_clone_scaled(fr_model_builtin(which), 1.0, 1, row_cap, &m) != FR_OK) { fprintf(stderr, "%s\n", fr_last_error()); return 1; }
+    const size_t cols = per_item ? 1 : (size_t)m->n_tables;
+    std::vector<std::thread> th;
+    std::vector<long> sent(threads, 0);
+    for (int t = 0; t < threads; t++) {
+        th.emplace_back([&, t]() {
+            std::vector<int32_t> idx((size_t)batch * cols);
+            std::vector<float> dense((size_t)batch * m->dense_len), scores(batch);
+            std::mt19937_64 rng(1234 + t);
+            int sock = socket(AF_INET, SOCK_STREAM, 0), one = 1;
+            sockaddr_in addr{};
+            addr.sin_family = AF_INET;
+            addr.sin_port = htons((uint16_t)(port + t));
+            inet_pton(AF_INET, host.c_str(), &addr.sin_addr);
+            int tries = 0;
+            while (connect(sock, (sockaddr *)&addr, sizeof(addr)) < 0) {  // the server may still be filling 63 GB of tables
+                if (++tries > 600) { fprintf(stderr, "connect to %s:%d failed\n", host.c_str(), port + t); return; }
+                usleep(100000);
+            }
+            setsockopt(sock, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+            for (long blk = 0; blk < max_blocks; blk++) {
+                for (int b = 0; b < batch; b++) {
+                    for (size_t c = 0; c < cols; c++) {
+                        int32_t v;
+                        if (indices == "reference") v = kIdxRandom[b % 32];  // same index for every table of the item (F4)
+                        else v = (int32_t)(rng() % (uint64_t)(per_item ? 100 : m->tables[c].rows));
+                        idx[(size_t)b * cols + c] = v;
+                    }
+                    for (int d = 0; d < m->dense_len; d++)
+                        dense[(size_t)b * m->dense_len + d] = (indices == "reference") ? ((kIdxRandom[b % 32] % 2 == 0) ? 1.0f : 0.0f)
+                                                                                        : (float)((rng() >> 11) * (2.0 / 9007199254740992.0) - 1.0);
+                }
+                if (send(sock, idx.data(), idx.size() * 4, MSG_NOSIGNAL) <= 0) break;
+                if (!dense.empty() && send(sock, dense.data(), dense.size() * 4, MSG_NOSIGNAL) <= 0) break;
+                sent[t]++;
+                if (reply) {
+                    size_t got = 0;
+                    while (got < scores.size() * 4) {
+                        ssize_t r = read(sock, (char *)scores.data() + got, scores.size() * 4 - got);
+                        if (r <= 0) break;
+                        got += (size_t)r;
+                    }
+                    if (got < scores.size() * 4) break;
+                }
+            }
+            close(sock);
+        });
+    }
+    for (auto &x : th) x.join();
+    long tot = 0;
+    for (long s : sent) tot += s;
+    printf("sender: %ld blocks sent over %d connections\n", tot, threads);
+    fr_model_free(m);
+    return 0;
+}

@@ -1,0 +1,45 @@
+"""End-to-end shape of the reference restored: the TCP request server (THREAD_NUM connections on
+PORT+i, fixed-size blocks, mutex-guarded batch counter) fed by the synthetic sender, with indices on the wire."""
+import os
+import re
+import subprocess
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "gpu-fpga-recommendation-system_amd", "host")
+
+
+@pytest.mark.parametrize("model,val,extra", [("A", 352.0 * 2 ** 27, []), ("C", 3968.0 * 2 ** 28, ["--row-cap", "200"])])
+def test_server_and_sender_known_answer(fr, gpu, model, val, extra):
+    """Reference data end to end: even/odd tables, the 32 fixed indices, all-ones weights -> the first five scores of the
+    last batch are 0 0 K*H1*H2*H3 K*H1*H2*H3 0 (indices 3, 99, 38, 72, 29), as the reference prints them (cuda_server.c:499-502)."""
+    if not os.path.exists(os.path.join(HOST, "fleetrec_server")):
+        subprocess.check_call(["make", "-s", "-C", HOST])
+    port = 18080 + (0 if model == "A" else 40)
+    threads, total = 4, 64
+    srv = subprocess.Popen([os.path.join(HOST, "fleetrec_server"), "--model", model, "--batch", "128", "--threads", str(threads),
+                            "--port", str(port), "--total", str(total), "--tables", "evenodd", "--weights", "ones"] + extra,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    time.sleep(0.5)
+    snd = subprocess.Popen([os.path.join(HOST, "fleetrec_sender"), "--model", model, "--batch", "128", "--threads", str(threads),
+                            "--port", str(port), "--indices", "reference"] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    try:
+        out, _ = srv.communicate(timeout=300)
+        sout, _ = snd.communicate(timeout=60)
+    finally:
+        for p in (srv, snd):
+            if p.poll() is None:
+                p.kill()
+    out = out.decode()
+    assert srv.returncode == 0, out
+    assert "processed %d batches" % total in out, out
+    rows = re.findall(r"thread \d+ scores:((?: [-0-9.e+]+)+)", out)
+    assert len(rows) == threads
+    for r in rows:
+        v = [float(x) for x in r.split()]
+        assert v == [0.0, 0.0, val, val, 0.0], (v, out)
+    assert "Average time from batch received to enqueued" in out
+    assert "blocks sent" in sout.decode()
