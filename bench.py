@@ -126,6 +126,9 @@ def main():
                          "sharded by table-ID over the ranks + one RCCL all-gather of the looked-up slices (BASELINE configs[3])")
     ap.add_argument("--model", choices=["A", "B", "C"], default="A", help="A = BASELINE configs[1] (default headline); B/C: other configs")
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32", help="FC chain arithmetic (bf16 = BASELINE configs[2])")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="skip the multi-stream throughput loop and the Model-C leg: only the single-stream roofline launches run, so "
+                         "that a rocprofv3 --kernel-trace --stats summary of this command shows the kernel under the roofline's conditions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-model-c", action="store_true", help="skip the Model-C batch-4096 gather roofline leg")
     args = ap.parse_args()
@@ -192,6 +195,8 @@ def main():
             print("sweep threads=%d depth=%d: %.2f us/batch, %.2f M inf/s" % (th, dp, 1e6 * el / 2000, 2000 * B / el / 1e6), file=sys.stderr)
             dv.close()
 
+    if args.roofline_only:
+        args.steps, args.warmup, args.no_cpu_baseline, args.no_model_c = 8, 8, True, True
     driver.run_resident(B, args.warmup, d_idx)
     barrier()
     t0 = time.perf_counter()
