@@ -282,6 +282,15 @@ def main():
                                                  "unit": "GB/s", "frac": gb / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                  "avg_launch_ms": g_ms, "algorithmic_bytes_per_launch": gb}
 
+        # ---- PCIe-inclusive rate (host index buffers through fr_worker_submit/sync; reported, never `value`) ----------
+        if not args.roofline_only:
+            hd = fr.Driver(ctx, args.threads, 4, B)
+            hd.run_host(B, 200, idx_host)
+            el = hd.run_host(B, 2000, idx_host)
+            hd.close()
+            result["pcie_inclusive"] = {"value": 2000 * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / 2000,
+                                        "what": "index rows start in host memory: memcpy to pinned -> H2D -> 5 stage launches -> D2H -> sync per batch, "
+                                                "%d threads x 4 workers" % args.threads}
         # ---- CPU baseline: the oracle ("port": C, OpenMP over items) on this node's host cores, bounded sample (~10 s).
         #      (The 4-GEMM chain through numpy/OpenBLAS sgemm was measured 3x SLOWER than the oracle's own loops at this
         #      batch size on the 128-core host -- threading overhead on 256-row matrices -- so the oracle's chain is used.)

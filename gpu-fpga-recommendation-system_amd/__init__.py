@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
     "fr_device_synchronize", "fr_ctx_shard_info", "fr_driver_create", "fr_driver_destroy", "fr_driver_run_resident",
-    "fr_driver_worker", "fr_model_shard_plan", "fr_worker_fc_from_slices",
+    "fr_driver_worker", "fr_driver_run_host", "fr_model_shard_plan", "fr_worker_fc_from_slices",
 ]
 
 
@@ -105,6 +105,7 @@ def lib():
         "fr_driver_create": (i32, [vp, i32, i32, i32, ctypes.POINTER(vp)]), "fr_driver_destroy": (None, [vp]),
         "fr_driver_run_resident": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
         "fr_driver_worker": (vp, [vp, i32, i32]),
+        "fr_driver_run_host": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
         "fr_model_shard_plan": (i32, [ctypes.POINTER(ModelDesc), i32, pi, pi, ctypes.POINTER(ctypes.c_int)]),
         "fr_worker_fc_from_slices": (i32, [vp, i32, i32, i32, vp, vp]),
     }
@@ -439,6 +440,19 @@ class Driver:
         dp = (ctypes.c_void_p * n)(*[b.ptr.value for b in dense_pool]) if dense_pool else None
         el = ctypes.c_double()
         _check(lib().fr_driver_run_resident(self._h, batch, total_batches, ip, dp, n, ctypes.byref(el)))
+        return el.value
+
+    def run_host(self, batch, total_batches, idx_pool_np, dense_pool_np=None):
+        """idx_pool_np / dense_pool_np: lists of C-contiguous numpy arrays in host memory.  -> elapsed seconds (PCIe-inclusive)."""
+        n = len(idx_pool_np)
+        keep = [np.ascontiguousarray(a, dtype=np.int32) for a in idx_pool_np]
+        ip = (ctypes.c_void_p * n)(*[a.ctypes.data for a in keep])
+        dp = None
+        if dense_pool_np:
+            keepd = [np.ascontiguousarray(a, dtype=np.float32) for a in dense_pool_np]
+            dp = (ctypes.c_void_p * n)(*[a.ctypes.data for a in keepd])
+        el = ctypes.c_double()
+        _check(lib().fr_driver_run_host(self._h, batch, total_batches, ip, dp, n, ctypes.byref(el)))
         return el.value
 
     def close(self):

@@ -10,6 +10,7 @@
 // stream(s) never drain while the host prepares the next submit.
 #include <atomic>
 #include <chrono>
+#include <cstring>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -99,6 +100,67 @@ extern "C" int fr_driver_run_resident(fr_driver *d, int batch, int64_t total_bat
                 int r2 = fr_worker_sync(wk[s]);
                 if (rc == FR_OK) rc = r2;
             }
+            status[t] = rc;
+            if (rc) messages[t] = fr_last_error();
+        });
+    }
+    for (auto &th : threads) th.join();
+    FR_HIP(hipDeviceSynchronize());
+    *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int t = 0; t < d->n_threads; t++)
+        if (status[t]) FR_FAIL(status[t], "driver thread %d: %s", t, messages[t].c_str());
+    return FR_OK;
+}
+
+// Host-buffer form of the loop: every batch's index rows (and dense features) are copied from pageable host memory into
+// the worker's pinned buffers (standing in for the socket read(), cuda_server.c:425-450), then submit + sync per batch --
+// exactly the reference's per-batch sequence including the PCIe transfers (cuda_server.c:460-495).
+extern "C" int fr_driver_run_host(fr_driver *d, int batch, int64_t total_batches, const int32_t *const *h_idx_pool,
+                                  const float *const *h_dense_pool, int n_pool, double *elapsed_s) {
+    if (!d || !h_idx_pool || n_pool < 1 || !elapsed_s) FR_FAIL(FR_ERR_INVALID, "bad argument");
+    if (batch < 1 || batch > d->max_batch || total_batches < 0) FR_FAIL(FR_ERR_INVALID, "batch %d / total %lld out of range", batch, (long long)total_batches);
+    const fr_model_desc &m = d->ctx->model;
+    const size_t idx_bytes = (size_t)batch * (m.index_mode == FR_INDEX_PER_TABLE ? (size_t)m.n_tables : 1) * sizeof(int32_t);
+    const size_t dense_bytes = (size_t)batch * m.dense_len * sizeof(float);
+    if (dense_bytes && !h_dense_pool) FR_FAIL(FR_ERR_INVALID, "model has dense features but h_dense_pool is NULL");
+    std::mutex mtx;
+    int64_t global_batch_count = 0;
+    std::vector<int> status(d->n_threads, FR_OK);
+    std::vector<std::string> messages(d->n_threads);
+    std::vector<std::thread> threads;
+    FR_HIP(hipSetDevice(d->ctx->device));
+    FR_HIP(hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < d->n_threads; t++) {
+        threads.emplace_back([&, t]() {
+            fr_worker **wk = &d->workers[(size_t)t * d->depth];
+            std::vector<char> busy(d->depth, 0);
+            int64_t local = 0;
+            int rc = FR_OK;
+            while (rc == FR_OK) {
+                int64_t id;
+                {
+                    std::lock_guard<std::mutex> g(mtx);
+                    if (global_batch_count >= total_batches) break;
+                    id = global_batch_count++;
+                }
+                const int slot = (int)(local++ % d->depth);
+                if (busy[slot]) {  // one batch in flight per worker: its pinned buffers are reused
+                    rc = fr_worker_sync(wk[slot]);
+                    busy[slot] = 0;
+                    if (rc) break;
+                }
+                const int p = (int)(id % n_pool);
+                memcpy(fr_worker_idx_ptr(wk[slot]), h_idx_pool[p], idx_bytes);
+                if (dense_bytes) memcpy(fr_worker_dense_ptr(wk[slot]), h_dense_pool[p], dense_bytes);
+                rc = fr_worker_submit(wk[slot], batch);
+                if (rc == FR_OK) busy[slot] = 1;
+            }
+            for (int s = 0; s < d->depth; s++)
+                if (busy[s]) {
+                    int r2 = fr_worker_sync(wk[s]);
+                    if (rc == FR_OK) rc = r2;
+                }
             status[t] = rc;
             if (rc) messages[t] = fr_last_error();
         });

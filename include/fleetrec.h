@@ -251,6 +251,11 @@ void fr_driver_destroy(fr_driver *d);
  * Returns wall time from first submit to last completion (device drained on both sides). */
 int fr_driver_run_resident(fr_driver *d, int batch, int64_t total_batches, const int32_t *const *d_idx_pool,
                            const float *const *d_dense_pool, int n_pool, double *elapsed_s);
+/* Host-buffer form: batch id i copies h_idx_pool[i % n_pool] (pageable host memory; stands in for the socket read()) into a
+ * worker's pinned buffers, then fr_worker_submit + fr_worker_sync -- the reference's per-batch sequence including the PCIe
+ * transfers (cuda_server.c:425-495).  Returns wall time. */
+int fr_driver_run_host(fr_driver *d, int batch, int64_t total_batches, const int32_t *const *h_idx_pool,
+                       const float *const *h_dense_pool, int n_pool, double *elapsed_s);
 fr_worker *fr_driver_worker(fr_driver *d, int thread, int slot);
 
 /* ---- device memory helpers (so hosts/tests need no other GPU runtime binding) ---------------- */
