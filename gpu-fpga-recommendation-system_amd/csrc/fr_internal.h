@@ -160,6 +160,8 @@ int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx
 // feature-major FC chain, stage-pipelined across batches (see fr_kernels.hip)
 int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, int precision, hipStream_t s);
 int frk_pack_weights_q8_bf16(const float *W, uint16_t *Wh, int K, int H, hipStream_t s);
+bool frk_fc_h_tiled_ok(int K, int N, int ldm);
+int frk_fc_h_tiled(const void *Wh, const void *Xh, void *Yh, int K, int N, int ldm, hipStream_t s);
 int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, hipStream_t s);
 int frk_pack_weights_q4(const float *W, float *Wq, int K, int H, hipStream_t s);
 int frk_stage_blocks(int stage, int n_words, int K, int N, int ldm, int nsplit);

@@ -877,3 +877,99 @@ int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, 
     KCHECK();
     return FR_OK;
 }
+
+// ===================================================================================================
+// fc_h_tiled: LDS-tiled bf16 GEMM for layers that are large enough to fill the chip on their own (Model-C FC1 at batch
+// 4096 is 2048 x 4096 x 3968).  Same q8 operands and output as fc_h_body, but each 16-byte element is fetched from L2 ONCE
+// per 128 x 128 workgroup tile and shared through LDS: 64 FLOP per operand byte instead of 8.
+//   workgroup = 8 waves as 2 (n) x 4 (m); wave tile 64 (n) x 32 (m) = two 32x32x16 MFMA tiles sharing one B fragment;
+//   K step 64 (8 k-octs): LDS images As[ko][n], Bs[ko][m] of 16-byte elements -- a fragment read is a ds_read_b128 with
+//   consecutive lanes on consecutive elements (conflict-free), no transpose anywhere;
+//   register-staged double buffering (next tile's global loads fly during the MFMAs), one barrier per K step.
+// ===================================================================================================
+constexpr int FR_TL = 128;  // tile edge (n and m)
+constexpr int FR_TKO = 8;   // k-octs per K step (64 k)
+
+__global__ void __launch_bounds__(512) fc_h_tiled_kernel(const uint4 *__restrict__ Wh, const uint4 *__restrict__ Xh, uint2 *__restrict__ Yh,
+                                                         int K, int N, int ldm) {
+    __shared__ uint4 As[2][FR_TKO][FR_TL];
+    __shared__ uint4 Bs[2][FR_TKO][FR_TL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, wm = wave >> 1;
+    const int tn = N / FR_TL;
+    // XCD-aware order: workgroups b, b+8, ... (one XCD) walk one column of m tiles for a fixed set of n tiles
+    const int n_tile = blockIdx.x % tn, m_tile = blockIdx.x / tn;
+    const int n0 = n_tile * FR_TL, m0 = m_tile * FR_TL;
+    const int r = lane & 31, h = lane >> 5;
+    // staging roles: elements e = tid, tid + 512 of the 8 x 128 tile
+    const int e_ko = tid >> 7, e_c = tid & 127;  // second element: ko + 4
+    const uint4 *a_src = Wh + (size_t)e_ko * N + n0 + e_c;
+    const uint4 *b_src = Xh + (size_t)e_ko * ldm + m0 + e_c;
+    const int nkt = K / (8 * FR_TKO);
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc0[i] = acc1[i] = 0.0f;
+
+    uint4 ga0, ga1, gb0, gb1;
+    auto gload = [&](int kt) {
+        const size_t ko = (size_t)kt * FR_TKO;
+        ga0 = a_src[ko * N];
+        ga1 = a_src[(ko + 4) * N];
+        gb0 = b_src[ko * ldm];
+        gb1 = b_src[(ko + 4) * ldm];
+    };
+    auto lstore = [&](int buf) {
+        As[buf][e_ko][e_c] = ga0;
+        As[buf][e_ko + 4][e_c] = ga1;
+        Bs[buf][e_ko][e_c] = gb0;
+        Bs[buf][e_ko + 4][e_c] = gb1;
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) gload(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < FR_TKO / 2; kk++) {
+            const uint4 a0 = As[cur][2 * kk + h][wn * 64 + r];
+            const uint4 a1 = As[cur][2 * kk + h][wn * 64 + 32 + r];
+            const uint4 b = Bs[cur][2 * kk + h][wm * 32 + r];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, b), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, b), acc1, 0, 0, 0);
+        }
+        if (kt + 1 < nkt) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    // epilogue: ONE rounding to bf16; registers 4i..4i+3 of a tile are 4 consecutive n = one 8-byte half of a q8 element
+    const int m = m0 + wm * 32 + r;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const f32x16 &acc = t ? acc1 : acc0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint2 hv;
+            hv.x = pack_bf16x2(acc[4 * i + 0], acc[4 * i + 1]);
+            hv.y = pack_bf16x2(acc[4 * i + 2], acc[4 * i + 3]);
+            const int no = ((n0 + wn * 64 + 32 * t) >> 3) + i;  // n = n0 + wn*64 + 32t + 8i + 4h + c
+            Yh[((size_t)no * ldm + m) * 2 + h] = hv;
+        }
+    }
+}
+
+bool frk_fc_h_tiled_ok(int K, int N, int ldm) {
+    static const int forced = getenv("FR_BF16_TILED") ? atoi(getenv("FR_BF16_TILED")) : -1;  // experiment knob: 0 = never, 1 = whenever legal
+    if (K % (8 * FR_TKO) || N % FR_TL || ldm % FR_TL) return false;
+    if (forced == 0) return false;
+    if (forced == 1) return true;
+    return (long)(N / FR_TL) * (ldm / FR_TL) >= 192;  // enough tiles to fill 256 CUs
+}
+
+int frk_fc_h_tiled(const void *Wh, const void *Xh, void *Yh, int K, int N, int ldm, hipStream_t s) {
+    dim3 grid((N / FR_TL) * (ldm / FR_TL));
+    fc_h_tiled_kernel<<<grid, dim3(512), 0, s>>>(reinterpret_cast<const uint4 *>(Wh), reinterpret_cast<const uint4 *>(Xh),
+                                                 reinterpret_cast<uint2 *>(Yh), K, N, ldm);
+    KCHECK();
+    return FR_OK;
+}
