@@ -129,24 +129,25 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the multi-stream throughput loop and the Model-C leg: only the single-stream roofline launches run, so "
                          "that a rocprofv3 --kernel-trace --stats summary of this command shows the kernel under the roofline's conditions")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--share-device", action="store_true", help="plumbing test: ranks share the visible GPU(s) (use with --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-model-c", action="store_true", help="skip the Model-C batch-4096 gather roofline leg")
     args = ap.parse_args()
 
     if args.mode == "sharded":
         return main_sharded(args)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import importlib
+    import torch
+    fr = graft.load_package()
+    dist_mod = importlib.import_module("fleetrec_amd.dist")
+    env = dist_mod.DistEnv(args.backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    rank, world = env.rank, env.world
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_dev = max(fr.device_count(), 1)
+    local_rank = env.local_rank % n_dev if args.share_device else env.local_rank  # --share-device: plumbing test on one GPU
+    dist = env.dist
 
     fr = graft.load_package()
     if fr.device_count() < 1:
@@ -159,7 +160,7 @@ def main():
     ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
     if args.precision == "bf16":
         ctx.set_fc_precision(fr.FC_BF16)
-    rng = np.random.default_rng(SEED_IDX + rank)
+    rng = np.random.default_rng(dist_mod.replica_seed(SEED_IDX, rank))
     rows = model.rows()
     n_bufs = N_IDX_BUFFERS if args.model == "A" else 8
     idx_host = [(rng.random((B, model.n_tables)) * rows[None, :]).astype(np.int32) for _ in range(n_bufs)]
@@ -182,9 +183,9 @@ def main():
     driver = fr.Driver(ctx, args.threads, args.depth, B)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        env.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         ctx.synchronize()
 
     if args.sweep and rank == 0:
@@ -202,11 +203,7 @@ def main():
     t0 = time.perf_counter()
     driver.run_resident(B, args.steps, d_idx)
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = env.max_over_ranks(time.perf_counter() - t0)   # MAX over ranks
 
     result = None
     if rank == 0:
@@ -357,9 +354,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    env.close()
 
 
 if __name__ == "__main__":
