@@ -508,3 +508,94 @@ def test_bf16_chain(fr, O, ctxs, which, B):
     wk = fr.Worker(ctx, B)
     assert rel_err(wk.infer(idx, dense), ref32) <= 1e-3   # back to the exact-f32 chain
     wk.close()
+
+
+def _random_model(fr, rng):
+    """A random user-defined model: random table dims/rows, an optional dense block in the middle of the record, an
+    optional COPY pad, random FC widths.  Exercises the descriptor machinery beyond the three reference models."""
+    import ctypes
+    n_tables = int(rng.integers(1, 40))
+    dims = rng.choice([4, 8, 16, 32, 64], size=n_tables)
+    rows = rng.integers(1, 3000, size=n_tables)
+    dense_len = int(rng.choice([0, 0, 8, 64]))
+    tabs = (fr.TableDesc * n_tables)()
+    for t in range(n_tables):
+        tabs[t] = fr.TableDesc(mem_class=int(rng.integers(0, 3)), table_id=t % 256, source=0, dim=int(dims[t]), rows=int(rows[t]),
+                               bank=t, round=0, addr_axi=0)
+    segs, pos = [], 0
+    dense_at = int(rng.integers(0, n_tables + 1)) if dense_len else -1
+    copy_of = int(rng.integers(0, n_tables)) if rng.random() < 0.5 else -1
+    for t in range(n_tables + 1):
+        if t == dense_at:
+            segs.append((fr.SEG_DENSE, -1, 0, pos, dense_len, 0))
+            pos += dense_len
+        if t == n_tables:
+            break
+        segs.append((fr.SEG_TABLE, t, 0, pos, int(dims[t]), 0))
+        pos += int(dims[t])
+        if t == copy_of:
+            c0 = 4 * int(rng.integers(0, dims[t] // 4))
+            segs.append((fr.SEG_COPY, t, c0, pos, 4, 0))
+            pos += 4
+    if pos % 8:   # the FC chain moves operands in groups of 8 k: pad with a COPY of table 0's first word
+        segs.append((fr.SEG_COPY, 0, 0, pos, 4, 0))
+        pos += 4
+    # the dense block must form one contiguous "source" run: give it source id 2, tables before it 0, after it 1
+    fixed = []
+    seen_dense = False
+    for (k, src, c0, off, ln, _) in segs:
+        if k == fr.SEG_DENSE:
+            seen_dense = True
+            fixed.append((k, src, c0, off, ln, 2))
+        else:
+            fixed.append((k, src, c0, off, ln, 1 if seen_dense else 0))
+    S = (fr.Segment * len(fixed))(*[fr.Segment(kind=k, src=s_, src_col=c, rec_offset=o, len=l, source=sr) for k, s_, c, o, l, sr in fixed])
+    d = fr.ModelDesc()
+    d.name = b"random"
+    d.n_tables, d.n_segments = n_tables, len(fixed)
+    d.tables = ctypes.cast(tabs, ctypes.POINTER(fr.TableDesc))
+    d.segments = ctypes.cast(S, ctypes.POINTER(fr.Segment))
+    d.record_len, d.dense_len = pos, dense_len
+    fcw = [pos] + [int(32 * rng.integers(1, 9)) for _ in range(3)] + [1]
+    for i, v in enumerate(fcw):
+        d.fc[i] = v
+    return fr.Model(ctypes.pointer(d), keepalive=(tabs, S, d)), fixed, fcw
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_custom_models(fr, O, gpu, seed):
+    rng = np.random.default_rng(1000 + seed)
+    m, segs, fcw = _random_model(fr, rng)
+    ctx = fr.Context(m, device=gpu)
+    tabs = m.tables()
+    host = [rng.standard_normal((t.rows, t.dim)).astype(np.float32) for t in tabs]
+    for t, a in enumerate(host):
+        ctx.upload_table(t, a)
+    ws = [(rng.uniform(-1, 1, fcw[i] * fcw[i + 1]) / np.sqrt(fcw[i])).astype(np.float32) for i in range(4)]
+    for l in range(4):
+        ctx.set_weights(l, ws[l])
+    B = int(rng.integers(1, 300))
+    idx = uniform_idx(rng, m.rows(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32) if m.dense_len else None
+    # semantic definition of the record: concatenate the segments
+    want = np.empty((B, m.record_len), np.float32)
+    for (k, src, c0, off, ln, _) in segs:
+        if k == fr.SEG_DENSE:
+            want[:, off:off + ln] = dense[:, c0:c0 + ln]
+        else:
+            want[:, off:off + ln] = host[src][idx[:, src], c0:c0 + ln]
+    wk = fr.Worker(ctx, B)
+    got = wk.gather_records(idx, dense).reshape(B, m.record_len)
+    assert np.array_equal(got, want.view(np.uint32))
+    scores = wk.infer(idx, dense)
+    assert np.array_equal(wk.features(B), want.view(np.uint32).T)
+    ref = O.OracleModel("A").fc_chain(want, ws, acc64=True, dims=fcw)
+    assert rel_err(scores, ref) <= 1e-3
+    # the same model in the bf16 chain when its widths allow it (multiples of 16)
+    if all(v % 16 == 0 for v in fcw[:4]):
+        ctx.set_fc_precision(fr.FC_BF16)
+        w2 = fr.Worker(ctx, B)
+        assert rel_err(w2.infer(idx, dense), chain_bf16_reference(want, ws, fcw)) <= 5e-3
+        w2.close()
+    wk.close()
+    ctx.close()
