@@ -79,16 +79,24 @@ def main_sharded(args):
     dns = [fr.DeviceBuffer.from_numpy(ctx, rng.uniform(-1, 1, (B, model.dense_len)).astype(np.float32)) for _ in range(nbuf)]
     wk = fr.Worker(ctx, B)
     local = torch.empty((B, F), dtype=torch.float32, device=dev)          # torch owns the exchange buffers (RCCL plumbing)
-    gathered = torch.empty((G, B, F), dtype=torch.float32, device=dev)
+    a2a = args.exchange == "alltoall"
+    if a2a and B % G:
+        raise SystemExit("--exchange alltoall needs the batch divisible by the number of ranks")
+    gathered = torch.empty((G, B // G if a2a else B, F), dtype=torch.float32, device=dev)
     lo, hi = dist_mod.item_range(r, G, B)
     scores = torch.empty((max(hi - lo, 1),), dtype=torch.float32, device=dev)
 
     def step(i):
         wk.gather_only(B, idxs[i % nbuf], dns[i % nbuf], local.data_ptr())
         wk.sync()                                      # the slice must be complete before RCCL reads it (different stream)
-        env.all_gather_slices(local, gathered)
-        torch.cuda.synchronize()
-        wk.fc_from_slices(B, lo, hi - lo, gathered.data_ptr(), scores.data_ptr())
+        if a2a:
+            env.all_to_all_slices(local, gathered)
+            torch.cuda.synchronize()
+            wk.fc_from_slices(B // G, 0, hi - lo, gathered.data_ptr(), scores.data_ptr())
+        else:
+            env.all_gather_slices(local, gathered)
+            torch.cuda.synchronize()
+            wk.fc_from_slices(B, lo, hi - lo, gathered.data_ptr(), scores.data_ptr())
         wk.sync()
 
     for i in range(args.warmup):
@@ -105,8 +113,8 @@ def main_sharded(args):
             "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Model-C batch=%d, %d-way table-ID shards (slice F=%d floats), 1 all-gather of [B x F] per step, "
-                                   "FC on B/G items per rank" % (B, G, F), "parallelism": "table-sharded x%d" % G,
-                       "allgather_bytes_per_rank_per_step": int(G * B * F * 4)}}))
+                                   "FC on B/G items per rank" % (B, G, F), "parallelism": "table-sharded x%d" % G, "exchange": args.exchange,
+                       "exchange_bytes_in_per_rank_per_step": int(G * (B // G if a2a else B) * F * 4)}}))
     wk.close()
     ctx.close()
     env.close()
@@ -129,6 +137,8 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the multi-stream throughput loop and the Model-C leg: only the single-stream roofline launches run, so "
                          "that a rocprofv3 --kernel-trace --stats summary of this command shows the kernel under the roofline's conditions")
+    ap.add_argument("--exchange", choices=["allgather", "alltoall"], default="allgather",
+                    help="sharded mode: all-gather every slice to every rank (BASELINE configs[3]) or all-to-all only each rank's items")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true", help="plumbing test: ranks share the visible GPU(s) (use with --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -73,6 +73,19 @@ class DistEnv:
         self.dist.all_gather_into_tensor(out.view((self.world * local.shape[0],) + tuple(local.shape[1:])), local.contiguous())
         return out
 
+    def all_to_all_slices(self, local, out=None):
+        """local: torch tensor [B, F], B divisible by world.  Rank r keeps only the items it will run the FC chain on:
+        it sends rows [j*B/G, (j+1)*B/G) of its slice to rank j and receives every shard's slice of ITS items
+        -> [world, B/world, F].  1/world of the all-gather's traffic."""
+        B = local.shape[0]
+        if self.dist is None:
+            return local.reshape((1,) + tuple(local.shape))
+        assert B % self.world == 0, "all-to-all exchange needs the batch divisible by the number of shards"
+        if out is None:
+            out = self.torch.empty((self.world, B // self.world) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        self.dist.all_to_all_single(out.view((B,) + tuple(local.shape[1:])), local.contiguous())
+        return out
+
     def close(self):
         if self.dist is not None:
             self.dist.barrier()

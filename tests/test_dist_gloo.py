@@ -55,6 +55,11 @@ WORKER = textwrap.dedent('''
     tot = torch.from_numpy(pad.copy()); env.dist.all_reduce(tot)
     ref = om.fc_chain(full.view(np.float32), ws)
     assert np.array_equal(tot.numpy(), ref)
+    # --- all-to-all variant: every rank receives only ITS items' slices (1/world of the all-gather traffic) --------
+    mine = env.all_to_all_slices(torch.from_numpy(local.view(np.int32))).numpy().view(np.uint32)
+    assert mine.shape == (2, B // 2, F)
+    assert (lo, hi) == (env.rank * B // 2, (env.rank + 1) * B // 2)
+    assert np.array_equal(dist_mod.assemble_records(mine, offs, lens, model.record_len), full[lo:hi])
     cover = [dist_mod.item_range(r, 2, B) for r in range(2)]
     assert cover[0][0] == 0 and cover[0][1] == cover[1][0] and cover[1][1] == B
     env.close()

@@ -438,6 +438,15 @@ def test_table_sharded_mode_single_device_emulation(fr, O, gpu, which, G):
         wk.sync()
         scores[lo:hi] = d_s.download(np.float32, hi - lo)
     assert rel_err(scores, ref) <= 1e-3
+    # all-to-all variant (section 8(f) N2): a rank only receives ITS items' slices -> [G][hi-lo][F]; same scores bit for bit
+    for r, (c, wk) in enumerate(ctxs_):
+        lo, hi = dist_mod.item_range(r, G, B)
+        mine = np.ascontiguousarray(gathered[:, lo:hi, :])
+        d_g = fr.DeviceBuffer.from_numpy(c, mine)
+        d_s = fr.DeviceBuffer(c, max(hi - lo, 1) * 4)
+        wk.fc_from_slices(hi - lo, 0, hi - lo, d_g, d_s)
+        wk.sync()
+        assert np.array_equal(d_s.download(np.float32, hi - lo), scores[lo:hi])
     # unsharded context on the same inputs: same records, scores equal up to the split-K order of a different batch size
     c0 = fr.Context(m, device=gpu)
     c0.fill_tables(fr.FILL_HASH, SEED_TABLES)
