@@ -138,6 +138,76 @@ class Model:
             _check(FR_ERR_INVALID)
         return cls(p)
 
+    @classmethod
+    def from_spec(cls, spec):
+        """Build a user-defined model from a plain dict (the run-time counterpart of the reference's generated
+        constants.hpp, FPGA/kernel/user_krnl/embedding_47_krnl/src/hls/constants.hpp:28,505):
+
+            {"name": "my_model",
+             "tables": [{"dim": 8, "rows": 100000, "class": "HBM"}, ...],     # listed in record (wire) order
+             "dense_len": 0,                                                    # floats per item supplied by the request
+             "dense_at": 0,                                                     # table position the dense block precedes
+             "pad": [{"after_table": 3, "copy_of": 1, "col": 0}],               # optional 4-float COPY pads
+             "fc": [1024, 512, 256]}                                            # hidden widths; K = record length, OUT = 1
+
+        The description is validated by the library (fr_model_clone_scaled -> fr_model_validate)."""
+        tabs_in = spec["tables"]
+        n = len(tabs_in)
+        tabs = (TableDesc * n)()
+        cls_id = {"HBM": 0, "DDR": 1, "PLRAM": 2}
+        for t, d in enumerate(tabs_in):
+            tabs[t] = TableDesc(mem_class=cls_id.get(d.get("class", "HBM"), 0), table_id=t % 256, source=0, dim=int(d["dim"]),
+                                rows=int(d["rows"]), bank=t, round=0, addr_axi=0)
+        dense_len, dense_at = int(spec.get("dense_len", 0)), int(spec.get("dense_at", 0))
+        pads = {int(p_["after_table"]): p_ for p_ in spec.get("pad", [])}
+        segs, pos, seen_dense = [], 0, False
+        for t in range(n + 1):
+            if dense_len and t == dense_at:
+                segs.append((SEG_DENSE, -1, 0, pos, dense_len, 2))
+                pos += dense_len
+                seen_dense = True
+            if t == n:
+                break
+            src_id = 1 if seen_dense else 0
+            segs.append((SEG_TABLE, t, 0, pos, int(tabs_in[t]["dim"]), src_id))
+            pos += int(tabs_in[t]["dim"])
+            if t in pads:
+                segs.append((SEG_COPY, int(pads[t]["copy_of"]), int(pads[t].get("col", 0)), pos, 4, src_id))
+                pos += 4
+        S = (Segment * len(segs))(*[Segment(kind=k, src=s_, src_col=c, rec_offset=o, len=l, source=sr) for k, s_, c, o, l, sr in segs])
+        d = ModelDesc()
+        d.name = spec.get("name", "custom").encode()[:31]
+        d.n_tables, d.n_segments = n, len(segs)
+        d.tables = ctypes.cast(tabs, ctypes.POINTER(TableDesc))
+        d.segments = ctypes.cast(S, ctypes.POINTER(Segment))
+        d.record_len, d.dense_len = pos, dense_len
+        fcw = [pos] + [int(v) for v in spec["fc"]] + [1]
+        if len(fcw) != 5:
+            raise FleetRecError(FR_ERR_INVALID, "spec['fc'] must list exactly three hidden widths")
+        for i, v in enumerate(fcw):
+            d.fc[i] = v
+        tmp = cls(ctypes.pointer(d), keepalive=(tabs, S, d))
+        return tmp.clone()  # validated deep copy owned by the library
+
+    def placement_report(self, l2_bytes=4 << 20, mall_bytes=256 << 20):
+        """Where each table will live on MI355X when accessed uniformly, and what the gather costs per item: the
+        MicroRec/FleetRec placement question (on-chip PLRAM vs HBM vs DDR banks) mapped onto L2 / Infinity Cache / HBM.
+        A row costs one 128-byte line beyond L2 whatever its size (profiles/r01_experiments.md)."""
+        tabs = self.tables()
+        order = sorted(range(len(tabs)), key=lambda t: tabs[t].rows * tabs[t].dim * 4)
+        cum, out = 0, []
+        for t in order:
+            b = tabs[t].rows * tabs[t].dim * 4
+            cum += b
+            level = "L2" if cum <= 8 * l2_bytes else ("InfinityCache" if cum <= mall_bytes else "HBM")
+            out.append({"table": t, "class": MEM_CLASS_NAMES[tabs[t].mem_class], "id": tabs[t].table_id, "dim": tabs[t].dim,
+                        "rows": tabs[t].rows, "bytes": b, "level": level})
+        rows_per_item = len(tabs)
+        useful = sum(t.dim * 4 for t in tabs)
+        return {"tables": sorted(out, key=lambda e: e["table"]), "table_bytes": cum, "rows_per_item": rows_per_item,
+                "useful_row_bytes_per_item": useful, "line_bytes_per_item_beyond_l2": 128 * sum(1 for e in out if e["level"] != "L2"),
+                "levels": {lv: sum(1 for e in out if e["level"] == lv) for lv in ("L2", "InfinityCache", "HBM")}}
+
     def clone(self, row_scale=1.0, min_rows=1, max_rows=0, layout=None, index_mode=None):
         out = ctypes.POINTER(ModelDesc)()
         _check(lib().fr_model_clone_scaled(self._ptr, row_scale, min_rows, max_rows, ctypes.byref(out)))

@@ -206,3 +206,19 @@ def test_model_clone_and_validation(fr):
     with pytest.raises(fr.FleetRecError) as e:
         bad.clone()
     assert "segment" in str(e.value)
+
+
+def test_model_from_spec_and_placement(fr):
+    spec = {"name": "tiny", "tables": [{"dim": 4, "rows": 100, "class": "PLRAM"}, {"dim": 8, "rows": 5000}, {"dim": 32, "rows": 2000000, "class": "DDR"}],
+            "dense_len": 8, "dense_at": 1, "pad": [{"after_table": 2, "copy_of": 0, "col": 0}], "fc": [64, 32, 32]}
+    m = fr.Model.from_spec(spec)
+    assert (m.n_tables, m.record_len, m.dense_len, m.fc) == (3, 4 + 8 + 8 + 32 + 4, 8, [56, 64, 32, 32, 1])
+    kinds = [(s.kind, s.rec_offset, s.len) for s in m.segments()]
+    assert kinds == [(fr.SEG_TABLE, 0, 4), (fr.SEG_DENSE, 4, 8), (fr.SEG_TABLE, 12, 8), (fr.SEG_TABLE, 20, 32), (fr.SEG_COPY, 52, 4)]
+    rep = m.placement_report()
+    assert rep["levels"] == {"L2": 2, "InfinityCache": 1, "HBM": 0} and rep["rows_per_item"] == 3
+    assert fr.Model.builtin(fr.MODEL_C).placement_report()["levels"]["HBM"] > 0
+    with pytest.raises(fr.FleetRecError):
+        fr.Model.from_spec(dict(spec, fc=[60, 32, 32]))   # width not a multiple of 32
+    with pytest.raises(fr.FleetRecError):
+        fr.Model.from_spec(dict(spec, tables=[{"dim": 6, "rows": 10}]))  # dim not a multiple of 4
