@@ -290,7 +290,7 @@ def main():
                                                  "avg_launch_ms": g_ms, "algorithmic_bytes_per_launch": gb}
 
         # ---- PCIe-inclusive rate (host index buffers through fr_worker_submit/sync; reported, never `value`) ----------
-        if not args.roofline_only:
+        if not args.roofline_only and world == 1:
             hd = fr.Driver(ctx, args.threads, 4, B)
             hd.run_host(B, 200, idx_host)
             el = hd.run_host(B, 2000, idx_host)
@@ -301,7 +301,7 @@ def main():
         # ---- CPU baseline: the oracle ("port": C, OpenMP over items) on this node's host cores, bounded sample (~10 s).
         #      (The 4-GEMM chain through numpy/OpenBLAS sgemm was measured 3x SLOWER than the oracle's own loops at this
         #      batch size on the 128-core host -- threading overhead on 256-row matrices -- so the oracle's chain is used.)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (bench contract)
             O = graft.load_oracle()
             om = O.OracleModel("A")
             ws = [ctx.get_weights(l) for l in range(4)]

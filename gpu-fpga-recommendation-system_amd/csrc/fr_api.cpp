@@ -533,12 +533,21 @@ static int pipeline_step(fr_worker *w) {
         for (int l = 0; l < 4; l++)
             wl[l] = bf16 ? reinterpret_cast<const float *>(c->d_w_bf16[l]) : (l < 3 ? c->d_wq[l] : c->d_w[3]);
         switch (s) {
-            case 0:
+            case 0: {
                 a.idx = sl.d_idx;
                 a.dense = sl.d_dense;
                 st.out = wr.x;
                 w->last_x_parity = par;
+                const int trb = frk_gather_tr_blocks(c->n_words, ldm);
+                if (trb > 0) {  // large batch: LDS-transposing gather
+                    st.variant = 1;
+                    blocks += (trb + 7) / 8 * 8;
+                    n_stages++;
+                    only = s;
+                    continue;
+                }
                 break;
+            }
             case 1:
                 st.K = fc[0]; st.N = fc[1]; st.nsplit = ns1; st.nparts_in = 1;
                 st.in = rd.x; st.in_part_stride = 0; st.out = wr.r1; st.part_stride = (int)wr.p1; st.w = wl[0];

@@ -54,6 +54,7 @@ struct FrStageArgs {
     int nsplit;       // FC stages: workgroups along K per output tile (partials written to out + p*part_stride);
                       // K % (8 * nsplit) == 0 is required (groups of 8 k)
     int nparts_in;    // FC/out stages: partial inputs to add while loading (1 or 2)
+    int variant;      // gather stage: 1 = LDS-transposing form for large batches (see gather_tr_body)
     int part_stride;  // floats between the partial OUTPUT buffers
     int in_part_stride;  // floats between the partial INPUT buffers
     const float *in;  // activations in (feature-major)
@@ -165,6 +166,7 @@ int frk_fc_h_tiled(const void *Wh, const void *Xh, void *Yh, int K, int N, int l
 int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, hipStream_t s);
 int frk_pack_weights_q4(const float *W, float *Wq, int K, int H, hipStream_t s);
 int frk_stage_blocks(int stage, int n_words, int K, int N, int ldm, int nsplit);
+int frk_gather_tr_blocks(int n_words, int ldm);  // 0 when the transposing gather does not apply
 int frk_transpose_records(const float *X, float *Xt, int batch, int K, int ldm, hipStream_t s);
 int frk_transpose_slices(const float *gathered, int n_shards, int batch_total, int slice_padded, const int *h_offsets, const int *h_lens,
                          int item0, int n_items, float *Xq, int ldm, hipStream_t s);

@@ -324,6 +324,94 @@ __device__ __forceinline__ void gather_q_body(const FrPipeArgs &a, const FrStage
     if (bad) atomicOr_system(a.err_flag, 1);  // pinned host word; error path only
 }
 
+// ---- stage 0, large batches: gather with an LDS transpose.  The lanes-along-items form above issues one 16-byte request
+// per (item, record word): a dim-16 row is fetched by four separate wave-instructions, and all 64 lanes of an instruction
+// hit 64 different lines.  Here a workgroup owns a tile of 32 items x 64 record words: phase 1 loads with lanes along
+// WORDS (a row is read by dim/4 adjacent lanes of one instruction, like gather_pack_kernel) into an LDS tile, phase 2 reads
+// the tile transposed (row stride 65 x 16 B: conflict-free ds_read_b128) and stores with lanes along ITEMS (512 contiguous
+// bytes per half-wave) in the chain's q4 (PREC 0) or bf16 q8 (PREC 1) layout.
+constexpr int FR_GT_ITEMS = 32, FR_GT_WORDS = 64, FR_GT_LD = 65;
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi);
+
+template <int PREC>
+__device__ __forceinline__ void gather_tr_body(const FrPipeArgs &a, const FrStageArgs &st, int local, uint4 *tile /* [32][65] */) {
+    const int m_blocks = st.ldm / FR_GT_ITEMS;
+    const int mb = local % m_blocks, wb = local / m_blocks;
+    const int m0 = mb * FR_GT_ITEMS, w0 = wb * FR_GT_WORDS;
+    if (w0 >= a.n_words) return;  // padding workgroup
+    {   // phase 1: lanes along words
+        const int wl = threadIdx.x & 63, ig = threadIdx.x >> 6;
+        const int w = w0 + wl;
+        bool bad = false;
+        if (w < a.n_words) {
+            const uint4 d0 = reinterpret_cast<const uint4 *>(a.words)[2 * w];
+            const uint4 d1 = reinterpret_cast<const uint4 *>(a.words)[2 * w + 1];
+            const uint64_t src = ((uint64_t)d0.y << 32) | d0.x;
+            const uint32_t stride = d0.z, idx_col = d0.w, rows = d1.x;
+            const bool is_dense = (idx_col & FR_DESC_DENSE) != 0;
+            const char *base = is_dense ? reinterpret_cast<const char *>(a.dense) + src : reinterpret_cast<const char *>(src);
+            uint32_t id[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int m = m0 + 4 * ig + i;
+                id[i] = 0;
+                if (m < st.batch) id[i] = is_dense ? (uint32_t)m : (uint32_t)a.idx[(size_t)m * a.idx_stride + idx_col];
+                if (!is_dense && id[i] >= rows) {
+                    bad = true;
+                    id[i] = 0;
+                }
+            }
+            uint4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const uint4 *>(base + (uint64_t)id[i] * stride);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int m = m0 + 4 * ig + i;
+                tile[(4 * ig + i) * FR_GT_LD + wl] = (m < st.batch) ? v[i] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        if (bad) atomicOr_system(a.err_flag, 1);
+    }
+    __syncthreads();
+    {   // phase 2: lanes along items
+        const int il = threadIdx.x & 31, ws = threadIdx.x >> 5;  // 16 word slots
+        const int m = m0 + il;
+        if constexpr (PREC == 0) {
+            uint4 *Xq = reinterpret_cast<uint4 *>(st.out);
+#pragma unroll
+            for (int j = 0; j < FR_GT_WORDS / 16; j++) {
+                const int wl = ws + 16 * j, w = w0 + wl;
+                if (w < a.n_words) Xq[(size_t)w * st.ldm + m] = tile[il * FR_GT_LD + wl];  // SEMANTIC layout: dst word == w
+            }
+        } else {
+            uint4 *Xh = reinterpret_cast<uint4 *>(st.out);  // q8 element = record words 2p, 2p+1
+#pragma unroll
+            for (int j = 0; j < FR_GT_WORDS / 32; j++) {
+                const int pl = ws + 16 * j, w = w0 + 2 * pl;
+                if (w < a.n_words) {
+                    const uint4 lo = tile[il * FR_GT_LD + 2 * pl], hi = tile[il * FR_GT_LD + 2 * pl + 1];
+                    uint4 h;
+                    h.x = pack_bf16x2(__uint_as_float(lo.x), __uint_as_float(lo.y));
+                    h.y = pack_bf16x2(__uint_as_float(lo.z), __uint_as_float(lo.w));
+                    h.z = pack_bf16x2(__uint_as_float(hi.x), __uint_as_float(hi.y));
+                    h.w = pack_bf16x2(__uint_as_float(hi.z), __uint_as_float(hi.w));
+                    Xh[(size_t)(w >> 1) * st.ldm + m] = h;
+                }
+            }
+        }
+    }
+}
+
+int frk_gather_tr_blocks(int n_words, int ldm) {
+    if (ldm % FR_GT_ITEMS || (n_words & 1)) return 0;
+    const int blocks = (ldm / FR_GT_ITEMS) * ((n_words + FR_GT_WORDS - 1) / FR_GT_WORDS);
+    static const int forced = getenv("FR_GATHER_TR") ? atoi(getenv("FR_GATHER_TR")) : -1;  // experiment knob
+    if (forced == 0) return 0;
+    if (forced == 1) return blocks;
+    return blocks >= 128 ? blocks : 0;  // needs enough workgroups to cover the chip; small batches keep the simple form
+}
+
 static int gather_q_blocks(int n_words, int ldm) { return ((ldm + 63) / 64) * ((n_words + FR_PIPE_WAVES * 2 - 1) / (FR_PIPE_WAVES * 2)); }
 
 // ---- stages 1..3: one 32(n) x 32(m) output tile per workgroup, 8 waves split the workgroup's K range in groups of
@@ -684,7 +772,8 @@ __device__ __forceinline__ void fc_out_h_body(const FrStageArgs &st, int local, 
 // PREC: 0 = fp32 chain (q4 operands, exact-f32 MFMA), 1 = bf16 chain (q8 operands, bf16 MFMA, fp32 accumulate).
 template <int STAGE, int PREC>
 __global__ void __launch_bounds__(FR_PIPE_THREADS) fr_pipeline_kernel(const FrPipeArgs a) {
-    __shared__ float red[FR_PIPE_WAVES * 16 * 64];  // 32 KiB
+    __shared__ uint4 smem[FR_GT_ITEMS * FR_GT_LD];  // 33,280 B: the gather tile; the FC stages use the first 32 KiB as float red[8][16][64]
+    float *red = reinterpret_cast<float *>(smem);
     const int b = blockIdx.x;
     int s = 0;
     if constexpr (STAGE >= 0) {
@@ -697,7 +786,9 @@ __global__ void __launch_bounds__(FR_PIPE_THREADS) fr_pipeline_kernel(const FrPi
     const int local = b - st.block_begin;
     unsigned long long t_in = 0;
     if (a.stamps) t_in = __builtin_amdgcn_s_memrealtime();  // diagnostics only; the values never feed an output
-    if constexpr (PREC == 1) {
+    if (s == 0 && st.variant == 1) {
+        gather_tr_body<PREC>(a, st, local, smem);
+    } else if constexpr (PREC == 1) {
         if (s == 0) gather_h_body(a, st, local);
         else if (s == 4) fc_out_h_body(st, local, red);
         else fc_h_body(st, local, red);
