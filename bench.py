@@ -123,10 +123,10 @@ def main_sharded(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=8000)
+    ap.add_argument("--warmup", type=int, default=800)
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--threads", type=int, default=4, help="host driver threads (reference THREAD_NUM = 4, constant.h:42)")
+    ap.add_argument("--threads", type=int, default=2, help="host driver threads (reference THREAD_NUM = 4, constant.h:42)")
     ap.add_argument("--depth", type=int, default=2, help="workers (streams) each driver thread keeps in flight")
     ap.add_argument("--sweep", action="store_true", help="also print a threads x depth sweep to stderr (experiments)")
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
@@ -229,32 +229,35 @@ def main():
                        "parallelism": "replicas x%d" % world},
         }
         # ---- roofline of the dominant kernel: measured live with HIP events on the worker's stream ----
-        # fr_pipeline_kernel<-1> = one pipelined launch: gather | FC1 | FC2 | FC3 | out, each on a different batch of the
-        # worker, i.e. exactly one batch worth of work (all 4 GEMMs) per launch.
+        # Model-A streams through fr_fused_tile_kernel: ONE launch = the whole hot path (gather + 4 GEMMs) of `group` queued
+        # batches, 32 items per workgroup.  (Models that do not fit LDS use fr_pipeline_kernel<-1>, group = 1.)
+        group = ctx.stream_group()
         wk = fr.Worker(ctx, B)
-        ring = [fr.DeviceBuffer(ctx, B * 4) for _ in range(8)]
-        for i in range(64):
-            wk.push_device(B, d_idx[i % N_IDX_BUFFERS], None, ring[i % 8])
+        ring = [fr.DeviceBuffer(ctx, B * 4) for _ in range(max(8, 2 * group))]
+        for i in range(4 * group):
+            wk.push_device(B, d_idx[i % N_IDX_BUFFERS], None, ring[i % len(ring)])
         wk.sync()
-        reps = 1000
-        for i in range(8):   # refill the pipeline so that every timed launch carries all five stages
-            wk.push_device(B, d_idx[i % N_IDX_BUFFERS], None, ring[i % 8])
+        launches = 60 if group > 1 else 1000
+        if group == 1:
+            for i in range(8):   # refill the stage pipeline so that every timed launch carries all five stages
+                wk.push_device(B, d_idx[i % N_IDX_BUFFERS], None, ring[i % len(ring)])
         wk.timer_start()
-        for i in range(reps):
-            wk.push_device(B, d_idx[i % N_IDX_BUFFERS], None, ring[i % 8])
-        pipe_ms = wk.timer_stop_ms() / reps
+        for i in range(launches * group):
+            wk.push_device(B, d_idx[i % N_IDX_BUFFERS], None, ring[i % len(ring)])
+        pipe_ms = wk.timer_stop_ms() / launches
         wk.sync()
         fc = model.fc
-        flops = fc_flops_per_inference(fc) * B
+        flops = fc_flops_per_inference(fc) * B * group
         ach = flops / (pipe_ms * 1e-3) / 1e12
+        kname = "fr_fused_tile_kernel<2, 44, 11>" if group > 1 else "fr_pipeline_kernel<-1, 0>"
         result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": ach / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("fr_pipeline_kernel<-1, 0>"),
+                              "frac": ach / MFMA_F32_PEAK_TF, "traffic": pmc_traffic(kname),
                               "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
                                                 "FETCH_SIZE x2 gfx950 correction), bytes per launch",
-                              "kernel": "fr_pipeline_kernel<-1, 0> (one launch = gather|FC1|FC2|FC3|out of 5 consecutive batches = one "
-                                        "batch worth of the 4-GEMM chain), back-to-back on ONE stream",
-                              "avg_launch_ms": pipe_ms, "algorithmic_flops_per_launch": flops,
-                              "note": "value above runs %d such streams concurrently" % (args.threads * args.depth)}
+                              "kernel": "%s: one launch = the whole hot path (gather + the 4-GEMM chain) of %d queued batches of %d, "
+                                        "back-to-back on ONE stream" % (kname, group, B),
+                              "batches_per_launch": group, "avg_launch_ms": pipe_ms, "algorithmic_flops_per_launch": flops,
+                              "note": "`value` above runs %d such streams concurrently" % (args.threads * args.depth)}
         # per-stage launches (unpipelined submit path), for reference
         d_sc = ring[0]
         wk.submit_device(B, d_idx[0], None, d_sc)

@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
     "fr_device_synchronize", "fr_ctx_shard_info", "fr_driver_create", "fr_driver_destroy", "fr_driver_run_resident",
-    "fr_driver_worker", "fr_driver_run_host", "fr_model_shard_plan", "fr_worker_fc_from_slices",
+    "fr_driver_worker", "fr_driver_run_host", "fr_ctx_stream_group", "fr_ctx_set_stream_group", "fr_model_shard_plan", "fr_worker_fc_from_slices",
 ]
 
 
@@ -104,7 +104,7 @@ def lib():
         "fr_ctx_shard_info": (i32, [vp] + [ctypes.POINTER(ctypes.c_int)] * 5),
         "fr_driver_create": (i32, [vp, i32, i32, i32, ctypes.POINTER(vp)]), "fr_driver_destroy": (None, [vp]),
         "fr_driver_run_resident": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
-        "fr_driver_worker": (vp, [vp, i32, i32]),
+        "fr_driver_worker": (vp, [vp, i32, i32]), "fr_ctx_stream_group": (i32, [vp]), "fr_ctx_set_stream_group": (i32, [vp, i32]),
         "fr_driver_run_host": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
         "fr_model_shard_plan": (i32, [ctypes.POINTER(ModelDesc), i32, pi, pi, ctypes.POINTER(ctypes.c_int)]),
         "fr_worker_fc_from_slices": (i32, [vp, i32, i32, i32, vp, vp]),
@@ -368,6 +368,12 @@ class Context:
         v = [ctypes.c_int() for _ in range(5)]
         _check(lib().fr_ctx_shard_info(self._h, *[ctypes.byref(x) for x in v]))
         return dict(zip(["shard_rank", "n_shards", "slice_offset", "slice_len", "slice_padded"], [x.value for x in v]))
+
+    def stream_group(self):
+        return lib().fr_ctx_stream_group(self._h)
+
+    def set_stream_group(self, batches_per_launch):
+        _check(lib().fr_ctx_set_stream_group(self._h, batches_per_launch))
 
     def synchronize(self):
         _check(lib().fr_device_synchronize(self._h))

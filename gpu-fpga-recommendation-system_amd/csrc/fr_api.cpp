@@ -45,6 +45,9 @@ static int select_device(int device) {
     return FR_OK;
 }
 
+static unsigned long long *g_stamp_buffer = nullptr;  // diagnostics (tools/experiments): see fr_debug_set_stamp_buffer
+extern "C" __attribute__((visibility("default"))) void fr_debug_set_stamp_buffer(void *dptr) { g_stamp_buffer = (unsigned long long *)dptr; }
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -472,8 +475,6 @@ static int launch_gather(fr_worker *w, int batch, const int32_t *d_idx, const fl
 }
 
 // ---- the stage pipeline ------------------------------------------------------------------------------
-static unsigned long long *g_stamp_buffer = nullptr;  // diagnostics (tools/experiments): see fr_debug_set_stamp_buffer
-extern "C" __attribute__((visibility("default"))) void fr_debug_set_stamp_buffer(void *dptr) { g_stamp_buffer = (unsigned long long *)dptr; }
 
 // K-split of one FC layer into 2 workgroups per output tile (partials summed by the next stage's loads):
 // only when the layer has fewer tiles than CUs and each wave still gets >= 16 k-pairs.
@@ -617,6 +618,63 @@ static int pipeline_flush(fr_worker *w) {
     return FR_OK;
 }
 
+// ---- fused item-tile path (fr_fused_tile_kernel): used by the streaming push for models whose activations fit in LDS --
+// Batches per fused launch: 32 x 8 workgroups = 256 = one per CU, so ONE stream's launch fills the chip.  Lower it to trade
+// throughput for latency (fr_ctx_set_stream_group; env FR_FUSED_GROUP sets the initial value).
+static int g_fused_group = [] {
+    const char *e = getenv("FR_FUSED_GROUP");
+    int v = e ? atoi(e) : FR_FUSED_MAX_BATCHES;
+    return v < 1 ? 1 : (v > FR_FUSED_MAX_BATCHES ? FR_FUSED_MAX_BATCHES : v);
+}();
+static int fused_group() { return g_fused_group; }
+
+static bool fused_eligible(const fr_ctx *c) {
+    static const int enabled = getenv("FR_FUSED") ? atoi(getenv("FR_FUSED")) : 1;  // experiment knob
+    const int32_t *fc = c->model.fc;
+    return enabled && c->fc_precision == FR_FC_FP32 && c->n_shards == 1 && c->model.layout == FR_LAYOUT_SEMANTIC &&
+           frk_fused_ok(fc[0], fc[1], fc[2], fc[3]);
+}
+
+// Batches one streaming launch carries on this context: 1 for the stage pipeline, the fused kernel's group otherwise.
+extern "C" int fr_ctx_set_stream_group(fr_ctx *ctx, int batches_per_launch) {
+    if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
+    if (batches_per_launch < 1 || batches_per_launch > FR_FUSED_MAX_BATCHES)
+        FR_FAIL(FR_ERR_INVALID, "batches_per_launch %d outside [1, %d]", batches_per_launch, FR_FUSED_MAX_BATCHES);
+    g_fused_group = batches_per_launch;  // process-wide knob (all contexts share it)
+    return FR_OK;
+}
+
+extern "C" int fr_ctx_stream_group(const fr_ctx *ctx) { return (ctx && fused_eligible(ctx)) ? fused_group() : 1; }
+
+static int fused_flush(fr_worker *w) {
+    if (w->n_pending == 0) return FR_OK;
+    fr_ctx *c = w->ctx;
+    FrFusedArgs a{};
+    int max_tiles = 0;
+    for (int i = 0; i < w->n_pending; i++) {
+        a.b[i] = w->pending[i];
+        const int tiles = (w->pending[i].batch + 31) / 32;
+        if (tiles > max_tiles) max_tiles = tiles;
+    }
+    a.n_batches = w->n_pending;
+    a.tiles_per_batch = max_tiles;
+    a.words = c->d_words;
+    a.n_words = c->n_words;
+    a.idx_stride = (int)idx_cols(c);
+    a.err_flag = w->d_err;
+    a.w1q = reinterpret_cast<const float4 *>(c->d_wq[0]);
+    a.w2q = reinterpret_cast<const float4 *>(c->d_wq[1]);
+    a.w3q = reinterpret_cast<const float4 *>(c->d_wq[2]);
+    a.wout = c->d_w[3];
+    a.K = c->model.fc[0];
+    a.H1 = c->model.fc[1];
+    a.H2 = c->model.fc[2];
+    a.H3 = c->model.fc[3];
+    a.stamps = g_stamp_buffer;
+    w->n_pending = 0;
+    return frk_fused_launch(a, w->stream);
+}
+
 static int check_gather_args(fr_worker *w, const int32_t *d_idx, const float *d_dense) {
     fr_ctx *c = w->ctx;
     if (!d_idx) FR_FAIL(FR_ERR_INVALID, "d_idx is NULL");
@@ -753,6 +811,16 @@ extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_i
     rc = check_gather_args(w, d_idx, d_dense);
     if (rc) return rc;
     FR_HIP(hipSetDevice(c->device));
+    if (fused_eligible(c)) {
+        // whole-path-per-item-tile kernel: queue the batch, launch when a group is full (fr_worker_sync launches the rest)
+        FrFusedBatch &fb = w->pending[w->n_pending++];
+        fb.idx = d_idx;
+        fb.dense = d_dense;
+        fb.scores = d_scores;
+        fb.batch = batch;
+        w->in_flight = true;
+        return (w->n_pending >= fused_group()) ? fused_flush(w) : FR_OK;
+    }
     rc = pipeline_push(w, batch, 0, d_idx, d_dense, d_scores);
     if (rc) return rc;
     w->in_flight = true;
@@ -764,7 +832,7 @@ extern "C" int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d
     if (rc) return rc;
     if (!d_scores) FR_FAIL(FR_ERR_INVALID, "d_scores is NULL");
     FR_HIP(hipSetDevice(w->ctx->device));
-    if (w->n_active) FR_FAIL(FR_ERR_STATE, "pipeline busy (push_device in flight): call fr_worker_sync first");
+    if (w->n_active || w->n_pending) FR_FAIL(FR_ERR_STATE, "pipeline busy (push_device in flight): call fr_worker_sync first");
     rc = launch_pipeline(w, batch, d_idx, d_dense, d_scores);
     if (rc) return rc;
     w->in_flight = true;
@@ -792,7 +860,9 @@ extern "C" int fr_worker_submit(fr_worker *w, int batch) {
 extern "C" int fr_worker_sync(fr_worker *w) {
     if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
     FR_HIP(hipSetDevice(w->ctx->device));
-    int frc = pipeline_flush(w);  // drain batches enqueued with fr_worker_push_device
+    int frc = fused_flush(w);  // launch batches still queued by fr_worker_push_device
+    if (frc) return frc;
+    frc = pipeline_flush(w);  // drain the stage pipeline
     if (frc) return frc;
     FR_HIP(hipStreamSynchronize(w->stream));
     w->in_flight = false;

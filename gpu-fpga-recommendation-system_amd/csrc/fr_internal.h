@@ -76,6 +76,29 @@ struct FrPipeArgs {
     unsigned long long *stamps;
 };
 
+// ---- fused item-tile kernel: launch arguments (see fr_kernels.hip) -----------------------------------
+constexpr int FR_FUSED_MAX_BATCHES = 32;
+struct FrFusedBatch {
+    const int32_t *idx;
+    const float *dense;
+    float *scores;
+    int batch;
+    int pad_;
+};
+struct FrFusedArgs {
+    FrFusedBatch b[FR_FUSED_MAX_BATCHES];
+    int n_batches;
+    int tiles_per_batch;  // max over the batches of ceil(batch / 32)
+    const struct FrWordDesc *words;
+    int n_words;
+    int idx_stride;
+    int *err_flag;
+    const float4 *w1q, *w2q, *w3q;  // q4-packed weights
+    const float *wout;
+    int K, H1, H2, H3;
+    unsigned long long *stamps;  // diagnostics only (NULL normally): 16 s_memrealtime stamps per workgroup
+};
+
 // ---- host objects -------------------------------------------------------------------------------
 struct FrTableMem {
     uint64_t byte_offset; // inside ctx->table_arena
@@ -138,6 +161,9 @@ struct fr_worker {
     uint64_t launch_no = 0;     // number of pipeline launches issued so far
     int n_active = 0;
     int last_x_parity = 0;      // which activation set holds Xt of the most recently pushed batch (debug hook)
+    // fused item-tile path: batches queued by fr_worker_push_device until a launch group is full
+    FrFusedBatch pending[FR_FUSED_MAX_BATCHES];
+    int n_pending = 0;
     float *d_score = nullptr;
     int *h_err = nullptr;  // sticky index-range flag: pinned host word ...
     int *d_err = nullptr;  // ... and its device-side alias
@@ -166,7 +192,9 @@ int frk_fc_h_tiled(const void *Wh, const void *Xh, void *Yh, int K, int N, int l
 int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, hipStream_t s);
 int frk_pack_weights_q4(const float *W, float *Wq, int K, int H, hipStream_t s);
 int frk_stage_blocks(int stage, int n_words, int K, int N, int ldm, int nsplit);
-int frk_gather_tr_blocks(int n_words, int ldm);  // 0 when the transposing gather does not apply
+int frk_gather_tr_blocks(int n_words, int ldm);
+bool frk_fused_ok(int K, int H1, int H2, int H3);
+int frk_fused_launch(const FrFusedArgs &a, hipStream_t s);  // 0 when the transposing gather does not apply
 int frk_transpose_records(const float *X, float *Xt, int batch, int K, int ldm, hipStream_t s);
 int frk_transpose_slices(const float *gathered, int n_shards, int batch_total, int slice_padded, const int *h_offsets, const int *h_lens,
                          int item0, int n_items, float *Xq, int ldm, hipStream_t s);

@@ -1064,3 +1064,314 @@ int frk_fc_h_tiled(const void *Wh, const void *Xh, void *Yh, int K, int N, int l
     KCHECK();
     return FR_OK;
 }
+
+// ===================================================================================================
+// fr_fused_tile_kernel: the whole hot path of 32 items in ONE workgroup, activations never leave LDS.
+//
+// The stage pipeline above re-reads every activation and weight panel once per 32x32 output tile: at batch 256 the CUs'
+// L2 ingest (not the MFMA pipe) bounds it at ~43 % of the f32 MFMA peak.  Here a workgroup owns 32 items for ALL layers:
+//   gather  -> Xq[K/4][32] in LDS (the record of its 32 items; 16-byte q4 elements, row stride 33)
+//   FC1     -> in chunks of 256 outputs (one 32-wide n tile per wave, full K, no split-K) -> R1 chunk in LDS
+//   FC2     -> every wave keeps its H2/256 n tiles in accumulators and adds each R1 chunk as it appears
+//   FC3     -> one n tile per wave from R2 in LDS, out layer from R3 in LDS, 32 scores stored
+// Only the weights stream from L2 (each element once per workgroup: 4 MB for Model-A = 38 GB/s per CU at the MFMA rate);
+// the B operand of every MFMA is a conflict-free ds_read_b128.  One launch carries the tiles of up to 16 queued batches
+// of a worker (8 workgroups per batch of 256), so that 4 concurrent streams fill the 256 CUs.
+// Needs max(K/4 + 128, H2/4 + 68) * 33 * 16 B of LDS <= 160 KiB, K % 32 == 0, H1 % 256 == 0, H2 in {256, 512}, H3 == 256.
+// ===================================================================================================
+constexpr int FR_FT_LD = 33;  // LDS row stride in 16-byte elements (32 items + 1 pad: conflict-free writes and reads)
+
+// acc[t] += Wq[k][n0 + 32 t ..] x B, for groups [g0, g0 + cnt) of 8 k; B group g' = g - g0 + gb0 lives in LDS at
+// Bq[(2 g' + hk) * 33 + lm].  Double-buffered blocks of D groups: the next block's weight loads fly during the MFMAs.
+template <int NT, int D>
+__device__ __forceinline__ void ft_load_a(float4 (&r)[D][NT], const float4 *__restrict__ aq, int N, int g) {
+#pragma unroll
+    for (int i = 0; i < D; i++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) r[i][t] = aq[(size_t)(2 * (g + i)) * N + 32 * t];
+}
+
+// MFMAs of one block.  Consecutive MFMAs of a wave always target different accumulators (the NT tiles when NT >= 2, else two
+// partial accumulators for even / odd k that the caller adds once at the end), so that no MFMA waits for its predecessor.
+template <int NT, int D>
+__device__ __forceinline__ void ft_compute(f32x16 (&acc)[NT], f32x16 &alt, const float4 (&r)[D][NT], const uint4 *bl, int gb) {
+    uint4 rb[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) rb[i] = bl[(size_t)(2 * (gb + i)) * FR_FT_LD];
+    __builtin_amdgcn_sched_barrier(0);  // weight loads of the other register set stay ahead of these MFMAs
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        const float bx = __uint_as_float(rb[i].x), by = __uint_as_float(rb[i].y), bz = __uint_as_float(rb[i].z), bw = __uint_as_float(rb[i].w);
+        if constexpr (NT == 1) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r[i][0].x, bx, acc[0], 0, 0, 0);
+            alt = __builtin_amdgcn_mfma_f32_32x32x2f32(r[i][0].y, by, alt, 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r[i][0].z, bz, acc[0], 0, 0, 0);
+            alt = __builtin_amdgcn_mfma_f32_32x32x2f32(r[i][0].w, bw, alt, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(r[i][t].x, bx, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(r[i][t].y, by, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(r[i][t].z, bz, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(r[i][t].w, bw, acc[t], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Compile-time trip count, fully unrolled, weight operands in a RING of R register slots refilled one group at a time:
+// group g's MFMAs are followed by the load of group g + R into the slot they just freed.  The loads are spread evenly over
+// the MFMA stream (no bursts into the CU's ~70 GB/s L2 ingest) and the prefetch distance is R - 1 groups, i.e. almost the
+// whole in-flight window -- a lone wave (its SIMD partner parked at a barrier) no longer exposes L2/Infinity-Cache latency
+// once per block.  Straight-line code: hipcc keeps counted vmcnt waits (a branch in here would degrade them to vmcnt(0)).
+template <int NT, int R, int CNT>
+__device__ __forceinline__ void ft_gemm_ct(f32x16 (&acc)[NT], const float4 *__restrict__ wq, int N, int n0, const uint4 *Bq, int gb0, int g0,
+                                           int hk, int lm) {
+    const float4 *aq = wq + (size_t)(2 * g0 + hk) * N + n0 + lm;
+    const uint4 *bl = Bq + (size_t)(2 * gb0 + hk) * FR_FT_LD + lm;
+    float4 ring[R][NT];
+    f32x16 alt;
+#pragma unroll
+    for (int i = 0; i < 16; i++) alt[i] = 0.0f;
+#pragma unroll
+    for (int g = 0; g < R && g < CNT; g++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) ring[g][t] = aq[(size_t)(2 * g) * N + 32 * t];
+    uint4 bcur = bl[0];
+#pragma unroll
+    for (int g = 0; g < CNT; g++) {
+        const uint4 bnext = bl[(size_t)(2 * ((g + 1 < CNT) ? g + 1 : g)) * FR_FT_LD];  // next group's B fragment from LDS
+        const float bx = __uint_as_float(bcur.x), by = __uint_as_float(bcur.y), bz = __uint_as_float(bcur.z), bw = __uint_as_float(bcur.w);
+        const float4(&a4)[NT] = ring[g % R];
+        if constexpr (NT == 1) {  // two partial accumulators (even / odd k): consecutive MFMAs are independent
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0].x, bx, acc[0], 0, 0, 0);
+            alt = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0].y, by, alt, 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0].z, bz, acc[0], 0, 0, 0);
+            alt = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0].w, bw, alt, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t].x, bx, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t].y, by, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t].z, bz, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t].w, bw, acc[t], 0, 0, 0);
+        }
+        if (g + R < CNT) {  // compile-time after unrolling: refill the slot just consumed
+#pragma unroll
+            for (int t = 0; t < NT; t++) ring[g % R][t] = aq[(size_t)(2 * (g + R)) * N + 32 * t];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep this interleave: the scheduler would otherwise sink the refills
+        bcur = bnext;
+    }
+    if constexpr (NT == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[0][i] += alt[i];
+    }
+}
+
+// Run-time trip count (models without a straight-line instantiation): one register set + copies, branch-free loop body.
+template <int NT, int D>
+__device__ __forceinline__ void ft_gemm(f32x16 (&acc)[NT], const float4 *__restrict__ wq, int N, int n0, const uint4 *Bq, int gb0, int g0,
+                                        int cnt, int hk, int lm) {
+    const float4 *aq = wq + (size_t)hk * N + n0 + lm;
+    const uint4 *bl = Bq + hk * FR_FT_LD + lm;
+    float4 ra[D][NT], na[D][NT];
+    f32x16 alt;
+#pragma unroll
+    for (int i = 0; i < 16; i++) alt[i] = 0.0f;
+    const int nblk = cnt / D;  // launcher guarantees cnt % D == 0
+    ft_load_a<NT, D>(ra, aq, N, g0);
+    for (int blk = 0; blk < nblk; blk++) {
+        const int nx = (blk + 1 < nblk) ? (blk + 1) : blk;  // last block re-loads itself: branch-free body
+        ft_load_a<NT, D>(na, aq, N, g0 + nx * D);
+        ft_compute<NT, D>(acc, alt, ra, bl, gb0 + blk * D);
+#pragma unroll
+        for (int i = 0; i < D; i++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) ra[i][t] = na[i][t];
+    }
+    if constexpr (NT == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[0][i] += alt[i];
+    }
+}
+
+// store a 32(n) x 32(m) accumulator tile as q4 elements into an LDS operand image: n_local = tile's first n inside the image
+__device__ __forceinline__ void ft_store_tile(uint4 *img, const f32x16 &acc, int n_local, int hk, int lm) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint4 v;
+        v.x = __float_as_uint(acc[4 * i + 0]);
+        v.y = __float_as_uint(acc[4 * i + 1]);
+        v.z = __float_as_uint(acc[4 * i + 2]);
+        v.w = __float_as_uint(acc[4 * i + 3]);
+        img[(size_t)((n_local >> 2) + 2 * i + hk) * FR_FT_LD + lm] = v;  // n = n_local + 8i + 4hk + c
+    }
+}
+
+// T2W = H2 / 256 (n tiles of FC2 per wave); KG = K / 8 when FC1 has a straight-line instantiation with blocks of D1 groups
+// (KG % D1 == 0), else 0 (run-time loop).
+template <int T2W, int KG, int D1>
+__global__ void __launch_bounds__(512) fr_fused_tile_kernel(const FrFusedArgs a) {
+    extern __shared__ uint4 lds[];
+    const int KQ = a.K / 4;
+    // LDS: [ Xq: KQ rows | R1 chunk buffer 0: 64 rows | R1 chunk buffer 1: 64 rows ]; R2 (H2/4 rows) overlays the start once
+    // Xq and the R1 chunks are dead, R3 (64 rows) follows R2.
+    uint4 *Xq = lds;                                  // [KQ][33]
+    uint4 *R1b[2] = {Xq + (size_t)KQ * FR_FT_LD, Xq + (size_t)(KQ + 64) * FR_FT_LD};  // [64][33] each: 256 outputs of FC1
+    uint4 *R2 = lds;                                  // [H2/4][33]
+    uint4 *R3 = lds + (size_t)(a.H2 / 4) * FR_FT_LD;  // [64][33]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hk = lane >> 5, lm = lane & 31;
+    const int bi = blockIdx.x / a.tiles_per_batch, tile = blockIdx.x - bi * a.tiles_per_batch;
+    const FrFusedBatch &bt = a.b[bi];
+    const int m0 = tile * 32;
+    if (m0 >= bt.batch) return;
+    int n_st = 0;
+    auto stamp = [&]() {  // diagnostic build aid; wave 0 lane 0 only, values never feed an output
+        if (a.stamps && tid == 0 && n_st < 14) {
+            a.stamps[16ull * blockIdx.x + n_st] = __builtin_amdgcn_s_memrealtime();
+            if (n_st == 1) a.stamps[16ull * blockIdx.x + 14] = __builtin_amdgcn_s_memtime();   // shader-clock cycles at "gather done"
+            if (n_st == 11) a.stamps[16ull * blockIdx.x + 15] = __builtin_amdgcn_s_memtime();  // ... and at "FC3 + R3"
+        }
+        if (a.stamps && lane == 0 && (n_st == 4 || n_st == 5))  // per-wave arrival at / release from the chunk-1 barrier
+            a.stamps[16ull * gridDim.x + (8ull * blockIdx.x + wave) * 2 + (n_st - 4)] = __builtin_amdgcn_s_memrealtime();
+        n_st++;
+    };
+    stamp();
+
+    // ---- gather: lanes along record words (a row is read by dim/4 adjacent lanes), 4 items per thread ----
+    {
+        const int wl = tid & 63, ig = tid >> 6;
+        bool bad = false;
+        for (int w0 = 0; w0 < a.n_words; w0 += 64) {
+            const int w = w0 + wl;
+            if (w < a.n_words) {
+                const uint4 d0 = reinterpret_cast<const uint4 *>(a.words)[2 * w];
+                const uint4 d1 = reinterpret_cast<const uint4 *>(a.words)[2 * w + 1];
+                const uint64_t src = ((uint64_t)d0.y << 32) | d0.x;
+                const uint32_t stride = d0.z, idx_col = d0.w, rows = d1.x;
+                const bool is_dense = (idx_col & FR_DESC_DENSE) != 0;
+                const char *base = is_dense ? reinterpret_cast<const char *>(bt.dense) + src : reinterpret_cast<const char *>(src);
+                uint32_t id[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int m = m0 + 4 * ig + i;
+                    id[i] = 0;
+                    if (m < bt.batch) id[i] = is_dense ? (uint32_t)m : (uint32_t)bt.idx[(size_t)m * a.idx_stride + idx_col];
+                    if (!is_dense && id[i] >= rows) {
+                        bad = true;
+                        id[i] = 0;
+                    }
+                }
+                uint4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const uint4 *>(base + (uint64_t)id[i] * stride);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    Xq[(size_t)w * FR_FT_LD + 4 * ig + i] = (m0 + 4 * ig + i < bt.batch) ? v[i] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        if (bad) atomicOr_system(a.err_flag, 1);
+    }
+    __syncthreads();
+    stamp();
+
+    // ---- FC1 in chunks of 256 outputs, FC2 accumulating each chunk ----
+    f32x16 acc2[T2W];
+#pragma unroll
+    for (int t = 0; t < T2W; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc2[t][i] = 0.0f;
+    const int n_chunks = a.H1 / 256;
+    for (int c = 0; c < n_chunks; c++) {
+        f32x16 acc1[1];
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc1[0][i] = 0.0f;
+        if constexpr (KG > 0) ft_gemm_ct<1, 16, KG>(acc1, a.w1q, a.H1, c * 256 + 32 * wave, Xq, 0, 0, hk, lm);
+        else ft_gemm<1, 4>(acc1, a.w1q, a.H1, c * 256 + 32 * wave, Xq, 0, 0, a.K / 8, hk, lm);
+        stamp();
+        uint4 *R1 = R1b[c & 1];  // double-buffered: ONE barrier per chunk (the buffer written now was last read two chunks ago)
+        ft_store_tile(R1, acc1[0], 32 * wave, hk, lm);
+        __syncthreads();
+        stamp();
+        // FC2: K range [256 c, 256 c + 256) = groups [32 c, 32 c + 32); this wave's n tiles start at 32 * T2W * wave
+        ft_gemm_ct<T2W, 24 / T2W, 32>(acc2, a.w2q, a.H2, 32 * T2W * wave, R1, 0, 32 * c, hk, lm);
+    }
+    __syncthreads();  // every wave is done with Xq and both R1 buffers: R2 may overlay them
+#pragma unroll
+    for (int t = 0; t < T2W; t++) ft_store_tile(R2, acc2[t], 32 * (T2W * wave + t), hk, lm);
+    __syncthreads();  // R2 complete
+    stamp();
+
+    // ---- FC3: one n tile per wave (H3 == 256), then the output layer ----
+    f32x16 acc3[1];
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc3[0][i] = 0.0f;
+    ft_gemm_ct<1, 16, 32 * T2W>(acc3, a.w3q, a.H3, 32 * wave, R2, 0, 0, hk, lm);  // H2 / 8 = 32 * T2W groups
+    ft_store_tile(R3, acc3[0], 32 * wave, hk, lm);  // R3 image [H3/4][33]
+    __syncthreads();
+    stamp();
+    {   // score[m] = sum_n wout[n] * R3[n][m]: 32 items x 16 slices of 4 q4 rows, fixed-order reduction through LDS (reuses Xq)
+        const int il = tid & 31, sl = tid >> 5;
+        const int rows_per = (a.H3 / 4) / 16;
+        float s = 0.0f;
+        for (int q = sl * rows_per; q < (sl + 1) * rows_per; q++) {
+            const uint4 r = R3[(size_t)q * FR_FT_LD + il];
+            const float4 w4 = reinterpret_cast<const float4 *>(a.wout)[q];
+            s = fmaf(w4.x, __uint_as_float(r.x), s);
+            s = fmaf(w4.y, __uint_as_float(r.y), s);
+            s = fmaf(w4.z, __uint_as_float(r.z), s);
+            s = fmaf(w4.w, __uint_as_float(r.w), s);
+        }
+        float *part = reinterpret_cast<float *>(R3 + (size_t)64 * FR_FT_LD);  // 2 KiB behind R3
+        part[sl * 32 + il] = s;
+        __syncthreads();
+        if (tid < 32 && m0 + tid < bt.batch) {
+            float t = part[tid];
+#pragma unroll
+            for (int i = 1; i < 16; i++) t += part[i * 32 + tid];
+            bt.scores[m0 + tid] = t;
+        }
+    }
+    stamp();
+}
+
+size_t frk_fused_lds_bytes(int K, int H2) {
+    const size_t phase1 = (size_t)(K / 4) + 128;      // Xq + two R1 chunk buffers
+    const size_t phase2 = (size_t)(H2 / 4) + 64 + 4;  // R2 + R3 + the 2 KiB reduction scratch
+    return (phase1 > phase2 ? phase1 : phase2) * FR_FT_LD * 16;
+}
+
+bool frk_fused_ok(int K, int H1, int H2, int H3) {
+    if (K % 32 || H1 % 256 || (H2 != 256 && H2 != 512) || H3 != 256) return false;  // K/8 groups must be a multiple of D = 4
+    return frk_fused_lds_bytes(K, H2) <= 160 * 1024;
+}
+
+template <int T2W, int KG, int D1>
+static int fused_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fr_fused_tile_kernel<T2W, KG, D1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            FR_FAIL(FR_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_set = true;
+    }
+    fr_fused_tile_kernel<T2W, KG, D1><<<grid, dim3(512), lds, s>>>(a);
+    KCHECK();
+    return FR_OK;
+}
+
+int frk_fused_launch(const FrFusedArgs &a, hipStream_t s) {
+    const size_t lds = frk_fused_lds_bytes(a.K, a.H2);
+    dim3 grid(a.n_batches * a.tiles_per_batch);
+    if (a.H2 == 512) {
+        if (a.K == 352) return fused_launch_inst<2, 44, 11>(a, grid, lds, s);  // Model-A: FC1 = 4 blocks of 11 groups
+        return fused_launch_inst<2, 0, 0>(a, grid, lds, s);
+    }
+    return fused_launch_inst<1, 0, 0>(a, grid, lds, s);
+}

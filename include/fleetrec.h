@@ -215,6 +215,13 @@ int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d_idx, const
  * drains the pipeline.  The caller keeps d_idx / d_dense / d_scores valid and distinct for every batch still in
  * the pipeline (up to 5).  Needs an unsharded, SEMANTIC-layout, fp32 context. */
 int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores);
+/* How many pushed batches one streaming launch carries on this context: 1 when fr_worker_push_device rides the stage
+ * pipeline, G (default 32) when the model qualifies for the fused item-tile kernel, which queues pushed batches and
+ * launches every G pushes (fr_worker_sync launches a partial group). */
+int fr_ctx_stream_group(const fr_ctx *ctx);
+/* Throughput/latency knob of the fused streaming path: batches per launch, 1..32 (default 32 = 256 workgroups = one per CU;
+ * process-wide).  Smaller groups cut the queueing latency of a pushed batch and leave CUs to other streams. */
+int fr_ctx_set_stream_group(fr_ctx *ctx, int batches_per_launch);
 /* Drains and waits for everything enqueued on the worker; returns FR_ERR_INDEX_RANGE if any index was out of range. */
 int fr_worker_sync(fr_worker *w);
 

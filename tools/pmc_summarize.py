@@ -16,7 +16,7 @@ for f in glob.glob(root + "/*/*/*counter_collection.csv"):
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, cs in agg.items():
-    if not any(x in k for x in ("gather_pack", "fr_pipeline_kernel<-1")):
+    if not any(x in k for x in ("gather_pack", "fr_pipeline_kernel<-1", "fr_fused_tile")):
         continue
     m = {c: sum(v) / len(v) for c, v in cs.items()}
     e = {"launches_averaged": {c: len(v) for c, v in cs.items()}, "raw": m}
