@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
     "fr_device_synchronize", "fr_ctx_shard_info", "fr_driver_create", "fr_driver_destroy", "fr_driver_run_resident",
-    "fr_driver_worker", "fr_driver_run_host", "fr_ctx_stream_group", "fr_ctx_set_stream_group", "fr_model_shard_plan", "fr_worker_fc_from_slices",
+    "fr_driver_worker", "fr_driver_score_ring", "fr_driver_run_host", "fr_ctx_stream_group", "fr_ctx_set_stream_group", "fr_model_shard_plan", "fr_worker_fc_from_slices",
 ]
 
 
@@ -104,7 +104,8 @@ def lib():
         "fr_ctx_shard_info": (i32, [vp] + [ctypes.POINTER(ctypes.c_int)] * 5),
         "fr_driver_create": (i32, [vp, i32, i32, i32, ctypes.POINTER(vp)]), "fr_driver_destroy": (None, [vp]),
         "fr_driver_run_resident": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
-        "fr_driver_worker": (vp, [vp, i32, i32]), "fr_ctx_stream_group": (i32, [vp]), "fr_ctx_set_stream_group": (i32, [vp, i32]),
+        "fr_driver_worker": (vp, [vp, i32, i32]), "fr_driver_score_ring": (vp, [vp, i32, i32, ctypes.POINTER(ctypes.c_int)]),
+        "fr_ctx_stream_group": (i32, [vp]), "fr_ctx_set_stream_group": (i32, [vp, i32]),
         "fr_driver_run_host": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
         "fr_model_shard_plan": (i32, [ctypes.POINTER(ModelDesc), i32, pi, pi, ctypes.POINTER(ctypes.c_int)]),
         "fr_worker_fc_from_slices": (i32, [vp, i32, i32, i32, vp, vp]),
@@ -517,6 +518,14 @@ class Driver:
         el = ctypes.c_double()
         _check(lib().fr_driver_run_resident(self._h, batch, total_batches, ip, dp, n, ctypes.byref(el)))
         return el.value
+
+    def score_ring(self, thread, slot, max_batch):
+        """-> float32 [ring_len][max_batch]: the scores of the last ring_len batches pushed to worker (thread, slot)."""
+        n = ctypes.c_int()
+        p = lib().fr_driver_score_ring(self._h, thread, slot, ctypes.byref(n))
+        out = np.empty((n.value, max_batch), dtype=np.float32)
+        _check(lib().fr_memcpy_d2h(self.ctx._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p), out.nbytes))
+        return out
 
     def run_host(self, batch, total_batches, idx_pool_np, dense_pool_np=None):
         """idx_pool_np / dense_pool_np: lists of C-contiguous numpy arrays in host memory.  -> elapsed seconds (PCIe-inclusive)."""

@@ -17,11 +17,14 @@
 
 #include "fr_internal.h"
 
+constexpr int FR_SCORE_RING = 64;
+
 struct fr_driver {
     fr_ctx *ctx = nullptr;
     int n_threads = 0, depth = 0, max_batch = 0;
     std::vector<fr_worker *> workers;  // [n_threads * depth]
-    std::vector<float *> score_rings;  // per worker: 8 x max_batch floats (a pushed batch's scores stay valid 8 pushes)
+    std::vector<float *> score_rings;  // per worker: FR_SCORE_RING x max_batch floats; the loop syncs a worker every
+                                       // FR_SCORE_RING pushes, so no two batches in flight ever share a score buffer
 };
 
 extern "C" void fr_driver_destroy(fr_driver *d) {
@@ -52,10 +55,11 @@ extern "C" int fr_driver_create(fr_ctx *ctx, int n_threads, int depth, int max_b
         }
         d->workers.push_back(w);
         float *ring = nullptr;
-        if (hipMalloc((void **)&ring, (size_t)8 * max_batch * sizeof(float)) != hipSuccess) {
+        if (hipMalloc((void **)&ring, (size_t)FR_SCORE_RING * max_batch * sizeof(float)) != hipSuccess) {
             fr_driver_destroy(d);
             FR_FAIL(FR_ERR_OOM, "hipMalloc(score ring) failed");
         }
+        (void)hipMemset(ring, 0, (size_t)FR_SCORE_RING * max_batch * sizeof(float));
         d->score_rings.push_back(ring);
     }
     *out = d;
@@ -89,12 +93,14 @@ extern "C" int fr_driver_run_resident(fr_driver *d, int batch, int64_t total_bat
                 }
                 // enqueue without synchronising, like the reference's loop body (cuda_server.c:460-495)
                 const int slot = (int)(local % d->depth);
-                float *scores = rings[slot] + (size_t)((local / d->depth) % 8) * d->max_batch;
+                float *scores = rings[slot] + (size_t)((local / d->depth) % FR_SCORE_RING) * d->max_batch;
                 local++;
                 const int p = (int)(id % n_pool);
                 rc = fr_worker_push_device(wk[slot], batch, d_idx_pool[p], d_dense_pool ? d_dense_pool[p] : nullptr, scores);
-                // bound the host's run-ahead: every 64 batches wait for this worker's stream
-                if (rc == FR_OK && (local % (64 * d->depth)) == 0) rc = fr_worker_sync(wk[slot]);
+                // bound the host's run-ahead (and keep score buffers unique): sync a worker after FR_SCORE_RING pushes
+                if (rc == FR_OK && (local % d->depth) == 0 && ((local / d->depth) % FR_SCORE_RING) == 0) {
+                    for (int s2 = 0; s2 < d->depth && rc == FR_OK; s2++) rc = fr_worker_sync(wk[s2]);
+                }
             }
             for (int s = 0; s < d->depth; s++) {
                 int r2 = fr_worker_sync(wk[s]);
@@ -171,6 +177,12 @@ extern "C" int fr_driver_run_host(fr_driver *d, int batch, int64_t total_batches
     for (int t = 0; t < d->n_threads; t++)
         if (status[t]) FR_FAIL(status[t], "driver thread %d: %s", t, messages[t].c_str());
     return FR_OK;
+}
+
+extern "C" const float *fr_driver_score_ring(fr_driver *d, int thread, int slot, int *ring_len) {
+    if (!d || thread < 0 || thread >= d->n_threads || slot < 0 || slot >= d->depth) return nullptr;
+    if (ring_len) *ring_len = FR_SCORE_RING;
+    return d->score_rings[(size_t)thread * d->depth + slot];
 }
 
 extern "C" fr_worker *fr_driver_worker(fr_driver *d, int thread, int slot) {

@@ -264,6 +264,9 @@ int fr_driver_run_resident(fr_driver *d, int batch, int64_t total_batches, const
 int fr_driver_run_host(fr_driver *d, int batch, int64_t total_batches, const int32_t *const *h_idx_pool,
                        const float *const *h_dense_pool, int n_pool, double *elapsed_s);
 fr_worker *fr_driver_worker(fr_driver *d, int thread, int slot);
+/* Device pointer of the score ring fr_driver_run_resident writes for worker (thread, slot): *ring_len buffers of max_batch
+ * floats; the k-th batch pushed to that worker lands in buffer k % *ring_len. */
+const float *fr_driver_score_ring(fr_driver *d, int thread, int slot, int *ring_len);
 
 /* ---- device memory helpers (so hosts/tests need no other GPU runtime binding) ---------------- */
 int fr_device_malloc(fr_ctx *ctx, size_t bytes, void **dptr);

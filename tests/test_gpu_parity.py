@@ -413,6 +413,21 @@ def test_driver_loop(fr, ctxs):
     drv = fr.Driver(ctx, 4, 2, 256)
     el = drv.run_resident(256, 403, pool)
     assert el > 0
+    # every worker's score ring holds results of pool batches: each ring slot must equal the scores of ONE of the 4 pool entries
+    wk0 = fr.Worker(ctx, 256)
+    expect = [wk0.infer(p_.download(np.int32, 256 * m.n_tables).reshape(256, -1)) for p_ in pool]
+    wk0.close()
+    scale = max(np.abs(e_).max() for e_ in expect)
+    checked = 0
+    for t in range(4):
+        for sl in range(2):
+            ring = drv.score_ring(t, sl, 256)
+            for row in ring:
+                if not row.any():          # slot never used: threads draw batch ids from a shared counter, shares are uneven
+                    continue
+                assert min(np.abs(row - e_).max() for e_ in expect) <= 1e-5 * scale
+                checked += 1
+    assert checked == 403                  # every batch's scores are intact in some worker's ring (403 < 8 x 64)
     el = drv.run_resident(256, 0, pool)  # empty run is fine
     drv.close()
 

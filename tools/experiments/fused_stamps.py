@@ -10,6 +10,7 @@ B = 256
 rng = np.random.default_rng(0)
 pool = [fr.DeviceBuffer.from_numpy(ctx, (rng.random((B, m.n_tables)) * m.rows()[None, :]).astype(np.int32)) for _ in range(8)]
 sc = [fr.DeviceBuffer(ctx, B * 4) for _ in range(16)]
+ctx.set_stream_group(8)
 wk = fr.Worker(ctx, B)
 for rep in range(4):
     for i in range(8):
