@@ -631,8 +631,8 @@ static int fused_group() { return g_fused_group; }
 static bool fused_eligible(const fr_ctx *c) {
     static const int enabled = getenv("FR_FUSED") ? atoi(getenv("FR_FUSED")) : 1;  // experiment knob
     const int32_t *fc = c->model.fc;
-    return enabled && c->fc_precision == FR_FC_FP32 && c->n_shards == 1 && c->model.layout == FR_LAYOUT_SEMANTIC &&
-           frk_fused_ok(fc[0], fc[1], fc[2], fc[3]);
+    if (!enabled || c->n_shards != 1 || c->model.layout != FR_LAYOUT_SEMANTIC) return false;
+    return c->fc_precision == FR_FC_BF16 ? frk_fused_h_ok(fc[0], fc[1], fc[2], fc[3]) : frk_fused_ok(fc[0], fc[1], fc[2], fc[3]);
 }
 
 // Batches one streaming launch carries on this context: 1 for the stage pipeline, the fused kernel's group otherwise.
@@ -650,10 +650,12 @@ static int fused_flush(fr_worker *w) {
     if (w->n_pending == 0) return FR_OK;
     fr_ctx *c = w->ctx;
     FrFusedArgs a{};
+    const bool bf16 = c->fc_precision == FR_FC_BF16;
+    const int per_wg = bf16 ? frk_fused_h_items_per_wg() : 32;  // items per workgroup
     int max_tiles = 0;
     for (int i = 0; i < w->n_pending; i++) {
         a.b[i] = w->pending[i];
-        const int tiles = (w->pending[i].batch + 31) / 32;
+        const int tiles = (w->pending[i].batch + per_wg - 1) / per_wg;
         if (tiles > max_tiles) max_tiles = tiles;
     }
     a.n_batches = w->n_pending;
@@ -662,17 +664,24 @@ static int fused_flush(fr_worker *w) {
     a.n_words = c->n_words;
     a.idx_stride = (int)idx_cols(c);
     a.err_flag = w->d_err;
-    a.w1q = reinterpret_cast<const float4 *>(c->d_wq[0]);
-    a.w2q = reinterpret_cast<const float4 *>(c->d_wq[1]);
-    a.w3q = reinterpret_cast<const float4 *>(c->d_wq[2]);
-    a.wout = c->d_w[3];
+    if (bf16) {  // the bf16 kernel reads the q8-packed bf16 copies through the same argument slots
+        a.w1q = reinterpret_cast<const float4 *>(c->d_w_bf16[0]);
+        a.w2q = reinterpret_cast<const float4 *>(c->d_w_bf16[1]);
+        a.w3q = reinterpret_cast<const float4 *>(c->d_w_bf16[2]);
+        a.wout = reinterpret_cast<const float *>(c->d_w_bf16[3]);
+    } else {
+        a.w1q = reinterpret_cast<const float4 *>(c->d_wq[0]);
+        a.w2q = reinterpret_cast<const float4 *>(c->d_wq[1]);
+        a.w3q = reinterpret_cast<const float4 *>(c->d_wq[2]);
+        a.wout = c->d_w[3];
+    }
     a.K = c->model.fc[0];
     a.H1 = c->model.fc[1];
     a.H2 = c->model.fc[2];
     a.H3 = c->model.fc[3];
     a.stamps = g_stamp_buffer;
     w->n_pending = 0;
-    return frk_fused_launch(a, w->stream);
+    return bf16 ? frk_fused_h_launch(a, w->stream) : frk_fused_launch(a, w->stream);
 }
 
 static int check_gather_args(fr_worker *w, const int32_t *d_idx, const float *d_dense) {

@@ -194,7 +194,10 @@ int frk_pack_weights_q4(const float *W, float *Wq, int K, int H, hipStream_t s);
 int frk_stage_blocks(int stage, int n_words, int K, int N, int ldm, int nsplit);
 int frk_gather_tr_blocks(int n_words, int ldm);
 bool frk_fused_ok(int K, int H1, int H2, int H3);
-int frk_fused_launch(const FrFusedArgs &a, hipStream_t s);  // 0 when the transposing gather does not apply
+int frk_fused_launch(const FrFusedArgs &a, hipStream_t s);
+bool frk_fused_h_ok(int K, int H1, int H2, int H3);
+int frk_fused_h_items_per_wg();
+int frk_fused_h_launch(const FrFusedArgs &a, hipStream_t s);  // 0 when the transposing gather does not apply
 int frk_transpose_records(const float *X, float *Xt, int batch, int K, int ldm, hipStream_t s);
 int frk_transpose_slices(const float *gathered, int n_shards, int batch_total, int slice_padded, const int *h_offsets, const int *h_lens,
                          int item0, int n_items, float *Xq, int ldm, hipStream_t s);

@@ -1375,3 +1375,215 @@ int frk_fused_launch(const FrFusedArgs &a, hipStream_t s) {
     }
     return fused_launch_inst<1, 0, 0>(a, grid, lds, s);
 }
+
+// ===================================================================================================
+// fr_fused_tile_h_kernel: the fused item-tile kernel in bf16 (BASELINE configs 2/3: "bf16 MFMA FC, fused concat + first FC").
+// Same phases as fr_fused_tile_kernel, q8 operands (8 bf16 per 16 bytes = one v_mfma_f32_32x32x16_bf16 operand per lane),
+// fp32 accumulation, ONE bf16 rounding per hidden activation.  A bf16 MFMA is 16x cheaper than the f32 one while the weights
+// are only 2x smaller, so the kernel is bound by streaming the weights into the CU (~70 GB/s): a workgroup therefore owns
+// 32 * MT items (MT = 2: every weight fragment feeds two m tiles) and the weight ring is as deep as the registers allow.
+// ===================================================================================================
+template <int NT, int MT, int R, int CNT>
+__device__ __forceinline__ void fth_gemm_ct(f32x16 (&acc)[NT][MT], const uint4 *__restrict__ wh, int N, int n0, const uint4 *Bh, int ld, int gb0,
+                                            int g0, int hk, int lm) {
+    const uint4 *aq = wh + (size_t)(2 * g0 + hk) * N + n0 + lm;
+    const uint4 *bl = Bh + (size_t)(2 * gb0 + hk) * ld + lm;
+    uint4 ring[R][NT];
+#pragma unroll
+    for (int g = 0; g < R && g < CNT; g++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) ring[g][t] = aq[(size_t)(2 * g) * N + 32 * t];
+#pragma unroll
+    for (int g = 0; g < CNT; g++) {
+        uint4 b8[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) b8[mt] = bl[(size_t)(2 * g) * ld + 32 * mt];
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+                acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[g % R][t]), __builtin_bit_cast(bf16x8, b8[mt]),
+                                                                     acc[t][mt], 0, 0, 0);
+        if (g + R < CNT) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) ring[g % R][t] = aq[(size_t)(2 * (g + R)) * N + 32 * t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// 32(n) x 32(m) fp32 accumulator tile -> bf16, stored as 8-byte halves of q8 elements of an LDS operand image (row stride ld)
+__device__ __forceinline__ void fth_store_tile(uint4 *img, int ld, const f32x16 &acc, int n_local, int m_local, int hk, int lm) {
+    uint2 *h = reinterpret_cast<uint2 *>(img);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint2 v;
+        v.x = pack_bf16x2(acc[4 * i + 0], acc[4 * i + 1]);
+        v.y = pack_bf16x2(acc[4 * i + 2], acc[4 * i + 3]);
+        h[((size_t)((n_local >> 3) + i) * ld + m_local + lm) * 2 + hk] = v;  // n = n_local + 8i + 4hk + c
+    }
+}
+
+template <int MT, int T2W, int KG, bool DB>
+__global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs a) {
+    extern __shared__ uint4 lds[];
+    constexpr int LD = 32 * MT + 1, TI = 32 * MT;
+    const int KO = a.K / 8;
+    uint4 *Xh = lds;                                                   // [K/8][LD]
+    uint4 *R1b[2] = {Xh + (size_t)KO * LD, Xh + (size_t)(KO + (DB ? 32 : 0)) * LD};  // [32][LD]: 256 outputs of FC1 (bf16)
+    uint4 *R2 = lds;                                                   // [H2/8][LD], overlays Xh / R1 once they are dead
+    uint4 *R3 = lds + (size_t)(a.H2 / 8) * LD;                         // [H3/8][LD]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hk = lane >> 5, lm = lane & 31;
+    const int bi = blockIdx.x / a.tiles_per_batch, tile = blockIdx.x - bi * a.tiles_per_batch;
+    const FrFusedBatch &bt = a.b[bi];
+    const int m0 = tile * TI;
+    if (m0 >= bt.batch) return;
+
+    {   // ---- gather + bf16 conversion: lanes along record words, TI / 8 items per thread ----
+        const int wl = tid & 63, ig = tid >> 6;
+        constexpr int IPT = TI / 8;
+        uint2 *Xh2 = reinterpret_cast<uint2 *>(Xh);
+        bool bad = false;
+        for (int w0 = 0; w0 < a.n_words; w0 += 64) {
+            const int w = w0 + wl;
+            if (w < a.n_words) {
+                const uint4 d0 = reinterpret_cast<const uint4 *>(a.words)[2 * w];
+                const uint4 d1 = reinterpret_cast<const uint4 *>(a.words)[2 * w + 1];
+                const uint64_t src = ((uint64_t)d0.y << 32) | d0.x;
+                const uint32_t stride = d0.z, idx_col = d0.w, rows = d1.x;
+                const bool is_dense = (idx_col & FR_DESC_DENSE) != 0;
+                const char *base = is_dense ? reinterpret_cast<const char *>(bt.dense) + src : reinterpret_cast<const char *>(src);
+                uint32_t id[IPT];
+#pragma unroll
+                for (int i = 0; i < IPT; i++) {
+                    const int m = m0 + IPT * ig + i;
+                    id[i] = 0;
+                    if (m < bt.batch) id[i] = is_dense ? (uint32_t)m : (uint32_t)bt.idx[(size_t)m * a.idx_stride + idx_col];
+                    if (!is_dense && id[i] >= rows) {
+                        bad = true;
+                        id[i] = 0;
+                    }
+                }
+                uint4 v[IPT];
+#pragma unroll
+                for (int i = 0; i < IPT; i++) v[i] = *reinterpret_cast<const uint4 *>(base + (uint64_t)id[i] * stride);
+#pragma unroll
+                for (int i = 0; i < IPT; i++) {
+                    uint2 hv = make_uint2(0u, 0u);
+                    if (m0 + IPT * ig + i < bt.batch) {
+                        hv.x = pack_bf16x2(__uint_as_float(v[i].x), __uint_as_float(v[i].y));
+                        hv.y = pack_bf16x2(__uint_as_float(v[i].z), __uint_as_float(v[i].w));
+                    }
+                    Xh2[((size_t)(w >> 1) * LD + IPT * ig + i) * 2 + (w & 1)] = hv;  // record word w = half (w & 1) of q8 element w / 2
+                }
+            }
+        }
+        if (bad) atomicOr_system(a.err_flag, 1);
+    }
+    __syncthreads();
+
+    f32x16 acc2[T2W][MT];
+#pragma unroll
+    for (int t = 0; t < T2W; t++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc2[t][mt][i] = 0.0f;
+    const int n_chunks = a.H1 / 256;
+    const uint4 *w1h = reinterpret_cast<const uint4 *>(a.w1q), *w2h = reinterpret_cast<const uint4 *>(a.w2q), *w3h = reinterpret_cast<const uint4 *>(a.w3q);
+    for (int c = 0; c < n_chunks; c++) {
+        f32x16 acc1[1][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc1[0][mt][i] = 0.0f;
+        fth_gemm_ct<1, MT, 16, KG>(acc1, w1h, a.H1, c * 256 + 32 * wave, Xh, LD, 0, 0, hk, lm);
+        uint4 *R1 = R1b[DB ? (c & 1) : 0];
+        if (!DB && c > 0) __syncthreads();  // single R1 buffer: every wave must be done reading the previous chunk
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) fth_store_tile(R1, LD, acc1[0][mt], 32 * wave, 32 * mt, hk, lm);
+        __syncthreads();
+        // FC2: K range [256 c, 256 c + 256) = 16 groups of 16 k
+        fth_gemm_ct<T2W, MT, 16 / T2W, 16>(acc2, w2h, a.H2, 32 * T2W * wave, R1, LD, 0, 16 * c, hk, lm);
+    }
+    __syncthreads();  // Xh and R1 dead: R2 may overlay them
+#pragma unroll
+    for (int t = 0; t < T2W; t++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) fth_store_tile(R2, LD, acc2[t][mt], 32 * (T2W * wave + t), 32 * mt, hk, lm);
+    __syncthreads();
+
+    f32x16 acc3[1][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc3[0][mt][i] = 0.0f;
+    fth_gemm_ct<1, MT, 16, 16 * T2W>(acc3, w3h, a.H3, 32 * wave, R2, LD, 0, 0, hk, lm);  // H2 / 16 groups
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) fth_store_tile(R3, LD, acc3[0][mt], 32 * wave, 32 * mt, hk, lm);
+    __syncthreads();
+    {   // score[m] = sum_n wout[n] * R3[n][m] (bf16 x bf16, fp32 sum): TI items x (512 / TI) slices of q8 rows, fixed-order reduction
+        const int il = tid % TI, sl = tid / TI;
+        constexpr int NSL = 512 / TI;
+        const int rows_per = (a.H3 / 8) / NSL;
+        const uint4 *wh = reinterpret_cast<const uint4 *>(a.wout);  // bf16 vector w[k], 8 per element
+        float s = 0.0f;
+        for (int q = sl * rows_per; q < (sl + 1) * rows_per; q++) {
+            const uint4 r = R3[(size_t)q * LD + il];
+            const uint4 w = wh[q];
+            const uint32_t rr[4] = {r.x, r.y, r.z, r.w}, ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                s = fmaf(__uint_as_float(ww[e] << 16), __uint_as_float(rr[e] << 16), s);
+                s = fmaf(__uint_as_float(ww[e] & 0xFFFF0000u), __uint_as_float(rr[e] & 0xFFFF0000u), s);
+            }
+        }
+        float *part = reinterpret_cast<float *>(R3 + (size_t)(a.H3 / 8) * LD);
+        part[sl * TI + il] = s;
+        __syncthreads();
+        if (tid < TI && m0 + tid < bt.batch) {
+            float t = part[tid];
+#pragma unroll
+            for (int i = 1; i < NSL; i++) t += part[i * TI + tid];
+            bt.scores[m0 + tid] = t;
+        }
+    }
+}
+
+static size_t fused_h_lds_bytes(int K, int H2, int H3, int MT, bool db) {
+    const size_t LD = 32 * MT + 1;
+    const size_t phase1 = (size_t)(K / 8) + (db ? 64 : 32);
+    const size_t phase2 = (size_t)(H2 / 8) + (size_t)(H3 / 8) + 2;  // + 2 rows: 512 floats of reduction scratch
+    return (phase1 > phase2 ? phase1 : phase2) * LD * 16;
+}
+
+// bf16 fused kernel: straight-line instantiations exist for K = 352 (Model-A) and K = 880 (Model-B), 64 items per workgroup
+bool frk_fused_h_ok(int K, int H1, int H2, int H3) {
+    if (H1 % 256 || H2 != 512 || H3 != 256) return false;
+    return K == 352 || K == 880;
+}
+
+int frk_fused_h_items_per_wg() { return 64; }
+
+template <int MT, int T2W, int KG, bool DB>
+static int fused_h_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fr_fused_tile_h_kernel<MT, T2W, KG, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            FR_FAIL(FR_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_set = true;
+    }
+    fr_fused_tile_h_kernel<MT, T2W, KG, DB><<<grid, dim3(512), lds, s>>>(a);
+    KCHECK();
+    return FR_OK;
+}
+
+// a.w1q/w2q/w3q/wout must point at the bf16 q8 weights; a.tiles_per_batch counts 64-item tiles
+int frk_fused_h_launch(const FrFusedArgs &a, hipStream_t s) {
+    dim3 grid(a.n_batches * a.tiles_per_batch);
+    if (a.K == 352) return fused_h_launch_inst<2, 2, 22, true>(a, grid, fused_h_lds_bytes(a.K, a.H2, a.H3, 2, true), s);
+    if (a.K == 880) return fused_h_launch_inst<2, 2, 55, false>(a, grid, fused_h_lds_bytes(a.K, a.H2, a.H3, 2, false), s);
+    FR_FAIL(FR_ERR_INVALID, "no bf16 fused instantiation for K=%d", a.K);
+}
