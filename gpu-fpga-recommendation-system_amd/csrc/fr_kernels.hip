@@ -252,6 +252,7 @@ int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ===================================================================================================
 // FC chain on k-quad-packed feature-major activations, split-K inside the workgroup, stages
@@ -1126,19 +1127,48 @@ __device__ __forceinline__ void ft_compute(f32x16 (&acc)[NT], f32x16 &alt, const
 // the MFMA stream (no bursts into the CU's ~70 GB/s L2 ingest) and the prefetch distance is R - 1 groups, i.e. almost the
 // whole in-flight window -- a lone wave (its SIMD partner parked at a barrier) no longer exposes L2/Infinity-Cache latency
 // once per block.  Straight-line code: hipcc keeps counted vmcnt waits (a branch in here would degrade them to vmcnt(0)).
+// Weight operands come through BUFFER loads: one resource descriptor per weight matrix (SGPRs), one constant per-lane byte offset
+// (a single VGPR, computed once per kernel), and the group / n-tile position as a uniform SGPR offset.  A global_load with a
+// 64-bit per-lane address needs a v_lshl_add_u64 per load and reads two address VGPRs; measured on this loop shape
+// (tools/experiments/mfma_loop) that alone stretches the MFMA issue interval from 65 to 75-77 cycles, buffer loads: 68.
+struct FtW {
+    __amdgpu_buffer_rsrc_t rs;  // base = weight matrix, num_records = its bytes (out-of-range lanes read 0, never fault)
+    unsigned voff;              // (hk * N + lm) * 16
+    unsigned row2;              // 2 * N * 16: byte step of one group (two q4 rows)
+};
+__device__ __forceinline__ FtW ft_w(const float4 *wq, int K, int N, int hk, int lm) {
+    FtW w;
+    w.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(wq), 0, (unsigned)(K / 4) * (unsigned)N * 16u, 0x00020000);
+    w.voff = (unsigned)(hk * N + lm) * 16u;
+    w.row2 = 2u * (unsigned)N * 16u;
+    return w;
+}
+__device__ __forceinline__ float4 ft_wload(const FtW &w, unsigned soff, int imm) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.voff + imm, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// Prologue of ft_gemm_ct, separated so that the caller can issue it BEFORE the barrier / LDS stores that precede the GEMM: the
+// weights do not depend on them, and a GEMM that starts with a cold ring exposes a full L2 round trip on all 8 waves at once.
+// n0 and g0 must be wave-uniform (they become the SGPR offset).
 template <int NT, int R, int CNT>
-__device__ __forceinline__ void ft_gemm_ct(f32x16 (&acc)[NT], const float4 *__restrict__ wq, int N, int n0, const uint4 *Bq, int gb0, int g0,
-                                           int hk, int lm) {
-    const float4 *aq = wq + (size_t)(2 * g0 + hk) * N + n0 + lm;
-    const uint4 *bl = Bq + (size_t)(2 * gb0 + hk) * FR_FT_LD + lm;
-    float4 ring[R][NT];
-    f32x16 alt;
-#pragma unroll
-    for (int i = 0; i < 16; i++) alt[i] = 0.0f;
+__device__ __forceinline__ void ft_ring_fill(float4 (&ring)[R][NT], const FtW &w, int n0, int g0) {
+    const unsigned s0 = (unsigned)g0 * w.row2 + (unsigned)n0 * 16u;
 #pragma unroll
     for (int g = 0; g < R && g < CNT; g++)
 #pragma unroll
-        for (int t = 0; t < NT; t++) ring[g][t] = aq[(size_t)(2 * g) * N + 32 * t];
+        for (int t = 0; t < NT; t++) ring[g][t] = ft_wload(w, s0 + (unsigned)g * w.row2, 512 * t);
+    __builtin_amdgcn_sched_barrier(0);  // the loads stay where the caller put them
+}
+
+template <int NT, int R, int CNT>
+__device__ __forceinline__ void ft_gemm_ct(f32x16 (&acc)[NT], float4 (&ring)[R][NT], const FtW &w, int n0, const uint4 *Bq, int gb0, int g0, int hk,
+                                           int lm) {
+    const unsigned s0 = (unsigned)g0 * w.row2 + (unsigned)n0 * 16u;
+    const uint4 *bl = Bq + (size_t)(2 * gb0 + hk) * FR_FT_LD + lm;
+    f32x16 alt;
+#pragma unroll
+    for (int i = 0; i < 16; i++) alt[i] = 0.0f;
     uint4 bcur = bl[0];
 #pragma unroll
     for (int g = 0; g < CNT; g++) {
@@ -1162,7 +1192,7 @@ __device__ __forceinline__ void ft_gemm_ct(f32x16 (&acc)[NT], const float4 *__re
         }
         if (g + R < CNT) {  // compile-time after unrolling: refill the slot just consumed
 #pragma unroll
-            for (int t = 0; t < NT; t++) ring[g % R][t] = aq[(size_t)(2 * (g + R)) * N + 32 * t];
+            for (int t = 0; t < NT; t++) ring[g % R][t] = ft_wload(w, s0 + (unsigned)(g + R) * w.row2, 512 * t);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep this interleave: the scheduler would otherwise sink the refills
         bcur = bnext;
@@ -1215,16 +1245,21 @@ __device__ __forceinline__ void ft_store_tile(uint4 *img, const f32x16 &acc, int
 
 // T2W = H2 / 256 (n tiles of FC2 per wave); KG = K / 8 when FC1 has a straight-line instantiation with blocks of D1 groups
 // (KG % D1 == 0), else 0 (run-time loop).
-template <int T2W, int KG, int D1>
-__global__ void __launch_bounds__(512) fr_fused_tile_kernel(const FrFusedArgs a) {
+// WPE = waves per SIMD the kernel is built for.  2: one workgroup per CU, double-buffered R1, deep weight rings.  4: TWO
+// workgroups per CU (<= 128 VGPRs, <= 80 KiB LDS: single R1 buffer, R3 overlays R2, half-depth rings -- the same bytes in
+// flight per CU) so that one workgroup's gather / barrier / epilogue phases run under the other one's MFMAs.
+template <int T2W, int KG, int D1, int WPE>
+__global__ void __launch_bounds__(512, WPE) fr_fused_tile_kernel(const FrFusedArgs a) {
     extern __shared__ uint4 lds[];
+    constexpr bool DB = (WPE == 2);
+    constexpr int RD = DB ? 1 : 2;  // ring depth divisor
     const int KQ = a.K / 4;
     // LDS: [ Xq: KQ rows | R1 chunk buffer 0: 64 rows | R1 chunk buffer 1: 64 rows ]; R2 (H2/4 rows) overlays the start once
     // Xq and the R1 chunks are dead, R3 (64 rows) follows R2.
     uint4 *Xq = lds;                                  // [KQ][33]
-    uint4 *R1b[2] = {Xq + (size_t)KQ * FR_FT_LD, Xq + (size_t)(KQ + 64) * FR_FT_LD};  // [64][33] each: 256 outputs of FC1
+    uint4 *R1b[2] = {Xq + (size_t)KQ * FR_FT_LD, Xq + (size_t)(KQ + (DB ? 64 : 0)) * FR_FT_LD};  // [64][33] each: 256 outputs of FC1
     uint4 *R2 = lds;                                  // [H2/4][33]
-    uint4 *R3 = lds + (size_t)(a.H2 / 4) * FR_FT_LD;  // [64][33]
+    uint4 *R3 = DB ? lds + (size_t)(a.H2 / 4) * FR_FT_LD : lds;  // [64][33]; WPE 4: overlays R2 once FC3 has read it
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hk = lane >> 5, lm = lane & 31;
@@ -1239,11 +1274,17 @@ __global__ void __launch_bounds__(512) fr_fused_tile_kernel(const FrFusedArgs a)
             if (n_st == 1) a.stamps[16ull * blockIdx.x + 14] = __builtin_amdgcn_s_memtime();   // shader-clock cycles at "gather done"
             if (n_st == 11) a.stamps[16ull * blockIdx.x + 15] = __builtin_amdgcn_s_memtime();  // ... and at "FC3 + R3"
         }
-        if (a.stamps && lane == 0 && (n_st == 4 || n_st == 5))  // per-wave arrival at / release from the chunk-1 barrier
-            a.stamps[16ull * gridDim.x + (8ull * blockIdx.x + wave) * 2 + (n_st - 4)] = __builtin_amdgcn_s_memrealtime();
         n_st++;
     };
+    auto wstamp = [&](int k) {  // per-wave stamps around chunk 1: FC1 done, barrier released, FC2 done, next FC1 done
+        if (a.stamps && lane == 0) a.stamps[16ull * gridDim.x + (8ull * blockIdx.x + wave) * 4 + k] = __builtin_amdgcn_s_memrealtime();
+    };
     stamp();
+    const FtW W1 = ft_w(a.w1q, a.K, a.H1, hk, lm), W2 = ft_w(a.w2q, a.H1, a.H2, hk, lm), W3 = ft_w(a.w3q, a.H2, a.H3, hk, lm);
+    constexpr int RA = 16 / RD, RB = 24 / T2W / RD;     // ring slots: FC1 / FC3 (one n tile), FC2 (T2W n tiles)
+    constexpr int KG1 = KG > 0 ? KG : 1;
+    float4 ring1[RA][1];                                // FC1's weight ring; chunk 0's first groups are requested before the gather
+    if constexpr (KG > 0) ft_ring_fill<1, RA, KG1>(ring1, W1, 32 * wave, 0);
 
     // ---- gather: lanes along record words (a row is read by dim/4 adjacent lanes), 4 items per thread ----
     {
@@ -1293,16 +1334,29 @@ __global__ void __launch_bounds__(512) fr_fused_tile_kernel(const FrFusedArgs a)
         f32x16 acc1[1];
 #pragma unroll
         for (int i = 0; i < 16; i++) acc1[0][i] = 0.0f;
-        if constexpr (KG > 0) ft_gemm_ct<1, 16, KG>(acc1, a.w1q, a.H1, c * 256 + 32 * wave, Xq, 0, 0, hk, lm);
+        if constexpr (KG > 0) ft_gemm_ct<1, RA, KG1>(acc1, ring1, W1, c * 256 + 32 * wave, Xq, 0, 0, hk, lm);
         else ft_gemm<1, 4>(acc1, a.w1q, a.H1, c * 256 + 32 * wave, Xq, 0, 0, a.K / 8, hk, lm);
         stamp();
+        if (c == 1) wstamp(0);
+        if (c == 2) wstamp(3);
+        float4 ring2[RB][T2W];  // FC2's first weight groups are requested before the R1 store and the barrier
+        ft_ring_fill<T2W, RB, 32>(ring2, W2, 32 * T2W * wave, 32 * c);
         uint4 *R1 = R1b[c & 1];  // double-buffered: ONE barrier per chunk (the buffer written now was last read two chunks ago)
+        if (!DB && c > 0) __syncthreads();  // single buffer: every wave must be done with the previous chunk's FC2
         ft_store_tile(R1, acc1[0], 32 * wave, hk, lm);
         __syncthreads();
         stamp();
         // FC2: K range [256 c, 256 c + 256) = groups [32 c, 32 c + 32); this wave's n tiles start at 32 * T2W * wave
-        ft_gemm_ct<T2W, 24 / T2W, 32>(acc2, a.w2q, a.H2, 32 * T2W * wave, R1, 0, 32 * c, hk, lm);
+        if (c == 1) wstamp(1);
+        ft_gemm_ct<T2W, RB, 32>(acc2, ring2, W2, 32 * T2W * wave, R1, 0, 32 * c, hk, lm);
+        if (c == 1) wstamp(2);
+        if constexpr (KG > 0) {  // next chunk's FC1 ring (the last chunk re-requests its own: branch-free, 16 harmless loads)
+            const int cn = (c + 1 < n_chunks) ? c + 1 : c;
+            ft_ring_fill<1, RA, KG1>(ring1, W1, cn * 256 + 32 * wave, 0);
+        }
     }
+    float4 ring3[RA][1];  // FC3's first weight groups, requested before the two barriers around the R2 store
+    ft_ring_fill<1, RA, 32 * T2W>(ring3, W3, 32 * wave, 0);
     __syncthreads();  // every wave is done with Xq and both R1 buffers: R2 may overlay them
 #pragma unroll
     for (int t = 0; t < T2W; t++) ft_store_tile(R2, acc2[t], 32 * (T2W * wave + t), hk, lm);
@@ -1313,7 +1367,8 @@ __global__ void __launch_bounds__(512) fr_fused_tile_kernel(const FrFusedArgs a)
     f32x16 acc3[1];
 #pragma unroll
     for (int i = 0; i < 16; i++) acc3[0][i] = 0.0f;
-    ft_gemm_ct<1, 16, 32 * T2W>(acc3, a.w3q, a.H3, 32 * wave, R2, 0, 0, hk, lm);  // H2 / 8 = 32 * T2W groups
+    ft_gemm_ct<1, RA, 32 * T2W>(acc3, ring3, W3, 32 * wave, R2, 0, 0, hk, lm);  // H2 / 8 = 32 * T2W groups
+    if (!DB) __syncthreads();                       // R3 overlays R2: every wave must have finished reading R2
     ft_store_tile(R3, acc3[0], 32 * wave, hk, lm);  // R3 image [H3/4][33]
     __syncthreads();
     stamp();
@@ -1342,7 +1397,11 @@ __global__ void __launch_bounds__(512) fr_fused_tile_kernel(const FrFusedArgs a)
     stamp();
 }
 
-size_t frk_fused_lds_bytes(int K, int H2) {
+size_t frk_fused_lds_bytes(int K, int H2, int wpe) {
+    if (wpe == 4) {  // Xq + one R1 buffer | R2, then R3 + scratch over R2
+        const size_t phase1 = (size_t)(K / 4) + 64, phase2 = (size_t)(H2 / 4) > 68 ? (size_t)(H2 / 4) : 68;
+        return (phase1 > phase2 ? phase1 : phase2) * FR_FT_LD * 16;
+    }
     const size_t phase1 = (size_t)(K / 4) + 128;      // Xq + two R1 chunk buffers
     const size_t phase2 = (size_t)(H2 / 4) + 64 + 4;  // R2 + R3 + the 2 KiB reduction scratch
     return (phase1 > phase2 ? phase1 : phase2) * FR_FT_LD * 16;
@@ -1350,30 +1409,44 @@ size_t frk_fused_lds_bytes(int K, int H2) {
 
 bool frk_fused_ok(int K, int H1, int H2, int H3) {
     if (K % 32 || H1 % 256 || (H2 != 256 && H2 != 512) || H3 != 256) return false;  // K/8 groups must be a multiple of D = 4
-    return frk_fused_lds_bytes(K, H2) <= 160 * 1024;
+    return frk_fused_lds_bytes(K, H2, 2) <= 160 * 1024;
 }
 
-template <int T2W, int KG, int D1>
+// two workgroups per CU need <= 80 KiB each (FR_FUSED_WPE=2 forces the one-workgroup build, for A/B measurements)
+static int fused_wpe(int K, int H2) {
+    static const int forced = [] {
+        const char *e = getenv("FR_FUSED_WPE");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 2 || forced == 4) return forced == 4 && frk_fused_lds_bytes(K, H2, 4) > 80 * 1024 ? 2 : forced;
+    return frk_fused_lds_bytes(K, H2, 4) <= 80 * 1024 ? 4 : 2;
+}
+
+template <int T2W, int KG, int D1, int WPE>
 static int fused_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fr_fused_tile_kernel<T2W, KG, D1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fr_fused_tile_kernel<T2W, KG, D1, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             FR_FAIL(FR_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
         attr_set = true;
     }
-    fr_fused_tile_kernel<T2W, KG, D1><<<grid, dim3(512), lds, s>>>(a);
+    fr_fused_tile_kernel<T2W, KG, D1, WPE><<<grid, dim3(512), lds, s>>>(a);
     KCHECK();
     return FR_OK;
 }
 
 int frk_fused_launch(const FrFusedArgs &a, hipStream_t s) {
-    const size_t lds = frk_fused_lds_bytes(a.K, a.H2);
+    const int wpe = fused_wpe(a.K, a.H2);
+    const size_t lds = frk_fused_lds_bytes(a.K, a.H2, wpe);
     dim3 grid(a.n_batches * a.tiles_per_batch);
     if (a.H2 == 512) {
-        if (a.K == 352) return fused_launch_inst<2, 44, 11>(a, grid, lds, s);  // Model-A: FC1 = 4 blocks of 11 groups
-        return fused_launch_inst<2, 0, 0>(a, grid, lds, s);
+        if (a.K == 352) {  // Model-A: straight-line FC1
+            if (wpe == 4) return fused_launch_inst<2, 44, 11, 4>(a, grid, lds, s);
+            return fused_launch_inst<2, 44, 11, 2>(a, grid, lds, s);
+        }
+        return fused_launch_inst<2, 0, 0, 2>(a, grid, lds, s);
     }
-    return fused_launch_inst<1, 0, 0>(a, grid, lds, s);
+    return fused_launch_inst<1, 0, 0, 2>(a, grid, lds, s);
 }
 
 // ===================================================================================================
