@@ -417,17 +417,11 @@ static int gather_q_blocks(int n_words, int ldm) { return ((ldm + 63) / 64) * ((
 
 // ---- stages 1..3: one 32(n) x 32(m) output tile per workgroup, 8 waves split the workgroup's K range in groups of
 // 8 k (one 16-byte load per operand per lane -> 4 MFMAs).
-template <bool TWO_IN>
-__device__ __forceinline__ float4 load_b4(const float4 *bq, const float4 *cq, size_t off) {
-    float4 b = bq[off];
-    if constexpr (TWO_IN) {  // launch-boundary reduce of the previous layer's two K halves
-        const float4 c = cq[off];
-        b.x += c.x;
-        b.y += c.y;
-        b.z += c.z;
-        b.w += c.w;
-    }
-    return b;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// 16 bytes per lane through a buffer resource: per-lane byte offset in a VGPR, wave-uniform byte offset in an SGPR
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
 __device__ __forceinline__ void mfma4(f32x16 &acc, const float4 &a, const float4 &b) {
@@ -477,17 +471,35 @@ __device__ __forceinline__ void fc_q_body(const FrStageArgs &st, int local, floa
     int ng = wg_begin + wg_ng - g_begin;
     ng = ng < 0 ? 0 : (ng > per ? per : ng);
 
-    // q4 element index of (k-quad 2g + hk, column): quad * ld + column
-    const float4 *aq = reinterpret_cast<const float4 *>(st.w) + (size_t)hk * N + n0 + lm;
-    const float4 *bq = reinterpret_cast<const float4 *>(st.in) + (size_t)hk * ldm + m0 + lm;
-    const float4 *cq = reinterpret_cast<const float4 *>(st.in + st.in_part_stride) + (size_t)hk * ldm + m0 + lm;
+    // q4 element (k-quad 2g + hk, column) of an operand = byte (quad * ld + column) * 16.  Both operands come through buffer
+    // loads: a constant per-lane VGPR offset plus a wave-uniform SGPR offset that advances by one group per step -- no 64-bit
+    // VALU address arithmetic in the loop (it costs MFMA issue slots: tools/experiments/mfma_loop, 75 -> 68 cycles per MFMA).
+    const unsigned KQ = (unsigned)(st.K / 4);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(st.w), 0, KQ * (unsigned)N * 16u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(st.in), 0, KQ * (unsigned)ldm * 16u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsC =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(st.in + (TWO_IN ? st.in_part_stride : 0)), 0, KQ * (unsigned)ldm * 16u, 0x00020000);
+    const unsigned voA = ((unsigned)hk * N + n0 + lm) * 16u, voB = ((unsigned)hk * ldm + m0 + lm) * 16u;
+    const unsigned stepA = 2u * (unsigned)N * 16u, stepB = 2u * (unsigned)ldm * 16u;
+    auto ld_a = [&](int g) { return bload4(rsA, voA, (unsigned)g * stepA); };
+    auto ld_b = [&](int g) {
+        float4 b = bload4(rsB, voB, (unsigned)g * stepB);
+        if constexpr (TWO_IN) {  // launch-boundary reduce of the previous layer's two K halves
+            const float4 c = bload4(rsC, voB, (unsigned)g * stepB);
+            b.x += c.x;
+            b.y += c.y;
+            b.z += c.z;
+            b.w += c.w;
+        }
+        return b;
+    };
 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
 
     // Double-buffered loop over blocks of D groups: the next block's 2*D 16-byte loads are in flight while the current
-    // block's 4*D MFMAs issue.  D = 2 keeps the kernel at 68 VGPRs (4 workgroups per CU): these workgroups are bound by
+    // block's 4*D MFMAs issue.  D = 2 keeps the kernel small (4 workgroups per CU): these workgroups are bound by
     // the CU's L2 ingest, not by issue slots, and measured faster than straight-line bodies that hold a whole K slice
     // in registers (110-165 VGPRs, 1-2 workgroups per CU).
     constexpr int D = 2;
@@ -496,16 +508,16 @@ __device__ __forceinline__ void fc_q_body(const FrStageArgs &st, int local, floa
     if (nb_full > 0) {
 #pragma unroll
         for (int i = 0; i < D; i++) {
-            ra[i] = aq[(size_t)(2 * (g_begin + i)) * N];
-            rb[i] = load_b4<TWO_IN>(bq, cq, (size_t)(2 * (g_begin + i)) * ldm);
+            ra[i] = ld_a(g_begin + i);
+            rb[i] = ld_b(g_begin + i);
         }
     }
     for (int blk = 0; blk < nb_full; blk++) {
         const int nx = (blk + 1 < nb_full) ? (blk + 1) : blk;  // the last block re-loads itself (harmless) -> branch-free body
 #pragma unroll
         for (int i = 0; i < D; i++) {
-            na[i] = aq[(size_t)(2 * (g_begin + nx * D + i)) * N];
-            nb[i] = load_b4<TWO_IN>(bq, cq, (size_t)(2 * (g_begin + nx * D + i)) * ldm);
+            na[i] = ld_a(g_begin + nx * D + i);
+            nb[i] = ld_b(g_begin + nx * D + i);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from sinking the loads next to their consumers
 #pragma unroll
@@ -518,7 +530,7 @@ __device__ __forceinline__ void fc_q_body(const FrStageArgs &st, int local, floa
         }
     }
     for (int g = g_begin + nb_full * D; g < g_begin + ng; g++)  // remainder (< D groups)
-        mfma4(acc, aq[(size_t)(2 * g) * N], load_b4<TWO_IN>(bq, cq, (size_t)(2 * g) * ldm));
+        mfma4(acc, ld_a(g), ld_b(g));
     // cross-wave reduction in fixed order, then the tile goes out as q4 elements (registers 4i..4i+3 = 4 consecutive n)
 #pragma unroll
     for (int r = 0; r < 16; r++) red[(wave * 16 + r) * 64 + lane] = acc[r];
