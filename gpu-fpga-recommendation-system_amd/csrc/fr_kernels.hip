@@ -418,6 +418,10 @@ static int gather_q_blocks(int n_words, int ldm) { return ((ldm + 63) / 64) * ((
 // ---- stages 1..3: one 32(n) x 32(m) output tile per workgroup, 8 waves split the workgroup's K range in groups of
 // 8 k (one 16-byte load per operand per lane -> 4 MFMAs).
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 bload4u(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 // 16 bytes per lane through a buffer resource: per-lane byte offset in a VGPR, wave-uniform byte offset in an SGPR
 __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
@@ -685,8 +689,14 @@ __device__ __forceinline__ void fc_h_body(const FrStageArgs &st, int local, floa
     const int g_begin = wave * per;
     int ng_ = groups - g_begin;
     ng_ = ng_ < 0 ? 0 : (ng_ > per ? per : ng_);
-    const uint4 *aq = reinterpret_cast<const uint4 *>(st.w) + (size_t)hk * N + n0 + lm;
-    const uint4 *bq = reinterpret_cast<const uint4 *>(st.in) + (size_t)hk * ldm + m0 + lm;
+    // buffer loads: constant per-lane VGPR offset + wave-uniform SGPR offset per group (see fc_q_body)
+    const unsigned KO = (unsigned)(st.K / 8);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(st.w), 0, KO * (unsigned)N * 16u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(st.in), 0, KO * (unsigned)ldm * 16u, 0x00020000);
+    const unsigned voA = ((unsigned)hk * N + n0 + lm) * 16u, voB = ((unsigned)hk * ldm + m0 + lm) * 16u;
+    const unsigned stepA = 2u * (unsigned)N * 16u, stepB = 2u * (unsigned)ldm * 16u;
+    auto ld_a = [&](int g) { return bload4u(rsA, voA, (unsigned)g * stepA); };
+    auto ld_b = [&](int g) { return bload4u(rsB, voB, (unsigned)g * stepB); };
 
     f32x16 acc;
 #pragma unroll
@@ -697,16 +707,16 @@ __device__ __forceinline__ void fc_h_body(const FrStageArgs &st, int local, floa
     if (nb_full > 0) {
 #pragma unroll
         for (int i = 0; i < D; i++) {
-            ra[i] = aq[(size_t)(2 * (g_begin + i)) * N];
-            rb[i] = bq[(size_t)(2 * (g_begin + i)) * ldm];
+            ra[i] = ld_a(g_begin + i);
+            rb[i] = ld_b(g_begin + i);
         }
     }
     for (int blk = 0; blk < nb_full; blk++) {
         const int nx = (blk + 1 < nb_full) ? (blk + 1) : blk;
 #pragma unroll
         for (int i = 0; i < D; i++) {
-            na[i] = aq[(size_t)(2 * (g_begin + nx * D + i)) * N];
-            nb[i] = bq[(size_t)(2 * (g_begin + nx * D + i)) * ldm];
+            na[i] = ld_a(g_begin + nx * D + i);
+            nb[i] = ld_b(g_begin + nx * D + i);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -720,7 +730,7 @@ __device__ __forceinline__ void fc_h_body(const FrStageArgs &st, int local, floa
         }
     }
     for (int g = g_begin + nb_full * D; g < g_begin + ng_; g++) {
-        const uint4 a8 = aq[(size_t)(2 * g) * N], b8 = bq[(size_t)(2 * g) * ldm];
+        const uint4 a8 = ld_a(g), b8 = ld_b(g);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, b8), acc, 0, 0, 0);
     }
 #pragma unroll
@@ -1469,15 +1479,14 @@ int frk_fused_launch(const FrFusedArgs &a, hipStream_t s) {
 // 32 * MT items (MT = 2: every weight fragment feeds two m tiles) and the weight ring is as deep as the registers allow.
 // ===================================================================================================
 template <int NT, int MT, int R, int CNT>
-__device__ __forceinline__ void fth_gemm_ct(f32x16 (&acc)[NT][MT], const uint4 *__restrict__ wh, int N, int n0, const uint4 *Bh, int ld, int gb0,
-                                            int g0, int hk, int lm) {
-    const uint4 *aq = wh + (size_t)(2 * g0 + hk) * N + n0 + lm;
+__device__ __forceinline__ void fth_gemm_ct(f32x16 (&acc)[NT][MT], const FtW &w, int n0, const uint4 *Bh, int ld, int gb0, int g0, int hk, int lm) {
+    const unsigned s0 = (unsigned)g0 * w.row2 + (unsigned)n0 * 16u;  // n0, g0 wave-uniform
     const uint4 *bl = Bh + (size_t)(2 * gb0 + hk) * ld + lm;
     uint4 ring[R][NT];
 #pragma unroll
     for (int g = 0; g < R && g < CNT; g++)
 #pragma unroll
-        for (int t = 0; t < NT; t++) ring[g][t] = aq[(size_t)(2 * g) * N + 32 * t];
+        for (int t = 0; t < NT; t++) ring[g][t] = __builtin_bit_cast(uint4, ft_wload(w, s0 + (unsigned)g * w.row2, 512 * t));
 #pragma unroll
     for (int g = 0; g < CNT; g++) {
         uint4 b8[MT];
@@ -1491,7 +1500,7 @@ __device__ __forceinline__ void fth_gemm_ct(f32x16 (&acc)[NT][MT], const uint4 *
                                                                      acc[t][mt], 0, 0, 0);
         if (g + R < CNT) {
 #pragma unroll
-            for (int t = 0; t < NT; t++) ring[g % R][t] = aq[(size_t)(2 * (g + R)) * N + 32 * t];
+            for (int t = 0; t < NT; t++) ring[g % R][t] = __builtin_bit_cast(uint4, ft_wload(w, s0 + (unsigned)(g + R) * w.row2, 512 * t));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -1577,21 +1586,22 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
 #pragma unroll
             for (int i = 0; i < 16; i++) acc2[t][mt][i] = 0.0f;
     const int n_chunks = a.H1 / 256;
-    const uint4 *w1h = reinterpret_cast<const uint4 *>(a.w1q), *w2h = reinterpret_cast<const uint4 *>(a.w2q), *w3h = reinterpret_cast<const uint4 *>(a.w3q);
+    // q8 weights: (K / 8) rows of N 16-byte elements -> ft_w's K / 4 rows of the q4 layout is K / 2 here
+    const FtW W1 = ft_w(a.w1q, a.K / 2, a.H1, hk, lm), W2 = ft_w(a.w2q, a.H1 / 2, a.H2, hk, lm), W3 = ft_w(a.w3q, a.H2 / 2, a.H3, hk, lm);
     for (int c = 0; c < n_chunks; c++) {
         f32x16 acc1[1][MT];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc1[0][mt][i] = 0.0f;
-        fth_gemm_ct<1, MT, 16, KG>(acc1, w1h, a.H1, c * 256 + 32 * wave, Xh, LD, 0, 0, hk, lm);
+        fth_gemm_ct<1, MT, 16, KG>(acc1, W1, c * 256 + 32 * wave, Xh, LD, 0, 0, hk, lm);
         uint4 *R1 = R1b[DB ? (c & 1) : 0];
         if (!DB && c > 0) __syncthreads();  // single R1 buffer: every wave must be done reading the previous chunk
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) fth_store_tile(R1, LD, acc1[0][mt], 32 * wave, 32 * mt, hk, lm);
         __syncthreads();
         // FC2: K range [256 c, 256 c + 256) = 16 groups of 16 k
-        fth_gemm_ct<T2W, MT, 16 / T2W, 16>(acc2, w2h, a.H2, 32 * T2W * wave, R1, LD, 0, 16 * c, hk, lm);
+        fth_gemm_ct<T2W, MT, 16 / T2W, 16>(acc2, W2, 32 * T2W * wave, R1, LD, 0, 16 * c, hk, lm);
     }
     __syncthreads();  // Xh and R1 dead: R2 may overlay them
 #pragma unroll
@@ -1605,7 +1615,7 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc3[0][mt][i] = 0.0f;
-    fth_gemm_ct<1, MT, 16, 16 * T2W>(acc3, w3h, a.H3, 32 * wave, R2, LD, 0, 0, hk, lm);  // H2 / 16 groups
+    fth_gemm_ct<1, MT, 16, 16 * T2W>(acc3, W3, 32 * wave, R2, LD, 0, 0, hk, lm);  // H2 / 16 groups
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) fth_store_tile(R3, LD, acc3[0][mt], 32 * wave, 32 * mt, hk, lm);
     __syncthreads();
