@@ -28,7 +28,7 @@ static const int kIdxRandom[32] = {3, 99, 38, 72, 29, 57, 1, 72, 36, 76, 35, 50,
 
 int main(int argc, char **argv) {
     int which = FR_MODEL_A, batch = 256, threads = 4, port = 8080;
-    long row_cap = 0, max_blocks = 1L << 40;
+    long row_cap = 0, max_blocks = 1L << 40, interval_us = 0;
     std::string host = "127.0.0.1", indices = "reference";
     bool per_item = false, reply = false;
     for (int i = 1; i < argc; i++) {
@@ -44,6 +44,7 @@ int main(int argc, char **argv) {
         else if (a == "--reply") reply = true;
         else if (a == "--row-cap") row_cap = atol(next());
         else if (a == "--max-blocks") max_blocks = atol(next());
+        else if (a == "--interval-us") interval_us = atol(next());
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     fr_model_desc *m = nullptr;
@@ -82,6 +83,7 @@ int main(int argc, char **argv) {
                 if (send(sock, idx.data(), idx.size() * 4, MSG_NOSIGNAL) <= 0) break;
                 if (!dense.empty() && send(sock, dense.data(), dense.size() * 4, MSG_NOSIGNAL) <= 0) break;
                 sent[t]++;
+                if (interval_us > 0) usleep((useconds_t)interval_us);  // rate limit of the latency experiment (reference sender: usleep(useconds))
                 if (reply) {
                     size_t got = 0;
                     while (got < scores.size() * 4) {

@@ -18,6 +18,7 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +35,7 @@ struct Options {
     long total = 1024;
     int tables = FR_FILL_EVEN_ODD, weights = FR_WEIGHTS_ONES;
     bool per_item = false, reply = false;
+    bool latency = false;  // latency-measurement mode: per-batch recv -> enqueued -> scores times (measure_network_cuda_cp_latency_*/cuda_server.c)
     long row_cap = 0;
 };
 
@@ -66,6 +68,7 @@ struct ThreadInfo {  // struct CUDA_thread_info (cuda_server.c:91-98)
     int port;
     fr_ctx *ctx;
     std::vector<double> recv_to_submit_us;
+    std::vector<double> recv_to_scores_us;  // latency mode: batch fully received -> its scores are in host memory
     std::vector<float> first_scores;
     long batches = 0;
     int status = 0;
@@ -128,6 +131,7 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
                 t->error = fr_last_error();
                 break;
             }
+            if (o.latency) t->recv_to_scores_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_recv).count());
             if (o.reply && !write_exact(sock, fr_worker_score_ptr(wk), (size_t)o.batch * sizeof(float))) {
                 t->status = -7;
                 t->error = "sending scores failed";
@@ -158,6 +162,7 @@ int main(int argc, char **argv) {
         else if (a == "--weights") o.weights = std::string(next()) == "uniform" ? FR_WEIGHTS_UNIFORM : FR_WEIGHTS_ONES;
         else if (a == "--per-item") o.per_item = true;
         else if (a == "--reply") o.reply = true;
+        else if (a == "--latency") o.latency = true;
         else if (a == "--row-cap") o.row_cap = atol(next());
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -201,6 +206,31 @@ int main(int argc, char **argv) {
     }
     printf("processed %ld batches (%ld inferences) in %.3f s incl. connection set-up\n", done, done * o.batch, secs);
     if (nlat) printf("Average time from batch received to enqueued: %.3f us\n", lat / nlat);  // the reference's memcpy-time statistic (:565-591)
+    if (o.latency) {
+        // The reference's latency experiment (measure_network_cuda_cp_latency_single_node/cuda_server.c:1-15,227,548,728-737): the
+        // sender is rate-limited so the server is never the bottleneck, and every batch's "received" and "on the device"
+        // timestamps are differenced; here the second stamp also exists for "scores back in host memory".
+        auto report = [&](const char *what, std::vector<double> v) {
+            if (v.empty()) return;
+            std::sort(v.begin(), v.end());
+            double sum = 0;
+            for (double x : v) sum += x;
+            auto pct = [&](double p) { return v[(size_t)std::min<double>(v.size() - 1, p * v.size())]; };
+            printf("latency %-34s n=%zu avg %.1f us  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f\n", what, v.size(), sum / v.size(), pct(0.50), pct(0.90), pct(0.99),
+                   v.back());
+        };
+        std::vector<double> a, b;
+        for (int i = 0; i < o.threads; i++) {
+            const size_t skip = std::min<size_t>(info[i].recv_to_submit_us.size(), 8);  // first batches include kernel/code-object warm-up
+            a.insert(a.end(), info[i].recv_to_submit_us.begin() + skip, info[i].recv_to_submit_us.end());
+            const size_t skip2 = std::min<size_t>(info[i].recv_to_scores_us.size(), 8);
+            b.insert(b.end(), info[i].recv_to_scores_us.begin() + skip2, info[i].recv_to_scores_us.end());
+        }
+        for (size_t i = 0; i < info[0].recv_to_scores_us.size() && i < 10; i++)  // the reference prints every batch (:732); first ten here
+            printf("i = %zu recv->enqueued = %.0f ns, recv->scores = %.0f ns\n", i, info[0].recv_to_submit_us[i] * 1e3, info[0].recv_to_scores_us[i] * 1e3);
+        report("batch received -> enqueued", a);
+        report("batch received -> scores on host", b);
+    }
     fr_ctx_destroy(ctx);
     fr_model_free(model);
     return rc;

@@ -43,3 +43,32 @@ def test_server_and_sender_known_answer(fr, gpu, model, val, extra):
         assert v == [0.0, 0.0, val, val, 0.0], (v, out)
     assert "Average time from batch received to enqueued" in out
     assert "blocks sent" in sout.decode()
+
+
+def test_latency_measurement_mode(fr, gpu):
+    """the reference's latency experiment (measure_network_cuda_cp_latency_single_node/cuda_server.c):
+    a rate-limited sender, per-batch 'received' -> 'enqueued on the device' -> 'scores on the host' times and their summary."""
+    if not os.path.exists(os.path.join(HOST, "fleetrec_server")):
+        subprocess.check_call(["make", "-s", "-C", HOST])
+    port, threads, total = 18160, 2, 80
+    srv = subprocess.Popen([os.path.join(HOST, "fleetrec_server"), "--model", "A", "--batch", "256", "--threads", str(threads), "--port", str(port),
+                            "--total", str(total), "--tables", "hash", "--weights", "uniform", "--latency"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    time.sleep(0.5)
+    snd = subprocess.Popen([os.path.join(HOST, "fleetrec_sender"), "--model", "A", "--batch", "256", "--threads", str(threads), "--port", str(port),
+                            "--interval-us", "1000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    try:
+        out, _ = srv.communicate(timeout=300)
+        snd.communicate(timeout=60)
+    finally:
+        for p in (srv, snd):
+            if p.poll() is None:
+                p.kill()
+    out = out.decode()
+    assert srv.returncode == 0, out
+    m1 = re.search(r"latency batch received -> enqueued\s+n=(\d+) avg ([0-9.]+) us", out)
+    m2 = re.search(r"latency batch received -> scores on host\s+n=(\d+) avg ([0-9.]+) us\s+p50 ([0-9.]+)", out)
+    assert m1 and m2, out
+    assert int(m2.group(1)) == total - 8 * threads          # the first 8 batches of each thread are warm-up
+    assert float(m1.group(2)) <= float(m2.group(2))          # enqueue returns before the scores exist
+    assert 0.0 < float(m2.group(3)) < 20000.0, out           # a batch of 256 answers within 20 ms even on a cold box
+    assert "i = 0 recv->enqueued" in out
