@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true", help="plumbing test: ranks share the visible GPU(s) (use with --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-zipf", action="store_true", help="skip the zipf-index repeat of the Model-C gather leg (PMC passes: one index law per kernel name)")
     ap.add_argument("--no-model-c", action="store_true", help="skip the Model-C batch-4096 gather roofline leg")
     args = ap.parse_args()
 
@@ -234,10 +235,12 @@ def main():
         group = ctx.stream_group()
         wk = fr.Worker(ctx, B)
         ring = [fr.DeviceBuffer(ctx, B * 4) for _ in range(max(8, 2 * group))]
-        for i in range(4 * group):
-            wk.push_device(B, d_idx[i % N_IDX_BUFFERS], None, ring[i % len(ring)])
-        wk.sync()
-        launches = 60 if group > 1 else 1000
+        t_warm = time.time()   # >= 1 s of back-to-back launches first: the shader clock ramps over many milliseconds of load, and
+        while time.time() - t_warm < 1.0:   # with --roofline-only nothing else has loaded the chip before this point
+            for i in range(4 * group):
+                wk.push_device(B, d_idx[i % N_IDX_BUFFERS], None, ring[i % len(ring)])
+            wk.sync()
+        launches = 200 if group > 1 else 1000
         if group == 1:
             for i in range(8):   # refill the stage pipeline so that every timed launch carries all five stages
                 wk.push_device(B, d_idx[i % N_IDX_BUFFERS], None, ring[i % len(ring)])
@@ -249,9 +252,10 @@ def main():
         fc = model.fc
         flops = fc_flops_per_inference(fc) * B * group
         ach = flops / (pipe_ms * 1e-3) / 1e12
-        kname = "fr_fused_tile_kernel<2, 44, 11>" if group > 1 else "fr_pipeline_kernel<-1, 0>"
+        wpe = int(os.environ.get("FR_FUSED_WPE", "4"))  # workgroups are built for 4 waves per SIMD (two per CU) unless forced to 2
+        kname = "fr_fused_tile_kernel<2, 44, 11, %d>" % wpe if group > 1 else "fr_pipeline_kernel<-1, 0>"
         result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": ach / MFMA_F32_PEAK_TF, "traffic": pmc_traffic(kname),
+                              "frac": ach / MFMA_F32_PEAK_TF, "traffic": pmc_traffic(kname.split(",")[0] if group > 1 else kname),
                               "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
                                                 "FETCH_SIZE x2 gfx950 correction), bytes per launch",
                               "kernel": "%s: one launch = the whole hot path (gather + the 4-GEMM chain) of %d queued batches of %d, "
@@ -360,6 +364,26 @@ def main():
                                 "traffic_source": "profiles/r01_pmc_traffic.json (PMC, FETCH_SIZE x2 correction), bytes per launch", "avg_launch_ms": ms,
                                 "algorithmic_bytes_per_launch": gb, "inferences_per_s": BC / (ms * 1e-3),
                                 "kernel": "gather_pack_xcd_kernel<8>"}
+            # same kernel, zipf(1.05) indices per table (SURVEY 8d input (ii)): popular rows repeat inside a batch, the repeats
+            # are merged by the texture-address coalescer / served by L2, so no explicit ballot/shuffle dedup pass is needed
+            def zipf_idx(shape, rows, alpha=1.05):
+                u = rng.random(shape)
+                x = ((rows[None, :].astype(np.float64) ** (1.0 - alpha) - 1.0) * u + 1.0) ** (1.0 / (1.0 - alpha))
+                return np.minimum(np.floor(x) - 1, rows[None, :] - 1).astype(np.int32)
+            zs = [zipf_idx((BC, mc.n_tables), rows) for _ in range(0 if args.no_zipf else nbuf)]
+            if zs:
+                dup = float(np.mean([1.0 - len(np.unique(z[:, t])) / BC for z in zs[:2] for t in range(0, mc.n_tables, 7)]))
+                zidx = [fr.DeviceBuffer.from_numpy(cc, z) for z in zs]
+                for i in range(10):
+                    wk.gather_only(BC, zidx[i % nbuf], dns[i % nbuf], rec)
+                wk.sync()
+                wk.timer_start()
+                for i in range(reps):
+                    wk.gather_only(BC, zidx[i % nbuf], dns[i % nbuf], rec)
+                zms = wk.timer_stop_ms() / reps
+                wk.sync()
+                result["gather"]["zipf_1.05"] = {"avg_launch_ms": zms, "achieved": gb / (zms * 1e-3) / 1e9, "frac": gb / (zms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                 "duplicate_fraction_within_batch": dup}
             wk.close()
             cc.close()
         except Exception as ex:  # the main metric must still be reported

@@ -1265,16 +1265,15 @@ __device__ __forceinline__ void ft_store_tile(uint4 *img, const f32x16 &acc, int
     }
 }
 
-// T2W = H2 / 256 (n tiles of FC2 per wave); KG = K / 8 when FC1 has a straight-line instantiation with blocks of D1 groups
-// (KG % D1 == 0), else 0 (run-time loop).
-// WPE = waves per SIMD the kernel is built for.  2: one workgroup per CU, double-buffered R1, deep weight rings.  4: TWO
-// workgroups per CU (<= 128 VGPRs, <= 80 KiB LDS: single R1 buffer, R3 overlays R2, half-depth rings -- the same bytes in
-// flight per CU) so that one workgroup's gather / barrier / epilogue phases run under the other one's MFMAs.
-template <int T2W, int KG, int D1, int WPE>
+// T2W = H2 / 256 (n tiles of FC2 per wave); KG = K / 8 when FC1 has a straight-line instantiation, else 0 (run-time loop).
+// WPE = waves per SIMD the kernel is built for.  2: one workgroup per CU, deep weight rings.  4: TWO workgroups per CU
+// (<= 128 VGPRs, <= 80 KiB LDS, half-depth rings -- the same bytes in flight per CU) so that one workgroup's gather / barrier /
+// epilogue phases run under the other one's MFMAs.  DB: double-buffered R1 (one barrier per chunk); !DB: single R1 buffer and
+// R3 overlaying R2 -- the small-LDS layout that WPE 4 needs and that lets a K = 880 record (Model-B) fit at WPE 2.
+template <int T2W, int KG, int WPE, bool DB>
 __global__ void __launch_bounds__(512, WPE) fr_fused_tile_kernel(const FrFusedArgs a) {
     extern __shared__ uint4 lds[];
-    constexpr bool DB = (WPE == 2);
-    constexpr int RD = DB ? 1 : 2;  // ring depth divisor
+    constexpr int RD = (WPE == 2) ? 1 : 2;  // ring depth divisor: half-depth rings when two workgroups share a CU's registers
     const int KQ = a.K / 4;
     // LDS: [ Xq: KQ rows | R1 chunk buffer 0: 64 rows | R1 chunk buffer 1: 64 rows ]; R2 (H2/4 rows) overlays the start once
     // Xq and the R1 chunks are dead, R3 (64 rows) follows R2.
@@ -1419,7 +1418,7 @@ __global__ void __launch_bounds__(512, WPE) fr_fused_tile_kernel(const FrFusedAr
     stamp();
 }
 
-size_t frk_fused_lds_bytes(int K, int H2, int wpe) {
+size_t frk_fused_lds_bytes(int K, int H2, int wpe) {  // wpe 4 stands for the single-buffer layout here
     if (wpe == 4) {  // Xq + one R1 buffer | R2, then R3 + scratch over R2
         const size_t phase1 = (size_t)(K / 4) + 64, phase2 = (size_t)(H2 / 4) > 68 ? (size_t)(H2 / 4) : 68;
         return (phase1 > phase2 ? phase1 : phase2) * FR_FT_LD * 16;
@@ -1430,8 +1429,9 @@ size_t frk_fused_lds_bytes(int K, int H2, int wpe) {
 }
 
 bool frk_fused_ok(int K, int H1, int H2, int H3) {
-    if (K % 32 || H1 % 256 || (H2 != 256 && H2 != 512) || H3 != 256) return false;  // K/8 groups must be a multiple of D = 4
-    return frk_fused_lds_bytes(K, H2, 2) <= 160 * 1024;
+    const bool straight = (K == 352 || K == 880) && H2 == 512;  // straight-line FC1 instantiations (Model-A, Model-B)
+    if ((!straight && K % 32) || H1 % 256 || (H2 != 256 && H2 != 512) || H3 != 256) return false;  // run-time loop: K/8 groups in blocks of 4
+    return frk_fused_lds_bytes(K, H2, 4) <= 160 * 1024;  // the single-buffer layout is the smallest
 }
 
 // two workgroups per CU need <= 80 KiB each (FR_FUSED_WPE=2 forces the one-workgroup build, for A/B measurements)
@@ -1444,31 +1444,35 @@ static int fused_wpe(int K, int H2) {
     return frk_fused_lds_bytes(K, H2, 4) <= 80 * 1024 ? 4 : 2;
 }
 
-template <int T2W, int KG, int D1, int WPE>
+template <int T2W, int KG, int WPE, bool DB>
 static int fused_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fr_fused_tile_kernel<T2W, KG, D1, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fr_fused_tile_kernel<T2W, KG, WPE, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             FR_FAIL(FR_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
         attr_set = true;
     }
-    fr_fused_tile_kernel<T2W, KG, D1, WPE><<<grid, dim3(512), lds, s>>>(a);
+    fr_fused_tile_kernel<T2W, KG, WPE, DB><<<grid, dim3(512), lds, s>>>(a);
     KCHECK();
     return FR_OK;
 }
 
 int frk_fused_launch(const FrFusedArgs &a, hipStream_t s) {
-    const int wpe = fused_wpe(a.K, a.H2);
-    const size_t lds = frk_fused_lds_bytes(a.K, a.H2, wpe);
+    int wpe = fused_wpe(a.K, a.H2);
+    const bool db = wpe == 2 && frk_fused_lds_bytes(a.K, a.H2, 2) <= 160 * 1024;
+    const size_t lds = frk_fused_lds_bytes(a.K, a.H2, db ? 2 : 4);
     dim3 grid(a.n_batches * a.tiles_per_batch);
     if (a.H2 == 512) {
         if (a.K == 352) {  // Model-A: straight-line FC1
-            if (wpe == 4) return fused_launch_inst<2, 44, 11, 4>(a, grid, lds, s);
-            return fused_launch_inst<2, 44, 11, 2>(a, grid, lds, s);
+            if (wpe == 4) return fused_launch_inst<2, 44, 4, false>(a, grid, lds, s);
+            return fused_launch_inst<2, 44, 2, true>(a, grid, lds, s);
         }
-        return fused_launch_inst<2, 0, 0, 2>(a, grid, lds, s);
+        if (a.K == 880) return fused_launch_inst<2, 110, 2, false>(a, grid, lds, s);  // Model-B: 150 KiB with one R1 buffer
+        if (db) return fused_launch_inst<2, 0, 2, true>(a, grid, lds, s);
+        return fused_launch_inst<2, 0, 2, false>(a, grid, lds, s);
     }
-    return fused_launch_inst<1, 0, 0, 2>(a, grid, lds, s);
+    if (db) return fused_launch_inst<1, 0, 2, true>(a, grid, lds, s);
+    return fused_launch_inst<1, 0, 2, false>(a, grid, lds, s);
 }
 
 // ===================================================================================================

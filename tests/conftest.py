@@ -34,3 +34,26 @@ def gpu(fr):
     if fr.device_count() < 1:
         pytest.fail("gpu-marked test running without a visible HIP device (no CPU fallback exists)")
     return 0
+
+
+def free_port_block(n=1):
+    """A base port such that base .. base+n-1 could all be bound right now (the GPU host's network namespace may be shared with
+    other jobs, so fixed port numbers are not safe)."""
+    import random
+    import socket
+    for _ in range(200):
+        base = random.randint(20000, 60000 - n)
+        socks = []
+        try:
+            for i in range(n):
+                sk = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                sk.bind(("0.0.0.0", base + i))
+                socks.append(sk)
+            return base
+        except OSError:
+            continue
+        finally:
+            for sk in socks:
+                sk.close()
+    raise RuntimeError("no free block of %d ports found" % n)

@@ -8,6 +8,7 @@ import textwrap
 
 import numpy as np
 import pytest
+from conftest import free_port_block
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -71,7 +72,7 @@ WORKER = textwrap.dedent('''
 def test_two_rank_gloo(tmp_path, which, name, fr, O):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT, "which": which, "name": name})
-    port = 29600 + which
+    port = free_port_block(1)
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),

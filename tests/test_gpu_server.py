@@ -6,6 +6,7 @@ import subprocess
 import time
 
 import pytest
+from conftest import free_port_block
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,8 +19,8 @@ def test_server_and_sender_known_answer(fr, gpu, model, val, extra):
     last batch are 0 0 K*H1*H2*H3 K*H1*H2*H3 0 (indices 3, 99, 38, 72, 29), as the reference prints them (cuda_server.c:499-502)."""
     if not os.path.exists(os.path.join(HOST, "fleetrec_server")):
         subprocess.check_call(["make", "-s", "-C", HOST])
-    port = 18080 + (0 if model == "A" else 40)
     threads, total = 4, 64
+    port = free_port_block(threads)
     srv = subprocess.Popen([os.path.join(HOST, "fleetrec_server"), "--model", model, "--batch", "128", "--threads", str(threads),
                             "--port", str(port), "--total", str(total), "--tables", "evenodd", "--weights", "ones"] + extra,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -50,7 +51,8 @@ def test_latency_measurement_mode(fr, gpu):
     a rate-limited sender, per-batch 'received' -> 'enqueued on the device' -> 'scores on the host' times and their summary."""
     if not os.path.exists(os.path.join(HOST, "fleetrec_server")):
         subprocess.check_call(["make", "-s", "-C", HOST])
-    port, threads, total = 18160, 2, 80
+    threads, total = 2, 80
+    port = free_port_block(threads)
     srv = subprocess.Popen([os.path.join(HOST, "fleetrec_server"), "--model", "A", "--batch", "256", "--threads", str(threads), "--port", str(port),
                             "--total", str(total), "--tables", "hash", "--weights", "uniform", "--latency"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     time.sleep(0.5)

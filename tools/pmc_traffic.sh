@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $pass | tr ' ' '_')
-  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/$tag -- python3 $ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline > $OUT/$tag.log 2>&1
+  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/$tag -- python3 $ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-zipf > $OUT/$tag.log 2>&1
 done
 cd $ROOT
 python3 tools/pmc_summarize.py $OUT > $OUT/summary.json
