@@ -200,9 +200,13 @@ int main(int argc, char **argv) {
         }
         done += info[i].batches;
         for (double v : info[i].recv_to_submit_us) lat += v, nlat++;
-        printf("thread %d scores:", i);
-        for (float v : info[i].first_scores) printf(" %f", v);
-        printf("\n");
+        if (info[i].batches > 0) {  // a thread whose connection came up after the last batch was taken has nothing to show
+            printf("thread %d scores:", i);
+            for (float v : info[i].first_scores) printf(" %f", v);
+            printf("\n");
+        } else {
+            printf("thread %d took no batch\n", i);
+        }
     }
     printf("processed %ld batches (%ld inferences) in %.3f s incl. connection set-up\n", done, done * o.batch, secs);
     if (nlat) printf("Average time from batch received to enqueued: %.3f us\n", lat / nlat);  // the reference's memcpy-time statistic (:565-591)

@@ -38,7 +38,8 @@ def test_server_and_sender_known_answer(fr, gpu, model, val, extra):
     assert srv.returncode == 0, out
     assert "processed %d batches" % total in out, out
     rows = re.findall(r"thread \d+ scores:((?: [-0-9.e+]+)+)", out)
-    assert len(rows) == threads
+    assert 1 <= len(rows) <= threads   # a thread that connected after the last batch was taken prints no scores
+    assert len(rows) + out.count("took no batch") == threads
     for r in rows:
         v = [float(x) for x in r.split()]
         assert v == [0.0, 0.0, val, val, 0.0], (v, out)
