@@ -71,7 +71,7 @@ def test_latency_measurement_mode(fr, gpu):
     m1 = re.search(r"latency batch received -> enqueued\s+n=(\d+) avg ([0-9.]+) us", out)
     m2 = re.search(r"latency batch received -> scores on host\s+n=(\d+) avg ([0-9.]+) us\s+p50 ([0-9.]+)", out)
     assert m1 and m2, out
-    assert int(m2.group(1)) == total - 8 * threads          # the first 8 batches of each thread are warm-up
+    assert total - 8 * threads <= int(m2.group(1)) <= total - 8   # up to the first 8 batches of each thread are dropped as warm-up
     assert float(m1.group(2)) <= float(m2.group(2))          # enqueue returns before the scores exist
     assert 0.0 < float(m2.group(3)) < 20000.0, out           # a batch of 256 answers within 20 ms even on a cold box
     assert "i = 0 recv->enqueued" in out
