@@ -623,7 +623,7 @@ static int pipeline_flush(fr_worker *w) {
 // throughput for latency (fr_ctx_set_stream_group; env FR_FUSED_GROUP sets the initial value).
 static int g_fused_group = [] {
     const char *e = getenv("FR_FUSED_GROUP");
-    int v = e ? atoi(e) : FR_FUSED_MAX_BATCHES;
+    int v = e ? atoi(e) : FR_FUSED_DEFAULT_BATCHES;
     return v < 1 ? 1 : (v > FR_FUSED_MAX_BATCHES ? FR_FUSED_MAX_BATCHES : v);
 }();
 static int fused_group() { return g_fused_group; }

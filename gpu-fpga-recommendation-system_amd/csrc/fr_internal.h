@@ -77,7 +77,8 @@ struct FrPipeArgs {
 };
 
 // ---- fused item-tile kernel: launch arguments (see fr_kernels.hip) -----------------------------------
-constexpr int FR_FUSED_MAX_BATCHES = 32;
+constexpr int FR_FUSED_MAX_BATCHES = 64;   // kernel-argument array size (64 x 32 B)
+constexpr int FR_FUSED_DEFAULT_BATCHES = 32;
 struct FrFusedBatch {
     const int32_t *idx;
     const float *dense;
