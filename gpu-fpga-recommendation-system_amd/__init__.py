@@ -20,7 +20,7 @@ FR_OK, FR_ERR_INVALID, FR_ERR_NO_DEVICE, FR_ERR_OOM, FR_ERR_HIP, FR_ERR_INDEX_RA
 MODEL_A, MODEL_B, MODEL_C = 0, 1, 2
 FILL_EVEN_ODD, FILL_HASH, FILL_TAGGED = 0, 1, 2
 WEIGHTS_ONES, WEIGHTS_UNIFORM = 0, 1
-FC_FP32, FC_BF16 = 0, 1
+FC_FP32, FC_BF16, FC_FP8 = 0, 1, 2
 LAYOUT_SEMANTIC, LAYOUT_BLOCKED = 0, 1
 INDEX_PER_TABLE, INDEX_PER_ITEM = 0, 1
 SEG_TABLE, SEG_COPY, SEG_DENSE = 0, 1, 2
@@ -58,7 +58,8 @@ ABI_SYMBOLS = [
     "fr_abi_version", "fr_last_error", "fr_device_count", "fr_model_builtin", "fr_model_clone_scaled", "fr_model_free",
     "fr_model_table_bytes", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
     "fr_ctx_fill_tables", "fr_ctx_upload_table", "fr_ctx_download_table", "fr_ctx_set_weights", "fr_ctx_fill_weights",
-    "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
+    "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_ctx_get_fp8_exponents", "fr_ctx_set_fp8_act_exponents",
+    "fr_worker_calibrate_fp8", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
     "fr_worker_dense_ptr", "fr_worker_score_ptr", "fr_worker_submit", "fr_worker_submit_device", "fr_worker_push_device", "fr_worker_sync",
     "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
@@ -91,6 +92,8 @@ def lib():
         "fr_ctx_upload_table": (i32, [vp, i32, i64, i64, vp]), "fr_ctx_download_table": (i32, [vp, i32, i64, i64, vp]),
         "fr_ctx_set_weights": (i32, [vp, i32, vp, sz]), "fr_ctx_fill_weights": (i32, [vp, i32, u32]),
         "fr_ctx_get_weights": (i32, [vp, i32, vp, sz]), "fr_ctx_set_fc_precision": (i32, [vp, i32]),
+        "fr_ctx_get_fp8_exponents": (i32, [vp, vp, vp]), "fr_ctx_set_fp8_act_exponents": (i32, [vp, vp]),
+        "fr_worker_calibrate_fp8": (i32, [vp, i32]),
         "fr_worker_create": (i32, [vp, i32, ctypes.POINTER(vp)]), "fr_worker_destroy": (None, [vp]),
         "fr_worker_idx_ptr": (pi, [vp]), "fr_worker_dense_ptr": (pf, [vp]), "fr_worker_score_ptr": (pf, [vp]),
         "fr_worker_submit": (i32, [vp, i32]), "fr_worker_submit_device": (i32, [vp, i32, vp, vp, vp]), "fr_worker_push_device": (i32, [vp, i32, vp, vp, vp]),
@@ -365,6 +368,15 @@ class Context:
     def set_fc_precision(self, precision):
         _check(lib().fr_ctx_set_fc_precision(self._h, precision))
 
+    def fp8_exponents(self):
+        """-> (act_exp[4] for X, R1, R2, R3; w_exp[3] for W1..W3): tensor T is stored as e4m3(saturate(T * 2**e))."""
+        a, w = (ctypes.c_int * 4)(), (ctypes.c_int * 3)()
+        _check(lib().fr_ctx_get_fp8_exponents(self._h, a, w))
+        return list(a), list(w)
+
+    def set_fp8_act_exponents(self, act_exp):
+        _check(lib().fr_ctx_set_fp8_act_exponents(self._h, (ctypes.c_int * 4)(*[int(v) for v in act_exp])))
+
     def shard_info(self):
         v = [ctypes.c_int() for _ in range(5)]
         _check(lib().fr_ctx_shard_info(self._h, *[ctypes.byref(x) for x in v]))
@@ -414,6 +426,15 @@ class Worker:
     def sync(self):
         _check(lib().fr_worker_sync(self._h))
 
+    def calibrate_fp8(self, idx, dense=None):
+        """fp8 chain: run this batch through the fp32 chain and derive the activation exponents from the observed maxima."""
+        idx = np.asarray(idx, dtype=np.int32).reshape(len(idx), -1)
+        B = idx.shape[0]
+        self.idx[:B] = idx
+        if self.dense is not None:
+            self.dense[:B] = np.asarray(dense, dtype=np.float32).reshape(B, -1)
+        _check(lib().fr_worker_calibrate_fp8(self._h, B))
+
     def infer(self, idx, dense=None):
         """Host-buffer path: idx int32 [B][idx_cols] (+ dense float32 [B][dense_len]) -> scores float32 [B]."""
         idx = np.asarray(idx, dtype=np.int32).reshape(len(idx), -1)
@@ -452,13 +473,18 @@ class Worker:
     def records_dptr(self):
         return lib().fr_worker_records_dptr(self._h)
 
-    def features(self, batch, bf16=False):
+    def features(self, batch, bf16=False, fp8=False):
         """Feature-major activations of the last submit(), un-packed from the device's q4 layout Xq[k/4][m][k%4]
         -> uint32 [record_len][batch] (debug/parity hook for the pipeline's own gather stage)."""
         ld_max = ctypes.c_int()
         p = lib().fr_worker_features_dptr(self._h, ctypes.byref(ld_max))
         K = self.ctx.model.record_len
         ld = (batch + 31) // 32 * 32
+        if fp8:  # q16 layout Xf[k/16][m][k%16] of e4m3 bytes, K zero-padded to a multiple of 64 -> uint8 [KP][batch]
+            KP = (K + 63) // 64 * 64
+            out = np.empty(KP * ld, dtype=np.uint8)
+            _check(lib().fr_memcpy_d2h(self.ctx._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p), out.nbytes))
+            return out.reshape(KP // 16, ld, 16).transpose(0, 2, 1).reshape(KP, ld)[:, :batch]
         if bf16:  # q8 layout Xh[k/8][m][k%8] of bf16 -> uint16 [record_len][batch]
             out = np.empty(K * ld, dtype=np.uint16)
             _check(lib().fr_memcpy_d2h(self.ctx._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p), out.nbytes))

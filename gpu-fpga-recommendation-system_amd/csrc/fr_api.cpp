@@ -61,7 +61,9 @@ static void ctx_free(fr_ctx *c) {
         if (c->d_w[i]) (void)hipFree(c->d_w[i]);
         if (i < 3 && c->d_wq[i]) (void)hipFree(c->d_wq[i]);
         if (c->d_w_bf16[i]) (void)hipFree(c->d_w_bf16[i]);
+        if (i < 3 && c->d_w_fp8[i]) (void)hipFree(c->d_w_fp8[i]);
     }
+    if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->setup_stream) (void)hipStreamDestroy(c->setup_stream);
     delete c;
 }
@@ -305,12 +307,51 @@ extern "C" int fr_ctx_download_table(fr_ctx *ctx, int table, int64_t row0, int64
 }
 
 // ---- weights ----------------------------------------------------------------------------------------
-// derived copies of one layer's weights: the q4 re-pack for the fp32 chain, the bf16 cast for the MFMA-bf16 chain
+static int floor_log2f(float v) {  // floor(log2(v)) for v > 0
+    int e;
+    (void)std::frexp(v, &e);  // v = m * 2^e, m in [0.5, 1)
+    return e - 1;
+}
+
+// fp8 activation exponents from an rms estimate (until a calibration batch replaces them): inputs are taken as U(-1,1)
+// (rms 0.58, the FR_FILL_HASH tables), each layer multiplies the rms by ||W||_F / sqrt(N), and 8 rms must still fit 448.
+static void f8_estimate_act_exponents(fr_ctx *ctx) {
+    if (ctx->f8_calibrated) return;
+    float rms = 0.58f;
+    for (int l = 0; l < 4; l++) {
+        const float absmax_est = 8.0f * (rms > 0.0f ? rms : 1.0f);
+        ctx->f8_e_act[l] = floor_log2f(448.0f / absmax_est);
+        if (l < 3) rms *= ctx->f8_w_rms_gain[l];
+    }
+}
+
+static int refresh_fp8(fr_ctx *ctx, int layer) {
+    if (layer >= 3) return FR_OK;  // the output layer stays in fp32
+    const int K = ctx->model.fc[layer], H = ctx->model.fc[layer + 1];
+    const int KP = (K + 63) / 64 * 64;
+    if (!ctx->d_w_fp8[layer]) FR_HIP(hipMalloc(&ctx->d_w_fp8[layer], (size_t)KP * H));
+    if (!ctx->d_stats) FR_HIP(hipMalloc((void **)&ctx->d_stats, 64));
+    int rc = frk_stats(ctx->d_w[layer], (size_t)K * H, ctx->d_stats, ctx->setup_stream);
+    if (rc) return rc;
+    uint32_t st[2];
+    FR_HIP(hipMemcpyAsync(st, ctx->d_stats, 8, hipMemcpyDeviceToHost, ctx->setup_stream));
+    FR_HIP(hipStreamSynchronize(ctx->setup_stream));
+    float absmax, sumsq;
+    memcpy(&absmax, &st[0], 4);
+    memcpy(&sumsq, &st[1], 4);
+    ctx->f8_e_w[layer] = absmax > 0.0f ? floor_log2f(448.0f / absmax) : 0;  // max |W| * 2^e_w lands in (224, 448]
+    ctx->f8_w_rms_gain[layer] = std::sqrt(sumsq / (float)H);
+    f8_estimate_act_exponents(ctx);
+    return frk_pack_weights_q16_fp8(ctx->d_w[layer], ctx->d_w_fp8[layer], K, H, ctx->f8_e_w[layer], ctx->setup_stream);
+}
+
+// derived copies of one layer's weights: the q4 re-pack for the fp32 chain, the bf16 / fp8 casts for the low-precision chains
 static int refresh_bf16(fr_ctx *ctx, int layer) {
     if (layer < 3) {
         int rc = frk_pack_weights_q4(ctx->d_w[layer], ctx->d_wq[layer], ctx->model.fc[layer], ctx->model.fc[layer + 1], ctx->setup_stream);
         if (rc) return rc;
     }
+    if (ctx->fc_precision == FR_FC_FP8) return refresh_fp8(ctx, layer);
     if (ctx->fc_precision != FR_FC_BF16) return FR_OK;
     size_t n = (size_t)ctx->model.fc[layer] * ctx->model.fc[layer + 1];
     if (!ctx->d_w_bf16[layer]) FR_HIP(hipMalloc((void **)&ctx->d_w_bf16[layer], n * sizeof(uint16_t)));
@@ -361,14 +402,19 @@ extern "C" int fr_ctx_get_weights(fr_ctx *ctx, int layer, float *w, size_t count
 
 extern "C" int fr_ctx_set_fc_precision(fr_ctx *ctx, int precision) {
     if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
-    if (precision != FR_FC_FP32 && precision != FR_FC_BF16) FR_FAIL(FR_ERR_INVALID, "bad precision %d", precision);
+    if (precision != FR_FC_FP32 && precision != FR_FC_BF16 && precision != FR_FC_FP8) FR_FAIL(FR_ERR_INVALID, "bad precision %d", precision);
     FR_HIP(hipSetDevice(ctx->device));
-    ctx->fc_precision = precision;
     if (precision == FR_FC_BF16) {
         for (int l = 0; l < 4; l++)
             if (ctx->model.fc[l] % 16) FR_FAIL(FR_ERR_INVALID, "bf16 chain needs fc[%d]=%d to be a multiple of 16", l, ctx->model.fc[l]);
     }
-    if (precision == FR_FC_BF16 && ctx->weights_set) {
+    if (precision == FR_FC_FP8) {  // the record is zero-padded to 64 k inside the q16 image; hidden widths are not
+        for (int l = 1; l < 4; l++)
+            if (ctx->model.fc[l] % 64) FR_FAIL(FR_ERR_INVALID, "fp8 chain needs fc[%d]=%d to be a multiple of 64", l, ctx->model.fc[l]);
+        if (ctx->n_shards > 1) FR_FAIL(FR_ERR_INVALID, "fp8 chain: unsharded contexts only");
+    }
+    ctx->fc_precision = precision;
+    if (precision != FR_FC_FP32 && ctx->weights_set) {
         for (int l = 0; l < 4; l++) {
             int rc = refresh_bf16(ctx, l);
             if (rc) return rc;
@@ -510,6 +556,7 @@ static int pipeline_step(fr_worker *w) {
     const uint64_t L = w->launch_no;
     const int par = (int)(L & 1);
     const ActSet wr = act_set(w, par), rd = act_set(w, par ^ 1);
+    const int prec = w->calibrating ? (int)FR_FC_FP32 : c->fc_precision;  // a calibration batch runs the fp32 chain
     FrPipeArgs a{};
     a.words = c->d_words;
     a.n_words = c->n_words;
@@ -527,22 +574,38 @@ static int pipeline_step(fr_worker *w) {
         st.ldm = sl.ldm;
         const int ldm = sl.ldm;
         // K-split plan of the three FC layers of this batch
-        const bool bf16 = c->fc_precision == FR_FC_BF16;  // no K-split partials in the bf16 chain
-        const int ns1 = bf16 ? 1 : pick_nsplit(fc[0], fc[1], ldm), ns2 = bf16 ? 1 : pick_nsplit(fc[1], fc[2], ldm),
-                  ns3 = bf16 ? 1 : pick_nsplit(fc[2], fc[3], ldm);
+        const bool bf16 = prec == FR_FC_BF16, fp8 = prec == FR_FC_FP8;  // no K-split partials in the low-precision chains
+        const bool one = bf16 || fp8 || w->calibrating;                // (nor while calibrating: whole activations are measured)
+        const int ns1 = one ? 1 : pick_nsplit(fc[0], fc[1], ldm), ns2 = one ? 1 : pick_nsplit(fc[1], fc[2], ldm),
+                  ns3 = one ? 1 : pick_nsplit(fc[2], fc[3], ldm);
         const float *wl[4];
-        for (int l = 0; l < 4; l++)
-            wl[l] = bf16 ? reinterpret_cast<const float *>(c->d_w_bf16[l]) : (l < 3 ? c->d_wq[l] : c->d_w[3]);
+        for (int l = 0; l < 4; l++) {
+            if (bf16) wl[l] = reinterpret_cast<const float *>(c->d_w_bf16[l]);
+            else if (fp8 && l < 3) wl[l] = reinterpret_cast<const float *>(c->d_w_fp8[l]);
+            else wl[l] = (l < 3 && !fp8) ? c->d_wq[l] : c->d_w[3];
+        }
+        if (fp8) {  // power-of-two quantisation exponents of this stage's operands / result
+            st.e_w = (s >= 1 && s <= 3) ? c->f8_e_w[s - 1] : 0;
+            st.e_in = s >= 1 ? c->f8_e_act[s - 1] : 0;
+            st.e_out = s <= 3 ? c->f8_e_act[s] : 0;
+        }
         switch (s) {
             case 0: {
                 a.idx = sl.d_idx;
                 a.dense = sl.d_dense;
                 st.out = wr.x;
+                st.K = fc[0];
                 w->last_x_parity = par;
                 const int trb = frk_gather_tr_blocks(c->n_words, ldm);
                 if (trb > 0) {  // large batch: LDS-transposing gather
                     st.variant = 1;
                     blocks += (trb + 7) / 8 * 8;
+                    n_stages++;
+                    only = s;
+                    continue;
+                }
+                if (fp8) {  // the q16 gather has its own grid shape
+                    blocks += frk_stage_blocks_f8_gather(fc[0], ldm);
                     n_stages++;
                     only = s;
                     continue;
@@ -589,9 +652,9 @@ static int pipeline_step(fr_worker *w) {
         const int begin = a.st[only].block_begin;
         for (int s = 0; s < FR_N_STAGES; s++) a.st[s].block_begin -= (s >= only) ? begin : 0;
         a.st[only].block_begin = 0;
-        return frk_pipeline_launch(a, only, c->fc_precision, w->stream);
+        return frk_pipeline_launch(a, only, prec, w->stream);
     }
-    return frk_pipeline_launch(a, -1, c->fc_precision, w->stream);
+    return frk_pipeline_launch(a, -1, prec, w->stream);
 }
 
 static int pipeline_push(fr_worker *w, int batch, int first_stage, const int32_t *d_idx, const float *d_dense, float *d_scores) {
@@ -632,6 +695,7 @@ static bool fused_eligible(const fr_ctx *c) {
     static const int enabled = getenv("FR_FUSED") ? atoi(getenv("FR_FUSED")) : 1;  // experiment knob
     const int32_t *fc = c->model.fc;
     if (!enabled || c->n_shards != 1 || c->model.layout != FR_LAYOUT_SEMANTIC) return false;
+    if (c->fc_precision == FR_FC_FP8) return false;  // stage pipeline only
     return c->fc_precision == FR_FC_BF16 ? frk_fused_h_ok(fc[0], fc[1], fc[2], fc[3]) : frk_fused_ok(fc[0], fc[1], fc[2], fc[3]);
 }
 
@@ -699,9 +763,10 @@ static int launch_fc(fr_worker *w, int batch, const float *d_records, float *d_s
     if (w->launch_no == 0) w->launch_no = 1;  // stage 1 of the next launch reads the set the (virtual) previous launch wrote
     const int ldm = round_up(batch, 32);
     const int par_prev = (int)((w->launch_no - 1) & 1);
-    int rc = (c->fc_precision == FR_FC_BF16)
-                 ? frk_records_to_q8_bf16(d_records, act_set(w, par_prev).x, batch, c->model.fc[0], ldm, w->stream)
-                 : frk_transpose_records(d_records, act_set(w, par_prev).x, batch, c->model.fc[0], ldm, w->stream);
+    int rc;
+    if (c->fc_precision == FR_FC_FP8) rc = frk_records_to_q16_fp8(d_records, act_set(w, par_prev).x, batch, c->model.fc[0], ldm, c->f8_e_act[0], w->stream);
+    else if (c->fc_precision == FR_FC_BF16) rc = frk_records_to_q8_bf16(d_records, act_set(w, par_prev).x, batch, c->model.fc[0], ldm, w->stream);
+    else rc = frk_transpose_records(d_records, act_set(w, par_prev).x, batch, c->model.fc[0], ldm, w->stream);
     if (rc) return rc;
     rc = pipeline_push(w, batch, 1, nullptr, nullptr, d_scores);
     if (rc) return rc;
@@ -863,6 +928,65 @@ extern "C" int fr_worker_submit(fr_worker *w, int batch) {
     // output D2H (cuda_server.c:494-495)
     FR_HIP(hipMemcpyAsync(w->h_score, w->d_score, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, w->stream));
     w->in_flight = true;
+    return FR_OK;
+}
+
+extern "C" int fr_ctx_get_fp8_exponents(const fr_ctx *ctx, int act_exp[4], int w_exp[3]) {
+    if (!ctx || !act_exp || !w_exp) FR_FAIL(FR_ERR_INVALID, "NULL argument");
+    for (int l = 0; l < 4; l++) act_exp[l] = ctx->f8_e_act[l];
+    for (int l = 0; l < 3; l++) w_exp[l] = ctx->f8_e_w[l];
+    return FR_OK;
+}
+
+extern "C" int fr_ctx_set_fp8_act_exponents(fr_ctx *ctx, const int act_exp[4]) {
+    if (!ctx || !act_exp) FR_FAIL(FR_ERR_INVALID, "NULL argument");
+    for (int l = 0; l < 4; l++)
+        if (act_exp[l] < -100 || act_exp[l] > 100) FR_FAIL(FR_ERR_INVALID, "act_exp[%d]=%d outside [-100, 100]", l, act_exp[l]);
+    for (int l = 0; l < 4; l++) ctx->f8_e_act[l] = act_exp[l];
+    ctx->f8_calibrated = true;
+    return FR_OK;
+}
+
+extern "C" int fr_worker_calibrate_fp8(fr_worker *w, int batch) {
+    int rc = check_ready(w, batch, true, true);
+    if (rc) return rc;
+    fr_ctx *c = w->ctx;
+    if (c->n_shards > 1 || c->model.layout != FR_LAYOUT_SEMANTIC) FR_FAIL(FR_ERR_STATE, "fp8 calibration: unsharded SEMANTIC contexts only");
+    if (w->in_flight || w->n_active || w->n_pending) FR_FAIL(FR_ERR_STATE, "worker busy: call fr_worker_sync first");
+    FR_HIP(hipSetDevice(c->device));
+    if (!c->d_stats) FR_HIP(hipMalloc((void **)&c->d_stats, 64));
+    FR_HIP(hipMemcpyAsync(w->d_idx, w->h_idx, (size_t)batch * idx_cols(c) * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
+    if (c->model.dense_len)
+        FR_HIP(hipMemcpyAsync(w->d_dense, w->h_dense, (size_t)batch * c->model.dense_len * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    rc = check_gather_args(w, w->d_idx, w->d_dense);
+    if (rc) return rc;
+    const uint64_t L0 = w->launch_no;
+    w->calibrating = true;  // fp32 stages, no K-split partials: every activation buffer holds whole sums
+    rc = pipeline_push(w, batch, 0, w->d_idx, w->d_dense, w->d_score);
+    if (!rc) rc = pipeline_flush(w);
+    w->calibrating = false;
+    if (rc) return rc;
+    const int32_t *fc = c->model.fc;
+    const size_t ldm = (size_t)round_up(batch, 32);
+    const float *reg[4] = {act_set(w, (int)(L0 & 1)).x, act_set(w, (int)((L0 + 1) & 1)).r1, act_set(w, (int)((L0 + 2) & 1)).r2,
+                           act_set(w, (int)((L0 + 3) & 1)).r3};
+    for (int l = 0; l < 4; l++) {
+        rc = frk_stats(reg[l], (size_t)fc[l] * ldm, c->d_stats + 2 * l, w->stream);
+        if (rc) return rc;
+    }
+    uint32_t st[8];
+    FR_HIP(hipMemcpyAsync(st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost, w->stream));
+    FR_HIP(hipStreamSynchronize(w->stream));
+    if (__atomic_load_n(w->h_err, __ATOMIC_ACQUIRE)) {
+        __atomic_store_n(w->h_err, 0, __ATOMIC_RELEASE);
+        FR_FAIL(FR_ERR_INDEX_RANGE, "a lookup index of the calibration batch was outside its table");
+    }
+    for (int l = 0; l < 4; l++) {
+        float absmax;
+        memcpy(&absmax, &st[2 * l], 4);
+        if (absmax > 0.0f && std::isfinite(absmax)) c->f8_e_act[l] = floor_log2f(448.0f / (2.0f * absmax));  // one binade of headroom
+    }
+    c->f8_calibrated = true;
     return FR_OK;
 }
 

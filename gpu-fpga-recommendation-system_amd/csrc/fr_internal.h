@@ -57,6 +57,7 @@ struct FrStageArgs {
     int variant;      // gather stage: 1 = LDS-transposing form for large batches (see gather_tr_body)
     int part_stride;  // floats between the partial OUTPUT buffers
     int in_part_stride;  // floats between the partial INPUT buffers
+    int e_w, e_in, e_out;  // fp8 chain: power-of-two quantisation exponents of the weights, the input and the output activations
     const float *in;  // activations in (feature-major)
     float *out;       // activations out / scores
     const float *w;   // weights Wt[K][N] (FC) or w[H] (out)
@@ -124,6 +125,13 @@ struct fr_ctx {
     float *d_w[4] = {nullptr, nullptr, nullptr, nullptr};
     float *d_wq[3] = {nullptr, nullptr, nullptr};  // FC1..FC3 re-packed as Wq[k/4][h][k%4] for the 16-byte operand loads
     uint16_t *d_w_bf16[4] = {nullptr, nullptr, nullptr, nullptr};
+    // fp8 chain: e4m3 q16 copies of FC1..FC3 and the power-of-two exponents (weights per layer; activations X, R1, R2, R3)
+    void *d_w_fp8[3] = {nullptr, nullptr, nullptr};
+    int f8_e_w[3] = {0, 0, 0};
+    int f8_e_act[4] = {0, 0, 0, 0};
+    float f8_w_rms_gain[3] = {1.0f, 1.0f, 1.0f};  // ||W_l||_F / sqrt(N_l): rms growth of layer l under uncorrelated inputs
+    bool f8_calibrated = false;
+    uint32_t *d_stats = nullptr;  // 16 words of reduction scratch (max |x| bits, sum x^2 per tensor)
     bool weights_set = false;
     int fc_precision = FR_FC_FP32;
     // sharding
@@ -161,6 +169,7 @@ struct fr_worker {
     } ring[8];
     uint64_t launch_no = 0;     // number of pipeline launches issued so far
     int n_active = 0;
+    bool calibrating = false;   // fr_worker_calibrate_fp8: the pushed batch runs the fp32 stages without K-split partials
     int last_x_parity = 0;      // which activation set holds Xt of the most recently pushed batch (debug hook)
     // fused item-tile path: batches queued by fr_worker_push_device until a launch group is full
     FrFusedBatch pending[FR_FUSED_MAX_BATCHES];
@@ -191,6 +200,10 @@ int frk_pack_weights_q8_bf16(const float *W, uint16_t *Wh, int K, int H, hipStre
 bool frk_fc_h_tiled_ok(int K, int N, int ldm);
 int frk_fc_h_tiled(const void *Wh, const void *Xh, void *Yh, int K, int N, int ldm, hipStream_t s);
 int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, hipStream_t s);
+int frk_pack_weights_q16_fp8(const float *W, void *Wf, int K, int H, int e_w, hipStream_t s);
+int frk_records_to_q16_fp8(const float *X, void *Xf, int batch, int K, int ldm, int e_x, hipStream_t s);
+int frk_stats(const float *p, size_t n, void *d_out, hipStream_t s);
+int frk_stage_blocks_f8_gather(int K, int ldm);
 int frk_pack_weights_q4(const float *W, float *Wq, int K, int H, hipStream_t s);
 int frk_stage_blocks(int stage, int n_words, int K, int N, int ldm, int nsplit);
 int frk_gather_tr_blocks(int n_words, int ldm);

@@ -334,6 +334,7 @@ __device__ __forceinline__ void gather_q_body(const FrPipeArgs &a, const FrStage
 constexpr int FR_GT_ITEMS = 32, FR_GT_WORDS = 64, FR_GT_LD = 65;
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi);
+__device__ __forceinline__ uint32_t pack_fp8_word(const uint4 &v, float scale);
 
 template <int PREC>
 __device__ __forceinline__ void gather_tr_body(const FrPipeArgs &a, const FrStageArgs &st, int local, uint4 *tile /* [32][65] */) {
@@ -384,6 +385,20 @@ __device__ __forceinline__ void gather_tr_body(const FrPipeArgs &a, const FrStag
             for (int j = 0; j < FR_GT_WORDS / 16; j++) {
                 const int wl = ws + 16 * j, w = w0 + wl;
                 if (w < a.n_words) Xq[(size_t)w * st.ldm + m] = tile[il * FR_GT_LD + wl];  // SEMANTIC layout: dst word == w
+            }
+        } else if constexpr (PREC == 2) {
+            uint4 *Xf = reinterpret_cast<uint4 *>(st.out);  // q16 element = record words 4e .. 4e+3 as e4m3 bytes (x 2^e_out, saturated)
+            const float scale = __builtin_ldexpf(1.0f, st.e_out);
+            const int KE = (st.K + 63) / 64 * 4;       // q16 rows including the zero pad up to a multiple of 64 k
+            const int el = ws, e = (w0 >> 2) + el;     // 16 element slots x 32 items = one element per thread
+            if (e < KE) {
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int wl = 4 * el + j;
+                    o[j] = (w0 + wl < a.n_words) ? pack_fp8_word(tile[il * FR_GT_LD + wl], scale) : 0u;
+                }
+                Xf[(size_t)e * st.ldm + m] = make_uint4(o[0], o[1], o[2], o[3]);
             }
         } else {
             uint4 *Xh = reinterpret_cast<uint4 *>(st.out);  // q8 element = record words 2p, 2p+1
@@ -790,9 +805,204 @@ __device__ __forceinline__ void fc_out_h_body(const FrStageArgs &st, int local, 
     }
 }
 
+// ===================================================================================================
+// fp8 variant of the chain (BASELINE configs[4]: "fp8 MFMA FC on CDNA4").
+// "q16" layout: 16 consecutive k per 16 bytes, Xf[k/16][m][k%16] / Wf[k/16][n][k%16] of OCP e4m3 bytes, K zero-padded to a
+// multiple of 64.  One v_mfma_scale_f32_32x32x64_f8f6f4 takes 32 bytes per lane per operand = two q16 elements (lane half h
+// carries k = 64g + 32h + j, j = 0..31 -- any assignment works as long as both operands use the same one).
+// Quantisation is per tensor with power-of-two scales: weights are stored as e4m3(W * 2^e_w), activations as
+// e4m3(sat(X * 2^e_x)); the MFMA's E8M0 block scales (127 - e_w, 127 - e_x) undo both inside the instruction, so the fp32
+// accumulator is in real units.  v_cvt_pk_fp8_f32 rounds to nearest even but yields NaN above 448 (probed on gfx950:
+// tools/experiments/fp8_probe.hip), hence the explicit clamp.  The activation exponents come from a calibration batch
+// (fr_worker_calibrate_fp8) or from an rms estimate made when the weights are packed.  The output layer (N = 1) multiplies
+// the decoded fp8 R3 by the fp32 master weights.  No K-split partials, no fused / tiled variants yet: stage pipeline only.
+// ===================================================================================================
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d, float scale) {
+    const float lim = 448.0f;  // largest finite e4m3fn
+    a = fminf(fmaxf(a * scale, -lim), lim);
+    b = fminf(fmaxf(b * scale, -lim), lim);
+    c = fminf(fmaxf(c * scale, -lim), lim);
+    d = fminf(fmaxf(d * scale, -lim), lim);
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (uint32_t)v;
+}
+__device__ __forceinline__ uint32_t pack_fp8_word(const uint4 &v, float scale) {
+    return pack_fp8x4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w), scale);
+}
+
+// stage 0, small batches: lanes = 64 consecutive items, each wave builds ONE q16 element (4 record words) per item
+__device__ __forceinline__ void gather_f_body(const FrPipeArgs &a, const FrStageArgs &st, int local) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m_blocks = (st.ldm + 63) / 64;
+    const int mb = local % m_blocks, eb = local / m_blocks;
+    const int m = mb * 64 + lane;
+    const int KE = (st.K + 63) / 64 * 4;  // q16 rows including the zero pad
+    const int e = eb * FR_PIPE_WAVES + wave;
+    if (e >= KE) return;
+    const bool live = m < st.batch;
+    const float scale = __builtin_ldexpf(1.0f, st.e_out);
+    uint32_t out[4];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int w = 4 * e + j;
+        out[j] = 0u;
+        if (w < a.n_words && live) {
+            const FrWordDesc d = a.words[w];  // wave-uniform; SEMANTIC layout: dst_off == w
+            const bool is_dense = (d.idx_col & FR_DESC_DENSE) != 0;
+            uint32_t id = is_dense ? (uint32_t)m : (uint32_t)a.idx[(size_t)m * a.idx_stride + d.idx_col];
+            if (!is_dense && id >= d.rows) {
+                bad = true;
+                id = 0;
+            }
+            const char *base = is_dense ? reinterpret_cast<const char *>(a.dense) + d.src : reinterpret_cast<const char *>(d.src);
+            out[j] = pack_fp8_word(*reinterpret_cast<const uint4 *>(base + (uint64_t)id * d.stride), scale);
+        }
+    }
+    if (m < st.ldm) reinterpret_cast<uint4 *>(st.out)[(size_t)e * st.ldm + m] = make_uint4(out[0], out[1], out[2], out[3]);
+    if (bad) atomicOr_system(a.err_flag, 1);
+}
+static int gather_f_blocks(int K, int ldm) { return ((ldm + 63) / 64) * (((K + 63) / 64 * 4 + FR_PIPE_WAVES - 1) / FR_PIPE_WAVES); }
+
+__device__ __forceinline__ void fc_f_body(const FrStageArgs &st, int local, float *red) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = st.N, ldm = st.ldm;
+    const int tiles_n = N / 32, tiles_m = ldm / 32, tiles = tiles_n * tiles_m;
+    int n_tile, m_tile;
+    const int MG = (tiles_m % 2 == 0) ? 2 : 1, NG = 8 / MG;
+    if (tiles_n % NG == 0) {  // same XCD-aware map as the fp32 body
+        const int x = local & 7, j = local >> 3;
+        const int mg = x % MG, ng = x / MG;
+        const int tn_x = tiles_n / NG;
+        if (j >= tn_x * (tiles_m / MG)) return;
+        n_tile = (j % tn_x) * NG + ng;
+        m_tile = (j / tn_x) * MG + mg;
+    } else {
+        if (local >= tiles) return;
+        n_tile = local % tiles_n;
+        m_tile = local / tiles_n;
+    }
+    const int n0 = n_tile * 32, m0 = m_tile * 32;
+    const int hk = lane >> 5, lm = lane & 31;
+    const int groups = (st.K + 63) / 64;  // one MFMA (64 k) per group
+    const int per = (groups + FR_PIPE_WAVES - 1) / FR_PIPE_WAVES;
+    const int g_begin = wave * per;
+    int ng_ = groups - g_begin;
+    ng_ = ng_ < 0 ? 0 : (ng_ > per ? per : ng_);
+    const unsigned KE = (unsigned)groups * 4u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(st.w), 0, KE * (unsigned)N * 16u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(st.in), 0, KE * (unsigned)ldm * 16u, 0x00020000);
+    // lane half h owns q16 rows 4g + 2h and 4g + 2h + 1
+    const unsigned voA = ((unsigned)(2 * hk) * N + n0 + lm) * 16u, voB = ((unsigned)(2 * hk) * ldm + m0 + lm) * 16u;
+    const unsigned voA2 = voA + (unsigned)N * 16u, voB2 = voB + (unsigned)ldm * 16u;
+    const unsigned stepA = 4u * (unsigned)N * 16u, stepB = 4u * (unsigned)ldm * 16u;
+    const int sc_a = 127 - st.e_w, sc_b = 127 - st.e_in;  // E8M0: 2^(code - 127)
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+    auto ld8 = [&](__amdgpu_buffer_rsrc_t rs, unsigned v0, unsigned v1, unsigned so) {
+        const uint4 lo = bload4u(rs, v0, so), hi = bload4u(rs, v1, so);
+        i32x8 r;
+        r[0] = (int)lo.x; r[1] = (int)lo.y; r[2] = (int)lo.z; r[3] = (int)lo.w;
+        r[4] = (int)hi.x; r[5] = (int)hi.y; r[6] = (int)hi.z; r[7] = (int)hi.w;
+        return r;
+    };
+    constexpr int D = 2;
+    i32x8 ra[D], rb[D], na[D], nb[D];
+    const int nb_full = ng_ / D;
+    if (nb_full > 0) {
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            ra[i] = ld8(rsA, voA, voA2, (unsigned)(g_begin + i) * stepA);
+            rb[i] = ld8(rsB, voB, voB2, (unsigned)(g_begin + i) * stepB);
+        }
+    }
+    for (int blk = 0; blk < nb_full; blk++) {
+        const int nx = (blk + 1 < nb_full) ? (blk + 1) : blk;
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            na[i] = ld8(rsA, voA, voA2, (unsigned)(g_begin + nx * D + i) * stepA);
+            nb[i] = ld8(rsB, voB, voB2, (unsigned)(g_begin + nx * D + i) * stepB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < D; i++) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ra[i], rb[i], acc, 0, 0, 0, sc_a, 0, sc_b);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            ra[i] = na[i];
+            rb[i] = nb[i];
+        }
+    }
+    for (int g = g_begin + nb_full * D; g < g_begin + ng_; g++) {
+        const i32x8 a8 = ld8(rsA, voA, voA2, (unsigned)g * stepA), b8 = ld8(rsB, voB, voB2, (unsigned)g * stepB);
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc, 0, 0, 0, sc_a, 0, sc_b);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    // fixed-order fp32 sum, ONE quantisation to e4m3 (x 2^e_out, saturated); 4 consecutive n = 4 bytes of a q16 element
+    uint32_t *Yf = reinterpret_cast<uint32_t *>(st.out);
+    const float oscale = __builtin_ldexpf(1.0f, st.e_out);
+    if (threadIdx.x < 4 * 64) {
+        const int i = threadIdx.x >> 6, l = threadIdx.x & 63;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float s = red[(4 * i + c) * 64 + l];
+#pragma unroll
+            for (int w = 1; w < FR_PIPE_WAVES; w++) s += red[(w * 16 + 4 * i + c) * 64 + l];
+            v[c] = s;
+        }
+        const int n = n0 + 8 * i + 4 * (l >> 5);  // + c
+        Yf[((size_t)(n >> 4) * ldm + m0 + (l & 31)) * 4 + ((n & 15) >> 2)] = pack_fp8x4(v[0], v[1], v[2], v[3], oscale);
+    }
+}
+
+// stage 4: score[m] = 2^-e_in * sum_k w[k] * e4m3(R3)[k][m]; fp32 master weights, 64 items x 8 slices of q16 rows
+__device__ __forceinline__ void fc_out_f_body(const FrStageArgs &st, int local, float *red) {
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = local * 64 + lane;
+    const int KE = st.K / 16, ldm = st.ldm;  // hidden widths are multiples of 32: no pad rows here
+    const int per = (KE + FR_PIPE_WAVES - 1) / FR_PIPE_WAVES;
+    const int h0 = q * per;
+    const int h1 = (h0 + per) < KE ? (h0 + per) : KE;
+    const uint4 *Rf = reinterpret_cast<const uint4 *>(st.in);
+    float s = 0.0f;
+    if (m < ldm) {
+        for (int h = h0; h < h1; h++) {
+            const uint4 r = Rf[(size_t)h * ldm + m];
+            const int rr[4] = {(int)r.x, (int)r.y, (int)r.z, (int)r.w};
+            const float *w = st.w + 16 * h;  // wave-uniform
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                s = fmaf(w[4 * c + 0], __builtin_amdgcn_cvt_f32_fp8(rr[c], 0), s);
+                s = fmaf(w[4 * c + 1], __builtin_amdgcn_cvt_f32_fp8(rr[c], 1), s);
+                s = fmaf(w[4 * c + 2], __builtin_amdgcn_cvt_f32_fp8(rr[c], 2), s);
+                s = fmaf(w[4 * c + 3], __builtin_amdgcn_cvt_f32_fp8(rr[c], 3), s);
+            }
+        }
+    }
+    red[q * 64 + lane] = s;
+    __syncthreads();
+    if (q == 0 && m < st.batch) {
+        float t = red[lane];
+#pragma unroll
+        for (int i = 1; i < FR_PIPE_WAVES; i++) t += red[i * 64 + lane];
+        st.out[m] = t * __builtin_ldexpf(1.0f, -st.e_in);
+    }
+}
+
 // STAGE = -1: all stages of one pipelined launch; STAGE = 0..4: that stage alone (separately named kernels so
 // that rocprof attributes time per stage when a batch is run unpipelined).
-// PREC: 0 = fp32 chain (q4 operands, exact-f32 MFMA), 1 = bf16 chain (q8 operands, bf16 MFMA, fp32 accumulate).
+// PREC: 0 = fp32 chain (q4 operands, exact-f32 MFMA), 1 = bf16 chain (q8 operands, bf16 MFMA, fp32 accumulate),
+// 2 = fp8 chain (q16 e4m3 operands, scaled f8f6f4 MFMA, fp32 accumulate).
 template <int STAGE, int PREC>
 __global__ void __launch_bounds__(FR_PIPE_THREADS) fr_pipeline_kernel(const FrPipeArgs a) {
     __shared__ uint4 smem[FR_GT_ITEMS * FR_GT_LD];  // 33,280 B: the gather tile; the FC stages use the first 32 KiB as float red[8][16][64]
@@ -815,6 +1025,10 @@ __global__ void __launch_bounds__(FR_PIPE_THREADS) fr_pipeline_kernel(const FrPi
         if (s == 0) gather_h_body(a, st, local);
         else if (s == 4) fc_out_h_body(st, local, red);
         else fc_h_body(st, local, red);
+    } else if constexpr (PREC == 2) {
+        if (s == 0) gather_f_body(a, st, local);
+        else if (s == 4) fc_out_f_body(st, local, red);
+        else fc_f_body(st, local, red);
     } else {
         if (s == 0) {
             gather_q_body(a, st, local);
@@ -859,8 +1073,11 @@ static int pipeline_launch_prec(const FrPipeArgs &a, int single_stage, hipStream
 
 int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, int precision, hipStream_t s) {
     if (a.n_blocks <= 0) return FR_OK;
+    if (precision == FR_FC_FP8) return pipeline_launch_prec<2>(a, single_stage, s);
     return precision == FR_FC_BF16 ? pipeline_launch_prec<1>(a, single_stage, s) : pipeline_launch_prec<0>(a, single_stage, s);
 }
+
+int frk_stage_blocks_f8_gather(int K, int ldm) { return pad8(gather_f_blocks(K, ldm)); }
 
 int frk_stage_blocks(int stage, int n_words, int K, int N, int ldm, int nsplit) {
     // every stage is padded to a multiple of 8 workgroups so that the next one starts on XCD group 0
@@ -963,6 +1180,100 @@ int frk_pack_weights_q8_bf16(const float *W, uint16_t *Wh, int K, int H, hipStre
     size_t n = (size_t)(K / 8) * H;
     unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     pack_weights_q8_bf16_kernel<<<dim3(blocks ? blocks : 1), dim3(256), 0, s>>>(W, reinterpret_cast<uint4 *>(Wh), K, H);
+    KCHECK();
+    return FR_OK;
+}
+
+// fp32 master weights (column-major H x K) -> Wf[k/16][h][k%16] e4m3(W * scale), K zero-padded to KP (multiple of 64)
+__global__ void __launch_bounds__(256) pack_weights_q16_fp8_kernel(const float *__restrict__ W, uint4 *__restrict__ Wf, int K, int KP, int H, float scale) {
+    const size_t n = (size_t)(KP / 16) * H;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t ke = e / H, h = e - ke * H;
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const size_t k = 16 * ke + 4 * j + c;
+                v[c] = (k < (size_t)K) ? W[h + k * H] : 0.0f;
+            }
+            o[j] = pack_fp8x4(v[0], v[1], v[2], v[3], scale);
+        }
+        Wf[e] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+int frk_pack_weights_q16_fp8(const float *W, void *Wf, int K, int H, int e_w, hipStream_t s) {
+    const int KP = (K + 63) / 64 * 64;
+    size_t n = (size_t)(KP / 16) * H;
+    unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    pack_weights_q16_fp8_kernel<<<dim3(blocks ? blocks : 1), dim3(256), 0, s>>>(W, reinterpret_cast<uint4 *>(Wf), K, KP, H, ldexpf(1.0f, e_w));
+    KCHECK();
+    return FR_OK;
+}
+
+// item-major fp32 records [B][K] -> Xf[KP/16][ldm][16] e4m3(x * scale) (fc_only diagnostic / BLOCKED layout in fp8 mode)
+__global__ void __launch_bounds__(256) records_to_q16_fp8_kernel(const float *__restrict__ X, uint4 *__restrict__ Xf, int batch, int K, int KE, int ldm, float scale) {
+    const size_t n = (size_t)KE * ldm;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int ke = (int)(e / ldm), m = (int)(e - (size_t)ke * ldm);
+        uint32_t o[4] = {0u, 0u, 0u, 0u};
+        if (m < batch) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = 16 * ke + 4 * j;
+                if (k < K) {  // K % 4 == 0
+                    const float4 v = *reinterpret_cast<const float4 *>(X + (size_t)m * K + k);
+                    o[j] = pack_fp8x4(v.x, v.y, v.z, v.w, scale);
+                }
+            }
+        }
+        Xf[e] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+int frk_records_to_q16_fp8(const float *X, void *Xf, int batch, int K, int ldm, int e_x, hipStream_t s) {
+    const int KE = (K + 63) / 64 * 4;
+    size_t n = (size_t)KE * ldm;
+    unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    records_to_q16_fp8_kernel<<<dim3(blocks ? blocks : 1), dim3(256), 0, s>>>(X, reinterpret_cast<uint4 *>(Xf), batch, K, KE, ldm, ldexpf(1.0f, e_x));
+    KCHECK();
+    return FR_OK;
+}
+
+// max |x| and sum x^2 of a float array (fp8 scale selection): out[0] = bits of max |x| (atomicMax on the uint pattern), out[1] = sum
+__global__ void __launch_bounds__(256) stats_kernel(const float *__restrict__ p, size_t n, unsigned *out_max, float *out_sumsq) {
+    float mx = 0.0f, ss = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = p[i];
+        if (v == v) {  // NaN never drives a scale
+            mx = fmaxf(mx, fabsf(v));
+            ss = fmaf(v, v, ss);
+        }
+    }
+    __shared__ float smx[256], sss[256];
+    smx[threadIdx.x] = mx;
+    sss[threadIdx.x] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            smx[threadIdx.x] = fmaxf(smx[threadIdx.x], smx[threadIdx.x + o]);
+            sss[threadIdx.x] += sss[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicMax(out_max, __float_as_uint(smx[0]));
+        atomicAdd(out_sumsq, sss[0]);
+    }
+}
+
+// d_out: 2 words (zeroed here); returns after the launch is enqueued
+int frk_stats(const float *p, size_t n, void *d_out, hipStream_t s) {
+    if (hipMemsetAsync(d_out, 0, 8, s) != hipSuccess) FR_FAIL(FR_ERR_HIP, "hipMemsetAsync failed");
+    unsigned blocks = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    stats_kernel<<<dim3(blocks ? blocks : 1), dim3(256), 0, s>>>(p, n, reinterpret_cast<unsigned *>(d_out), reinterpret_cast<float *>(d_out) + 1);
     KCHECK();
     return FR_OK;
 }

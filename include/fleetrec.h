@@ -137,7 +137,9 @@ typedef enum fr_weight_mode {
 
 typedef enum fr_fc_precision {
     FR_FC_FP32 = 0, /* fp32 in, fp32 accumulate: CUBLAS_COMPUTE_32F + CUDA_R_32F (cuda_server.c:211) */
-    FR_FC_BF16 = 1  /* bf16 operands on MFMA, fp32 accumulate (BASELINE configs 3/4) */
+    FR_FC_BF16 = 1, /* bf16 operands on MFMA, fp32 accumulate (BASELINE configs 3/4) */
+    FR_FC_FP8 = 2   /* OCP e4m3 operands on the CDNA4 scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4), per-tensor
+                       power-of-two scales, fp32 accumulate; output layer in fp32 (BASELINE configs[4]) */
 } fr_fc_precision;
 
 typedef struct fr_ctx fr_ctx;       /* device + model + tables + weights; shared by all workers,
@@ -187,6 +189,11 @@ int fr_ctx_set_weights(fr_ctx *ctx, int layer, const float *w_colmajor, size_t c
 int fr_ctx_fill_weights(fr_ctx *ctx, int mode /* fr_weight_mode */, uint32_t seed);
 int fr_ctx_get_weights(fr_ctx *ctx, int layer, float *w_colmajor, size_t count);
 int fr_ctx_set_fc_precision(fr_ctx *ctx, int precision /* fr_fc_precision */);
+/* fp8 chain: quantisation exponents.  Tensor T is stored as e4m3(saturate(T * 2^e)): w_exp[l] for W1..W3 (chosen from max|W|
+ * when the weights are packed), act_exp[l] for X, R1, R2, R3 (an rms estimate until fr_worker_calibrate_fp8 or
+ * fr_ctx_set_fp8_act_exponents replaces it).  No counterpart in the reference (its chain is fp32 only, cuda_server.c:211). */
+int fr_ctx_get_fp8_exponents(const fr_ctx *ctx, int act_exp[4], int w_exp[3]);
+int fr_ctx_set_fp8_act_exponents(fr_ctx *ctx, const int act_exp[4]);
 
 /* ---- worker: replaces thread_consume()'s set-up (cuda_server.c:110-354) --------------------- */
 int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out);
@@ -224,6 +231,10 @@ int fr_ctx_stream_group(const fr_ctx *ctx);
 int fr_ctx_set_stream_group(fr_ctx *ctx, int batches_per_launch);
 /* Drains and waits for everything enqueued on the worker; returns FR_ERR_INDEX_RANGE if any index was out of range. */
 int fr_worker_sync(fr_worker *w);
+/* fp8 chain: run `batch` items (the worker's pinned idx/dense buffers, as for fr_worker_submit) through the fp32 chain, take
+ * max|.| of X, R1, R2, R3 and set the context's activation exponents so that twice that maximum still fits e4m3's 448.
+ * Synchronous. */
+int fr_worker_calibrate_fp8(fr_worker *w, int batch);
 
 /* Diagnostic / roofline entry points (same kernels as submit, run alone).
  * gather_only: d_records receives batch*record_len floats in the model's layout (device pointer).

@@ -560,6 +560,104 @@ def test_bf16_chain(fr, O, ctxs, which, B):
     wk.close()
 
 
+def e4m3_decode_table():
+    t = np.zeros(256, dtype=np.float64)
+    for b in range(256):
+        sgn, e, m = b >> 7, (b >> 3) & 15, b & 7
+        v = np.nan if (e == 15 and m == 7) else (m * 2.0 ** -9 if e == 0 else (1 + m / 8.0) * 2.0 ** (e - 7))
+        t[b] = -v if sgn else v
+    return t
+
+
+def e4m3_encode(x):
+    """float32 -> OCP e4m3fn byte: clamp to +-448, then round to nearest even (what the device does: fmin/fmax + v_cvt_pk_fp8_f32;
+    conversions probed against this restatement on gfx950 by tools/experiments/fp8_probe.hip)."""
+    x = np.clip(np.asarray(x, dtype=np.float32), -448.0, 448.0)
+    sgn = np.signbit(x)
+    a = np.abs(x).astype(np.float64)
+    _, ex = np.frexp(a)                       # a = m * 2^ex, m in [0.5, 1)
+    e = np.maximum(ex - 1, -6)                # subnormal quantum below 2^-6
+    q = np.ldexp(1.0, e - 3)
+    v = np.rint(a / q) * q                    # np.rint = round half to even
+    _, ex2 = np.frexp(v)
+    e2 = ex2 - 1
+    sub = v < 2.0 ** -6
+    mant = np.where(sub, np.rint(v * 2.0 ** 9), np.rint((v / np.ldexp(1.0, e2) - 1.0) * 8.0)).astype(np.int64)
+    expo = np.where(sub, 0, e2 + 7).astype(np.int64)
+    code = np.where(v == 0, 0, (expo << 3) | mant)
+    return (code | (sgn.astype(np.int64) << 7)).astype(np.uint8)
+
+
+def chain_fp8_reference(rec_f32, ws, dims, act_exp, w_exp):
+    """The fp8 chain restated on the host: e4m3(T * 2^e) operands, exact products, wide accumulation, ONE quantisation per hidden
+    activation, fp32 master weights in the output layer."""
+    dec = e4m3_decode_table()
+    x = dec[e4m3_encode(rec_f32 * np.float32(2.0 ** act_exp[0]))]
+    for l in range(3):
+        W = ws[l].reshape(dims[l], dims[l + 1])                      # [k][h] == column-major H x K
+        Wf = dec[e4m3_encode(W * np.float32(2.0 ** w_exp[l]))]
+        r = (x @ Wf) * 2.0 ** -(act_exp[l] + w_exp[l])               # real units
+        x = dec[e4m3_encode(r.astype(np.float32) * np.float32(2.0 ** act_exp[l + 1]))]
+    return ((x * 2.0 ** -act_exp[3]) @ ws[3].astype(np.float64)).astype(np.float32)
+
+
+@pytest.mark.parametrize("which,B", [(0, 256), (0, 37), (1, 1024), (2, 512)])
+def test_fp8_chain(fr, O, ctxs, which, B):
+    """BASELINE configs[4]: fp8 (OCP e4m3) MFMA FC on CDNA4 -- per-tensor power-of-two scales, calibration batch, saturating
+    conversion.  The gather stage's fp8 features are bit-exact against the host restatement; scores within 2e-2 of max|ref| of
+    the restated fp8 arithmetic (an fp32-vs-wide accumulation difference can flip an e4m3 rounding: 6 % of ONE activation) and
+    within 0.15 of the fp32 oracle (e4m3 keeps 3 mantissa bits)."""
+    m, ctx = ctxs(which)
+    om = O.OracleModel(NAMES[which])
+    rng = np.random.default_rng(303)
+    idx = uniform_idx(rng, m.rows(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32) if m.dense_len else None
+    rec = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES).view(np.float32)
+    ws = [ctx.get_weights(l) for l in range(4)]
+    ref32 = om.fc_chain(rec, ws, acc64=True)
+    ctx.set_fc_precision(fr.FC_FP8)
+    try:
+        wk = fr.Worker(ctx, B)
+        est_act, w_exp = ctx.fp8_exponents()
+        for l in range(3):   # max|W| * 2^e_w lands in (224, 448]
+            assert 224.0 < np.abs(ws[l]).max() * 2.0 ** w_exp[l] <= 448.0
+        s_est = wk.infer(idx, dense)                         # rms-estimated activation exponents
+        assert rel_err(s_est, ref32) <= 0.2, rel_err(s_est, ref32)
+        wk.calibrate_fp8(idx, dense)
+        act_exp, w_exp2 = ctx.fp8_exponents()
+        assert w_exp2 == w_exp
+        K = m.record_len
+        assert 112.0 < np.abs(rec).max() * 2.0 ** act_exp[0] <= 224.0   # one binade of headroom below 448
+        scores = wk.infer(idx, dense)
+        feat = wk.features(B, fp8=True)
+        want = e4m3_encode(rec * np.float32(2.0 ** act_exp[0])).T
+        assert np.array_equal(feat[:K], want)
+        assert not feat[K:].any()                            # zero pad up to a multiple of 64 k
+        reff = chain_fp8_reference(rec, ws, m.fc, act_exp, w_exp)
+        assert rel_err(scores, reff) <= 2e-2, rel_err(scores, reff)
+        assert rel_err(scores, ref32) <= 0.15, rel_err(scores, ref32)
+        assert np.array_equal(wk.infer(idx, dense), scores)                        # deterministic
+        assert rel_err(wk.fc_scores(rec), reff) <= 2e-2                            # fc_only entry point in fp8 mode
+        d_i = fr.DeviceBuffer.from_numpy(ctx, idx)
+        d_d = fr.DeviceBuffer.from_numpy(ctx, dense) if dense is not None else None
+        outs = [fr.DeviceBuffer(ctx, B * 4) for _ in range(7)]
+        for o in outs:
+            wk.push_device(B, d_i, d_d, o)
+        wk.sync()
+        for o in outs:
+            assert np.array_equal(o.download(np.float32, B), scores)               # stage pipeline on both paths
+        # saturation instead of NaN: exponents 6 binades too large clamp at +-448 and the scores stay finite
+        ctx.set_fp8_act_exponents([e + 6 for e in act_exp])
+        assert np.isfinite(wk.infer(idx, dense)).all()
+        ctx.set_fp8_act_exponents(act_exp)
+        wk.close()
+    finally:
+        ctx.set_fc_precision(fr.FC_FP32)
+    wk = fr.Worker(ctx, B)
+    assert rel_err(wk.infer(idx, dense), ref32) <= 1e-3   # back to the exact-f32 chain
+    wk.close()
+
+
 def _random_model(fr, rng):
     """A random user-defined model: random table dims/rows, an optional dense block in the middle of the record, an
     optional COPY pad, random FC widths.  Exercises the descriptor machinery beyond the three reference models."""
