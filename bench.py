@@ -133,7 +133,8 @@ def main():
                     help="replicas: BASELINE configs[1] (default, the headline metric); sharded: Model-C batch 4096 with tables "
                          "sharded by table-ID over the ranks + one RCCL all-gather of the looked-up slices (BASELINE configs[3])")
     ap.add_argument("--model", choices=["A", "B", "C"], default="A", help="A = BASELINE configs[1] (default headline); B/C: other configs")
-    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32", help="FC chain arithmetic (bf16 = BASELINE configs[2])")
+    ap.add_argument("--precision", choices=["f32", "bf16", "fp8"], default="f32",
+                    help="FC chain arithmetic (bf16 = BASELINE configs[2], fp8 = configs[4]: e4m3, calibrated on the first batch)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the multi-stream throughput loop and the Model-C leg: only the single-stream roofline launches run, so "
                          "that a rocprofv3 --kernel-trace --stats summary of this command shows the kernel under the roofline's conditions")
@@ -178,6 +179,12 @@ def main():
     d_idx = [fr.DeviceBuffer.from_numpy(ctx, a) for a in idx_host]
     d_dense = ([fr.DeviceBuffer.from_numpy(ctx, rng.uniform(-1, 1, (B, model.dense_len)).astype(np.float32)) for _ in range(n_bufs)]
                if model.dense_len else None)
+    if args.precision == "fp8":
+        ctx.set_fc_precision(fr.FC_FP8)
+        dense_host = rng.uniform(-1, 1, (B, model.dense_len)).astype(np.float32) if model.dense_len else None
+        cal = fr.Worker(ctx, B)
+        cal.calibrate_fp8(idx_host[0], dense_host)   # activation exponents from one batch of the same index law
+        cal.close()
     if args.model != "A" or args.precision != "f32":
         # non-headline configurations: throughput line only
         driver = fr.Driver(ctx, args.threads, args.depth, B)

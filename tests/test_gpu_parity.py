@@ -150,6 +150,16 @@ def test_readme_known_answers(fr, gpu):
         s = wk.infer(np.zeros((128, 1), np.int32))
         assert (s == np.float32(want)).all()
         wk.close()
+        # the same closed form is exact in the low-precision chains: every operand and every activation (K, K*2^10, K*2^19) is a
+        # power of two, representable in bf16 and -- once the calibration batch has set the exponents -- in e4m3
+        for prec in (fr.FC_BF16, fr.FC_FP8):
+            ctx.set_fc_precision(prec)
+            wk = fr.Worker(ctx, 128)
+            if prec == fr.FC_FP8:
+                wk.calibrate_fp8(np.zeros((128, 1), np.int32))
+            s = wk.infer(np.zeros((128, 1), np.int32))
+            assert (s == np.float32(want)).all(), (prec, s[:4])
+            wk.close()
         ctx.close()
 
 
