@@ -260,7 +260,7 @@ def main():
         flops = fc_flops_per_inference(fc) * B * group
         ach = flops / (pipe_ms * 1e-3) / 1e12
         wpe = int(os.environ.get("FR_FUSED_WPE", "4"))  # workgroups are built for 4 waves per SIMD (two per CU) unless forced to 2
-        kname = "fr_fused_tile_kernel<2, 44, 11, %d>" % wpe if group > 1 else "fr_pipeline_kernel<-1, 0>"
+        kname = "fr_fused_tile_kernel<2, 44, %d, %s>" % (wpe, "false" if wpe == 4 else "true") if group > 1 else "fr_pipeline_kernel<-1, 0>"
         result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                               "frac": ach / MFMA_F32_PEAK_TF, "traffic": pmc_traffic(kname.split(",")[0] if group > 1 else kname),
                               "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
