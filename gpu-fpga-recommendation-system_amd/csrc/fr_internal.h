@@ -191,14 +191,13 @@ static inline uint32_t fr_table_uid(const fr_table_desc &t) {
 }
 int frk_fill_table(float *base, int64_t rows, int dim, int mode, uint32_t seed, uint32_t uid, hipStream_t s);
 int frk_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t layer, float scale, hipStream_t s);
-int frk_f32_to_bf16(const float *src, uint16_t *dst, size_t count, hipStream_t s);
 int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense,
                float *out, int batch, int *err_flag, hipStream_t s);
 // feature-major FC chain, stage-pipelined across batches (see fr_kernels.hip)
 int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, int precision, hipStream_t s);
 int frk_pack_weights_q8_bf16(const float *W, uint16_t *Wh, int K, int H, hipStream_t s);
-bool frk_fc_h_tiled_ok(int K, int N, int ldm);
-int frk_fc_h_tiled(const void *Wh, const void *Xh, void *Yh, int K, int N, int ldm, hipStream_t s);
+bool frk_fc_lp_gemm_ok(int precision, int K, int N, int ldm);
+int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, hipStream_t s);
 int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, hipStream_t s);
 int frk_pack_weights_q16_fp8(const float *W, void *Wf, int K, int H, int e_w, hipStream_t s);
 int frk_records_to_q16_fp8(const float *X, void *Xf, int batch, int K, int ldm, int e_x, hipStream_t s);

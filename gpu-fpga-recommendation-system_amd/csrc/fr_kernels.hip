@@ -101,22 +101,6 @@ int frk_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t l
     return FR_OK;
 }
 
-__global__ void __launch_bounds__(256) f32_to_bf16_kernel(const float *src, uint16_t *dst, uint64_t n) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        __hip_bfloat16 b = __float2bfloat16(src[i]);  // round-to-nearest-even, NaN stays NaN
-        dst[i] = *reinterpret_cast<uint16_t *>(&b);
-    }
-}
-
-int frk_f32_to_bf16(const float *src, uint16_t *dst, size_t count, hipStream_t s) {
-    uint64_t blocks = (count + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks == 0) return FR_OK;
-    f32_to_bf16_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(src, dst, count);
-    KCHECK();
-    return FR_OK;
-}
 
 // ---------------------------------------------------------------------------------------------------
 // gather_pack: HBM-bound, no MFMA.
@@ -329,15 +313,20 @@ __device__ __forceinline__ void gather_q_body(const FrPipeArgs &a, const FrStage
 // per (item, record word): a dim-16 row is fetched by four separate wave-instructions, and all 64 lanes of an instruction
 // hit 64 different lines.  Here a workgroup owns a tile of 32 items x 64 record words: phase 1 loads with lanes along
 // WORDS (a row is read by dim/4 adjacent lanes of one instruction, like gather_pack_kernel) into an LDS tile, phase 2 reads
-// the tile transposed (row stride 65 x 16 B: conflict-free ds_read_b128) and stores with lanes along ITEMS (512 contiguous
+// the tile transposed (XOR-swizzled columns: conflict-free ds_read_b128) and stores with lanes along ITEMS (512 contiguous
 // bytes per half-wave) in the chain's q4 (PREC 0) or bf16 q8 (PREC 1) layout.
-constexpr int FR_GT_ITEMS = 32, FR_GT_WORDS = 64, FR_GT_LD = 65;
+constexpr int FR_GT_ITEMS = 32, FR_GT_WORDS = 64;
+// tile element (item, word) lives at item * 64 + (word ^ (item & 15)): exactly 32 KiB (a padded stride of 65 would be 33,280 B and
+// one such workgroup would no longer fit beside two 64 KiB GEMM workgroups on a CU), conflict-free both ways -- a b128 access is
+// served 16 lanes at a time, and 16 consecutive words of one item (phase 1) or one word of 16 consecutive items (phase 2) land in
+// 16 different 16-byte bank groups.
+__device__ __forceinline__ int gt_at(int item, int word) { return item * FR_GT_WORDS + (word ^ (item & 15)); }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi);
 __device__ __forceinline__ uint32_t pack_fp8_word(const uint4 &v, float scale);
 
 template <int PREC>
-__device__ __forceinline__ void gather_tr_body(const FrPipeArgs &a, const FrStageArgs &st, int local, uint4 *tile /* [32][65] */) {
+__device__ __forceinline__ void gather_tr_body(const FrPipeArgs &a, const FrStageArgs &st, int local, uint4 *tile /* [32][64], swizzled */) {
     const int m_blocks = st.ldm / FR_GT_ITEMS;
     const int mb = local % m_blocks, wb = local / m_blocks;
     const int m0 = mb * FR_GT_ITEMS, w0 = wb * FR_GT_WORDS;
@@ -370,7 +359,7 @@ __device__ __forceinline__ void gather_tr_body(const FrPipeArgs &a, const FrStag
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int m = m0 + 4 * ig + i;
-                tile[(4 * ig + i) * FR_GT_LD + wl] = (m < st.batch) ? v[i] : make_uint4(0u, 0u, 0u, 0u);
+                tile[gt_at(4 * ig + i, wl)] = (m < st.batch) ? v[i] : make_uint4(0u, 0u, 0u, 0u);
             }
         }
         if (bad) atomicOr_system(a.err_flag, 1);
@@ -384,7 +373,7 @@ __device__ __forceinline__ void gather_tr_body(const FrPipeArgs &a, const FrStag
 #pragma unroll
             for (int j = 0; j < FR_GT_WORDS / 16; j++) {
                 const int wl = ws + 16 * j, w = w0 + wl;
-                if (w < a.n_words) Xq[(size_t)w * st.ldm + m] = tile[il * FR_GT_LD + wl];  // SEMANTIC layout: dst word == w
+                if (w < a.n_words) Xq[(size_t)w * st.ldm + m] = tile[gt_at(il, wl)];  // SEMANTIC layout: dst word == w
             }
         } else if constexpr (PREC == 2) {
             uint4 *Xf = reinterpret_cast<uint4 *>(st.out);  // q16 element = record words 4e .. 4e+3 as e4m3 bytes (x 2^e_out, saturated)
@@ -396,7 +385,7 @@ __device__ __forceinline__ void gather_tr_body(const FrPipeArgs &a, const FrStag
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int wl = 4 * el + j;
-                    o[j] = (w0 + wl < a.n_words) ? pack_fp8_word(tile[il * FR_GT_LD + wl], scale) : 0u;
+                    o[j] = (w0 + wl < a.n_words) ? pack_fp8_word(tile[gt_at(il, wl)], scale) : 0u;
                 }
                 Xf[(size_t)e * st.ldm + m] = make_uint4(o[0], o[1], o[2], o[3]);
             }
@@ -406,7 +395,7 @@ __device__ __forceinline__ void gather_tr_body(const FrPipeArgs &a, const FrStag
             for (int j = 0; j < FR_GT_WORDS / 32; j++) {
                 const int pl = ws + 16 * j, w = w0 + 2 * pl;
                 if (w < a.n_words) {
-                    const uint4 lo = tile[il * FR_GT_LD + 2 * pl], hi = tile[il * FR_GT_LD + 2 * pl + 1];
+                    const uint4 lo = tile[gt_at(il, 2 * pl)], hi = tile[gt_at(il, 2 * pl + 1)];
                     uint4 h;
                     h.x = pack_bf16x2(__uint_as_float(lo.x), __uint_as_float(lo.y));
                     h.y = pack_bf16x2(__uint_as_float(lo.z), __uint_as_float(lo.w));
@@ -818,6 +807,7 @@ __device__ __forceinline__ void fc_out_h_body(const FrStageArgs &st, int local, 
 // the decoded fp8 R3 by the fp32 master weights.  No K-split partials, no fused / tiled variants yet: stage pipeline only.
 // ===================================================================================================
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d, float scale) {
     const float lim = 448.0f;  // largest finite e4m3fn
@@ -1005,7 +995,7 @@ __device__ __forceinline__ void fc_out_f_body(const FrStageArgs &st, int local, 
 // 2 = fp8 chain (q16 e4m3 operands, scaled f8f6f4 MFMA, fp32 accumulate).
 template <int STAGE, int PREC>
 __global__ void __launch_bounds__(FR_PIPE_THREADS) fr_pipeline_kernel(const FrPipeArgs a) {
-    __shared__ uint4 smem[FR_GT_ITEMS * FR_GT_LD];  // 33,280 B: the gather tile; the FC stages use the first 32 KiB as float red[8][16][64]
+    __shared__ uint4 smem[FR_GT_ITEMS * FR_GT_WORDS];  // 32 KiB: the gather tile, or float red[8][16][64] of the FC stages
     float *red = reinterpret_cast<float *>(smem);
     const int b = blockIdx.x;
     int s = 0;
@@ -1304,99 +1294,168 @@ int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, 
 }
 
 // ===================================================================================================
-// fc_h_tiled: LDS-tiled bf16 GEMM for layers that are large enough to fill the chip on their own (Model-C FC1 at batch
-// 4096 is 2048 x 4096 x 3968).  Same q8 operands and output as fc_h_body, but each 16-byte element is fetched from L2 ONCE
-// per 128 x 128 workgroup tile and shared through LDS: 64 FLOP per operand byte instead of 8.
-//   workgroup = 8 waves as 2 (n) x 4 (m); wave tile 64 (n) x 32 (m) = two 32x32x16 MFMA tiles sharing one B fragment;
-//   K step 64 (8 k-octs): LDS images As[ko][n], Bs[ko][m] of 16-byte elements -- a fragment read is a ds_read_b128 with
-//   consecutive lanes on consecutive elements (conflict-free), no transpose anywhere;
-//   register-staged double buffering (next tile's global loads fly during the MFMAs), one barrier per K step.
+// fc_lp_gemm_kernel<PREC>: LDS-tiled GEMM for low-precision layers that fill the chip on their own (Model-C FC1 at batch 4096).
+// PREC 1 = bf16 (q8 elements, v_mfma_f32_32x32x16_bf16), PREC 2 = fp8 (q16 elements, v_mfma_scale_f32_32x32x64_f8f6f4).
+// Block tile 128 (n) x 256 (m), 8 waves as 2 x 4 with 64 x 64 wave tiles (2 x 2 MFMA tiles: 4 fragment reads per 4 MFMAs).
+// A K step is 8 rows of 16-byte elements (64 k in bf16, 128 k in fp8): 16 KiB of W + 32 KiB of X, three steps in LDS (144 KiB).
+// Operands go global -> LDS directly (buffer_load ... lds, 64 consecutive elements per wave-instruction, no VGPR staging) two
+// steps ahead of the MFMAs; one barrier per step.  Fragment reads are conflict-free ds_read_b128 (a b128 access is served 16
+// lanes at a time, and 16 consecutive elements of a row are 256 contiguous bytes).  L2 -> CU traffic per output is 25 % below
+// that of 128 x 128 tiles.
 // ===================================================================================================
-constexpr int FR_TL = 128;  // tile edge (n and m)
-constexpr int FR_TKO = 8;   // k-octs per K step (64 k)
+constexpr int FR_GN = 128, FR_GM = 256, FR_GR = 8;
+// STAGES K steps in LDS: 3 = 144 KiB, loads two steps ahead (the workgroup owns its CU); 2 = 96 KiB, one step ahead, leaves room
+// for a 32 KiB stage-pipeline workgroup of another stream on the same CU (FR_LP_GEMM_STAGES=2).
 
-__global__ void __launch_bounds__(512) fc_h_tiled_kernel(const uint4 *__restrict__ Wh, const uint4 *__restrict__ Xh, uint2 *__restrict__ Yh,
-                                                         int K, int N, int ldm) {
-    __shared__ uint4 As[2][FR_TKO][FR_TL];
-    __shared__ uint4 Bs[2][FR_TKO][FR_TL];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+template <int PREC, int STAGES>
+__global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
+                                                         int N, int ldm, int sc_a, int sc_b, float oscale) {
+    extern __shared__ uint4 glds[];
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wm = wave >> 1;
-    const int tn = N / FR_TL;
-    // XCD-aware order: workgroups b, b+8, ... (one XCD) walk one column of m tiles for a fixed set of n tiles
-    const int n_tile = blockIdx.x % tn, m_tile = blockIdx.x / tn;
-    const int n0 = n_tile * FR_TL, m0 = m_tile * FR_TL;
+    const int tn = N / FR_GN;
+    const int n_tile = blockIdx.x % tn, m_tile = blockIdx.x / tn;  // workgroups b, b+8, ... (one XCD) share m tiles' X panels through that L2
+    const int n0 = n_tile * FR_GN, m0 = m_tile * FR_GM;
     const int r = lane & 31, h = lane >> 5;
-    // staging roles: elements e = tid, tid + 512 of the 8 x 128 tile
-    const int e_ko = tid >> 7, e_c = tid & 127;  // second element: ko + 4
-    const uint4 *a_src = Wh + (size_t)e_ko * N + n0 + e_c;
-    const uint4 *b_src = Xh + (size_t)e_ko * ldm + m0 + e_c;
-    const int nkt = K / (8 * FR_TKO);
-
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc0[i] = acc1[i] = 0.0f;
-
-    uint4 ga0, ga1, gb0, gb1;
-    auto gload = [&](int kt) {
-        const size_t ko = (size_t)kt * FR_TKO;
-        ga0 = a_src[ko * N];
-        ga1 = a_src[(ko + 4) * N];
-        gb0 = b_src[ko * ldm];
-        gb1 = b_src[(ko + 4) * ldm];
+    // Buffer resources built by hand (SGPR quads for the inline asm below): base, stride 0, bytes, gfx9 raw-buffer flags.
+    auto make_rs = [](const void *p, unsigned bytes) {
+        const unsigned long long a = (unsigned long long)p;
+        i32x4_t rs;
+        rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        rs[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+        rs[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+        rs[3] = 0x00020000;
+        return rs;
     };
-    auto lstore = [&](int buf) {
-        As[buf][e_ko][e_c] = ga0;
-        As[buf][e_ko + 4][e_c] = ga1;
-        Bs[buf][e_ko][e_c] = gb0;
-        Bs[buf][e_ko + 4][e_c] = gb1;
+    const i32x4_t rsW = make_rs(W, (unsigned)KE * (unsigned)N * 16u), rsX = make_rs(X, (unsigned)KE * (unsigned)ldm * 16u);
+    auto As = [&](int st, int row) { return glds + ((size_t)st * FR_GR + row) * (FR_GN + FR_GM); };          // 128 elements
+    auto Bs = [&](int st, int row) { return glds + ((size_t)st * FR_GR + row) * (FR_GN + FR_GM) + FR_GN; };  // 256 elements
+    // global -> LDS without a VGPR round trip: lane i's 16 bytes land at M0 + 16 i.  Inline asm on purpose: through the builtin the
+    // compiler treats every LDS read as a possible alias of the DMA write and waits for vmcnt(0) before each fragment read, which
+    // removes the two-step prefetch distance; the counted s_waitcnt below are the only synchronisation these loads need.
+    auto dma = [&](const i32x4_t &rs, const uint4 *dst, unsigned voff, unsigned soff) {
+        const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_ptr)dst);
+        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
     };
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; kt++) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) gload(kt + 1);
+    // staging: 48 wave-instructions of 64 elements per step; every wave issues 2 of W's 16 and 4 of X's 32
+    const unsigned vW = (unsigned)(n0 + 64 * (wave & 1) + lane) * 16u, vX = (unsigned)(m0 + lane) * 16u;
+    auto issue = [&](int step, int st) {
 #pragma unroll
-        for (int kk = 0; kk < FR_TKO / 2; kk++) {
-            const uint4 a0 = As[cur][2 * kk + h][wn * 64 + r];
-            const uint4 a1 = As[cur][2 * kk + h][wn * 64 + 32 + r];
-            const uint4 b = Bs[cur][2 * kk + h][wm * 32 + r];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, b), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, b), acc1, 0, 0, 0);
+        for (int i = 0; i < 2; i++) {
+            const int row = (wave >> 1) + 4 * i;  // 8 waves x 2 = rows 0..7 x 2 halves
+            dma(rsW, As(st, row) + 64 * (wave & 1), vW, (unsigned)(step * FR_GR + row) * (unsigned)N * 16u);
         }
-        if (kt + 1 < nkt) lstore(cur ^ 1);
-        __syncthreads();
-    }
-    // epilogue: ONE rounding to bf16; registers 4i..4i+3 of a tile are 4 consecutive n = one 8-byte half of a q8 element
-    const int m = m0 + wm * 32 + r;
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const f32x16 &acc = t ? acc1 : acc0;
+        for (int i = 0; i < 4; i++)  // row = wave, four quarters
+            dma(rsX, Bs(st, wave) + 64 * i, vX + 64u * 16u * i, (unsigned)(step * FR_GR + wave) * (unsigned)ldm * 16u);
+    };
+    f32x16 acc[2][2];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            uint2 hv;
-            hv.x = pack_bf16x2(acc[4 * i + 0], acc[4 * i + 1]);
-            hv.y = pack_bf16x2(acc[4 * i + 2], acc[4 * i + 3]);
-            const int no = ((n0 + wn * 64 + 32 * t) >> 3) + i;  // n = n0 + wn*64 + 32t + 8i + 4h + c
-            Yh[((size_t)no * ldm + m) * 2 + h] = hv;
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[t][u][i] = 0.0f;
+    const int nsteps = KE / FR_GR;
+    issue(0, 0);
+    if (STAGES == 3 && nsteps > 1) issue(1, 1);
+    for (int s = 0; s < nsteps; s++) {
+        // this wave's loads of step s have landed once at most the 6 of step s+1 are outstanding
+        if (STAGES == 3 && s + 1 < nsteps) __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0)
+        __syncthreads();  // everyone's step-s data is in LDS, and everyone is done reading the buffer the next issue overwrites
+        if (s + STAGES - 1 < nsteps) issue(s + STAGES - 1, (s + STAGES - 1) % STAGES);
+        const int st = s % STAGES;
+        if constexpr (PREC == 1) {
+#pragma unroll
+            for (int kk = 0; kk < FR_GR / 2; kk++) {
+                const uint4 *ar = As(st, 2 * kk + h) + wn * 64 + r, *br = Bs(st, 2 * kk + h) + wm * 64 + r;
+                const uint4 a0 = ar[0], a1 = ar[32], b0 = br[0], b1 = br[32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, b0), acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, b0), acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, b1), acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, b1), acc[1][1], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < FR_GR / 4; kk++) {
+                i32x8 a[2], b[2];
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const uint4 alo = As(st, 4 * kk + 2 * h)[wn * 64 + 32 * t + r], ahi = As(st, 4 * kk + 2 * h + 1)[wn * 64 + 32 * t + r];
+                    const uint4 blo = Bs(st, 4 * kk + 2 * h)[wm * 64 + 32 * t + r], bhi = Bs(st, 4 * kk + 2 * h + 1)[wm * 64 + 32 * t + r];
+                    a[t][0] = (int)alo.x; a[t][1] = (int)alo.y; a[t][2] = (int)alo.z; a[t][3] = (int)alo.w;
+                    a[t][4] = (int)ahi.x; a[t][5] = (int)ahi.y; a[t][6] = (int)ahi.z; a[t][7] = (int)ahi.w;
+                    b[t][0] = (int)blo.x; b[t][1] = (int)blo.y; b[t][2] = (int)blo.z; b[t][3] = (int)blo.w;
+                    b[t][4] = (int)bhi.x; b[t][5] = (int)bhi.y; b[t][6] = (int)bhi.z; b[t][7] = (int)bhi.w;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int t = 0; t < 2; t++) acc[t][u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t], b[u], acc[t][u], 0, 0, 0, sc_a, 0, sc_b);
+            }
         }
     }
+    // epilogue: ONE rounding per output; registers 4i..4i+3 of a tile are 4 consecutive n
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const f32x16 &c = acc[t][u];
+            const int m = m0 + wm * 64 + 32 * u + r;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int n = n0 + wn * 64 + 32 * t + 8 * i + 4 * h;  // + c
+                if constexpr (PREC == 1) {
+                    uint2 hv;
+                    hv.x = pack_bf16x2(c[4 * i + 0], c[4 * i + 1]);
+                    hv.y = pack_bf16x2(c[4 * i + 2], c[4 * i + 3]);
+                    reinterpret_cast<uint2 *>(Y)[((size_t)(n >> 3) * ldm + m) * 2 + ((n & 7) >> 2)] = hv;
+                } else {
+                    reinterpret_cast<uint32_t *>(Y)[((size_t)(n >> 4) * ldm + m) * 4 + ((n & 15) >> 2)] =
+                        pack_fp8x4(c[4 * i + 0], c[4 * i + 1], c[4 * i + 2], c[4 * i + 3], oscale);
+                }
+            }
+        }
 }
 
-bool frk_fc_h_tiled_ok(int K, int N, int ldm) {
-    static const int forced = getenv("FR_BF16_TILED") ? atoi(getenv("FR_BF16_TILED")) : -1;  // experiment knob: 0 = never, 1 = whenever legal
-    if (K % (8 * FR_TKO) || N % FR_TL || ldm % FR_TL) return false;
+// precision: FR_FC_BF16 (K % 64 == 0) or FR_FC_FP8 (K padded to 128 by the caller's layout: KE % 8 == 0)
+bool frk_fc_lp_gemm_ok(int precision, int K, int N, int ldm) {
+    static const int forced = getenv("FR_LP_GEMM") ? atoi(getenv("FR_LP_GEMM")) : -1;  // experiment knob: 0 = never, 1 = whenever legal
+    const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : K / 8;
+    if ((precision == FR_FC_BF16 && K % 8) || KE % FR_GR || KE / FR_GR < 2 || N % FR_GN || ldm % FR_GM) return false;
     if (forced == 0) return false;
     if (forced == 1) return true;
-    return (long)(N / FR_TL) * (ldm / FR_TL) >= 192;  // enough tiles to fill 256 CUs
+    static const int min_tiles = getenv("FR_LP_GEMM_MIN_TILES") ? atoi(getenv("FR_LP_GEMM_MIN_TILES")) : 64;
+    return (long)(N / FR_GN) * (ldm / FR_GM) >= min_tiles;  // 64 tiles = a quarter of the CUs (Model-C FC2 at batch 4096: runs beside another stream's gather)
 }
 
-int frk_fc_h_tiled(const void *Wh, const void *Xh, void *Yh, int K, int N, int ldm, hipStream_t s) {
-    dim3 grid((N / FR_TL) * (ldm / FR_TL));
-    fc_h_tiled_kernel<<<grid, dim3(512), 0, s>>>(reinterpret_cast<const uint4 *>(Wh), reinterpret_cast<const uint4 *>(Xh),
-                                                 reinterpret_cast<uint2 *>(Yh), K, N, ldm);
+template <int PREC, int STAGES>
+static int lp_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)STAGES * FR_GR * (FR_GN + FR_GM) * 16;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fc_lp_gemm_kernel<PREC, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            FR_FAIL(FR_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_set = true;
+    }
+    dim3 grid((N / FR_GN) * (ldm / FR_GM));
+    fc_lp_gemm_kernel<PREC, STAGES><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale);
     KCHECK();
     return FR_OK;
+}
+
+int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, hipStream_t s) {
+    static const int stages = getenv("FR_LP_GEMM_STAGES") ? atoi(getenv("FR_LP_GEMM_STAGES")) : 2;  // 2: co-resident with other streams' stage kernels
+    const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : K / 8;
+    if (precision == FR_FC_FP8) {
+        const float os = ldexpf(1.0f, e_out);
+        return stages == 2 ? lp_gemm_launch<2, 2>(Wp, Xp, Yp, KE, N, ldm, 127 - e_w, 127 - e_in, os, s)
+                           : lp_gemm_launch<2, 3>(Wp, Xp, Yp, KE, N, ldm, 127 - e_w, 127 - e_in, os, s);
+    }
+    return stages == 2 ? lp_gemm_launch<1, 2>(Wp, Xp, Yp, KE, N, ldm, 0, 0, 1.0f, s) : lp_gemm_launch<1, 3>(Wp, Xp, Yp, KE, N, ldm, 0, 0, 1.0f, s);
 }
 
 // ===================================================================================================
