@@ -629,7 +629,7 @@ static int pipeline_step(fr_worker *w) {
                 st.in = rd.r3; st.in_part_stride = (int)rd.p3; st.out = sl.d_scores; st.w = wl[3];
                 break;
         }
-        if ((bf16 || fp8) && s >= 1 && s <= 3 && frk_fc_lp_gemm_ok(prec, st.K, st.N, ldm)) {
+        if (s >= 1 && s <= 3 && st.nparts_in == 1 && st.nsplit == 1 && frk_fc_lp_gemm_ok(prec, st.K, st.N, ldm)) {
             // a layer big enough to fill the chip alone runs as its own LDS-tiled GEMM launch (same stream, same step)
             int rc = frk_fc_lp_gemm(prec, st.w, st.in, st.out, st.K, st.N, ldm, st.e_w, st.e_in, st.e_out, w->stream);
             if (rc) return rc;

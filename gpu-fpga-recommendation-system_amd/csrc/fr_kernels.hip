@@ -1295,7 +1295,8 @@ int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, 
 
 // ===================================================================================================
 // fc_lp_gemm_kernel<PREC>: LDS-tiled GEMM for low-precision layers that fill the chip on their own (Model-C FC1 at batch 4096).
-// PREC 1 = bf16 (q8 elements, v_mfma_f32_32x32x16_bf16), PREC 2 = fp8 (q16 elements, v_mfma_scale_f32_32x32x64_f8f6f4).
+// PREC 0 = fp32 (q4 elements, v_mfma_f32_32x32x2_f32: the same k-ordered exact-f32 sums as the other fp32 kernels, full K per
+// output), PREC 1 = bf16 (q8 elements, v_mfma_f32_32x32x16_bf16), PREC 2 = fp8 (q16 elements, v_mfma_scale_f32_32x32x64_f8f6f4).
 // Block tile 128 (n) x 256 (m), 8 waves as 2 x 4 with 64 x 64 wave tiles (2 x 2 MFMA tiles: 4 fragment reads per 4 MFMAs).
 // A K step is 8 rows of 16-byte elements (64 k in bf16, 128 k in fp8): 16 KiB of W + 32 KiB of X, three steps in LDS (144 KiB).
 // Operands go global -> LDS directly (buffer_load ... lds, 64 consecutive elements per wave-instruction, no VGPR staging) two
@@ -1368,7 +1369,22 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict
         __syncthreads();  // everyone's step-s data is in LDS, and everyone is done reading the buffer the next issue overwrites
         if (s + STAGES - 1 < nsteps) issue(s + STAGES - 1, (s + STAGES - 1) % STAGES);
         const int st = s % STAGES;
-        if constexpr (PREC == 1) {
+        if constexpr (PREC == 0) {  // q4 fp32 elements: one element per lane feeds four v_mfma_f32_32x32x2_f32 (k = 8 kk + 4 h + c)
+#pragma unroll
+            for (int kk = 0; kk < FR_GR / 2; kk++) {
+                const uint4 *ar = As(st, 2 * kk + h) + wn * 64 + r, *br = Bs(st, 2 * kk + h) + wm * 64 + r;
+                const uint4 a0 = ar[0], a1 = ar[32], b0 = br[0], b1 = br[32];
+                const uint32_t a0c[4] = {a0.x, a0.y, a0.z, a0.w}, a1c[4] = {a1.x, a1.y, a1.z, a1.w};
+                const uint32_t b0c[4] = {b0.x, b0.y, b0.z, b0.w}, b1c[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a0c[c]), __uint_as_float(b0c[c]), acc[0][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a1c[c]), __uint_as_float(b0c[c]), acc[1][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a0c[c]), __uint_as_float(b1c[c]), acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a1c[c]), __uint_as_float(b1c[c]), acc[1][1], 0, 0, 0);
+                }
+            }
+        } else if constexpr (PREC == 1) {
 #pragma unroll
             for (int kk = 0; kk < FR_GR / 2; kk++) {
                 const uint4 *ar = As(st, 2 * kk + h) + wn * 64 + r, *br = Bs(st, 2 * kk + h) + wm * 64 + r;
@@ -1408,7 +1424,9 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int n = n0 + wn * 64 + 32 * t + 8 * i + 4 * h;  // + c
-                if constexpr (PREC == 1) {
+                if constexpr (PREC == 0) {  // q4 element (n / 4) of the next layer's operand
+                    reinterpret_cast<float4 *>(Y)[(size_t)(n >> 2) * ldm + m] = make_float4(c[4 * i + 0], c[4 * i + 1], c[4 * i + 2], c[4 * i + 3]);
+                } else if constexpr (PREC == 1) {
                     uint2 hv;
                     hv.x = pack_bf16x2(c[4 * i + 0], c[4 * i + 1]);
                     hv.y = pack_bf16x2(c[4 * i + 2], c[4 * i + 3]);
@@ -1424,8 +1442,8 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict
 // precision: FR_FC_BF16 (K % 64 == 0) or FR_FC_FP8 (K padded to 128 by the caller's layout: KE % 8 == 0)
 bool frk_fc_lp_gemm_ok(int precision, int K, int N, int ldm) {
     static const int forced = getenv("FR_LP_GEMM") ? atoi(getenv("FR_LP_GEMM")) : -1;  // experiment knob: 0 = never, 1 = whenever legal
-    const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : K / 8;
-    if ((precision == FR_FC_BF16 && K % 8) || KE % FR_GR || KE / FR_GR < 2 || N % FR_GN || ldm % FR_GM) return false;
+    const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : (precision == FR_FC_BF16 ? K / 8 : K / 4);
+    if ((precision == FR_FC_BF16 && K % 8) || (precision == FR_FC_FP32 && K % 4) || KE % FR_GR || KE / FR_GR < 2 || N % FR_GN || ldm % FR_GM) return false;
     if (forced == 0) return false;
     if (forced == 1) return true;
     static const int min_tiles = getenv("FR_LP_GEMM_MIN_TILES") ? atoi(getenv("FR_LP_GEMM_MIN_TILES")) : 64;
@@ -1449,7 +1467,9 @@ static int lp_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int 
 
 int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, hipStream_t s) {
     static const int stages = getenv("FR_LP_GEMM_STAGES") ? atoi(getenv("FR_LP_GEMM_STAGES")) : 2;  // 2: co-resident with other streams' stage kernels
-    const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : K / 8;
+    const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : (precision == FR_FC_BF16 ? K / 8 : K / 4);
+    if (precision == FR_FC_FP32)
+        return stages == 2 ? lp_gemm_launch<0, 2>(Wp, Xp, Yp, KE, N, ldm, 0, 0, 1.0f, s) : lp_gemm_launch<0, 3>(Wp, Xp, Yp, KE, N, ldm, 0, 0, 1.0f, s);
     if (precision == FR_FC_FP8) {
         const float os = ldexpf(1.0f, e_out);
         return stages == 2 ? lp_gemm_launch<2, 2>(Wp, Xp, Yp, KE, N, ldm, 127 - e_w, 127 - e_in, os, s)
