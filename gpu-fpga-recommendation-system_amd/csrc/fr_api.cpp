@@ -458,6 +458,12 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
     if (!ctx || !out) FR_FAIL(FR_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (max_batch <= 0 || max_batch > (1 << 24)) FR_FAIL(FR_ERR_INVALID, "max_batch %d out of range", max_batch);
+    {   // the FC kernels address every operand through a buffer resource: 32-bit byte offsets, so each tensor must stay below 4 GiB
+        int widest = 0;
+        for (int l = 0; l < 4; l++) widest = ctx->model.fc[l] > widest ? ctx->model.fc[l] : widest;
+        if ((uint64_t)widest * (uint64_t)round_up(max_batch, 64) * 4ull >= (1ull << 32))
+            FR_FAIL(FR_ERR_INVALID, "max_batch %d: an activation tensor of %d x batch floats would reach 4 GiB (32-bit buffer offsets)", max_batch, widest);
+    }
     FR_HIP(hipSetDevice(ctx->device));
     fr_worker *w = new (std::nothrow) fr_worker();
     if (!w) FR_FAIL(FR_ERR_OOM, "out of host memory");

@@ -1316,8 +1316,21 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wm = wave >> 1;
-    const int tn = N / FR_GN;
-    const int n_tile = blockIdx.x % tn, m_tile = blockIdx.x / tn;  // workgroups b, b+8, ... (one XCD) share m tiles' X panels through that L2
+    const int tn = N / FR_GN, tm = ldm / FR_GM;
+    // XCD-aware tile map: workgroup b runs on XCD b % 8.  The XCDs form a 2 (n) x 4 (m) grid and each owns a tn/2 x tm/4 block
+    // of tiles, so its L2 sees tn/2 weight panels + tm/4 activation panels instead of (with a linear map) two weight panels and
+    // EVERY activation panel: half the traffic from beyond L2 for Model-C FC1.  The workgroups of an XCD walk K in step, so a
+    // panel row is fetched once and hit by the others whatever the L2 capacity.
+    int n_tile, m_tile;
+    if (tn % 2 == 0 && tm % 4 == 0) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int tnx = tn / 2;
+        n_tile = (x & 1) * tnx + j % tnx;
+        m_tile = (x >> 1) * (tm / 4) + j / tnx;
+    } else {
+        n_tile = blockIdx.x % tn;
+        m_tile = blockIdx.x / tn;
+    }
     const int n0 = n_tile * FR_GN, m0 = m_tile * FR_GM;
     const int r = lane & 31, h = lane >> 5;
     // Buffer resources built by hand (SGPR quads for the inline asm below): base, stride 0, bytes, gfx9 raw-buffer flags.
