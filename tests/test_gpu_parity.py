@@ -262,6 +262,22 @@ def test_state_errors(fr, gpu):
         ctx.set_weights(0, np.ones(7, np.float32))
     with pytest.raises(fr.FleetRecError):
         fr.Context(m, device=99)
+    for bad in (0, -3, 1 << 25):
+        with pytest.raises(fr.FleetRecError) as e:
+            fr.Worker(ctx, bad)   # empty / negative / absurd batch capacity
+        assert e.value.status == fr.FR_ERR_INVALID
+    with pytest.raises(fr.FleetRecError) as e:
+        fr.Worker(ctx, 1 << 21)   # 1024 x 2 Mi floats: an activation tensor would not fit 32-bit buffer offsets
+    assert e.value.status == fr.FR_ERR_INVALID and "4 GiB" in str(e.value)
+    with pytest.raises(fr.FleetRecError) as e:
+        wk.submit(0)              # empty batch
+    assert e.value.status == fr.FR_ERR_INVALID
+    with pytest.raises(fr.FleetRecError) as e:
+        wk.submit(9)              # more than the worker's capacity
+    assert e.value.status == fr.FR_ERR_INVALID
+    with pytest.raises(fr.FleetRecError) as e:
+        ctx.set_fc_precision(7)
+    assert e.value.status == fr.FR_ERR_INVALID
     wk.close()
     ctx.close()
 
