@@ -237,8 +237,9 @@ def main():
                        "parallelism": "replicas x%d" % world},
         }
         # ---- roofline of the dominant kernel: measured live with HIP events on the worker's stream ----
-        # Model-A streams through fr_fused_tile_kernel: ONE launch = the whole hot path (gather + 4 GEMMs) of `group` queued
-        # batches, 32 items per workgroup.  (Models that do not fit LDS use fr_pipeline_kernel<-1>, group = 1.)
+        # Model-A streams through the fused item-tile kernel: ONE launch = the whole hot path (gather + 4 GEMMs) of `group` queued
+        # batches, 64 items per workgroup at the default group of 64 (32 items for smaller groups).  (Models that do not fit
+        # LDS use fr_pipeline_kernel<-1>, group = 1.)
         group = ctx.stream_group()
         wk = fr.Worker(ctx, B)
         ring = [fr.DeviceBuffer(ctx, B * 4) for _ in range(max(8, 2 * group))]
@@ -260,7 +261,12 @@ def main():
         flops = fc_flops_per_inference(fc) * B * group
         ach = flops / (pipe_ms * 1e-3) / 1e12
         wpe = int(os.environ.get("FR_FUSED_WPE", "4"))  # workgroups are built for 4 waves per SIMD (two per CU) unless forced to 2
-        kname = "fr_fused_tile_kernel<2, 44, %d, %s>" % (wpe, "false" if wpe == 4 else "true") if group > 1 else "fr_pipeline_kernel<-1, 0>"
+        if group >= 64 and os.environ.get("FR_FUSED_M2", "1") != "0":
+            kname = "fr_fused_tile_m2_kernel<44>"   # 64 items per workgroup: one launch of 64 batches covers the 256 CUs
+        elif group > 1:
+            kname = "fr_fused_tile_kernel<2, 44, %d, %s>" % (wpe, "false" if wpe == 4 else "true")
+        else:
+            kname = "fr_pipeline_kernel<-1, 0>"
         result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                               "frac": ach / MFMA_F32_PEAK_TF, "traffic": pmc_traffic(kname.split(",")[0] if group > 1 else kname),
                               "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "

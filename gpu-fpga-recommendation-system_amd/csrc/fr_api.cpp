@@ -720,7 +720,11 @@ static int fused_flush(fr_worker *w) {
     fr_ctx *c = w->ctx;
     FrFusedArgs a{};
     const bool bf16 = c->fc_precision == FR_FC_BF16;
-    const int per_wg = bf16 ? frk_fused_h_items_per_wg() : 32;  // items per workgroup
+    // fp32: the 64-item kernel needs 64 queued batches to cover the chip; smaller groups keep the 32-item kernel (env FR_FUSED_M2=0/1 forces)
+    static const int m2_forced = getenv("FR_FUSED_M2") ? atoi(getenv("FR_FUSED_M2")) : -1;
+    const bool m2 = !bf16 && frk_fused_m2_ok(c->model.fc[0], c->model.fc[1], c->model.fc[2], c->model.fc[3]) &&
+                    (m2_forced == 1 || (m2_forced != 0 && fused_group() >= 64));
+    const int per_wg = bf16 ? frk_fused_h_items_per_wg() : (m2 ? 64 : 32);  // items per workgroup
     int max_tiles = 0;
     for (int i = 0; i < w->n_pending; i++) {
         a.b[i] = w->pending[i];
@@ -750,6 +754,7 @@ static int fused_flush(fr_worker *w) {
     a.H3 = c->model.fc[3];
     a.stamps = g_stamp_buffer;
     w->n_pending = 0;
+    if (m2) return frk_fused_m2_launch(a, w->stream);
     return bf16 ? frk_fused_h_launch(a, w->stream) : frk_fused_launch(a, w->stream);
 }
 

@@ -17,7 +17,7 @@
 
 #include "fr_internal.h"
 
-constexpr int FR_SCORE_RING = 64;
+constexpr int FR_SCORE_RING = 256;  // four launches of 64 batches per worker between two syncs
 
 struct fr_driver {
     fr_ctx *ctx = nullptr;
@@ -97,10 +97,10 @@ extern "C" int fr_driver_run_resident(fr_driver *d, int batch, int64_t total_bat
                 local++;
                 const int p = (int)(id % n_pool);
                 rc = fr_worker_push_device(wk[slot], batch, d_idx_pool[p], d_dense_pool ? d_dense_pool[p] : nullptr, scores);
-                // bound the host's run-ahead (and keep score buffers unique): sync a worker after FR_SCORE_RING pushes
-                if (rc == FR_OK && (local % d->depth) == 0 && ((local / d->depth) % FR_SCORE_RING) == 0) {
-                    for (int s2 = 0; s2 < d->depth && rc == FR_OK; s2++) rc = fr_worker_sync(wk[s2]);
-                }
+                // bound the host's run-ahead (and keep score buffers unique): a worker is synchronised once per trip round its
+                // ring, the workers of a thread at staggered points so that one of them always has launches queued
+                const int64_t mine = (local - 1) / d->depth + 1;  // pushes this worker has received
+                if (rc == FR_OK && (mine + (int64_t)slot * (FR_SCORE_RING / d->depth)) % FR_SCORE_RING == 0) rc = fr_worker_sync(wk[slot]);
             }
             for (int s = 0; s < d->depth; s++) {
                 int r2 = fr_worker_sync(wk[s]);

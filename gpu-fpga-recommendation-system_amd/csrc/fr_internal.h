@@ -79,7 +79,7 @@ struct FrPipeArgs {
 
 // ---- fused item-tile kernel: launch arguments (see fr_kernels.hip) -----------------------------------
 constexpr int FR_FUSED_MAX_BATCHES = 64;   // kernel-argument array size (64 x 32 B)
-constexpr int FR_FUSED_DEFAULT_BATCHES = 32;
+constexpr int FR_FUSED_DEFAULT_BATCHES = 64;  // 64 batches of 256 = one 64-item workgroup per CU (fr_fused_tile_m2_kernel)
 struct FrFusedBatch {
     const int32_t *idx;
     const float *dense;
@@ -208,6 +208,8 @@ int frk_stage_blocks(int stage, int n_words, int K, int N, int ldm, int nsplit);
 int frk_gather_tr_blocks(int n_words, int ldm);
 bool frk_fused_ok(int K, int H1, int H2, int H3);
 int frk_fused_launch(const FrFusedArgs &a, hipStream_t s);
+bool frk_fused_m2_ok(int K, int H1, int H2, int H3);
+int frk_fused_m2_launch(const FrFusedArgs &a, hipStream_t s);
 bool frk_fused_h_ok(int K, int H1, int H2, int H3);
 int frk_fused_h_items_per_wg();
 int frk_fused_h_launch(const FrFusedArgs &a, hipStream_t s);  // 0 when the transposing gather does not apply

@@ -1879,6 +1879,223 @@ int frk_fused_launch(const FrFusedArgs &a, hipStream_t s) {
 }
 
 // ===================================================================================================
+// fr_fused_tile_m2_kernel<KG>: the fp32 fused item-tile kernel with 64 items (two m tiles) per workgroup.
+// Every weight fragment now feeds two m tiles: half as many weight loads per MFMA (they cost MFMA issue slots, see
+// tools/experiments/mfma_loop) and half as many barriers, ring cold starts and gather phases per item.  Needs the whole CU
+// (158 KiB of LDS: Xq[K/4][65] + ONE R1 buffer; R3 overlays R2) and 64 queued batches of 256 to put one workgroup on every CU,
+// so it is used only when the launch group is 64 (fr_ctx_set_stream_group) -- twice the queueing latency of the 32-item kernel.
+// Same arithmetic as fr_fused_tile_kernel: full-K k-ordered f32 sums, bit-identical scores.
+// ===================================================================================================
+constexpr int FR_M2_LD = 65;
+
+template <int NT, int MT, int R, int CNT>
+__device__ __forceinline__ void ftm_gemm_ct(f32x16 (&acc)[NT][MT], float4 (&ring)[R][NT], const FtW &w, int n0, const uint4 *Bq, int gb0, int g0, int hk,
+                                            int lm) {
+    const unsigned s0 = (unsigned)g0 * w.row2 + (unsigned)n0 * 16u;
+    const uint4 *bl = Bq + (size_t)(2 * gb0 + hk) * FR_M2_LD + lm;
+    uint4 bcur[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) bcur[mt] = bl[32 * mt];
+    // NT == 1: even / odd k partial accumulators exactly as in fr_fused_tile_kernel, so that both kernels return the same bits
+    f32x16 alt[MT];
+    if constexpr (NT == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) alt[mt][i] = 0.0f;
+    }
+#pragma unroll
+    for (int g = 0; g < CNT; g++) {
+        uint4 bnext[MT];
+        const int gn = (g + 1 < CNT) ? g + 1 : g;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) bnext[mt] = bl[(size_t)(2 * gn) * FR_M2_LD + 32 * mt];  // next group's B fragments from LDS
+        const float4(&a4)[NT] = ring[g % R];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const float av = c == 0 ? a4[t].x : c == 1 ? a4[t].y : c == 2 ? a4[t].z : a4[t].w;
+                    const uint32_t bv = c == 0 ? bcur[mt].x : c == 1 ? bcur[mt].y : c == 2 ? bcur[mt].z : bcur[mt].w;
+                    if (NT == 1 && (c & 1)) alt[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, __uint_as_float(bv), alt[mt], 0, 0, 0);
+                    else acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, __uint_as_float(bv), acc[t][mt], 0, 0, 0);
+                }
+        if (g + R < CNT) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) ring[g % R][t] = ft_wload(w, s0 + (unsigned)(g + R) * w.row2, 512 * t);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) bcur[mt] = bnext[mt];
+    }
+    if constexpr (NT == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[0][mt][i] += alt[mt][i];
+    }
+}
+
+__device__ __forceinline__ void ftm_store_tile(uint4 *img, const f32x16 &acc, int n_local, int m_local, int hk, int lm) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint4 v;
+        v.x = __float_as_uint(acc[4 * i + 0]);
+        v.y = __float_as_uint(acc[4 * i + 1]);
+        v.z = __float_as_uint(acc[4 * i + 2]);
+        v.w = __float_as_uint(acc[4 * i + 3]);
+        img[(size_t)((n_local >> 2) + 2 * i + hk) * FR_M2_LD + m_local + lm] = v;  // n = n_local + 8i + 4hk + c
+    }
+}
+
+template <int KG>
+__global__ void __launch_bounds__(512) fr_fused_tile_m2_kernel(const FrFusedArgs a) {
+    extern __shared__ uint4 lds[];
+    constexpr int LD = FR_M2_LD, MT = 2, T2W = 2, TI = 64;
+    constexpr int RA = 12, RB = 8;
+    const int KQ = a.K / 4;
+    uint4 *Xq = lds;                     // [KQ][65]
+    uint4 *R1 = Xq + (size_t)KQ * LD;    // [64][65]: 256 outputs of FC1
+    uint4 *R2 = lds;                     // [H2/4][65], overlays Xq / R1 once they are dead
+    uint4 *R3 = lds;                     // [64][65], overlays R2 once FC3 has read it
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hk = lane >> 5, lm = lane & 31;
+    const int bi = blockIdx.x / a.tiles_per_batch, tile = blockIdx.x - bi * a.tiles_per_batch;
+    const FrFusedBatch &bt = a.b[bi];
+    const int m0 = tile * TI;
+    if (m0 >= bt.batch) return;
+    const FtW W1 = ft_w(a.w1q, a.K, a.H1, hk, lm), W2 = ft_w(a.w2q, a.H1, a.H2, hk, lm), W3 = ft_w(a.w3q, a.H2, a.H3, hk, lm);
+    float4 ring1[RA][1];
+    ft_ring_fill<1, RA, KG>(ring1, W1, 32 * wave, 0);  // FC1 chunk 0's first weight groups: requested before the gather
+
+    {   // ---- gather: lanes along record words, 8 items per thread ----
+        const int wl = tid & 63, ig = tid >> 6;
+        bool bad = false;
+        for (int w0 = 0; w0 < a.n_words; w0 += 64) {
+            const int w = w0 + wl;
+            if (w < a.n_words) {
+                const uint4 d0 = reinterpret_cast<const uint4 *>(a.words)[2 * w];
+                const uint4 d1 = reinterpret_cast<const uint4 *>(a.words)[2 * w + 1];
+                const uint64_t src = ((uint64_t)d0.y << 32) | d0.x;
+                const uint32_t stride = d0.z, idx_col = d0.w, rows = d1.x;
+                const bool is_dense = (idx_col & FR_DESC_DENSE) != 0;
+                const char *base = is_dense ? reinterpret_cast<const char *>(bt.dense) + src : reinterpret_cast<const char *>(src);
+                uint32_t id[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int m = m0 + 8 * ig + i;
+                    id[i] = 0;
+                    if (m < bt.batch) id[i] = is_dense ? (uint32_t)m : (uint32_t)bt.idx[(size_t)m * a.idx_stride + idx_col];
+                    if (!is_dense && id[i] >= rows) {
+                        bad = true;
+                        id[i] = 0;
+                    }
+                }
+                uint4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = *reinterpret_cast<const uint4 *>(base + (uint64_t)id[i] * stride);
+#pragma unroll
+                for (int i = 0; i < 8; i++) Xq[(size_t)w * LD + 8 * ig + i] = (m0 + 8 * ig + i < bt.batch) ? v[i] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        if (bad) atomicOr_system(a.err_flag, 1);
+    }
+    __syncthreads();
+
+    f32x16 acc2[T2W][MT];
+#pragma unroll
+    for (int t = 0; t < T2W; t++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc2[t][mt][i] = 0.0f;
+    const int n_chunks = a.H1 / 256;
+    for (int c = 0; c < n_chunks; c++) {
+        f32x16 acc1[1][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc1[0][mt][i] = 0.0f;
+        ftm_gemm_ct<1, MT, RA, KG>(acc1, ring1, W1, c * 256 + 32 * wave, Xq, 0, 0, hk, lm);
+        float4 ring2[RB][T2W];  // FC2's first weight groups are requested before the R1 store and the barriers
+        ft_ring_fill<T2W, RB, 32>(ring2, W2, 32 * T2W * wave, 32 * c);
+        if (c > 0) __syncthreads();  // single R1 buffer: every wave must be done with the previous chunk's FC2
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) ftm_store_tile(R1, acc1[0][mt], 32 * wave, 32 * mt, hk, lm);
+        __syncthreads();
+        ftm_gemm_ct<T2W, MT, RB, 32>(acc2, ring2, W2, 32 * T2W * wave, R1, 0, 32 * c, hk, lm);
+        const int cn = (c + 1 < n_chunks) ? c + 1 : c;  // the last chunk re-requests its own: branch-free, harmless
+        ft_ring_fill<1, RA, KG>(ring1, W1, cn * 256 + 32 * wave, 0);
+    }
+    float4 ring3[RA][1];
+    ft_ring_fill<1, RA, 32 * T2W>(ring3, W3, 32 * wave, 0);
+    __syncthreads();  // Xq and R1 dead: R2 may overlay them
+#pragma unroll
+    for (int t = 0; t < T2W; t++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) ftm_store_tile(R2, acc2[t][mt], 32 * (T2W * wave + t), 32 * mt, hk, lm);
+    __syncthreads();
+
+    f32x16 acc3[1][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc3[0][mt][i] = 0.0f;
+    ftm_gemm_ct<1, MT, RA, 32 * T2W>(acc3, ring3, W3, 32 * wave, R2, 0, 0, hk, lm);
+    __syncthreads();  // R3 overlays R2: every wave must have finished reading R2
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) ftm_store_tile(R3, acc3[0][mt], 32 * wave, 32 * mt, hk, lm);
+    __syncthreads();
+    {   // score[m] = sum_n wout[n] * R3[n][m]: 64 items x 16 slices of 4 q4 rows (two slices per thread), fixed-order reduction
+        // through LDS -- the same partial sums in the same order as fr_fused_tile_kernel
+        const int il = tid & 63, sg = tid >> 6;
+        const int rows_per = (a.H3 / 4) / 16;
+        float *part = reinterpret_cast<float *>(R3 + (size_t)(a.H3 / 4) * LD);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+            const int sl = 2 * sg + h2;
+            float s = 0.0f;
+            for (int q = sl * rows_per; q < (sl + 1) * rows_per; q++) {
+                const uint4 r = R3[(size_t)q * LD + il];
+                const float4 w4 = reinterpret_cast<const float4 *>(a.wout)[q];
+                s = fmaf(w4.x, __uint_as_float(r.x), s);
+                s = fmaf(w4.y, __uint_as_float(r.y), s);
+                s = fmaf(w4.z, __uint_as_float(r.z), s);
+                s = fmaf(w4.w, __uint_as_float(r.w), s);
+            }
+            part[sl * 64 + il] = s;
+        }
+        __syncthreads();
+        if (tid < 64 && m0 + tid < bt.batch) {
+            float t = part[tid];
+#pragma unroll
+            for (int i = 1; i < 16; i++) t += part[i * 64 + tid];
+            bt.scores[m0 + tid] = t;
+        }
+    }
+}
+
+bool frk_fused_m2_ok(int K, int H1, int H2, int H3) { return K == 352 && H1 % 256 == 0 && H2 == 512 && H3 == 256; }
+
+// a.tiles_per_batch counts 64-item tiles
+int frk_fused_m2_launch(const FrFusedArgs &a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fr_fused_tile_m2_kernel<44>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            FR_FAIL(FR_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_set = true;
+    }
+    const size_t rows1 = (size_t)(a.K / 4) + 64, rows2 = (size_t)(a.H2 / 4), rows3 = 64 + 4;  // R3 + 4 KiB of reduction scratch
+    const size_t rows = rows1 > rows2 ? (rows1 > rows3 ? rows1 : rows3) : (rows2 > rows3 ? rows2 : rows3);
+    fr_fused_tile_m2_kernel<44><<<dim3(a.n_batches * a.tiles_per_batch), dim3(512), rows * FR_M2_LD * 16, s>>>(a);
+    KCHECK();
+    return FR_OK;
+}
+
+// ===================================================================================================
 // fr_fused_tile_h_kernel: the fused item-tile kernel in bf16 (BASELINE configs 2/3: "bf16 MFMA FC, fused concat + first FC").
 // Same phases as fr_fused_tile_kernel, q8 operands (8 bf16 per 16 bytes = one v_mfma_f32_32x32x16_bf16 operand per lane),
 // fp32 accumulation, ONE bf16 rounding per hidden activation.  A bf16 MFMA is 16x cheaper than the f32 one while the weights

@@ -453,8 +453,18 @@ def test_driver_loop(fr, ctxs):
                     continue
                 assert min(np.abs(row - e_).max() for e_ in expect) <= 1e-5 * scale
                 checked += 1
-    assert checked == 403                  # every batch's scores are intact in some worker's ring (403 < 8 x 64)
+    assert checked == 403                  # every batch's scores are intact in some worker's ring (403 pushes < one trip round the rings)
     el = drv.run_resident(256, 0, pool)  # empty run is fine
+    # a long run wraps every ring several times (staggered per-worker syncs): whatever is left in the rings is still a valid result
+    drv.run_resident(256, 6000, pool)
+    full = 0
+    for t in range(4):
+        for sl in range(2):
+            for row in drv.score_ring(t, sl, 256):
+                if row.any():
+                    assert min(np.abs(row - e_).max() for e_ in expect) <= 1e-5 * scale
+                    full += 1
+    assert full >= 8 * 128
     drv.close()
 
 
