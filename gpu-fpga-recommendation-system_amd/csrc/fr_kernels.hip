@@ -1501,9 +1501,10 @@ int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int 
 //   FC2     -> every wave keeps its H2/256 n tiles in accumulators and adds each R1 chunk as it appears
 //   FC3     -> one n tile per wave from R2 in LDS, out layer from R3 in LDS, 32 scores stored
 // Only the weights stream from L2 (each element once per workgroup: 4 MB for Model-A = 38 GB/s per CU at the MFMA rate);
-// the B operand of every MFMA is a conflict-free ds_read_b128.  One launch carries the tiles of up to 16 queued batches
-// of a worker (8 workgroups per batch of 256), so that 4 concurrent streams fill the 256 CUs.
-// Needs max(K/4 + 128, H2/4 + 68) * 33 * 16 B of LDS <= 160 KiB, K % 32 == 0, H1 % 256 == 0, H2 in {256, 512}, H3 == 256.
+// the B operand of every MFMA is a conflict-free ds_read_b128.  One launch carries the tiles of up to 64 queued batches
+// of a worker (8 workgroups per batch of 256): 32 batches put one workgroup on every CU.
+// Needs (K/4 + 64) * 33 * 16 B of LDS <= 160 KiB (one R1 buffer; two when they fit), H1 % 256 == 0, H2 in {256, 512}, H3 == 256,
+// and K % 32 == 0 unless FC1 has a straight-line instantiation (K = 352, 880).
 // ===================================================================================================
 constexpr int FR_FT_LD = 33;  // LDS row stride in 16-byte elements (32 items + 1 pad: conflict-free writes and reads)
 
