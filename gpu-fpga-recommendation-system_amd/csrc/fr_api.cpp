@@ -754,6 +754,7 @@ static int fused_flush(fr_worker *w) {
     a.H3 = c->model.fc[3];
     a.stamps = g_stamp_buffer;
     w->n_pending = 0;
+    w->pending_items = 0;
     if (m2) return frk_fused_m2_launch(a, w->stream);
     return bf16 ? frk_fused_h_launch(a, w->stream) : frk_fused_launch(a, w->stream);
 }
@@ -902,8 +903,11 @@ extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_i
         fb.dense = d_dense;
         fb.scores = d_scores;
         fb.batch = batch;
+        w->pending_items += batch;
         w->in_flight = true;
-        return (w->n_pending >= fused_group()) ? fused_flush(w) : FR_OK;
+        // a launch is due when the group is full or when the queue already covers the chip (256 CUs x 64 items): large batches
+        // need fewer of them per launch
+        return (w->n_pending >= fused_group() || w->pending_items >= 256 * 64) ? fused_flush(w) : FR_OK;
     }
     rc = pipeline_push(w, batch, 0, d_idx, d_dense, d_scores);
     if (rc) return rc;

@@ -174,6 +174,7 @@ struct fr_worker {
     // fused item-tile path: batches queued by fr_worker_push_device until a launch group is full
     FrFusedBatch pending[FR_FUSED_MAX_BATCHES];
     int n_pending = 0;
+    int64_t pending_items = 0;
     float *d_score = nullptr;
     int *h_err = nullptr;  // sticky index-range flag: pinned host word ...
     int *d_err = nullptr;  // ... and its device-side alias
