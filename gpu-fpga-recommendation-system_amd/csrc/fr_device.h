@@ -1,0 +1,55 @@
+// Device-side helpers shared by the kernel translation units of libfleetrec (gfx950 only): vector typedefs of the MFMA
+// builtins, the launch-error macro, bf16 / e4m3 packing, 16-byte buffer loads.
+#pragma once
+#include <cstdlib>
+
+#include <hip/hip_bf16.h>
+#include <hip/hip_runtime.h>
+
+#include "fr_internal.h"
+
+#define KCHECK()                                                                          \
+    do {                                                                                  \
+        hipError_t e_ = hipGetLastError();                                                \
+        if (e_ != hipSuccess) {                                                           \
+            fr_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return FR_ERR_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const __bf16 a = (__bf16)lo, b = (__bf16)hi;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+    return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d, float scale) {
+    const float lim = 448.0f;  // largest finite e4m3fn
+    a = fminf(fmaxf(a * scale, -lim), lim);
+    b = fminf(fmaxf(b * scale, -lim), lim);
+    c = fminf(fmaxf(c * scale, -lim), lim);
+    d = fminf(fmaxf(d * scale, -lim), lim);
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (uint32_t)v;
+}
+__device__ __forceinline__ uint32_t pack_fp8_word(const uint4 &v, float scale) {
+    return pack_fp8x4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w), scale);
+}
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 bload4u(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+// 16 bytes per lane through a buffer resource: per-lane byte offset in a VGPR, wave-uniform byte offset in an SGPR
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}

@@ -1,0 +1,296 @@
+// Table / weight fills, operand re-packs and reductions: one-off or diagnostic kernels around the hot path.
+#include "fr_device.h"
+
+// ---------------------------------------------------------------------------------------------------
+// Procedural contents.  Bit-for-bit the same functions as oracle/fleetrec_oracle.c content_bits().
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+__device__ __forceinline__ uint32_t content_bits(int mode, uint32_t h_seed_uid, uint32_t uid, uint64_t row, uint32_t col) {
+    if (mode == FR_FILL_EVEN_ODD) return (row & 1) ? 0u : 0x3F800000u;
+    if (mode == FR_FILL_TAGGED) {
+        uint32_t source = uid >> 10, cls = (uid >> 8) & 3, tid = uid & 255;
+        return (source << 31) | (cls << 29) | (tid << 21) | ((uint32_t)(row & 0xFFFF) << 5) | (col & 31);
+    }
+    uint32_t h = fmix32(h_seed_uid ^ (uint32_t)row);
+    h = fmix32(h ^ (uint32_t)(row >> 32) ^ (col * 0x27D4EB2Fu));
+    float v = (float)(int32_t)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
+    return __float_as_uint(v);
+}
+
+// one thread per 16-byte word, grid-stride; stores are 16 B/lane fully coalesced
+__global__ void __launch_bounds__(256) fill_table_kernel(uint4 *base, uint64_t n_words, uint32_t words_per_row, int mode,
+                                                          uint32_t seed, uint32_t uid) {
+    const uint32_t h0 = fmix32(seed ^ (uid * 0x9E3779B1u));
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
+        const uint64_t row = w / words_per_row;
+        const uint32_t c0 = (uint32_t)(w - row * words_per_row) * 4;
+        uint4 v;
+        v.x = content_bits(mode, h0, uid, row, c0 + 0);
+        v.y = content_bits(mode, h0, uid, row, c0 + 1);
+        v.z = content_bits(mode, h0, uid, row, c0 + 2);
+        v.w = content_bits(mode, h0, uid, row, c0 + 3);
+        base[w] = v;
+    }
+}
+
+int frk_fill_table(float *base, int64_t rows, int dim, int mode, uint32_t seed, uint32_t uid, hipStream_t s) {
+    const uint64_t n_words = (uint64_t)rows * (uint64_t)(dim / 4);
+    uint64_t blocks = (n_words + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks == 0) return FR_OK;
+    fill_table_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>((uint4 *)base, n_words, (uint32_t)(dim / 4), mode, seed, uid);
+    KCHECK();
+    return FR_OK;
+}
+
+__global__ void __launch_bounds__(256) fill_weights_kernel(float *w, uint64_t n, int mode, uint32_t seed, uint32_t layer, float scale) {
+    const uint32_t h0 = fmix32(seed ^ ((layer + 1u) * 0x9E3779B1u));
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = 1.0f;
+        if (mode == FR_WEIGHTS_UNIFORM) {
+            uint32_t h = fmix32(h0 ^ (uint32_t)i);
+            h = fmix32(h ^ (uint32_t)(i >> 32));
+            v = ((float)(int32_t)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale;
+        }
+        w[i] = v;
+    }
+}
+
+int frk_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t layer, float scale, hipStream_t s) {
+    uint64_t blocks = (count + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) return FR_OK;
+    fill_weights_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(w, count, mode, seed, layer, scale);
+    KCHECK();
+    return FR_OK;
+}
+
+
+
+// Reference weight layout (column-major H x K, W[h + k*H], cuda_server.c:215) -> Wq[k/4][h][k%4]
+__global__ void __launch_bounds__(256) pack_weights_q4_kernel(const float *__restrict__ W, float4 *__restrict__ Wq, int K, int H) {
+    const size_t n = (size_t)(K / 4) * H;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t kq = e / H, h = e - kq * H;
+        Wq[e] = make_float4(W[h + (4 * kq + 0) * H], W[h + (4 * kq + 1) * H], W[h + (4 * kq + 2) * H], W[h + (4 * kq + 3) * H]);
+    }
+}
+
+int frk_pack_weights_q4(const float *W, float *Wq, int K, int H, hipStream_t s) {
+    if (K % 4) FR_FAIL(FR_ERR_INVALID, "pack_weights_q4 needs K %% 4 == 0 (K=%d)", K);
+    size_t n = (size_t)(K / 4) * H;
+    unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    pack_weights_q4_kernel<<<dim3(blocks), dim3(256), 0, s>>>(W, reinterpret_cast<float4 *>(Wq), K, H);
+    KCHECK();
+    return FR_OK;
+}
+
+// item-major records [B][K] -> Xq[K/4][ldm][4]: a transpose of 16-byte elements (only used by the fc_only diagnostic
+// entry point and the BLOCKED layout)
+__global__ void __launch_bounds__(256) transpose_records_kernel(const float4 *__restrict__ X, float4 *__restrict__ Xq, int batch, int KQ, int ldm) {
+    __shared__ float4 tile[16][17];
+    const int q0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16
+    {
+        const int m = m0 + ty, q = q0 + tx;
+        tile[ty][tx] = (m < batch && q < KQ) ? X[(size_t)m * KQ + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    {
+        const int q = q0 + ty, m = m0 + tx;
+        if (q < KQ && m < ldm) Xq[(size_t)q * ldm + m] = tile[tx][ty];
+    }
+}
+
+int frk_transpose_records(const float *X, float *Xq, int batch, int K, int ldm, hipStream_t s) {
+    dim3 grid((K / 4 + 15) / 16, (ldm + 15) / 16);
+    transpose_records_kernel<<<grid, dim3(256), 0, s>>>(reinterpret_cast<const float4 *>(X), reinterpret_cast<float4 *>(Xq), batch, K / 4, ldm);
+    KCHECK();
+    return FR_OK;
+}
+
+// Sharded mode: all-gathered padded slices [G][B][F] (item-major per shard) -> Xq[K/4][ldm][4] for items [item0, item0+n).
+// One launch per shard (slice offsets/lengths are host data); a transpose of 16-byte elements like the one above.
+__global__ void __launch_bounds__(256) transpose_slice_kernel(const float4 *__restrict__ S /* [B][F/4] of this shard */, int FQ, int item0,
+                                                              int n_items, int q_off, int q_len, float4 *__restrict__ Xq, int ldm) {
+    __shared__ float4 tile[16][17];
+    const int q0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    {
+        const int m = m0 + ty, q = q0 + tx;
+        tile[ty][tx] = (m < n_items && q < q_len) ? S[(size_t)(item0 + m) * FQ + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    {
+        const int q = q0 + ty, m = m0 + tx;
+        if (q < q_len && m < ldm) Xq[(size_t)(q_off + q) * ldm + m] = tile[tx][ty];
+    }
+}
+
+int frk_transpose_slices(const float *gathered, int n_shards, int batch_total, int slice_padded, const int *h_offsets, const int *h_lens,
+                         int item0, int n_items, float *Xq, int ldm, hipStream_t s) {
+    if (slice_padded % 4) FR_FAIL(FR_ERR_INVALID, "slice_padded %d must be a multiple of 4", slice_padded);
+    const int FQ = slice_padded / 4;
+    for (int g = 0; g < n_shards; g++) {
+        const int q_len = h_lens[g] / 4;
+        if (q_len == 0) continue;
+        dim3 grid((q_len + 15) / 16, (ldm + 15) / 16);
+        transpose_slice_kernel<<<grid, dim3(256), 0, s>>>(reinterpret_cast<const float4 *>(gathered) + (size_t)g * batch_total * FQ, FQ, item0,
+                                                         n_items, h_offsets[g] / 4, q_len, reinterpret_cast<float4 *>(Xq), ldm);
+    }
+    KCHECK();
+    return FR_OK;
+}
+
+// fp32 master weights (column-major H x K) -> Wh[k/8][h][k%8] bf16 (RNE)
+__global__ void __launch_bounds__(256) pack_weights_q8_bf16_kernel(const float *__restrict__ W, uint4 *__restrict__ Wh, int K, int H) {
+    const size_t n = (size_t)(K / 8) * H;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t ko = e / H, h = e - ko * H;
+        uint4 o;
+        o.x = pack_bf16x2(W[h + (8 * ko + 0) * H], W[h + (8 * ko + 1) * H]);
+        o.y = pack_bf16x2(W[h + (8 * ko + 2) * H], W[h + (8 * ko + 3) * H]);
+        o.z = pack_bf16x2(W[h + (8 * ko + 4) * H], W[h + (8 * ko + 5) * H]);
+        o.w = pack_bf16x2(W[h + (8 * ko + 6) * H], W[h + (8 * ko + 7) * H]);
+        Wh[e] = o;
+    }
+}
+
+int frk_pack_weights_q8_bf16(const float *W, uint16_t *Wh, int K, int H, hipStream_t s) {
+    if (K % 8) FR_FAIL(FR_ERR_INVALID, "pack_weights_q8 needs K %% 8 == 0 (K=%d)", K);
+    size_t n = (size_t)(K / 8) * H;
+    unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    pack_weights_q8_bf16_kernel<<<dim3(blocks ? blocks : 1), dim3(256), 0, s>>>(W, reinterpret_cast<uint4 *>(Wh), K, H);
+    KCHECK();
+    return FR_OK;
+}
+
+// fp32 master weights (column-major H x K) -> Wf[k/16][h][k%16] e4m3(W * scale), K zero-padded to KP (multiple of 64)
+__global__ void __launch_bounds__(256) pack_weights_q16_fp8_kernel(const float *__restrict__ W, uint4 *__restrict__ Wf, int K, int KP, int H, float scale) {
+    const size_t n = (size_t)(KP / 16) * H;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t ke = e / H, h = e - ke * H;
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const size_t k = 16 * ke + 4 * j + c;
+                v[c] = (k < (size_t)K) ? W[h + k * H] : 0.0f;
+            }
+            o[j] = pack_fp8x4(v[0], v[1], v[2], v[3], scale);
+        }
+        Wf[e] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+int frk_pack_weights_q16_fp8(const float *W, void *Wf, int K, int H, int e_w, hipStream_t s) {
+    const int KP = (K + 63) / 64 * 64;
+    size_t n = (size_t)(KP / 16) * H;
+    unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    pack_weights_q16_fp8_kernel<<<dim3(blocks ? blocks : 1), dim3(256), 0, s>>>(W, reinterpret_cast<uint4 *>(Wf), K, KP, H, ldexpf(1.0f, e_w));
+    KCHECK();
+    return FR_OK;
+}
+
+// item-major fp32 records [B][K] -> Xf[KP/16][ldm][16] e4m3(x * scale) (fc_only diagnostic / BLOCKED layout in fp8 mode)
+__global__ void __launch_bounds__(256) records_to_q16_fp8_kernel(const float *__restrict__ X, uint4 *__restrict__ Xf, int batch, int K, int KE, int ldm, float scale) {
+    const size_t n = (size_t)KE * ldm;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int ke = (int)(e / ldm), m = (int)(e - (size_t)ke * ldm);
+        uint32_t o[4] = {0u, 0u, 0u, 0u};
+        if (m < batch) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = 16 * ke + 4 * j;
+                if (k < K) {  // K % 4 == 0
+                    const float4 v = *reinterpret_cast<const float4 *>(X + (size_t)m * K + k);
+                    o[j] = pack_fp8x4(v.x, v.y, v.z, v.w, scale);
+                }
+            }
+        }
+        Xf[e] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+int frk_records_to_q16_fp8(const float *X, void *Xf, int batch, int K, int ldm, int e_x, hipStream_t s) {
+    const int KE = (K + 63) / 64 * 4;
+    size_t n = (size_t)KE * ldm;
+    unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    records_to_q16_fp8_kernel<<<dim3(blocks ? blocks : 1), dim3(256), 0, s>>>(X, reinterpret_cast<uint4 *>(Xf), batch, K, KE, ldm, ldexpf(1.0f, e_x));
+    KCHECK();
+    return FR_OK;
+}
+
+// max |x| and sum x^2 of a float array (fp8 scale selection): out[0] = bits of max |x| (atomicMax on the uint pattern), out[1] = sum
+__global__ void __launch_bounds__(256) stats_kernel(const float *__restrict__ p, size_t n, unsigned *out_max, float *out_sumsq) {
+    float mx = 0.0f, ss = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = p[i];
+        if (v == v) {  // NaN never drives a scale
+            mx = fmaxf(mx, fabsf(v));
+            ss = fmaf(v, v, ss);
+        }
+    }
+    __shared__ float smx[256], sss[256];
+    smx[threadIdx.x] = mx;
+    sss[threadIdx.x] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            smx[threadIdx.x] = fmaxf(smx[threadIdx.x], smx[threadIdx.x + o]);
+            sss[threadIdx.x] += sss[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicMax(out_max, __float_as_uint(smx[0]));
+        atomicAdd(out_sumsq, sss[0]);
+    }
+}
+
+// d_out: 2 words (zeroed here); returns after the launch is enqueued
+int frk_stats(const float *p, size_t n, void *d_out, hipStream_t s) {
+    if (hipMemsetAsync(d_out, 0, 8, s) != hipSuccess) FR_FAIL(FR_ERR_HIP, "hipMemsetAsync failed");
+    unsigned blocks = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    stats_kernel<<<dim3(blocks ? blocks : 1), dim3(256), 0, s>>>(p, n, reinterpret_cast<unsigned *>(d_out), reinterpret_cast<float *>(d_out) + 1);
+    KCHECK();
+    return FR_OK;
+}
+
+// item-major fp32 records [B][K] -> Xh[K/8][ldm][8] bf16 (fc_only diagnostic / BLOCKED layout in bf16 mode)
+__global__ void __launch_bounds__(256) records_to_q8_bf16_kernel(const float *__restrict__ X, uint4 *__restrict__ Xh, int batch, int KO, int ldm) {
+    const size_t n = (size_t)KO * ldm;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t ko = e / ldm, m = e - ko * ldm;
+        uint4 o = make_uint4(0u, 0u, 0u, 0u);
+        if ((int)m < batch) {
+            const float *x = X + m * (size_t)KO * 8 + ko * 8;
+            o.x = pack_bf16x2(x[0], x[1]);
+            o.y = pack_bf16x2(x[2], x[3]);
+            o.z = pack_bf16x2(x[4], x[5]);
+            o.w = pack_bf16x2(x[6], x[7]);
+        }
+        Xh[e] = o;
+    }
+}
+
+int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, hipStream_t s) {
+    size_t n = (size_t)(K / 8) * ldm;
+    unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    records_to_q8_bf16_kernel<<<dim3(blocks ? blocks : 1), dim3(256), 0, s>>>(X, reinterpret_cast<uint4 *>(Xh), batch, K / 8, ldm);
+    KCHECK();
+    return FR_OK;
+}
+

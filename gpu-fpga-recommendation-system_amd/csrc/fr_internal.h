@@ -1,5 +1,5 @@
 // Internal declarations shared by the host-side C-ABI (fr_api.cpp, fr_registry.cpp) and the
-// gfx950 kernels (fr_kernels.hip).  Not installed; the public surface is include/fleetrec.h.
+// gfx950 kernels (fr_fill / fr_gather / fr_pipeline / fr_gemm / fr_fused .hip).  Not installed; the public surface is include/fleetrec.h.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -43,7 +43,7 @@ struct FrWordDesc {
 static_assert(sizeof(FrWordDesc) == 32, "FrWordDesc must be 32 bytes");
 #define FR_DESC_DENSE 0x80000000u
 
-// ---- pipelined FC chain: launch arguments (see fr_kernels.hip) -------------------------------------
+// ---- pipelined FC chain: launch arguments (see fr_pipeline.hip) ------------------------------------
 constexpr int FR_N_STAGES = 5;  // gather | FC1 | FC2 | FC3 | out
 
 struct FrStageArgs {
@@ -77,7 +77,7 @@ struct FrPipeArgs {
     unsigned long long *stamps;
 };
 
-// ---- fused item-tile kernel: launch arguments (see fr_kernels.hip) -----------------------------------
+// ---- fused item-tile kernel: launch arguments (see fr_fused.hip) -------------------------------------
 constexpr int FR_FUSED_MAX_BATCHES = 64;   // kernel-argument array size (64 x 32 B)
 constexpr int FR_FUSED_DEFAULT_BATCHES = 64;  // 64 batches of 256 = one 64-item workgroup per CU (fr_fused_tile_m2_kernel)
 struct FrFusedBatch {
@@ -185,7 +185,7 @@ struct fr_worker {
 // ---- registry (fr_registry.cpp) -------------------------------------------------------------------
 int fr_model_validate(const fr_model_desc *m);
 
-// ---- kernel launchers (fr_kernels.hip) --------------------------------------------------------------
+// ---- kernel launchers (fr_*.hip) -------------------------------------------------------------------
 // uid used by the procedural fills: source*1024 + class*256 + table_id
 static inline uint32_t fr_table_uid(const fr_table_desc &t) {
     return (uint32_t)t.source * 1024u + (uint32_t)t.mem_class * 256u + (uint32_t)t.table_id;
@@ -194,7 +194,7 @@ int frk_fill_table(float *base, int64_t rows, int dim, int mode, uint32_t seed, 
 int frk_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t layer, float scale, hipStream_t s);
 int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense,
                float *out, int batch, int *err_flag, hipStream_t s);
-// feature-major FC chain, stage-pipelined across batches (see fr_kernels.hip)
+// feature-major FC chain, stage-pipelined across batches (see fr_pipeline.hip)
 int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, int precision, hipStream_t s);
 int frk_pack_weights_q8_bf16(const float *W, uint16_t *Wh, int K, int H, hipStream_t s);
 bool frk_fc_lp_gemm_ok(int precision, int K, int N, int ldm);
