@@ -725,7 +725,7 @@ def test_tiled_gemm_model_c_batch_4096(fr, O, ctxs, prec):
         ctx.set_fc_precision(fr.FC_FP32)
 
 
-def _random_model(fr, rng):
+def _random_model(fr, rng, width_mult=32):
     """A random user-defined model: random table dims/rows, an optional dense block in the middle of the record, an
     optional COPY pad, random FC widths.  Exercises the descriptor machinery beyond the three reference models."""
     import ctypes
@@ -771,7 +771,7 @@ def _random_model(fr, rng):
     d.tables = ctypes.cast(tabs, ctypes.POINTER(fr.TableDesc))
     d.segments = ctypes.cast(S, ctypes.POINTER(fr.Segment))
     d.record_len, d.dense_len = pos, dense_len
-    fcw = [pos] + [int(32 * rng.integers(1, 9)) for _ in range(3)] + [1]
+    fcw = [pos] + [int(width_mult * rng.integers(1, 256 // width_mult + 1)) for _ in range(3)] + [1]
     for i, v in enumerate(fcw):
         d.fc[i] = v
     return fr.Model(ctypes.pointer(d), keepalive=(tabs, S, d)), fixed, fcw
@@ -780,7 +780,7 @@ def _random_model(fr, rng):
 @pytest.mark.parametrize("seed", range(6))
 def test_random_custom_models(fr, O, gpu, seed):
     rng = np.random.default_rng(1000 + seed)
-    m, segs, fcw = _random_model(fr, rng)
+    m, segs, fcw = _random_model(fr, rng, 64 if seed % 2 == 0 else 32)   # even seeds: hidden widths the fp8 chain accepts
     ctx = fr.Context(m, device=gpu)
     tabs = m.tables()
     host = [rng.standard_normal((t.rows, t.dim)).astype(np.float32) for t in tabs]
@@ -812,5 +812,19 @@ def test_random_custom_models(fr, O, gpu, seed):
         w2 = fr.Worker(ctx, B)
         assert rel_err(w2.infer(idx, dense), chain_bf16_reference(want, ws, fcw)) <= 5e-3
         w2.close()
+    # ... and in the fp8 chain (hidden widths multiples of 64; the record is zero-padded to 64 k inside the q16 image)
+    if all(v % 64 == 0 for v in fcw[1:4]):
+        ctx.set_fc_precision(fr.FC_FP8)
+        w3 = fr.Worker(ctx, B)
+        w3.calibrate_fp8(idx, dense)
+        act_exp, w_exp = ctx.fp8_exponents()
+        s8 = w3.infer(idx, dense)
+        feat = w3.features(B, fp8=True)
+        assert np.array_equal(feat[:m.record_len], e4m3_encode(want * np.float32(2.0 ** act_exp[0])).T) and not feat[m.record_len:].any()
+        assert rel_err(s8, chain_fp8_reference(want, ws, fcw, act_exp, w_exp)) <= 3e-2
+        w3.close()
+    else:
+        with pytest.raises(fr.FleetRecError):
+            ctx.set_fc_precision(fr.FC_FP8)
     wk.close()
     ctx.close()
