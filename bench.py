@@ -99,6 +99,19 @@ def main_sharded(args):
             wk.fc_from_slices(B, lo, hi - lo, gathered.data_ptr(), scores.data_ptr())
         wk.sync()
 
+    if args.precision != "f32":   # the slices travel as fp32; the FC chain re-packs them to bf16 / e4m3 operands
+        ctx.set_fc_precision(fr.FC_BF16 if args.precision == "bf16" else fr.FC_FP8)
+        if args.precision == "fp8":   # activation exponents from the first batch's gathered slices (same on every rank)
+            wk.gather_only(B, idxs[0], dns[0], local.data_ptr())
+            wk.sync()
+            if a2a:
+                env.all_to_all_slices(local, gathered)
+                torch.cuda.synchronize()
+                wk.calibrate_fp8_slices(B // G, 0, hi - lo, gathered.data_ptr())
+            else:
+                env.all_gather_slices(local, gathered)
+                torch.cuda.synchronize()
+                wk.calibrate_fp8_slices(B, 0, B, gathered.data_ptr())
     for i in range(args.warmup):
         step(i)
     env.barrier(); torch.cuda.synchronize(); ctx.synchronize()
@@ -111,7 +124,7 @@ def main_sharded(args):
         print(json.dumps({
             "metric": "inferences/sec, Model-C batch 4096, tables sharded by table-ID", "value": B * args.steps / dt, "unit": "inferences/s",
             "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "Model-C batch=%d, %d-way table-ID shards (slice F=%d floats), 1 all-gather of [B x F] per step, "
                                    "FC on B/G items per rank" % (B, G, F), "parallelism": "table-sharded x%d" % G, "exchange": args.exchange,
                        "exchange_bytes_in_per_rank_per_step": int(G * (B // G if a2a else B) * F * 4)}}))

@@ -411,7 +411,6 @@ extern "C" int fr_ctx_set_fc_precision(fr_ctx *ctx, int precision) {
     if (precision == FR_FC_FP8) {  // the record is zero-padded to 64 k inside the q16 image; hidden widths are not
         for (int l = 1; l < 4; l++)
             if (ctx->model.fc[l] % 64) FR_FAIL(FR_ERR_INVALID, "fp8 chain needs fc[%d]=%d to be a multiple of 64", l, ctx->model.fc[l]);
-        if (ctx->n_shards > 1) FR_FAIL(FR_ERR_INVALID, "fp8 chain: unsharded contexts only");
     }
     ctx->fc_precision = precision;
     if (precision != FR_FC_FP32 && ctx->weights_set) {
@@ -786,24 +785,41 @@ static int launch_fc(fr_worker *w, int batch, const float *d_records, float *d_s
 
 // Sharded mode, after the all-gather: d_gathered = [n_shards][batch_total][slice_padded] floats (every shard's padded slice,
 // item-major).  Runs the FC chain for items [item0, item0 + n_items) of the batch; d_scores receives n_items floats.
-extern "C" int fr_worker_fc_from_slices(fr_worker *w, int batch_total, int item0, int n_items, const float *d_gathered, float *d_scores) {
+// Shared body of fr_worker_fc_from_slices / fr_worker_calibrate_fp8_slices.  Returns the launch number the batch's stage 1 ran in.
+static int fc_from_slices_impl(fr_worker *w, int batch_total, int item0, int n_items, const float *d_gathered, float *d_scores, uint64_t *stage1_launch) {
     int rc = check_ready(w, n_items, false, true);
     if (rc) return rc;
     fr_ctx *c = w->ctx;
     if (!d_gathered || !d_scores) FR_FAIL(FR_ERR_INVALID, "NULL device pointer");
     if (batch_total < 1 || item0 < 0 || item0 + n_items > batch_total) FR_FAIL(FR_ERR_INVALID, "items [%d,+%d) outside batch %d", item0, n_items, batch_total);
-    if (c->fc_precision != FR_FC_FP32) FR_FAIL(FR_ERR_STATE, "fc_from_slices: fp32 chain only (bf16 slice transport not built yet)");
-    if (w->n_active) FR_FAIL(FR_ERR_STATE, "pipeline busy: call fr_worker_sync first");
+    if (w->n_active || w->n_pending) FR_FAIL(FR_ERR_STATE, "pipeline busy: call fr_worker_sync first");
     FR_HIP(hipSetDevice(c->device));
     if (w->launch_no == 0) w->launch_no = 1;
     const int ldm = round_up(n_items, 32);
     const int par_prev = (int)((w->launch_no - 1) & 1);
-    rc = frk_transpose_slices(d_gathered, c->n_shards, batch_total, c->slice_padded, c->shard_offset.data(), c->shard_len.data(), item0,
-                              n_items, act_set(w, par_prev).x, ldm, w->stream);
+    const int prec = w->calibrating ? (int)FR_FC_FP32 : c->fc_precision;
+    // the slices arrive as fp32: transpose them into q4 elements, then (low-precision chains) re-pack that image; the other
+    // activation set's X region is free scratch while the pipeline is idle
+    float *xq = prec == FR_FC_FP32 ? act_set(w, par_prev).x : act_set(w, par_prev ^ 1).x;
+    rc = frk_transpose_slices(d_gathered, c->n_shards, batch_total, c->slice_padded, c->shard_offset.data(), c->shard_len.data(), item0, n_items, xq, ldm,
+                              w->stream);
     if (rc) return rc;
+    if (prec != FR_FC_FP32) {
+        rc = frk_q4_to_lp(prec, xq, act_set(w, par_prev).x, c->model.fc[0], ldm, c->f8_e_act[0], w->stream);
+        if (rc) return rc;
+    }
+    if (stage1_launch) *stage1_launch = w->launch_no;
     rc = pipeline_push(w, n_items, 1, nullptr, nullptr, d_scores);
     if (rc) return rc;
-    rc = pipeline_flush(w);
+    return pipeline_flush(w);
+}
+
+// Sharded mode, after the all-gather: d_gathered = [n_shards][batch_total][slice_padded] floats (every shard's padded slice,
+// item-major).  Runs the FC chain (in the context's precision) for items [item0, item0 + n_items) of the batch; d_scores
+// receives n_items floats.
+extern "C" int fr_worker_fc_from_slices(fr_worker *w, int batch_total, int item0, int n_items, const float *d_gathered, float *d_scores) {
+    if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
+    int rc = fc_from_slices_impl(w, batch_total, item0, n_items, d_gathered, d_scores, nullptr);
     if (rc) return rc;
     w->in_flight = true;
     return FR_OK;
@@ -961,31 +977,15 @@ extern "C" int fr_ctx_set_fp8_act_exponents(fr_ctx *ctx, const int act_exp[4]) {
     return FR_OK;
 }
 
-extern "C" int fr_worker_calibrate_fp8(fr_worker *w, int batch) {
-    int rc = check_ready(w, batch, true, true);
-    if (rc) return rc;
+// max |.| of X, R1, R2, R3 of the batch whose (virtual) stage 0 ran in launch L0 -> the context's activation exponents
+static int f8_calibrate_finish(fr_worker *w, uint64_t L0, int batch) {
     fr_ctx *c = w->ctx;
-    if (c->n_shards > 1 || c->model.layout != FR_LAYOUT_SEMANTIC) FR_FAIL(FR_ERR_STATE, "fp8 calibration: unsharded SEMANTIC contexts only");
-    if (w->in_flight || w->n_active || w->n_pending) FR_FAIL(FR_ERR_STATE, "worker busy: call fr_worker_sync first");
-    FR_HIP(hipSetDevice(c->device));
-    if (!c->d_stats) FR_HIP(hipMalloc((void **)&c->d_stats, 64));
-    FR_HIP(hipMemcpyAsync(w->d_idx, w->h_idx, (size_t)batch * idx_cols(c) * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
-    if (c->model.dense_len)
-        FR_HIP(hipMemcpyAsync(w->d_dense, w->h_dense, (size_t)batch * c->model.dense_len * sizeof(float), hipMemcpyHostToDevice, w->stream));
-    rc = check_gather_args(w, w->d_idx, w->d_dense);
-    if (rc) return rc;
-    const uint64_t L0 = w->launch_no;
-    w->calibrating = true;  // fp32 stages, no K-split partials: every activation buffer holds whole sums
-    rc = pipeline_push(w, batch, 0, w->d_idx, w->d_dense, w->d_score);
-    if (!rc) rc = pipeline_flush(w);
-    w->calibrating = false;
-    if (rc) return rc;
     const int32_t *fc = c->model.fc;
     const size_t ldm = (size_t)round_up(batch, 32);
     const float *reg[4] = {act_set(w, (int)(L0 & 1)).x, act_set(w, (int)((L0 + 1) & 1)).r1, act_set(w, (int)((L0 + 2) & 1)).r2,
                            act_set(w, (int)((L0 + 3) & 1)).r3};
     for (int l = 0; l < 4; l++) {
-        rc = frk_stats(reg[l], (size_t)fc[l] * ldm, c->d_stats + 2 * l, w->stream);
+        int rc = frk_stats(reg[l], (size_t)fc[l] * ldm, c->d_stats + 2 * l, w->stream);
         if (rc) return rc;
     }
     uint32_t st[8];
@@ -1002,6 +1002,43 @@ extern "C" int fr_worker_calibrate_fp8(fr_worker *w, int batch) {
     }
     c->f8_calibrated = true;
     return FR_OK;
+}
+
+extern "C" int fr_worker_calibrate_fp8(fr_worker *w, int batch) {
+    int rc = check_ready(w, batch, true, true);
+    if (rc) return rc;
+    fr_ctx *c = w->ctx;
+    if (c->n_shards > 1 || c->model.layout != FR_LAYOUT_SEMANTIC) FR_FAIL(FR_ERR_STATE, "fp8 calibration from index rows: unsharded SEMANTIC contexts only (sharded: fr_worker_calibrate_fp8_slices)");
+    if (w->in_flight || w->n_active || w->n_pending) FR_FAIL(FR_ERR_STATE, "worker busy: call fr_worker_sync first");
+    FR_HIP(hipSetDevice(c->device));
+    if (!c->d_stats) FR_HIP(hipMalloc((void **)&c->d_stats, 64));
+    FR_HIP(hipMemcpyAsync(w->d_idx, w->h_idx, (size_t)batch * idx_cols(c) * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
+    if (c->model.dense_len)
+        FR_HIP(hipMemcpyAsync(w->d_dense, w->h_dense, (size_t)batch * c->model.dense_len * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    rc = check_gather_args(w, w->d_idx, w->d_dense);
+    if (rc) return rc;
+    const uint64_t L0 = w->launch_no;
+    w->calibrating = true;  // fp32 stages, no K-split partials: every activation buffer holds whole sums
+    rc = pipeline_push(w, batch, 0, w->d_idx, w->d_dense, w->d_score);
+    if (!rc) rc = pipeline_flush(w);
+    w->calibrating = false;
+    if (rc) return rc;
+    return f8_calibrate_finish(w, L0, batch);
+}
+
+// The sharded form: calibrate on all-gathered slices (same arguments as fr_worker_fc_from_slices, no scores returned).
+extern "C" int fr_worker_calibrate_fp8_slices(fr_worker *w, int batch_total, int item0, int n_items, const float *d_gathered) {
+    if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
+    fr_ctx *c = w->ctx;
+    if (w->in_flight) FR_FAIL(FR_ERR_STATE, "worker busy: call fr_worker_sync first");
+    FR_HIP(hipSetDevice(c->device));
+    if (!c->d_stats) FR_HIP(hipMalloc((void **)&c->d_stats, 64));
+    uint64_t L1 = 0;
+    w->calibrating = true;
+    int rc = fc_from_slices_impl(w, batch_total, item0, n_items, d_gathered, w->d_score, &L1);
+    w->calibrating = false;
+    if (rc) return rc;
+    return f8_calibrate_finish(w, L1 - 1, n_items);
 }
 
 extern "C" int fr_worker_sync(fr_worker *w) {

@@ -152,6 +152,48 @@ int frk_transpose_slices(const float *gathered, int n_shards, int batch_total, i
     return FR_OK;
 }
 
+// q4 fp32 activations Xq[K/4][ldm] -> the low-precision operand image of the same tensor: PREC 1 = q8 bf16 Xh[K/8][ldm],
+// PREC 2 = q16 e4m3 Xf[KP/16][ldm] (x 2^e, saturated, zero rows up to a multiple of 64 k).  Used by the sharded mode's FC entry
+// point, whose slices arrive as fp32.
+template <int PREC>
+__global__ void __launch_bounds__(256) q4_to_lp_kernel(const uint4 *__restrict__ Xq, uint4 *__restrict__ Xo, int KQ, int rows_out, int ldm, float scale) {
+    const size_t n = (size_t)rows_out * ldm;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int ro = (int)(e / ldm), m = (int)(e - (size_t)ro * ldm);
+        constexpr int PER = PREC == 1 ? 2 : 4;  // q4 rows per output element
+        uint4 in[PER];
+#pragma unroll
+        for (int j = 0; j < PER; j++) in[j] = (PER * ro + j < KQ) ? Xq[(size_t)(PER * ro + j) * ldm + m] : make_uint4(0u, 0u, 0u, 0u);
+        uint4 o;
+        if constexpr (PREC == 1) {
+            o.x = pack_bf16x2(__uint_as_float(in[0].x), __uint_as_float(in[0].y));
+            o.y = pack_bf16x2(__uint_as_float(in[0].z), __uint_as_float(in[0].w));
+            o.z = pack_bf16x2(__uint_as_float(in[1].x), __uint_as_float(in[1].y));
+            o.w = pack_bf16x2(__uint_as_float(in[1].z), __uint_as_float(in[1].w));
+        } else {
+            o.x = pack_fp8_word(in[0], scale);
+            o.y = pack_fp8_word(in[1], scale);
+            o.z = pack_fp8_word(in[2], scale);
+            o.w = pack_fp8_word(in[3], scale);
+        }
+        Xo[e] = o;
+    }
+}
+
+int frk_q4_to_lp(int precision, const float *Xq, void *Xo, int K, int ldm, int e_x, hipStream_t s) {
+    const int KQ = K / 4;
+    const int rows_out = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : K / 8;
+    if (precision == FR_FC_BF16 && K % 8) FR_FAIL(FR_ERR_INVALID, "bf16 operands need K %% 8 == 0 (K=%d)", K);
+    const size_t n = (size_t)rows_out * ldm;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    if (precision == FR_FC_FP8)
+        q4_to_lp_kernel<2><<<dim3(blocks ? blocks : 1), dim3(256), 0, s>>>(reinterpret_cast<const uint4 *>(Xq), reinterpret_cast<uint4 *>(Xo), KQ, rows_out, ldm, ldexpf(1.0f, e_x));
+    else
+        q4_to_lp_kernel<1><<<dim3(blocks ? blocks : 1), dim3(256), 0, s>>>(reinterpret_cast<const uint4 *>(Xq), reinterpret_cast<uint4 *>(Xo), KQ, rows_out, ldm, 1.0f);
+    KCHECK();
+    return FR_OK;
+}
+
 // fp32 master weights (column-major H x K) -> Wh[k/8][h][k%8] bf16 (RNE)
 __global__ void __launch_bounds__(256) pack_weights_q8_bf16_kernel(const float *__restrict__ W, uint4 *__restrict__ Wh, int K, int H) {
     const size_t n = (size_t)(K / 8) * H;

@@ -203,6 +203,7 @@ int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, 
 int frk_pack_weights_q16_fp8(const float *W, void *Wf, int K, int H, int e_w, hipStream_t s);
 int frk_records_to_q16_fp8(const float *X, void *Xf, int batch, int K, int ldm, int e_x, hipStream_t s);
 int frk_stats(const float *p, size_t n, void *d_out, hipStream_t s);
+int frk_q4_to_lp(int precision, const float *Xq, void *Xo, int K, int ldm, int e_x, hipStream_t s);
 int frk_stage_blocks_f8_gather(int K, int ldm);
 int frk_pack_weights_q4(const float *W, float *Wq, int K, int H, hipStream_t s);
 int frk_stage_blocks(int stage, int n_words, int K, int N, int ldm, int nsplit);

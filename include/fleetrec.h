@@ -235,6 +235,8 @@ int fr_worker_sync(fr_worker *w);
  * max|.| of X, R1, R2, R3 and set the context's activation exponents so that twice that maximum still fits e4m3's 448.
  * Synchronous. */
 int fr_worker_calibrate_fp8(fr_worker *w, int batch);
+/* The same for table-sharded contexts: calibrate on all-gathered slices (arguments as fr_worker_fc_from_slices). */
+int fr_worker_calibrate_fp8_slices(fr_worker *w, int batch_total, int item0, int n_items, const float *d_gathered);
 
 /* Diagnostic / roofline entry points (same kernels as submit, run alone).
  * gather_only: d_records receives batch*record_len floats in the model's layout (device pointer).

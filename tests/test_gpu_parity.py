@@ -525,9 +525,34 @@ def test_table_sharded_mode_single_device_emulation(fr, O, gpu, which, G):
     c0.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
     w0 = fr.Worker(c0, B)
     assert np.abs(w0.infer(idx, dense) - scores).max() <= 1e-5 * np.abs(ref).max()
-    for c, wk in ctxs_ + [(c0, w0)]:
+    w0.close()
+    # BASELINE configs[4]: the sharded FC in the low-precision chains -- the all-gathered fp32 slices are re-packed to bf16 / e4m3
+    # operands on the way into the chain; fp8 activation exponents come from a calibration on the gathered slices.  Same scores as
+    # the unsharded context in the same precision, bit for bit (same operand images, same per-item arithmetic).
+    for prec, tol32 in ((fr.FC_BF16, 3e-2), (fr.FC_FP8, 0.15)):
+        lp = np.empty(B, np.float32)
+        for r, (c, wk) in enumerate(ctxs_):
+            c.set_fc_precision(prec)
+            lo, hi = dist_mod.item_range(r, G, B)
+            d_g = fr.DeviceBuffer.from_numpy(c, gathered)
+            if prec == fr.FC_FP8:
+                wk.calibrate_fp8_slices(B, 0, B, d_g)
+            d_s = fr.DeviceBuffer(c, max(hi - lo, 1) * 4)
+            wk.fc_from_slices(B, lo, hi - lo, d_g, d_s)
+            wk.sync()
+            lp[lo:hi] = d_s.download(np.float32, hi - lo)
+        assert rel_err(lp, ref) <= tol32, (prec, rel_err(lp, ref))
+        c0.set_fc_precision(prec)
+        w0 = fr.Worker(c0, B)
+        if prec == fr.FC_FP8:
+            w0.calibrate_fp8(idx, dense)
+            assert c0.fp8_exponents() == ctxs_[0][0].fp8_exponents()
+        assert np.array_equal(w0.infer(idx, dense), lp), prec
+        w0.close()
+    for c, wk in ctxs_:
         wk.close()
         c.close()
+    c0.close()
 
 
 def bf16_round(x):
