@@ -222,3 +222,28 @@ def test_model_from_spec_and_placement(fr):
         fr.Model.from_spec(dict(spec, fc=[60, 32, 32]))   # width not a multiple of 32
     with pytest.raises(fr.FleetRecError):
         fr.Model.from_spec(dict(spec, tables=[{"dim": 6, "rows": 10}]))  # dim not a multiple of 4
+
+
+def test_config5_inflated_tables_need_eight_shards(fr):
+    """BASELINE configs[4]: Model-C with its big tables inflated until one GPU's 288 GB no longer holds them, sharded 8 ways by
+    table-ID.  Host-side plan only (no GPU memory is touched): the inflated model exceeds 288 GB, every one of the 8 shards
+    fits, the slices tile the record and are float-balanced."""
+    HBM = 288e9
+    base = fr.Model.builtin(fr.MODEL_C)
+    assert base.table_bytes() < HBM
+    m = base.clone(row_scale=5.0)
+    assert m.table_bytes() > HBM                      # 63.2 GB x 5 = 316 GB: does not fit one MI355X
+    G = 8
+    offs, lens, F = m.shard_plan(G)
+    assert offs[0] == 0 and all(offs[r] + lens[r] == (offs[r + 1] if r + 1 < G else m.record_len) for r in range(G))
+    assert F % 4 == 0 and F >= max(lens) and max(lens) - min(lens) <= 64   # 3968 / 8 = 496 floats per shard, whole segments only
+    tabs = m.tables()
+    per_shard = [0] * G
+    for sg in m.segments():
+        if sg.kind != fr.SEG_TABLE:
+            continue
+        r = next(i for i in range(G) if offs[i] <= sg.rec_offset < offs[i] + lens[i])
+        assert sg.rec_offset + sg.len <= offs[r] + lens[r]                  # a table never straddles two shards
+        per_shard[r] += tabs[sg.src].rows * tabs[sg.src].dim * 4
+    assert sum(per_shard) == m.table_bytes()
+    assert max(per_shard) < HBM                       # every shard fits its GPU
