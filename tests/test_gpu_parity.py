@@ -555,6 +555,36 @@ def test_table_sharded_mode_single_device_emulation(fr, O, gpu, which, G):
     c0.close()
 
 
+@pytest.mark.parametrize("rank", [1, 6])
+def test_config5_inflated_shard_gather(fr, O, gpu, rank):
+    """BASELINE configs[4] on one GPU: one of the 8 table-ID shards of Model-C inflated 5x (316 GB in total, 30-60 GB per shard).
+    Indices run up to 500 M rows and row addresses far beyond 4 GiB inside the shard's arena; the slice must be bit-exact."""
+    G = 8
+    m = fr.Model.builtin(fr.MODEL_C).clone(row_scale=5.0)
+    assert m.table_bytes() > 288e9
+    offs, lens, F = m.shard_plan(G)
+    c = fr.Context(m, device=gpu, shard_rank=rank, n_shards=G)
+    c.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    rng = np.random.default_rng(500 + rank)
+    B = 512
+    rows = m.rows()
+    idx = uniform_idx(rng, rows, B)
+    idx[0], idx[1] = 0, rows - 1                      # first and last row of every table
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+    wk = fr.Worker(c, B)
+    sl = wk.gather_records(idx, dense).reshape(B, F)
+    full = O.OracleModel("C").gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES)
+    assert np.array_equal(sl[:, :lens[rank]], full[:, offs[rank]:offs[rank] + lens[rank]])
+    bad = idx.copy()
+    seg_tables = [sg.src for sg in m.segments() if sg.kind == fr.SEG_TABLE and offs[rank] <= sg.rec_offset < offs[rank] + lens[rank]]
+    bad[7, seg_tables[0]] = rows[seg_tables[0]]       # one past the end of a table this shard owns
+    with pytest.raises(fr.FleetRecError) as e:
+        wk.gather_records(bad, dense)
+    assert e.value.status == fr.FR_ERR_INDEX_RANGE
+    wk.close()
+    c.close()
+
+
 def bf16_round(x):
     """float32 -> nearest-even bf16, returned as float32 (what v_cvt_pk_bf16_f32 does for finite values)."""
     u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
