@@ -331,6 +331,17 @@ def main():
             result["pcie_inclusive"] = {"value": 2000 * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / 2000,
                                         "what": "index rows start in host memory: memcpy to pinned -> H2D -> 5 stage launches -> D2H -> sync per batch, "
                                                 "%d threads x 4 workers" % args.threads}
+            # the same host-resident stream through fr_worker_push_host: pinned staging blocks, one H2D + one fused launch + one D2H
+            # per block of batches, scores delivered to host memory -- still PCIe-inclusive, still never `value`
+            hs = fr.Driver(ctx, args.threads, args.depth, B)
+            hs.run_host(B, 2000, idx_host, streaming=True)
+            n_s = 20000
+            el = hs.run_host(B, n_s, idx_host, streaming=True)
+            hs.close()
+            result["pcie_inclusive_streaming"] = {"value": n_s * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / n_s,
+                                                  "what": "index rows start in host memory, scores end in host memory: blocks of batches staged in pinned "
+                                                          "memory, one H2D + one fused launch + one D2H per block, %d threads x %d workers"
+                                                          % (args.threads, args.depth)}
         # ---- CPU baseline: the oracle ("port": C, OpenMP over items) on this node's host cores, bounded sample (~10 s).
         #      (The 4-GEMM chain through numpy/OpenBLAS sgemm was measured 3x SLOWER than the oracle's own loops at this
         #      batch size on the 128-core host -- threading overhead on 256-row matrices -- so the oracle's chain is used.)

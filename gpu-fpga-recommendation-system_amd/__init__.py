@@ -59,12 +59,12 @@ ABI_SYMBOLS = [
     "fr_model_table_bytes", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
     "fr_ctx_fill_tables", "fr_ctx_upload_table", "fr_ctx_download_table", "fr_ctx_set_weights", "fr_ctx_fill_weights",
     "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_ctx_get_fp8_exponents", "fr_ctx_set_fp8_act_exponents",
-    "fr_worker_calibrate_fp8", "fr_worker_calibrate_fp8_slices", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
+    "fr_worker_calibrate_fp8", "fr_worker_calibrate_fp8_slices", "fr_worker_push_host", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
     "fr_worker_dense_ptr", "fr_worker_score_ptr", "fr_worker_submit", "fr_worker_submit_device", "fr_worker_push_device", "fr_worker_sync",
     "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
     "fr_device_synchronize", "fr_ctx_shard_info", "fr_driver_create", "fr_driver_destroy", "fr_driver_run_resident",
-    "fr_driver_worker", "fr_driver_score_ring", "fr_driver_run_host", "fr_ctx_stream_group", "fr_ctx_set_stream_group", "fr_model_shard_plan", "fr_worker_fc_from_slices",
+    "fr_driver_worker", "fr_driver_score_ring", "fr_driver_run_host", "fr_driver_run_host_streaming", "fr_driver_host_score_ring", "fr_ctx_stream_group", "fr_ctx_set_stream_group", "fr_model_shard_plan", "fr_worker_fc_from_slices",
 ]
 
 
@@ -93,6 +93,7 @@ def lib():
         "fr_ctx_set_weights": (i32, [vp, i32, vp, sz]), "fr_ctx_fill_weights": (i32, [vp, i32, u32]),
         "fr_ctx_get_weights": (i32, [vp, i32, vp, sz]), "fr_ctx_set_fc_precision": (i32, [vp, i32]),
         "fr_ctx_get_fp8_exponents": (i32, [vp, vp, vp]), "fr_ctx_set_fp8_act_exponents": (i32, [vp, vp]),
+        "fr_worker_push_host": (i32, [vp, i32, vp, vp, vp]),
         "fr_worker_calibrate_fp8": (i32, [vp, i32]), "fr_worker_calibrate_fp8_slices": (i32, [vp, i32, i32, i32, vp]),
         "fr_worker_create": (i32, [vp, i32, ctypes.POINTER(vp)]), "fr_worker_destroy": (None, [vp]),
         "fr_worker_idx_ptr": (pi, [vp]), "fr_worker_dense_ptr": (pf, [vp]), "fr_worker_score_ptr": (pf, [vp]),
@@ -110,6 +111,8 @@ def lib():
         "fr_driver_worker": (vp, [vp, i32, i32]), "fr_driver_score_ring": (vp, [vp, i32, i32, ctypes.POINTER(ctypes.c_int)]),
         "fr_ctx_stream_group": (i32, [vp]), "fr_ctx_set_stream_group": (i32, [vp, i32]),
         "fr_driver_run_host": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
+        "fr_driver_run_host_streaming": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
+        "fr_driver_host_score_ring": (vp, [vp, i32, i32, ctypes.POINTER(ctypes.c_int)]),
         "fr_model_shard_plan": (i32, [ctypes.POINTER(ModelDesc), i32, pi, pi, ctypes.POINTER(ctypes.c_int)]),
         "fr_worker_fc_from_slices": (i32, [vp, i32, i32, i32, vp, vp]),
     }
@@ -455,6 +458,16 @@ class Worker:
     def submit_device(self, batch, d_idx, d_dense, d_scores):
         _check(lib().fr_worker_submit_device(self._h, batch, self._ptr(d_idx), self._ptr(d_dense), self._ptr(d_scores)))
 
+    def push_host(self, idx, dense, scores_out):
+        """Host-fed streaming push: idx int32 [B][idx_cols] (+ dense float32 [B][dense_len]); scores_out: a float32 numpy array of
+        at least B elements that stays alive until sync() -- it receives the scores."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        B = idx.shape[0]
+        d = None if dense is None else np.ascontiguousarray(dense, dtype=np.float32)
+        assert scores_out.dtype == np.float32 and scores_out.flags["C_CONTIGUOUS"] and scores_out.size >= B
+        _check(lib().fr_worker_push_host(self._h, B, idx.ctypes.data_as(ctypes.c_void_p), None if d is None else d.ctypes.data_as(ctypes.c_void_p),
+                                         scores_out.ctypes.data_as(ctypes.c_void_p)))
+
     def push_device(self, batch, d_idx, d_dense, d_scores):
         _check(lib().fr_worker_push_device(self._h, batch, self._ptr(d_idx), self._ptr(d_dense), self._ptr(d_scores)))
 
@@ -556,8 +569,9 @@ class Driver:
         _check(lib().fr_memcpy_d2h(self.ctx._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p), out.nbytes))
         return out
 
-    def run_host(self, batch, total_batches, idx_pool_np, dense_pool_np=None):
-        """idx_pool_np / dense_pool_np: lists of C-contiguous numpy arrays in host memory.  -> elapsed seconds (PCIe-inclusive)."""
+    def run_host(self, batch, total_batches, idx_pool_np, dense_pool_np=None, streaming=False):
+        """idx_pool_np / dense_pool_np: lists of C-contiguous numpy arrays in host memory.  -> elapsed seconds (PCIe-inclusive).
+        streaming=False: submit + sync per batch (the reference's sequence); True: fr_worker_push_host blocks."""
         n = len(idx_pool_np)
         keep = [np.ascontiguousarray(a, dtype=np.int32) for a in idx_pool_np]
         ip = (ctypes.c_void_p * n)(*[a.ctypes.data for a in keep])
@@ -566,8 +580,14 @@ class Driver:
             keepd = [np.ascontiguousarray(a, dtype=np.float32) for a in dense_pool_np]
             dp = (ctypes.c_void_p * n)(*[a.ctypes.data for a in keepd])
         el = ctypes.c_double()
-        _check(lib().fr_driver_run_host(self._h, batch, total_batches, ip, dp, n, ctypes.byref(el)))
+        _check((lib().fr_driver_run_host_streaming if streaming else lib().fr_driver_run_host)(self._h, batch, total_batches, ip, dp, n, ctypes.byref(el)))
         return el.value
+
+    def host_score_ring(self, thread, slot, max_batch):
+        """-> float32 [ring_len][max_batch] (host memory): scores of the last ring_len batches run_host(streaming=True) gave worker (thread, slot)."""
+        n = ctypes.c_int()
+        p = lib().fr_driver_host_score_ring(self._h, thread, slot, ctypes.byref(n))
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_float)), shape=(n.value, max_batch)).copy()
 
     def close(self):
         if self._h:

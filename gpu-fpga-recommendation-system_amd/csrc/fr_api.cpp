@@ -435,6 +435,14 @@ extern "C" void fr_worker_destroy(fr_worker *w) {
     void *dev[] = {w->d_idx, w->d_dense, w->d_records, w->d_act[0], w->d_act[1], w->d_score};
     for (void *p : dev)
         if (p) (void)hipFree(p);
+    if (w->hr.h_idx) (void)hipHostFree(w->hr.h_idx);
+    if (w->hr.h_dense) (void)hipHostFree(w->hr.h_dense);
+    if (w->hr.h_sc) (void)hipHostFree(w->hr.h_sc);
+    void *hdev[] = {w->hr.d_idx, w->hr.d_dense, w->hr.d_sc};
+    for (void *p : hdev)
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : w->hr.ev)
+        if (e) (void)hipEventDestroy(e);
     if (w->ev_start) (void)hipEventDestroy(w->ev_start);
     if (w->ev_stop) (void)hipEventDestroy(w->ev_stop);
     if (w->stream) (void)hipStreamDestroy(w->stream);
@@ -961,6 +969,114 @@ extern "C" int fr_worker_submit(fr_worker *w, int batch) {
     return FR_OK;
 }
 
+// ---- host-fed streaming ------------------------------------------------------------------------------
+// The reference's loop reads a batch from the socket into pinned memory and enqueues H2D + GEMMs + D2H for it
+// (cuda_server.c:425-495).  Here batches that arrive in host memory are staged in pinned blocks of `g` batches; a full block
+// travels as one H2D copy, one fused launch and one D2H copy, and FR_HOST_BLOCKS blocks rotate so that copies, kernels and the
+// host's staging of the next block overlap.
+static int host_ring_init(fr_worker *w) {
+    fr_worker::HostRing &r = w->hr;
+    if (r.g) return FR_OK;
+    fr_ctx *c = w->ctx;
+    int g = 16384 / (w->max_batch > 0 ? w->max_batch : 1);  // the queue launches once it holds 256 x 64 items
+    if (g < 1) g = 1;
+    if (g > fused_group()) g = fused_group();
+    r.idx_slot = (size_t)w->max_batch * idx_cols(c);
+    r.dense_slot = (size_t)w->max_batch * c->model.dense_len;
+    r.score_slot = (size_t)w->max_batch;
+    const size_t slots = (size_t)g * FR_HOST_BLOCKS;
+    FR_HIP(hipHostMalloc((void **)&r.h_idx, slots * r.idx_slot * sizeof(int32_t), hipHostMallocDefault));
+    FR_HIP(hipMalloc((void **)&r.d_idx, slots * r.idx_slot * sizeof(int32_t)));
+    if (r.dense_slot) {
+        FR_HIP(hipHostMalloc((void **)&r.h_dense, slots * r.dense_slot * sizeof(float), hipHostMallocDefault));
+        FR_HIP(hipMalloc((void **)&r.d_dense, slots * r.dense_slot * sizeof(float)));
+    }
+    FR_HIP(hipHostMalloc((void **)&r.h_sc, slots * r.score_slot * sizeof(float), hipHostMallocDefault));
+    FR_HIP(hipMalloc((void **)&r.d_sc, slots * r.score_slot * sizeof(float)));
+    for (int b = 0; b < FR_HOST_BLOCKS; b++) FR_HIP(hipEventCreateWithFlags(&r.ev[b], hipEventDisableTiming));
+    r.g = g;
+    return FR_OK;
+}
+
+// scores of a finished block -> the callers' buffers
+static int host_block_deliver(fr_worker *w, int b) {
+    fr_worker::HostRing &r = w->hr;
+    if (!r.inflight[b]) return FR_OK;
+    FR_HIP(hipEventSynchronize(r.ev[b]));
+    for (int i = 0; i < r.count[b]; i++)
+        memcpy(r.dst[b][i], r.h_sc + ((size_t)b * r.g + i) * r.score_slot, (size_t)r.bsz[b][i] * sizeof(float));
+    r.inflight[b] = false;
+    r.count[b] = 0;
+    return FR_OK;
+}
+
+// the block being filled leaves: H2D, fused launch, D2H, event
+static int host_block_launch(fr_worker *w) {
+    fr_worker::HostRing &r = w->hr;
+    const int b = r.cur, n = r.count[b];
+    if (n == 0) return FR_OK;
+    fr_ctx *c = w->ctx;
+    int rc = fused_flush(w);  // batches queued by fr_worker_push_device go first
+    if (rc) return rc;
+    const size_t s0 = (size_t)b * r.g;
+    FR_HIP(hipMemcpyAsync(r.d_idx + s0 * r.idx_slot, r.h_idx + s0 * r.idx_slot, (size_t)n * r.idx_slot * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
+    if (r.dense_slot)
+        FR_HIP(hipMemcpyAsync(r.d_dense + s0 * r.dense_slot, r.h_dense + s0 * r.dense_slot, (size_t)n * r.dense_slot * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    for (int i = 0; i < n; i++) {
+        FrFusedBatch &fb = w->pending[w->n_pending++];
+        fb.idx = r.d_idx + (s0 + i) * r.idx_slot;
+        fb.dense = r.dense_slot ? r.d_dense + (s0 + i) * r.dense_slot : nullptr;
+        fb.scores = r.d_sc + (s0 + i) * r.score_slot;
+        fb.batch = r.bsz[b][i];
+    }
+    rc = fused_flush(w);
+    if (rc) return rc;
+    FR_HIP(hipMemcpyAsync(r.h_sc + s0 * r.score_slot, r.d_sc + s0 * r.score_slot, (size_t)n * r.score_slot * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+    FR_HIP(hipEventRecord(r.ev[b], w->stream));
+    r.inflight[b] = true;
+    r.cur = (b + 1) % FR_HOST_BLOCKS;
+    (void)c;
+    return FR_OK;
+}
+
+extern "C" int fr_worker_push_host(fr_worker *w, int batch, const int32_t *h_idx, const float *h_dense, float *h_scores) {
+    int rc = check_ready(w, batch, true, true);
+    if (rc) return rc;
+    fr_ctx *c = w->ctx;
+    if (!h_idx || !h_scores) FR_FAIL(FR_ERR_INVALID, "NULL host pointer");
+    if (c->model.dense_len && !h_dense) FR_FAIL(FR_ERR_INVALID, "model has dense features but h_dense is NULL");
+    if (!fused_eligible(c)) FR_FAIL(FR_ERR_STATE, "fr_worker_push_host needs a model that streams through the fused item-tile kernel (use fr_worker_submit)");
+    FR_HIP(hipSetDevice(c->device));
+    rc = host_ring_init(w);
+    if (rc) return rc;
+    fr_worker::HostRing &r = w->hr;
+    const int b = r.cur;
+    if (r.inflight[b]) {  // the oldest block: wait for its scores and hand them out before its staging memory is reused
+        rc = host_block_deliver(w, b);
+        if (rc) return rc;
+    }
+    const int i = r.count[b];
+    memcpy(r.h_idx + ((size_t)b * r.g + i) * r.idx_slot, h_idx, (size_t)batch * idx_cols(c) * sizeof(int32_t));
+    if (r.dense_slot) memcpy(r.h_dense + ((size_t)b * r.g + i) * r.dense_slot, h_dense, (size_t)batch * c->model.dense_len * sizeof(float));
+    r.dst[b][i] = h_scores;
+    r.bsz[b][i] = batch;
+    r.count[b] = i + 1;
+    w->in_flight = true;
+    return (r.count[b] >= r.g) ? host_block_launch(w) : FR_OK;
+}
+
+static int host_ring_drain(fr_worker *w) {
+    fr_worker::HostRing &r = w->hr;
+    if (!r.g) return FR_OK;
+    int rc = host_block_launch(w);  // partial block
+    if (rc) return rc;
+    for (int k = 0; k < FR_HOST_BLOCKS; k++) {
+        rc = host_block_deliver(w, (r.cur + k) % FR_HOST_BLOCKS);  // oldest first
+        if (rc) return rc;
+    }
+    return FR_OK;
+}
+
 extern "C" int fr_ctx_get_fp8_exponents(const fr_ctx *ctx, int act_exp[4], int w_exp[3]) {
     if (!ctx || !act_exp || !w_exp) FR_FAIL(FR_ERR_INVALID, "NULL argument");
     for (int l = 0; l < 4; l++) act_exp[l] = ctx->f8_e_act[l];
@@ -1044,7 +1160,9 @@ extern "C" int fr_worker_calibrate_fp8_slices(fr_worker *w, int batch_total, int
 extern "C" int fr_worker_sync(fr_worker *w) {
     if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
     FR_HIP(hipSetDevice(w->ctx->device));
-    int frc = fused_flush(w);  // launch batches still queued by fr_worker_push_device
+    int frc = host_ring_drain(w);  // host-fed blocks: launch the partial one, deliver every block's scores
+    if (frc) return frc;
+    frc = fused_flush(w);  // launch batches still queued by fr_worker_push_device
     if (frc) return frc;
     frc = pipeline_flush(w);  // drain the stage pipeline
     if (frc) return frc;

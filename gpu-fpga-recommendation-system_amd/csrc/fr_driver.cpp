@@ -23,6 +23,7 @@ struct fr_driver {
     fr_ctx *ctx = nullptr;
     int n_threads = 0, depth = 0, max_batch = 0;
     std::vector<fr_worker *> workers;  // [n_threads * depth]
+    std::vector<std::vector<float>> host_rings;  // per worker: FR_SCORE_RING x max_batch floats in host memory (run_host_streaming)
     std::vector<float *> score_rings;  // per worker: FR_SCORE_RING x max_batch floats; the loop syncs a worker every
                                        // FR_SCORE_RING pushes, so no two batches in flight ever share a score buffer
 };
@@ -177,6 +178,68 @@ extern "C" int fr_driver_run_host(fr_driver *d, int batch, int64_t total_batches
     for (int t = 0; t < d->n_threads; t++)
         if (status[t]) FR_FAIL(status[t], "driver thread %d: %s", t, messages[t].c_str());
     return FR_OK;
+}
+
+// Host-fed STREAMING form: the same host-resident request stream, but batches are handed to fr_worker_push_host -- staged in
+// pinned blocks and moved as one H2D copy + one fused launch + one D2H copy per block, no per-batch synchronisation.  Scores land
+// in per-worker host rings (fr_driver_host_score_ring).  Models that do not stream through the fused kernel are refused.
+extern "C" int fr_driver_run_host_streaming(fr_driver *d, int batch, int64_t total_batches, const int32_t *const *h_idx_pool,
+                                            const float *const *h_dense_pool, int n_pool, double *elapsed_s) {
+    if (!d || !h_idx_pool || n_pool < 1 || !elapsed_s) FR_FAIL(FR_ERR_INVALID, "bad argument");
+    if (batch < 1 || batch > d->max_batch || total_batches < 0) FR_FAIL(FR_ERR_INVALID, "batch %d / total %lld out of range", batch, (long long)total_batches);
+    if (d->ctx->model.dense_len && !h_dense_pool) FR_FAIL(FR_ERR_INVALID, "model has dense features but h_dense_pool is NULL");
+    if (d->host_rings.empty()) {
+        d->host_rings.resize(d->workers.size());
+        for (auto &r : d->host_rings) r.assign((size_t)FR_SCORE_RING * d->max_batch, 0.0f);
+    }
+    std::mutex mtx;
+    int64_t global_batch_count = 0;
+    std::vector<int> status(d->n_threads, FR_OK);
+    std::vector<std::string> messages(d->n_threads);
+    std::vector<std::thread> threads;
+    FR_HIP(hipSetDevice(d->ctx->device));
+    FR_HIP(hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < d->n_threads; t++) {
+        threads.emplace_back([&, t]() {
+            fr_worker **wk = &d->workers[(size_t)t * d->depth];
+            int64_t local = 0;
+            int rc = FR_OK;
+            while (rc == FR_OK) {
+                int64_t id;
+                {
+                    std::lock_guard<std::mutex> g(mtx);
+                    if (global_batch_count >= total_batches) break;
+                    id = global_batch_count++;
+                }
+                const int slot = (int)(local % d->depth);
+                // at most 4 blocks x 64 batches of a worker are in flight, and a block is delivered before its staging is refilled:
+                // a ring of FR_SCORE_RING = 256 destinations per worker is never overwritten before delivery
+                float *scores = d->host_rings[(size_t)t * d->depth + slot].data() + (size_t)((local / d->depth) % FR_SCORE_RING) * d->max_batch;
+                local++;
+                const int p = (int)(id % n_pool);
+                rc = fr_worker_push_host(wk[slot], batch, h_idx_pool[p], h_dense_pool ? h_dense_pool[p] : nullptr, scores);
+            }
+            for (int s = 0; s < d->depth; s++) {
+                int r2 = fr_worker_sync(wk[s]);
+                if (rc == FR_OK) rc = r2;
+            }
+            status[t] = rc;
+            if (rc) messages[t] = fr_last_error();
+        });
+    }
+    for (auto &th : threads) th.join();
+    FR_HIP(hipDeviceSynchronize());
+    *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int t = 0; t < d->n_threads; t++)
+        if (status[t]) FR_FAIL(status[t], "driver thread %d: %s", t, messages[t].c_str());
+    return FR_OK;
+}
+
+extern "C" const float *fr_driver_host_score_ring(fr_driver *d, int thread, int slot, int *ring_len) {
+    if (!d || thread < 0 || thread >= d->n_threads || slot < 0 || slot >= d->depth || d->host_rings.empty()) return nullptr;
+    if (ring_len) *ring_len = FR_SCORE_RING;
+    return d->host_rings[(size_t)thread * d->depth + slot].data();
 }
 
 extern "C" const float *fr_driver_score_ring(fr_driver *d, int thread, int slot, int *ring_len) {

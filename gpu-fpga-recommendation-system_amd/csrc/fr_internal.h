@@ -79,7 +79,8 @@ struct FrPipeArgs {
 
 // ---- fused item-tile kernel: launch arguments (see fr_fused.hip) -------------------------------------
 constexpr int FR_FUSED_MAX_BATCHES = 64;   // kernel-argument array size (64 x 32 B)
-constexpr int FR_FUSED_DEFAULT_BATCHES = 64;  // 64 batches of 256 = one 64-item workgroup per CU (fr_fused_tile_m2_kernel)
+constexpr int FR_FUSED_DEFAULT_BATCHES = 64;
+constexpr int FR_HOST_BLOCKS = 4;  // 64 batches of 256 = one 64-item workgroup per CU (fr_fused_tile_m2_kernel)
 struct FrFusedBatch {
     const int32_t *idx;
     const float *dense;
@@ -176,6 +177,20 @@ struct fr_worker {
     int n_pending = 0;
     int64_t pending_items = 0;
     float *d_score = nullptr;
+    // host-fed streaming (fr_worker_push_host): FR_HOST_BLOCKS staging blocks of `g` batches each; a block is filled by CPU copies
+    // into pinned memory, then moves as ONE H2D copy + ONE fused launch + ONE D2H copy; its event says when the scores are home
+    struct HostRing {
+        int g = 0;                 // batches per block (fixed when the ring is created)
+        size_t idx_slot = 0, dense_slot = 0, score_slot = 0;  // elements per batch slot
+        int32_t *h_idx = nullptr, *d_idx = nullptr;
+        float *h_dense = nullptr, *d_dense = nullptr, *h_sc = nullptr, *d_sc = nullptr;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool inflight[4] = {false, false, false, false};
+        int count[4] = {0, 0, 0, 0};          // batches in the block
+        float *dst[4][FR_FUSED_MAX_BATCHES];  // where each batch's scores go
+        int bsz[4][FR_FUSED_MAX_BATCHES];
+        int cur = 0;               // block being filled
+    } hr;
     int *h_err = nullptr;  // sticky index-range flag: pinned host word ...
     int *d_err = nullptr;  // ... and its device-side alias
     bool in_flight = false;

@@ -35,6 +35,7 @@ struct Options {
     long total = 1024;
     int tables = FR_FILL_EVEN_ODD, weights = FR_WEIGHTS_ONES;
     bool per_item = false, reply = false;
+    bool stream = false;   // throughput mode: fr_worker_push_host (blocks of batches per launch) instead of submit + sync per batch
     bool latency = false;  // latency-measurement mode: per-batch recv -> enqueued -> scores times (measure_network_cuda_cp_latency_*/cuda_server.c)
     long row_cap = 0;
 };
@@ -107,7 +108,39 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
     if (t->status == 0) {
         setsockopt(sock, IPPROTO_TCP, TCP_NODELAY, &opt, sizeof(opt));
         printf("Successfully built connection on port %d.\n", t->port);
-        while (true) {
+        // --stream: the socket is read into ordinary host memory and every batch is handed to fr_worker_push_host; scores come
+        // back in blocks, the last batch's are available after the final sync
+        std::vector<float> stream_scores(o.stream ? (size_t)256 * o.batch : 0);
+        std::vector<int32_t> stream_idx(o.stream ? idx_bytes / sizeof(int32_t) : 0);
+        std::vector<float> stream_dense(o.stream ? dense_bytes / sizeof(float) : 0);
+        while (o.stream) {
+            {
+                std::lock_guard<std::mutex> g(g_mtx);
+                if (g_global_batch_count >= o.total) break;
+                g_global_batch_count++;
+            }
+            if (!read_exact(sock, stream_idx.data(), idx_bytes) || (dense_bytes && !read_exact(sock, stream_dense.data(), dense_bytes))) {
+                t->status = -4;
+                t->error = "Receiving data UNSUCCESSFUL (peer closed before the batch was complete)";
+                break;
+            }
+            if (fr_worker_push_host(wk, o.batch, stream_idx.data(), dense_bytes ? stream_dense.data() : nullptr,
+                                    stream_scores.data() + (size_t)(t->batches % 256) * o.batch) != FR_OK) {
+                t->status = -5;
+                t->error = fr_last_error();
+                break;
+            }
+            t->batches++;
+        }
+        if (o.stream) {
+            if (t->status == 0 && fr_worker_sync(wk) != FR_OK) {
+                t->status = -6;
+                t->error = fr_last_error();
+            }
+            if (t->batches > 0)
+                for (int j = 0; j < 5 && j < o.batch; j++) t->first_scores.push_back(stream_scores[(size_t)((t->batches - 1) % 256) * o.batch + j]);
+        }
+        while (!o.stream) {
             {
                 std::lock_guard<std::mutex> g(g_mtx);
                 if (g_global_batch_count >= o.total) break;
@@ -139,8 +172,10 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
             }
             t->batches++;
         }
-        const float *sc = fr_worker_score_ptr(wk);
-        for (int j = 0; j < 5 && j < o.batch; j++) t->first_scores.push_back(sc[j]);  // cuda_server.c:499-502
+        if (!o.stream) {
+            const float *sc = fr_worker_score_ptr(wk);
+            for (int j = 0; j < 5 && j < o.batch; j++) t->first_scores.push_back(sc[j]);  // cuda_server.c:499-502
+        }
     }
     if (sock >= 0) close(sock);
     if (server_fd >= 0) close(server_fd);
@@ -163,6 +198,7 @@ int main(int argc, char **argv) {
         else if (a == "--per-item") o.per_item = true;
         else if (a == "--reply") o.reply = true;
         else if (a == "--latency") o.latency = true;
+        else if (a == "--stream") o.stream = true;
         else if (a == "--row-cap") o.row_cap = atol(next());
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }

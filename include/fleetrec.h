@@ -230,6 +230,11 @@ int fr_ctx_stream_group(const fr_ctx *ctx);
  * process-wide).  Smaller groups cut the queueing latency of a pushed batch and leave CUs to other streams. */
 int fr_ctx_set_stream_group(fr_ctx *ctx, int batches_per_launch);
 /* Drains and waits for everything enqueued on the worker; returns FR_ERR_INDEX_RANGE if any index was out of range. */
+/* Host-fed streaming: like fr_worker_push_device for a batch that sits in (any) host memory.  The rows are copied into the worker's
+ * pinned staging before the call returns (h_idx / h_dense may be reused at once); batches travel in groups as one H2D copy + one
+ * launch + one D2H copy; h_scores[0..batch) is valid after fr_worker_sync, or earlier once 4 x group later pushes have been made.
+ * The streaming counterpart of the per-batch recv -> H2D -> GEMMs -> D2H sequence of cuda_server.c:425-495. */
+int fr_worker_push_host(fr_worker *w, int batch, const int32_t *h_idx, const float *h_dense, float *h_scores);
 int fr_worker_sync(fr_worker *w);
 /* fp8 chain: run `batch` items (the worker's pinned idx/dense buffers, as for fr_worker_submit) through the fp32 chain, take
  * max|.| of X, R1, R2, R3 and set the context's activation exponents so that twice that maximum still fits e4m3's 448.
@@ -276,6 +281,12 @@ int fr_driver_run_resident(fr_driver *d, int batch, int64_t total_batches, const
  * transfers (cuda_server.c:425-495).  Returns wall time. */
 int fr_driver_run_host(fr_driver *d, int batch, int64_t total_batches, const int32_t *const *h_idx_pool,
                        const float *const *h_dense_pool, int n_pool, double *elapsed_s);
+/* Host-buffer STREAMING form: the same host-resident request stream handed to fr_worker_push_host (pinned staging blocks, one
+ * H2D + one fused launch + one D2H per block, no per-batch synchronisation).  Only for models that stream through the fused
+ * item-tile kernel.  Scores land in per-worker host rings (fr_driver_host_score_ring, same indexing as fr_driver_score_ring). */
+int fr_driver_run_host_streaming(fr_driver *d, int batch, int64_t total_batches, const int32_t *const *h_idx_pool,
+                                 const float *const *h_dense_pool, int n_pool, double *elapsed_s);
+const float *fr_driver_host_score_ring(fr_driver *d, int thread, int slot, int *ring_len);
 fr_worker *fr_driver_worker(fr_driver *d, int thread, int slot);
 /* Device pointer of the score ring fr_driver_run_resident writes for worker (thread, slot): *ring_len buffers of max_batch
  * floats; the k-th batch pushed to that worker lands in buffer k % *ring_len. */

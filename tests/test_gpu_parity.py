@@ -468,6 +468,63 @@ def test_driver_loop(fr, ctxs):
     drv.close()
 
 
+def test_host_fed_streaming(fr, ctxs):
+    """fr_worker_push_host / fr_driver_run_host_streaming: batches that sit in host memory are staged in pinned blocks and travel as
+    one H2D + one fused launch + one D2H per block; scores equal the device-resident streaming path bit for bit, ragged batches,
+    partial blocks, several trips round the 4 staging blocks."""
+    m, ctx = ctxs(fr.MODEL_A)
+    rng = np.random.default_rng(77)
+    sizes = [256, 1, 200, 256, 37] * 70      # 350 pushes: > 4 blocks of 64
+    pool = [uniform_idx(rng, m.rows(), 256) for _ in range(5)]
+    wk = fr.Worker(ctx, 256)
+    d_pool = [fr.DeviceBuffer.from_numpy(ctx, p_) for p_ in pool]
+    d_sc = [fr.DeviceBuffer(ctx, 256 * 4) for _ in range(5)]
+    for j in range(5):
+        wk.push_device(sizes[j], d_pool[j], None, d_sc[j])
+    wk.sync()
+    expect = [d_sc[j].download(np.float32, 256)[:sizes[j]] for j in range(5)]
+    outs = [np.full(256, np.nan, np.float32) for _ in sizes]
+    for j, b in enumerate(sizes):
+        wk.push_host(pool[j % 5][:b], None, outs[j])
+        if j == 100:
+            wk.sync()                         # a sync in the middle of a block
+    wk.sync()
+    for j, b in enumerate(sizes):
+        assert np.array_equal(outs[j][:b], expect[j % 5]), j
+        assert np.isnan(outs[j][b:]).all()
+    bad = pool[0].copy()
+    bad[3, 5] = m.rows()[5]
+    wk.push_host(bad, None, outs[0])
+    with pytest.raises(fr.FleetRecError) as e:
+        wk.sync()
+    assert e.value.status == fr.FR_ERR_INDEX_RANGE
+    wk.close()
+    # the native loop
+    drv = fr.Driver(ctx, 2, 2, 256)
+    el = drv.run_host(256, 3000, pool, streaming=True)
+    assert el > 0
+    w0 = fr.Worker(ctx, 256)
+    full = [w0.infer(p_) for p_ in pool]
+    w0.close()
+    scale = max(np.abs(f).max() for f in full)
+    seen = 0
+    for t in range(2):
+        for sl in range(2):
+            for row in drv.host_score_ring(t, sl, 256):
+                if row.any():
+                    assert min(np.abs(row - f).max() for f in full) <= 1e-5 * scale
+                    seen += 1
+    assert seen >= 4 * 128
+    drv.close()
+    # a model that does not stream through the fused kernel is refused
+    mc, cc = ctxs(fr.MODEL_C)
+    wc = fr.Worker(cc, 64)
+    with pytest.raises(fr.FleetRecError) as e:
+        wc.push_host(uniform_idx(rng, mc.rows(), 64), np.zeros((64, mc.dense_len), np.float32), np.zeros(64, np.float32))
+    assert e.value.status == fr.FR_ERR_STATE
+    wc.close()
+
+
 @pytest.mark.parametrize("which,G", [(0, 2), (1, 4), (2, 8)])
 def test_table_sharded_mode_single_device_emulation(fr, O, gpu, which, G):
     """BASELINE config 4 on one GPU: G table-sharded contexts (each holds only its tables), every shard gathers its
