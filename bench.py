@@ -136,8 +136,8 @@ def main_sharded(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8000)
-    ap.add_argument("--warmup", type=int, default=800)
+    ap.add_argument("--steps", type=int, default=40000)
+    ap.add_argument("--warmup", type=int, default=4000)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--threads", type=int, default=2, help="host driver threads (reference THREAD_NUM = 4, constant.h:42)")
     ap.add_argument("--depth", type=int, default=2, help="workers (streams) each driver thread keeps in flight")
