@@ -77,47 +77,69 @@ def main_sharded(args):
     nbuf = 8
     idxs = [fr.DeviceBuffer.from_numpy(ctx, (rng.random((B, model.n_tables)) * rows[None, :]).astype(np.int32)) for _ in range(nbuf)]
     dns = [fr.DeviceBuffer.from_numpy(ctx, rng.uniform(-1, 1, (B, model.dense_len)).astype(np.float32)) for _ in range(nbuf)]
-    wk = fr.Worker(ctx, B)
-    local = torch.empty((B, F), dtype=torch.float32, device=dev)          # torch owns the exchange buffers (RCCL plumbing)
+    # Two workers and two sets of exchange buffers: while the FC chain of batch i-1 runs on worker B's stream, worker A gathers
+    # batch i and the all-gather of batch i runs on torch's (RCCL) stream -- gather + exchange are hidden behind the MFMA work.
+    wk = fr.Worker(ctx, B)       # gathers
+    wk_fc = fr.Worker(ctx, B)    # FC chains
     a2a = args.exchange == "alltoall"
     if a2a and B % G:
         raise SystemExit("--exchange alltoall needs the batch divisible by the number of ranks")
-    gathered = torch.empty((G, B // G if a2a else B, F), dtype=torch.float32, device=dev)
+    local = [torch.empty((B, F), dtype=torch.float32, device=dev) for _ in range(2)]   # torch owns the exchange buffers (RCCL plumbing)
+    gathered = [torch.empty((G, B // G if a2a else B, F), dtype=torch.float32, device=dev) for _ in range(2)]
     lo, hi = dist_mod.item_range(r, G, B)
     scores = torch.empty((max(hi - lo, 1),), dtype=torch.float32, device=dev)
 
-    def step(i):
-        wk.gather_only(B, idxs[i % nbuf], dns[i % nbuf], local.data_ptr())
-        wk.sync()                                      # the slice must be complete before RCCL reads it (different stream)
+    def exchange(k):
         if a2a:
-            env.all_to_all_slices(local, gathered)
-            torch.cuda.synchronize()
-            wk.fc_from_slices(B // G, 0, hi - lo, gathered.data_ptr(), scores.data_ptr())
+            env.all_to_all_slices(local[k], gathered[k])
         else:
-            env.all_gather_slices(local, gathered)
-            torch.cuda.synchronize()
-            wk.fc_from_slices(B, lo, hi - lo, gathered.data_ptr(), scores.data_ptr())
-        wk.sync()
+            env.all_gather_slices(local[k], gathered[k])
+
+    def fc(k):
+        if a2a:
+            wk_fc.fc_from_slices(B // G, 0, hi - lo, gathered[k].data_ptr(), scores.data_ptr())
+        else:
+            wk_fc.fc_from_slices(B, lo, hi - lo, gathered[k].data_ptr(), scores.data_ptr())
+
+    state = {"pending": None}   # buffer set whose slices are gathered + exchanged and wait for their FC chain
+
+    def step(i):
+        k = i & 1
+        wk.gather_only(B, idxs[i % nbuf], dns[i % nbuf], local[k].data_ptr())        # async on the gather worker's stream
+        if state["pending"] is not None:
+            fc(state["pending"])                                                     # async on the FC worker's stream: overlaps
+        wk.sync()                                      # the slice must be complete before RCCL reads it (different stream)
+        exchange(k)
+        torch.cuda.synchronize()                       # exchange done (torch's stream); the FC of the previous batch may still run
+        if state["pending"] is not None:
+            wk_fc.sync()
+        state["pending"] = k
+
+    def drain():
+        if state["pending"] is not None:
+            fc(state["pending"])
+            wk_fc.sync()
+            state["pending"] = None
 
     if args.precision != "f32":   # the slices travel as fp32; the FC chain re-packs them to bf16 / e4m3 operands
         ctx.set_fc_precision(fr.FC_BF16 if args.precision == "bf16" else fr.FC_FP8)
         if args.precision == "fp8":   # activation exponents from the first batch's gathered slices (same on every rank)
-            wk.gather_only(B, idxs[0], dns[0], local.data_ptr())
+            wk.gather_only(B, idxs[0], dns[0], local[0].data_ptr())
             wk.sync()
+            exchange(0)
+            torch.cuda.synchronize()
             if a2a:
-                env.all_to_all_slices(local, gathered)
-                torch.cuda.synchronize()
-                wk.calibrate_fp8_slices(B // G, 0, hi - lo, gathered.data_ptr())
+                wk_fc.calibrate_fp8_slices(B // G, 0, hi - lo, gathered[0].data_ptr())
             else:
-                env.all_gather_slices(local, gathered)
-                torch.cuda.synchronize()
-                wk.calibrate_fp8_slices(B, 0, B, gathered.data_ptr())
+                wk_fc.calibrate_fp8_slices(B, 0, B, gathered[0].data_ptr())
     for i in range(args.warmup):
         step(i)
+    drain()
     env.barrier(); torch.cuda.synchronize(); ctx.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    drain()                                            # the last batch's FC chain is inside the timed region
     env.barrier(); torch.cuda.synchronize(); ctx.synchronize()
     dt = env.max_over_ranks(time.perf_counter() - t0)
     if r == 0:
@@ -129,6 +151,7 @@ def main_sharded(args):
                                    "FC on B/G items per rank" % (B, G, F), "parallelism": "table-sharded x%d" % G, "exchange": args.exchange,
                        "exchange_bytes_in_per_rank_per_step": int(G * (B // G if a2a else B) * F * 4)}}))
     wk.close()
+    wk_fc.close()
     ctx.close()
     env.close()
 
