@@ -707,7 +707,7 @@ static bool fused_eligible(const fr_ctx *c) {
     static const int enabled = getenv("FR_FUSED") ? atoi(getenv("FR_FUSED")) : 1;  // experiment knob
     const int32_t *fc = c->model.fc;
     if (!enabled || c->n_shards != 1 || c->model.layout != FR_LAYOUT_SEMANTIC) return false;
-    if (c->fc_precision == FR_FC_FP8) return false;  // stage pipeline only
+    if (c->fc_precision == FR_FC_FP8) return frk_fused_f8_ok(fc[0], fc[1], fc[2], fc[3]);
     return c->fc_precision == FR_FC_BF16 ? frk_fused_h_ok(fc[0], fc[1], fc[2], fc[3]) : frk_fused_ok(fc[0], fc[1], fc[2], fc[3]);
 }
 
@@ -729,9 +729,10 @@ static int fused_flush(fr_worker *w) {
     const bool bf16 = c->fc_precision == FR_FC_BF16;
     // fp32: the 64-item kernel needs 64 queued batches to cover the chip; smaller groups keep the 32-item kernel (env FR_FUSED_M2=0/1 forces)
     static const int m2_forced = getenv("FR_FUSED_M2") ? atoi(getenv("FR_FUSED_M2")) : -1;
-    const bool m2 = !bf16 && frk_fused_m2_ok(c->model.fc[0], c->model.fc[1], c->model.fc[2], c->model.fc[3]) &&
+    const bool m2 = !bf16 && c->fc_precision == FR_FC_FP32 && frk_fused_m2_ok(c->model.fc[0], c->model.fc[1], c->model.fc[2], c->model.fc[3]) &&
                     (m2_forced == 1 || (m2_forced != 0 && fused_group() >= 64));
-    const int per_wg = bf16 ? frk_fused_h_items_per_wg() : (m2 ? 64 : 32);  // items per workgroup
+    const bool fp8 = c->fc_precision == FR_FC_FP8;
+    const int per_wg = (bf16 || fp8) ? frk_fused_h_items_per_wg() : (m2 ? 64 : 32);  // items per workgroup
     int max_tiles = 0;
     for (int i = 0; i < w->n_pending; i++) {
         a.b[i] = w->pending[i];
@@ -744,7 +745,14 @@ static int fused_flush(fr_worker *w) {
     a.n_words = c->n_words;
     a.idx_stride = (int)idx_cols(c);
     a.err_flag = w->d_err;
-    if (bf16) {  // the bf16 kernel reads the q8-packed bf16 copies through the same argument slots
+    if (fp8) {  // e4m3 q16 copies of FC1..FC3, fp32 output weights, the quantisation exponents
+        a.w1q = reinterpret_cast<const float4 *>(c->d_w_fp8[0]);
+        a.w2q = reinterpret_cast<const float4 *>(c->d_w_fp8[1]);
+        a.w3q = reinterpret_cast<const float4 *>(c->d_w_fp8[2]);
+        a.wout = c->d_w[3];
+        for (int l = 0; l < 3; l++) a.e_w[l] = c->f8_e_w[l];
+        for (int l = 0; l < 4; l++) a.e_act[l] = c->f8_e_act[l];
+    } else if (bf16) {  // the bf16 kernel reads the q8-packed bf16 copies through the same argument slots
         a.w1q = reinterpret_cast<const float4 *>(c->d_w_bf16[0]);
         a.w2q = reinterpret_cast<const float4 *>(c->d_w_bf16[1]);
         a.w3q = reinterpret_cast<const float4 *>(c->d_w_bf16[2]);
@@ -762,6 +770,7 @@ static int fused_flush(fr_worker *w) {
     a.stamps = g_stamp_buffer;
     w->n_pending = 0;
     w->pending_items = 0;
+    if (fp8) return frk_fused_f8_launch(a, w->stream);
     if (m2) return frk_fused_m2_launch(a, w->stream);
     return bf16 ? frk_fused_h_launch(a, w->stream) : frk_fused_launch(a, w->stream);
 }

@@ -817,3 +817,219 @@ int frk_fused_h_launch(const FrFusedArgs &a, hipStream_t s) {
     FR_FAIL(FR_ERR_INVALID, "no bf16 fused instantiation for K=%d", a.K);
 }
 
+// ===================================================================================================
+// fr_fused_tile_f8_kernel: the fused item-tile kernel in fp8 (e4m3 q16 operands, v_mfma_scale_f32_32x32x64_f8f6f4).
+// Same phases as the bf16 kernel, 64 items per workgroup, every activation image in LDS as e4m3 bytes (x 2^e_act[l], saturated),
+// the MFMA's E8M0 block scales undo the weight and activation exponents, the output layer multiplies the decoded R3 by the fp32
+// master weights.  A group is 64 k: lane half h supplies q16 rows 4g + 2h and 4g + 2h + 1 of both operands.  The record is
+// zero-padded to a multiple of 64 k inside the LDS image (Model-A 352 -> 384, Model-B 880 -> 896).
+// ===================================================================================================
+struct FtW8 {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned voff, voff2;  // rows 2h and 2h + 1 of a group
+    unsigned grp;          // byte step of one group (4 rows)
+};
+__device__ __forceinline__ FtW8 ft_w8(const void *wf, int KE, int N, int hk, int lm) {
+    FtW8 w;
+    w.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(wf), 0, (unsigned)KE * (unsigned)N * 16u, 0x00020000);
+    w.voff = ((unsigned)(2 * hk) * N + lm) * 16u;
+    w.voff2 = w.voff + (unsigned)N * 16u;
+    w.grp = 4u * (unsigned)N * 16u;
+    return w;
+}
+__device__ __forceinline__ i32x8 ft_w8load(const FtW8 &w, unsigned soff, int imm) {
+    const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.voff + imm, soff, 0), hi = __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.voff2 + imm, soff, 0);
+    i32x8 r;
+    r[0] = (int)lo.x; r[1] = (int)lo.y; r[2] = (int)lo.z; r[3] = (int)lo.w;
+    r[4] = (int)hi.x; r[5] = (int)hi.y; r[6] = (int)hi.z; r[7] = (int)hi.w;
+    return r;
+}
+
+template <int NT, int MT, int R, int CNT>
+__device__ __forceinline__ void ft8_gemm_ct(f32x16 (&acc)[NT][MT], const FtW8 &w, int n0, const uint4 *Bf, int ld, int gb0, int g0, int hk, int lm, int sc_a,
+                                            int sc_b) {
+    const unsigned s0 = (unsigned)g0 * w.grp + (unsigned)n0 * 16u;  // n0, g0 wave-uniform
+    const uint4 *bl = Bf + (size_t)(4 * gb0 + 2 * hk) * ld + lm;
+    i32x8 ring[R][NT];
+#pragma unroll
+    for (int g = 0; g < R && g < CNT; g++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) ring[g][t] = ft_w8load(w, s0 + (unsigned)g * w.grp, 512 * t);
+#pragma unroll
+    for (int g = 0; g < CNT; g++) {
+        i32x8 b8[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const uint4 lo = bl[(size_t)(4 * g) * ld + 32 * mt], hi = bl[(size_t)(4 * g + 1) * ld + 32 * mt];
+            b8[mt][0] = (int)lo.x; b8[mt][1] = (int)lo.y; b8[mt][2] = (int)lo.z; b8[mt][3] = (int)lo.w;
+            b8[mt][4] = (int)hi.x; b8[mt][5] = (int)hi.y; b8[mt][6] = (int)hi.z; b8[mt][7] = (int)hi.w;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) acc[t][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ring[g % R][t], b8[mt], acc[t][mt], 0, 0, 0, sc_a, 0, sc_b);
+        if (g + R < CNT) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) ring[g % R][t] = ft_w8load(w, s0 + (unsigned)(g + R) * w.grp, 512 * t);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// 32(n) x 32(m) fp32 accumulator tile -> e4m3 (x oscale, saturated), stored as 4-byte quarters of q16 elements of an LDS image
+__device__ __forceinline__ void ft8_store_tile(uint4 *img, int ld, const f32x16 &acc, int n_local, int m_local, int hk, int lm, float oscale) {
+    uint32_t *q = reinterpret_cast<uint32_t *>(img);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int n = n_local + 8 * i + 4 * hk;  // + c
+        q[((size_t)(n >> 4) * ld + m_local + lm) * 4 + ((n & 15) >> 2)] = pack_fp8x4(acc[4 * i + 0], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3], oscale);
+    }
+}
+
+template <int G1 /* FC1 groups of 64 k */>
+__global__ void __launch_bounds__(512) fr_fused_tile_f8_kernel(const FrFusedArgs a) {
+    extern __shared__ uint4 lds[];
+    constexpr int MT = 2, T2W = 2, LD = 32 * MT + 1, TI = 32 * MT;
+    constexpr int KE1 = 4 * G1;                       // q16 rows of the (padded) record
+    uint4 *Xf = lds;                                  // [KE1][LD]
+    uint4 *R1b[2] = {Xf + (size_t)KE1 * LD, Xf + (size_t)(KE1 + 16) * LD};  // [16][LD] each: 256 outputs of FC1
+    uint4 *R2 = lds;                                  // [H2/16][LD], overlays Xf / R1 once they are dead
+    uint4 *R3 = lds + (size_t)(a.H2 / 16) * LD;       // [H3/16][LD]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hk = lane >> 5, lm = lane & 31;
+    const int bi = blockIdx.x / a.tiles_per_batch, tile = blockIdx.x - bi * a.tiles_per_batch;
+    const FrFusedBatch &bt = a.b[bi];
+    const int m0 = tile * TI;
+    if (m0 >= bt.batch) return;
+
+    {   // ---- gather + e4m3 conversion: lanes along record words (incl. the zero pad), 8 items per thread ----
+        const int wl = tid & 63, ig = tid >> 6;
+        uint32_t *Xw = reinterpret_cast<uint32_t *>(Xf);
+        const float scale = __builtin_ldexpf(1.0f, a.e_act[0]);
+        bool bad = false;
+        for (int w0 = 0; w0 < 4 * KE1; w0 += 64) {
+            const int w = w0 + wl;
+            if (w < a.n_words) {
+                const uint4 d0 = reinterpret_cast<const uint4 *>(a.words)[2 * w];
+                const uint4 d1 = reinterpret_cast<const uint4 *>(a.words)[2 * w + 1];
+                const uint64_t src = ((uint64_t)d0.y << 32) | d0.x;
+                const uint32_t stride = d0.z, idx_col = d0.w, rows = d1.x;
+                const bool is_dense = (idx_col & FR_DESC_DENSE) != 0;
+                const char *base = is_dense ? reinterpret_cast<const char *>(bt.dense) + src : reinterpret_cast<const char *>(src);
+                uint32_t id[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int m = m0 + 8 * ig + i;
+                    id[i] = 0;
+                    if (m < bt.batch) id[i] = is_dense ? (uint32_t)m : (uint32_t)bt.idx[(size_t)m * a.idx_stride + idx_col];
+                    if (!is_dense && id[i] >= rows) {
+                        bad = true;
+                        id[i] = 0;
+                    }
+                }
+                uint4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = *reinterpret_cast<const uint4 *>(base + (uint64_t)id[i] * stride);
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    Xw[((size_t)(w >> 2) * LD + 8 * ig + i) * 4 + (w & 3)] = (m0 + 8 * ig + i < bt.batch) ? pack_fp8_word(v[i], scale) : 0u;
+            } else if (w < 4 * KE1) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) Xw[((size_t)(w >> 2) * LD + 8 * ig + i) * 4 + (w & 3)] = 0u;  // pad up to a multiple of 64 k
+            }
+        }
+        if (bad) atomicOr_system(a.err_flag, 1);
+    }
+    __syncthreads();
+
+    f32x16 acc2[T2W][MT];
+#pragma unroll
+    for (int t = 0; t < T2W; t++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc2[t][mt][i] = 0.0f;
+    const int n_chunks = a.H1 / 256;
+    const FtW8 W1 = ft_w8(a.w1q, KE1, a.H1, hk, lm), W2 = ft_w8(a.w2q, a.H1 / 16, a.H2, hk, lm), W3 = ft_w8(a.w3q, a.H2 / 16, a.H3, hk, lm);
+    const float os1 = __builtin_ldexpf(1.0f, a.e_act[1]), os2 = __builtin_ldexpf(1.0f, a.e_act[2]), os3 = __builtin_ldexpf(1.0f, a.e_act[3]);
+    for (int c = 0; c < n_chunks; c++) {
+        f32x16 acc1[1][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc1[0][mt][i] = 0.0f;
+        ft8_gemm_ct<1, MT, (G1 < 8 ? G1 : 8), G1>(acc1, W1, c * 256 + 32 * wave, Xf, LD, 0, 0, hk, lm, 127 - a.e_w[0], 127 - a.e_act[0]);
+        uint4 *R1 = R1b[c & 1];  // double-buffered: one barrier per chunk
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) ft8_store_tile(R1, LD, acc1[0][mt], 32 * wave, 32 * mt, hk, lm, os1);
+        __syncthreads();
+        // FC2: K range [256 c, 256 c + 256) = 4 groups of 64 k
+        ft8_gemm_ct<T2W, MT, 4, 4>(acc2, W2, 32 * T2W * wave, R1, LD, 0, 4 * c, hk, lm, 127 - a.e_w[1], 127 - a.e_act[1]);
+    }
+    __syncthreads();  // Xf and R1 dead: R2 may overlay them
+#pragma unroll
+    for (int t = 0; t < T2W; t++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) ft8_store_tile(R2, LD, acc2[t][mt], 32 * (T2W * wave + t), 32 * mt, hk, lm, os2);
+    __syncthreads();
+
+    f32x16 acc3[1][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc3[0][mt][i] = 0.0f;
+    ft8_gemm_ct<1, MT, 8, 8>(acc3, W3, 32 * wave, R2, LD, 0, 0, hk, lm, 127 - a.e_w[2], 127 - a.e_act[2]);  // H2 / 64 = 8 groups
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) ft8_store_tile(R3, LD, acc3[0][mt], 32 * wave, 32 * mt, hk, lm, os3);
+    __syncthreads();
+    {   // score[m] = 2^-e3 * sum_n wout[n] * e4m3(R3)[n][m]: 64 items x 8 slices of 2 q16 rows, fp32 master weights, fixed order
+        const int il = tid & 63, sl = tid >> 6;
+        const int rows_per = (a.H3 / 16) / 8;
+        float s = 0.0f;
+        for (int q = sl * rows_per; q < (sl + 1) * rows_per; q++) {
+            const uint4 r = R3[(size_t)q * LD + il];
+            const int rr[4] = {(int)r.x, (int)r.y, (int)r.z, (int)r.w};
+            const float *w = a.wout + 16 * q;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                s = fmaf(w[4 * c + 0], __builtin_amdgcn_cvt_f32_fp8(rr[c], 0), s);
+                s = fmaf(w[4 * c + 1], __builtin_amdgcn_cvt_f32_fp8(rr[c], 1), s);
+                s = fmaf(w[4 * c + 2], __builtin_amdgcn_cvt_f32_fp8(rr[c], 2), s);
+                s = fmaf(w[4 * c + 3], __builtin_amdgcn_cvt_f32_fp8(rr[c], 3), s);
+            }
+        }
+        float *part = reinterpret_cast<float *>(R3 + (size_t)(a.H3 / 16) * LD);
+        part[sl * 64 + il] = s;
+        __syncthreads();
+        if (tid < 64 && m0 + tid < bt.batch) {
+            float t = part[tid];
+#pragma unroll
+            for (int i = 1; i < 8; i++) t += part[i * 64 + tid];
+            bt.scores[m0 + tid] = t * __builtin_ldexpf(1.0f, -a.e_act[3]);
+        }
+    }
+}
+
+bool frk_fused_f8_ok(int K, int H1, int H2, int H3) { return (K == 352 || K == 880) && H1 % 256 == 0 && H2 == 512 && H3 == 256; }
+
+template <int G1>
+static int fused_f8_launch_inst(const FrFusedArgs &a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fr_fused_tile_f8_kernel<G1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            FR_FAIL(FR_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_set = true;
+    }
+    const size_t rows1 = 4 * G1 + 32, rows2 = (size_t)(a.H2 / 16) + (size_t)(a.H3 / 16) + 2;  // + 2 rows: 512 floats of reduction scratch
+    fr_fused_tile_f8_kernel<G1><<<dim3(a.n_batches * a.tiles_per_batch), dim3(512), (rows1 > rows2 ? rows1 : rows2) * 65 * 16, s>>>(a);
+    KCHECK();
+    return FR_OK;
+}
+
+// a.w1q/w2q/w3q point at the e4m3 q16 weights, a.wout at the fp32 output weights; a.tiles_per_batch counts 64-item tiles
+int frk_fused_f8_launch(const FrFusedArgs &a, hipStream_t s) {
+    if (a.K == 352) return fused_f8_launch_inst<6>(a, s);
+    if (a.K == 880) return fused_f8_launch_inst<14>(a, s);
+    FR_FAIL(FR_ERR_INVALID, "no fp8 fused instantiation for K=%d", a.K);
+}

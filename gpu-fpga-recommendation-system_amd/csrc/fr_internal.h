@@ -99,6 +99,7 @@ struct FrFusedArgs {
     const float4 *w1q, *w2q, *w3q;  // q4-packed weights
     const float *wout;
     int K, H1, H2, H3;
+    int e_w[3], e_act[4];        // fp8 kernel only: quantisation exponents (weights W1..W3; activations X, R1, R2, R3)
     unsigned long long *stamps;  // diagnostics only (NULL normally): 16 s_memrealtime stamps per workgroup
 };
 
@@ -228,6 +229,8 @@ int frk_fused_launch(const FrFusedArgs &a, hipStream_t s);
 bool frk_fused_m2_ok(int K, int H1, int H2, int H3);
 int frk_fused_m2_launch(const FrFusedArgs &a, hipStream_t s);
 bool frk_fused_h_ok(int K, int H1, int H2, int H3);
+bool frk_fused_f8_ok(int K, int H1, int H2, int H3);
+int frk_fused_f8_launch(const FrFusedArgs &a, hipStream_t s);
 int frk_fused_h_items_per_wg();
 int frk_fused_h_launch(const FrFusedArgs &a, hipStream_t s);  // 0 when the transposing gather does not apply
 int frk_transpose_records(const float *X, float *Xt, int batch, int K, int ldm, hipStream_t s);

@@ -792,8 +792,12 @@ def test_fp8_chain(fr, O, ctxs, which, B):
         for o in outs:
             wk.push_device(B, d_i, d_d, o)
         wk.sync()
+        first = outs[0].download(np.float32, B)
+        assert rel_err(first, reff) <= 2e-2, rel_err(first, reff)
         for o in outs:
-            assert np.array_equal(o.download(np.float32, B), scores)               # stage pipeline on both paths
+            assert np.array_equal(o.download(np.float32, B), first)                # bitwise run to run
+        if which == 2:
+            assert np.array_equal(first, scores)   # Model-C: stage pipeline on both paths (A / B stream through the fused fp8 kernel)
         # saturation instead of NaN: exponents 6 binades too large clamp at +-448 and the scores stay finite
         ctx.set_fp8_act_exponents([e + 6 for e in act_exp])
         assert np.isfinite(wk.infer(idx, dense)).all()
