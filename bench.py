@@ -38,6 +38,18 @@ def gather_bytes_per_inference(model, fr):
     return rows + idx + dense + write
 
 
+def pmc_field(kernel_prefix, field):
+    """A per-kernel figure of the committed PMC summary (mfma_busy_fraction, mfma_f32_flops_per_launch, l2_hit_rate ...) or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        for k, v in d.items():
+            if k.startswith(kernel_prefix) and field in v:
+                return v[field]
+    except Exception:
+        pass
+    return None
+
+
 def pmc_traffic(kernel_prefix):
     """HBM/fabric bytes per launch from the committed PMC summary (tools/pmc_traffic.sh: separate rocprofv3 --pmc passes over
     this same bench command, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md) -- or None."""
@@ -310,6 +322,8 @@ def main():
                               "kernel": "%s: one launch = the whole hot path (gather + the 4-GEMM chain) of %d queued batches of %d, "
                                         "back-to-back on ONE stream" % (kname, group, B),
                               "batches_per_launch": group, "avg_launch_ms": pipe_ms, "algorithmic_flops_per_launch": flops,
+                              "pmc_mfma_busy_fraction": pmc_field(kname.split(",")[0] if group > 1 else kname, "mfma_busy_fraction"),
+                              "pmc_mfma_f32_flops_per_launch": pmc_field(kname.split(",")[0] if group > 1 else kname, "mfma_f32_flops_per_launch"),
                               "note": "`value` above runs %d such streams concurrently" % (args.threads * args.depth)}
         # per-stage launches (unpipelined submit path), for reference
         d_sc = ring[0]

@@ -24,6 +24,12 @@ for k, cs in agg.items():
         e["fetch_bytes_corrected"] = 2.0 * m["FETCH_SIZE"] * 1024
         e["write_bytes"] = m["WRITE_SIZE"] * 1024
         e["traffic_bytes_per_launch"] = e["fetch_bytes_corrected"] + e["write_bytes"]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
+        # rocprofv3's derived MfmaUtil: busy cycles of all MFMA pipes / (active cycles of one XCD x 1024 SIMDs); the counter
+        # values are summed over the 8 XCDs, so GRBM_GUI_ACTIVE / 8 is the per-XCD figure
+        e["mfma_busy_fraction"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    if "SQ_INSTS_VALU_MFMA_MOPS_F32" in m:
+        e["mfma_f32_flops_per_launch"] = m["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0
     if "TCC_HIT_sum" in m:
         e["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
     out[k] = e
