@@ -96,8 +96,12 @@ def main_sharded(args):
     a2a = args.exchange == "alltoall"
     if a2a and B % G:
         raise SystemExit("--exchange alltoall needs the batch divisible by the number of ranks")
-    local = [torch.empty((B, F), dtype=torch.float32, device=dev) for _ in range(2)]   # torch owns the exchange buffers (RCCL plumbing)
-    gathered = [torch.empty((G, B // G if a2a else B, F), dtype=torch.float32, device=dev) for _ in range(2)]
+    # slice transport: fp32, or the chain's own operand type (bf16: half the exchange bytes, e4m3: a quarter)
+    lp = args.transport == "lp" and args.precision != "f32"
+    prec_enum = {"f32": fr.FC_FP32, "bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[args.precision]
+    esz = {"f32": 4, "bf16": 2, "fp8": 1}[args.precision] if lp else 4
+    local = [torch.empty((B, F * esz), dtype=torch.uint8, device=dev) for _ in range(2)]   # torch owns the exchange buffers (RCCL plumbing)
+    gathered = [torch.empty((G, B // G if a2a else B, F * esz), dtype=torch.uint8, device=dev) for _ in range(2)]
     lo, hi = dist_mod.item_range(r, G, B)
     scores = torch.empty((max(hi - lo, 1),), dtype=torch.float32, device=dev)
 
@@ -108,16 +112,17 @@ def main_sharded(args):
             env.all_gather_slices(local[k], gathered[k])
 
     def fc(k):
+        tp = prec_enum if lp else fr.FC_FP32
         if a2a:
-            wk_fc.fc_from_slices(B // G, 0, hi - lo, gathered[k].data_ptr(), scores.data_ptr())
+            wk_fc.fc_from_slices_lp(B // G, 0, hi - lo, gathered[k].data_ptr(), tp, scores.data_ptr())
         else:
-            wk_fc.fc_from_slices(B, lo, hi - lo, gathered[k].data_ptr(), scores.data_ptr())
+            wk_fc.fc_from_slices_lp(B, lo, hi - lo, gathered[k].data_ptr(), tp, scores.data_ptr())
 
     state = {"pending": None}   # buffer set whose slices are gathered + exchanged and wait for their FC chain
 
     def step(i):
         k = i & 1
-        wk.gather_only(B, idxs[i % nbuf], dns[i % nbuf], local[k].data_ptr())        # async on the gather worker's stream
+        wk.gather_slices(B, idxs[i % nbuf], dns[i % nbuf], local[k].data_ptr(), prec_enum if lp else fr.FC_FP32)   # async, gather worker's stream
         if state["pending"] is not None:
             fc(state["pending"])                                                     # async on the FC worker's stream: overlaps
         wk.sync()                                      # the slice must be complete before RCCL reads it (different stream)
@@ -136,14 +141,20 @@ def main_sharded(args):
     if args.precision != "f32":   # the slices travel as fp32; the FC chain re-packs them to bf16 / e4m3 operands
         ctx.set_fc_precision(fr.FC_BF16 if args.precision == "bf16" else fr.FC_FP8)
         if args.precision == "fp8":   # activation exponents from the first batch's gathered slices (same on every rank)
-            wk.gather_only(B, idxs[0], dns[0], local[0].data_ptr())
+            cal_l = torch.empty((B, F), dtype=torch.float32, device=dev)   # calibration always sees fp32 slices
+            cal_g = torch.empty((G, B // G if a2a else B, F), dtype=torch.float32, device=dev)
+            wk.gather_only(B, idxs[0], dns[0], cal_l.data_ptr())
             wk.sync()
-            exchange(0)
+            if a2a:
+                env.all_to_all_slices(cal_l, cal_g)
+            else:
+                env.all_gather_slices(cal_l, cal_g)
             torch.cuda.synchronize()
             if a2a:
-                wk_fc.calibrate_fp8_slices(B // G, 0, hi - lo, gathered[0].data_ptr())
+                wk_fc.calibrate_fp8_slices(B // G, 0, hi - lo, cal_g.data_ptr())
             else:
-                wk_fc.calibrate_fp8_slices(B, 0, B, gathered[0].data_ptr())
+                wk_fc.calibrate_fp8_slices(B, 0, B, cal_g.data_ptr())
+            del cal_l, cal_g
     for i in range(args.warmup):
         step(i)
     drain()
@@ -161,7 +172,8 @@ def main_sharded(args):
             "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "Model-C batch=%d, %d-way table-ID shards (slice F=%d floats), 1 all-gather of [B x F] per step, "
                                    "FC on B/G items per rank" % (B, G, F), "parallelism": "table-sharded x%d" % G, "exchange": args.exchange,
-                       "exchange_bytes_in_per_rank_per_step": int(G * (B // G if a2a else B) * F * 4)}}))
+                       "slice_transport": args.precision if lp else "f32",
+                       "exchange_bytes_in_per_rank_per_step": int(G * (B // G if a2a else B) * F * esz)}}))
     wk.close()
     wk_fc.close()
     ctx.close()
@@ -186,6 +198,8 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the multi-stream throughput loop and the Model-C leg: only the single-stream roofline launches run, so "
                          "that a rocprofv3 --kernel-trace --stats summary of this command shows the kernel under the roofline's conditions")
+    ap.add_argument("--transport", choices=["f32", "lp"], default="lp",
+                    help="sharded mode: slices travel as fp32, or (lp) in the chain's own operand type when --precision is bf16 / fp8")
     ap.add_argument("--exchange", choices=["allgather", "alltoall"], default="allgather",
                     help="sharded mode: all-gather every slice to every rank (BASELINE configs[3]) or all-to-all only each rank's items")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")

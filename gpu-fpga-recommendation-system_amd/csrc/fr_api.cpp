@@ -522,7 +522,7 @@ static int check_ready(fr_worker *w, int batch, bool need_tables, bool need_weig
     return FR_OK;
 }
 
-static int launch_gather(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_records) {
+static int launch_gather(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, void *d_records, int transport = FR_FC_FP32) {
     fr_ctx *c = w->ctx;
     if (!d_idx) FR_FAIL(FR_ERR_INVALID, "d_idx is NULL");
     if (c->model.dense_len && !d_dense) {
@@ -530,7 +530,7 @@ static int launch_gather(fr_worker *w, int batch, const int32_t *d_idx, const fl
         for (const FrWordDesc &wd : c->h_words) needs |= (wd.idx_col & FR_DESC_DENSE) != 0;
         if (needs) FR_FAIL(FR_ERR_INVALID, "model has dense features but d_dense is NULL");
     }
-    return frk_gather(c->d_words, c->n_words, d_idx, (int)idx_cols(c), d_dense, d_records, batch, w->d_err, w->stream);
+    return frk_gather(c->d_words, c->n_words, d_idx, (int)idx_cols(c), d_dense, d_records, batch, w->d_err, transport, c->f8_e_act[0], w->stream);
 }
 
 // ---- the stage pipeline ------------------------------------------------------------------------------
@@ -865,6 +865,48 @@ extern "C" int fr_worker_gather_only(fr_worker *w, int batch, const int32_t *d_i
     if (!d_records) FR_FAIL(FR_ERR_INVALID, "d_records is NULL");
     FR_HIP(hipSetDevice(w->ctx->device));
     rc = launch_gather(w, batch, d_idx, d_dense, d_records);
+    if (rc) return rc;
+    w->in_flight = true;
+    return FR_OK;
+}
+
+// Sharded mode, low-precision transport: the shard's slice [batch][slice_padded] as bf16 or e4m3 (x 2^e of the context's X exponent)
+// instead of fp32 -- what travels through the all-gather.  transport = FR_FC_FP32 is fr_worker_gather_only.
+extern "C" int fr_worker_gather_slices(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, void *d_slice, int transport) {
+    int rc = check_ready(w, batch, true, false);
+    if (rc) return rc;
+    if (!d_slice) FR_FAIL(FR_ERR_INVALID, "d_slice is NULL");
+    if (transport != FR_FC_FP32 && transport != FR_FC_BF16 && transport != FR_FC_FP8) FR_FAIL(FR_ERR_INVALID, "bad transport %d", transport);
+    if (transport != FR_FC_FP32 && w->ctx->model.layout != FR_LAYOUT_SEMANTIC) FR_FAIL(FR_ERR_STATE, "low-precision transport: SEMANTIC layout only");
+    FR_HIP(hipSetDevice(w->ctx->device));
+    rc = launch_gather(w, batch, d_idx, d_dense, d_slice, transport);
+    if (rc) return rc;
+    w->in_flight = true;
+    return FR_OK;
+}
+
+// ... and the receiving side: d_gathered = [n_shards][batch_total][slice_padded] elements of the transport type.  The transport must
+// be the context's FC precision (the slices become the chain's operand image without another rounding).
+extern "C" int fr_worker_fc_from_slices_lp(fr_worker *w, int batch_total, int item0, int n_items, const void *d_gathered, int transport, float *d_scores) {
+    if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
+    if (transport == FR_FC_FP32) return fr_worker_fc_from_slices(w, batch_total, item0, n_items, reinterpret_cast<const float *>(d_gathered), d_scores);
+    int rc = check_ready(w, n_items, false, true);
+    if (rc) return rc;
+    fr_ctx *c = w->ctx;
+    if (transport != c->fc_precision) FR_FAIL(FR_ERR_STATE, "slice transport %d does not match the context's FC precision %d", transport, c->fc_precision);
+    if (!d_gathered || !d_scores) FR_FAIL(FR_ERR_INVALID, "NULL device pointer");
+    if (batch_total < 1 || item0 < 0 || item0 + n_items > batch_total) FR_FAIL(FR_ERR_INVALID, "items [%d,+%d) outside batch %d", item0, n_items, batch_total);
+    if (w->n_active || w->n_pending) FR_FAIL(FR_ERR_STATE, "pipeline busy: call fr_worker_sync first");
+    FR_HIP(hipSetDevice(c->device));
+    if (w->launch_no == 0) w->launch_no = 1;
+    const int ldm = round_up(n_items, 32);
+    const int par_prev = (int)((w->launch_no - 1) & 1);
+    rc = frk_transpose_slices_lp(transport, d_gathered, c->n_shards, batch_total, c->slice_padded, c->shard_offset.data(), c->shard_len.data(), item0, n_items,
+                                 act_set(w, par_prev).x, c->model.fc[0], ldm, w->stream);
+    if (rc) return rc;
+    rc = pipeline_push(w, n_items, 1, nullptr, nullptr, d_scores);
+    if (rc) return rc;
+    rc = pipeline_flush(w);
     if (rc) return rc;
     w->in_flight = true;
     return FR_OK;

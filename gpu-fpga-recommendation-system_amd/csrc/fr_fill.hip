@@ -1,4 +1,6 @@
 // Table / weight fills, operand re-packs and reductions: one-off or diagnostic kernels around the hot path.
+#include <type_traits>
+
 #include "fr_device.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -147,6 +149,52 @@ int frk_transpose_slices(const float *gathered, int n_shards, int batch_total, i
         dim3 grid((q_len + 15) / 16, (ldm + 15) / 16);
         transpose_slice_kernel<<<grid, dim3(256), 0, s>>>(reinterpret_cast<const float4 *>(gathered) + (size_t)g * batch_total * FQ, FQ, item0,
                                                          n_items, h_offsets[g] / 4, q_len, reinterpret_cast<float4 *>(Xq), ldm);
+    }
+    KCHECK();
+    return FR_OK;
+}
+
+// Sharded mode with low-precision transport: all-gathered slices [G][B][F] of bf16 (PREC 1: 8 bytes per record word) or e4m3
+// (PREC 2: 4 bytes per word) -> the q8 / q16 operand image for items [item0, item0+n).  The image is zeroed first (fp8 pad rows).
+template <int PREC>
+__global__ void __launch_bounds__(256) transpose_slice_lp_kernel(const void *__restrict__ S /* [B][F/4] words of this shard */, int FQ, int item0, int n_items,
+                                                                  int q_off, int q_len, void *__restrict__ X, int ldm) {
+    typedef typename std::conditional<PREC == 1, uint2, uint32_t>::type word_t;
+    __shared__ word_t tile[16][17];
+    const int q0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    {
+        const int m = m0 + ty, q = q0 + tx;
+        word_t z{};
+        tile[ty][tx] = (m < n_items && q < q_len) ? reinterpret_cast<const word_t *>(S)[(size_t)(item0 + m) * FQ + q] : z;
+    }
+    __syncthreads();
+    {
+        const int q = q0 + ty, m = m0 + tx;
+        if (q < q_len && m < ldm) {
+            const int w = q_off + q;  // record word
+            if constexpr (PREC == 1) reinterpret_cast<uint2 *>(X)[((size_t)(w >> 1) * ldm + m) * 2 + (w & 1)] = tile[tx][ty];
+            else reinterpret_cast<uint32_t *>(X)[((size_t)(w >> 2) * ldm + m) * 4 + (w & 3)] = tile[tx][ty];
+        }
+    }
+}
+
+int frk_transpose_slices_lp(int precision, const void *gathered, int n_shards, int batch_total, int slice_padded, const int *h_offsets, const int *h_lens,
+                            int item0, int n_items, void *X, int K, int ldm, hipStream_t s) {
+    if (slice_padded % 4) FR_FAIL(FR_ERR_INVALID, "slice_padded %d must be a multiple of 4", slice_padded);
+    const int FQ = slice_padded / 4;
+    const size_t esz = precision == FR_FC_BF16 ? 8 : 4;  // bytes per record word on the wire
+    const size_t rows = precision == FR_FC_FP8 ? (size_t)(K + 63) / 64 * 4 : (size_t)K / 8;
+    if (hipMemsetAsync(X, 0, rows * ldm * 16, s) != hipSuccess) FR_FAIL(FR_ERR_HIP, "hipMemsetAsync failed");
+    for (int g = 0; g < n_shards; g++) {
+        const int q_len = h_lens[g] / 4;
+        if (q_len == 0) continue;
+        dim3 grid((q_len + 15) / 16, (ldm + 15) / 16);
+        const char *src = reinterpret_cast<const char *>(gathered) + (size_t)g * batch_total * FQ * esz;
+        if (precision == FR_FC_BF16)
+            transpose_slice_lp_kernel<1><<<grid, dim3(256), 0, s>>>(src, FQ, item0, n_items, h_offsets[g] / 4, q_len, X, ldm);
+        else
+            transpose_slice_lp_kernel<2><<<grid, dim3(256), 0, s>>>(src, FQ, item0, n_items, h_offsets[g] / 4, q_len, X, ldm);
     }
     KCHECK();
     return FR_OK;

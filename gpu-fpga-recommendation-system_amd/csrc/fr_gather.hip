@@ -11,11 +11,25 @@
 // All ITEMS index loads are issued before the row loads, and all row loads before the stores, so a
 // wave keeps ITEMS x 1 KiB of gathers in flight.
 // ---------------------------------------------------------------------------------------------------
-template <int ITEMS>
+// TP = what a record word is stored as: 0 fp32 (16 bytes, a bit copy), 1 bf16 (8 bytes, RNE), 2 e4m3 (4 bytes, x scale, saturated).
+// The low-precision forms are the sharded mode's slice TRANSPORT formats: half / a quarter of the all-gather bytes, and exactly the
+// values the bf16 / fp8 chain would have made of the fp32 slice on arrival.
+template <int TP>
+__device__ __forceinline__ void store_word(void *out, size_t word, const uint4 &v, float scale) {
+    if constexpr (TP == 0) {
+        reinterpret_cast<uint4 *>(out)[word] = v;
+    } else if constexpr (TP == 1) {
+        reinterpret_cast<uint2 *>(out)[word] = make_uint2(pack_bf16x2(__uint_as_float(v.x), __uint_as_float(v.y)), pack_bf16x2(__uint_as_float(v.z), __uint_as_float(v.w)));
+    } else {
+        reinterpret_cast<uint32_t *>(out)[word] = pack_fp8_word(v, scale);
+    }
+}
+
+template <int ITEMS, int TP>
 __global__ void __launch_bounds__(256) gather_pack_kernel(const FrWordDesc *__restrict__ words, int n_words,
                                                           const int32_t *__restrict__ idx, int idx_stride,
-                                                          const float *__restrict__ dense, uint4 *__restrict__ out,
-                                                          int batch, int *__restrict__ err_flag) {
+                                                          const float *__restrict__ dense, void *__restrict__ out,
+                                                          int batch, int *__restrict__ err_flag, float scale) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_words) return;
     const uint4 d0 = reinterpret_cast<const uint4 *>(words)[2 * w];
@@ -49,7 +63,7 @@ __global__ void __launch_bounds__(256) gather_pack_kernel(const FrWordDesc *__re
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const int b = b0 + i;
-        if (b < batch) out[blk + (size_t)b * dst_stride] = v[i];
+        if (b < batch) store_word<TP>(out, blk + (size_t)b * dst_stride, v[i], scale);
     }
     if (bad) atomicOr_system(err_flag, 1);  // pinned host word; error path only
 }
@@ -59,11 +73,11 @@ __global__ void __launch_bounds__(256) gather_pack_kernel(const FrWordDesc *__re
 // ALL items.  Every table is then touched from ONE XCD only, so the 8 x 4 MiB L2s cache 8 different table sets instead of
 // 8 copies of the same hottest 4 MiB -- rows served by L2 cost ~5 cycles/CU instead of ~12 from the fabric
 // (profiles/r01_experiments.md, ta_cost2).
-template <int ITEMS>
+template <int ITEMS, int TP>
 __global__ void __launch_bounds__(256) gather_pack_xcd_kernel(const FrWordDesc *__restrict__ words, int n_words, int words_per_group,
                                                               const int32_t *__restrict__ idx, int idx_stride,
-                                                              const float *__restrict__ dense, uint4 *__restrict__ out,
-                                                              int batch, int *__restrict__ err_flag) {
+                                                              const float *__restrict__ dense, void *__restrict__ out,
+                                                              int batch, int *__restrict__ err_flag, float scale) {
     const int group = blockIdx.x & 7, chunk = blockIdx.x >> 3;
     const int w = group * words_per_group + threadIdx.x;
     if ((int)threadIdx.x >= words_per_group || w >= n_words) return;
@@ -97,14 +111,14 @@ __global__ void __launch_bounds__(256) gather_pack_xcd_kernel(const FrWordDesc *
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const int b = b0 + i;
-        if (b < batch) out[blk + (size_t)b * dst_stride] = v[i];
+        if (b < batch) store_word<TP>(out, blk + (size_t)b * dst_stride, v[i], scale);
     }
     if (bad) atomicOr_system(err_flag, 1);
 }
 
-int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, float *out,
-               int batch, int *err_flag, hipStream_t s) {
-    if (n_words <= 0 || batch <= 0) return FR_OK;
+template <int TP>
+static int gather_launch(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
+                         float scale, hipStream_t s) {
     static const int force = getenv("FR_GATHER_XCD") ? atoi(getenv("FR_GATHER_XCD")) : -1;  // experiment knob
     const bool xcd = force >= 0 ? force != 0 : (n_words >= 512 && batch >= 1024);
     if (xcd) {
@@ -113,7 +127,7 @@ int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx
         if (wpg <= 256) {
             const int bx = ((wpg + 63) / 64) * 64;
             dim3 grid(8 * ((batch + ITEMS - 1) / ITEMS));
-            gather_pack_xcd_kernel<ITEMS><<<grid, dim3(bx), 0, s>>>(words, n_words, wpg, idx, idx_stride, dense, (uint4 *)out, batch, err_flag);
+            gather_pack_xcd_kernel<ITEMS, TP><<<grid, dim3(bx), 0, s>>>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale);
             KCHECK();
             return FR_OK;
         }
@@ -124,13 +138,21 @@ int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx
     if (batch >= 2048) {
         constexpr int ITEMS = 8;
         dim3 grid((n_words + bx - 1) / bx, (batch + ITEMS - 1) / ITEMS);
-        gather_pack_kernel<ITEMS><<<grid, block, 0, s>>>(words, n_words, idx, idx_stride, dense, (uint4 *)out, batch, err_flag);
+        gather_pack_kernel<ITEMS, TP><<<grid, block, 0, s>>>(words, n_words, idx, idx_stride, dense, out, batch, err_flag, scale);
     } else {
         constexpr int ITEMS = 4;
         dim3 grid((n_words + bx - 1) / bx, (batch + ITEMS - 1) / ITEMS);
-        gather_pack_kernel<ITEMS><<<grid, block, 0, s>>>(words, n_words, idx, idx_stride, dense, (uint4 *)out, batch, err_flag);
+        gather_pack_kernel<ITEMS, TP><<<grid, block, 0, s>>>(words, n_words, idx, idx_stride, dense, out, batch, err_flag, scale);
     }
     KCHECK();
     return FR_OK;
 }
 
+// transport: FR_FC_FP32 (fp32 records, the reference's wire format), FR_FC_BF16 or FR_FC_FP8 (slice transport of the sharded mode)
+int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
+               int transport, int e_x, hipStream_t s) {
+    if (n_words <= 0 || batch <= 0) return FR_OK;
+    if (transport == FR_FC_BF16) return gather_launch<1>(words, n_words, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s);
+    if (transport == FR_FC_FP8) return gather_launch<2>(words, n_words, idx, idx_stride, dense, out, batch, err_flag, ldexpf(1.0f, e_x), s);
+    return gather_launch<0>(words, n_words, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s);
+}

@@ -208,8 +208,10 @@ static inline uint32_t fr_table_uid(const fr_table_desc &t) {
 }
 int frk_fill_table(float *base, int64_t rows, int dim, int mode, uint32_t seed, uint32_t uid, hipStream_t s);
 int frk_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t layer, float scale, hipStream_t s);
-int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense,
-               float *out, int batch, int *err_flag, hipStream_t s);
+int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
+               int transport, int e_x, hipStream_t s);
+int frk_transpose_slices_lp(int precision, const void *gathered, int n_shards, int batch_total, int slice_padded, const int *h_offsets, const int *h_lens,
+                            int item0, int n_items, void *X, int K, int ldm, hipStream_t s);
 // feature-major FC chain, stage-pipelined across batches (see fr_pipeline.hip)
 int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, int precision, hipStream_t s);
 int frk_pack_weights_q8_bf16(const float *W, uint16_t *Wh, int K, int H, hipStream_t s);

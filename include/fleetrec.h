@@ -312,6 +312,12 @@ int fr_model_shard_plan(const fr_model_desc *m, int n_shards, int *slice_offset,
  * Runs the FC chain for items [item0, item0+n_items) of the batch on this GPU (FC weights are replicated);
  * d_scores receives n_items floats.  Asynchronous on the worker's stream; follow with fr_worker_sync(). */
 int fr_worker_fc_from_slices(fr_worker *w, int batch_total, int item0, int n_items, const float *d_gathered, float *d_scores);
+/* Low-precision slice TRANSPORT for the sharded mode: the shard's slice as bf16 (2 bytes per float) or e4m3 (1 byte, scaled by the
+ * context's X exponent) -- half / a quarter of the all-gather bytes -- and the FC entry point that consumes [n_shards][batch_total]
+ * [slice_padded] elements of that type.  transport = fr_fc_precision; it must equal the context's FC precision (FR_FC_FP32 falls
+ * back to fr_worker_gather_only / fr_worker_fc_from_slices).  Scores are bit-identical to fp32 transport in the same precision. */
+int fr_worker_gather_slices(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, void *d_slice, int transport);
+int fr_worker_fc_from_slices_lp(fr_worker *w, int batch_total, int item0, int n_items, const void *d_gathered, int transport, float *d_scores);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

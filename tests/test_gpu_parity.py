@@ -599,6 +599,34 @@ def test_table_sharded_mode_single_device_emulation(fr, O, gpu, which, G):
             wk.sync()
             lp[lo:hi] = d_s.download(np.float32, hi - lo)
         assert rel_err(lp, ref) <= tol32, (prec, rel_err(lp, ref))
+        # low-precision TRANSPORT: the shards emit bf16 / e4m3 slices (half / a quarter of the all-gather bytes); they are exactly the
+        # values the chain made of the fp32 slices above, so the scores do not change by a bit
+        esz, dt = (2, np.uint16) if prec == fr.FC_BF16 else (1, np.uint8)
+        lp_slices = []
+        d_i = None
+        for r, (c, wk) in enumerate(ctxs_):
+            d_i = fr.DeviceBuffer.from_numpy(c, idx)
+            d_d = fr.DeviceBuffer.from_numpy(c, dense) if dense is not None else None
+            d_sl = fr.DeviceBuffer(c, B * F * esz)
+            wk.gather_slices(B, d_i, d_d, d_sl, prec)
+            wk.sync()
+            lp_slices.append(d_sl.download(dt, B * F).reshape(B, F))
+        if prec == fr.FC_BF16:   # the wire format itself: RNE of the fp32 slice
+            for r in range(G):
+                want16 = (bf16_round(slices[r].view(np.float32)).view(np.uint32) >> 16).astype(np.uint16)
+                assert np.array_equal(lp_slices[r][:, :lens[r]], want16[:, :lens[r]])
+        g_lp = np.stack(lp_slices)
+        tr = np.empty(B, np.float32)
+        for r, (c, wk) in enumerate(ctxs_):
+            lo, hi = dist_mod.item_range(r, G, B)
+            d_g = fr.DeviceBuffer.from_numpy(c, g_lp)
+            d_s = fr.DeviceBuffer(c, max(hi - lo, 1) * 4)
+            wk.fc_from_slices_lp(B, lo, hi - lo, d_g, prec, d_s)
+            wk.sync()
+            tr[lo:hi] = d_s.download(np.float32, hi - lo)
+        assert np.array_equal(tr, lp), prec
+        with pytest.raises(fr.FleetRecError):   # the transport type must be the chain's precision
+            ctxs_[0][1].fc_from_slices_lp(B, 0, 1, d_g, fr.FC_BF16 if prec == fr.FC_FP8 else fr.FC_FP8, d_s)
         c0.set_fc_precision(prec)
         w0 = fr.Worker(c0, B)
         if prec == fr.FC_FP8:
