@@ -118,25 +118,39 @@ def main_sharded(args):
         else:
             wk_fc.fc_from_slices_lp(B, lo, hi - lo, gathered[k].data_ptr(), tp, scores.data_ptr())
 
-    state = {"pending": None}   # buffer set whose slices are gathered + exchanged and wait for their FC chain
+    # Stream-ordered hand-over, no host synchronisation inside a step: the gather worker's stream, torch's exchange stream and the FC
+    # worker's stream wait for one another through events (torch.cuda.ExternalStream wraps the workers' hipStream_t).
+    s_gather = torch.cuda.ExternalStream(wk.stream_ptr(), device=dev)
+    s_fc = torch.cuda.ExternalStream(wk_fc.stream_ptr(), device=dev)
+    s_x = torch.cuda.Stream(device=dev)            # the exchange (RCCL) stream
+    state = {"pending": None, "fc_done": [None, None]}   # pending: buffer set gathered + exchanged, waiting for its FC chain
 
     def step(i):
         k = i & 1
+        if state["fc_done"][k] is not None:
+            s_gather.wait_event(state["fc_done"][k])   # the FC chain that read gathered[k] / local[k] two steps ago has finished
         wk.gather_slices(B, idxs[i % nbuf], dns[i % nbuf], local[k].data_ptr(), prec_enum if lp else fr.FC_FP32)   # async, gather worker's stream
         if state["pending"] is not None:
-            fc(state["pending"])                                                     # async on the FC worker's stream: overlaps
-        wk.sync()                                      # the slice must be complete before RCCL reads it (different stream)
-        exchange(k)
-        torch.cuda.synchronize()                       # exchange done (torch's stream); the FC of the previous batch may still run
-        if state["pending"] is not None:
-            wk_fc.sync()
+            p = state["pending"]
+            s_fc.wait_stream(s_x)                      # its exchange has landed
+            fc(p)                                      # async on the FC worker's stream: overlaps this step's gather + exchange
+            ev = torch.cuda.Event()
+            ev.record(s_fc)
+            state["fc_done"][p] = ev
+        s_x.wait_stream(s_gather)                      # the slice must be complete before RCCL reads it
+        with torch.cuda.stream(s_x):
+            exchange(k)
         state["pending"] = k
 
     def drain():
         if state["pending"] is not None:
+            s_fc.wait_stream(s_x)
             fc(state["pending"])
-            wk_fc.sync()
             state["pending"] = None
+        wk.sync()
+        wk_fc.sync()
+        torch.cuda.synchronize()
+        state["fc_done"] = [None, None]
 
     if args.precision != "f32":   # the slices travel as fp32; the FC chain re-packs them to bf16 / e4m3 operands
         ctx.set_fc_precision(fr.FC_BF16 if args.precision == "bf16" else fr.FC_FP8)
@@ -165,6 +179,17 @@ def main_sharded(args):
     drain()                                            # the last batch's FC chain is inside the timed region
     env.barrier(); torch.cuda.synchronize(); ctx.synchronize()
     dt = env.max_over_ranks(time.perf_counter() - t0)
+    # outside the timed region: the last pipelined batch against the same batch run step by step with host synchronisation
+    piped = scores.clone()
+    last = args.steps - 1
+    wk.gather_slices(B, idxs[last % nbuf], dns[last % nbuf], local[0].data_ptr(), prec_enum if lp else fr.FC_FP32)
+    wk.sync()
+    exchange(0)
+    torch.cuda.synchronize()
+    fc(0)
+    wk_fc.sync()
+    torch.cuda.synchronize()
+    verified = bool(torch.equal(piped, scores)) if args.steps > 0 else None
     if r == 0:
         print(json.dumps({
             "metric": "inferences/sec, Model-C batch 4096, tables sharded by table-ID", "value": B * args.steps / dt, "unit": "inferences/s",
@@ -172,7 +197,7 @@ def main_sharded(args):
             "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "Model-C batch=%d, %d-way table-ID shards (slice F=%d floats), 1 all-gather of [B x F] per step, "
                                    "FC on B/G items per rank" % (B, G, F), "parallelism": "table-sharded x%d" % G, "exchange": args.exchange,
-                       "slice_transport": args.precision if lp else "f32",
+                       "slice_transport": args.precision if lp else "f32", "pipelined_equals_stepwise": verified,
                        "exchange_bytes_in_per_rank_per_step": int(G * (B // G if a2a else B) * F * esz)}}))
     wk.close()
     wk_fc.close()

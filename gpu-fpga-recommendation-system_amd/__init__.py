@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "fr_model_table_bytes", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
     "fr_ctx_fill_tables", "fr_ctx_upload_table", "fr_ctx_download_table", "fr_ctx_set_weights", "fr_ctx_fill_weights",
     "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_ctx_get_fp8_exponents", "fr_ctx_set_fp8_act_exponents",
-    "fr_worker_calibrate_fp8", "fr_worker_calibrate_fp8_slices", "fr_worker_push_host", "fr_worker_gather_slices", "fr_worker_fc_from_slices_lp", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
+    "fr_worker_calibrate_fp8", "fr_worker_calibrate_fp8_slices", "fr_worker_push_host", "fr_worker_stream", "fr_worker_gather_slices", "fr_worker_fc_from_slices_lp", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
     "fr_worker_dense_ptr", "fr_worker_score_ptr", "fr_worker_submit", "fr_worker_submit_device", "fr_worker_push_device", "fr_worker_sync",
     "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
@@ -93,7 +93,7 @@ def lib():
         "fr_ctx_set_weights": (i32, [vp, i32, vp, sz]), "fr_ctx_fill_weights": (i32, [vp, i32, u32]),
         "fr_ctx_get_weights": (i32, [vp, i32, vp, sz]), "fr_ctx_set_fc_precision": (i32, [vp, i32]),
         "fr_ctx_get_fp8_exponents": (i32, [vp, vp, vp]), "fr_ctx_set_fp8_act_exponents": (i32, [vp, vp]),
-        "fr_worker_push_host": (i32, [vp, i32, vp, vp, vp]),
+        "fr_worker_push_host": (i32, [vp, i32, vp, vp, vp]), "fr_worker_stream": (vp, [vp]),
         "fr_worker_gather_slices": (i32, [vp, i32, vp, vp, vp, i32]), "fr_worker_fc_from_slices_lp": (i32, [vp, i32, i32, i32, vp, i32, vp]),
         "fr_worker_calibrate_fp8": (i32, [vp, i32]), "fr_worker_calibrate_fp8_slices": (i32, [vp, i32, i32, i32, vp]),
         "fr_worker_create": (i32, [vp, i32, ctypes.POINTER(vp)]), "fr_worker_destroy": (None, [vp]),
@@ -483,6 +483,10 @@ class Worker:
 
     def fc_from_slices(self, batch_total, item0, n_items, d_gathered, d_scores):
         _check(lib().fr_worker_fc_from_slices(self._h, batch_total, item0, n_items, self._ptr(d_gathered), self._ptr(d_scores)))
+
+    def stream_ptr(self):
+        """The worker's hipStream_t as an integer (torch.cuda.ExternalStream(ptr) orders torch streams against it)."""
+        return lib().fr_worker_stream(self._h)
 
     def gather_slices(self, batch, d_idx, d_dense, d_slice, transport):
         _check(lib().fr_worker_gather_slices(self._h, batch, self._ptr(d_idx), self._ptr(d_dense), self._ptr(d_slice), transport))

@@ -507,6 +507,7 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
 extern "C" int32_t *fr_worker_idx_ptr(fr_worker *w) { return w ? w->h_idx : nullptr; }
 extern "C" float *fr_worker_dense_ptr(fr_worker *w) { return w ? w->h_dense : nullptr; }
 extern "C" float *fr_worker_score_ptr(fr_worker *w) { return w ? w->h_score : nullptr; }
+extern "C" void *fr_worker_stream(fr_worker *w) { return w ? (void *)w->stream : nullptr; }
 extern "C" float *fr_worker_records_dptr(fr_worker *w) { return w ? w->d_records : nullptr; }
 extern "C" float *fr_worker_features_dptr(fr_worker *w, int *ld_max) {
     if (!w) return nullptr;

@@ -204,6 +204,9 @@ void fr_worker_destroy(fr_worker *w);
 int32_t *fr_worker_idx_ptr(fr_worker *w);
 float *fr_worker_dense_ptr(fr_worker *w);
 float *fr_worker_score_ptr(fr_worker *w);
+/* The worker's HIP stream (a hipStream_t), so that a host framework can order its own streams against the worker's without a
+ * host synchronisation (e.g. torch.cuda.ExternalStream for the RCCL exchange of the sharded mode). */
+void *fr_worker_stream(fr_worker *w);
 
 /* ---- hot loop body (cuda_server.c:460-495) --------------------------------------------------- */
 /* Asynchronous: idx(+dense) H2D -> gather+pack -> 4-GEMM FC chain -> score D2H on the worker's
