@@ -1067,7 +1067,6 @@ static int host_block_launch(fr_worker *w) {
     fr_worker::HostRing &r = w->hr;
     const int b = r.cur, n = r.count[b];
     if (n == 0) return FR_OK;
-    fr_ctx *c = w->ctx;
     int rc = fused_flush(w);  // batches queued by fr_worker_push_device go first
     if (rc) return rc;
     const size_t s0 = (size_t)b * r.g;
@@ -1087,7 +1086,6 @@ static int host_block_launch(fr_worker *w) {
     FR_HIP(hipEventRecord(r.ev[b], w->stream));
     r.inflight[b] = true;
     r.cur = (b + 1) % FR_HOST_BLOCKS;
-    (void)c;
     return FR_OK;
 }
 
