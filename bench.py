@@ -1,19 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on BASELINE.json's config.
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config, plus the evidence legs VERDICT r01 asked for.
 
-metric  : inferences/sec at batch 256 (Model-A = embedding_47_krnl tables + FC 352-1024-512-256-1, fp32 FC),
-          all tables resident in one GPU's HBM (BASELINE configs[1]); plus the embedding-gather HBM GB/s
-          against peak on the largest model (Model-C, batch 4096) as the extra "gather" object.
-step    : one pass of the hot path (index rows -> gather+pack -> 4-GEMM FC chain -> scores) over one batch
-          of 256 synthetic requests whose index rows are already resident in HBM.
-N > 1   : the path shards by independent request batches -> one replica per GPU, no data-path collective
-          ("scaling": "weak"); value = batches all ranks processed / max-over-ranks time.
+metric  : inferences/sec at batch 256 (Model-A = embedding_47_krnl tables + FC 352-1024-512-256-1, fp32 FC), all tables
+          resident in one GPU's HBM (BASELINE configs[1]); plus the embedding-gather HBM GB/s against peak on the largest
+          model (Model-C, batch 4096) as the "gather" object.
+step    : one pass of the hot path (index rows -> gather+pack -> 4-GEMM FC chain -> scores) over one batch of 256 synthetic
+          requests whose index rows are already resident in HBM when the timed region starts (bench contract).
+value   : STEADY-STATE rate: whatever --steps says, the timed region runs back-to-back batches for >= 2 s of wall clock
+          (SURVEY 8(d)); `timed_batches` / `timed_s` say how many and how long, `ms_per_step` = timed_s / timed_batches.  The
+          figure for EXACTLY --steps batches after --warmup batches is reported beside it as `burst` (with the driver's
+          --steps 20 that is a launch-latency number: 20 batches do not even fill one fused launch group).
+          `pcie_inclusive_streaming` is the same request stream starting in HOST memory with scores delivered to HOST memory
+          (the reference loop's H2D / D2H included, cuda_server.c:460-461,494-495): reported next to `value`, never as it.
+N > 1   : the path shards by independent request batches -> one replica per GPU, no data-path collective ("scaling":
+          "weak"); value = batches all ranks processed / max-over-ranks time.  Launched by torchrun (RANK / WORLD_SIZE in
+          the environment) or, when WORLD_SIZE is unset, by this script itself: the parent starts N rank processes BEFORE
+          anything touches the GPU and never touches it itself.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,95 +33,399 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import __graft_entry__ as graft  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-MFMA_F32_PEAK_TF = 157.3   # dense f32-input MFMA peak (same guide)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0}   # dense MFMA peaks (same guide; no 2:1 sparsity)
 SEED_TABLES, SEED_IDX, SEED_WEIGHTS = 0xF1EE7, 1234, 99
-N_IDX_BUFFERS = 32         # distinct index buffers rotated through, so caches are not re-hit artificially
+N_IDX_BUFFERS = 64           # distinct index buffers rotated through (>= 32), so caches are not re-hit artificially
+STEADY_S = 2.2               # minimum wall clock of the timed region behind `value`
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# multi-GPU self-launch (no GPU call may precede this)
+# ------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE: start N fresh rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set) and wait for them.  The parent has not imported the library or torch.cuda at this point and never does."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "FR_BENCH_SELF_LAUNCHED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------------------------
 def gather_bytes_per_inference(model, fr):
-    """row reads + index reads + dense read + record write."""
+    """row reads + index reads + dense read + record write (index reads follow the index mode)."""
     rows = sum(s.len * 4 for s in model.segments() if s.kind != fr.SEG_DENSE)
-    idx = 4 * model.n_tables
-    dense = 4 * model.dense_len
-    write = 4 * model.record_len
-    return rows + idx + dense + write
-
-
-def pmc_field(kernel_prefix, field):
-    """A per-kernel figure of the committed PMC summary (mfma_busy_fraction, mfma_f32_flops_per_launch, l2_hit_rate ...) or None."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        for k, v in d.items():
-            if k.startswith(kernel_prefix) and field in v:
-                return v[field]
-    except Exception:
-        pass
-    return None
-
-
-def pmc_traffic(kernel_prefix):
-    """HBM/fabric bytes per launch from the committed PMC summary (tools/pmc_traffic.sh: separate rocprofv3 --pmc passes over
-    this same bench command, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md) -- or None."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        for k, v in d.items():
-            if k.startswith(kernel_prefix) and "traffic_bytes_per_launch" in v:
-                return v["traffic_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+    return rows + 4 * model.idx_cols + 4 * model.dense_len + 4 * model.record_len
 
 
 def fc_flops_per_inference(fc):
     return 2 * sum(fc[i] * fc[i + 1] for i in range(4))
 
 
-def main_sharded(args):
-    """BASELINE configs[3]: Model-C, batch 4096, tables sharded by table-ID over the ranks; per step every rank gathers its
-    [B x F] slice, ONE RCCL all-gather over xGMI rebuilds the records on every GPU, rank r runs the FC chain on its B/G items.
+def pmc(key, field=None):
+    """Committed PMC summary (tools/pmc_passes.sh -> profiles/r02_pmc.json): separate rocprofv3 --pmc passes of this script's legs,
+    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md.  -> the entry, one field of it, or None."""
+    try:
+        e = json.load(open(PMC_FILE)).get(key)
+        return e if (field is None or e is None) else e.get(field)
+    except Exception:
+        return None
+
+
+def uniform_idx(rng, ranges, B):
+    return (rng.random((B, len(ranges))) * ranges[None, :]).astype(np.int32)
+
+
+def zipf_idx(rng, rows, B, alpha=1.05):
+    u = rng.random((B, len(rows)))
+    x = ((rows[None, :].astype(np.float64) ** (1.0 - alpha) - 1.0) * u + 1.0) ** (1.0 / (1.0 - alpha))
+    return np.minimum(np.floor(x) - 1, rows[None, :] - 1).astype(np.int32)
+
+
+def steady_run(run_fn, min_s, n_first=4096, env=None, quantum=256):
+    """Time run_fn(n) (-> elapsed seconds of n back-to-back batches) for at least min_s: a calibration run sizes n."""
+    el = run_fn(n_first)
+    n = max(n_first, int(n_first / max(el, 1e-6) * min_s))
+    n = (n + quantum - 1) // quantum * quantum
+    if env is not None:
+        n = int(env.max_over_ranks(n))
+    return n
+
+
+def time_launches(wk, push, per_launch, launches, warm_launches=4):
+    """HIP events on the worker's own stream around `launches` launches (push(i) enqueues one batch; per_launch of them make
+    one launch).  -> average launch duration in ms."""
+    for i in range(warm_launches * per_launch):
+        push(i)
+    wk.sync()
+    wk.timer_start()
+    for i in range(launches * per_launch):
+        push(i)
+    ms = wk.timer_stop_ms() / launches
+    wk.sync()
+    return ms
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline: memory-resident OpenMP gather + OpenBLAS sgemm chain (checker side; rank 0, N = 1 only)
+# ------------------------------------------------------------------------------------------------------------------
+def load_blas():
+    """BASELINE.md section 2 probe order: a system libopenblas (cblas_sgemm, LP64) -> numpy's bundled libscipy_openblas64_
+    (scipy_cblas_sgemm64_, ILP64) -> scipy's bundled libscipy_openblas (scipy_cblas_sgemm, LP64) -> None (torch.mm on CPU)."""
+    import ctypes.util
+    cands = []
+    p = ctypes.util.find_library("openblas")
+    if p:
+        cands.append((p, "cblas_sgemm", ctypes.c_int, "openblas_get_config", "openblas_get_num_threads"))
+    for pat in ("/usr/lib/x86_64-linux-gnu/libopenblas.so*", "/usr/lib64/libopenblas.so*", "/usr/lib/libopenblas.so*", "/opt/*/lib/libopenblas.so*"):
+        for f in sorted(glob.glob(pat)):
+            cands.append((f, "cblas_sgemm", ctypes.c_int, "openblas_get_config", "openblas_get_num_threads"))
+    npd = os.path.join(os.path.dirname(os.path.dirname(np.__file__)), "numpy.libs")
+    for f in sorted(glob.glob(os.path.join(npd, "libscipy_openblas64_*.so"))):
+        cands.append((f, "scipy_cblas_sgemm64_", ctypes.c_int64, "scipy_openblas_get_config64_", "scipy_openblas_get_num_threads64_"))
+    try:
+        import scipy
+        spd = os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs")
+        for f in sorted(glob.glob(os.path.join(spd, "libscipy_openblas-*.so"))):
+            cands.append((f, "scipy_cblas_sgemm", ctypes.c_int, "scipy_openblas_get_config", "scipy_openblas_get_num_threads"))
+    except Exception:
+        pass
+    for path, sym, itype, cfg, nthr in cands:
+        try:
+            L = ctypes.CDLL(path)
+            fn = getattr(L, sym)
+        except Exception:
+            continue
+        fp = ctypes.POINTER(ctypes.c_float)
+        fn.restype = None
+        fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, itype, itype, itype, ctypes.c_float, fp, itype, fp, itype, ctypes.c_float, fp, itype]
+        ident, threads = os.path.basename(path), None
+        try:
+            g = getattr(L, cfg)
+            g.restype = ctypes.c_char_p
+            ident += ": " + g().decode()
+            t = getattr(L, nthr)
+            t.restype = ctypes.c_int
+            threads = int(t())
+        except Exception:
+            pass
+        return {"sgemm": fn, "name": ident, "symbol": sym, "threads": threads}
+    return None
+
+
+def cpu_fc_chain(blas, X, ws, fc, bufs):
+    """cuda_server.c:468-491 on the host: R1 = W1*X, R2 = W2*R1, R3 = W3*R2, out = Wout*R3, column-major, alpha = 1, beta = 0.
+    X: float32 [B][K] (= column-major K x B); ws[l]: column-major H x K flattened; bufs: pre-allocated R1..R3, out."""
+    B = X.shape[0]
+    fp = ctypes.POINTER(ctypes.c_float)
+    src = X
+    for l in range(4):
+        H, K = fc[l + 1], fc[l]
+        dst = bufs[l]
+        if blas is None:
+            import torch
+            w = torch.from_numpy(ws[l]).view(K, H)                     # element (h, k) at [k][h]
+            torch.mm(torch.from_numpy(src).view(B, K), w, out=torch.from_numpy(dst).view(B, H))
+        else:   # CblasColMajor = 102, CblasNoTrans = 111: C (H x B, ld H) = A (H x K, ld H) * B (K x B, ld K)
+            blas["sgemm"](102, 111, 111, H, B, K, 1.0, ws[l].ctypes.data_as(fp), H, src.ctypes.data_as(fp), K, 0.0, dst.ctypes.data_as(fp), H)
+        src = dst
+    return bufs[3]
+
+
+def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=2.5):
+    """Model-A on the node's host cores: tables materialised in host RAM exactly as host.cpp lays out the card's banks (1.4 GB),
+    OpenMP gather that READS them, sgemm chain through OpenBLAS over the same 64 x 256 = 16384-item grouping one GPU launch
+    gets.  Three figures: gather-only, FC-only, end-to-end (each >= budget_s of wall clock)."""
+    O = graft.load_oracle()
+    om = O.OracleModel("A")
+    h = om.halves[0]
+    t0 = time.perf_counter()
+    imgs = h.bank_images_native(O.FILL_HASH, SEED_TABLES)
+    t_fill = time.perf_counter() - t0
+    group = 64
+    idx = np.concatenate(idx_host[:group], axis=0)                      # [16384][47] in wire order
+    hidx = np.empty_like(idx)
+    hidx[:, h.wire_to_round] = idx                                       # wire order -> (bank, round) order
+    n = idx.shape[0]
+    ws = [ctx.get_weights(l) for l in range(4)]
+    fc = model.fc
+    rec = np.empty((n, h.record_len), dtype=np.uint32)
+    bufs = [np.empty((n, fc[l + 1]), dtype=np.float32) for l in range(4)]
+    blas = load_blas()
+    threads = O.lib().oracle_num_threads()
+
+    def timed(fn):
+        fn()
+        reps, t_begin = 0, time.perf_counter()
+        while True:
+            fn()
+            reps += 1
+            el = time.perf_counter() - t_begin
+            if el >= budget_s and reps >= 2:
+                return n * reps / el, reps
+
+    g_rate, g_reps = timed(lambda: h.gather_direct(hidx, True, imgs, out=rec))
+    X = rec.view(np.float32)
+    f_rate, f_reps = timed(lambda: cpu_fc_chain(blas, X, ws, fc, bufs))
+    e_rate, e_reps = timed(lambda: (h.gather_direct(hidx, True, imgs, out=rec), cpu_fc_chain(blas, X, ws, fc, bufs)))
+    cpu_scores = bufs[3].ravel()[:B].copy()
+    err = float(np.abs(cpu_scores - gpu_scores_first).max() / max(np.abs(cpu_scores).max(), 1e-30)) if gpu_scores_first is not None else None
+    gbytes = 1408 + 188 + 1408
+    return {"value": e_rate, "unit": "inferences/s", "cores": threads, "kind": "port",
+            "gather_only": g_rate, "fc_only": f_rate, "end_to_end": e_rate,
+            "gather_GBps_algorithmic": g_rate * gbytes / 1e9, "fc_GFLOPs": f_rate * fc_flops_per_inference(fc) / 1e9,
+            "blas": blas["name"] if blas else "torch.mm (" + __import__("torch").__config__.parallel_info().split("\n")[0] + ")",
+            "blas_symbol": blas["symbol"] if blas else "torch.mm", "blas_threads": blas["threads"] if blas else None,
+            "gpu_vs_cpu_max_rel_err_first_batch": err, "host_table_bytes": int(sum(im.nbytes for im in imgs)), "host_table_fill_s": t_fill,
+            "sample": "Model-A, %d items per call (64 batches of 256, the grouping one fused GPU launch gets), same seeded indices / tables / weights; "
+                      "gather-only %d calls, FC-only %d, end-to-end %d (>= %.1f s each); gather = OpenMP over items reading bank images in host RAM "
+                      "(oracle_gather_banks_direct), FC = 4 chained column-major sgemm calls" % (n, g_reps, f_reps, e_reps, budget_s)}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU legs
+# ------------------------------------------------------------------------------------------------------------------
+def leg_group_table(fr, ctx, model, B, d_idx, threads, depth):
+    """Model-A batch 256 fp32: throughput and latency against the launch group (batches per fused launch)."""
+    out = []
+    flops = fc_flops_per_inference(model.fc) * B
+    for g in (1, 8, 32, 64):
+        ctx.set_stream_group(g)
+        dv = fr.Driver(ctx, threads, depth, B)
+        dv.run_resident(B, 2048, d_idx)
+        n = steady_run(lambda k: dv.run_resident(B, k, d_idx), 0.5, n_first=4096)
+        el = dv.run_resident(B, n, d_idx)
+        dv.close()
+        wk = fr.Worker(ctx, B)
+        ring = [fr.DeviceBuffer(ctx, B * 4) for _ in range(2 * g)]
+        push = lambda i: wk.push_device(B, d_idx[i % len(d_idx)], None, ring[i % len(ring)])
+        ms = time_launches(wk, push, g, 200 if g > 1 else 1000, warm_launches=50)
+        lat = []
+        for _ in range(40):                      # idle worker: first push -> all g batches' scores complete (queueing + launch + sync)
+            t0 = time.perf_counter()
+            for i in range(g):
+                push(i)
+            wk.sync()
+            lat.append(time.perf_counter() - t0)
+        wk.close()
+        for b_ in ring:
+            b_.free()
+        out.append({"group": g, "inferences_per_s": n * B / el, "launch_ms_one_stream": ms, "tflops_one_stream": flops * g / (ms * 1e-3) / 1e12,
+                    "push_to_scores_ms_p50": 1e3 * float(np.median(lat)), "push_to_scores_ms_p90": 1e3 * float(np.percentile(lat, 90))})
+    ctx.set_stream_group(64)
+    return out
+
+
+def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_host0, threads, depth, label):
+    """One non-headline BASELINE configuration: steady-state throughput (>= 1 s) + an in-run roofline object for its dominant
+    kernel from HIP events on one worker's stream."""
+    prec_enum = {"f32": fr.FC_FP32, "bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[precision]
+    ctx.set_fc_precision(prec_enum)
+    if precision == "fp8":
+        cal = fr.Worker(ctx, B)
+        cal.calibrate_fp8(idx_host0, dense_host0)
+        cal.close()
+    fc = model.fc
+    flops_inf = fc_flops_per_inference(fc)
+    dv = fr.Driver(ctx, threads, depth, B)
+    dv.run_resident(B, 256, d_idx, d_dense)
+    n = steady_run(lambda k: dv.run_resident(B, k, d_idx, d_dense), 1.0, n_first=512, quantum=64)
+    el = dv.run_resident(B, n, d_idx, d_dense)
+    dv.close()
+    res = {"workload": label, "dtype": precision, "value": n * B / el, "unit": "inferences/s", "timed_batches": n, "timed_s": el,
+           "ms_per_step": 1e3 * el / n, "fc_tflops_end_to_end": flops_inf * B * n / el / 1e12,
+           "frac_of_mfma_peak_end_to_end": flops_inf * B * n / el / 1e12 / MFMA_PEAK_TF[precision]}
+    wk = fr.Worker(ctx, B)
+    group = ctx.stream_group()
+    if group > 1:   # fused item-tile kernel: one launch = the whole hot path of min(group, 16384 / B) queued batches
+        per_launch = max(1, min(group, 16384 // B))
+        ring = [fr.DeviceBuffer(ctx, B * 4) for _ in range(2 * per_launch)]
+        push = lambda i: wk.push_device(B, d_idx[i % len(d_idx)], d_dense[i % len(d_dense)] if d_dense else None, ring[i % len(ring)])
+        ms = time_launches(wk, push, per_launch, 100, warm_launches=30)
+        flops = flops_inf * B * per_launch
+        kname = {"f32": "fr_fused_tile_kernel / fr_fused_tile_m2_kernel", "bf16": "fr_fused_tile_h_kernel", "fp8": "fr_fused_tile_f8_kernel"}[precision]
+        what = "%s: one launch = gather + 4-GEMM chain of %d queued batches of %d, back-to-back on ONE stream" % (kname, per_launch, B)
+        for b_ in ring:
+            b_.free()
+    else:           # stage pipeline: FC1 runs as its own LDS-tiled GEMM launch (fc_lp_gemm_kernel) -- the dominant kernel
+        d_sc = fr.DeviceBuffer(ctx, B * 4)
+        wk.submit_device(B, d_idx[0], d_dense[0] if d_dense else None, d_sc)
+        wk.sync()
+        layer_ms = []
+        for layer in range(4):
+            for _ in range(10):
+                wk.fc_layer_only(B, layer)
+            wk.sync()
+            wk.timer_start()
+            for _ in range(50):
+                wk.fc_layer_only(B, layer)
+            layer_ms.append(wk.timer_stop_ms() / 50)
+            wk.sync()
+        ms = layer_ms[0]
+        flops = 2 * fc[0] * fc[1] * B
+        what = "fc_lp_gemm_kernel<%d, 2> (FC1: %d x %d x %d) alone on ONE stream" % (prec_enum, fc[0], fc[1], B)
+        res["layer_launch_ms"] = layer_ms
+        d_sc.free()
+    wk.close()
+    ach = flops / (ms * 1e-3) / 1e12
+    res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TF[precision], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TF[precision],
+                       "traffic": None, "kernel": what, "avg_launch_ms": ms, "algorithmic_flops_per_launch": flops}
+    return res
+
+
+def leg_gather(fr, ctx, model, B, law, reps=200, nbuf=32, seed=SEED_IDX):
+    """fr_worker_gather_only (record-producing gather, the section-8(d) roofline kernel) at Model-C batch 4096: `nbuf` rotating
+    index buffers, `reps` timed launches, HIP events on the worker's stream."""
+    rng = np.random.default_rng(seed)
+    ranges = model.index_ranges()
+    mk = (lambda: zipf_idx(rng, ranges, B)) if law == "zipf" else (lambda: uniform_idx(rng, ranges, B))
+    host = [mk() for _ in range(nbuf)]
+    idxs = [fr.DeviceBuffer.from_numpy(ctx, a) for a in host]
+    dns = [fr.DeviceBuffer.from_numpy(ctx, rng.uniform(-1, 1, (B, model.dense_len)).astype(np.float32)) for _ in range(nbuf)] if model.dense_len else None
+    wk = fr.Worker(ctx, B)
+    rec = wk.records_dptr()
+    for i in range(20):
+        wk.gather_only(B, idxs[i % nbuf], dns[i % nbuf] if dns else None, rec)
+    wk.sync()
+    wk.timer_start()
+    for i in range(reps):
+        wk.gather_only(B, idxs[i % nbuf], dns[i % nbuf] if dns else None, rec)
+    ms = wk.timer_stop_ms() / reps
+    wk.sync()
+    wk.close()
+    for b_ in idxs + (dns or []):
+        b_.free()
+    gb = gather_bytes_per_inference(model, fr) * B
+    out = {"avg_launch_ms": ms, "achieved": gb / (ms * 1e-3) / 1e9, "frac": gb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": gb, "inferences_per_s": B / (ms * 1e-3), "index_buffers": nbuf, "timed_launches": reps}
+    if law == "zipf":
+        cols = range(0, host[0].shape[1], 7)
+        out["duplicate_fraction_within_batch"] = float(np.mean([1.0 - len(np.unique(z[:, t])) / B for z in host[:2] for t in cols]))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# sharded mode (BASELINE configs[3] / [4])
+# ------------------------------------------------------------------------------------------------------------------
+def main_sharded(args, graft):
+    """Model-C, batch 4096, tables sharded by table-ID over the ranks; per step every rank gathers its [B x F] slice, ONE RCCL
+    all-gather (or all-to-all) over xGMI delivers the slices, rank r runs the FC chain on its B/G items.
     value = B x steps / max-over-ranks time (one batch per step for the whole job: "scaling": "strong")."""
     import importlib
     import torch
     fr = graft.load_package()
     dist_mod = importlib.import_module("fleetrec_amd.dist")
-    env = dist_mod.DistEnv("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env = dist_mod.DistEnv(args.backend if world > 1 else None)
     G, r = env.world, env.rank
+    n_dev = max(fr.device_count(), 1)
+    dev_id = env.local_rank % n_dev if args.share_device else env.local_rank
     B = 4096 if args.batch == 256 else args.batch
+    steps, warmup = max(args.steps, 1), args.warmup
     model = fr.Model.builtin(fr.MODEL_C)
-    ctx = fr.Context(model, device=env.local_rank, shard_rank=r, n_shards=G)
+    if args.rows_cap:
+        model = model.clone(max_rows=args.rows_cap)
+    ctx = fr.Context(model, device=dev_id, shard_rank=r, n_shards=G)
     ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
     ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
     offs, lens, F = model.shard_plan(G)
-    dev = torch.device("cuda", env.local_rank)
+    dev = torch.device("cuda", dev_id)
+    torch.cuda.set_device(dev)
     rng = np.random.default_rng(SEED_IDX)             # same request stream on every rank (replicated request)
     rows = model.rows()
     nbuf = 8
-    idxs = [fr.DeviceBuffer.from_numpy(ctx, (rng.random((B, model.n_tables)) * rows[None, :]).astype(np.int32)) for _ in range(nbuf)]
-    dns = [fr.DeviceBuffer.from_numpy(ctx, rng.uniform(-1, 1, (B, model.dense_len)).astype(np.float32)) for _ in range(nbuf)]
+    idx_host = [uniform_idx(rng, rows, B) for _ in range(nbuf)]
+    dense_host = [rng.uniform(-1, 1, (B, model.dense_len)).astype(np.float32) for _ in range(nbuf)]
+    idxs = [fr.DeviceBuffer.from_numpy(ctx, a) for a in idx_host]
+    dns = [fr.DeviceBuffer.from_numpy(ctx, a) for a in dense_host]
     # Two workers and two sets of exchange buffers: while the FC chain of batch i-1 runs on worker B's stream, worker A gathers
-    # batch i and the all-gather of batch i runs on torch's (RCCL) stream -- gather + exchange are hidden behind the MFMA work.
+    # batch i and the exchange of batch i runs on torch's (RCCL) stream -- gather + exchange are hidden behind the MFMA work.
     wk = fr.Worker(ctx, B)       # gathers
     wk_fc = fr.Worker(ctx, B)    # FC chains
     a2a = args.exchange == "alltoall"
     if a2a and B % G:
         raise SystemExit("--exchange alltoall needs the batch divisible by the number of ranks")
-    # slice transport: fp32, or the chain's own operand type (bf16: half the exchange bytes, e4m3: a quarter)
-    lp = args.transport == "lp" and args.precision != "f32"
+    lp = args.transport == "lp" and args.precision != "f32"   # slices travel in the chain's own operand type
     prec_enum = {"f32": fr.FC_FP32, "bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[args.precision]
     esz = {"f32": 4, "bf16": 2, "fp8": 1}[args.precision] if lp else 4
     local = [torch.empty((B, F * esz), dtype=torch.uint8, device=dev) for _ in range(2)]   # torch owns the exchange buffers (RCCL plumbing)
     gathered = [torch.empty((G, B // G if a2a else B, F * esz), dtype=torch.uint8, device=dev) for _ in range(2)]
     lo, hi = dist_mod.item_range(r, G, B)
     scores = torch.empty((max(hi - lo, 1),), dtype=torch.float32, device=dev)
+    gloo = world > 1 and args.backend == "gloo"   # plumbing test: gloo moves host tensors
+
+    def xchg(fn, src, dst):
+        if gloo:
+            torch.cuda.synchronize()
+            h = fn(src.cpu())
+            dst.copy_(h.view(dst.shape).to(dev))
+        else:
+            fn(src, dst)
 
     def exchange(k):
-        if a2a:
-            env.all_to_all_slices(local[k], gathered[k])
-        else:
-            env.all_gather_slices(local[k], gathered[k])
+        xchg(env.all_to_all_slices if a2a else env.all_gather_slices, local[k], gathered[k])
 
     def fc(k):
         tp = prec_enum if lp else fr.FC_FP32
@@ -152,36 +468,38 @@ def main_sharded(args):
         torch.cuda.synchronize()
         state["fc_done"] = [None, None]
 
-    if args.precision != "f32":   # the slices travel as fp32; the FC chain re-packs them to bf16 / e4m3 operands
-        ctx.set_fc_precision(fr.FC_BF16 if args.precision == "bf16" else fr.FC_FP8)
-        if args.precision == "fp8":   # activation exponents from the first batch's gathered slices (same on every rank)
-            cal_l = torch.empty((B, F), dtype=torch.float32, device=dev)   # calibration always sees fp32 slices
+    if args.precision != "f32":
+        ctx.set_fc_precision(prec_enum)
+        if args.precision == "fp8":
+            # activation exponents from the first batch's gathered fp32 slices; every rank must end up with the SAME exponents (a slice
+            # encoded with one rank's X exponent is decoded with the receiver's): MIN over ranks = the most conservative scale
+            cal_l = torch.empty((B, F), dtype=torch.float32, device=dev)
             cal_g = torch.empty((G, B // G if a2a else B, F), dtype=torch.float32, device=dev)
             wk.gather_only(B, idxs[0], dns[0], cal_l.data_ptr())
             wk.sync()
-            if a2a:
-                env.all_to_all_slices(cal_l, cal_g)
-            else:
-                env.all_gather_slices(cal_l, cal_g)
+            xchg(env.all_to_all_slices if a2a else env.all_gather_slices, cal_l, cal_g)
             torch.cuda.synchronize()
             if a2a:
                 wk_fc.calibrate_fp8_slices(B // G, 0, hi - lo, cal_g.data_ptr())
             else:
                 wk_fc.calibrate_fp8_slices(B, 0, B, cal_g.data_ptr())
+            act, _ = ctx.fp8_exponents()
+            ctx.set_fp8_act_exponents(env.min_over_ranks_int(act))
             del cal_l, cal_g
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     drain()
     env.barrier(); torch.cuda.synchronize(); ctx.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i)
     drain()                                            # the last batch's FC chain is inside the timed region
     env.barrier(); torch.cuda.synchronize(); ctx.synchronize()
     dt = env.max_over_ranks(time.perf_counter() - t0)
-    # outside the timed region: the last pipelined batch against the same batch run step by step with host synchronisation
+    # outside the timed region: (1) the last pipelined batch against the same batch run step by step with host synchronisation;
+    # (2) this rank's scores against an UNSHARDED context of the same model fed the same batch (rank 0 only: a second copy of the tables)
     piped = scores.clone()
-    last = args.steps - 1
+    last = steps - 1
     wk.gather_slices(B, idxs[last % nbuf], dns[last % nbuf], local[0].data_ptr(), prec_enum if lp else fr.FC_FP32)
     wk.sync()
     exchange(0)
@@ -189,15 +507,32 @@ def main_sharded(args):
     fc(0)
     wk_fc.sync()
     torch.cuda.synchronize()
-    verified = bool(torch.equal(piped, scores)) if args.steps > 0 else None
+    verified = bool(torch.equal(piped, scores))
+    vs_unsharded = None
+    if r == 0 and not args.no_unsharded_check:
+        full = fr.Context(model, device=dev_id)
+        full.fill_tables(fr.FILL_HASH, SEED_TABLES)
+        full.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+        if args.precision != "f32":
+            full.set_fc_precision(prec_enum)
+            if args.precision == "fp8":
+                full.set_fp8_act_exponents(ctx.fp8_exponents()[0])
+        fw = fr.Worker(full, B)
+        ref = fw.infer(idx_host[last % nbuf], dense_host[last % nbuf])[lo:hi]
+        got = scores.cpu().numpy()[:hi - lo]
+        vs_unsharded = {"max_rel_err": float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)), "bit_identical": bool(np.array_equal(got, ref))}
+        fw.close()
+        full.close()
     if r == 0:
         print(json.dumps({
-            "metric": "inferences/sec, Model-C batch 4096, tables sharded by table-ID", "value": B * args.steps / dt, "unit": "inferences/s",
-            "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "metric": "inferences/sec, Model-C batch 4096, tables sharded by table-ID", "value": B * steps / dt, "unit": "inferences/s",
+            "n_gpus": G, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "Model-C batch=%d, %d-way table-ID shards (slice F=%d floats), 1 all-gather of [B x F] per step, "
-                                   "FC on B/G items per rank" % (B, G, F), "parallelism": "table-sharded x%d" % G, "exchange": args.exchange,
+            "config": {"workload": "Model-C batch=%d, %d-way table-ID shards (slice F=%d floats), 1 %s of [B x F] per step, "
+                                   "FC on B/G items per rank" % (B, G, F, "all-to-all" if a2a else "all-gather"), "parallelism": "table-sharded x%d" % G,
+                       "exchange": args.exchange, "backend": args.backend if world > 1 else None,
                        "slice_transport": args.precision if lp else "f32", "pipelined_equals_stepwise": verified,
+                       "sharded_vs_unsharded_context": vs_unsharded,
                        "exchange_bytes_in_per_rank_per_step": int(G * (B // G if a2a else B) * F * esz)}}))
     wk.close()
     wk_fc.close()
@@ -205,305 +540,298 @@ def main_sharded(args):
     env.close()
 
 
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40000)
-    ap.add_argument("--warmup", type=int, default=4000)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--threads", type=int, default=2, help="host driver threads (reference THREAD_NUM = 4, constant.h:42)")
     ap.add_argument("--depth", type=int, default=2, help="workers (streams) each driver thread keeps in flight")
-    ap.add_argument("--sweep", action="store_true", help="also print a threads x depth sweep to stderr (experiments)")
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
                     help="replicas: BASELINE configs[1] (default, the headline metric); sharded: Model-C batch 4096 with tables "
                          "sharded by table-ID over the ranks + one RCCL all-gather of the looked-up slices (BASELINE configs[3])")
-    ap.add_argument("--model", choices=["A", "B", "C"], default="A", help="A = BASELINE configs[1] (default headline); B/C: other configs")
+    ap.add_argument("--model", choices=["A", "B", "C"], default="A", help="A = BASELINE configs[1] (default headline); B/C: one other config, throughput + roofline leg only")
     ap.add_argument("--precision", choices=["f32", "bf16", "fp8"], default="f32",
                     help="FC chain arithmetic (bf16 = BASELINE configs[2], fp8 = configs[4]: e4m3, calibrated on the first batch)")
-    ap.add_argument("--roofline-only", action="store_true",
-                    help="skip the multi-stream throughput loop and the Model-C leg: only the single-stream roofline launches run, so "
-                         "that a rocprofv3 --kernel-trace --stats summary of this command shows the kernel under the roofline's conditions")
+    ap.add_argument("--legs", default="all",
+                    help="comma list of the extra legs rank 0 runs at N = 1: roofline,groups,pcie,cpu,configs,gather,bank (default all; 'none' = headline only)")
+    ap.add_argument("--gather-law", choices=["all", "uniform", "zipf"], default="all", help="gather leg: per-table index law(s) to run (PMC passes: one law per kernel name)")
     ap.add_argument("--transport", choices=["f32", "lp"], default="lp",
                     help="sharded mode: slices travel as fp32, or (lp) in the chain's own operand type when --precision is bf16 / fp8")
     ap.add_argument("--exchange", choices=["allgather", "alltoall"], default="allgather",
                     help="sharded mode: all-gather every slice to every rank (BASELINE configs[3]) or all-to-all only each rank's items")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true", help="plumbing test: ranks share the visible GPU(s) (use with --backend gloo)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-zipf", action="store_true", help="skip the zipf-index repeat of the Model-C gather leg (PMC passes: one index law per kernel name)")
-    ap.add_argument("--no-model-c", action="store_true", help="skip the Model-C batch-4096 gather roofline leg")
+    ap.add_argument("--rows-cap", type=int, default=0, help="plumbing tests: cap every table's row count (sharded mode)")
+    ap.add_argument("--no-unsharded-check", action="store_true", help="sharded mode: skip rank 0's comparison against an unsharded context")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="launch / rendezvous / timing-rule check without touching a GPU or the library (CPU test of the multi-GPU launcher)")
     args = ap.parse_args()
 
-    if args.mode == "sharded":
-        return main_sharded(args)
+    # ---- rank processes: torchrun supplies WORLD_SIZE; otherwise start them ourselves, before anything touches the GPU ----
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to report a different n_gpus than requested" % (args.gpus, world_env))
+
     import importlib
-    import torch
+    import __graft_entry__ as graft
+    if args.plumbing_only:
+        return main_plumbing(args, graft)
+    if args.mode == "sharded":
+        return main_sharded(args, graft)
     fr = graft.load_package()
     dist_mod = importlib.import_module("fleetrec_amd.dist")
-    env = dist_mod.DistEnv(args.backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    env = dist_mod.DistEnv(args.backend if world_env > 1 else None)
     rank, world = env.rank, env.world
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    n_dev = max(fr.device_count(), 1)
-    local_rank = env.local_rank % n_dev if args.share_device else env.local_rank  # --share-device: plumbing test on one GPU
-    dist = env.dist
-
-    fr = graft.load_package()
     if fr.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    n_dev = fr.device_count()
+    local_rank = env.local_rank % n_dev if args.share_device else env.local_rank  # --share-device: plumbing test on one GPU
+    legs = set() if args.legs == "none" else set(args.legs.split(","))
+    want = lambda name: rank == 0 and world == 1 and ("all" in legs or name in legs)
 
     B = args.batch
-    model = fr.Model.builtin({"A": fr.MODEL_A, "B": fr.MODEL_B, "C": fr.MODEL_C}[args.model])
+    which = {"A": fr.MODEL_A, "B": fr.MODEL_B, "C": fr.MODEL_C}[args.model]
+    model = fr.Model.builtin(which)
     ctx = fr.Context(model, device=local_rank)
     ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
     ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
-    if args.precision == "bf16":
-        ctx.set_fc_precision(fr.FC_BF16)
     rng = np.random.default_rng(dist_mod.replica_seed(SEED_IDX, rank))
     rows = model.rows()
-    n_bufs = N_IDX_BUFFERS if args.model == "A" else 8
-    idx_host = [(rng.random((B, model.n_tables)) * rows[None, :]).astype(np.int32) for _ in range(n_bufs)]
+    n_bufs = N_IDX_BUFFERS if args.model == "A" else 16
+    idx_host = [uniform_idx(rng, rows, B) for _ in range(n_bufs)]
     d_idx = [fr.DeviceBuffer.from_numpy(ctx, a) for a in idx_host]
-    d_dense = ([fr.DeviceBuffer.from_numpy(ctx, rng.uniform(-1, 1, (B, model.dense_len)).astype(np.float32)) for _ in range(n_bufs)]
-               if model.dense_len else None)
-    if args.precision == "fp8":
-        ctx.set_fc_precision(fr.FC_FP8)
-        dense_host = rng.uniform(-1, 1, (B, model.dense_len)).astype(np.float32) if model.dense_len else None
-        cal = fr.Worker(ctx, B)
-        cal.calibrate_fp8(idx_host[0], dense_host)   # activation exponents from one batch of the same index law
-        cal.close()
-    if args.model != "A" or args.precision != "f32":
-        # non-headline configurations: throughput line only
-        driver = fr.Driver(ctx, args.threads, args.depth, B)
-        driver.run_resident(B, args.warmup, d_idx, d_dense)
-        ctx.synchronize()
-        el = driver.run_resident(B, args.steps, d_idx, d_dense)
-        print(json.dumps({"metric": "inferences/sec", "value": args.steps * B / el, "unit": "inferences/s", "n_gpus": 1, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "dtype": args.precision,
-                          "data": "synthetic", "config": {"workload": "Model-%s batch=%d %s FC chain, index rows resident in HBM" % (
-                              args.model, B, args.precision), "fc_tflops": fc_flops_per_inference(model.fc) * B * args.steps / el / 1e12}}))
-        driver.close()
-        ctx.close()
-        return
-    driver = fr.Driver(ctx, args.threads, args.depth, B)
+    dense_host = [rng.uniform(-1, 1, (B, model.dense_len)).astype(np.float32) for _ in range(n_bufs)] if model.dense_len else None
+    d_dense = [fr.DeviceBuffer.from_numpy(ctx, a) for a in dense_host] if dense_host else None
 
     def barrier():
         env.barrier()
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
         ctx.synchronize()
 
-    if args.sweep and rank == 0:
-        for th, dp in ((1, 1), (1, 2), (1, 4), (2, 2), (4, 1), (4, 2), (4, 4), (8, 2), (8, 4), (16, 2)):
-            dv = fr.Driver(ctx, th, dp, B)
-            dv.run_resident(B, 200, d_idx)
-            el = dv.run_resident(B, 2000, d_idx)
-            print("sweep threads=%d depth=%d: %.2f us/batch, %.2f M inf/s" % (th, dp, 1e6 * el / 2000, 2000 * B / el / 1e6), file=sys.stderr)
-            dv.close()
+    if args.model != "A" or args.precision != "f32":
+        # one non-headline configuration on its own: throughput + its roofline leg
+        res = leg_config(fr, ctx, model, B, args.precision, d_idx, d_dense, idx_host[0], dense_host[0] if dense_host else None, args.threads, args.depth,
+                         "Model-%s batch=%d %s FC chain, index rows resident in HBM" % (args.model, B, args.precision))
+        if rank == 0:
+            print(json.dumps({"metric": "inferences/sec", "value": res["value"], "unit": "inferences/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": args.precision, "data": "synthetic", "config": {"workload": res["workload"]}, "timed_batches": res["timed_batches"],
+                              "timed_s": res["timed_s"], "roofline": res["roofline"], "fc_tflops_end_to_end": res["fc_tflops_end_to_end"],
+                              "layer_launch_ms": res.get("layer_launch_ms")}))
+        ctx.close()
+        env.close()
+        return
 
-    if args.roofline_only:
-        args.steps, args.warmup, args.no_cpu_baseline, args.no_model_c = 8, 8, True, True
-    driver.run_resident(B, args.warmup, d_idx)
+    # ---- headline: Model-A batch 256 fp32, index rows resident in HBM, native driver loop ---------------------------------------
+    driver = fr.Driver(ctx, args.threads, args.depth, B)
+    driver.run_resident(B, max(args.warmup, 0), d_idx)
     barrier()
     t0 = time.perf_counter()
-    driver.run_resident(B, args.steps, d_idx)
+    driver.run_resident(B, max(args.steps, 1), d_idx)            # exactly --steps batches: the burst figure
     barrier()
-    dt = env.max_over_ranks(time.perf_counter() - t0)   # MAX over ranks
+    burst_dt = env.max_over_ranks(time.perf_counter() - t0)
+    n_timed = max(steady_run(lambda k: driver.run_resident(B, k, d_idx), STEADY_S, n_first=8192, env=env), args.steps)
+    barrier()
+    t0 = time.perf_counter()
+    driver.run_resident(B, n_timed, d_idx)                       # >= 2 s of back-to-back batches: `value`
+    barrier()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
 
     result = None
     if rank == 0:
-        value = world * args.steps * B / dt
         result = {
-            "metric": "inferences/sec at batch 256", "value": value, "unit": "inferences/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "metric": "inferences/sec at batch 256", "value": world * n_timed * B / dt, "unit": "inferences/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / n_timed, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Model-A (embedding_47_krnl: 47 tables, 1.415 GB) batch=%d, fp32 FC 352-1024-512-256-1, "
-                                   "all tables resident in one GPU's HBM; hash-filled tables, uniform indices, "
-                                   "index rows resident in HBM" % B,
+                                   "all tables resident in one GPU's HBM; hash-filled tables, uniform per-table indices, "
+                                   "index rows resident in HBM (%d rotating buffers), scores left in HBM" % (B, n_bufs),
                        "batch": B, "driver_threads": args.threads, "workers_per_thread": args.depth,
-                       "parallelism": "replicas x%d" % world},
+                       "batches_per_fused_launch": ctx.stream_group(), "parallelism": "replicas x%d" % world},
+            "timed_batches": n_timed, "timed_s": dt,
+            "value_is": "steady state: %d back-to-back batches per rank over %.2f s (>= %.1f s whatever --steps says)" % (n_timed, dt, STEADY_S),
+            "burst": {"steps": args.steps, "warmup": args.warmup, "value": world * args.steps * B / burst_dt, "unit": "inferences/s",
+                      "ms_per_step": 1e3 * burst_dt / max(args.steps, 1),
+                      "what": "EXACTLY --steps batches after --warmup batches, barrier + device sync on both sides: with few steps this is launch "
+                              "latency (a fused launch carries %d batches), not throughput" % ctx.stream_group()},
         }
+
+    gpu_scores_first = None
+    if want("roofline"):
         # ---- roofline of the dominant kernel: measured live with HIP events on the worker's stream ----
         # Model-A streams through the fused item-tile kernel: ONE launch = the whole hot path (gather + 4 GEMMs) of `group` queued
-        # batches, 64 items per workgroup at the default group of 64 (32 items for smaller groups).  (Models that do not fit
-        # LDS use fr_pipeline_kernel<-1>, group = 1.)
+        # batches, 64 items per workgroup at the default group of 64.
         group = ctx.stream_group()
         wk = fr.Worker(ctx, B)
         ring = [fr.DeviceBuffer(ctx, B * 4) for _ in range(max(8, 2 * group))]
-        t_warm = time.time()   # >= 1 s of back-to-back launches first: the shader clock ramps over many milliseconds of load, and
-        while time.time() - t_warm < 1.0:   # with --roofline-only nothing else has loaded the chip before this point
+        push = lambda i: wk.push_device(B, d_idx[i % n_bufs], None, ring[i % len(ring)])
+        t_warm = time.time()   # >= 1 s of back-to-back launches first: the shader clock ramps over many milliseconds of load
+        while time.time() - t_warm < 1.0:
             for i in range(4 * group):
-                wk.push_device(B, d_idx[i % N_IDX_BUFFERS], None, ring[i % len(ring)])
+                push(i)
             wk.sync()
-        launches = 200 if group > 1 else 1000
-        if group == 1:
-            for i in range(8):   # refill the stage pipeline so that every timed launch carries all five stages
-                wk.push_device(B, d_idx[i % N_IDX_BUFFERS], None, ring[i % len(ring)])
-        wk.timer_start()
-        for i in range(launches * group):
-            wk.push_device(B, d_idx[i % N_IDX_BUFFERS], None, ring[i % len(ring)])
-        pipe_ms = wk.timer_stop_ms() / launches
-        wk.sync()
-        fc = model.fc
-        flops = fc_flops_per_inference(fc) * B * group
+        pipe_ms = time_launches(wk, push, group, 200, warm_launches=4)
+        flops = fc_flops_per_inference(model.fc) * B * group
         ach = flops / (pipe_ms * 1e-3) / 1e12
-        wpe = int(os.environ.get("FR_FUSED_WPE", "4"))  # workgroups are built for 4 waves per SIMD (two per CU) unless forced to 2
-        if group >= 64 and os.environ.get("FR_FUSED_M2", "1") != "0":
-            kname = "fr_fused_tile_m2_kernel<44>"   # 64 items per workgroup: one launch of 64 batches covers the 256 CUs
-        elif group > 1:
-            kname = "fr_fused_tile_kernel<2, 44, %d, %s>" % (wpe, "false" if wpe == 4 else "true")
-        else:
-            kname = "fr_pipeline_kernel<-1, 0>"
-        result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": ach / MFMA_F32_PEAK_TF, "traffic": pmc_traffic(kname.split(",")[0] if group > 1 else kname),
-                              "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
+        kname = "fr_fused_tile_m2_kernel<44>" if group >= 64 else "fr_fused_tile_kernel"
+        pm = pmc("fused_m2_A256") or {}
+        result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TF["f32"], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TF["f32"],
+                              "traffic": pm.get("traffic_bytes_per_launch"),
+                              "traffic_source": "profiles/r02_pmc.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --legs roofline`; "
                                                 "FETCH_SIZE x2 gfx950 correction), bytes per launch",
                               "kernel": "%s: one launch = the whole hot path (gather + the 4-GEMM chain) of %d queued batches of %d, "
                                         "back-to-back on ONE stream" % (kname, group, B),
                               "batches_per_launch": group, "avg_launch_ms": pipe_ms, "algorithmic_flops_per_launch": flops,
-                              "pmc_mfma_busy_fraction": pmc_field(kname.split(",")[0] if group > 1 else kname, "mfma_busy_fraction"),
-                              "pmc_mfma_f32_flops_per_launch": pmc_field(kname.split(",")[0] if group > 1 else kname, "mfma_f32_flops_per_launch"),
+                              "pmc_mfma_busy_fraction": pm.get("mfma_busy_fraction"), "pmc_mfma_f32_flops_per_launch": pm.get("mfma_f32_flops_per_launch"),
                               "note": "`value` above runs %d such streams concurrently" % (args.threads * args.depth)}
-        # per-stage launches (unpipelined submit path), for reference
-        d_sc = ring[0]
+        wk.sync()
+        # scores of the first index buffer, for the CPU leg's cross-check
+        d_sc = fr.DeviceBuffer(ctx, B * 4)
         wk.submit_device(B, d_idx[0], None, d_sc)
         wk.sync()
-        rec = wk.records_dptr()
-        layer_ms = []
-        for layer in range(4):
-            for _ in range(20):
-                wk.fc_layer_only(B, layer)
-            wk.sync()
-            wk.timer_start()
-            for _ in range(200):
-                wk.fc_layer_only(B, layer)
-            layer_ms.append(wk.timer_stop_ms() / 200)
-            wk.sync()
-        result["roofline"]["single_stage_avg_launch_ms"] = layer_ms
-        reps = 300
-        # gather kernel at the bench batch
-        for _ in range(20):
-            wk.gather_only(B, d_idx[0], None, rec)
-        wk.sync()
-        wk.timer_start()
-        for i in range(reps):
-            wk.gather_only(B, d_idx[i % N_IDX_BUFFERS], None, rec)
-        g_ms = wk.timer_stop_ms() / reps
-        wk.sync()
+        gpu_scores_first = d_sc.download(np.float32, B)
+        d_sc.free()
         wk.close()
         for b_ in ring:
             b_.free()
-        gb = gather_bytes_per_inference(model, fr) * B
-        result["gather_roofline_bench_batch"] = {"bound": "hbm", "achieved": gb / (g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                                 "unit": "GB/s", "frac": gb / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                 "avg_launch_ms": g_ms, "algorithmic_bytes_per_launch": gb}
 
-        # ---- PCIe-inclusive rate (host index buffers through fr_worker_submit/sync; reported, never `value`) ----------
-        if not args.roofline_only and world == 1:
-            hd = fr.Driver(ctx, args.threads, 4, B)
-            hd.run_host(B, 200, idx_host)
-            el = hd.run_host(B, 2000, idx_host)
-            hd.close()
-            result["pcie_inclusive"] = {"value": 2000 * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / 2000,
-                                        "what": "index rows start in host memory: memcpy to pinned -> H2D -> 5 stage launches -> D2H -> sync per batch, "
-                                                "%d threads x 4 workers" % args.threads}
-            # the same host-resident stream through fr_worker_push_host: pinned staging blocks, one H2D + one fused launch + one D2H
-            # per block of batches, scores delivered to host memory -- still PCIe-inclusive, still never `value`
-            hs = fr.Driver(ctx, args.threads, args.depth, B)
-            hs.run_host(B, 2000, idx_host, streaming=True)
-            n_s = 20000
-            el = hs.run_host(B, n_s, idx_host, streaming=True)
-            hs.close()
-            result["pcie_inclusive_streaming"] = {"value": n_s * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / n_s,
-                                                  "what": "index rows start in host memory, scores end in host memory: blocks of batches staged in pinned "
-                                                          "memory, one H2D + one fused launch + one D2H per block, %d threads x %d workers"
-                                                          % (args.threads, args.depth)}
-        # ---- CPU baseline: the oracle ("port": C, OpenMP over items) on this node's host cores, bounded sample (~10 s).
-        #      (The 4-GEMM chain through numpy/OpenBLAS sgemm was measured 3x SLOWER than the oracle's own loops at this
-        #      batch size on the 128-core host -- threading overhead on 256-row matrices -- so the oracle's chain is used.)
-        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (bench contract)
-            O = graft.load_oracle()
-            om = O.OracleModel("A")
-            ws = [ctx.get_weights(l) for l in range(4)]
-            nthreads = O.lib().oracle_num_threads()
-            n_done, t_cpu, t_g = 0, 0.0, 0.0
-            t_start = time.perf_counter()
-            while time.perf_counter() - t_start < 10.0:
-                a = idx_host[n_done % N_IDX_BUFFERS]
-                t1 = time.perf_counter()
-                r = om.gather(a, content_mode=O.FILL_HASH, seed=SEED_TABLES)
-                t2 = time.perf_counter()
-                om.fc_chain(r.view(np.float32), ws, acc64=False)
-                t3 = time.perf_counter()
-                t_cpu += t3 - t1
-                t_g += t2 - t1
-                n_done += 1
-            result["cpu_baseline"] = {"value": n_done * B / t_cpu, "unit": "inferences/s", "cores": nthreads, "kind": "port",
-                                      "sample": "%d batches of %d (Model-A, same seeded indices): oracle C port -- OpenMP gather with "
-                                                "on-the-fly hash tables (%.0f%% of the time) + fp32 4-GEMM chain" % (n_done, B, 100.0 * t_g / t_cpu)}
+    if want("groups"):
+        result["launch_group_table"] = {"workload": "Model-A batch 256 fp32, %d threads x %d workers; group = batches per fused launch "
+                                                    "(fr_ctx_set_stream_group)" % (args.threads, args.depth),
+                                        "rows": leg_group_table(fr, ctx, model, B, d_idx, args.threads, args.depth)}
+
+    if want("pcie"):
+        # ---- PCIe-inclusive rates (index rows start in HOST memory, scores end in HOST memory; reported, never `value`) ----
+        hd = fr.Driver(ctx, args.threads, 4, B)
+        hd.run_host(B, 200, idx_host)
+        n = steady_run(lambda k: hd.run_host(B, k, idx_host), 1.0, n_first=1000, quantum=64)
+        el = hd.run_host(B, n, idx_host)
+        hd.close()
+        result["pcie_inclusive"] = {"value": n * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / n, "timed_batches": n, "timed_s": el,
+                                    "what": "per batch: memcpy to pinned -> H2D -> 5 stage launches -> D2H -> sync (the reference's own per-batch "
+                                            "sequence, cuda_server.c:425-495), %d threads x 4 workers" % args.threads}
+        hs = fr.Driver(ctx, args.threads, args.depth, B)
+        hs.run_host(B, 2048, idx_host, streaming=True)
+        n = steady_run(lambda k: hs.run_host(B, k, idx_host, streaming=True), STEADY_S, n_first=8192)
+        el = hs.run_host(B, n, idx_host, streaming=True)
+        hs.close()
+        result["pcie_inclusive_streaming"] = {"value": n * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / n, "timed_batches": n, "timed_s": el,
+                                              "what": "host-resident request stream, scores delivered to host memory: blocks of 64 batches staged in pinned "
+                                                      "memory, one H2D + one fused launch + one D2H per block (fr_worker_push_host), %d threads x %d workers"
+                                                      % (args.threads, args.depth)}
+
+    if want("cpu"):
+        try:
+            result["cpu_baseline"] = leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first)
+        except Exception as ex:
+            result["cpu_baseline"] = {"error": repr(ex)}
 
     driver.close()
     for b in d_idx:
         b.free()
     ctx.close()
 
-    # ---- the headline gather measurement: Model-C, batch 4096 (rank 0, N=1 only) -------------------------
-    if rank == 0 and world == 1 and not args.no_model_c:
+    # ---- the other BASELINE configurations, each with its own in-run roofline object (rank 0, N = 1 only) ----------------------------
+    if want("configs"):
+        cfgs = []
         try:
-            mc = fr.Model.builtin(fr.MODEL_C)
-            cc = fr.Context(mc, device=local_rank)
-            cc.fill_tables(fr.FILL_HASH, SEED_TABLES)
+            mb = fr.Model.builtin(fr.MODEL_B)
+            cb = fr.Context(mb, device=local_rank)
+            cb.fill_tables(fr.FILL_HASH, SEED_TABLES)
+            cb.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+            rngb = np.random.default_rng(SEED_IDX)
+            ih = [uniform_idx(rngb, mb.rows(), 1024) for _ in range(32)]
+            di = [fr.DeviceBuffer.from_numpy(cb, a) for a in ih]
+            for prec in ("bf16", "f32"):
+                cfgs.append(leg_config(fr, cb, mb, 1024, prec, di, None, ih[0], None, args.threads, args.depth,
+                                       "BASELINE configs[2]: Model-B (embedding_98_krnl, 15.1 GB) batch=1024, %s FC, fused concat + FC chain" % prec
+                                       if prec == "bf16" else "Model-B batch=1024, f32 FC (the reference's own precision)"))
+            cb.close()
+        except Exception as ex:
+            cfgs.append({"workload": "Model-B", "error": repr(ex)})
+        result["configs"] = cfgs
+
+    if want("gather") or want("configs") or want("bank"):
+        try:
             BC = 4096
-            rng = np.random.default_rng(SEED_IDX)
-            rows = mc.rows()
-            nbuf = 8
-            idxs = [fr.DeviceBuffer.from_numpy(cc, (rng.random((BC, mc.n_tables)) * rows[None, :]).astype(np.int32)) for _ in range(nbuf)]
-            dns = [fr.DeviceBuffer.from_numpy(cc, rng.uniform(-1, 1, (BC, mc.dense_len)).astype(np.float32)) for _ in range(nbuf)]
-            wk = fr.Worker(cc, BC)
-            rec = wk.records_dptr()
-            for i in range(10):
-                wk.gather_only(BC, idxs[i % nbuf], dns[i % nbuf], rec)
-            wk.sync()
-            reps = 100
-            wk.timer_start()
-            for i in range(reps):
-                wk.gather_only(BC, idxs[i % nbuf], dns[i % nbuf], rec)
-            ms = wk.timer_stop_ms() / reps
-            wk.sync()
-            gb = gather_bytes_per_inference(mc, fr) * BC
-            result["gather"] = {"workload": "Model-C (2x embedding_377_krnl + 64 dense: 376 tables, 63.2 GB) batch=4096, uniform indices",
-                                "bound": "hbm", "achieved": gb / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": gb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("gather_pack_xcd_kernel<8>"),
-                                "traffic_source": "profiles/r01_pmc_traffic.json (PMC, FETCH_SIZE x2 correction), bytes per launch", "avg_launch_ms": ms,
-                                "algorithmic_bytes_per_launch": gb, "inferences_per_s": BC / (ms * 1e-3),
-                                "kernel": "gather_pack_xcd_kernel<8>"}
-            # same kernel, zipf(1.05) indices per table (SURVEY 8d input (ii)): popular rows repeat inside a batch, the repeats
-            # are merged by the texture-address coalescer / served by L2, so no explicit ballot/shuffle dedup pass is needed
-            def zipf_idx(shape, rows, alpha=1.05):
-                u = rng.random(shape)
-                x = ((rows[None, :].astype(np.float64) ** (1.0 - alpha) - 1.0) * u + 1.0) ** (1.0 / (1.0 - alpha))
-                return np.minimum(np.floor(x) - 1, rows[None, :] - 1).astype(np.int32)
-            zs = [zipf_idx((BC, mc.n_tables), rows) for _ in range(0 if args.no_zipf else nbuf)]
-            if zs:
-                dup = float(np.mean([1.0 - len(np.unique(z[:, t])) / BC for z in zs[:2] for t in range(0, mc.n_tables, 7)]))
-                zidx = [fr.DeviceBuffer.from_numpy(cc, z) for z in zs]
-                for i in range(10):
-                    wk.gather_only(BC, zidx[i % nbuf], dns[i % nbuf], rec)
-                wk.sync()
-                wk.timer_start()
-                for i in range(reps):
-                    wk.gather_only(BC, zidx[i % nbuf], dns[i % nbuf], rec)
-                zms = wk.timer_stop_ms() / reps
-                wk.sync()
-                result["gather"]["zipf_1.05"] = {"avg_launch_ms": zms, "achieved": gb / (zms * 1e-3) / 1e9, "frac": gb / (zms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                 "duplicate_fraction_within_batch": dup}
-            wk.close()
-            cc.close()
+            mc = fr.Model.builtin(fr.MODEL_C)
+            if want("gather") or want("configs"):
+                cc = fr.Context(mc, device=local_rank)
+                cc.fill_tables(fr.FILL_HASH, SEED_TABLES)
+                cc.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+            if want("gather"):
+                g = {"workload": "Model-C (2x embedding_377_krnl + 64 dense: 376 tables, 63.2 GB) batch=4096, record-producing gather "
+                                 "(fr_worker_gather_only), per-table indices", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "kernel": "gather_pack_xcd_kernel<8>"}
+                if args.gather_law in ("all", "uniform"):
+                    g.update(leg_gather(fr, cc, mc, BC, "uniform"))
+                    pm = pmc("gather_C4096_per_table_uniform") or {}
+                    g["traffic"] = pm.get("traffic_bytes_per_launch")
+                    g["l2_hit_rate"] = pm.get("l2_hit_rate")
+                    g["traffic_source"] = "profiles/r02_pmc.json (PMC passes of `bench.py --legs gather --gather-law uniform`, FETCH_SIZE x2 correction), bytes per launch"
+                if args.gather_law in ("all", "zipf"):
+                    z = leg_gather(fr, cc, mc, BC, "zipf", seed=SEED_IDX + 1)
+                    pm = pmc("gather_C4096_per_table_zipf") or {}
+                    z["traffic"] = pm.get("traffic_bytes_per_launch")
+                    z["l2_hit_rate"] = pm.get("l2_hit_rate")
+                    g["zipf_1.05"] = z
+                result["gather"] = g
+            if want("configs"):
+                rngc = np.random.default_rng(SEED_IDX)
+                ih = [uniform_idx(rngc, mc.rows(), BC) for _ in range(8)]
+                dh = [rngc.uniform(-1, 1, (BC, mc.dense_len)).astype(np.float32) for _ in range(8)]
+                di = [fr.DeviceBuffer.from_numpy(cc, a) for a in ih]
+                dd = [fr.DeviceBuffer.from_numpy(cc, a) for a in dh]
+                for prec in ("f32", "bf16", "fp8"):
+                    result["configs"].append(leg_config(fr, cc, mc, BC, prec, di, dd, ih[0], dh[0], args.threads, args.depth,
+                                                        "Model-C (63.2 GB, unsharded replica) batch=4096, %s FC chain end to end "
+                                                        "(BASELINE configs[3]/[4] shapes on one GPU)" % prec))
+            if want("gather") or want("configs"):
+                cc.close()
+            if want("bank"):
+                # the reference kernel's real index contract: ONE index per bank per item, bank-interleaved table layout
+                mcb = mc.clone(index_mode=fr.INDEX_PER_BANK)
+                cbk = fr.Context(mcb, device=local_rank)
+                cbk.fill_tables(fr.FILL_HASH, SEED_TABLES)
+                gb = {"workload": "Model-C batch=4096, FR_INDEX_PER_BANK: one index per memory bank per item (82 banks; embedding_377_krnl.cpp:1261-1290), "
+                                  "tables of a bank row-interleaved in HBM; uniform indices over each bank's valid range", "bound": "hbm",
+                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "gather_pack_xcd_kernel<8>"}
+                gb.update(leg_gather(fr, cbk, mcb, BC, "uniform"))
+                pm = pmc("gather_C4096_per_bank_uniform") or {}
+                gb["traffic"] = pm.get("traffic_bytes_per_launch")
+                gb["l2_hit_rate"] = pm.get("l2_hit_rate")
+                result["gather_per_bank"] = gb
+                cbk.close()
         except Exception as ex:  # the main metric must still be reported
-            result["gather"] = {"error": str(ex)}
+            result.setdefault("gather", {})["error"] = repr(ex)
 
     if rank == 0:
         print(json.dumps(result))
+    env.close()
+
+
+def main_plumbing(args, graft):
+    """CPU check of the launcher + rendezvous + timing rule: no GPU, no library.  Every rank 'processes' --steps fake steps."""
+    import importlib.util
+    fr_dir = graft.PKG_DIR
+    spec = importlib.util.spec_from_file_location("fleetrec_dist_only", os.path.join(fr_dir, "dist.py"))
+    dist_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dist_mod)
+    env = dist_mod.DistEnv("gloo" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    env.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (1 + env.rank))
+    env.barrier()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    if env.rank == 0:
+        print(json.dumps({"metric": "plumbing-only", "value": None, "unit": "inferences/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "none", "config": {"workload": "launcher / rendezvous / max-over-ranks check, no GPU work",
+                                                     "self_launched": os.environ.get("FR_BENCH_SELF_LAUNCHED") == "1"}}))
     env.close()
 
 

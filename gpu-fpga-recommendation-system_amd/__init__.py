@@ -22,7 +22,7 @@ FILL_EVEN_ODD, FILL_HASH, FILL_TAGGED = 0, 1, 2
 WEIGHTS_ONES, WEIGHTS_UNIFORM = 0, 1
 FC_FP32, FC_BF16, FC_FP8 = 0, 1, 2
 LAYOUT_SEMANTIC, LAYOUT_BLOCKED = 0, 1
-INDEX_PER_TABLE, INDEX_PER_ITEM = 0, 1
+INDEX_PER_TABLE, INDEX_PER_ITEM, INDEX_PER_BANK = 0, 1, 2
 SEG_TABLE, SEG_COPY, SEG_DENSE = 0, 1, 2
 MEM_CLASS_NAMES = {0: "HBM", 1: "DDR", 2: "PLRAM"}
 
@@ -56,7 +56,7 @@ _lib = None
 # every symbol include/fleetrec.h declares (the not-gpu test checks the .so exports all of them)
 ABI_SYMBOLS = [
     "fr_abi_version", "fr_last_error", "fr_device_count", "fr_model_builtin", "fr_model_clone_scaled", "fr_model_free",
-    "fr_model_table_bytes", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
+    "fr_model_table_bytes", "fr_model_index_cols", "fr_model_bank_map", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
     "fr_ctx_fill_tables", "fr_ctx_upload_table", "fr_ctx_download_table", "fr_ctx_set_weights", "fr_ctx_fill_weights",
     "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_ctx_get_fp8_exponents", "fr_ctx_set_fp8_act_exponents",
     "fr_worker_calibrate_fp8", "fr_worker_calibrate_fp8_slices", "fr_worker_push_host", "fr_worker_stream", "fr_worker_gather_slices", "fr_worker_fc_from_slices_lp", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
@@ -85,6 +85,8 @@ def lib():
         "fr_model_clone_scaled": (i32, [ctypes.POINTER(ModelDesc), ctypes.c_double, i64, i64, ctypes.POINTER(ctypes.POINTER(ModelDesc))]),
         "fr_model_free": (None, [ctypes.POINTER(ModelDesc)]),
         "fr_model_table_bytes": (i64, [ctypes.POINTER(ModelDesc)]),
+        "fr_model_index_cols": (i32, [ctypes.POINTER(ModelDesc)]),
+        "fr_model_bank_map": (i32, [ctypes.POINTER(ModelDesc), pi, ctypes.POINTER(ctypes.c_int64)]),
         "fr_ctx_create": (i32, [ctypes.POINTER(ModelDesc), i32, ctypes.POINTER(vp)]),
         "fr_ctx_create_sharded": (i32, [ctypes.POINTER(ModelDesc), i32, i32, i32, ctypes.POINTER(vp)]),
         "fr_ctx_destroy": (None, [vp]), "fr_ctx_model": (ctypes.POINTER(ModelDesc), [vp]),
@@ -152,7 +154,8 @@ class Model:
         constants.hpp, FPGA/kernel/user_krnl/embedding_47_krnl/src/hls/constants.hpp:28,505):
 
             {"name": "my_model",
-             "tables": [{"dim": 8, "rows": 100000, "class": "HBM"}, ...],     # listed in record (wire) order
+             "tables": [{"dim": 8, "rows": 100000, "class": "HBM", "bank": 0}, ...],   # listed in record (wire) order; tables with
+                                                                                # equal (class, bank) share a memory bank (default: own bank)
              "dense_len": 0,                                                    # floats per item supplied by the request
              "dense_at": 0,                                                     # table position the dense block precedes
              "pad": [{"after_table": 3, "copy_of": 1, "col": 0}],               # optional 4-float COPY pads
@@ -165,7 +168,7 @@ class Model:
         cls_id = {"HBM": 0, "DDR": 1, "PLRAM": 2}
         for t, d in enumerate(tabs_in):
             tabs[t] = TableDesc(mem_class=cls_id.get(d.get("class", "HBM"), 0), table_id=t % 256, source=0, dim=int(d["dim"]),
-                                rows=int(d["rows"]), bank=t, round=0, addr_axi=0)
+                                rows=int(d["rows"]), bank=int(d.get("bank", t)), round=0, addr_axi=0)
         dense_len, dense_at = int(spec.get("dense_len", 0)), int(spec.get("dense_at", 0))
         pads = {int(p_["after_table"]): p_ for p_ in spec.get("pad", [])}
         segs, pos, seen_dense = [], 0, False
@@ -257,7 +260,31 @@ class Model:
 
     @property
     def idx_cols(self):
-        return self.desc.n_tables if self.desc.index_mode == INDEX_PER_TABLE else 1
+        """int32 columns of one item's index row: n_tables (PER_TABLE), 1 (PER_ITEM) or the number of banks (PER_BANK)."""
+        n = lib().fr_model_index_cols(self._ptr)
+        if n <= 0:
+            _check(n if n < 0 else FR_ERR_INVALID)
+        return n
+
+    def bank_map(self):
+        """-> (bank_of_table int32 [n_tables], bank_rows int64 [n_banks]): the memory bank (= index column in PER_BANK mode) of
+        every table, banks numbered by first appearance in the table list, and the valid index range of each bank (the smallest
+        row count among its tables)."""
+        bot = np.empty(self.n_tables, dtype=np.int32)
+        rows = np.empty(self.n_tables, dtype=np.int64)
+        nb = lib().fr_model_bank_map(self._ptr, bot.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+        if nb < 0:
+            _check(nb)
+        return bot, rows[:nb].copy()
+
+    def index_ranges(self):
+        """Exclusive upper bound of every index column in the model's index mode (uniform-index generators use this)."""
+        mode = self.desc.index_mode
+        if mode == INDEX_PER_TABLE:
+            return self.rows()
+        if mode == INDEX_PER_BANK:
+            return self.bank_map()[1]
+        return np.array([self.rows().min()], dtype=np.int64)
 
     def tables(self):
         d = self.desc

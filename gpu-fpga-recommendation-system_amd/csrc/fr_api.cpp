@@ -48,6 +48,7 @@ static int select_device(int device) {
 static unsigned long long *g_stamp_buffer = nullptr;  // diagnostics (tools/experiments): see fr_debug_set_stamp_buffer
 extern "C" __attribute__((visibility("default"))) void fr_debug_set_stamp_buffer(void *dptr) { g_stamp_buffer = (unsigned long long *)dptr; }
 
+static int fused_group_initial();
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -118,10 +119,55 @@ static int build_words(fr_ctx *c) {
     for (int s = s0; s < s1; s++)
         if (m.segments[s].kind != FR_SEG_DENSE) c->table_mem[m.segments[s].src].resident = true;
     // arena layout
+    c->n_banks = fr_bank_map(m, c->bank_of_table, c->bank_rows);
     size_t off = 0;
+    std::vector<char> placed(m.n_tables, 0);
+    if (m.index_mode == FR_INDEX_PER_BANK) {
+        // Bank-interleaved regions: the resident tables of one bank share "bank rows" -- row r of every table side by side -- for the
+        // rows every one of them has (r < min rows = the valid range of the bank's index); one bank costs one contiguous fetch per
+        // item.  The bank-row stride is padded when that lowers the expected number of 128-byte lines a row touches (112 -> 128,
+        // 224 -> 256 bytes: a fetch beyond L2 costs whole lines, profiles/r01_experiments.md).
+        for (int b = 0; b < c->n_banks; b++) {
+            std::vector<int> members;
+            size_t payload = 0;
+            for (int t = 0; t < m.n_tables; t++)
+                if (c->bank_of_table[t] == b && c->table_mem[t].resident) {
+                    members.push_back(t);
+                    payload += (size_t)m.tables[t].dim * 4;
+                }
+            if (members.size() < 2) continue;  // a lone table is its own bank row already
+            auto lines_x128 = [](size_t stride, size_t bytes) {  // expected 128-byte lines per row, x128 (exact over one period)
+                size_t acc = 0;
+                for (size_t r = 0; r < 128; r++) acc += ((r * stride) % 128 + bytes + 127) / 128;
+                return acc;
+            };
+            size_t best = payload;
+            for (size_t cand : {align_up(payload, 32), align_up(payload, 64), align_up(payload, 128)})
+                if (lines_x128(cand, payload) < lines_x128(best, payload)) best = cand;
+            const uint64_t il_rows = (uint64_t)c->bank_rows[b];
+            off = align_up(off, 256);
+            size_t col = 0;
+            for (int t : members) {
+                FrTableMem &tm = c->table_mem[t];
+                tm.byte_offset = off + col;
+                tm.row_stride = best;
+                tm.il_rows = il_rows;
+                col += (size_t)m.tables[t].dim * 4;
+                placed[t] = 1;
+            }
+            off = align_up(off + (size_t)il_rows * best, 256);
+            for (int t : members) {  // rows beyond the bank's common range: contiguous, reachable only by upload / download / fill
+                FrTableMem &tm = c->table_mem[t];
+                tm.tail_offset = off;
+                off = align_up(off + ((size_t)m.tables[t].rows - (size_t)il_rows) * m.tables[t].dim * 4, 256);
+            }
+        }
+    }
     for (int t = 0; t < m.n_tables; t++) {
-        if (!c->table_mem[t].resident) continue;
+        if (!c->table_mem[t].resident || placed[t]) continue;
         c->table_mem[t].byte_offset = off;
+        c->table_mem[t].row_stride = (uint64_t)m.tables[t].dim * 4;
+        c->table_mem[t].il_rows = 0;
         off = align_up(off + (size_t)m.tables[t].rows * m.tables[t].dim * 4, 256);
     }
     c->table_arena_bytes = off;
@@ -147,9 +193,10 @@ static int build_words(fr_ctx *c) {
             } else {
                 const fr_table_desc &t = m.tables[g.src];
                 w.src = (uint64_t)(uintptr_t)(c->table_arena + c->table_mem[g.src].byte_offset) + (uint64_t)(g.src_col + 4 * j) * 4;
-                w.stride = (uint32_t)t.dim * 4;
-                w.idx_col = (m.index_mode == FR_INDEX_PER_TABLE) ? (uint32_t)g.src : 0u;
-                w.rows = (uint32_t)t.rows;
+                w.stride = (uint32_t)c->table_mem[g.src].row_stride;
+                w.idx_col = m.index_mode == FR_INDEX_PER_TABLE ? (uint32_t)g.src : (m.index_mode == FR_INDEX_PER_BANK ? (uint32_t)c->bank_of_table[g.src] : 0u);
+                // PER_BANK: the bank's index addresses every table of the bank, so it must stay below the smallest of them
+                w.rows = m.index_mode == FR_INDEX_PER_BANK ? (uint32_t)c->bank_rows[c->bank_of_table[g.src]] : (uint32_t)t.rows;
             }
             const int rec_pos = g.rec_offset + 4 * j;
             if (c->n_shards > 1) {
@@ -192,9 +239,10 @@ extern "C" int fr_ctx_create_sharded(const fr_model_desc *m, int device, int sha
     c->model = *m;
     c->model.tables = c->tables.data();
     c->model.segments = c->segments.data();
-    c->table_mem.assign(m->n_tables, FrTableMem{0, false});
+    c->table_mem.assign(m->n_tables, FrTableMem{});
     c->shard_rank = shard_rank;
     c->n_shards = n_shards;
+    c->stream_group.store(fused_group_initial(), std::memory_order_relaxed);
     hipError_t e = hipStreamCreateWithFlags(&c->setup_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         fr_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -263,47 +311,64 @@ extern "C" int fr_ctx_fill_tables(fr_ctx *ctx, int mode, uint32_t seed) {
     for (int t = 0; t < ctx->model.n_tables; t++) {
         if (!ctx->table_mem[t].resident) continue;
         const fr_table_desc &d = ctx->tables[t];
-        int rc = frk_fill_table((float *)(ctx->table_arena + ctx->table_mem[t].byte_offset), d.rows, d.dim, mode, seed,
-                                fr_table_uid(d), ctx->setup_stream);
+        const FrTableMem &tm = ctx->table_mem[t];
+        const int64_t head = tm.il_rows ? (int64_t)tm.il_rows : d.rows;  // rows at byte_offset (all of them unless interleaved)
+        int rc = frk_fill_table((float *)(ctx->table_arena + tm.byte_offset), 0, head, d.dim, (int64_t)tm.row_stride, mode, seed, fr_table_uid(d), ctx->setup_stream);
         if (rc) return rc;
+        if (head < d.rows) {
+            rc = frk_fill_table((float *)(ctx->table_arena + tm.tail_offset), head, d.rows - head, d.dim, (int64_t)d.dim * 4, mode, seed, fr_table_uid(d), ctx->setup_stream);
+            if (rc) return rc;
+        }
     }
     FR_HIP(hipStreamSynchronize(ctx->setup_stream));
     ctx->tables_filled = true;
     return FR_OK;
 }
 
-static int table_span(fr_ctx *ctx, int table, int64_t row0, int64_t nrows, char **p, size_t *bytes) {
+// Copies rows [row0, row0 + nrows) of a table between host (dense rows of dim floats) and the arena, whatever the table's layout:
+// a plain table is one contiguous span; a bank-interleaved one is a strided 2-D copy for its rows < il_rows plus a contiguous tail.
+static int table_copy(fr_ctx *ctx, int table, int64_t row0, int64_t nrows, float *host_rows, bool to_device) {
     if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
     if (table < 0 || table >= ctx->model.n_tables) FR_FAIL(FR_ERR_INVALID, "table %d out of range", table);
     if (!ctx->table_mem[table].resident) FR_FAIL(FR_ERR_STATE, "table %d is not resident on shard %d", table, ctx->shard_rank);
     const fr_table_desc &d = ctx->tables[table];
     if (row0 < 0 || nrows < 0 || row0 + nrows > d.rows) FR_FAIL(FR_ERR_INVALID, "rows [%lld,+%lld) outside table %d", (long long)row0, (long long)nrows, table);
-    *p = ctx->table_arena + ctx->table_mem[table].byte_offset + (size_t)row0 * d.dim * 4;
-    *bytes = (size_t)nrows * d.dim * 4;
+    if (!host_rows && nrows) FR_FAIL(FR_ERR_INVALID, "host_rows is NULL");
+    FR_HIP(hipSetDevice(ctx->device));
+    const FrTableMem &tm = ctx->table_mem[table];
+    const size_t row_bytes = (size_t)d.dim * 4;
+    const int64_t head_rows = tm.il_rows ? (int64_t)tm.il_rows : d.rows;
+    const int64_t n_head = row0 < head_rows ? (row0 + nrows < head_rows ? nrows : head_rows - row0) : 0;  // rows of the request below head_rows
+    if (n_head > 0) {
+        char *dev = ctx->table_arena + tm.byte_offset + (size_t)row0 * tm.row_stride;
+        if (tm.row_stride == row_bytes) {
+            if (to_device) FR_HIP(hipMemcpy(dev, host_rows, (size_t)n_head * row_bytes, hipMemcpyHostToDevice));
+            else FR_HIP(hipMemcpy(host_rows, dev, (size_t)n_head * row_bytes, hipMemcpyDeviceToHost));
+        } else if (to_device) {
+            FR_HIP(hipMemcpy2D(dev, tm.row_stride, host_rows, row_bytes, row_bytes, (size_t)n_head, hipMemcpyHostToDevice));
+        } else {
+            FR_HIP(hipMemcpy2D(host_rows, row_bytes, dev, tm.row_stride, row_bytes, (size_t)n_head, hipMemcpyDeviceToHost));
+        }
+    }
+    if (nrows > n_head) {
+        const int64_t t0 = row0 + n_head - head_rows;  // first tail row of the request
+        char *dev = ctx->table_arena + tm.tail_offset + (size_t)t0 * row_bytes;
+        float *host = host_rows + (size_t)n_head * d.dim;
+        if (to_device) FR_HIP(hipMemcpy(dev, host, (size_t)(nrows - n_head) * row_bytes, hipMemcpyHostToDevice));
+        else FR_HIP(hipMemcpy(host, dev, (size_t)(nrows - n_head) * row_bytes, hipMemcpyDeviceToHost));
+    }
     return FR_OK;
 }
 
 extern "C" int fr_ctx_upload_table(fr_ctx *ctx, int table, int64_t row0, int64_t nrows, const float *host_rows) {
-    char *p;
-    size_t bytes;
-    int rc = table_span(ctx, table, row0, nrows, &p, &bytes);
+    int rc = table_copy(ctx, table, row0, nrows, const_cast<float *>(host_rows), true);
     if (rc) return rc;
-    if (!host_rows && bytes) FR_FAIL(FR_ERR_INVALID, "host_rows is NULL");
-    FR_HIP(hipSetDevice(ctx->device));
-    if (bytes) FR_HIP(hipMemcpy(p, host_rows, bytes, hipMemcpyHostToDevice));
     ctx->tables_filled = true;
     return FR_OK;
 }
 
 extern "C" int fr_ctx_download_table(fr_ctx *ctx, int table, int64_t row0, int64_t nrows, float *host_rows) {
-    char *p;
-    size_t bytes;
-    int rc = table_span(ctx, table, row0, nrows, &p, &bytes);
-    if (rc) return rc;
-    if (!host_rows && bytes) FR_FAIL(FR_ERR_INVALID, "host_rows is NULL");
-    FR_HIP(hipSetDevice(ctx->device));
-    if (bytes) FR_HIP(hipMemcpy(host_rows, p, bytes, hipMemcpyDeviceToHost));
-    return FR_OK;
+    return table_copy(ctx, table, row0, nrows, host_rows, false);
 }
 
 // ---- weights ----------------------------------------------------------------------------------------
@@ -449,7 +514,10 @@ extern "C" void fr_worker_destroy(fr_worker *w) {
     delete w;
 }
 
-static size_t idx_cols(const fr_ctx *c) { return c->model.index_mode == FR_INDEX_PER_TABLE ? (size_t)c->model.n_tables : 1; }
+static size_t idx_cols(const fr_ctx *c) {
+    const int mode = c->model.index_mode;
+    return mode == FR_INDEX_PER_TABLE ? (size_t)c->model.n_tables : (mode == FR_INDEX_PER_BANK ? (size_t)c->n_banks : 1);
+}
 
 #define W_HIP(call)                                                                       \
     do {                                                                                  \
@@ -695,14 +763,18 @@ static int pipeline_flush(fr_worker *w) {
 }
 
 // ---- fused item-tile path (fr_fused_tile_kernel): used by the streaming push for models whose activations fit in LDS --
-// Batches per fused launch: 32 x 8 workgroups = 256 = one per CU, so ONE stream's launch fills the chip.  Lower it to trade
-// throughput for latency (fr_ctx_set_stream_group; env FR_FUSED_GROUP sets the initial value).
-static int g_fused_group = [] {
-    const char *e = getenv("FR_FUSED_GROUP");
-    int v = e ? atoi(e) : FR_FUSED_DEFAULT_BATCHES;
-    return v < 1 ? 1 : (v > FR_FUSED_MAX_BATCHES ? FR_FUSED_MAX_BATCHES : v);
-}();
-static int fused_group() { return g_fused_group; }
+// Batches per fused launch: a per-CONTEXT knob (fr_ctx_set_stream_group; env FR_FUSED_GROUP sets the initial value of every new
+// context).  64 batches of 256 = one 64-item workgroup per CU, so ONE stream's launch fills the chip; lower it to trade throughput
+// for latency.  Atomic: driver threads read it while a control thread may change it.
+static int fused_group_initial() {
+    static const int v = [] {
+        const char *e = getenv("FR_FUSED_GROUP");
+        int g = e ? atoi(e) : FR_FUSED_DEFAULT_BATCHES;
+        return g < 1 ? 1 : (g > FR_FUSED_MAX_BATCHES ? FR_FUSED_MAX_BATCHES : g);
+    }();
+    return v;
+}
+static int fused_group(const fr_ctx *c) { return c->stream_group.load(std::memory_order_relaxed); }
 
 static bool fused_eligible(const fr_ctx *c) {
     static const int enabled = getenv("FR_FUSED") ? atoi(getenv("FR_FUSED")) : 1;  // experiment knob
@@ -717,11 +789,11 @@ extern "C" int fr_ctx_set_stream_group(fr_ctx *ctx, int batches_per_launch) {
     if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
     if (batches_per_launch < 1 || batches_per_launch > FR_FUSED_MAX_BATCHES)
         FR_FAIL(FR_ERR_INVALID, "batches_per_launch %d outside [1, %d]", batches_per_launch, FR_FUSED_MAX_BATCHES);
-    g_fused_group = batches_per_launch;  // process-wide knob (all contexts share it)
+    ctx->stream_group.store(batches_per_launch, std::memory_order_relaxed);  // queues already holding more are launched by their next push / sync
     return FR_OK;
 }
 
-extern "C" int fr_ctx_stream_group(const fr_ctx *ctx) { return (ctx && fused_eligible(ctx)) ? fused_group() : 1; }
+extern "C" int fr_ctx_stream_group(const fr_ctx *ctx) { return (ctx && fused_eligible(ctx)) ? fused_group(ctx) : 1; }
 
 static int fused_flush(fr_worker *w) {
     if (w->n_pending == 0) return FR_OK;
@@ -731,7 +803,7 @@ static int fused_flush(fr_worker *w) {
     // fp32: the 64-item kernel needs 64 queued batches to cover the chip; smaller groups keep the 32-item kernel (env FR_FUSED_M2=0/1 forces)
     static const int m2_forced = getenv("FR_FUSED_M2") ? atoi(getenv("FR_FUSED_M2")) : -1;
     const bool m2 = !bf16 && c->fc_precision == FR_FC_FP32 && frk_fused_m2_ok(c->model.fc[0], c->model.fc[1], c->model.fc[2], c->model.fc[3]) &&
-                    (m2_forced == 1 || (m2_forced != 0 && fused_group() >= 64));
+                    (m2_forced == 1 || (m2_forced != 0 && fused_group(c) >= 64));
     const bool fp8 = c->fc_precision == FR_FC_FP8;
     const int per_wg = (bf16 || fp8) ? frk_fused_h_items_per_wg() : (m2 ? 64 : 32);  // items per workgroup
     int max_tiles = 0;
@@ -983,7 +1055,7 @@ extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_i
         w->in_flight = true;
         // a launch is due when the group is full or when the queue already covers the chip (256 CUs x 64 items): large batches
         // need fewer of them per launch
-        return (w->n_pending >= fused_group() || w->pending_items >= 256 * 64) ? fused_flush(w) : FR_OK;
+        return (w->n_pending >= fused_group(c) || w->pending_items >= 256 * 64) ? fused_flush(w) : FR_OK;
     }
     rc = pipeline_push(w, batch, 0, d_idx, d_dense, d_scores);
     if (rc) return rc;
@@ -1032,7 +1104,7 @@ static int host_ring_init(fr_worker *w) {
     fr_ctx *c = w->ctx;
     int g = 16384 / (w->max_batch > 0 ? w->max_batch : 1);  // the queue launches once it holds 256 x 64 items
     if (g < 1) g = 1;
-    if (g > fused_group()) g = fused_group();
+    if (g > fused_group(c)) g = fused_group(c);
     r.idx_slot = (size_t)w->max_batch * idx_cols(c);
     r.dense_slot = (size_t)w->max_batch * c->model.dense_len;
     r.score_slot = (size_t)w->max_batch;

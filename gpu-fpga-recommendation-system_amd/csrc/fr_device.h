@@ -1,7 +1,9 @@
 // Device-side helpers shared by the kernel translation units of libfleetrec (gfx950 only): vector typedefs of the MFMA
 // builtins, the launch-error macro, bf16 / e4m3 packing, 16-byte buffer loads.
 #pragma once
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include <hip/hip_bf16.h>
 #include <hip/hip_runtime.h>
@@ -16,6 +18,26 @@
             return FR_ERR_HIP;                                                            \
         }                                                                                 \
     } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: raise it once per (instantiation, device),
+// safely from concurrent driver threads.  One FrLdsAttrOnce lives next to each launcher (function-local static).
+struct FrLdsAttrOnce {
+    std::mutex m;
+    std::atomic<unsigned long long> done[4] = {};  // one bit per device ordinal (256 devices)
+};
+template <class Kernel>
+static inline int fr_allow_full_lds(Kernel kernel, FrLdsAttrOnce &once) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) FR_FAIL(FR_ERR_HIP, "hipGetDevice failed");
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (once.done[dev >> 6].load(std::memory_order_acquire) & bit) return FR_OK;
+    std::lock_guard<std::mutex> g(once.m);
+    if (once.done[dev >> 6].load(std::memory_order_relaxed) & bit) return FR_OK;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        FR_FAIL(FR_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed on device %d", dev);
+    once.done[dev >> 6].fetch_or(bit, std::memory_order_release);
+    return FR_OK;
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

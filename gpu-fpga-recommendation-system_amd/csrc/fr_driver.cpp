@@ -127,7 +127,7 @@ extern "C" int fr_driver_run_host(fr_driver *d, int batch, int64_t total_batches
     if (!d || !h_idx_pool || n_pool < 1 || !elapsed_s) FR_FAIL(FR_ERR_INVALID, "bad argument");
     if (batch < 1 || batch > d->max_batch || total_batches < 0) FR_FAIL(FR_ERR_INVALID, "batch %d / total %lld out of range", batch, (long long)total_batches);
     const fr_model_desc &m = d->ctx->model;
-    const size_t idx_bytes = (size_t)batch * (m.index_mode == FR_INDEX_PER_TABLE ? (size_t)m.n_tables : 1) * sizeof(int32_t);
+    const size_t idx_bytes = (size_t)batch * (size_t)fr_model_index_cols(&m) * sizeof(int32_t);
     const size_t dense_bytes = (size_t)batch * m.dense_len * sizeof(float);
     if (dense_bytes && !h_dense_pool) FR_FAIL(FR_ERR_INVALID, "model has dense features but h_dense_pool is NULL");
     std::mutex mtx;

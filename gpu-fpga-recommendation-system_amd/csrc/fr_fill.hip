@@ -27,29 +27,32 @@ __device__ __forceinline__ uint32_t content_bits(int mode, uint32_t h_seed_uid, 
     return __float_as_uint(v);
 }
 
-// one thread per 16-byte word, grid-stride; stores are 16 B/lane fully coalesced
-__global__ void __launch_bounds__(256) fill_table_kernel(uint4 *base, uint64_t n_words, uint32_t words_per_row, int mode,
-                                                          uint32_t seed, uint32_t uid) {
+// one thread per 16-byte word, grid-stride; stores are 16 B/lane fully coalesced.  Row r of the table (r = row0 + local row) lives at
+// base + local_row * row_stride_words: row_stride_words == words_per_row for a table stored on its own, larger for a table that is one
+// column block of a bank-interleaved region (FR_INDEX_PER_BANK, fr_api.cpp build_words).
+__global__ void __launch_bounds__(256) fill_table_kernel(uint4 *base, uint64_t n_words, uint32_t words_per_row, uint64_t row_stride_words, uint64_t row0,
+                                                          int mode, uint32_t seed, uint32_t uid) {
     const uint32_t h0 = fmix32(seed ^ (uid * 0x9E3779B1u));
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
-        const uint64_t row = w / words_per_row;
-        const uint32_t c0 = (uint32_t)(w - row * words_per_row) * 4;
+        const uint64_t lrow = w / words_per_row, row = row0 + lrow;
+        const uint32_t wc = (uint32_t)(w - lrow * words_per_row), c0 = wc * 4;
         uint4 v;
         v.x = content_bits(mode, h0, uid, row, c0 + 0);
         v.y = content_bits(mode, h0, uid, row, c0 + 1);
         v.z = content_bits(mode, h0, uid, row, c0 + 2);
         v.w = content_bits(mode, h0, uid, row, c0 + 3);
-        base[w] = v;
+        base[lrow * row_stride_words + wc] = v;
     }
 }
 
-int frk_fill_table(float *base, int64_t rows, int dim, int mode, uint32_t seed, uint32_t uid, hipStream_t s) {
+int frk_fill_table(float *base, int64_t row0, int64_t rows, int dim, int64_t row_stride_bytes, int mode, uint32_t seed, uint32_t uid, hipStream_t s) {
     const uint64_t n_words = (uint64_t)rows * (uint64_t)(dim / 4);
     uint64_t blocks = (n_words + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks == 0) return FR_OK;
-    fill_table_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>((uint4 *)base, n_words, (uint32_t)(dim / 4), mode, seed, uid);
+    fill_table_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>((uint4 *)base, n_words, (uint32_t)(dim / 4), (uint64_t)row_stride_bytes / 16, (uint64_t)row0, mode, seed,
+                                                                 uid);
     KCHECK();
     return FR_OK;
 }

@@ -359,12 +359,8 @@ static int fused_wpe(int K, int H2) {
 
 template <int T2W, int KG, int WPE, bool DB>
 static int fused_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipStream_t s) {
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fr_fused_tile_kernel<T2W, KG, WPE, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            FR_FAIL(FR_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
-        attr_set = true;
-    }
+    static FrLdsAttrOnce lds_once;  // per instantiation, per device
+    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_kernel<T2W, KG, WPE, DB>, lds_once)) return rc_;
     fr_fused_tile_kernel<T2W, KG, WPE, DB><<<grid, dim3(512), lds, s>>>(a);
     KCHECK();
     return FR_OK;
@@ -592,12 +588,8 @@ bool frk_fused_m2_ok(int K, int H1, int H2, int H3) { return K == 352 && H1 % 25
 
 // a.tiles_per_batch counts 64-item tiles
 int frk_fused_m2_launch(const FrFusedArgs &a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fr_fused_tile_m2_kernel<44>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            FR_FAIL(FR_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
-        attr_set = true;
-    }
+    static FrLdsAttrOnce lds_once;  // per instantiation, per device
+    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_m2_kernel<44>, lds_once)) return rc_;
     const size_t rows1 = (size_t)(a.K / 4) + 64, rows2 = (size_t)(a.H2 / 4), rows3 = 64 + 4;  // R3 + 4 KiB of reduction scratch
     const size_t rows = rows1 > rows2 ? (rows1 > rows3 ? rows1 : rows3) : (rows2 > rows3 ? rows2 : rows3);
     fr_fused_tile_m2_kernel<44><<<dim3(a.n_batches * a.tiles_per_batch), dim3(512), rows * FR_M2_LD * 16, s>>>(a);
@@ -798,12 +790,8 @@ int frk_fused_h_items_per_wg() { return 64; }
 
 template <int MT, int T2W, int KG, bool DB>
 static int fused_h_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fr_fused_tile_h_kernel<MT, T2W, KG, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            FR_FAIL(FR_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
-        attr_set = true;
-    }
+    static FrLdsAttrOnce lds_once;  // per instantiation, per device
+    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_h_kernel<MT, T2W, KG, DB>, lds_once)) return rc_;
     fr_fused_tile_h_kernel<MT, T2W, KG, DB><<<grid, dim3(512), lds, s>>>(a);
     KCHECK();
     return FR_OK;
@@ -1015,12 +1003,8 @@ bool frk_fused_f8_ok(int K, int H1, int H2, int H3) { return (K == 352 || K == 8
 
 template <int G1>
 static int fused_f8_launch_inst(const FrFusedArgs &a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fr_fused_tile_f8_kernel<G1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            FR_FAIL(FR_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
-        attr_set = true;
-    }
+    static FrLdsAttrOnce lds_once;  // per instantiation, per device
+    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_f8_kernel<G1>, lds_once)) return rc_;
     const size_t rows1 = 4 * G1 + 32, rows2 = (size_t)(a.H2 / 16) + (size_t)(a.H3 / 16) + 2;  // + 2 rows: 512 floats of reduction scratch
     fr_fused_tile_f8_kernel<G1><<<dim3(a.n_batches * a.tiles_per_batch), dim3(512), (rows1 > rows2 ? rows1 : rows2) * 65 * 16, s>>>(a);
     KCHECK();

@@ -58,7 +58,9 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict
     auto Bs = [&](int st, int row) { return glds + ((size_t)st * FR_GR + row) * ROW + FR_GN; };  // GM elements
     // global -> LDS without a VGPR round trip: lane i's 16 bytes land at M0 + 16 i.  Inline asm on purpose: through the builtin the
     // compiler treats every LDS read as a possible alias of the DMA write and waits for vmcnt(0) before each fragment read; the
-    // s_waitcnt below is the only synchronisation these loads need.
+    // s_waitcnt below is the only synchronisation these loads need.  M0 is written here without a clobber entry: hipcc rejects "m0" in a
+    // clobber list (reserved register, the entry is ignored with a warning), and this kernel contains no other M0 user (no LDS-DMA
+    // builtin, s_sendmsg, s_movrel or GWS op) whose M0 set-up the compiler could have hoisted across the asm.
     auto dma = [&](const i32x4_t &rs, const uint4 *dst, unsigned voff, unsigned soff) {
         const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_ptr)dst);
         asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
@@ -189,13 +191,9 @@ bool frk_fc_lp_gemm_ok(int precision, int K, int N, int ldm) { return lp_gemm_mu
 
 template <int PREC, int MU>
 static int lp_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
-    static bool attr_set = false;
+    static FrLdsAttrOnce lds_once;  // per instantiation, per device
     const size_t lds = (size_t)FR_GSTAGES * FR_GR * (FR_GN + 128 * MU) * 16;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fc_lp_gemm_kernel<PREC, MU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            FR_FAIL(FR_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
-        attr_set = true;
-    }
+    if (int rc_ = fr_allow_full_lds(&fc_lp_gemm_kernel<PREC, MU>, lds_once)) return rc_;
     dim3 grid((N / FR_GN) * (ldm / (128 * MU)));
     fc_lp_gemm_kernel<PREC, MU><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale);
     KCHECK();

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -104,9 +105,17 @@ struct FrFusedArgs {
 };
 
 // ---- host objects -------------------------------------------------------------------------------
+// Where a table's rows live inside ctx->table_arena.  A table stored on its own: row r at byte_offset + r * dim * 4 (il_rows == 0).
+// FR_INDEX_PER_BANK contexts interleave the tables of one memory bank: rows [0, il_rows) of every table of the bank share one
+// "bank row" of row_stride bytes (row r of this table at byte_offset + r * row_stride, byte_offset already including the table's
+// column offset inside the bank row); rows [il_rows, rows) -- unreachable through a per-bank index, kept so that upload / download /
+// fill see the whole table -- sit contiguously at tail_offset.
 struct FrTableMem {
-    uint64_t byte_offset; // inside ctx->table_arena
-    bool resident;        // false when the table belongs to another shard
+    uint64_t byte_offset = 0;  // inside ctx->table_arena: row 0
+    uint64_t row_stride = 0;   // bytes between rows [0, il_rows) when interleaved; dim * 4 otherwise
+    uint64_t il_rows = 0;      // rows held in the bank-interleaved region (0 = none)
+    uint64_t tail_offset = 0;  // inside ctx->table_arena: row il_rows (interleaved tables only)
+    bool resident = false;     // false when the table belongs to another shard
 };
 
 struct fr_ctx {
@@ -115,6 +124,9 @@ struct fr_ctx {
     std::vector<fr_table_desc> tables;
     std::vector<fr_segment> segments;
     std::vector<FrTableMem> table_mem;
+    std::vector<int> bank_of_table;        // index column of every table in FR_INDEX_PER_BANK mode (banks numbered by first appearance)
+    std::vector<int64_t> bank_rows;        // per bank: min rows over its tables = the valid range of the bank's index
+    int n_banks = 0;
     char *table_arena = nullptr;           // one allocation holding every resident table, 256-B aligned starts
     size_t table_arena_bytes = 0;
     bool tables_filled = false;
@@ -141,6 +153,8 @@ struct fr_ctx {
     int slice_offset = 0, slice_len = 0, slice_padded = 0;
     std::vector<int> shard_offset, shard_len;  // record range of EVERY shard (floats), for the all-gathered layout
     hipStream_t setup_stream = nullptr;
+    // batches one fused streaming launch carries (fr_ctx_set_stream_group): per context; read by every driver thread
+    std::atomic<int> stream_group{FR_FUSED_DEFAULT_BATCHES};
 };
 
 struct fr_worker {
@@ -206,7 +220,7 @@ int fr_model_validate(const fr_model_desc *m);
 static inline uint32_t fr_table_uid(const fr_table_desc &t) {
     return (uint32_t)t.source * 1024u + (uint32_t)t.mem_class * 256u + (uint32_t)t.table_id;
 }
-int frk_fill_table(float *base, int64_t rows, int dim, int mode, uint32_t seed, uint32_t uid, hipStream_t s);
+int frk_fill_table(float *base, int64_t row0, int64_t rows, int dim, int64_t row_stride_bytes, int mode, uint32_t seed, uint32_t uid, hipStream_t s);
 int frk_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t layer, float scale, hipStream_t s);
 int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
                int transport, int e_x, hipStream_t s);
@@ -239,3 +253,5 @@ int frk_transpose_records(const float *X, float *Xt, int batch, int K, int ldm, 
 int frk_transpose_slices(const float *gathered, int n_shards, int batch_total, int slice_padded, const int *h_offsets, const int *h_lens,
                          int item0, int n_items, float *Xq, int ldm, hipStream_t s);
 void fr_shard_bounds(const fr_model_desc &m, int n_shards, std::vector<int> &seg_begin);
+// memory banks of the model: bank key = (source, mem_class, bank); numbered by first appearance in the table list
+int fr_bank_map(const fr_model_desc &m, std::vector<int> &bank_of_table, std::vector<int64_t> &bank_min_rows);

@@ -35,7 +35,7 @@ int fr_model_validate(const fr_model_desc *m) {
         if (m->fc[i] % 32) FR_FAIL(FR_ERR_INVALID, "fc[%d]=%d must be a multiple of 32 (32x32 MFMA output tiles)", i, m->fc[i]);
     if (m->fc[4] != 1) FR_FAIL(FR_ERR_INVALID, "only OUTPUT_FEATURE_LEN == 1 is supported (got %d)", m->fc[4]);
     if (m->layout != FR_LAYOUT_SEMANTIC && m->layout != FR_LAYOUT_BLOCKED) FR_FAIL(FR_ERR_INVALID, "bad layout %d", m->layout);
-    if (m->index_mode != FR_INDEX_PER_TABLE && m->index_mode != FR_INDEX_PER_ITEM) FR_FAIL(FR_ERR_INVALID, "bad index_mode %d", m->index_mode);
+    if (m->index_mode != FR_INDEX_PER_TABLE && m->index_mode != FR_INDEX_PER_ITEM && m->index_mode != FR_INDEX_PER_BANK) FR_FAIL(FR_ERR_INVALID, "bad index_mode %d", m->index_mode);
     for (int t = 0; t < m->n_tables; t++) {
         const fr_table_desc &d = m->tables[t];
         if (d.dim <= 0 || d.dim % 4 || d.dim > 1024) FR_FAIL(FR_ERR_INVALID, "table %d: dim %d must be a multiple of 4 in (0,1024]", t, d.dim);
@@ -117,6 +117,49 @@ extern "C" int fr_model_clone_scaled(const fr_model_desc *src, double row_scale,
 }
 
 extern "C" void fr_model_free(fr_model_desc *m) { free(m); }
+
+// Memory banks (the reference's table_HBMx / table_DDRx / table_PLRAMx kernel arguments, embedding_47_krnl.hpp:32-71): bank key =
+// (source, mem_class, bank), numbered by first appearance in the table list (tables are in wire order).
+int fr_bank_map(const fr_model_desc &m, std::vector<int> &bank_of_table, std::vector<int64_t> &bank_min_rows) {
+    bank_of_table.assign(m.n_tables, 0);
+    bank_min_rows.clear();
+    std::vector<int64_t> keys;
+    for (int t = 0; t < m.n_tables; t++) {
+        const fr_table_desc &d = m.tables[t];
+        const int64_t key = ((int64_t)d.source << 40) | ((int64_t)d.mem_class << 32) | (uint32_t)d.bank;
+        int b = -1;
+        for (size_t i = 0; i < keys.size(); i++)
+            if (keys[i] == key) { b = (int)i; break; }
+        if (b < 0) {
+            b = (int)keys.size();
+            keys.push_back(key);
+            bank_min_rows.push_back(d.rows);
+        }
+        if (d.rows < bank_min_rows[b]) bank_min_rows[b] = d.rows;
+        bank_of_table[t] = b;
+    }
+    return (int)keys.size();
+}
+
+extern "C" int fr_model_bank_map(const fr_model_desc *m, int32_t *bank_of_table, int64_t *bank_rows) {
+    int rc = fr_model_validate(m);
+    if (rc) return rc;
+    std::vector<int> bot;
+    std::vector<int64_t> rows;
+    const int nb = fr_bank_map(*m, bot, rows);
+    if (bank_of_table)
+        for (int t = 0; t < m->n_tables; t++) bank_of_table[t] = bot[t];
+    if (bank_rows)
+        for (int b = 0; b < nb; b++) bank_rows[b] = rows[b];
+    return nb;
+}
+
+extern "C" int fr_model_index_cols(const fr_model_desc *m) {
+    if (!m) return FR_ERR_INVALID;
+    if (m->index_mode == FR_INDEX_PER_ITEM) return 1;
+    if (m->index_mode == FR_INDEX_PER_TABLE) return m->n_tables;
+    return fr_model_bank_map(m, nullptr, nullptr);
+}
 
 extern "C" int64_t fr_model_table_bytes(const fr_model_desc *m) {
     if (!m || !m->tables) return 0;

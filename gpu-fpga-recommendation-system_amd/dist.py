@@ -65,8 +65,8 @@ class DistEnv:
     def all_gather_slices(self, local, out=None):
         """local: torch tensor [B, F] (same shape on every rank) -> [world, B, F]: the ONE exchange step of the sharded
         mode (ncclAllGather over xGMI when the backend is nccl)."""
-        if self.dist is None:
-            return local.reshape((1,) + tuple(local.shape))
+        if self.dist is None:  # one rank: the "exchange" is the identity -- but the caller's buffer must still receive it
+            return self._single_rank(local, out)
         if out is None:
             out = self.torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
         # the concatenated form [world*B, F] is what both the nccl and the gloo back-ends accept
@@ -79,12 +79,35 @@ class DistEnv:
         -> [world, B/world, F].  1/world of the all-gather's traffic."""
         B = local.shape[0]
         if self.dist is None:
-            return local.reshape((1,) + tuple(local.shape))
+            return self._single_rank(local, out)
         assert B % self.world == 0, "all-to-all exchange needs the batch divisible by the number of shards"
         if out is None:
             out = self.torch.empty((self.world, B // self.world) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         self.dist.all_to_all_single(out.view((B,) + tuple(local.shape[1:])), local.contiguous())
         return out
+
+    @staticmethod
+    def _single_rank(local, out):
+        """world == 1: [B, F] -> [1, B, F]; when the caller supplies `out`, the slice is copied INTO it (the caller keeps
+        reading its own buffer), otherwise a view of `local` is returned."""
+        shape = (1,) + tuple(local.shape)
+        if out is None:
+            return local.reshape(shape)
+        dst = out.reshape(shape)
+        if hasattr(dst, "copy_"):
+            dst.copy_(local.reshape(shape))      # torch
+        else:
+            dst[...] = local.reshape(shape)      # numpy
+        return out
+
+    def min_over_ranks_int(self, values):
+        """Element-wise MIN of a short list of python ints over all ranks (fp8 chain: every rank must quantise X, R1, R2, R3
+        with the SAME power-of-two exponents, or slices encoded by one rank are decoded with another rank's scale)."""
+        if self.dist is None:
+            return [int(v) for v in values]
+        t = self.torch.tensor([int(v) for v in values], dtype=self.torch.int64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return [int(v) for v in t.tolist()]
 
     def close(self):
         if self.dist is not None:

@@ -93,11 +93,20 @@ typedef struct fr_segment {
 typedef enum fr_layout { FR_LAYOUT_SEMANTIC = 0, FR_LAYOUT_BLOCKED = 1 } fr_layout;
 
 /* Index mode.
- *  PER_TABLE: idx[B][n_tables], column t = table t of the model (tables are listed in wire order).
- *  PER_ITEM : idx[B], one index per item reused for every table -- what the reference actually does
- *             (load_access_idx feeds the same stream to every bank and each bank reuses it for all its
- *             rounds: embedding_47_krnl.cpp:580-628,899-914; embedding_98_krnl.cpp:1026-1040). */
-typedef enum fr_index_mode { FR_INDEX_PER_TABLE = 0, FR_INDEX_PER_ITEM = 1 } fr_index_mode;
+ *  PER_TABLE: idx[B][n_tables], column t = table t of the model (tables are listed in wire order).  A generalisation: the
+ *             reference cannot address the tables of a bank independently.
+ *  PER_ITEM : idx[B], one index per item reused for every table -- what the reference's built-in index source does
+ *             (load_access_idx feeds the same stream to every bank: embedding_47_krnl.cpp:580-628,899-914).
+ *  PER_BANK : idx[B][n_banks], ONE index per memory bank per item, reused for every table ("round") of that bank -- the
+ *             kernel's real contract: load_single_embedding_{2,4,5}_tables reads s_idx_buffer once per item and addresses each
+ *             round's table with it (embedding_98_krnl.cpp:1026-1040, embedding_377_krnl.cpp:1261-1290).  Banks are numbered by
+ *             first appearance in the model's table list (fr_model_bank_map); bank key = (source, mem_class, bank).  A bank's
+ *             index must be < the row count of EVERY table of the bank (the reference reads the next table instead,
+ *             embedding_47_krnl.cpp:927-933; here FR_ERR_INDEX_RANGE).  In this mode the context stores the tables of a bank
+ *             row-interleaved in HBM (row r of all its tables in one contiguous 112..256-byte "bank row", padded to whole
+ *             128-byte lines where that saves a line), so a bank costs one contiguous fetch per item instead of one scattered
+ *             row per table: 82 fetches instead of 376 rows for Model-C. */
+typedef enum fr_index_mode { FR_INDEX_PER_TABLE = 0, FR_INDEX_PER_ITEM = 1, FR_INDEX_PER_BANK = 2 } fr_index_mode;
 
 typedef struct fr_model_desc {
     char name[32];
@@ -164,6 +173,13 @@ int fr_model_clone_scaled(const fr_model_desc *src, double row_scale, int64_t mi
 void fr_model_free(fr_model_desc *m); /* only for fr_model_clone_scaled results */
 /* Σ rows*dim*4 over the model's tables. */
 int64_t fr_model_table_bytes(const fr_model_desc *m);
+/* int32 columns of one item's index row in the model's index_mode: n_tables, 1 or the number of banks (<= 0: invalid model). */
+int fr_model_index_cols(const fr_model_desc *m);
+/* Memory banks of the model, numbered by first appearance in the table list.  Returns the number of banks (negative fr_status on
+ * error); bank_of_table (n_tables ints, may be NULL) receives each table's bank = its index column in FR_INDEX_PER_BANK mode;
+ * bank_rows (one int64 per bank, may be NULL; size it n_tables) the smallest row count among the bank's tables = the valid range of
+ * that bank's index. */
+int fr_model_bank_map(const fr_model_desc *m, int32_t *bank_of_table, int64_t *bank_rows);
 
 /* ---- context: replaces main()'s device probe + cublasLtCreate (cuda_server.c:508-522,547-551)
  *      plus the FPGA host's table set-up (host.cpp:264-423,691-731) ----------------------------- */
@@ -199,7 +215,7 @@ int fr_ctx_set_fp8_act_exponents(fr_ctx *ctx, const int act_exp[4]);
 int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out);
 void fr_worker_destroy(fr_worker *w);
 /* Pinned host staging buffers the driver's socket read() lands in directly (cuda_server.c:437 reads
- * into pinned input_feature): int32 idx[max_batch][n_tables] (PER_TABLE) or idx[max_batch] (PER_ITEM),
+ * into pinned input_feature): int32 idx[max_batch][fr_model_index_cols(model)],
  * float dense[max_batch][dense_len] (NULL when dense_len == 0), float score[max_batch]. */
 int32_t *fr_worker_idx_ptr(fr_worker *w);
 float *fr_worker_dense_ptr(fr_worker *w);
@@ -214,30 +230,39 @@ void *fr_worker_stream(fr_worker *w);
  * pinned buffers are touched again (this fixes the reference's unsynchronised reuse, cuda_server.c:406-497). */
 int fr_worker_submit(fr_worker *w, int batch);
 /* Same, with inputs/outputs already resident in HBM (device pointers; no PCIe traffic):
- * d_idx int32 [batch][n_tables] or [batch]; d_dense float [batch][dense_len] or NULL;
+ * d_idx int32 [batch][fr_model_index_cols(model)]; d_dense float [batch][dense_len] or NULL;
  * d_scores float [batch]. */
 int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense,
                             float *d_scores);
 /* Streaming form of the hot loop: enqueue batch after batch WITHOUT synchronising, as the reference's loop does
- * (cuda_server.c:406-497).  Each call issues one launch in which this batch is gathered while the previous four
- * batches of this worker advance through FC1, FC2, FC3 and the output layer (stage pipeline across batches).
- * d_scores of a pushed batch are complete once four more pushes have executed, or after fr_worker_sync(), which
- * drains the pipeline.  The caller keeps d_idx / d_dense / d_scores valid and distinct for every batch still in
- * the pipeline (up to 5).  Needs an unsharded, SEMANTIC-layout, fp32 context. */
+ * (cuda_server.c:406-497).  Any FC precision; needs an unsharded, SEMANTIC-layout context.  Two execution forms, chosen per context:
+ *  - models whose activations fit in LDS (A, B) stream through the fused item-tile kernel: pushed batches are QUEUED on the worker and
+ *    one launch carries fr_ctx_stream_group(ctx) of them (or fewer once 16384 items are queued); nothing runs before the group is full
+ *    or fr_worker_sync() is called;
+ *  - every other model rides the stage pipeline: each push issues one launch in which this batch is gathered while the previous four
+ *    batches of the worker advance through FC1, FC2, FC3 and the output layer.
+ * BUFFER LIFETIME (both forms): d_idx / d_dense / d_scores of a pushed batch must stay valid, distinct and untouched until
+ * fr_worker_sync(w) returns -- the only completion point this API defines.  A caller that wants to bound its buffer count rotates
+ * R >= 2 * max(fr_ctx_stream_group(ctx), 5) buffer sets and calls fr_worker_sync once per trip round the ring (what
+ * fr_driver_run_resident does with R = 256). */
 int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores);
-/* How many pushed batches one streaming launch carries on this context: 1 when fr_worker_push_device rides the stage
- * pipeline, G (default 32) when the model qualifies for the fused item-tile kernel, which queues pushed batches and
- * launches every G pushes (fr_worker_sync launches a partial group). */
+/* How many pushed batches one streaming launch carries on this context: 1 when fr_worker_push_device rides the stage pipeline,
+ * G (1..64, default 64; env FR_FUSED_GROUP overrides the default of new contexts) when the model streams through the fused
+ * item-tile kernel. */
 int fr_ctx_stream_group(const fr_ctx *ctx);
-/* Throughput/latency knob of the fused streaming path: batches per launch, 1..32 (default 32 = 256 workgroups = one per CU;
- * process-wide).  Smaller groups cut the queueing latency of a pushed batch and leave CUs to other streams. */
+/* Throughput/latency knob of the fused streaming path, PER CONTEXT: batches per launch, 1..64.  64 batches of 256 items = one 64-item
+ * workgroup per CU (fp32: fr_fused_tile_m2_kernel); <= 32 selects the 32-item kernel, halves the queueing latency of a pushed batch and
+ * leaves CUs to other streams.  Scores are bit-identical for every group size.  May be called while workers are pushing (atomic); a
+ * worker's queue that already holds >= the new size launches at its next push or sync. */
 int fr_ctx_set_stream_group(fr_ctx *ctx, int batches_per_launch);
-/* Drains and waits for everything enqueued on the worker; returns FR_ERR_INDEX_RANGE if any index was out of range. */
 /* Host-fed streaming: like fr_worker_push_device for a batch that sits in (any) host memory.  The rows are copied into the worker's
  * pinned staging before the call returns (h_idx / h_dense may be reused at once); batches travel in groups as one H2D copy + one
- * launch + one D2H copy; h_scores[0..batch) is valid after fr_worker_sync, or earlier once 4 x group later pushes have been made.
+ * launch + one D2H copy; h_scores[0..batch) is valid after fr_worker_sync (earlier deliveries happen -- a block's scores are copied out
+ * before its staging is reused, i.e. at the latest 4 blocks later -- but fr_worker_sync is the only completion point the API defines).
  * The streaming counterpart of the per-batch recv -> H2D -> GEMMs -> D2H sequence of cuda_server.c:425-495. */
 int fr_worker_push_host(fr_worker *w, int batch, const int32_t *h_idx, const float *h_dense, float *h_scores);
+/* Launches whatever is still queued, drains the pipeline and waits for everything enqueued on the worker; returns
+ * FR_ERR_INDEX_RANGE if any index was out of range. */
 int fr_worker_sync(fr_worker *w);
 /* fp8 chain: run `batch` items (the worker's pinned idx/dense buffers, as for fr_worker_submit) through the fp32 chain, take
  * max|.| of X, R1, R2, R3 and set the context's activation exponents so that twice that maximum still fits e4m3's 448.

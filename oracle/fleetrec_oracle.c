@@ -223,3 +223,53 @@ void oracle_block_records(int n_src, const int32_t *src_len, int64_t B, const fl
         off += src_len[s];
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Memory-resident CPU baseline pieces (bench.py's cpu_baseline leg; SURVEY section 8(d): "own OpenMP
+ * gather (H3/H4 restatement) + sgemm chain via OpenBLAS").  Same semantics as oracle_gather_banks in
+ * MEMORY mode -- rows at bank word ADDR_AXI + idx*AXI_PADDED_SIZE (embedding_47_krnl.cpp:916-935), the
+ * packers' fixed word order (embedding_47_krnl.cpp:964-1217) -- but written the way a CPU server would
+ * run it: the (bank, k) -> (round, word-in-row) resolution is done once, each record word is one
+ * 16-byte copy straight from the bank image into the record, items are spread over the cores.
+ * tests/test_oracle.py checks it word for word against oracle_gather_banks.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Writes table rows [0, rows) into a bank image exactly where host.cpp's init_vectors puts them
+ * (host.cpp:66-88: bank word ADDR_AXI + row*AXI_PADDED_SIZE + j), contents = content_bits. */
+void oracle_fill_bank_table(int mode, uint32_t seed, uint32_t uid, int64_t addr_axi, int axi_words, int64_t rows, uint8_t *bank_image) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; r++) {
+        uint32_t *dst = (uint32_t *)(bank_image + 16 * (addr_axi + r * (int64_t)axi_words));
+        for (int c = 0; c < 4 * axi_words; c++) dst[c] = content_bits(mode, seed, uid, (uint64_t)r, (uint32_t)c);
+    }
+}
+
+void oracle_gather_banks_direct(int n_banks, const int32_t *bank_ntab, const int64_t *tab_addr, const int32_t *tab_axi,
+                                const uint8_t *const *bank_mem, int n_rec_words, const int32_t *rec_bank, const int32_t *rec_k,
+                                const int32_t *idx, int idx_per_round, int64_t n_items, uint8_t *out) {
+    int *first = (int *)malloc(sizeof(int) * (n_banks + 1));
+    first[0] = 0;
+    for (int b = 0; b < n_banks; b++) first[b + 1] = first[b] + bank_ntab[b];
+    const int idx_cols = idx_per_round ? first[n_banks] : n_banks;
+    const uint8_t **src = (const uint8_t **)malloc(sizeof(void *) * n_rec_words);
+    int64_t *stride = (int64_t *)malloc(sizeof(int64_t) * n_rec_words);
+    int *col = (int *)malloc(sizeof(int) * n_rec_words);
+    for (int w = 0; w < n_rec_words; w++) {
+        const int b = rec_bank[w];
+        int k = rec_k[w], r = first[b];
+        while (k >= tab_axi[r]) k -= tab_axi[r++];  /* k-th word of the bank's per-item stream -> (round r, word k of its row) */
+        src[w] = bank_mem[b] + 16 * (tab_addr[r] + k);
+        stride[w] = 16 * (int64_t)tab_axi[r];
+        col[w] = idx_per_round ? r : b;
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t item = 0; item < n_items; item++) {
+        const int32_t *irow = idx + item * idx_cols;
+        uint8_t *o = out + (size_t)item * n_rec_words * 16;
+        for (int w = 0; w < n_rec_words; w++) memcpy(o + 16 * w, src[w] + (int64_t)irow[col[w]] * stride[w], 16);
+    }
+    free(first);
+    free(src);
+    free(stride);
+    free(col);
+}

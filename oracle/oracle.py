@@ -90,6 +90,23 @@ class Half:
     def n_tables(self):
         return len(self.rounds)
 
+    def banks_in_wire_order(self):
+        """Bank numbers (positions in the registry's bank list) in order of first appearance in the record -- the column order of a
+        per-bank index row as a host that lists tables in wire order would number them."""
+        order = []
+        for r in self.wire_to_round:
+            b = self.rounds[r][0]
+            if b not in order:
+                order.append(b)
+        assert len(order) == self.n_banks
+        return order
+
+    def bank_min_rows(self):
+        """Per bank (registry order): the smallest TABLE_SIZE among its tables = the range over which ONE index is valid for every
+        round of the bank (beyond it the reference reads the next table's rows, embedding_47_krnl.cpp:927-933)."""
+        first = np.concatenate([[0], np.cumsum(self.bank_ntab)])
+        return np.array([self.tab_rows[first[b]:first[b + 1]].min() for b in range(self.n_banks)], dtype=np.int64)
+
     def bank_images(self, fill_rows_fn):
         """Materialise the card's bank memories like host.cpp does: table t's row r sits at
         bank word ADDR_AXI + r*AXI_PADDED_SIZE.  fill_rows_fn(round_index, table_json, rows) ->
@@ -104,6 +121,37 @@ class Half:
                 img[t["addr_axi"]:t["addr_axi"] + t["rows"] * t["axi_words"]] = rows.reshape(-1, 4)
             imgs.append(img)
         return imgs
+
+    def bank_images_native(self, content_mode, seed=0):
+        """Full-size bank memory images in host RAM, filled by the C side (OpenMP) -- what host.cpp migrates to the card
+        (host.cpp:324-423,739-749).  -> list of uint8 arrays, one per bank.  Model-A: 1.4 GB, Model-B: 15 GB."""
+        imgs = []
+        first = np.concatenate([[0], np.cumsum(self.bank_ntab)])
+        for bi, b in enumerate(self.reg["banks"]):
+            need = max(t["addr_axi"] + t["rows"] * t["axi_words"] for t in b["tables"])
+            img = np.zeros(need * 16, dtype=np.uint8)
+            for r, t in zip(range(first[bi], first[bi + 1]), b["tables"]):
+                lib().oracle_fill_bank_table(ctypes.c_int(content_mode), ctypes.c_uint32(seed), ctypes.c_uint32(int(self.tab_uid[r])),
+                                             ctypes.c_int64(t["addr_axi"]), ctypes.c_int(t["axi_words"]), ctypes.c_int64(t["rows"]),
+                                             _p(img, ctypes.c_uint8))
+            imgs.append(img)
+        return imgs
+
+    def gather_direct(self, idx, per_round, bank_images, out=None):
+        """The memory-resident CPU-baseline gather (oracle_gather_banks_direct): same arguments and result as
+        gather(..., content_mode=FILL_MEMORY, bank_images=...)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        B = idx.shape[0]
+        assert idx.shape[1] == (len(self.rounds) if per_round else self.n_banks)
+        if out is None:
+            out = np.empty((B, self.record_len), dtype=np.uint32)
+        ptrs = (ctypes.c_void_p * self.n_banks)(*[im.ctypes.data for im in bank_images])
+        lib().oracle_gather_banks_direct(
+            ctypes.c_int(self.n_banks), _p(self.bank_ntab, ctypes.c_int32), _p(self.tab_addr, ctypes.c_int64),
+            _p(self.tab_axi, ctypes.c_int32), ptrs, ctypes.c_int(self.n_rec_words), _p(self.rec_bank, ctypes.c_int32),
+            _p(self.rec_k, ctypes.c_int32), _p(idx, ctypes.c_int32), ctypes.c_int(1 if per_round else 0),
+            ctypes.c_int64(B), _p(out, ctypes.c_uint8))
+        return out
 
     def gather(self, idx, per_round, content_mode, seed=0, bank_images=None):
         """idx: int32 [B][n_banks] (per_round=False) or [B][n_rounds] in flattened (bank, round) order.
@@ -153,12 +201,34 @@ class OracleModel:
         """per-source record lengths in the 3-node block order [CPU, FPGA0, FPGA1]"""
         return ([self.dense_len] if self.dense_len else []) + [h.record_len for h in self.halves]
 
-    def gather(self, idx, dense=None, content_mode=FILL_HASH, seed=0, bank_images=None, rows_wire=None):
+    @property
+    def n_banks(self):
+        return sum(h.n_banks for h in self.halves)
+
+    def bank_rows_wire(self):
+        """Valid index range of every bank, banks in wire order of first appearance (half 0 first)."""
+        return np.concatenate([h.bank_min_rows()[h.banks_in_wire_order()] for h in self.halves])
+
+    def gather(self, idx, dense=None, content_mode=FILL_HASH, seed=0, bank_images=None, rows_wire=None, per_bank=False):
         """idx: int32 [B][n_tables] with columns in WIRE order (the product's table order), or int32 [B]
-        (reference behaviour: one index per item for everything).  -> uint32 [B][record_len], SEMANTIC layout
-        [dense | half0 | half1]."""
+        (reference behaviour: one index per item for everything), or -- per_bank=True -- int32 [B][n_banks] with ONE index per
+        bank per item (the kernel's contract: embedding_98_krnl.cpp:1026-1040), banks in wire order of first appearance.
+        -> uint32 [B][record_len], SEMANTIC layout [dense | half0 | half1]."""
         idx = np.asarray(idx, dtype=np.int32)
         B = idx.shape[0]
+        if per_bank:
+            assert idx.ndim == 2 and idx.shape[1] == self.n_banks
+            parts = []
+            if self.dense_len:
+                parts.append(np.ascontiguousarray(dense, dtype=np.float32).reshape(B, self.dense_len).view(np.uint32))
+            col = 0
+            for hi, h in enumerate(self.halves):
+                sub = idx[:, col:col + h.n_banks]
+                hidx = np.empty_like(sub)
+                hidx[:, h.banks_in_wire_order()] = sub  # wire order of banks -> registry bank order
+                col += h.n_banks
+                parts.append(h.gather(hidx, False, content_mode, seed, None if bank_images is None else bank_images[hi]))
+            return np.concatenate(parts, axis=1)
         parts = []
         if self.dense_len:
             d = np.ascontiguousarray(dense, dtype=np.float32).reshape(B, self.dense_len)

@@ -32,6 +32,8 @@ WORKER = textwrap.dedent('''
     assert dist_mod.replica_seed(1234, 0) != dist_mod.replica_seed(1234, 1)
     assert dist_mod.aggregate_throughput(1000, mx, env.world) == 2 * 1000 / 0.75
     assert abs(env.sum_over_ranks(env.rank + 1) - 3.0) < 1e-12
+    # fp8 chain: every rank adopts the element-wise MIN of the per-rank activation exponents
+    assert env.min_over_ranks_int([3 + env.rank, 5 - env.rank, -2, 7]) == [3, 4, -2, 7]
     # --- sharded mode: every rank sees the whole request, gathers only its slice, one all-gather --------------------
     which, name = %(which)d, %(name)r
     model = fr.Model.builtin(which)
@@ -107,3 +109,75 @@ def test_shard_plan_properties(fr):
             assert max(lens) - min(lens) <= 64                # float-balanced (largest row is 32 floats, dense block 64)
     with pytest.raises(fr.FleetRecError):
         fr.Model.builtin(fr.MODEL_A).shard_plan(48)           # more shards than segments
+
+
+def test_single_rank_exchange_fills_the_callers_buffer(fr):
+    """world == 1: the exchange is the identity, but a caller-supplied output buffer must still receive the slice (bench.py's
+    sharded mode reads ITS buffer; round 1 left it uninitialised -- ADVICE r01)."""
+    import importlib
+    import torch
+    import __graft_entry__ as g
+    g.load_package()
+    dist_mod = importlib.import_module("fleetrec_amd.dist")
+    env_keep = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    try:
+        env = dist_mod.DistEnv(None)
+        assert env.world == 1 and env.dist is None
+        local = torch.arange(24, dtype=torch.uint8).reshape(4, 6)
+        for fn in (env.all_gather_slices, env.all_to_all_slices):
+            out = torch.full((1, 4, 6), 255, dtype=torch.uint8)
+            ret = fn(local, out)
+            assert ret is out and torch.equal(out[0], local)
+            assert tuple(fn(local).shape) == (1, 4, 6)
+        assert env.min_over_ranks_int([4, -1]) == [4, -1]
+    finally:
+        for k, v in env_keep.items():
+            if v is not None:
+                os.environ[k] = v
+
+
+def _run_bench(args, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def test_bench_self_launches_ranks_and_refuses_a_wrong_world():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must start 2 rank processes itself (before any GPU call) and report
+    n_gpus == 2; a WORLD_SIZE that contradicts --gpus is refused instead of being reported as a different n_gpus.
+    --plumbing-only = launcher + gloo rendezvous + barrier + max-over-ranks timing, no GPU and no library."""
+    import json
+    rc, out, err = _run_bench(["--gpus", "2", "--plumbing-only", "--steps", "7", "--warmup", "3"])
+    assert rc == 0, err
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out                      # ONE JSON line, from rank 0
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 7 and j["warmup"] == 3 and j["config"]["self_launched"] is True
+    assert j["ms_per_step"] * 7 >= 20.0 - 1e-6       # max over ranks: rank 1 sleeps 20 ms
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--plumbing-only"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0 and b"refusing" in p.stderr and b"{" not in p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--mode", "sharded", "--rows-cap", "20000", "--steps", "3", "--warmup", "1"],
+                                   ["--mode", "sharded", "--rows-cap", "20000", "--steps", "3", "--warmup", "1", "--precision", "fp8", "--exchange", "alltoall"]])
+def test_bench_two_ranks_on_one_gpu(gpu, extra):
+    """The N = 2 path end to end on a one-GPU box: self-launched ranks, gloo rendezvous, both ranks on device 0
+    (--share-device).  Replicas: value aggregates both ranks.  Sharded: 2-way table-ID shards, the exchange through gloo, scores
+    of rank 0's items equal to an unsharded context (bit-identical) and the pipelined run equal to the stepwise one."""
+    import json
+    args = ["--gpus", "2", "--backend", "gloo", "--share-device", "--legs", "none"] + (extra or ["--steps", "300", "--warmup", "100"])
+    rc, out, err = _run_bench(args, timeout=900)
+    assert rc == 0, err[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0
+    if extra:
+        c = j["config"]
+        assert c["pipelined_equals_stepwise"] is True
+        assert c["sharded_vs_unsharded_context"]["bit_identical"] is True, c
+    else:
+        assert j["timed_batches"] >= 300 and j["timed_s"] >= 2.0 and j["scaling"] == "weak"

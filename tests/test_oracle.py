@@ -170,3 +170,57 @@ def test_content_rows_matches_c(O):
             assert int(a[r, c]) == O.lib().oracle_content_bits(mode, 0xF1EE7, uid, 2 ** 32 - 100 + r, c)
     h = O.content_rows(O.FILL_HASH, 1, 5, 4096, 32).view(np.float32)
     assert h.min() >= -1.0 and h.max() < 1.0 and abs(h.mean()) < 0.02 and 0.3 < h.var() < 0.37
+
+
+def test_memory_resident_gather_matches_bank_oracle(O):
+    """The cpu_baseline leg's memory-resident gather (bank images in host RAM filled like host.cpp:66-88 + one 16-byte copy per
+    record word) == oracle_gather_banks on procedural contents, per-table and per-bank index forms, Model-A at full size (1.4 GB)."""
+    h = O.Half(47, 0)
+    imgs = h.bank_images_native(O.FILL_HASH, 0xF1EE7)
+    assert sum(im.nbytes for im in imgs) == 1414678400
+    rng = np.random.default_rng(3)
+    B = 300
+    idx = (rng.random((B, h.n_tables)) * h.tab_rows[None, :]).astype(np.int32)
+    idx[0], idx[1] = 0, h.tab_rows - 1
+    want = h.gather(idx, True, O.FILL_HASH, 0xF1EE7)
+    assert np.array_equal(h.gather_direct(idx, True, imgs), want)
+    assert np.array_equal(h.gather(idx, True, O.FILL_MEMORY, bank_images=imgs), want)
+    bidx = (rng.random((B, h.n_banks)) * h.bank_min_rows()[None, :]).astype(np.int32)
+    assert np.array_equal(h.gather_direct(bidx, False, imgs), h.gather(bidx, False, O.FILL_HASH, 0xF1EE7))
+
+
+def test_per_bank_oracle_is_the_per_table_oracle_with_shared_indices(O):
+    """One index per bank reused by every round (embedding_98_krnl.cpp:1026-1040) == the per-table form fed that index for every
+    table of the bank; Model-B and one Model-C half, tagged contents."""
+    for n in (98, 377):
+        h = O.Half(n, 0)
+        rng = np.random.default_rng(n)
+        B = 64
+        bidx = (rng.random((B, h.n_banks)) * h.bank_min_rows()[None, :]).astype(np.int32)
+        bank_of_round = np.array([b for b, _ in h.rounds])
+        assert np.array_equal(h.gather(bidx, False, O.FILL_TAGGED), h.gather(bidx[:, bank_of_round], True, O.FILL_TAGGED))
+
+
+def test_golden_tagged_records_fixture(O, fr):
+    """tests/golden/records_*.bin (committed bytes, made by tests/golden/make_records.py): the oracle reproduces them, and every
+    float decodes to the table / row / column the product's segment list says belongs at that position of the record."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_records", os.path.join(GOLD, "make_records.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    for which, fname in mk.FILES.items():
+        idx, dense, rec = mk.read(os.path.join(GOLD, fname))
+        om = O.OracleModel(which)
+        assert rec.shape == (32, om.record_len) and idx.shape == (32, om.n_tables)
+        assert np.array_equal(om.gather(idx, dense=dense if om.dense_len else None, content_mode=O.FILL_TAGGED), rec)
+        m = fr.Model.builtin({"A": fr.MODEL_A, "B": fr.MODEL_B, "C": fr.MODEL_C}[which])
+        tabs = m.tables()
+        for s in m.segments():
+            got = rec[:, s.rec_offset:s.rec_offset + s.len]
+            if s.kind == fr.SEG_DENSE:
+                assert np.array_equal(got.view(np.float32), dense[:, s.src_col:s.src_col + s.len])
+                continue
+            t = tabs[s.src]
+            tag = (np.uint32(t.source) << np.uint32(31)) | (np.uint32(t.mem_class) << np.uint32(29)) | (np.uint32(t.table_id) << np.uint32(21))
+            want = tag | (idx[:, s.src].astype(np.uint32)[:, None] << np.uint32(5)) | (np.arange(s.src_col, s.src_col + s.len, dtype=np.uint32)[None, :] & np.uint32(31))
+            assert np.array_equal(got, want), (which, s.src, s.rec_offset)

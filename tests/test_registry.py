@@ -247,3 +247,22 @@ def test_config5_inflated_tables_need_eight_shards(fr):
         per_shard[r] += tabs[sg.src].rows * tabs[sg.src].dim * 4
     assert sum(per_shard) == m.table_bytes()
     assert max(per_shard) < HBM                       # every shard fits its GPU
+
+
+def test_bank_map_matches_the_extracted_banks(fr, O):
+    """FR_INDEX_PER_BANK's index columns = the reference's memory banks (47 / 49 / 2 x 41), numbered by first appearance in
+    the wire order; each bank's valid index range = the smallest TABLE_SIZE among its rounds."""
+    for which, name, nb in ((fr.MODEL_A, "A", 47), (fr.MODEL_B, "B", 49), (fr.MODEL_C, "C", 82)):
+        m = fr.Model.builtin(which).clone(index_mode=fr.INDEX_PER_BANK)
+        om = O.OracleModel(name)
+        bot, brows = m.bank_map()
+        assert m.idx_cols == nb == om.n_banks == len(brows)
+        assert np.array_equal(brows, om.bank_rows_wire())
+        # tables of one bank share (source, class, bank) and are listed in round order
+        tabs = m.tables()
+        for b in range(nb):
+            members = [t for t in range(m.n_tables) if bot[t] == b]
+            assert len({(tabs[t].source, tabs[t].mem_class, tabs[t].bank) for t in members}) == 1
+            assert [tabs[t].round for t in members] == list(range(len(members)))
+        assert fr.Model.builtin(which).idx_cols == m.n_tables
+        assert fr.Model.builtin(which).clone(index_mode=fr.INDEX_PER_ITEM).idx_cols == 1
