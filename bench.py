@@ -198,9 +198,15 @@ def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=
     """Model-A on the node's host cores: tables materialised in host RAM exactly as host.cpp lays out the card's banks (1.4 GB),
     OpenMP gather that READS them, sgemm chain through OpenBLAS over the same 64 x 256 = 16384-item grouping one GPU launch
     gets.  Three figures: gather-only, FC-only, end-to-end (each >= budget_s of wall clock)."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # idle OpenMP threads must not spin beside OpenBLAS's pool (and vice versa)
     O = graft.load_oracle()
     om = O.OracleModel("A")
     h = om.halves[0]
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:
+        usable = os.cpu_count() or 1
+    O.lib().oracle_set_num_threads(usable)
     t0 = time.perf_counter()
     imgs = h.bank_images_native(O.FILL_HASH, SEED_TABLES)
     t_fill = time.perf_counter() - t0
@@ -214,7 +220,17 @@ def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=
     rec = np.empty((n, h.record_len), dtype=np.uint32)
     bufs = [np.empty((n, fc[l + 1]), dtype=np.float32) for l in range(4)]
     blas = load_blas()
-    threads = O.lib().oracle_num_threads()
+    # gather threads: the fastest of {all usable cores, 1/2, 1/4, 64, 32} on a short probe (hyper-threads and cgroup CPU quotas make
+    # "all" a poor choice on some hosts); `cores` reports what the timed runs actually used
+    probe = {}
+    for nt in sorted({usable, max(usable // 2, 1), max(usable // 4, 1), min(64, usable), min(32, usable)}, reverse=True):
+        O.lib().oracle_set_num_threads(nt)
+        h.gather_direct(hidx, True, imgs, out=rec)
+        t1 = time.perf_counter()
+        h.gather_direct(hidx, True, imgs, out=rec)
+        probe[nt] = time.perf_counter() - t1
+    threads = min(probe, key=probe.get)
+    O.lib().oracle_set_num_threads(threads)
 
     def timed(fn):
         fn()
@@ -238,6 +254,7 @@ def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=
             "gather_GBps_algorithmic": g_rate * gbytes / 1e9, "fc_GFLOPs": f_rate * fc_flops_per_inference(fc) / 1e9,
             "blas": blas["name"] if blas else "torch.mm (" + __import__("torch").__config__.parallel_info().split("\n")[0] + ")",
             "blas_symbol": blas["symbol"] if blas else "torch.mm", "blas_threads": blas["threads"] if blas else None,
+            "gather_thread_probe_s": {str(k): v for k, v in probe.items()}, "host_cpus_usable": usable,
             "gpu_vs_cpu_max_rel_err_first_batch": err, "host_table_bytes": int(sum(im.nbytes for im in imgs)), "host_table_fill_s": t_fill,
             "sample": "Model-A, %d items per call (64 batches of 256, the grouping one fused GPU launch gets), same seeded indices / tables / weights; "
                       "gather-only %d calls, FC-only %d, end-to-end %d (>= %.1f s each); gather = OpenMP over items reading bank images in host RAM "
@@ -335,9 +352,11 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
     return res
 
 
-def leg_gather(fr, ctx, model, B, law, reps=200, nbuf=32, seed=SEED_IDX):
+def leg_gather(fr, ctx, model, B, law, reps=200, nbuf=32, seed=SEED_IDX, variants=False):
     """fr_worker_gather_only (record-producing gather, the section-8(d) roofline kernel) at Model-C batch 4096: `nbuf` rotating
-    index buffers, `reps` timed launches, HIP events on the worker's stream."""
+    index buffers, `reps` timed launches, HIP events on the worker's stream.  variants=True adds the A/B of the three gather
+    kernels on the same index buffers (word-major / item-tile / item-tile + wave-level dedup) with the dedup kernel's own count of
+    merged lookups."""
     rng = np.random.default_rng(seed)
     ranges = model.index_ranges()
     mk = (lambda: zipf_idx(rng, ranges, B)) if law == "zipf" else (lambda: uniform_idx(rng, ranges, B))
@@ -354,12 +373,35 @@ def leg_gather(fr, ctx, model, B, law, reps=200, nbuf=32, seed=SEED_IDX):
         wk.gather_only(B, idxs[i % nbuf], dns[i % nbuf] if dns else None, rec)
     ms = wk.timer_stop_ms() / reps
     wk.sync()
+    ab = None
+    if variants:
+        ab = {}
+        lookups = B * model.n_tables if model.desc.index_mode == fr.INDEX_PER_TABLE else B * model.idx_cols
+        for name, var in (("word_major", fr.GATHER_WORD_MAJOR), ("item_tile", fr.GATHER_ITEM_TILE), ("item_tile_dedup", fr.GATHER_ITEM_TILE_DEDUP)):
+            ctx.set_gather_variant(var)
+            for i in range(20):
+                wk.gather_only(B, idxs[i % nbuf], dns[i % nbuf] if dns else None, rec)
+            wk.sync()
+            wk.timer_start()
+            for i in range(reps):
+                wk.gather_only(B, idxs[i % nbuf], dns[i % nbuf] if dns else None, rec)
+            ab[name] = {"avg_launch_ms": wk.timer_stop_ms() / reps}
+            wk.sync()
+        ctx.set_gather_variant(fr.GATHER_ITEM_TILE_DEDUP_COUNT)   # un-timed: how many lookups the waves actually merged
+        ctx.gather_merged_lookups(reset=True)
+        for i in range(nbuf):
+            wk.gather_only(B, idxs[i], dns[i] if dns else None, rec)
+        wk.sync()
+        ab["item_tile_dedup"]["merged_lookup_fraction"] = ctx.gather_merged_lookups() / float(nbuf * lookups)
+        ctx.set_gather_variant(fr.GATHER_WORD_MAJOR)
     wk.close()
     for b_ in idxs + (dns or []):
         b_.free()
     gb = gather_bytes_per_inference(model, fr) * B
     out = {"avg_launch_ms": ms, "achieved": gb / (ms * 1e-3) / 1e9, "frac": gb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "algorithmic_bytes_per_launch": gb, "inferences_per_s": B / (ms * 1e-3), "index_buffers": nbuf, "timed_launches": reps}
+    if ab is not None:
+        out["kernel_ab"] = ab
     if law == "zipf":
         cols = range(0, host[0].shape[1], 7)
         out["duplicate_fraction_within_batch"] = float(np.mean([1.0 - len(np.unique(z[:, t])) / B for z in host[:2] for t in cols]))
@@ -566,6 +608,8 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="plumbing test: ranks share the visible GPU(s) (use with --backend gloo)")
     ap.add_argument("--rows-cap", type=int, default=0, help="plumbing tests: cap every table's row count (sharded mode)")
     ap.add_argument("--no-unsharded-check", action="store_true", help="sharded mode: skip rank 0's comparison against an unsharded context")
+    ap.add_argument("--no-gather-ab", action="store_true", help="gather legs: skip the kernel A/B (PMC passes: one kernel per leg)")
+    ap.add_argument("--quick", action="store_true", help="profiling runs: 0.3 s instead of >= 2 s behind `value` (the legs are what is being profiled)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch / rendezvous / timing-rule check without touching a GPU or the library (CPU test of the multi-GPU launcher)")
     args = ap.parse_args()
@@ -634,7 +678,7 @@ def main():
     driver.run_resident(B, max(args.steps, 1), d_idx)            # exactly --steps batches: the burst figure
     barrier()
     burst_dt = env.max_over_ranks(time.perf_counter() - t0)
-    n_timed = max(steady_run(lambda k: driver.run_resident(B, k, d_idx), STEADY_S, n_first=8192, env=env), args.steps)
+    n_timed = max(steady_run(lambda k: driver.run_resident(B, k, d_idx), 0.3 if args.quick else STEADY_S, n_first=8192, env=env), args.steps)
     barrier()
     t0 = time.perf_counter()
     driver.run_resident(B, n_timed, d_idx)                       # >= 2 s of back-to-back batches: `value`
@@ -768,13 +812,13 @@ def main():
                                  "(fr_worker_gather_only), per-table indices", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "kernel": "gather_pack_xcd_kernel<8>"}
                 if args.gather_law in ("all", "uniform"):
-                    g.update(leg_gather(fr, cc, mc, BC, "uniform"))
+                    g.update(leg_gather(fr, cc, mc, BC, "uniform", variants=not args.no_gather_ab))
                     pm = pmc("gather_C4096_per_table_uniform") or {}
                     g["traffic"] = pm.get("traffic_bytes_per_launch")
                     g["l2_hit_rate"] = pm.get("l2_hit_rate")
                     g["traffic_source"] = "profiles/r02_pmc.json (PMC passes of `bench.py --legs gather --gather-law uniform`, FETCH_SIZE x2 correction), bytes per launch"
                 if args.gather_law in ("all", "zipf"):
-                    z = leg_gather(fr, cc, mc, BC, "zipf", seed=SEED_IDX + 1)
+                    z = leg_gather(fr, cc, mc, BC, "zipf", seed=SEED_IDX + 1, variants=not args.no_gather_ab)
                     pm = pmc("gather_C4096_per_table_zipf") or {}
                     z["traffic"] = pm.get("traffic_bytes_per_launch")
                     z["l2_hit_rate"] = pm.get("l2_hit_rate")
@@ -800,7 +844,7 @@ def main():
                 gb = {"workload": "Model-C batch=4096, FR_INDEX_PER_BANK: one index per memory bank per item (82 banks; embedding_377_krnl.cpp:1261-1290), "
                                   "tables of a bank row-interleaved in HBM; uniform indices over each bank's valid range", "bound": "hbm",
                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "gather_pack_xcd_kernel<8>"}
-                gb.update(leg_gather(fr, cbk, mcb, BC, "uniform"))
+                gb.update(leg_gather(fr, cbk, mcb, BC, "uniform", variants=not args.no_gather_ab))
                 pm = pmc("gather_C4096_per_bank_uniform") or {}
                 gb["traffic"] = pm.get("traffic_bytes_per_launch")
                 gb["l2_hit_rate"] = pm.get("l2_hit_rate")

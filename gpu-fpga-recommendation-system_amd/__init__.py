@@ -24,6 +24,7 @@ FC_FP32, FC_BF16, FC_FP8 = 0, 1, 2
 LAYOUT_SEMANTIC, LAYOUT_BLOCKED = 0, 1
 INDEX_PER_TABLE, INDEX_PER_ITEM, INDEX_PER_BANK = 0, 1, 2
 SEG_TABLE, SEG_COPY, SEG_DENSE = 0, 1, 2
+GATHER_WORD_MAJOR, GATHER_ITEM_TILE, GATHER_ITEM_TILE_DEDUP, GATHER_ITEM_TILE_DEDUP_COUNT = 0, 1, 2, 3
 MEM_CLASS_NAMES = {0: "HBM", 1: "DDR", 2: "PLRAM"}
 
 
@@ -56,7 +57,8 @@ _lib = None
 # every symbol include/fleetrec.h declares (the not-gpu test checks the .so exports all of them)
 ABI_SYMBOLS = [
     "fr_abi_version", "fr_last_error", "fr_device_count", "fr_model_builtin", "fr_model_clone_scaled", "fr_model_free",
-    "fr_model_table_bytes", "fr_model_index_cols", "fr_model_bank_map", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
+    "fr_model_table_bytes", "fr_model_index_cols", "fr_model_bank_map", "fr_ctx_set_gather_variant", "fr_ctx_gather_variant",
+    "fr_ctx_gather_merged_lookups", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
     "fr_ctx_fill_tables", "fr_ctx_upload_table", "fr_ctx_download_table", "fr_ctx_set_weights", "fr_ctx_fill_weights",
     "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_ctx_get_fp8_exponents", "fr_ctx_set_fp8_act_exponents",
     "fr_worker_calibrate_fp8", "fr_worker_calibrate_fp8_slices", "fr_worker_push_host", "fr_worker_stream", "fr_worker_gather_slices", "fr_worker_fc_from_slices_lp", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
@@ -113,6 +115,8 @@ def lib():
         "fr_driver_run_resident": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
         "fr_driver_worker": (vp, [vp, i32, i32]), "fr_driver_score_ring": (vp, [vp, i32, i32, ctypes.POINTER(ctypes.c_int)]),
         "fr_ctx_stream_group": (i32, [vp]), "fr_ctx_set_stream_group": (i32, [vp, i32]),
+        "fr_ctx_set_gather_variant": (i32, [vp, i32]), "fr_ctx_gather_variant": (i32, [vp]),
+        "fr_ctx_gather_merged_lookups": (i32, [vp, ctypes.POINTER(ctypes.c_uint64), i32]),
         "fr_driver_run_host": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
         "fr_driver_run_host_streaming": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
         "fr_driver_host_score_ring": (vp, [vp, i32, i32, ctypes.POINTER(ctypes.c_int)]),
@@ -418,6 +422,15 @@ class Context:
 
     def set_stream_group(self, batches_per_launch):
         _check(lib().fr_ctx_set_stream_group(self._h, batches_per_launch))
+
+    def set_gather_variant(self, variant):
+        """GATHER_WORD_MAJOR (default) / GATHER_ITEM_TILE / GATHER_ITEM_TILE_DEDUP(_COUNT): which kernel fr_worker_gather_only runs."""
+        _check(lib().fr_ctx_set_gather_variant(self._h, variant))
+
+    def gather_merged_lookups(self, reset=True):
+        v = ctypes.c_uint64()
+        _check(lib().fr_ctx_gather_merged_lookups(self._h, ctypes.byref(v), 1 if reset else 0))
+        return v.value
 
     def synchronize(self):
         _check(lib().fr_device_synchronize(self._h))

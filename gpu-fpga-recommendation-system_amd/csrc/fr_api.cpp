@@ -58,6 +58,9 @@ static void ctx_free(fr_ctx *c) {
     if (c->device >= 0) (void)hipSetDevice(c->device);
     if (c->table_arena) (void)hipFree(c->table_arena);
     if (c->d_words) (void)hipFree(c->d_words);
+    if (c->d_passes) (void)hipFree(c->d_passes);
+    if (c->d_chunks) (void)hipFree(c->d_chunks);
+    if (c->d_merged) (void)hipFree(c->d_merged);
     for (int i = 0; i < 4; i++) {
         if (c->d_w[i]) (void)hipFree(c->d_w[i]);
         if (i < 3 && c->d_wq[i]) (void)hipFree(c->d_wq[i]);
@@ -218,6 +221,56 @@ static int build_words(fr_ctx *c) {
     c->n_words = (int)c->h_words.size();
     FR_HIP(hipMalloc((void **)&c->d_words, sizeof(FrWordDesc) * c->n_words));
     FR_HIP(hipMemcpy(c->d_words, c->h_words.data(), sizeof(FrWordDesc) * c->n_words, hipMemcpyHostToDevice));
+    // Item-tile gather plan (gather_tile_kernel): every record segment is cut in power-of-two pieces of <= 16 words, a piece of w words
+    // becomes w passes (64 / w items each), consecutive pieces are grouped in chunks of <= FR_TILE_WORDS words.  The destination must
+    // be item-major with one stride (SEMANTIC layout or a shard's slice).
+    c->n_chunks = 0;
+    if (m.layout == FR_LAYOUT_SEMANTIC || c->n_shards > 1) {
+        std::vector<FrPassDesc> passes;
+        std::vector<FrChunkDesc> chunks;
+        FrChunkDesc cur{0, 0, 0, 0};
+        int w = 0;  // index into h_words: words are listed segment by segment, in destination order
+        for (int sg = s0; sg < s1; sg++) {
+            int left = m.segments[sg].len / 4;
+            while (left > 0) {
+                int pw = 16;
+                while (pw > left) pw >>= 1;
+                if (cur.n_words + pw > FR_TILE_WORDS) {
+                    chunks.push_back(cur);
+                    cur = FrChunkDesc{(int)passes.size(), (int)passes.size(), 0, 0};
+                }
+                const FrWordDesc &wd = c->h_words[w];
+                if (cur.n_words == 0) cur.word0 = (int)wd.dst_off;
+                int lg = 0;
+                while ((1 << lg) < pw) lg++;
+                for (int k = 0; k < pw; k++) {
+                    FrPassDesc pd{};
+                    pd.src = wd.src;
+                    pd.stride = wd.stride;
+                    pd.idx_col = wd.idx_col;
+                    pd.rows = wd.rows;
+                    pd.tile_word = (uint16_t)((int)wd.dst_off - cur.word0);
+                    pd.log2_words = (uint8_t)lg;
+                    pd.item0 = (uint8_t)(k * (FR_TILE_ITEMS / pw));
+                    passes.push_back(pd);
+                }
+                cur.n_words += pw;
+                cur.pass_end = (int)passes.size();
+                w += pw;
+                left -= pw;
+            }
+        }
+        if (cur.n_words) chunks.push_back(cur);
+        c->n_chunks = (int)chunks.size();
+        if (c->n_chunks) {
+            FR_HIP(hipMalloc((void **)&c->d_passes, sizeof(FrPassDesc) * passes.size()));
+            FR_HIP(hipMemcpy(c->d_passes, passes.data(), sizeof(FrPassDesc) * passes.size(), hipMemcpyHostToDevice));
+            FR_HIP(hipMalloc((void **)&c->d_chunks, sizeof(FrChunkDesc) * chunks.size()));
+            FR_HIP(hipMemcpy(c->d_chunks, chunks.data(), sizeof(FrChunkDesc) * chunks.size(), hipMemcpyHostToDevice));
+            FR_HIP(hipMalloc((void **)&c->d_merged, sizeof(unsigned long long)));
+            FR_HIP(hipMemset(c->d_merged, 0, sizeof(unsigned long long)));
+        }
+    }
     return FR_OK;
 }
 
@@ -599,7 +652,34 @@ static int launch_gather(fr_worker *w, int batch, const int32_t *d_idx, const fl
         for (const FrWordDesc &wd : c->h_words) needs |= (wd.idx_col & FR_DESC_DENSE) != 0;
         if (needs) FR_FAIL(FR_ERR_INVALID, "model has dense features but d_dense is NULL");
     }
+    const int variant = c->gather_variant.load(std::memory_order_relaxed);
+    if (variant != FR_GATHER_WORD_MAJOR && transport == FR_FC_FP32 && c->n_chunks > 0)
+        return frk_gather_tile(c->d_passes, c->d_chunks, c->n_chunks, d_idx, (int)idx_cols(c), d_dense, d_records, c->slice_padded / 4, batch, w->d_err,
+                               variant != FR_GATHER_ITEM_TILE, variant == FR_GATHER_ITEM_TILE_DEDUP_COUNT ? c->d_merged : nullptr, w->stream);
     return frk_gather(c->d_words, c->n_words, d_idx, (int)idx_cols(c), d_dense, d_records, batch, w->d_err, transport, c->f8_e_act[0], w->stream);
+}
+
+extern "C" int fr_ctx_set_gather_variant(fr_ctx *ctx, int variant) {
+    if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
+    if (variant < FR_GATHER_WORD_MAJOR || variant > FR_GATHER_ITEM_TILE_DEDUP_COUNT) FR_FAIL(FR_ERR_INVALID, "bad gather variant %d", variant);
+    if (variant != FR_GATHER_WORD_MAJOR && ctx->n_chunks == 0) FR_FAIL(FR_ERR_STATE, "the item-tile gather needs the SEMANTIC layout (or a shard slice)");
+    ctx->gather_variant.store(variant, std::memory_order_relaxed);
+    return FR_OK;
+}
+
+extern "C" int fr_ctx_gather_variant(const fr_ctx *ctx) { return ctx ? ctx->gather_variant.load(std::memory_order_relaxed) : FR_ERR_INVALID; }
+
+extern "C" int fr_ctx_gather_merged_lookups(fr_ctx *ctx, uint64_t *merged, int reset) {
+    if (!ctx || !merged) FR_FAIL(FR_ERR_INVALID, "NULL argument");
+    *merged = 0;
+    if (!ctx->d_merged) return FR_OK;
+    FR_HIP(hipSetDevice(ctx->device));
+    FR_HIP(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    FR_HIP(hipMemcpy(&v, ctx->d_merged, sizeof(v), hipMemcpyDeviceToHost));
+    if (reset) FR_HIP(hipMemset(ctx->d_merged, 0, sizeof(v)));
+    *merged = (uint64_t)v;
+    return FR_OK;
 }
 
 // ---- the stage pipeline ------------------------------------------------------------------------------

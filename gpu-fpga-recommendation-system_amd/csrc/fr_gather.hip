@@ -116,20 +116,33 @@ __global__ void __launch_bounds__(256) gather_pack_xcd_kernel(const FrWordDesc *
     if (bad) atomicOr_system(err_flag, 1);
 }
 
+template <int ITEMS, int TP>
+static int gather_launch_xcd(const FrWordDesc *words, int n_words, int wpg, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch,
+                             int *err_flag, float scale, hipStream_t s) {
+    const int bx = ((wpg + 63) / 64) * 64;
+    dim3 grid(8 * ((batch + ITEMS - 1) / ITEMS));
+    gather_pack_xcd_kernel<ITEMS, TP><<<grid, dim3(bx), 0, s>>>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale);
+    KCHECK();
+    return FR_OK;
+}
+
 template <int TP>
 static int gather_launch(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
                          float scale, hipStream_t s) {
-    static const int force = getenv("FR_GATHER_XCD") ? atoi(getenv("FR_GATHER_XCD")) : -1;  // experiment knob
+    // experiment knobs (tools/experiments/gather_sweep.py), read per launch: FR_GATHER_XCD = 0 / 1 forces the kernel form,
+    // FR_GATHER_ITEMS = items per thread of the XCD-partitioned form
+    const char *e_xcd = getenv("FR_GATHER_XCD"), *e_items = getenv("FR_GATHER_ITEMS");
+    const int force = e_xcd ? atoi(e_xcd) : -1;
     const bool xcd = force >= 0 ? force != 0 : (n_words >= 512 && batch >= 1024);
     if (xcd) {
-        constexpr int ITEMS = 8;
         const int wpg = (n_words + 7) / 8;
         if (wpg <= 256) {
-            const int bx = ((wpg + 63) / 64) * 64;
-            dim3 grid(8 * ((batch + ITEMS - 1) / ITEMS));
-            gather_pack_xcd_kernel<ITEMS, TP><<<grid, dim3(bx), 0, s>>>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale);
-            KCHECK();
-            return FR_OK;
+            switch (e_items ? atoi(e_items) : 8) {
+                case 2: return gather_launch_xcd<2, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
+                case 4: return gather_launch_xcd<4, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
+                case 16: return gather_launch_xcd<16, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
+                default: return gather_launch_xcd<8, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
+            }
         }
     }
     // block width: whole waves, at most 256 lanes
@@ -155,4 +168,127 @@ int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx
     if (transport == FR_FC_BF16) return gather_launch<1>(words, n_words, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s);
     if (transport == FR_FC_FP8) return gather_launch<2>(words, n_words, idx, idx_stride, dense, out, batch, err_flag, ldexpf(1.0f, e_x), s);
     return gather_launch<0>(words, n_words, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gather_tile_kernel<DEDUP>: the item-tile form of the record-producing gather -- LDS-staged row packing, with (DEDUP) or without a
+// wave-level merge of duplicate lookups (north_star: "LDS-staged row packing and wavefront ballot/shuffle for index dedup").
+//
+// A 256-thread workgroup owns 64 items x one chunk of <= 64 consecutive record words.  A wave-instruction ("pass") covers 64 / w items
+// x the w 16-byte words of one source row each, so every row is one contiguous request of w adjacent lanes and a wave sees up to 64
+// lookups of the SAME table at once -- which is what makes duplicates visible to it (in gather_pack_kernel a wave holds one item's
+// words of many tables: no two lanes ever want the same row).  DEDUP: the lanes of a pass agree on one leader per distinct index
+// through a 128-slot LDS hash of the index (last writer wins; a slot collision between different indices only costs a missed
+// merge, never a wrong row: the leader's index is compared through a shuffle), only leaders load, the others take the leader's
+// registers by ds_bpermute (__shfl); __ballot counts the merged lookups when a counter is supplied.
+// All index loads of the wave's passes are issued first, then all row loads, then the rows go to the LDS tile; after one barrier the
+// tile leaves as whole 1 KiB record pieces per item (fully coalesced, like gather_pack_kernel's stores).
+// ---------------------------------------------------------------------------------------------------
+constexpr int FR_TILE_LD = FR_TILE_WORDS + 1;     // LDS tile row stride in 16-byte words (+1: conflict-free column writes)
+constexpr int FR_TILE_MAXP = FR_TILE_WORDS / 4;   // passes per wave: a chunk has <= 64 passes, dealt round-robin to 4 waves
+
+template <bool DEDUP>
+__global__ void __launch_bounds__(256) gather_tile_kernel(const FrPassDesc *__restrict__ passes, const FrChunkDesc *__restrict__ chunks, int n_chunks,
+                                                          int chunks_per_group, const int32_t *__restrict__ idx, int idx_stride,
+                                                          const float *__restrict__ dense, uint4 *__restrict__ out, int out_stride_words, int batch,
+                                                          int *__restrict__ err_flag, unsigned long long *__restrict__ dup_counter) {
+    __shared__ uint4 tile[FR_TILE_ITEMS * FR_TILE_LD];
+    __shared__ uint32_t hash_slots[4][128];
+    // workgroup b serves XCD group b % 8 (round-robin dealing; a speed assumption only): a chunk, hence a table, is always fetched by
+    // the same XCD, so the 8 L2s cache 8 different table sets (as gather_pack_xcd_kernel does)
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int chunk = (j % chunks_per_group) * 8 + x;
+    const int item_tile = j / chunks_per_group;
+    if (chunk >= n_chunks) return;
+    const FrChunkDesc ch = chunks[chunk];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: descriptors load through SMEM
+    const int m0 = item_tile * FR_TILE_ITEMS;
+
+    uint32_t id[FR_TILE_MAXP];
+    uint4 v[FR_TILE_MAXP];
+    bool bad = false;
+    // phase 1: index loads of every pass of this wave
+#pragma unroll
+    for (int q = 0; q < FR_TILE_MAXP; q++) {
+        const int p = ch.pass_begin + 4 * q + wave;
+        id[q] = 0;
+        if (p < ch.pass_end) {
+            const FrPassDesc d = passes[p];
+            const int m = m0 + d.item0 + (lane >> d.log2_words);
+            const bool is_dense = (d.idx_col & FR_DESC_DENSE) != 0;
+            if (m < batch) id[q] = is_dense ? (uint32_t)m : (uint32_t)idx[(size_t)m * idx_stride + d.idx_col];
+        }
+    }
+    // phase 2: (dedup,) row loads
+    uint32_t src_lane[FR_TILE_MAXP];
+    unsigned merged = 0;
+#pragma unroll
+    for (int q = 0; q < FR_TILE_MAXP; q++) {
+        const int p = ch.pass_begin + 4 * q + wave;
+        src_lane[q] = (uint32_t)lane;
+        if (p < ch.pass_end) {
+            const FrPassDesc d = passes[p];
+            const bool is_dense = (d.idx_col & FR_DESC_DENSE) != 0;
+            const uint32_t word = (uint32_t)lane & ((1u << d.log2_words) - 1u);
+            if (!is_dense && id[q] >= d.rows) {  // reference: silent out-of-bounds read (embedding_47_krnl.cpp:927-933)
+                bad = true;
+                id[q] = 0;
+            }
+            bool dup = false;
+            if (DEDUP && !is_dense) {
+                const uint32_t slot = (uint32_t)lane >> d.log2_words;
+                const uint32_t h = (id[q] * 0x9E3779B1u) >> 25;
+                hash_slots[wave][h] = slot;  // same-wave LDS accesses execute in order: the read below sees this pass's last writer
+                const uint32_t winner = hash_slots[wave][h];
+                const uint32_t wid = (uint32_t)__shfl((int)id[q], (int)(winner << d.log2_words));
+                dup = wid == id[q] && winner != slot;
+                if (dup) src_lane[q] = (winner << d.log2_words) + word;
+                if (dup_counter) merged += (unsigned)__popcll(__ballot(dup && word == 0));
+            }
+            const char *base = is_dense ? reinterpret_cast<const char *>(dense) + d.src : reinterpret_cast<const char *>(d.src);
+            if (!dup) v[q] = *reinterpret_cast<const uint4 *>(base + (uint64_t)id[q] * d.stride + 16u * word);
+        }
+    }
+    // phase 3: duplicates take their leader's registers; rows -> LDS tile
+#pragma unroll
+    for (int q = 0; q < FR_TILE_MAXP; q++) {
+        const int p = ch.pass_begin + 4 * q + wave;
+        if (p < ch.pass_end) {
+            const FrPassDesc d = passes[p];
+            uint4 r = v[q];
+            if (DEDUP) {
+                r.x = (uint32_t)__shfl((int)v[q].x, (int)src_lane[q]);
+                r.y = (uint32_t)__shfl((int)v[q].y, (int)src_lane[q]);
+                r.z = (uint32_t)__shfl((int)v[q].z, (int)src_lane[q]);
+                r.w = (uint32_t)__shfl((int)v[q].w, (int)src_lane[q]);
+            }
+            const uint32_t word = (uint32_t)lane & ((1u << d.log2_words) - 1u);
+            tile[(d.item0 + (lane >> d.log2_words)) * FR_TILE_LD + d.tile_word + word] = r;
+        }
+    }
+    __syncthreads();
+    // phase 4: whole record pieces out, 16 items per wave
+#pragma unroll 4
+    for (int i = 0; i < FR_TILE_ITEMS / 4; i++) {
+        const int it = wave * (FR_TILE_ITEMS / 4) + i, m = m0 + it;
+        if (m < batch && lane < ch.n_words) out[(size_t)m * out_stride_words + ch.word0 + lane] = tile[it * FR_TILE_LD + lane];
+    }
+    if (bad) atomicOr_system(err_flag, 1);
+    if (DEDUP && dup_counter && lane == 0 && merged) atomicAdd(dup_counter, (unsigned long long)merged);
+}
+
+int frk_gather_tile(const FrPassDesc *passes, const FrChunkDesc *chunks, int n_chunks, const int32_t *idx, int idx_stride, const float *dense, void *out,
+                    int out_stride_words, int batch, int *err_flag, bool dedup, unsigned long long *dup_counter, hipStream_t s) {
+    if (n_chunks <= 0 || batch <= 0) return FR_OK;
+    const int cpg = (n_chunks + 7) / 8;
+    const int tiles = (batch + FR_TILE_ITEMS - 1) / FR_TILE_ITEMS;
+    dim3 grid(8 * cpg * tiles);
+    if (dedup)
+        gather_tile_kernel<true><<<grid, dim3(256), 0, s>>>(passes, chunks, n_chunks, cpg, idx, idx_stride, dense, reinterpret_cast<uint4 *>(out), out_stride_words, batch,
+                                                           err_flag, dup_counter);
+    else
+        gather_tile_kernel<false><<<grid, dim3(256), 0, s>>>(passes, chunks, n_chunks, cpg, idx, idx_stride, dense, reinterpret_cast<uint4 *>(out), out_stride_words, batch,
+                                                            err_flag, nullptr);
+    KCHECK();
+    return FR_OK;
 }

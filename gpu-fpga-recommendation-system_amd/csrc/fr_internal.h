@@ -44,6 +44,26 @@ struct FrWordDesc {
 static_assert(sizeof(FrWordDesc) == 32, "FrWordDesc must be 32 bytes");
 #define FR_DESC_DENSE 0x80000000u
 
+// One wave-instruction of the item-tile gather (gather_tile_kernel, fr_gather.hip): 64 / n_words items x n_words consecutive
+// 16-byte words of ONE source row each (n_words = 1, 2, 4, 8 or 16: a whole table row, or a power-of-two piece of one).  A record
+// segment of w words appears as w passes (item0 = 0, 64/w, 2*64/w, ...) so that the passes of a 64-item tile cover every item.
+struct FrPassDesc {
+    uint64_t src;        // TABLE/COPY: device address of the piece inside row 0; DENSE: byte offset inside the item's dense row
+    uint32_t stride;     // bytes between rows of the source
+    uint32_t idx_col;    // index column (bit 31: DENSE)
+    uint32_t rows;       // range check (DENSE: unused)
+    uint16_t tile_word;  // first word of the piece inside the chunk's LDS tile row
+    uint8_t log2_words;  // log2(n_words)
+    uint8_t item0;       // first item of the tile this pass serves
+    uint32_t pad_;
+};
+static_assert(sizeof(FrPassDesc) == 32, "FrPassDesc must be 32 bytes");
+constexpr int FR_TILE_ITEMS = 64, FR_TILE_WORDS = 64;  // gather_tile_kernel: items per workgroup, record words per chunk
+struct FrChunkDesc {
+    int pass_begin, pass_end;  // passes of the chunk inside ctx->d_passes
+    int word0, n_words;        // the chunk's word range inside the item's destination row
+};
+
 // ---- pipelined FC chain: launch arguments (see fr_pipeline.hip) ------------------------------------
 constexpr int FR_N_STAGES = 5;  // gather | FC1 | FC2 | FC3 | out
 
@@ -134,6 +154,12 @@ struct fr_ctx {
     int n_words = 0;                       // words this ctx gathers per item (whole record, or the shard's slice)
     FrWordDesc *d_words = nullptr;         // [n_words]
     std::vector<FrWordDesc> h_words;
+    // item-tile gather plan (SEMANTIC / sharded layouts): passes grouped in chunks of <= FR_TILE_WORDS record words
+    FrPassDesc *d_passes = nullptr;
+    FrChunkDesc *d_chunks = nullptr;
+    int n_chunks = 0;
+    unsigned long long *d_merged = nullptr;  // lookups merged by the dedup gather (FR_GATHER_ITEM_TILE_DEDUP_COUNT)
+    std::atomic<int> gather_variant{0};    // fr_gather_variant (fr_ctx_set_gather_variant)
     // FC weights: fp32 master copies in the reference's column-major H x K layout
     // (= K-major "Wt[k][h]", cuda_server.c:215) and optional bf16 copies.
     float *d_w[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -224,6 +250,8 @@ int frk_fill_table(float *base, int64_t row0, int64_t rows, int dim, int64_t row
 int frk_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t layer, float scale, hipStream_t s);
 int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
                int transport, int e_x, hipStream_t s);
+int frk_gather_tile(const FrPassDesc *passes, const FrChunkDesc *chunks, int n_chunks, const int32_t *idx, int idx_stride, const float *dense, void *out,
+                    int out_stride_words, int batch, int *err_flag, bool dedup, unsigned long long *dup_counter, hipStream_t s);
 int frk_transpose_slices_lp(int precision, const void *gathered, int n_shards, int batch_total, int slice_padded, const int *h_offsets, const int *h_lens,
                             int item0, int n_items, void *X, int K, int ldm, hipStream_t s);
 // feature-major FC chain, stage-pipelined across batches (see fr_pipeline.hip)

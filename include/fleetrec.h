@@ -281,6 +281,24 @@ int fr_worker_fc_only(fr_worker *w, int batch, const float *d_records, float *d_
 /* Roofline hook: launch ONE layer of the FC chain (0..2 = FC1..FC3, 3 = output layer) on the worker's resident
  * activations, exactly as submit() launches it. */
 int fr_worker_fc_layer_only(fr_worker *w, int batch, int layer);
+/* Which kernel serves the record-producing gather (fr_worker_gather_only; fp32 records, SEMANTIC layout or a shard slice) -- a tuning
+ * knob with no counterpart in the reference (its gather is 28-47 independent HLS pipelines, embedding_47_krnl.cpp:645-740).
+ *  WORD_MAJOR (default): one thread per 16-byte record word, lanes along the record (gather_pack_kernel): a wave never holds two
+ *                        lookups of the same table, duplicate rows of a batch are merged by L1 / L2;
+ *  ITEM_TILE           : 64 items x 64 record words per workgroup, lanes along (item, word-of-row), rows staged in LDS and written
+ *                        out as whole 1 KiB record pieces (gather_tile_kernel<false>);
+ *  ITEM_TILE_DEDUP     : the same with a wave-level merge of duplicate lookups (LDS hash + __shfl: only one lane per distinct
+ *                        index loads the row) -- BASELINE.json north_star's "ballot/shuffle index dedup";
+ *  ..._DEDUP_COUNT     : DEDUP + a __ballot count of the merged lookups (diagnostic; fr_ctx_gather_merged_lookups).
+ * All variants produce bit-identical records.  DESIGN.md section 3.1 holds the measured A/B. */
+typedef enum fr_gather_variant {
+    FR_GATHER_WORD_MAJOR = 0, FR_GATHER_ITEM_TILE = 1, FR_GATHER_ITEM_TILE_DEDUP = 2, FR_GATHER_ITEM_TILE_DEDUP_COUNT = 3
+} fr_gather_variant;
+int fr_ctx_set_gather_variant(fr_ctx *ctx, int variant);
+int fr_ctx_gather_variant(const fr_ctx *ctx);
+/* Lookups (rows) the DEDUP_COUNT variant did NOT load because another lane of the wave loaded the same row, summed since the last
+ * reset.  Synchronises the device. */
+int fr_ctx_gather_merged_lookups(fr_ctx *ctx, uint64_t *merged, int reset);
 /* Device pointer of the worker's own record buffer ([max_batch][record_len] floats). */
 float *fr_worker_records_dptr(fr_worker *w);
 /* Debug/parity hook: device pointer of the worker's feature-major activation buffer written by the gather stage

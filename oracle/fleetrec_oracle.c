@@ -75,6 +75,14 @@ uint32_t oracle_content_bits(int mode, uint32_t seed, uint32_t uid, uint64_t row
     return content_bits(mode, seed, uid, row, col);
 }
 
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -166,7 +166,7 @@ def test_bench_self_launches_ranks_and_refuses_a_wrong_world():
 def test_bench_two_ranks_on_one_gpu(gpu, extra):
     """The N = 2 path end to end on a one-GPU box: self-launched ranks, gloo rendezvous, both ranks on device 0
     (--share-device).  Replicas: value aggregates both ranks.  Sharded: 2-way table-ID shards, the exchange through gloo, scores
-    of rank 0's items equal to an unsharded context (bit-identical) and the pipelined run equal to the stepwise one."""
+    of rank 0's items equal to an unsharded context (1e-5 in fp32, bit-identical in fp8) and the pipelined run equal to the stepwise one."""
     import json
     args = ["--gpus", "2", "--backend", "gloo", "--share-device", "--legs", "none"] + (extra or ["--steps", "300", "--warmup", "100"])
     rc, out, err = _run_bench(args, timeout=900)
@@ -178,6 +178,10 @@ def test_bench_two_ranks_on_one_gpu(gpu, extra):
     if extra:
         c = j["config"]
         assert c["pipelined_equals_stepwise"] is True
-        assert c["sharded_vs_unsharded_context"]["bit_identical"] is True, c
+        chk = c["sharded_vs_unsharded_context"]
+        if j["dtype"] == "f32":   # B/G items per rank vs batch B unsharded: a different split-K plan, sums differ in the last bits
+            assert chk["max_rel_err"] <= 1e-5, c
+        else:                     # low-precision chains sum whole K per output in one order: bit for bit
+            assert chk["bit_identical"] is True, c
     else:
         assert j["timed_batches"] >= 300 and j["timed_s"] >= 2.0 and j["scaling"] == "weak"

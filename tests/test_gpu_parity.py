@@ -101,6 +101,50 @@ def test_gather_tagged_wire_order(fr, O, gpu, which):
     ctx.close()
 
 
+@pytest.mark.parametrize("which,mode", [(0, "table"), (1, "table"), (2, "table"), (2, "bank"), (1, "item")])
+def test_gather_kernel_variants_are_bit_identical(fr, O, gpu, which, mode):
+    """fr_ctx_set_gather_variant: the item-tile gather (LDS-staged row packing) with and without the wave-level merge of duplicate
+    lookups (LDS hash + __shfl, counted with __ballot) writes the same records as the word-major kernel and as the oracle -- ragged
+    batch, indices with many repeats (so that leaders, duplicates and hash-slot collisions all occur), every index mode."""
+    imode = {"table": fr.INDEX_PER_TABLE, "bank": fr.INDEX_PER_BANK, "item": fr.INDEX_PER_ITEM}[mode]
+    m = fr.Model.builtin(which).clone(max_rows=50000, index_mode=imode)
+    om = O.OracleModel(NAMES[which])
+    ctx = fr.Context(m, device=gpu)
+    ctx.fill_tables(fr.FILL_TAGGED, 0)
+    rng = np.random.default_rng(77)
+    B = 333
+    ranges = m.index_ranges()
+    idx = uniform_idx(rng, np.minimum(ranges, 40), B)        # <= 40 distinct rows per column: most lookups repeat inside a wave
+    idx[::7] = uniform_idx(rng, ranges, len(idx[::7]))       # ... plus full-range rows
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32) if m.dense_len else None
+    if mode == "table":
+        want = om.gather(idx, dense=dense, content_mode=O.FILL_TAGGED)
+    elif mode == "bank":
+        want = om.gather(idx, dense=dense, content_mode=O.FILL_TAGGED, per_bank=True)
+    else:
+        want = om.gather(idx[:, 0], dense=dense, content_mode=O.FILL_TAGGED)
+    wk = fr.Worker(ctx, B)
+    for var in (fr.GATHER_WORD_MAJOR, fr.GATHER_ITEM_TILE, fr.GATHER_ITEM_TILE_DEDUP, fr.GATHER_ITEM_TILE_DEDUP_COUNT):
+        ctx.set_gather_variant(var)
+        got = wk.gather_records(idx, dense).reshape(B, m.record_len)
+        assert np.array_equal(got, want), var
+    merged = ctx.gather_merged_lookups()
+    lookups = B * (m.n_tables if mode != "bank" else m.idx_cols)
+    assert 0.3 * lookups < merged <= lookups, (merged, lookups)   # the waves did merge repeated rows
+    # out-of-range indices are still reported by the item-tile kernels
+    bad = idx.copy()
+    bad[5, 0] = int(ranges[0])
+    d_idx = fr.DeviceBuffer.from_numpy(ctx, bad)
+    d_dense = fr.DeviceBuffer.from_numpy(ctx, dense) if dense is not None else None
+    d_rec = fr.DeviceBuffer(ctx, B * m.record_len * 4)
+    wk.gather_only(B, d_idx, d_dense, d_rec)
+    with pytest.raises(fr.FleetRecError) as e:
+        wk.sync()
+    assert e.value.status == fr.FR_ERR_INDEX_RANGE
+    wk.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("which,fname", [(0, "records_47.bin"), (1, "records_98.bin"), (2, "records_377x2.bin")])
 def test_gather_matches_committed_golden_records(fr, gpu, which, fname):
     """The device gather against COMMITTED bytes (tests/golden/records_*.bin, tagged tables: every float names its table / row /
@@ -127,33 +171,17 @@ def test_gather_matches_committed_golden_records(fr, gpu, which, fname):
     ctx.close()
 
 
-@pytest.fixture(scope="module")
-def bank_ctxs(fr, gpu):
-    """Full-size Model A / B / C contexts in FR_INDEX_PER_BANK mode (bank-interleaved table layout)."""
-    cache = {}
-
-    def get(which):
-        if which not in cache:
-            m = fr.Model.builtin(which).clone(index_mode=fr.INDEX_PER_BANK)
-            c = fr.Context(m, device=gpu)
-            c.fill_tables(fr.FILL_HASH, SEED_TABLES)
-            c.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
-            cache[which] = (m, c)
-        return cache[which]
-
-    yield get
-    for m, c in cache.values():
-        c.close()
-
-
 @pytest.mark.parametrize("which,B", [(0, 256), (1, 1024), (2, 4096)])
-def test_per_bank_gather_bit_exact_full_models(fr, O, bank_ctxs, ctxs, which, B):
+def test_per_bank_gather_bit_exact_full_models(fr, O, gpu, ctxs, which, B):
     """FR_INDEX_PER_BANK = the kernel's real contract (ONE index per bank per item, reused by every round of the bank:
     embedding_98_krnl.cpp:1026-1040, embedding_377_krnl.cpp:1261-1290) on the bank-interleaved HBM layout, full-size tables:
     records bit-exact against the oracle's per-bank mode (bank memories addressed at ADDR_AXI + idx*AXI_PADDED_SIZE), uniform
     indices over every bank's whole valid range incl. 0 and the maximum; and scores bit-identical to the PER_TABLE context fed
     the same index expanded per table (same kernels, same arithmetic, different table layout)."""
-    m, ctx = bank_ctxs(which)
+    m = fr.Model.builtin(which).clone(index_mode=fr.INDEX_PER_BANK)   # own context, closed at the end (HBM budget of the module)
+    ctx = fr.Context(m, device=gpu)
+    ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
     om = O.OracleModel(NAMES[which])
     bot, brows = m.bank_map()
     assert m.idx_cols == om.n_banks and np.array_equal(brows, om.bank_rows_wire())
@@ -187,6 +215,7 @@ def test_per_bank_gather_bit_exact_full_models(fr, O, bank_ctxs, ctxs, which, B)
     assert rel_err(pushed, s_bank) <= 1e-5
     wk.close()
     wt.close()
+    ctx.close()
 
 
 @pytest.mark.parametrize("which", [1, 2])

@@ -1,0 +1,31 @@
+#!/bin/bash
+# HBM/fabric traffic, L2 hit rate and MFMA activity of the roofline kernels from PMC counters, as MI355X_MICROARCH.md ("HBM",
+# "rocprofv3 PMC slots") prescribes: SEPARATE --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), --kernel-trace only, the
+# program itself directly after `--`.  One bench leg per key, so that every kernel name carries ONE workload:
+#   fused_m2_A256                    bench.py --legs roofline                      fr_fused_tile_m2_kernel
+#   gather_C4096_per_table_uniform   bench.py --legs gather --gather-law uniform   gather_pack_xcd_kernel
+#   gather_C4096_per_table_zipf      bench.py --legs gather --gather-law zipf      gather_pack_xcd_kernel
+#   gather_C4096_per_bank_uniform    bench.py --legs bank                          gather_pack_xcd_kernel
+# Run on the GPU box from the repo root:  bash tools/pmc_passes.sh [key ...]   -> gpurun_out/pmc/<key>/<pass>/ + gpurun_out/pmc/r02_pmc.json
+set -e
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/pmc
+mkdir -p $OUT
+KEYS=${@:-"fused_m2_A256 gather_C4096_per_table_uniform gather_C4096_per_table_zipf gather_C4096_per_bank_uniform"}
+cd /tmp && export TMPDIR=/tmp
+for key in $KEYS; do
+  case $key in
+    fused_m2_A256) ARGS="--legs roofline"; KERNEL="fr_fused_tile_m2_kernel"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32");;
+    gather_C4096_per_table_uniform) ARGS="--legs gather --gather-law uniform"; KERNEL="gather_pack"; EXTRA=();;
+    gather_C4096_per_table_zipf) ARGS="--legs gather --gather-law zipf"; KERNEL="gather_pack"; EXTRA=();;
+    gather_C4096_per_bank_uniform) ARGS="--legs bank"; KERNEL="gather_pack"; EXTRA=();;
+    *) echo "unknown key $key"; exit 1;;
+  esac
+  mkdir -p $OUT/$key
+  for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum" "${EXTRA[@]}"; do
+    tag=$(echo $pass | tr ' ' '_')
+    rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/$key/$tag -- python3 $ROOT/bench.py --quick --no-gather-ab $ARGS > $OUT/$key/$tag.log 2>&1 || echo "pass $key/$tag failed"
+  done
+  python3 $ROOT/tools/pmc_summarize.py $OUT/$key $key $KERNEL $OUT/r02_pmc.json
+done
+cat $OUT/r02_pmc.json
