@@ -137,11 +137,11 @@ static int gather_launch(const FrWordDesc *words, int n_words, const int32_t *id
     if (xcd) {
         const int wpg = (n_words + 7) / 8;
         if (wpg <= 256) {
-            switch (e_items ? atoi(e_items) : 8) {
+            switch (e_items ? atoi(e_items) : 4) {  // 4 items per thread: fastest in the r02 sweep (profiles/r02_gather_sweep.txt)
                 case 2: return gather_launch_xcd<2, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
-                case 4: return gather_launch_xcd<4, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
+                case 8: return gather_launch_xcd<8, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
                 case 16: return gather_launch_xcd<16, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
-                default: return gather_launch_xcd<8, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
+                default: return gather_launch_xcd<4, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
             }
         }
     }
@@ -238,8 +238,12 @@ __global__ void __launch_bounds__(256) gather_tile_kernel(const FrPassDesc *__re
             if (DEDUP && !is_dense) {
                 const uint32_t slot = (uint32_t)lane >> d.log2_words;
                 const uint32_t h = (id[q] * 0x9E3779B1u) >> 25;
-                hash_slots[wave][h] = slot;  // same-wave LDS accesses execute in order: the read below sees this pass's last writer
-                const uint32_t winner = hash_slots[wave][h];
+                // same-wave LDS accesses execute in order: the read sees this pass's last writer.  volatile: without it hipcc forwards
+                // the lane's own store to its load and no lane ever finds a leader
+                volatile uint32_t *slots = hash_slots[wave];
+                slots[h] = slot;
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t winner = slots[h];
                 const uint32_t wid = (uint32_t)__shfl((int)id[q], (int)(winner << d.log2_words));
                 dup = wid == id[q] && winner != slot;
                 if (dup) src_lane[q] = (winner << d.log2_words) + word;

@@ -130,7 +130,8 @@ def test_gather_kernel_variants_are_bit_identical(fr, O, gpu, which, mode):
         assert np.array_equal(got, want), var
     merged = ctx.gather_merged_lookups()
     lookups = B * (m.n_tables if mode != "bank" else m.idx_cols)
-    assert 0.3 * lookups < merged <= lookups, (merged, lookups)   # the waves did merge repeated rows
+    # the waves did merge repeated rows (a bank row is cut in power-of-two pieces, each piece counts its own merges: <= 3 per lookup)
+    assert 0.3 * lookups < merged <= 3 * lookups, (merged, lookups)
     # out-of-range indices are still reported by the item-tile kernels
     bad = idx.copy()
     bad[5, 0] = int(ranges[0])
