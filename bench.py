@@ -295,7 +295,7 @@ def leg_group_table(fr, ctx, model, B, d_idx, threads, depth):
     return out
 
 
-def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_host0, threads, depth, label):
+def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_host0, threads, depth, label, min_s=1.0):
     """One non-headline BASELINE configuration: steady-state throughput (>= 1 s) + an in-run roofline object for its dominant
     kernel from HIP events on one worker's stream."""
     prec_enum = {"f32": fr.FC_FP32, "bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[precision]
@@ -308,7 +308,7 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
     flops_inf = fc_flops_per_inference(fc)
     dv = fr.Driver(ctx, threads, depth, B)
     dv.run_resident(B, 256, d_idx, d_dense)
-    n = steady_run(lambda k: dv.run_resident(B, k, d_idx, d_dense), 1.0, n_first=512, quantum=64)
+    n = steady_run(lambda k: dv.run_resident(B, k, d_idx, d_dense), min_s, n_first=512 if min_s >= 1.0 else 64, quantum=64)
     el = dv.run_resident(B, n, d_idx, d_dense)
     dv.close()
     res = {"workload": label, "dtype": precision, "value": n * B / el, "unit": "inferences/s", "timed_batches": n, "timed_s": el,
@@ -659,7 +659,7 @@ def main():
     if args.model != "A" or args.precision != "f32":
         # one non-headline configuration on its own: throughput + its roofline leg
         res = leg_config(fr, ctx, model, B, args.precision, d_idx, d_dense, idx_host[0], dense_host[0] if dense_host else None, args.threads, args.depth,
-                         "Model-%s batch=%d %s FC chain, index rows resident in HBM" % (args.model, B, args.precision))
+                         "Model-%s batch=%d %s FC chain, index rows resident in HBM" % (args.model, B, args.precision), min_s=0.05 if args.quick else 1.0)
         if rank == 0:
             print(json.dumps({"metric": "inferences/sec", "value": res["value"], "unit": "inferences/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -1,3 +1,5 @@
+#include <type_traits>
+
 #include "fr_device.h"
 
 // ===================================================================================================
@@ -174,6 +176,307 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict
         }
 }
 
+// ===================================================================================================
+// fc_gemm_pipe_kernel<PREC, NS>: the software-pipelined form of the bf16 / fp8 GEMM for the 128 (n) x 256 (m) block tile
+// (Model-C FC1 at batch 4096: 256 tiles = one per CU).  Same operand images (q8 / q16 elements, global -> LDS DMA, conflict-free
+// ds_read_b128 fragment reads), same 2 x 4 wave grid with 64 x 64 wave tiles, but:
+//   * a K SUB-step is 4 element rows (32 k in bf16, 64 k in fp8 = 256 MFMA cycles per wave) and NS of them live in LDS (NS = 5:
+//     120 KiB); the DMA loads of sub-step s + NS - 1 are issued in iteration s, and iteration s waits -- with a COUNTED vmcnt that
+//     leaves the youngest NS - 3 sub-steps in flight -- only for sub-step s + 1: NS - 2 sub-steps (~0.75 us) of latency tolerance
+//     instead of one K step, and no vmcnt(0) drain in the loop;
+//   * the fragments of sub-step s + 1 are read into a second register set WHILE the MFMAs of sub-step s run, so the MFMAs after a
+//     barrier start from registers (with one barrier per step and the reads behind it, both waves of a SIMD used to wait for LDS at
+//     the same moment);
+//   * raw s_barrier (no vmcnt(0) fence), s_setprio around the MFMA cluster;
+//   * bf16 uses v_mfma_f32_16x16x32_bf16 (16 per sub-step per wave): same LDS bytes and cycles per FLOP as the 32x32x16 form, but the
+//     chip holds a higher clock on it under load (MI355X_MICROARCH.md, DVFS give-back item 7); fp8 keeps the block-scaled 32x32x64.
+// Sums are over whole K in k order per output, as in fc_lp_gemm_kernel; results differ from it only through the MFMA's own internal
+// summation inside one instruction (16x16x32 vs 32x32x16 group k differently) -- same tolerance class, tested against the oracle.
+// ===================================================================================================
+constexpr int FR_PR = 4;  // element rows per row group; a sub-step is G groups
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int PREC>
+struct FrPipeFrag {  // one row group's operands of one wave: bf16: 4 + 4 fragments of 16 rows x 32 k; fp8: 2 + 2 fragments of 32 rows x 64 k (two elements each)
+    uint4 a[4], b[4];
+};
+
+template <int PREC>
+__device__ __forceinline__ void pipe_read_frags(FrPipeFrag<PREC> &f, const uint4 *grp, int row_elems, int wn, int wm, int lane) {
+    if constexpr (PREC == 1) {
+        const uint4 *p = grp + (size_t)(lane >> 4) * row_elems + (lane & 15);  // k group = lane / 16, row = lane % 16
+#pragma unroll
+        for (int t = 0; t < 4; t++) f.a[t] = p[wn * 64 + 16 * t];
+#pragma unroll
+        for (int u = 0; u < 4; u++) f.b[u] = p[FR_GN + wm * 64 + 16 * u];
+    } else {
+        const uint4 *p = grp + (size_t)(2 * (lane >> 5)) * row_elems + (lane & 31);  // k = 32 h + j: element rows 2h, 2h + 1
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            f.a[2 * t] = p[wn * 64 + 32 * t];
+            f.a[2 * t + 1] = p[row_elems + wn * 64 + 32 * t];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            f.b[2 * u] = p[FR_GN + wm * 64 + 32 * u];
+            f.b[2 * u + 1] = p[row_elems + FR_GN + wm * 64 + 32 * u];
+        }
+    }
+}
+
+template <int PREC, int NS, int G>
+__global__ void __launch_bounds__(512) fc_gemm_pipe_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
+                                                           int N, int ldm, int sc_a, int sc_b, float oscale, int ablate) {
+    extern __shared__ uint4 glds[];
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    constexpr int GM = 256, ROW = FR_GN + GM, STAGE = G * FR_PR * ROW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int tn = N / FR_GN, tm = ldm / GM;
+    int n_tile, m_tile;  // XCD-aware 2 (n) x 4 (m) tile map, as in fc_lp_gemm_kernel
+    if (tn % 2 == 0 && tm % 4 == 0) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int tnx = tn / 2;
+        n_tile = (x & 1) * tnx + j % tnx;
+        m_tile = (x >> 1) * (tm / 4) + j / tnx;
+    } else {
+        n_tile = blockIdx.x % tn;
+        m_tile = blockIdx.x / tn;
+    }
+    const int n0 = n_tile * FR_GN, m0 = m_tile * GM;
+    auto make_rs = [](const void *p, unsigned bytes) {
+        const unsigned long long a = (unsigned long long)p;
+        i32x4_t rs;
+        rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        rs[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+        rs[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+        rs[3] = 0x00020000;
+        return rs;
+    };
+    const i32x4_t rsW = make_rs(W, (unsigned)KE * (unsigned)N * 16u), rsX = make_rs(X, (unsigned)KE * (unsigned)ldm * 16u);
+    // global -> LDS DMA (see fc_lp_gemm_kernel for why this is inline asm and why M0 carries no clobber).  LDS addresses are kept as
+    // plain wave-uniform integers and advanced incrementally: through pointers every DMA cost ~15 scalar instructions (stage modulo by
+    // multiplication, address-space casts with null checks), and the issue of a sub-step's three DMAs is what a wave spends longest on
+    // besides its MFMAs.
+    auto dma = [&](const i32x4_t &rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+        const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr), so = __builtin_amdgcn_readfirstlane(soff);  // wave-uniform by construction
+        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(la), "v"(voff), "s"(rs), "s"(so) : "memory");
+    };
+    // staging of one sub-step: 4 rows x (128 + 256) elements = 24 wave-instructions of 64 elements, 3 per wave: wave w takes row w / 2,
+    // W's half w % 2 and X's quarters 2 (w % 2), 2 (w % 2) + 1.  Sub-steps are issued strictly in order, so the state is a running one.
+    const int drow = wave >> 1, dpart = wave & 1;
+    const unsigned vW = (unsigned)(n0 + 64 * dpart + lane) * 16u, vX = (unsigned)(m0 + 128 * dpart + lane) * 16u;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_ptr)glds);
+    unsigned iss_lds = lds0 + (unsigned)(drow * ROW) * 16u;                               // this wave's row of the stage being filled
+    unsigned iss_w = (unsigned)drow * (unsigned)N * 16u, iss_x = (unsigned)drow * (unsigned)ldm * 16u;  // SGPR offsets of that row in W / X
+    // ablate (timing experiments only, results are wrong): 2 = every sub-step re-reads sub-step 0's rows (operands stay in L2 / L1)
+    const unsigned grp_w = (unsigned)FR_PR * (unsigned)N * 16u, grp_x = (unsigned)FR_PR * (unsigned)ldm * 16u;  // one row group further in W / X
+    const unsigned step_w = (ablate & 15) == 2 ? 0u : G * grp_w, step_x = (ablate & 15) == 2 ? 0u : G * grp_x;
+    int iss_stage = 0, issued = 0;
+    auto issue_next = [&]() {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const unsigned l = iss_lds + (unsigned)(g * FR_PR * ROW) * 16u;
+            dma(rsW, l + (unsigned)(64 * dpart) * 16u, vW, iss_w + g * grp_w);
+            dma(rsX, l + (unsigned)(FR_GN + 128 * dpart) * 16u, vX, iss_x + g * grp_x);
+            dma(rsX, l + (unsigned)(FR_GN + 128 * dpart + 64) * 16u, vX + 64u * 16u, iss_x + g * grp_x);
+        }
+        iss_w += step_w;
+        iss_x += step_x;
+        issued++;
+        iss_stage++;
+        iss_lds += (unsigned)STAGE * 16u;
+        if (iss_stage == NS) {
+            iss_stage = 0;
+            iss_lds -= (unsigned)(NS * STAGE) * 16u;
+        }
+    };
+    constexpr int NACC = PREC == 1 ? 16 : 4;
+    f32x4_t acc16[PREC == 1 ? 16 : 1];
+    f32x16 acc32[PREC == 1 ? 1 : 4];
+    if constexpr (PREC == 1) {
+#pragma unroll
+        for (int i = 0; i < NACC; i++) acc16[i] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    } else {
+#pragma unroll
+        for (int i = 0; i < NACC; i++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc32[i][e] = 0.0f;
+    }
+    auto mfmas = [&](const FrPipeFrag<PREC> &f) {
+        if (ablate & 256) __builtin_amdgcn_s_setprio(1);
+        if constexpr (PREC == 1) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    acc16[4 * t + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.a[t]), __builtin_bit_cast(bf16x8, f.b[u]), acc16[4 * t + u], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const uint4 &a0 = f.a[2 * t], &a1 = f.a[2 * t + 1], &b0 = f.b[2 * u], &b1 = f.b[2 * u + 1];
+                    i32x8 av, bv;
+                    av[0] = (int)a0.x; av[1] = (int)a0.y; av[2] = (int)a0.z; av[3] = (int)a0.w;
+                    av[4] = (int)a1.x; av[5] = (int)a1.y; av[6] = (int)a1.z; av[7] = (int)a1.w;
+                    bv[0] = (int)b0.x; bv[1] = (int)b0.y; bv[2] = (int)b0.z; bv[3] = (int)b0.w;
+                    bv[4] = (int)b1.x; bv[5] = (int)b1.y; bv[6] = (int)b1.z; bv[7] = (int)b1.w;
+                    acc32[2 * t + u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc32[2 * t + u], 0, 0, 0, sc_a, 0, sc_b);
+                }
+        }
+        if (ablate & 256) __builtin_amdgcn_s_setprio(0);
+    };
+    const int nsub = KE / (G * FR_PR);
+    constexpr unsigned WAIT_LOOP = 3 * G * (NS - 3), WAIT_FIRST = 3 * G * (NS - 2);
+    constexpr int IMM_LOOP = (int)((WAIT_LOOP & 0xF) | ((WAIT_LOOP >> 4) << 14) | 0x0F70u), IMM_FIRST = (int)((WAIT_FIRST & 0xF) | ((WAIT_FIRST >> 4) << 14) | 0x0F70u);
+    // One iteration = one ROW GROUP (4 element rows): it is multiplied from `cur` (already in registers) while `nxt` receives the next
+    // group.  Synchronisation is per SUB-STEP (G groups): its first group (HEAD) waits for the NEXT sub-step's loads and passes the
+    // barrier, and the sub-step's DMAs are issued either there or after its last group (TAIL).  MAIN: the steady state (a sub-step is
+    // issued, NS - 2 are in flight), branch-free around the waits so that hipcc counts its own lgkmcnt waits; otherwise the pipeline's
+    // tail (plain vmcnt(0), nothing may be left to issue).  The fragment prefetch is unconditional: past the last group it reads a stage
+    // nobody uses.
+    // STAGGER (order 1, default): the two waves of a SIMD (w and w + 4) would otherwise do the same thing at the same time -- issue
+    // DMAs (expensive beside other memory instructions), read fragments, and only then both want the matrix pipe.  Waves 0-3 issue and
+    // read first and multiply afterwards, waves 4-7 multiply the moment the barrier opens and read / issue afterwards: one partner's
+    // memory instructions hide behind the other's MFMAs (Model-C FC1 bf16: 57.5 -> 52.9 us; profiles/r02_gemm_experiments.md).
+    const int order = (ablate >> 4) & 15;  // experiment knob FR_GEMM_ORDER: 0 = every wave multiplies first, 1 = stagger, 2 = every wave issues + reads first
+    const bool early = order == 2 || (order == 1 && wave < 4);
+    int rd_grp = 1;                      // group to prefetch next, counted inside the ring of NS * G groups
+    const uint4 *rd_ptr = glds + FR_PR * ROW;
+    auto step = [&](const FrPipeFrag<PREC> &cur, FrPipeFrag<PREC> &nxt, auto main_tag, auto head_tag, auto tail_tag) {
+        constexpr bool MAIN = decltype(main_tag)::value, HEAD = decltype(head_tag)::value, TAIL = decltype(tail_tag)::value;
+        if constexpr (HEAD) {
+            if constexpr (MAIN) __builtin_amdgcn_s_waitcnt(IMM_LOOP);  // this wave's loads of the NEXT sub-step have landed ...
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // ... everybody's have, and everybody is past the fragment reads of the previous sub-step
+            asm volatile("" ::: "memory");
+        }
+        const bool no_dma = (ablate & 15) == 1;  // timing experiment: no DMA inside the loop
+        if (order == 3 || (order == 4 && wave < 4)) {  // issue, multiply, read
+            if (HEAD && !no_dma && (MAIN || issued < nsub)) issue_next();
+            mfmas(cur);
+            pipe_read_frags<PREC>(nxt, rd_ptr, ROW, wn, wm, lane);
+        } else if (early) {
+            if (HEAD && !no_dma && (MAIN || issued < nsub)) issue_next();  // overwrites the stage the previous sub-step lived in
+            pipe_read_frags<PREC>(nxt, rd_ptr, ROW, wn, wm, lane);
+            mfmas(cur);
+        } else {
+            mfmas(cur);
+            pipe_read_frags<PREC>(nxt, rd_ptr, ROW, wn, wm, lane);
+            if (TAIL && !no_dma && (MAIN || issued < nsub)) issue_next();
+        }
+        rd_grp++;
+        rd_ptr += FR_PR * ROW;
+        if (rd_grp == NS * G) {
+            rd_grp = 0;
+            rd_ptr = glds;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < NS - 1; i++)
+        if (i < nsub) issue_next();
+    FrPipeFrag<PREC> fa, fb;
+    if (nsub >= NS - 1) __builtin_amdgcn_s_waitcnt(IMM_FIRST);  // sub-step 0 has landed
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    pipe_read_frags<PREC>(fa, glds, ROW, wn, wm, lane);
+    using T = std::true_type;
+    using F = std::false_type;
+    const int main_end = nsub - (NS - 1);  // sub < main_end: an issue happens and the counted wait is valid
+    int sub = 0;
+    if constexpr (G == 1) {  // two sub-steps per trip (the register sets alternate)
+        for (; sub + 1 < main_end; sub += 2) {
+            step(fa, fb, T{}, T{}, T{});
+            step(fb, fa, T{}, T{}, T{});
+        }
+        for (; sub < nsub; sub += 2) {  // nsub is even (checked by the launcher)
+            step(fa, fb, F{}, T{}, T{});
+            step(fb, fa, F{}, T{}, T{});
+        }
+    } else {  // G == 2: one sub-step per trip
+        for (; sub < main_end; sub++) {
+            step(fa, fb, T{}, T{}, F{});
+            step(fb, fa, T{}, F{}, T{});
+        }
+        for (; sub < nsub; sub++) {
+            step(fa, fb, F{}, T{}, F{});
+            step(fb, fa, F{}, F{}, T{});
+        }
+    }
+    // epilogue: ONE rounding per output
+    if constexpr (PREC == 1) {  // 16 x 16 tiles: lane holds m = lane % 16 and n = 4 (lane / 16) + c
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const f32x4_t &c = acc16[4 * t + u];
+                const int m = m0 + wm * 64 + 16 * u + (lane & 15);
+                const int n = n0 + wn * 64 + 16 * t + 4 * (lane >> 4);
+                uint2 hv;
+                hv.x = pack_bf16x2(c[0], c[1]);
+                hv.y = pack_bf16x2(c[2], c[3]);
+                reinterpret_cast<uint2 *>(Y)[((size_t)(n >> 3) * ldm + m) * 2 + ((n & 7) >> 2)] = hv;
+            }
+    } else {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const f32x16 &c = acc32[2 * t + u];
+                const int m = m0 + wm * 64 + 32 * u + r;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int n = n0 + wn * 64 + 32 * t + 8 * i + 4 * h;
+                    reinterpret_cast<uint32_t *>(Y)[((size_t)(n >> 4) * ldm + m) * 4 + ((n & 15) >> 2)] =
+                        pack_fp8x4(c[4 * i + 0], c[4 * i + 1], c[4 * i + 2], c[4 * i + 3], oscale);
+                }
+            }
+    }
+}
+
+// Pipeline shape (experiment knob FR_GEMM_PIPE = 10 * G + NS; 0 = fc_lp_gemm_kernel): G row groups of 4 element rows per sub-step, NS
+// sub-steps in LDS.  Default: see pipe_shape().
+static int pipe_shape() {
+    static const int v = getenv("FR_GEMM_PIPE") ? atoi(getenv("FR_GEMM_PIPE")) : 15;
+    return v;
+}
+
+template <int PREC, int NS, int G>
+static int pipe_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
+    static FrLdsAttrOnce lds_once;
+    const size_t lds = (size_t)NS * G * FR_PR * (FR_GN + 256) * 16;
+    if (int rc_ = fr_allow_full_lds(&fc_gemm_pipe_kernel<PREC, NS, G>, lds_once)) return rc_;
+    dim3 grid((N / FR_GN) * (ldm / 256));
+    static const int ablate = (getenv("FR_GEMM_ABLATE") ? atoi(getenv("FR_GEMM_ABLATE")) : 0) |   // timing experiments only
+                              ((getenv("FR_GEMM_ORDER") ? atoi(getenv("FR_GEMM_ORDER")) : 1) << 4) | ((getenv("FR_GEMM_PRIO") ? atoi(getenv("FR_GEMM_PRIO")) : 1) << 8);
+    fc_gemm_pipe_kernel<PREC, NS, G><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale, ablate);
+    KCHECK();
+    return FR_OK;
+}
+
+// sub-steps must come in pairs (the loop alternates two fragment register sets) and there must be enough of them to fill the pipeline
+static bool pipe_shape_ok(int shape, int KE) {
+    const int g = shape / 10, ns = shape % 10;
+    if (!((g == 1 && (ns == 4 || ns == 5 || ns == 6)) || (g == 2 && ns == 3))) return false;
+    return KE % (2 * FR_PR) == 0 && KE / (g * FR_PR) >= 2 * ns;  // G == 1 consumes sub-steps in pairs, G == 2 one at a time (8 rows either way)
+}
+
+template <int PREC>
+static int pipe_gemm_dispatch(int shape, const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
+    switch (shape) {
+        case 14: return pipe_gemm_launch<PREC, 4, 1>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+        case 16: return pipe_gemm_launch<PREC, 6, 1>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+        case 23: return pipe_gemm_launch<PREC, 3, 2>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+        default: return pipe_gemm_launch<PREC, 5, 1>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+    }
+}
+
 // Which block tile serves the layer: 2 (128 x 256) when those tiles cover most of the chip, 1 (128 x 128) when only the smaller ones
 // reach a quarter of it, 0 = not worth a GEMM launch (the stage pipeline's per-tile body takes it).
 static int lp_gemm_mu(int precision, int K, int N, int ldm) {
@@ -206,6 +509,13 @@ int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int 
     const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : (precision == FR_FC_BF16 ? K / 8 : K / 4);
     if (precision == FR_FC_FP32)
         return mu == 2 ? lp_gemm_launch<0, 2>(Wp, Xp, Yp, KE, N, ldm, 0, 0, 1.0f, s) : lp_gemm_launch<0, 1>(Wp, Xp, Yp, KE, N, ldm, 0, 0, 1.0f, s);
+    // bf16 128 x 256 layers run the software-pipelined kernel; fp8 stays on fc_lp_gemm_kernel, which measured faster there (29.4 vs
+    // 32.9 us on Model-C FC1: its 8-row steps halve the barriers per 64-cycle MFMA) unless FR_GEMM_PIPE_FP8=1 asks for the experiment
+    static const bool pipe_fp8 = getenv("FR_GEMM_PIPE_FP8") && atoi(getenv("FR_GEMM_PIPE_FP8")) != 0;
+    if (mu == 2 && (precision == FR_FC_BF16 || (precision == FR_FC_FP8 && pipe_fp8)) && pipe_shape_ok(pipe_shape(), KE)) {
+        if (precision == FR_FC_FP8) return pipe_gemm_dispatch<2>(pipe_shape(), Wp, Xp, Yp, KE, N, ldm, 127 - e_w, 127 - e_in, ldexpf(1.0f, e_out), s);
+        return pipe_gemm_dispatch<1>(pipe_shape(), Wp, Xp, Yp, KE, N, ldm, 0, 0, 1.0f, s);
+    }
     if (precision == FR_FC_FP8) {
         const float os = ldexpf(1.0f, e_out);
         return mu == 2 ? lp_gemm_launch<2, 2>(Wp, Xp, Yp, KE, N, ldm, 127 - e_w, 127 - e_in, os, s)
