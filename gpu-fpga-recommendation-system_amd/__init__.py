@@ -58,7 +58,8 @@ _lib = None
 ABI_SYMBOLS = [
     "fr_abi_version", "fr_last_error", "fr_device_count", "fr_model_builtin", "fr_model_clone_scaled", "fr_model_free",
     "fr_model_table_bytes", "fr_model_index_cols", "fr_model_bank_map", "fr_ctx_set_gather_variant", "fr_ctx_gather_variant",
-    "fr_ctx_gather_merged_lookups", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
+    "fr_ctx_gather_merged_lookups", "fr_comm_unique_id", "fr_comm_init_rank", "fr_comm_init_all", "fr_comm_destroy",
+    "fr_worker_submit_sharded", "fr_worker_calibrate_fp8_sharded", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
     "fr_ctx_fill_tables", "fr_ctx_upload_table", "fr_ctx_download_table", "fr_ctx_set_weights", "fr_ctx_fill_weights",
     "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_ctx_get_fp8_exponents", "fr_ctx_set_fp8_act_exponents",
     "fr_worker_calibrate_fp8", "fr_worker_calibrate_fp8_slices", "fr_worker_push_host", "fr_worker_stream", "fr_worker_gather_slices", "fr_worker_fc_from_slices_lp", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
@@ -116,6 +117,9 @@ def lib():
         "fr_driver_worker": (vp, [vp, i32, i32]), "fr_driver_score_ring": (vp, [vp, i32, i32, ctypes.POINTER(ctypes.c_int)]),
         "fr_ctx_stream_group": (i32, [vp]), "fr_ctx_set_stream_group": (i32, [vp, i32]),
         "fr_ctx_set_gather_variant": (i32, [vp, i32]), "fr_ctx_gather_variant": (i32, [vp]),
+        "fr_comm_unique_id": (i32, [vp]), "fr_comm_init_rank": (i32, [vp, vp, ctypes.POINTER(vp)]),
+        "fr_comm_init_all": (i32, [ctypes.POINTER(vp), i32, ctypes.POINTER(vp)]), "fr_comm_destroy": (None, [vp]),
+        "fr_worker_submit_sharded": (i32, [vp, vp, i32]), "fr_worker_calibrate_fp8_sharded": (i32, [vp, vp, i32]),
         "fr_ctx_gather_merged_lookups": (i32, [vp, ctypes.POINTER(ctypes.c_uint64), i32]),
         "fr_driver_run_host": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
         "fr_driver_run_host_streaming": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
@@ -496,6 +500,25 @@ class Worker:
             return None
         return x.ptr if isinstance(x, DeviceBuffer) else ctypes.c_void_p(x)
 
+    def infer_sharded(self, comm, idx, dense=None):
+        """The sharded hot-loop body (collective): this rank's worker receives the WHOLE request batch; -> all `batch` scores."""
+        idx = np.asarray(idx, dtype=np.int32).reshape(len(idx), -1)
+        B = idx.shape[0]
+        self.idx[:B] = idx
+        if self.dense is not None:
+            self.dense[:B] = np.asarray(dense, dtype=np.float32).reshape(B, -1)
+        _check(lib().fr_worker_submit_sharded(self._h, comm._h, B))
+        self.sync()
+        return self.score[:B].copy()
+
+    def calibrate_fp8_sharded(self, comm, idx, dense=None):
+        idx = np.asarray(idx, dtype=np.int32).reshape(len(idx), -1)
+        B = idx.shape[0]
+        self.idx[:B] = idx
+        if self.dense is not None:
+            self.dense[:B] = np.asarray(dense, dtype=np.float32).reshape(B, -1)
+        _check(lib().fr_worker_calibrate_fp8_sharded(self._h, comm._h, B))
+
     def submit_device(self, batch, d_idx, d_dense, d_scores):
         _check(lib().fr_worker_submit_device(self._h, batch, self._ptr(d_idx), self._ptr(d_dense), self._ptr(d_scores)))
 
@@ -592,6 +615,38 @@ class Worker:
         self.fc_only(B, d_rec, d_sc)
         self.sync()
         return d_sc.download(np.float32, B)
+
+
+class Comm:
+    """One rank's RCCL communicator over the shards of a table-sharded model (fr_comm_*)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _check(lib().fr_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def init_rank(cls, ctx, unique_id):
+        h = ctypes.c_void_p()
+        _check(lib().fr_comm_init_rank(ctx._h, ctypes.create_string_buffer(unique_id, 128), ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def init_all(cls, ctxs):
+        n = len(ctxs)
+        arr = (ctypes.c_void_p * n)(*[c._h for c in ctxs])
+        out = (ctypes.c_void_p * n)()
+        _check(lib().fr_comm_init_all(arr, n, out))
+        return [cls(ctypes.c_void_p(out[i])) for i in range(n)]
+
+    def close(self):
+        if self._h:
+            lib().fr_comm_destroy(self._h)
+            self._h = None
 
 
 class Driver:

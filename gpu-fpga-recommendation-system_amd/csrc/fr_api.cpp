@@ -550,7 +550,7 @@ extern "C" void fr_worker_destroy(fr_worker *w) {
     if (w->h_dense) (void)hipHostFree(w->h_dense);
     if (w->h_score) (void)hipHostFree(w->h_score);
     if (w->h_err) (void)hipHostFree(w->h_err);
-    void *dev[] = {w->d_idx, w->d_dense, w->d_records, w->d_act[0], w->d_act[1], w->d_score};
+    void *dev[] = {w->d_idx, w->d_dense, w->d_records, w->d_act[0], w->d_act[1], w->d_score, w->d_slice, w->d_gathered, w->d_score_part, w->d_score_all};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (w->hr.h_idx) (void)hipHostFree(w->hr.h_idx);

@@ -1,0 +1,222 @@
+// Table-sharded mode behind the C-ABI: the exchange step on RCCL (include/fleetrec.h "table-sharded mode").
+//
+// Reference shape: the 3-node GPU server receives the three parts of every batch from three senders (CPU0, FPGA0, FPGA1) over
+// three sockets before its GEMMs (GPU/final_network_cublasLt_3_nodes_no_FIFO_scatter/cuda_server.c:513-591).  Here the "senders" are
+// the G GPUs that hold the table-ID shards: each gathers its slice of the record, ONE ncclAllGather over xGMI delivers all slices to
+// everybody, each GPU runs the FC chain on its B/G items, and a second (tiny) all-gather hands every rank all B scores.
+// librccl.so is opened on first use (dlopen), so unsharded users never load it; every RCCL failure surfaces as FR_ERR_COMM.
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the functions are resolved through dlsym
+
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "fr_internal.h"
+
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+bool g_rccl_ok = false;
+
+int rccl_load() {
+    std::call_once(g_rccl_once, [] {
+        const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *n : names) {
+            g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (g_rccl.handle) break;
+        }
+        if (!g_rccl.handle) return;
+#define FR_SYM(field, name)                                              \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.handle, name)); \
+    if (!g_rccl.field) return;
+        FR_SYM(GetUniqueId, "ncclGetUniqueId")
+        FR_SYM(CommInitRank, "ncclCommInitRank")
+        FR_SYM(CommInitAll, "ncclCommInitAll")
+        FR_SYM(CommDestroy, "ncclCommDestroy")
+        FR_SYM(AllGather, "ncclAllGather")
+        FR_SYM(GetErrorString, "ncclGetErrorString")
+#undef FR_SYM
+        g_rccl_ok = true;
+    });
+    if (!g_rccl_ok) FR_FAIL(FR_ERR_COMM, "librccl.so could not be loaded (dlopen / dlsym): %s", dlerror() ? dlerror() : "symbol missing");
+    return FR_OK;
+}
+}  // namespace
+
+#define FR_NCCL(call)                                                                                   \
+    do {                                                                                                \
+        ncclResult_t r_ = (call);                                                                       \
+        if (r_ != ncclSuccess) FR_FAIL(FR_ERR_COMM, "%s failed: %s", #call, g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+struct fr_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, n_ranks = 1;
+    fr_ctx *ctx = nullptr;
+};
+
+static_assert(sizeof(ncclUniqueId) == 128, "fr_comm_unique_id hands out 128 bytes");
+
+extern "C" int fr_comm_unique_id(void *id128) {
+    if (!id128) FR_FAIL(FR_ERR_INVALID, "id128 is NULL");
+    int rc = rccl_load();
+    if (rc) return rc;
+    ncclUniqueId id;
+    FR_NCCL(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return FR_OK;
+}
+
+static int comm_check_ctx(const fr_ctx *ctx) {
+    if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
+    if (ctx->model.layout != FR_LAYOUT_SEMANTIC) FR_FAIL(FR_ERR_STATE, "the sharded exchange needs the SEMANTIC layout");
+    return FR_OK;
+}
+
+extern "C" int fr_comm_init_rank(fr_ctx *ctx, const void *id128, fr_comm **out) {
+    if (!out || !id128) FR_FAIL(FR_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    int rc = comm_check_ctx(ctx);
+    if (rc) return rc;
+    rc = rccl_load();
+    if (rc) return rc;
+    FR_HIP(hipSetDevice(ctx->device));
+    fr_comm *c = new (std::nothrow) fr_comm();
+    if (!c) FR_FAIL(FR_ERR_OOM, "out of host memory");
+    c->rank = ctx->shard_rank;
+    c->n_ranks = ctx->n_shards;
+    c->ctx = ctx;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, c->n_ranks, id, c->rank);
+    if (r != ncclSuccess) {
+        delete c;
+        FR_FAIL(FR_ERR_COMM, "ncclCommInitRank(rank %d of %d) failed: %s", ctx->shard_rank, ctx->n_shards, g_rccl.GetErrorString(r));
+    }
+    *out = c;
+    return FR_OK;
+}
+
+extern "C" int fr_comm_init_all(fr_ctx *const *ctxs, int n, fr_comm **out) {
+    if (!ctxs || !out || n < 1 || n > 64) FR_FAIL(FR_ERR_INVALID, "bad argument");
+    for (int r = 0; r < n; r++) out[r] = nullptr;
+    int rc = rccl_load();
+    if (rc) return rc;
+    int devs[64];
+    for (int r = 0; r < n; r++) {
+        rc = comm_check_ctx(ctxs[r]);
+        if (rc) return rc;
+        if (ctxs[r]->n_shards != n || ctxs[r]->shard_rank != r) FR_FAIL(FR_ERR_INVALID, "ctxs[%d] is shard %d of %d, expected %d of %d", r, ctxs[r]->shard_rank, ctxs[r]->n_shards, r, n);
+        devs[r] = ctxs[r]->device;
+        for (int q = 0; q < r; q++)
+            if (devs[q] == devs[r]) FR_FAIL(FR_ERR_INVALID, "shards %d and %d share device %d: RCCL needs one device per rank", q, r, devs[r]);
+    }
+    ncclComm_t comms[64];
+    FR_NCCL(g_rccl.CommInitAll(comms, n, devs));
+    for (int r = 0; r < n; r++) {
+        fr_comm *c = new (std::nothrow) fr_comm();
+        if (!c) FR_FAIL(FR_ERR_OOM, "out of host memory");
+        c->comm = comms[r];
+        c->rank = r;
+        c->n_ranks = n;
+        c->ctx = ctxs[r];
+        out[r] = c;
+    }
+    return FR_OK;
+}
+
+extern "C" void fr_comm_destroy(fr_comm *c) {
+    if (!c) return;
+    if (c->comm && g_rccl_ok) {
+        if (c->ctx) (void)hipSetDevice(c->ctx->device);
+        (void)g_rccl.CommDestroy(c->comm);
+    }
+    delete c;
+}
+
+// exchange buffers of a worker: slice [max_batch][F] and gathered [G][max_batch][F] sized for fp32 elements, score chunks
+static int shard_buffers(fr_worker *w, int G) {
+    if (w->sh_ranks == G && w->d_slice) return FR_OK;
+    fr_ctx *c = w->ctx;
+    const size_t slice = (size_t)w->max_batch * (size_t)c->slice_padded * sizeof(float);
+    const size_t chunk = ((size_t)w->max_batch + G - 1) / G;
+    void **bufs[] = {&w->d_slice, &w->d_gathered, (void **)&w->d_score_part, (void **)&w->d_score_all};
+    for (void **b : bufs)
+        if (*b) {
+            (void)hipFree(*b);
+            *b = nullptr;
+        }
+    FR_HIP(hipMalloc(&w->d_slice, slice));
+    FR_HIP(hipMalloc(&w->d_gathered, slice * G));
+    FR_HIP(hipMalloc((void **)&w->d_score_part, chunk * sizeof(float)));
+    FR_HIP(hipMalloc((void **)&w->d_score_all, chunk * G * sizeof(float)));
+    w->sh_ranks = G;
+    return FR_OK;
+}
+
+static int sharded_prologue(fr_worker *w, fr_comm *comm, int batch) {
+    if (!w || !comm) FR_FAIL(FR_ERR_INVALID, "NULL argument");
+    fr_ctx *c = w->ctx;
+    if (comm->ctx != c) FR_FAIL(FR_ERR_INVALID, "the communicator belongs to another context");
+    if (batch <= 0 || batch > w->max_batch) FR_FAIL(FR_ERR_INVALID, "batch %d outside (0, max_batch=%d]", batch, w->max_batch);
+    if (!c->tables_filled) FR_FAIL(FR_ERR_STATE, "tables have not been filled or uploaded");
+    if (!c->weights_set) FR_FAIL(FR_ERR_STATE, "FC weights have not been set");
+    if (w->in_flight) FR_FAIL(FR_ERR_STATE, "a batch is already in flight on this worker: call fr_worker_sync first");
+    FR_HIP(hipSetDevice(c->device));
+    int rc = shard_buffers(w, comm->n_ranks);
+    if (rc) return rc;
+    const size_t icols = c->model.index_mode == FR_INDEX_PER_TABLE ? (size_t)c->model.n_tables : (c->model.index_mode == FR_INDEX_PER_BANK ? (size_t)c->n_banks : 1);
+    FR_HIP(hipMemcpyAsync(w->d_idx, w->h_idx, (size_t)batch * icols * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
+    if (c->model.dense_len)
+        FR_HIP(hipMemcpyAsync(w->d_dense, w->h_dense, (size_t)batch * c->model.dense_len * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    return FR_OK;
+}
+
+extern "C" int fr_worker_submit_sharded(fr_worker *w, fr_comm *comm, int batch) {
+    int rc = sharded_prologue(w, comm, batch);
+    if (rc) return rc;
+    fr_ctx *c = w->ctx;
+    const int G = comm->n_ranks, r = comm->rank;
+    const int transport = c->fc_precision;  // slices travel in the chain's own operand type: fp32, bf16 (half) or e4m3 (a quarter of the bytes)
+    const size_t esz = transport == FR_FC_FP32 ? 4 : (transport == FR_FC_BF16 ? 2 : 1);
+    rc = fr_worker_gather_slices(w, batch, w->d_idx, w->d_dense, w->d_slice, transport);
+    if (rc) return rc;
+    FR_NCCL(g_rccl.AllGather(w->d_slice, w->d_gathered, (size_t)batch * c->slice_padded * esz, ncclChar, comm->comm, w->stream));
+    const int base = batch / G, rem = batch % G, chunk = base + (rem ? 1 : 0);
+    const int lo = r * base + (r < rem ? r : rem), n_mine = base + (r < rem ? 1 : 0);
+    if (n_mine > 0) {
+        w->in_flight = false;  // fr_worker_fc_from_slices_lp is a public entry point with its own state checks
+        rc = fr_worker_fc_from_slices_lp(w, batch, lo, n_mine, w->d_gathered, transport, w->d_score_part);
+        if (rc) return rc;
+    }
+    FR_NCCL(g_rccl.AllGather(w->d_score_part, w->d_score_all, (size_t)chunk, ncclFloat, comm->comm, w->stream));
+    for (int q = 0; q < G; q++) {  // every rank ends up with all B scores in its pinned score buffer
+        const int qlo = q * base + (q < rem ? q : rem), qn = base + (q < rem ? 1 : 0);
+        if (qn > 0) FR_HIP(hipMemcpyAsync(w->h_score + qlo, w->d_score_all + (size_t)q * chunk, (size_t)qn * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+    }
+    w->in_flight = true;
+    return FR_OK;
+}
+
+// fp8 chain on sharded contexts: every rank calibrates on the SAME all-gathered fp32 slices of the whole batch with the same
+// (replicated) weights, so all ranks arrive at identical activation exponents without a further reduction.
+extern "C" int fr_worker_calibrate_fp8_sharded(fr_worker *w, fr_comm *comm, int batch) {
+    int rc = sharded_prologue(w, comm, batch);
+    if (rc) return rc;
+    fr_ctx *c = w->ctx;
+    rc = fr_worker_gather_only(w, batch, w->d_idx, w->d_dense, reinterpret_cast<float *>(w->d_slice));
+    if (rc) return rc;
+    FR_NCCL(g_rccl.AllGather(w->d_slice, w->d_gathered, (size_t)batch * c->slice_padded * sizeof(float), ncclChar, comm->comm, w->stream));
+    w->in_flight = false;
+    return fr_worker_calibrate_fp8_slices(w, batch, 0, batch, reinterpret_cast<const float *>(w->d_gathered));
+}

@@ -77,8 +77,8 @@ template <int ITEMS, int TP>
 __global__ void __launch_bounds__(256) gather_pack_xcd_kernel(const FrWordDesc *__restrict__ words, int n_words, int words_per_group,
                                                               const int32_t *__restrict__ idx, int idx_stride,
                                                               const float *__restrict__ dense, void *__restrict__ out,
-                                                              int batch, int *__restrict__ err_flag, float scale) {
-    const int group = blockIdx.x & 7, chunk = blockIdx.x >> 3;
+                                                              int batch, int *__restrict__ err_flag, float scale, int n_chunks) {
+    const int group = blockIdx.x & 7;
     const int w = group * words_per_group + threadIdx.x;
     if ((int)threadIdx.x >= words_per_group || w >= n_words) return;
     const uint4 d0 = reinterpret_cast<const uint4 *>(words)[2 * w];
@@ -88,30 +88,33 @@ __global__ void __launch_bounds__(256) gather_pack_xcd_kernel(const FrWordDesc *
     const uint32_t rows = d1.x, dst_off = d1.y, dst_stride = d1.z, dst_blk = d1.w;
     const bool is_dense = (idx_col & FR_DESC_DENSE) != 0;
     const char *base = is_dense ? reinterpret_cast<const char *>(dense) + src : reinterpret_cast<const char *>(src);
-    const int b0 = chunk * ITEMS;
-    uint32_t id[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const int b = b0 + i;
-        id[i] = 0;
-        if (b < batch) id[i] = is_dense ? (uint32_t)b : (uint32_t)idx[(size_t)b * idx_stride + idx_col];
-    }
-    bool bad = false;
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        if (!is_dense && id[i] >= rows) {
-            bad = true;
-            id[i] = 0;
-        }
-    }
-    uint4 v[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) v[i] = *reinterpret_cast<const uint4 *>(base + (uint64_t)id[i] * stride);
     const size_t blk = (size_t)dst_blk * (size_t)batch + dst_off;
+    bool bad = false;
+    // a thread keeps its descriptor and walks chunks of ITEMS items: chunk = blockIdx.x / 8, stepping by the grid's chunk count
+    for (int chunk = blockIdx.x >> 3; chunk < n_chunks; chunk += gridDim.x >> 3) {
+        const int b0 = chunk * ITEMS;
+        uint32_t id[ITEMS];
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const int b = b0 + i;
-        if (b < batch) store_word<TP>(out, blk + (size_t)b * dst_stride, v[i], scale);
+        for (int i = 0; i < ITEMS; i++) {
+            const int b = b0 + i;
+            id[i] = 0;
+            if (b < batch) id[i] = is_dense ? (uint32_t)b : (uint32_t)idx[(size_t)b * idx_stride + idx_col];
+        }
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            if (!is_dense && id[i] >= rows) {
+                bad = true;
+                id[i] = 0;
+            }
+        }
+        uint4 v[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) v[i] = *reinterpret_cast<const uint4 *>(base + (uint64_t)id[i] * stride);
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const int b = b0 + i;
+            if (b < batch) store_word<TP>(out, blk + (size_t)b * dst_stride, v[i], scale);
+        }
     }
     if (bad) atomicOr_system(err_flag, 1);
 }
@@ -120,8 +123,11 @@ template <int ITEMS, int TP>
 static int gather_launch_xcd(const FrWordDesc *words, int n_words, int wpg, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch,
                              int *err_flag, float scale, hipStream_t s) {
     const int bx = ((wpg + 63) / 64) * 64;
-    dim3 grid(8 * ((batch + ITEMS - 1) / ITEMS));
-    gather_pack_xcd_kernel<ITEMS, TP><<<grid, dim3(bx), 0, s>>>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale);
+    const int n_chunks = (batch + ITEMS - 1) / ITEMS;
+    const char *e_loop = getenv("FR_GATHER_LOOP");  // experiment knob: chunks a workgroup walks (1 = one chunk per workgroup)
+    const int per_wg = e_loop ? (atoi(e_loop) > 0 ? atoi(e_loop) : 1) : 1;
+    dim3 grid(8 * ((n_chunks + per_wg - 1) / per_wg));
+    gather_pack_xcd_kernel<ITEMS, TP><<<grid, dim3(bx), 0, s>>>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, n_chunks);
     KCHECK();
     return FR_OK;
 }
@@ -138,6 +144,7 @@ static int gather_launch(const FrWordDesc *words, int n_words, const int32_t *id
         const int wpg = (n_words + 7) / 8;
         if (wpg <= 256) {
             switch (e_items ? atoi(e_items) : 4) {  // 4 items per thread: fastest in the r02 sweep (profiles/r02_gather_sweep.txt)
+                case 1: return gather_launch_xcd<1, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
                 case 2: return gather_launch_xcd<2, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
                 case 8: return gather_launch_xcd<8, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
                 case 16: return gather_launch_xcd<16, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);

@@ -232,6 +232,10 @@ struct fr_worker {
         int bsz[4][FR_FUSED_MAX_BATCHES];
         int cur = 0;               // block being filled
     } hr;
+    // table-sharded exchange (fr_worker_submit_sharded, fr_comm.cpp): this shard's slice, the all-gathered slices, score chunks
+    void *d_slice = nullptr, *d_gathered = nullptr;
+    float *d_score_part = nullptr, *d_score_all = nullptr;
+    int sh_ranks = 0;
     int *h_err = nullptr;  // sticky index-range flag: pinned host word ...
     int *d_err = nullptr;  // ... and its device-side alias
     bool in_flight = false;

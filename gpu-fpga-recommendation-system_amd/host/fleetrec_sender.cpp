@@ -5,7 +5,7 @@
 // the connection.  A block is B x T int32 indices (+ B x 64 dense floats for Model-C).
 //
 // Usage: fleetrec_sender --model A|B|C [--batch 256] [--threads 4] [--port 8080] [--host 127.0.0.1]
-//                        [--indices reference|uniform] [--per-item] [--row-cap N] [--max-blocks N] [--reply]
+//                        [--indices reference|uniform] [--per-item | --per-bank] [--row-cap N] [--max-blocks N] [--reply]
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
@@ -30,7 +30,7 @@ int main(int argc, char **argv) {
     int which = FR_MODEL_A, batch = 256, threads = 4, port = 8080;
     long row_cap = 0, max_blocks = 1L << 40, interval_us = 0;
     std::string host = "127.0.0.1", indices = "reference";
-    bool per_item = false, reply = false;
+    bool per_item = false, per_bank = false, reply = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { return (i + 1 < argc) ? argv[++i] : ""; };
@@ -41,6 +41,7 @@ int main(int argc, char **argv) {
         else if (a == "--host") host = next();
         else if (a == "--indices") indices = next();
         else if (a == "--per-item") per_item = true;
+        else if (a == "--per-bank") per_bank = true;
         else if (a == "--reply") reply = true;
         else if (a == "--row-cap") row_cap = atol(next());
         else if (a == "--max-blocks") max_blocks = atol(next());
@@ -49,7 +50,17 @@ int main(int argc, char **argv) {
     }
     fr_model_desc *m = nullptr;
     if (fr_model_clone_scaled(fr_model_builtin(which), 1.0, 1, row_cap, &m) != FR_OK) { fprintf(stderr, "%s\n", fr_last_error()); return 1; }
-    const size_t cols = per_item ? 1 : (size_t)m->n_tables;
+    if (per_item) m->index_mode = FR_INDEX_PER_ITEM;
+    if (per_bank) m->index_mode = FR_INDEX_PER_BANK;   // one index per memory bank per item: the reference kernel's own contract
+    const size_t cols = (size_t)fr_model_index_cols(m);
+    std::vector<int64_t> col_range(cols, 100);          // exclusive upper bound of every index column
+    if (per_bank) {
+        std::vector<int64_t> rows(m->n_tables);
+        fr_model_bank_map(m, nullptr, rows.data());
+        for (size_t c = 0; c < cols; c++) col_range[c] = rows[c];
+    } else if (!per_item) {
+        for (size_t c = 0; c < cols; c++) col_range[c] = m->tables[c].rows;
+    }
     std::vector<std::thread> th;
     std::vector<long> sent(threads, 0);
     for (int t = 0; t < threads; t++) {
@@ -73,7 +84,7 @@ int main(int argc, char **argv) {
                     for (size_t c = 0; c < cols; c++) {
                         int32_t v;
                         if (indices == "reference") v = kIdxRandom[b % 32];  // same index for every table of the item (F4)
-                        else v = (int32_t)(rng() % (uint64_t)(per_item ? 100 : m->tables[c].rows));
+                        else v = (int32_t)(rng() % (uint64_t)col_range[c]);
                         idx[(size_t)b * cols + c] = v;
                     }
                     for (int d = 0; d < m->dense_len; d++)

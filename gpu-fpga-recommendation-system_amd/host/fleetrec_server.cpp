@@ -11,7 +11,12 @@
 // (--reply), which the reference never did (its "Finish receiving." message is defined but never sent, :363).
 //
 // Usage: fleetrec_server --model A|B|C [--batch 256] [--threads 4] [--port 8080] [--total 1024] [--device 0]
-//                        [--tables evenodd|hash] [--weights ones|uniform] [--per-item] [--reply] [--row-cap N]
+//                        [--tables evenodd|hash] [--weights ones|uniform] [--per-item | --per-bank] [--reply] [--row-cap N]
+//                        [--shards G [--precision f32|bf16|fp8]]
+// --shards G: BASELINE configs[3]/[4] -- the tables are sharded by table-ID over GPUs device .. device + G - 1 of this node (one
+// context and one worker per shard, fr_comm_init_all); every batch goes through fr_worker_submit_sharded on all shards (slices
+// all-gathered over RCCL, FC on batch / G items per GPU, scores all-gathered).  The counterpart of the 3-node server, whose batch
+// arrives in three parts from three senders (3-node cuda_server.c:513-591).
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
@@ -20,6 +25,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,7 +40,9 @@ struct Options {
     int model = FR_MODEL_A, batch = 256, threads = 4, port = 8080, device = 0;
     long total = 1024;
     int tables = FR_FILL_EVEN_ODD, weights = FR_WEIGHTS_ONES;
-    bool per_item = false, reply = false;
+    bool per_item = false, per_bank = false, reply = false;
+    int shards = 0;            // > 0: table-sharded over `shards` GPUs
+    int precision = FR_FC_FP32;
     bool stream = false;   // throughput mode: fr_worker_push_host (blocks of batches per launch) instead of submit + sync per batch
     bool latency = false;  // latency-measurement mode: per-batch recv -> enqueued -> scores times (measure_network_cuda_cp_latency_*/cuda_server.c)
     long row_cap = 0;
@@ -65,6 +73,71 @@ static bool write_exact(int fd, const void *buf, size_t n) {
 static std::mutex g_mtx;            // pthread_mutex_t mtx            (cuda_server.c:25)
 static long g_global_batch_count = 0;  // int global_batch_count      (cuda_server.c:23)
 
+// The sharded engine: G persistent threads, one per shard (RCCL's collectives of one communicator must come from one thread per
+// rank).  A connection thread that holds a complete batch takes the engine, every shard thread copies the request into its worker's
+// pinned buffers and runs fr_worker_submit_sharded + fr_worker_sync, shard 0's pinned score buffer then holds all scores.
+struct ShardedEngine {
+    int G = 0, batch = 0;
+    std::vector<fr_ctx *> ctxs;
+    std::vector<fr_comm *> comms;
+    std::vector<fr_worker *> workers;
+    std::vector<std::thread> threads;
+    std::mutex mtx, user;  // mtx guards the hand-over state; user serialises the connection threads
+    std::condition_variable cv;
+    long generation = 0;
+    int pending = 0;
+    bool stop = false;
+    const int32_t *req_idx = nullptr;
+    const float *req_dense = nullptr;
+    size_t idx_bytes = 0, dense_bytes = 0;
+    int status = 0;
+    std::string error;
+
+    void shard_loop(int r) {
+        long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mtx);
+            cv.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+            lk.unlock();
+            memcpy(fr_worker_idx_ptr(workers[r]), req_idx, idx_bytes);
+            if (dense_bytes) memcpy(fr_worker_dense_ptr(workers[r]), req_dense, dense_bytes);
+            int rc = fr_worker_submit_sharded(workers[r], comms[r], batch);
+            if (rc == FR_OK) rc = fr_worker_sync(workers[r]);
+            lk.lock();
+            if (rc != FR_OK && status == 0) {
+                status = rc;
+                error = fr_last_error();
+            }
+            if (--pending == 0) cv.notify_all();
+        }
+    }
+    // -> 0 and scores in fr_worker_score_ptr(workers[0]); called under `user`
+    int run(const int32_t *idx, const float *dense) {
+        std::unique_lock<std::mutex> lk(mtx);
+        req_idx = idx;
+        req_dense = dense;
+        pending = G;
+        generation++;
+        cv.notify_all();
+        cv.wait(lk, [&] { return pending == 0; });
+        return status;
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(mtx);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &t : threads) t.join();
+        for (auto *w : workers) fr_worker_destroy(w);
+        for (auto *c : comms) fr_comm_destroy(c);
+        for (auto *c : ctxs) fr_ctx_destroy(c);
+    }
+};
+static ShardedEngine *g_engine = nullptr;
+
 struct ThreadInfo {  // struct CUDA_thread_info (cuda_server.c:91-98)
     int port;
     fr_ctx *ctx;
@@ -84,7 +157,7 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
         t->error = fr_last_error();
         return;
     }
-    const size_t idx_cols = m->index_mode == FR_INDEX_PER_ITEM ? 1 : (size_t)m->n_tables;
+    const size_t idx_cols = (size_t)fr_model_index_cols(m);
     const size_t idx_bytes = (size_t)o.batch * idx_cols * sizeof(int32_t);
     const size_t dense_bytes = (size_t)o.batch * m->dense_len * sizeof(float);
     int server_fd = socket(AF_INET, SOCK_STREAM, 0), opt = 1;
@@ -113,7 +186,40 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
         std::vector<float> stream_scores(o.stream ? (size_t)256 * o.batch : 0);
         std::vector<int32_t> stream_idx(o.stream ? idx_bytes / sizeof(int32_t) : 0);
         std::vector<float> stream_dense(o.stream ? dense_bytes / sizeof(float) : 0);
-        while (o.stream) {
+        std::vector<int32_t> sh_idx(g_engine ? idx_bytes / sizeof(int32_t) : 0);
+        std::vector<float> sh_dense(g_engine ? dense_bytes / sizeof(float) : 0), sh_scores(g_engine ? (size_t)o.batch : 0);
+        while (g_engine) {   // table-sharded mode: the whole batch is received here, then every shard works on it
+            {
+                std::lock_guard<std::mutex> g(g_mtx);
+                if (g_global_batch_count >= o.total) break;
+                g_global_batch_count++;
+            }
+            if (!read_exact(sock, sh_idx.data(), idx_bytes) || (dense_bytes && !read_exact(sock, sh_dense.data(), dense_bytes))) {
+                t->status = -4;
+                t->error = "Receiving data UNSUCCESSFUL (peer closed before the batch was complete)";
+                break;
+            }
+            const auto t_recv = std::chrono::steady_clock::now();
+            {
+                std::lock_guard<std::mutex> u(g_engine->user);
+                if (g_engine->run(sh_idx.data(), dense_bytes ? sh_dense.data() : nullptr) != 0) {
+                    t->status = -5;
+                    t->error = g_engine->error;
+                    break;
+                }
+                memcpy(sh_scores.data(), fr_worker_score_ptr(g_engine->workers[0]), (size_t)o.batch * sizeof(float));
+            }
+            t->recv_to_scores_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_recv).count());
+            if (o.reply && !write_exact(sock, sh_scores.data(), (size_t)o.batch * sizeof(float))) {
+                t->status = -7;
+                t->error = "sending scores failed";
+                break;
+            }
+            t->batches++;
+        }
+        if (g_engine)
+            for (int j = 0; j < 5 && j < o.batch && t->batches > 0; j++) t->first_scores.push_back(sh_scores[j]);
+        while (o.stream && !g_engine) {
             {
                 std::lock_guard<std::mutex> g(g_mtx);
                 if (g_global_batch_count >= o.total) break;
@@ -132,7 +238,7 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
             }
             t->batches++;
         }
-        if (o.stream) {
+        if (o.stream && !g_engine) {
             if (t->status == 0 && fr_worker_sync(wk) != FR_OK) {
                 t->status = -6;
                 t->error = fr_last_error();
@@ -140,7 +246,7 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
             if (t->batches > 0)
                 for (int j = 0; j < 5 && j < o.batch; j++) t->first_scores.push_back(stream_scores[(size_t)((t->batches - 1) % 256) * o.batch + j]);
         }
-        while (!o.stream) {
+        while (!o.stream && !g_engine) {
             {
                 std::lock_guard<std::mutex> g(g_mtx);
                 if (g_global_batch_count >= o.total) break;
@@ -172,7 +278,7 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
             }
             t->batches++;
         }
-        if (!o.stream) {
+        if (!o.stream && !g_engine) {
             const float *sc = fr_worker_score_ptr(wk);
             for (int j = 0; j < 5 && j < o.batch; j++) t->first_scores.push_back(sc[j]);  // cuda_server.c:499-502
         }
@@ -196,6 +302,9 @@ int main(int argc, char **argv) {
         else if (a == "--tables") o.tables = std::string(next()) == "hash" ? FR_FILL_HASH : FR_FILL_EVEN_ODD;
         else if (a == "--weights") o.weights = std::string(next()) == "uniform" ? FR_WEIGHTS_UNIFORM : FR_WEIGHTS_ONES;
         else if (a == "--per-item") o.per_item = true;
+        else if (a == "--per-bank") o.per_bank = true;
+        else if (a == "--shards") o.shards = atoi(next());
+        else if (a == "--precision") { std::string v = next(); o.precision = v == "bf16" ? FR_FC_BF16 : v == "fp8" ? FR_FC_FP8 : FR_FC_FP32; }
         else if (a == "--reply") o.reply = true;
         else if (a == "--latency") o.latency = true;
         else if (a == "--stream") o.stream = true;
@@ -206,9 +315,35 @@ int main(int argc, char **argv) {
     fr_model_desc *model = nullptr;
     if (fr_model_clone_scaled(fr_model_builtin(o.model), 1.0, 1, o.row_cap, &model) != FR_OK) { fprintf(stderr, "%s\n", fr_last_error()); return 1; }
     if (o.per_item) model->index_mode = FR_INDEX_PER_ITEM;
+    if (o.per_bank) model->index_mode = FR_INDEX_PER_BANK;
     fr_ctx *ctx = nullptr;
-    if (fr_ctx_create(model, o.device, &ctx) != FR_OK || fr_ctx_fill_tables(ctx, o.tables, 0xF1EE7) != FR_OK ||
-        fr_ctx_fill_weights(ctx, o.weights, 99) != FR_OK) {
+    ShardedEngine engine;
+    if (o.shards > 0) {  // one context + worker + communicator handle per shard, devices device .. device + G - 1
+        engine.G = o.shards;
+        engine.batch = o.batch;
+        engine.ctxs.assign(o.shards, nullptr);
+        engine.comms.assign(o.shards, nullptr);
+        engine.workers.assign(o.shards, nullptr);
+        for (int r = 0; r < o.shards; r++) {
+            if (fr_ctx_create_sharded(model, o.device + r, r, o.shards, &engine.ctxs[r]) != FR_OK || fr_ctx_fill_tables(engine.ctxs[r], o.tables, 0xF1EE7) != FR_OK ||
+                fr_ctx_fill_weights(engine.ctxs[r], o.weights, 99) != FR_OK || fr_ctx_set_fc_precision(engine.ctxs[r], o.precision) != FR_OK ||
+                fr_worker_create(engine.ctxs[r], o.batch, &engine.workers[r]) != FR_OK) {
+                fprintf(stderr, "shard %d set-up failed: %s\n", r, fr_last_error());
+                return 1;
+            }
+        }
+        if (fr_comm_init_all(engine.ctxs.data(), o.shards, engine.comms.data()) != FR_OK) {
+            fprintf(stderr, "RCCL set-up failed: %s\n", fr_last_error());
+            return 1;
+        }
+        engine.idx_bytes = (size_t)o.batch * (size_t)fr_model_index_cols(model) * sizeof(int32_t);
+        engine.dense_bytes = (size_t)o.batch * model->dense_len * sizeof(float);
+        for (int r = 0; r < o.shards; r++) engine.threads.emplace_back(&ShardedEngine::shard_loop, &engine, r);
+        g_engine = &engine;
+        ctx = engine.ctxs[0];
+        printf("table-sharded over %d GPUs (RCCL all-gather of the looked-up slices)\n", o.shards);
+    } else if (fr_ctx_create(model, o.device, &ctx) != FR_OK || fr_ctx_fill_tables(ctx, o.tables, 0xF1EE7) != FR_OK ||
+               fr_ctx_fill_weights(ctx, o.weights, 99) != FR_OK || fr_ctx_set_fc_precision(ctx, o.precision) != FR_OK) {
         fprintf(stderr, "set-up failed: %s\n", fr_last_error());
         return 1;
     }
@@ -271,7 +406,8 @@ int main(int argc, char **argv) {
         report("batch received -> enqueued", a);
         report("batch received -> scores on host", b);
     }
-    fr_ctx_destroy(ctx);
+    if (g_engine) engine.shutdown();
+    else fr_ctx_destroy(ctx);
     fr_model_free(model);
     return rc;
 }

@@ -42,7 +42,7 @@ typedef enum fr_status {
     FR_ERR_INDEX_RANGE = -5, /* a lookup index was >= the table's row count (reference: silent OOB,
                                 embedding_47_krnl.cpp:927-933) */
     FR_ERR_STATE = -6,       /* call sequence error (e.g. sync without submit, tables not filled) */
-    FR_ERR_COMM = -7         /* RCCL error in the table-sharded mode */
+    FR_ERR_COMM = -7         /* RCCL error in the table-sharded mode (fr_comm_*, fr_worker_submit_sharded) */
 } fr_status;
 
 /* Memory class a table lived in on the FPGA card.  Purely descriptive on MI355X (everything is in
@@ -364,6 +364,27 @@ int fr_worker_fc_from_slices(fr_worker *w, int batch_total, int item0, int n_ite
  * back to fr_worker_gather_only / fr_worker_fc_from_slices).  Scores are bit-identical to fp32 transport in the same precision. */
 int fr_worker_gather_slices(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, void *d_slice, int transport);
 int fr_worker_fc_from_slices_lp(fr_worker *w, int batch_total, int item0, int n_items, const void *d_gathered, int transport, float *d_scores);
+
+/* ---- the exchange step on RCCL: the sharded hot-loop body behind the ABI ------------------------------------------------------
+ * The 3-node reference server receives every batch in three parts from three senders before its GEMMs (3-node cuda_server.c:513-591).
+ * Here the parts are the table-ID shards held by G GPUs of one node; librccl.so is loaded on first use of these entry points.
+ * One process per GPU: rank 0 calls fr_comm_unique_id, the host ships the 128 bytes to the other ranks (socket, file, launcher),
+ * every rank calls fr_comm_init_rank with its sharded context (rank = shard_rank, size = n_shards; collective).
+ * One process driving G GPUs: fr_comm_init_all(ctxs, G, comms) with ctxs[r] = shard r on its own device (ncclCommInitAll); the
+ * collective calls below must then come from G different threads. */
+typedef struct fr_comm fr_comm;
+int fr_comm_unique_id(void *id128);
+int fr_comm_init_rank(fr_ctx *ctx, const void *id128, fr_comm **out);
+int fr_comm_init_all(fr_ctx *const *ctxs, int n, fr_comm **out /* n handles */);
+void fr_comm_destroy(fr_comm *c);
+/* COLLECTIVE, asynchronous on the worker's stream: every rank holds the whole request batch in its worker's pinned idx / dense
+ * buffers (as for fr_worker_submit).  Per rank: H2D -> gather of this shard's slice (in the chain's operand type: fp32, bf16 or e4m3)
+ * -> ncclAllGather of the [batch x F] slices over xGMI -> FC chain on this rank's batch / G items -> ncclAllGather of the score
+ * chunks -> D2H.  After fr_worker_sync() EVERY rank's fr_worker_score_ptr() holds all `batch` scores.  RCCL failures: FR_ERR_COMM. */
+int fr_worker_submit_sharded(fr_worker *w, fr_comm *comm, int batch);
+/* COLLECTIVE, synchronous: fp8 activation exponents of a sharded context from this batch -- every rank calibrates on the same
+ * all-gathered fp32 slices, so all ranks end with identical exponents (a slice encoded by one rank is decoded by the others). */
+int fr_worker_calibrate_fp8_sharded(fr_worker *w, fr_comm *comm, int batch);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

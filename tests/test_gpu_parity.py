@@ -852,6 +852,46 @@ def test_table_sharded_full_size_g8(fr, O, gpu):
         c.close()
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16", "fp8"])
+def test_submit_sharded_through_rccl_one_rank(fr, O, gpu, prec):
+    """The sharded hot-loop body behind the C-ABI (fr_comm_* + fr_worker_submit_sharded) on the one GPU a test box has: a one-rank RCCL
+    communicator (ncclCommInitRank through the unique-id path), so the all-gathers are degenerate but every call -- dlopen of
+    librccl, communicator set-up, two ncclAllGather on the worker's stream, the slice transport formats -- really runs.  Scores must
+    equal the unsharded submit of the same context geometry bit for bit (one shard = the whole record), the oracle within tolerance."""
+    m = fr.Model.builtin(fr.MODEL_C).clone(max_rows=30000)
+    om = O.OracleModel("C")
+    P = {"f32": fr.FC_FP32, "bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[prec]
+    ctx = fr.Context(m, device=gpu, shard_rank=0, n_shards=1)
+    ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    ctx.set_fc_precision(P)
+    comm = fr.Comm.init_rank(ctx, fr.Comm.unique_id())
+    rng = np.random.default_rng(31)
+    B = 300
+    idx = uniform_idx(rng, m.rows(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+    wk = fr.Worker(ctx, 512)
+    if prec == "fp8":
+        wk.calibrate_fp8_sharded(comm, idx, dense)
+    got = wk.infer_sharded(comm, idx, dense)
+    plain = wk.infer(idx, dense)                      # same context, unsharded path
+    assert np.array_equal(got, plain) if prec != "f32" else rel_err(got, plain) <= 1e-5
+    rec = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES).view(np.float32)
+    ref = om.fc_chain(rec, [ctx.get_weights(l) for l in range(4)], acc64=True)
+    assert rel_err(got, ref) <= {"f32": 1e-3, "bf16": 3e-2, "fp8": 0.15}[prec]
+    assert np.array_equal(wk.infer_sharded(comm, idx[:77], dense[:77]), got[:77]) if prec != "f32" else True   # ragged batch, reuse
+    # a communicator belongs to its context
+    other = fr.Context(m, device=gpu)
+    w2 = fr.Worker(other, 64)
+    with pytest.raises(fr.FleetRecError):
+        w2.infer_sharded(comm, idx[:8], dense[:8])
+    w2.close()
+    other.close()
+    wk.close()
+    comm.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("rank", [1, 6])
 def test_config5_inflated_shard_gather(fr, O, gpu, rank):
     """BASELINE configs[4] on one GPU: one of the 8 table-ID shards of Model-C inflated 5x (316 GB in total, 30-60 GB per shard).

@@ -14,7 +14,9 @@ HOST = os.path.join(ROOT, "gpu-fpga-recommendation-system_amd", "host")
 
 
 @pytest.mark.parametrize("model,val,extra", [("A", 352.0 * 2 ** 27, []), ("C", 3968.0 * 2 ** 28, ["--row-cap", "200"]),
-                                             ("A", 352.0 * 2 ** 27, ["--stream"])])
+                                             ("A", 352.0 * 2 ** 27, ["--stream"]),
+                                             ("B", 880.0 * 2 ** 27, ["--per-bank", "--row-cap", "200"]),          # the kernel's own index contract on the wire
+                                             ("C", 3968.0 * 2 ** 28, ["--row-cap", "200", "--shards", "1"])])     # sharded engine + RCCL (one-rank communicator)
 def test_server_and_sender_known_answer(fr, gpu, model, val, extra):
     """Reference data end to end: even/odd tables, the 32 fixed indices, all-ones weights -> the first five scores of the
     last batch are 0 0 K*H1*H2*H3 K*H1*H2*H3 0 (indices 3, 99, 38, 72, 29), as the reference prints them (cuda_server.c:499-502)."""
@@ -27,7 +29,7 @@ def test_server_and_sender_known_answer(fr, gpu, model, val, extra):
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     time.sleep(0.5)
     snd = subprocess.Popen([os.path.join(HOST, "fleetrec_sender"), "--model", model, "--batch", "128", "--threads", str(threads),
-                            "--port", str(port), "--indices", "reference"] + [e_ for e_ in extra if e_ != "--stream"],
+                            "--port", str(port), "--indices", "reference"] + [e_ for e_ in extra if e_ not in ("--stream", "--shards", "1")],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     try:
         out, _ = srv.communicate(timeout=300)
@@ -45,8 +47,10 @@ def test_server_and_sender_known_answer(fr, gpu, model, val, extra):
     for r in rows:
         v = [float(x) for x in r.split()]
         assert v == [0.0, 0.0, val, val, 0.0], (v, out)
-    if "--stream" not in extra:
+    if "--stream" not in extra and "--shards" not in extra:
         assert "Average time from batch received to enqueued" in out
+    if "--shards" in extra:
+        assert "table-sharded over 1 GPUs" in out
     assert "blocks sent" in sout.decode()
 
 

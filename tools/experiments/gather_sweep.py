@@ -15,11 +15,9 @@ for mode, name in ((fr.INDEX_PER_BANK, "per_bank"), (fr.INDEX_PER_TABLE, "per_ta
     m = mc.clone(index_mode=mode)
     ctx = fr.Context(m, device=0)
     ctx.fill_tables(fr.FILL_HASH, bench.SEED_TABLES)
-    for xcd in ("1", "0"):
-        for items in ("2", "4", "8", "16"):
-            if xcd == "0" and items != "8":
-                continue
-            os.environ["FR_GATHER_XCD"], os.environ["FR_GATHER_ITEMS"] = xcd, items
-            r = bench.leg_gather(fr, ctx, m, 4096, "uniform", reps=200, nbuf=32)
-            print("%s xcd=%s items=%s: %.2f us  %.0f GB/s  frac %.3f" % (name, xcd, items, 1e3 * r["avg_launch_ms"], r["achieved"], r["frac"]), flush=True)
+    for xcd, items, loop in (("1", "4", "1"), ("1", "4", "2"), ("1", "4", "4"), ("1", "2", "2"), ("1", "2", "4"), ("1", "2", "8"), ("1", "8", "2"), ("1", "1", "4"), ("1", "1", "8"),
+                             ("0", "8", "1"), ("1", "4", "1")):
+        os.environ["FR_GATHER_XCD"], os.environ["FR_GATHER_ITEMS"], os.environ["FR_GATHER_LOOP"] = xcd, items, loop
+        r = bench.leg_gather(fr, ctx, m, 4096, "uniform", reps=200, nbuf=32)
+        print("%s xcd=%s items=%s loop=%s: %.2f us  %.0f GB/s  frac %.3f" % (name, xcd, items, loop, 1e3 * r["avg_launch_ms"], r["achieved"], r["frac"]), flush=True)
     ctx.close()
