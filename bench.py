@@ -211,10 +211,19 @@ def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=
     imgs = h.bank_images_native(O.FILL_HASH, SEED_TABLES)
     t_fill = time.perf_counter() - t0
     group = 64
-    idx = np.concatenate(idx_host[:group], axis=0)                      # [16384][47] in wire order
-    hidx = np.empty_like(idx)
-    hidx[:, h.wire_to_round] = idx                                       # wire order -> (bank, round) order
+    idx = np.concatenate(idx_host[:group], axis=0)                      # [16384][47] in wire order: the GPU run's own 64 index buffers
     n = idx.shape[0]
+    # ... plus 7 more groups of the same index law, rotated through: 8 x 770 k distinct rows = ~400 MB of cache lines, so that the
+    # gather reads MEMORY instead of re-hitting one group's rows in the host's last-level cache
+    rng_c = np.random.default_rng(SEED_IDX + 77)
+    n_groups = 8
+    hidx_groups = []
+    for gi in range(n_groups):
+        src = idx if gi == 0 else uniform_idx(rng_c, model.rows(), n)
+        hi_ = np.empty_like(src)
+        hi_[:, h.wire_to_round] = src                                    # wire order -> (bank, round) order
+        hidx_groups.append(hi_)
+    hidx = hidx_groups[0]
     ws = [ctx.get_weights(l) for l in range(4)]
     fc = model.fc
     rec = np.empty((n, h.record_len), dtype=np.uint32)
@@ -233,19 +242,21 @@ def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=
     O.lib().oracle_set_num_threads(threads)
 
     def timed(fn):
-        fn()
+        fn(0)
         reps, t_begin = 0, time.perf_counter()
         while True:
-            fn()
+            fn(reps)
             reps += 1
             el = time.perf_counter() - t_begin
             if el >= budget_s and reps >= 2:
                 return n * reps / el, reps
 
-    g_rate, g_reps = timed(lambda: h.gather_direct(hidx, True, imgs, out=rec))
+    g_rate, g_reps = timed(lambda i: h.gather_direct(hidx_groups[i % n_groups], True, imgs, out=rec))
     X = rec.view(np.float32)
-    f_rate, f_reps = timed(lambda: cpu_fc_chain(blas, X, ws, fc, bufs))
-    e_rate, e_reps = timed(lambda: (h.gather_direct(hidx, True, imgs, out=rec), cpu_fc_chain(blas, X, ws, fc, bufs)))
+    f_rate, f_reps = timed(lambda i: cpu_fc_chain(blas, X, ws, fc, bufs))
+    e_rate, e_reps = timed(lambda i: (h.gather_direct(hidx_groups[i % n_groups], True, imgs, out=rec), cpu_fc_chain(blas, X, ws, fc, bufs)))
+    h.gather_direct(hidx_groups[0], True, imgs, out=rec)               # group 0 = the GPU's index buffers: cross-check the first batch
+    cpu_fc_chain(blas, X, ws, fc, bufs)
     cpu_scores = bufs[3].ravel()[:B].copy()
     err = float(np.abs(cpu_scores - gpu_scores_first).max() / max(np.abs(cpu_scores).max(), 1e-30)) if gpu_scores_first is not None else None
     gbytes = 1408 + 188 + 1408
@@ -256,7 +267,8 @@ def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=
             "blas_symbol": blas["symbol"] if blas else "torch.mm", "blas_threads": blas["threads"] if blas else None,
             "gather_thread_probe_s": {str(k): v for k, v in probe.items()}, "host_cpus_usable": usable,
             "gpu_vs_cpu_max_rel_err_first_batch": err, "host_table_bytes": int(sum(im.nbytes for im in imgs)), "host_table_fill_s": t_fill,
-            "sample": "Model-A, %d items per call (64 batches of 256, the grouping one fused GPU launch gets), same seeded indices / tables / weights; "
+            "sample": "Model-A, %d items per call (64 batches of 256, the grouping one fused GPU launch gets), same seeded tables / weights / index law, 8 index "
+                      "groups rotated (the first = the GPU run's buffers); "
                       "gather-only %d calls, FC-only %d, end-to-end %d (>= %.1f s each); gather = OpenMP over items reading bank images in host RAM "
                       "(oracle_gather_banks_direct), FC = 4 chained column-major sgemm calls" % (n, g_reps, f_reps, e_reps, budget_s)}
 
@@ -306,14 +318,18 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
         cal.close()
     fc = model.fc
     flops_inf = fc_flops_per_inference(fc)
-    dv = fr.Driver(ctx, threads, depth, B)
-    dv.run_resident(B, 256, d_idx, d_dense)
-    n = steady_run(lambda k: dv.run_resident(B, k, d_idx, d_dense), min_s, n_first=512 if min_s >= 1.0 else 64, quantum=64)
-    el = dv.run_resident(B, n, d_idx, d_dense)
-    dv.close()
-    res = {"workload": label, "dtype": precision, "value": n * B / el, "unit": "inferences/s", "timed_batches": n, "timed_s": el,
-           "ms_per_step": 1e3 * el / n, "fc_tflops_end_to_end": flops_inf * B * n / el / 1e12,
-           "frac_of_mfma_peak_end_to_end": flops_inf * B * n / el / 1e12 / MFMA_PEAK_TF[precision]}
+    if min_s > 0:
+        dv = fr.Driver(ctx, threads, depth, B)
+        dv.run_resident(B, 256, d_idx, d_dense)
+        n = steady_run(lambda k: dv.run_resident(B, k, d_idx, d_dense), min_s, n_first=512 if min_s >= 1.0 else 64, quantum=64)
+        el = dv.run_resident(B, n, d_idx, d_dense)
+        dv.close()
+        res = {"workload": label, "dtype": precision, "value": n * B / el, "unit": "inferences/s", "timed_batches": n, "timed_s": el,
+               "ms_per_step": 1e3 * el / n, "fc_tflops_end_to_end": flops_inf * B * n / el / 1e12,
+               "frac_of_mfma_peak_end_to_end": flops_inf * B * n / el / 1e12 / MFMA_PEAK_TF[precision]}
+    else:   # --roofline-only: no multi-stream loop
+        res = {"workload": label, "dtype": precision, "value": None, "unit": "inferences/s", "timed_batches": 0, "timed_s": 0.0, "ms_per_step": None,
+               "fc_tflops_end_to_end": None, "frac_of_mfma_peak_end_to_end": None}
     wk = fr.Worker(ctx, B)
     group = ctx.stream_group()
     if group > 1:   # fused item-tile kernel: one launch = the whole hot path of min(group, 16384 / B) queued batches
@@ -609,6 +625,10 @@ def main():
     ap.add_argument("--rows-cap", type=int, default=0, help="plumbing tests: cap every table's row count (sharded mode)")
     ap.add_argument("--no-unsharded-check", action="store_true", help="sharded mode: skip rank 0's comparison against an unsharded context")
     ap.add_argument("--no-gather-ab", action="store_true", help="gather legs: skip the kernel A/B (PMC passes: one kernel per leg)")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="rocprofv3 --kernel-trace --stats runs: nothing but the single-stream roofline launches touches the kernels being priced (the "
+                         "multi-stream throughput loops, whose concurrent launches stretch each other, are skipped), so the profiler's average agrees with "
+                         "the HIP-event figure on the bench line")
     ap.add_argument("--quick", action="store_true", help="profiling runs: 0.3 s instead of >= 2 s behind `value` (the legs are what is being profiled)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch / rendezvous / timing-rule check without touching a GPU or the library (CPU test of the multi-GPU launcher)")
@@ -659,7 +679,8 @@ def main():
     if args.model != "A" or args.precision != "f32":
         # one non-headline configuration on its own: throughput + its roofline leg
         res = leg_config(fr, ctx, model, B, args.precision, d_idx, d_dense, idx_host[0], dense_host[0] if dense_host else None, args.threads, args.depth,
-                         "Model-%s batch=%d %s FC chain, index rows resident in HBM" % (args.model, B, args.precision), min_s=0.05 if args.quick else 1.0)
+                         "Model-%s batch=%d %s FC chain, index rows resident in HBM" % (args.model, B, args.precision),
+                         min_s=0.0 if args.roofline_only else (0.05 if args.quick else 1.0))
         if rank == 0:
             print(json.dumps({"metric": "inferences/sec", "value": res["value"], "unit": "inferences/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -671,6 +692,12 @@ def main():
         return
 
     # ---- headline: Model-A batch 256 fp32, index rows resident in HBM, native driver loop ---------------------------------------
+    if args.roofline_only:   # one stream only, a token number of batches: see --roofline-only
+        args.threads, args.depth, args.steps, args.warmup, args.quick = 1, 1, 64, 64, True
+        if args.legs == "all":
+            args.legs = "roofline"
+            legs.clear()
+            legs.add("roofline")
     driver = fr.Driver(ctx, args.threads, args.depth, B)
     driver.run_resident(B, max(args.warmup, 0), d_idx)
     barrier()
@@ -678,7 +705,8 @@ def main():
     driver.run_resident(B, max(args.steps, 1), d_idx)            # exactly --steps batches: the burst figure
     barrier()
     burst_dt = env.max_over_ranks(time.perf_counter() - t0)
-    n_timed = max(steady_run(lambda k: driver.run_resident(B, k, d_idx), 0.3 if args.quick else STEADY_S, n_first=8192, env=env), args.steps)
+    n_timed = args.steps if args.roofline_only else max(steady_run(lambda k: driver.run_resident(B, k, d_idx), 0.3 if args.quick else STEADY_S, n_first=8192, env=env),
+                                                        args.steps)
     barrier()
     t0 = time.perf_counter()
     driver.run_resident(B, n_timed, d_idx)                       # >= 2 s of back-to-back batches: `value`
