@@ -625,6 +625,7 @@ def main():
     ap.add_argument("--rows-cap", type=int, default=0, help="plumbing tests: cap every table's row count (sharded mode)")
     ap.add_argument("--no-unsharded-check", action="store_true", help="sharded mode: skip rank 0's comparison against an unsharded context")
     ap.add_argument("--no-gather-ab", action="store_true", help="gather legs: skip the kernel A/B (PMC passes: one kernel per leg)")
+    ap.add_argument("--group", type=int, default=0, help="batches per fused launch (fr_ctx_set_stream_group); 0 = the context's default")
     ap.add_argument("--roofline-only", action="store_true",
                     help="rocprofv3 --kernel-trace --stats runs: nothing but the single-stream roofline launches touches the kernels being priced (the "
                          "multi-stream throughput loops, whose concurrent launches stretch each other, are skipped), so the profiler's average agrees with "
@@ -676,6 +677,8 @@ def main():
         env.barrier()
         ctx.synchronize()
 
+    if args.group > 0:
+        ctx.set_stream_group(args.group)
     if args.model != "A" or args.precision != "f32":
         # one non-headline configuration on its own: throughput + its roofline leg
         res = leg_config(fr, ctx, model, B, args.precision, d_idx, d_dense, idx_host[0], dense_host[0] if dense_host else None, args.threads, args.depth,

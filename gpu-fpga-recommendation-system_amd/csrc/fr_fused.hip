@@ -660,6 +660,12 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
     const FrFusedBatch &bt = a.b[bi];
     const int m0 = tile * TI;
     if (m0 >= bt.batch) return;
+    int n_st = 0;
+    auto stamp = [&]() {  // diagnostic build aid (tools/experiments/fused_h_stamps.py); wave 0 lane 0 only, values never feed an output
+        if (a.stamps && tid == 0 && n_st < 14) a.stamps[16ull * blockIdx.x + n_st] = __builtin_amdgcn_s_memrealtime();
+        n_st++;
+    };
+    stamp();
 
     {   // ---- gather + bf16 conversion: lanes along record words, TI / 8 items per thread ----
         const int wl = tid & 63, ig = tid >> 6;
@@ -703,6 +709,7 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
         if (bad) atomicOr_system(a.err_flag, 1);
     }
     __syncthreads();
+    stamp();
 
     f32x16 acc2[T2W][MT];
 #pragma unroll
@@ -721,6 +728,7 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
 #pragma unroll
             for (int i = 0; i < 16; i++) acc1[0][mt][i] = 0.0f;
         fth_gemm_ct<1, MT, 16, KG>(acc1, W1, c * 256 + 32 * wave, Xh, LD, 0, 0, hk, lm);
+        stamp();
         uint4 *R1 = R1b[DB ? (c & 1) : 0];
         if (!DB && c > 0) __syncthreads();  // single R1 buffer: every wave must be done reading the previous chunk
 #pragma unroll
@@ -728,6 +736,7 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
         __syncthreads();
         // FC2: K range [256 c, 256 c + 256) = 16 groups of 16 k
         fth_gemm_ct<T2W, MT, 16 / T2W, 16>(acc2, W2, 32 * T2W * wave, R1, LD, 0, 16 * c, hk, lm);
+        stamp();
     }
     __syncthreads();  // Xh and R1 dead: R2 may overlay them
 #pragma unroll
@@ -745,6 +754,7 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) fth_store_tile(R3, LD, acc3[0][mt], 32 * wave, 32 * mt, hk, lm);
     __syncthreads();
+    stamp();
     {   // score[m] = sum_n wout[n] * R3[n][m] (bf16 x bf16, fp32 sum): TI items x (512 / TI) slices of q8 rows, fixed-order reduction
         const int il = tid % TI, sl = tid / TI;
         constexpr int NSL = 512 / TI;
