@@ -823,8 +823,18 @@ def main():
             di = [fr.DeviceBuffer.from_numpy(cb, a) for a in ih]
             for prec in ("bf16", "f32"):
                 cfgs.append(leg_config(fr, cb, mb, 1024, prec, di, None, ih[0], None, args.threads, args.depth,
-                                       "BASELINE configs[2]: Model-B (embedding_98_krnl, 15.1 GB) batch=1024, %s FC, fused concat + FC chain" % prec
-                                       if prec == "bf16" else "Model-B batch=1024, f32 FC (the reference's own precision)"))
+                                       "BASELINE configs[2]: Model-B (embedding_98_krnl, 15.1 GB) batch=1024, %s FC, fused concat + FC chain, per-table indices" % prec
+                                       if prec == "bf16" else "Model-B batch=1024, f32 FC (the reference's own precision), per-table indices"))
+            cb.close()
+            # the same configuration under the reference kernel's index contract: one index per bank (49 banks of 2 tables), bank rows in HBM
+            mbb = mb.clone(index_mode=fr.INDEX_PER_BANK)
+            cb = fr.Context(mbb, device=local_rank)
+            cb.fill_tables(fr.FILL_HASH, SEED_TABLES)
+            cb.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+            ihb = [uniform_idx(rngb, mbb.index_ranges(), 1024) for _ in range(32)]
+            dib = [fr.DeviceBuffer.from_numpy(cb, a) for a in ihb]
+            cfgs.append(leg_config(fr, cb, mbb, 1024, "bf16", dib, None, ihb[0], None, args.threads, args.depth,
+                                   "BASELINE configs[2] under the kernel's index contract: Model-B batch=1024, bf16 FC, ONE index per bank (FR_INDEX_PER_BANK, 49 banks)"))
             cb.close()
         except Exception as ex:
             cfgs.append({"workload": "Model-B", "error": repr(ex)})
@@ -880,6 +890,16 @@ def main():
                 gb["traffic"] = pm.get("traffic_bytes_per_launch")
                 gb["l2_hit_rate"] = pm.get("l2_hit_rate")
                 result["gather_per_bank"] = gb
+                if want("configs"):   # Model-C end to end under the bank contract (82 bank fetches per item instead of 376 rows)
+                    cbk.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+                    rngk = np.random.default_rng(SEED_IDX)
+                    ihk = [uniform_idx(rngk, mcb.index_ranges(), BC) for _ in range(8)]
+                    dhk = [rngk.uniform(-1, 1, (BC, mcb.dense_len)).astype(np.float32) for _ in range(8)]
+                    dik = [fr.DeviceBuffer.from_numpy(cbk, a) for a in ihk]
+                    ddk = [fr.DeviceBuffer.from_numpy(cbk, a) for a in dhk]
+                    for prec in ("bf16", "fp8"):
+                        result["configs"].append(leg_config(fr, cbk, mcb, BC, prec, dik, ddk, ihk[0], dhk[0], args.threads, args.depth,
+                                                            "Model-C batch=4096, %s FC chain end to end, ONE index per bank (FR_INDEX_PER_BANK, 82 banks)" % prec))
                 cbk.close()
         except Exception as ex:  # the main metric must still be reported
             result.setdefault("gather", {})["error"] = repr(ex)
