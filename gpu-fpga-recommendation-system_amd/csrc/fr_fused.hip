@@ -721,21 +721,75 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
     const int n_chunks = a.H1 / 256;
     // q8 weights: (K / 8) rows of N 16-byte elements -> ft_w's K / 4 rows of the q4 layout is K / 2 here
     const FtW W1 = ft_w(a.w1q, a.K / 2, a.H1, hk, lm), W2 = ft_w(a.w2q, a.H1 / 2, a.H2, hk, lm), W3 = ft_w(a.w3q, a.H2 / 2, a.H3, hk, lm);
+    // ONE weight ring of 16 registers (16-byte fragments) feeds FC1, FC2 and FC3 as a continuous stream: a slot freed by the last 16
+    // groups of FC1 is refilled with the first elements of this chunk's FC2 weights, a slot freed by the last 8 groups of FC2 with the
+    // first groups of the next chunk's FC1 weights (or of W3 after the last chunk).  With a ring of its own every GEMM phase used to start
+    // cold -- all 8 waves waiting for an L2 round trip at once: FC2's 16 groups took 5.4 us for 1.95 us of MFMA work, FC3 6.0 us
+    // (tools/experiments/fused_h_stamps.py).  FC1 group g lives in slot g % 16, W3 group g likewise, FC2 element e = 2 j + t (group j,
+    // n tile t) in slot (e + OFF2) % 16 with OFF2 = KG % 16 -- the slot FC1's tail frees first.  Every index is a compile-time
+    // constant (the bodies are unrolled), so the ring stays in registers and hipcc counts the vmcnt waits.  The order of the sums is
+    // unchanged: scores are bit-identical to the per-phase rings.
+    static_assert(T2W == 2 && KG >= 16, "the stream ring assumes two n tiles per wave in FC2 and at least 16 k groups in FC1");
+    constexpr int OFF2 = KG % 16;
+    uint4 ring[16];
+    auto w1load = [&](int c, int g) { return __builtin_bit_cast(uint4, ft_wload(W1, (unsigned)g * W1.row2 + (unsigned)(c * 256 + 32 * wave) * 16u, 0)); };
+    auto w2load = [&](int c, int e) {
+        return __builtin_bit_cast(uint4, ft_wload(W2, (unsigned)(16 * c + (e >> 1)) * W2.row2 + (unsigned)(32 * T2W * wave) * 16u, 512 * (e & 1)));
+    };
+#pragma unroll
+    for (int g = 0; g < 16; g++) ring[g] = w1load(0, g);
+    const uint4 *blx = Xh + (size_t)hk * LD + lm;
     for (int c = 0; c < n_chunks; c++) {
         f32x16 acc1[1][MT];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc1[0][mt][i] = 0.0f;
-        fth_gemm_ct<1, MT, 16, KG>(acc1, W1, c * 256 + 32 * wave, Xh, LD, 0, 0, hk, lm);
+#pragma unroll
+        for (int g = 0; g < KG; g++) {  // FC1, chunk c: K / 16 groups
+            uint4 b8[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) b8[mt] = blx[(size_t)(2 * g) * LD + 32 * mt];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+                acc1[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[g % 16]), __builtin_bit_cast(bf16x8, b8[mt]), acc1[0][mt], 0, 0, 0);
+            if (g + 16 < KG) ring[g % 16] = w1load(c, g + 16);
+            else ring[g % 16] = w2load(c, (g % 16 - OFF2 + 16) % 16);  // FC1's tail: the first 16 elements (8 groups) of this chunk's FC2 weights
+            __builtin_amdgcn_sched_barrier(0);
+        }
         stamp();
         uint4 *R1 = R1b[DB ? (c & 1) : 0];
         if (!DB && c > 0) __syncthreads();  // single R1 buffer: every wave must be done reading the previous chunk
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) fth_store_tile(R1, LD, acc1[0][mt], 32 * wave, 32 * mt, hk, lm);
         __syncthreads();
-        // FC2: K range [256 c, 256 c + 256) = 16 groups of 16 k
-        fth_gemm_ct<T2W, MT, 16 / T2W, 16>(acc2, W2, 32 * T2W * wave, R1, LD, 0, 16 * c, hk, lm);
+        // FC2: K range [256 c, 256 c + 256) = 16 groups of 16 k; its tail requests the next stream: W1 chunk c + 1, or W3 after the last chunk
+        const bool last = c + 1 == n_chunks;
+        FtW WN = W1;
+        if (last) WN = W3;
+        const unsigned nsoff = last ? (unsigned)(32 * wave) * 16u : (unsigned)((c + 1) * 256 + 32 * wave) * 16u;
+        const uint4 *blr = R1 + (size_t)hk * LD + lm;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            uint4 b8[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) b8[mt] = blr[(size_t)(2 * j) * LD + 32 * mt];
+#pragma unroll
+            for (int t = 0; t < T2W; t++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                    acc2[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[(2 * j + t + OFF2) % 16]), __builtin_bit_cast(bf16x8, b8[mt]),
+                                                                         acc2[t][mt], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < T2W; t++) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int r = (2 * j + t + OFF2) % 16;
+                if (j + 8 < 16) ring[r] = w2load(c, 2 * j + t + 16);
+                else ring[r] = __builtin_bit_cast(uint4, ft_wload(WN, (unsigned)r * WN.row2 + nsoff, 0));  // group r of the next stream lives in slot r
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         stamp();
     }
     __syncthreads();  // Xh and R1 dead: R2 may overlay them
@@ -750,7 +804,20 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc3[0][mt][i] = 0.0f;
-    fth_gemm_ct<1, MT, 16, 16 * T2W>(acc3, W3, 32 * wave, R2, LD, 0, 0, hk, lm);  // H2 / 16 groups
+    {   // FC3: H2 / 16 = 32 groups; groups 0..15 are already in (or on their way into) the ring
+        const uint4 *bl3 = R2 + (size_t)hk * LD + lm;
+#pragma unroll
+        for (int g = 0; g < 16 * T2W; g++) {
+            uint4 b8[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) b8[mt] = bl3[(size_t)(2 * g) * LD + 32 * mt];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+                acc3[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[g % 16]), __builtin_bit_cast(bf16x8, b8[mt]), acc3[0][mt], 0, 0, 0);
+            if (g + 16 < 16 * T2W) ring[g % 16] = __builtin_bit_cast(uint4, ft_wload(W3, (unsigned)(g + 16) * W3.row2 + (unsigned)(32 * wave) * 16u, 0));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) fth_store_tile(R3, LD, acc3[0][mt], 32 * wave, 32 * mt, hk, lm);
     __syncthreads();
