@@ -443,8 +443,11 @@ def main_sharded(args, graft):
     B = 4096 if args.batch == 256 else args.batch
     steps, warmup = max(args.steps, 1), args.warmup
     model = fr.Model.builtin(fr.MODEL_C)
-    if args.rows_cap:
-        model = model.clone(max_rows=args.rows_cap)
+    if args.rows_cap or args.row_scale != 1.0:
+        # --row-scale 5: BASELINE configs[4] -- every table 5 x its rows: 316 GB in total, more than one GPU's 288 GB, 30-141 GB per 8-way shard
+        model = model.clone(row_scale=args.row_scale, max_rows=args.rows_cap)
+    if args.row_scale > 1.0:
+        args.no_unsharded_check = True   # the whole model no longer fits one GPU: that is the point of the configuration
     ctx = fr.Context(model, device=dev_id, shard_rank=r, n_shards=G)
     ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
     ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
@@ -586,8 +589,11 @@ def main_sharded(args, graft):
             "metric": "inferences/sec, Model-C batch 4096, tables sharded by table-ID", "value": B * steps / dt, "unit": "inferences/s",
             "n_gpus": G, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "Model-C batch=%d, %d-way table-ID shards (slice F=%d floats), 1 %s of [B x F] per step, "
-                                   "FC on B/G items per rank" % (B, G, F, "all-to-all" if a2a else "all-gather"), "parallelism": "table-sharded x%d" % G,
+            "config": {"workload": "Model-C%s batch=%d, %d-way table-ID shards (slice F=%d floats), 1 %s of [B x F] per step, "
+                                   "FC on B/G items per rank" % (" (rows x %g: %.0f GB of tables)" % (args.row_scale, model.table_bytes() / 1e9) if args.row_scale != 1.0 else "",
+                                                                 B, G, F, "all-to-all" if a2a else "all-gather"), "parallelism": "table-sharded x%d" % G,
+                       "shard_table_bytes_this_rank": int(sum(t.rows * t.dim * 4 for si in model.segments() if si.kind == fr.SEG_TABLE and offs[r] <= si.rec_offset < offs[r] + lens[r]
+                                                            for t in [model.tables()[si.src]])),
                        "exchange": args.exchange, "backend": args.backend if world > 1 else None,
                        "slice_transport": args.precision if lp else "f32", "pipelined_equals_stepwise": verified,
                        "sharded_vs_unsharded_context": vs_unsharded,
@@ -623,6 +629,8 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true", help="plumbing test: ranks share the visible GPU(s) (use with --backend gloo)")
     ap.add_argument("--rows-cap", type=int, default=0, help="plumbing tests: cap every table's row count (sharded mode)")
+    ap.add_argument("--row-scale", type=float, default=1.0,
+                    help="sharded mode: multiply every table's row count (BASELINE configs[4]: 5 inflates Model-C to 316 GB, past one GPU's 288 GB)")
     ap.add_argument("--no-unsharded-check", action="store_true", help="sharded mode: skip rank 0's comparison against an unsharded context")
     ap.add_argument("--no-gather-ab", action="store_true", help="gather legs: skip the kernel A/B (PMC passes: one kernel per leg)")
     ap.add_argument("--group", type=int, default=0, help="batches per fused launch (fr_ctx_set_stream_group); 0 = the context's default")
@@ -794,6 +802,7 @@ def main():
         n = steady_run(lambda k: hs.run_host(B, k, idx_host, streaming=True), STEADY_S, n_first=8192)
         el = hs.run_host(B, n, idx_host, streaming=True)
         hs.close()
+        result["value_pcie_inclusive"] = n * B / el   # the same metric with the reference loop's H2D / D2H inside (never `value`: bench contract)
         result["pcie_inclusive_streaming"] = {"value": n * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / n, "timed_batches": n, "timed_s": el,
                                               "what": "host-resident request stream, scores delivered to host memory: blocks of 64 batches staged in pinned "
                                                       "memory, one H2D + one fused launch + one D2H per block (fr_worker_push_host), %d threads x %d workers"
