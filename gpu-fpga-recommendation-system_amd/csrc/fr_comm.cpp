@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: the functions are resolved through dlsym
 
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -27,6 +28,7 @@ struct Rccl {
 Rccl g_rccl;
 std::once_flag g_rccl_once;
 bool g_rccl_ok = false;
+char g_rccl_why[256] = "symbol missing";
 
 int rccl_load() {
     std::call_once(g_rccl_once, [] {
@@ -34,8 +36,11 @@ int rccl_load() {
         for (const char *n : names) {
             g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (g_rccl.handle) break;
+            const char *e = dlerror();  // dlerror() clears itself: read it once
+            if (e) snprintf(g_rccl_why, sizeof(g_rccl_why), "%s", e);
         }
         if (!g_rccl.handle) return;
+        snprintf(g_rccl_why, sizeof(g_rccl_why), "symbol missing");
 #define FR_SYM(field, name)                                              \
     g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.handle, name)); \
     if (!g_rccl.field) return;
@@ -48,7 +53,7 @@ int rccl_load() {
 #undef FR_SYM
         g_rccl_ok = true;
     });
-    if (!g_rccl_ok) FR_FAIL(FR_ERR_COMM, "librccl.so could not be loaded (dlopen / dlsym): %s", dlerror() ? dlerror() : "symbol missing");
+    if (!g_rccl_ok) FR_FAIL(FR_ERR_COMM, "librccl.so could not be loaded (dlopen / dlsym): %s", g_rccl_why);
     return FR_OK;
 }
 }  // namespace
@@ -125,7 +130,14 @@ extern "C" int fr_comm_init_all(fr_ctx *const *ctxs, int n, fr_comm **out) {
     FR_NCCL(g_rccl.CommInitAll(comms, n, devs));
     for (int r = 0; r < n; r++) {
         fr_comm *c = new (std::nothrow) fr_comm();
-        if (!c) FR_FAIL(FR_ERR_OOM, "out of host memory");
+        if (!c) {
+            for (int q = 0; q < r; q++) {
+                fr_comm_destroy(out[q]);
+                out[q] = nullptr;
+            }
+            for (int q = r; q < n; q++) (void)g_rccl.CommDestroy(comms[q]);
+            FR_FAIL(FR_ERR_OOM, "out of host memory");
+        }
         c->comm = comms[r];
         c->rank = r;
         c->n_ranks = n;
