@@ -644,7 +644,7 @@ __device__ __forceinline__ void fth_store_tile(uint4 *img, int ld, const f32x16 
     }
 }
 
-template <int MT, int T2W, int KG, bool DB>
+template <int MT, int T2W, int KG, bool DB, int RD>
 __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs a) {
     extern __shared__ uint4 lds[];
     constexpr int LD = 32 * MT + 1, TI = 32 * MT;
@@ -729,15 +729,15 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
     // n tile t) in slot (e + OFF2) % 16 with OFF2 = KG % 16 -- the slot FC1's tail frees first.  Every index is a compile-time
     // constant (the bodies are unrolled), so the ring stays in registers and hipcc counts the vmcnt waits.  The order of the sums is
     // unchanged: scores are bit-identical to the per-phase rings.
-    static_assert(T2W == 2 && KG >= 16, "the stream ring assumes two n tiles per wave in FC2 and at least 16 k groups in FC1");
-    constexpr int OFF2 = KG % 16;
-    uint4 ring[16];
+    static_assert(T2W == 2 && KG >= RD && RD >= 8 && RD <= 32 && RD % 2 == 0, "the stream ring assumes two n tiles per wave in FC2 (32 elements per chunk) and at least RD k groups in FC1");
+    constexpr int OFF2 = KG % RD;
+    uint4 ring[RD];
     auto w1load = [&](int c, int g) { return __builtin_bit_cast(uint4, ft_wload(W1, (unsigned)g * W1.row2 + (unsigned)(c * 256 + 32 * wave) * 16u, 0)); };
     auto w2load = [&](int c, int e) {
         return __builtin_bit_cast(uint4, ft_wload(W2, (unsigned)(16 * c + (e >> 1)) * W2.row2 + (unsigned)(32 * T2W * wave) * 16u, 512 * (e & 1)));
     };
 #pragma unroll
-    for (int g = 0; g < 16; g++) ring[g] = w1load(0, g);
+    for (int g = 0; g < RD; g++) ring[g] = w1load(0, g);
     const uint4 *blx = Xh + (size_t)hk * LD + lm;
     for (int c = 0; c < n_chunks; c++) {
         f32x16 acc1[1][MT];
@@ -752,9 +752,9 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
             for (int mt = 0; mt < MT; mt++) b8[mt] = blx[(size_t)(2 * g) * LD + 32 * mt];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
-                acc1[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[g % 16]), __builtin_bit_cast(bf16x8, b8[mt]), acc1[0][mt], 0, 0, 0);
-            if (g + 16 < KG) ring[g % 16] = w1load(c, g + 16);
-            else ring[g % 16] = w2load(c, (g % 16 - OFF2 + 16) % 16);  // FC1's tail: the first 16 elements (8 groups) of this chunk's FC2 weights
+                acc1[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[g % RD]), __builtin_bit_cast(bf16x8, b8[mt]), acc1[0][mt], 0, 0, 0);
+            if (g + RD < KG) ring[g % RD] = w1load(c, g + RD);
+            else ring[g % RD] = w2load(c, (g % RD - OFF2 + RD) % RD);  // FC1's tail: the first 16 elements (8 groups) of this chunk's FC2 weights
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp();
@@ -778,14 +778,12 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
             for (int t = 0; t < T2W; t++)
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
-                    acc2[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[(2 * j + t + OFF2) % 16]), __builtin_bit_cast(bf16x8, b8[mt]),
+                    acc2[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[(2 * j + t + OFF2) % RD]), __builtin_bit_cast(bf16x8, b8[mt]),
                                                                          acc2[t][mt], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < T2W; t++) {
-                constexpr int dummy = 0;
-                (void)dummy;
-                const int r = (2 * j + t + OFF2) % 16;
-                if (j + 8 < 16) ring[r] = w2load(c, 2 * j + t + 16);
+                const int r = (2 * j + t + OFF2) % RD;
+                if (2 * j + t + RD < 32) ring[r] = w2load(c, 2 * j + t + RD);
                 else ring[r] = __builtin_bit_cast(uint4, ft_wload(WN, (unsigned)r * WN.row2 + nsoff, 0));  // group r of the next stream lives in slot r
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -813,8 +811,8 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
             for (int mt = 0; mt < MT; mt++) b8[mt] = bl3[(size_t)(2 * g) * LD + 32 * mt];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
-                acc3[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[g % 16]), __builtin_bit_cast(bf16x8, b8[mt]), acc3[0][mt], 0, 0, 0);
-            if (g + 16 < 16 * T2W) ring[g % 16] = __builtin_bit_cast(uint4, ft_wload(W3, (unsigned)(g + 16) * W3.row2 + (unsigned)(32 * wave) * 16u, 0));
+                acc3[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[g % RD]), __builtin_bit_cast(bf16x8, b8[mt]), acc3[0][mt], 0, 0, 0);
+            if (g + RD < 16 * T2W) ring[g % RD] = __builtin_bit_cast(uint4, ft_wload(W3, (unsigned)(g + RD) * W3.row2 + (unsigned)(32 * wave) * 16u, 0));
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -865,11 +863,11 @@ bool frk_fused_h_ok(int K, int H1, int H2, int H3) {
 
 int frk_fused_h_items_per_wg() { return 64; }
 
-template <int MT, int T2W, int KG, bool DB>
+template <int MT, int T2W, int KG, bool DB, int RD>
 static int fused_h_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     static FrLdsAttrOnce lds_once;  // per instantiation, per device
-    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_h_kernel<MT, T2W, KG, DB>, lds_once)) return rc_;
-    fr_fused_tile_h_kernel<MT, T2W, KG, DB><<<grid, dim3(512), lds, s>>>(a);
+    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_h_kernel<MT, T2W, KG, DB, RD>, lds_once)) return rc_;
+    fr_fused_tile_h_kernel<MT, T2W, KG, DB, RD><<<grid, dim3(512), lds, s>>>(a);
     KCHECK();
     return FR_OK;
 }
@@ -877,8 +875,14 @@ static int fused_h_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipS
 // a.w1q/w2q/w3q/wout must point at the bf16 q8 weights; a.tiles_per_batch counts 64-item tiles
 int frk_fused_h_launch(const FrFusedArgs &a, hipStream_t s) {
     dim3 grid(a.n_batches * a.tiles_per_batch);
-    if (a.K == 352) return fused_h_launch_inst<2, 2, 22, true>(a, grid, fused_h_lds_bytes(a.K, a.H2, a.H3, 2, true), s);
-    if (a.K == 880) return fused_h_launch_inst<2, 2, 55, false>(a, grid, fused_h_lds_bytes(a.K, a.H2, a.H3, 2, false), s);
+    static const int ring = [] { const char *e = getenv("FR_FUSED_H_RING"); return e ? atoi(e) : 16; }();  // experiment knob: weight-ring depth
+    if (a.K == 352) return fused_h_launch_inst<2, 2, 22, true, 16>(a, grid, fused_h_lds_bytes(a.K, a.H2, a.H3, 2, true), s);
+    if (a.K == 880) {
+        const size_t lds = fused_h_lds_bytes(a.K, a.H2, a.H3, 2, false);
+        if (ring == 32) return fused_h_launch_inst<2, 2, 55, false, 32>(a, grid, lds, s);
+        if (ring == 24) return fused_h_launch_inst<2, 2, 55, false, 24>(a, grid, lds, s);
+        return fused_h_launch_inst<2, 2, 55, false, 16>(a, grid, lds, s);
+    }
     FR_FAIL(FR_ERR_INVALID, "no bf16 fused instantiation for K=%d", a.K);
 }
 
