@@ -58,7 +58,7 @@ _lib = None
 ABI_SYMBOLS = [
     "fr_abi_version", "fr_last_error", "fr_device_count", "fr_model_builtin", "fr_model_clone_scaled", "fr_model_free",
     "fr_model_table_bytes", "fr_model_index_cols", "fr_model_bank_map", "fr_ctx_set_gather_variant", "fr_ctx_gather_variant",
-    "fr_ctx_gather_merged_lookups", "fr_comm_unique_id", "fr_comm_init_rank", "fr_comm_init_all", "fr_comm_destroy",
+    "fr_ctx_gather_merged_lookups", "fr_ctx_gather_groups", "fr_comm_unique_id", "fr_comm_init_rank", "fr_comm_init_all", "fr_comm_destroy",
     "fr_worker_submit_sharded", "fr_worker_calibrate_fp8_sharded", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
     "fr_ctx_fill_tables", "fr_ctx_upload_table", "fr_ctx_download_table", "fr_ctx_set_weights", "fr_ctx_fill_weights",
     "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_ctx_get_fp8_exponents", "fr_ctx_set_fp8_act_exponents",
@@ -121,6 +121,7 @@ def lib():
         "fr_comm_init_all": (i32, [ctypes.POINTER(vp), i32, ctypes.POINTER(vp)]), "fr_comm_destroy": (None, [vp]),
         "fr_worker_submit_sharded": (i32, [vp, vp, i32]), "fr_worker_calibrate_fp8_sharded": (i32, [vp, vp, i32]),
         "fr_ctx_gather_merged_lookups": (i32, [vp, ctypes.POINTER(ctypes.c_uint64), i32]),
+        "fr_ctx_gather_groups": (i32, [vp, ctypes.POINTER(ctypes.c_int)]),
         "fr_driver_run_host": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
         "fr_driver_run_host_streaming": (i32, [vp, i32, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, ctypes.POINTER(ctypes.c_double)]),
         "fr_driver_host_score_ring": (vp, [vp, i32, i32, ctypes.POINTER(ctypes.c_int)]),
@@ -430,6 +431,12 @@ class Context:
     def set_gather_variant(self, variant):
         """GATHER_WORD_MAJOR (default) / GATHER_ITEM_TILE / GATHER_ITEM_TILE_DEDUP(_COUNT): which kernel fr_worker_gather_only runs."""
         _check(lib().fr_ctx_set_gather_variant(self._h, variant))
+
+    def gather_groups(self):
+        """Word ranges [starts[g], starts[g + 1]) the word-major gather deals to the 8 XCD groups (fr_ctx_gather_groups)."""
+        st = (ctypes.c_int * 9)()
+        _check(lib().fr_ctx_gather_groups(self._h, st))
+        return [int(x) for x in st]
 
     def gather_merged_lookups(self, reset=True):
         v = ctypes.c_uint64()

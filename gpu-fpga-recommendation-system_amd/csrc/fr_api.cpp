@@ -89,6 +89,84 @@ void fr_shard_bounds(const fr_model_desc &m, int n_shards, std::vector<int> &seg
     }
 }
 
+// XCD partition of the record words for gather_pack_xcd_kernel (FrGatherGroups): 8 contiguous runs of words cut on SOURCE-ROW
+// boundaries, balanced by a cost per word run.  An "atom" is a maximal run of consecutive record words that one item reads from ONE
+// source row -- a table row, a whole bank row in a bank-interleaved context (one contiguous 112-256-byte fetch), 128 bytes of the
+// dense block.  Cutting inside an atom makes two XCDs fetch the same 128-byte line through two L2s: with Model-C's 992 words dealt
+// 124 per group, 6 of the 7 cuts split a bank row -- 6 extra lines on 142 per item.  Cost of an atom = the bytes it writes + the
+// 128-byte lines it fetches, weighted by where its table lives (FR_GATHER_COST = "write,l2,cache,hbm" weights; tables up to 2 MiB
+// per XCD group are taken as L2-resident, up to 64 MiB as Infinity-Cache-resident); a linear-partition DP minimises the costliest
+// group, then the sum of squares.  Groups wider than 256 words (the kernel's block) leave max_words = 0: the launcher then deals
+// n_words / 8 words per group as before.
+static void plan_gather_groups(fr_ctx *c) {
+    FrGatherGroups &gg = c->gather_groups;
+    gg = FrGatherGroups{};
+    const int n = c->n_words;
+    if (n < 64) return;
+    double wt[4] = {1.0, 0.0, 0.0, 0.0};  // write, fetch from L2-class, cache-class, HBM-class tables
+    if (const char *e = getenv("FR_GATHER_COST")) sscanf(e, "%lf,%lf,%lf,%lf", &wt[0], &wt[1], &wt[2], &wt[3]);
+    struct Atom { int w0, nw; double cost; };
+    std::vector<Atom> atoms;
+    auto close_atom = [&](int w0, int w1) {
+        const FrWordDesc &d = c->h_words[w0];
+        const size_t bytes = (size_t)(w1 - w0) * 16;
+        double fetch = 0.0;
+        if (!(d.idx_col & FR_DESC_DENSE)) {
+            size_t acc = 0;  // expected 128-byte lines per fetched row, over one period of the stride
+            for (size_t r = 0; r < 128; r++) acc += ((d.src + r * d.stride) % 128 + bytes + 127) / 128;
+            const double lines = (double)acc / 128.0;
+            const double footprint = (double)d.rows * d.stride;
+            fetch = lines * 128.0 * (footprint <= 2.0 * 1048576 ? wt[1] : footprint <= 64.0 * 1048576 ? wt[2] : wt[3]);
+        }
+        atoms.push_back(Atom{w0, w1 - w0, wt[0] * (double)bytes + fetch});
+    };
+    int a0 = 0;
+    for (int w = 1; w <= n; w++) {
+        bool same = false;
+        if (w < n) {
+            const FrWordDesc &p = c->h_words[w - 1], &q = c->h_words[w];
+            const bool pd = (p.idx_col & FR_DESC_DENSE) != 0, qd = (q.idx_col & FR_DESC_DENSE) != 0;
+            if (pd && qd) same = q.src == p.src + 16 && (w - a0) % 8 != 0;
+            else if (!pd && !qd) same = p.idx_col == q.idx_col && p.stride == q.stride && (q.src > p.src ? q.src - p.src : p.src - q.src) < p.stride;
+        }
+        if (!same) {
+            close_atom(a0, w);
+            a0 = w;
+        }
+    }
+    const int na = (int)atoms.size();
+    if (na < 8) return;
+    std::vector<double> pc(na + 1, 0.0);
+    std::vector<int> pw(na + 1, 0);
+    for (int i = 0; i < na; i++) {
+        pc[i + 1] = pc[i] + atoms[i].cost;
+        pw[i + 1] = pw[i] + atoms[i].nw;
+    }
+    const double INF = 1e300;
+    struct Cell { double mx, sq; int from; };
+    std::vector<std::vector<Cell>> dp(9, std::vector<Cell>(na + 1, Cell{INF, INF, -1}));
+    dp[0][0] = Cell{0.0, 0.0, -1};
+    for (int g = 1; g <= 8; g++)
+        for (int i = g; i <= na - (8 - g); i++)
+            for (int j = g - 1; j < i; j++) {
+                if (dp[g - 1][j].mx >= INF || pw[i] - pw[j] > 256) continue;
+                const double cst = pc[i] - pc[j];
+                const double mx = dp[g - 1][j].mx > cst ? dp[g - 1][j].mx : cst, sq = dp[g - 1][j].sq + cst * cst;
+                Cell &t = dp[g][i];
+                if (mx < t.mx * (1.0 - 1e-12) || (mx <= t.mx * (1.0 + 1e-12) && sq < t.sq)) t = Cell{mx, sq, j};
+            }
+    if (dp[8][na].mx >= INF) return;
+    int i = na;
+    gg.start[8] = n;
+    for (int g = 8; g >= 1; g--) {
+        const int j = dp[g][i].from;
+        gg.start[g - 1] = atoms[j].w0;
+        const int width = gg.start[g] - gg.start[g - 1];
+        if (width > gg.max_words) gg.max_words = width;
+        i = j;
+    }
+}
+
 static int build_words(fr_ctx *c) {
     const fr_model_desc &m = c->model;
     std::vector<int> seg_begin;
@@ -219,6 +297,7 @@ static int build_words(fr_ctx *c) {
         }
     }
     c->n_words = (int)c->h_words.size();
+    plan_gather_groups(c);
     FR_HIP(hipMalloc((void **)&c->d_words, sizeof(FrWordDesc) * c->n_words));
     FR_HIP(hipMemcpy(c->d_words, c->h_words.data(), sizeof(FrWordDesc) * c->n_words, hipMemcpyHostToDevice));
     // Item-tile gather plan (gather_tile_kernel): every record segment is cut in power-of-two pieces of <= 16 words, a piece of w words
@@ -656,7 +735,7 @@ static int launch_gather(fr_worker *w, int batch, const int32_t *d_idx, const fl
     if (variant != FR_GATHER_WORD_MAJOR && transport == FR_FC_FP32 && c->n_chunks > 0)
         return frk_gather_tile(c->d_passes, c->d_chunks, c->n_chunks, d_idx, (int)idx_cols(c), d_dense, d_records, c->slice_padded / 4, batch, w->d_err,
                                variant != FR_GATHER_ITEM_TILE, variant == FR_GATHER_ITEM_TILE_DEDUP_COUNT ? c->d_merged : nullptr, w->stream);
-    return frk_gather(c->d_words, c->n_words, d_idx, (int)idx_cols(c), d_dense, d_records, batch, w->d_err, transport, c->f8_e_act[0], w->stream);
+    return frk_gather(c->d_words, c->n_words, c->gather_groups, d_idx, (int)idx_cols(c), d_dense, d_records, batch, w->d_err, transport, c->f8_e_act[0], w->stream);
 }
 
 extern "C" int fr_ctx_set_gather_variant(fr_ctx *ctx, int variant) {
@@ -668,6 +747,13 @@ extern "C" int fr_ctx_set_gather_variant(fr_ctx *ctx, int variant) {
 }
 
 extern "C" int fr_ctx_gather_variant(const fr_ctx *ctx) { return ctx ? ctx->gather_variant.load(std::memory_order_relaxed) : FR_ERR_INVALID; }
+
+extern "C" int fr_ctx_gather_groups(const fr_ctx *ctx, int starts[9]) {
+    if (!ctx || !starts) FR_FAIL(FR_ERR_INVALID, "ctx or starts is NULL");
+    if (ctx->gather_groups.max_words <= 0) FR_FAIL(FR_ERR_STATE, "no XCD partition for this record (%d words)", ctx->n_words);
+    for (int g = 0; g <= 8; g++) starts[g] = ctx->gather_groups.start[g];
+    return FR_OK;
+}
 
 extern "C" int fr_ctx_gather_merged_lookups(fr_ctx *ctx, uint64_t *merged, int reset) {
     if (!ctx || !merged) FR_FAIL(FR_ERR_INVALID, "NULL argument");

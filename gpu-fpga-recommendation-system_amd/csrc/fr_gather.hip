@@ -69,18 +69,19 @@ __global__ void __launch_bounds__(256) gather_pack_kernel(const FrWordDesc *__re
 }
 
 // XCD-partitioned form for wide records and large batches: workgroup b serves XCD group b % 8 (workgroups are dealt
-// round-robin over the 8 XCDs; a speed assumption only), and each group owns a fixed contiguous 1/8 of the record words for
-// ALL items.  Every table is then touched from ONE XCD only, so the 8 x 4 MiB L2s cache 8 different table sets instead of
-// 8 copies of the same hottest 4 MiB -- rows served by L2 cost ~5 cycles/CU instead of ~12 from the fabric
-// (profiles/r01_experiments.md, ta_cost2).
+// round-robin over the 8 XCDs; a speed assumption only), and each group owns a fixed contiguous run of the record words for
+// ALL items (FrGatherGroups: cut on source-row boundaries, so no table row / bank row is fetched by two XCDs).  Every table is then
+// touched from ONE XCD only, so the 8 x 4 MiB L2s cache 8 different table sets instead of 8 copies of the same hottest 4 MiB --
+// rows served by L2 cost ~5 cycles/CU instead of ~12 from the fabric (profiles/r01_experiments.md, ta_cost2).
 template <int ITEMS, int TP>
-__global__ void __launch_bounds__(256) gather_pack_xcd_kernel(const FrWordDesc *__restrict__ words, int n_words, int words_per_group,
+__global__ void __launch_bounds__(256) gather_pack_xcd_kernel(const FrWordDesc *__restrict__ words, const FrGatherGroups groups,
                                                               const int32_t *__restrict__ idx, int idx_stride,
                                                               const float *__restrict__ dense, void *__restrict__ out,
                                                               int batch, int *__restrict__ err_flag, float scale, int n_chunks) {
     const int group = blockIdx.x & 7;
-    const int w = group * words_per_group + threadIdx.x;
-    if ((int)threadIdx.x >= words_per_group || w >= n_words) return;
+    const int w0 = groups.start[group];
+    if ((int)threadIdx.x >= groups.start[group + 1] - w0) return;
+    const int w = w0 + threadIdx.x;
     const uint4 d0 = reinterpret_cast<const uint4 *>(words)[2 * w];
     const uint4 d1 = reinterpret_cast<const uint4 *>(words)[2 * w + 1];
     const uint64_t src = ((uint64_t)d0.y << 32) | d0.x;
@@ -120,20 +121,20 @@ __global__ void __launch_bounds__(256) gather_pack_xcd_kernel(const FrWordDesc *
 }
 
 template <int ITEMS, int TP>
-static int gather_launch_xcd(const FrWordDesc *words, int n_words, int wpg, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch,
+static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &groups, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch,
                              int *err_flag, float scale, hipStream_t s) {
-    const int bx = ((wpg + 63) / 64) * 64;
+    const int bx = ((groups.max_words + 63) / 64) * 64;
     const int n_chunks = (batch + ITEMS - 1) / ITEMS;
     const char *e_loop = getenv("FR_GATHER_LOOP");  // experiment knob: chunks a workgroup walks (1 = one chunk per workgroup)
     const int per_wg = e_loop ? (atoi(e_loop) > 0 ? atoi(e_loop) : 1) : 1;
     dim3 grid(8 * ((n_chunks + per_wg - 1) / per_wg));
-    gather_pack_xcd_kernel<ITEMS, TP><<<grid, dim3(bx), 0, s>>>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, n_chunks);
+    gather_pack_xcd_kernel<ITEMS, TP><<<grid, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, n_chunks);
     KCHECK();
     return FR_OK;
 }
 
 template <int TP>
-static int gather_launch(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
+static int gather_launch(const FrWordDesc *words, int n_words, const FrGatherGroups &planned, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
                          float scale, hipStream_t s) {
     // experiment knobs (tools/experiments/gather_sweep.py), read per launch: FR_GATHER_XCD = 0 / 1 forces the kernel form,
     // FR_GATHER_ITEMS = items per thread of the XCD-partitioned form
@@ -141,14 +142,19 @@ static int gather_launch(const FrWordDesc *words, int n_words, const int32_t *id
     const int force = e_xcd ? atoi(e_xcd) : -1;
     const bool xcd = force >= 0 ? force != 0 : (n_words >= 512 && batch >= 1024);
     if (xcd) {
-        const int wpg = (n_words + 7) / 8;
-        if (wpg <= 256) {
+        FrGatherGroups groups = planned;
+        if (groups.max_words <= 0 || (getenv("FR_GATHER_UNIFORM_GROUPS") && atoi(getenv("FR_GATHER_UNIFORM_GROUPS")))) {  // no plan (or the experiment knob): n_words / 8 each
+            const int wpg = (n_words + 7) / 8;
+            for (int g = 0; g <= 8; g++) groups.start[g] = g * wpg < n_words ? g * wpg : n_words;
+            groups.max_words = wpg;
+        }
+        if (groups.max_words <= 256) {
             switch (e_items ? atoi(e_items) : 4) {  // 4 items per thread: fastest in the r02 sweep (profiles/r02_gather_sweep.txt)
-                case 1: return gather_launch_xcd<1, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
-                case 2: return gather_launch_xcd<2, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
-                case 8: return gather_launch_xcd<8, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
-                case 16: return gather_launch_xcd<16, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
-                default: return gather_launch_xcd<4, TP>(words, n_words, wpg, idx, idx_stride, dense, out, batch, err_flag, scale, s);
+                case 1: return gather_launch_xcd<1, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s);
+                case 2: return gather_launch_xcd<2, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s);
+                case 8: return gather_launch_xcd<8, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s);
+                case 16: return gather_launch_xcd<16, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s);
+                default: return gather_launch_xcd<4, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s);
             }
         }
     }
@@ -169,12 +175,12 @@ static int gather_launch(const FrWordDesc *words, int n_words, const int32_t *id
 }
 
 // transport: FR_FC_FP32 (fp32 records, the reference's wire format), FR_FC_BF16 or FR_FC_FP8 (slice transport of the sharded mode)
-int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
+int frk_gather(const FrWordDesc *words, int n_words, const FrGatherGroups &groups, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
                int transport, int e_x, hipStream_t s) {
     if (n_words <= 0 || batch <= 0) return FR_OK;
-    if (transport == FR_FC_BF16) return gather_launch<1>(words, n_words, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s);
-    if (transport == FR_FC_FP8) return gather_launch<2>(words, n_words, idx, idx_stride, dense, out, batch, err_flag, ldexpf(1.0f, e_x), s);
-    return gather_launch<0>(words, n_words, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s);
+    if (transport == FR_FC_BF16) return gather_launch<1>(words, n_words, groups, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s);
+    if (transport == FR_FC_FP8) return gather_launch<2>(words, n_words, groups, idx, idx_stride, dense, out, batch, err_flag, ldexpf(1.0f, e_x), s);
+    return gather_launch<0>(words, n_words, groups, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -44,6 +44,14 @@ struct FrWordDesc {
 static_assert(sizeof(FrWordDesc) == 32, "FrWordDesc must be 32 bytes");
 #define FR_DESC_DENSE 0x80000000u
 
+// How gather_pack_xcd_kernel deals the record words to the 8 XCD groups: group g owns words [start[g], start[g + 1]).  The cuts
+// sit on SOURCE-ROW boundaries (a table row, or a whole bank row of a bank-interleaved context): a row cut in two would be fetched
+// by two XCDs -- the same 128-byte line through two L2s.  max_words = the widest group (the kernel's block size).
+struct FrGatherGroups {
+    int start[9];
+    int max_words;
+};
+
 // One wave-instruction of the item-tile gather (gather_tile_kernel, fr_gather.hip): 64 / n_words items x n_words consecutive
 // 16-byte words of ONE source row each (n_words = 1, 2, 4, 8 or 16: a whole table row, or a power-of-two piece of one).  A record
 // segment of w words appears as w passes (item0 = 0, 64/w, 2*64/w, ...) so that the passes of a 64-item tile cover every item.
@@ -154,6 +162,7 @@ struct fr_ctx {
     int n_words = 0;                       // words this ctx gathers per item (whole record, or the shard's slice)
     FrWordDesc *d_words = nullptr;         // [n_words]
     std::vector<FrWordDesc> h_words;
+    FrGatherGroups gather_groups{};        // XCD partition of the record words (gather_pack_xcd_kernel); max_words == 0: none
     // item-tile gather plan (SEMANTIC / sharded layouts): passes grouped in chunks of <= FR_TILE_WORDS record words
     FrPassDesc *d_passes = nullptr;
     FrChunkDesc *d_chunks = nullptr;
@@ -252,7 +261,7 @@ static inline uint32_t fr_table_uid(const fr_table_desc &t) {
 }
 int frk_fill_table(float *base, int64_t row0, int64_t rows, int dim, int64_t row_stride_bytes, int mode, uint32_t seed, uint32_t uid, hipStream_t s);
 int frk_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t layer, float scale, hipStream_t s);
-int frk_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
+int frk_gather(const FrWordDesc *words, int n_words, const FrGatherGroups &groups, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
                int transport, int e_x, hipStream_t s);
 int frk_gather_tile(const FrPassDesc *passes, const FrChunkDesc *chunks, int n_chunks, const int32_t *idx, int idx_stride, const float *dense, void *out,
                     int out_stride_words, int batch, int *err_flag, bool dedup, unsigned long long *dup_counter, hipStream_t s);

@@ -299,6 +299,11 @@ int fr_ctx_gather_variant(const fr_ctx *ctx);
 /* Lookups (rows) the DEDUP_COUNT variant did NOT load because another lane of the wave loaded the same row, summed since the last
  * reset.  Synchronises the device. */
 int fr_ctx_gather_merged_lookups(fr_ctx *ctx, uint64_t *merged, int reset);
+/* Diagnostic: how the word-major gather deals the record's 16-byte words to the chip's 8 XCDs at large batches -- group g owns words
+ * [starts[g], starts[g + 1]) of the record (the shard's slice).  The cuts sit on source-row boundaries (a table row; a whole bank row
+ * of an FR_INDEX_PER_BANK context), so that no row is fetched through two L2s.  Returns FR_ERR_STATE when the context has no such plan
+ * (short records: every group would be narrower than a wave). */
+int fr_ctx_gather_groups(const fr_ctx *ctx, int starts[9]);
 /* Device pointer of the worker's own record buffer ([max_batch][record_len] floats). */
 float *fr_worker_records_dptr(fr_worker *w);
 /* Debug/parity hook: device pointer of the worker's feature-major activation buffer written by the gather stage

@@ -146,6 +146,43 @@ def test_gather_kernel_variants_are_bit_identical(fr, O, gpu, which, mode):
     ctx.close()
 
 
+@pytest.mark.parametrize("which,mode", [(2, "table"), (2, "bank"), (1, "bank"), (1, "table")])
+def test_gather_groups_cut_on_source_rows(fr, O, gpu, which, mode):
+    """fr_ctx_gather_groups: the 8 word ranges the word-major gather deals to the XCDs cover the record exactly once, are at most
+    256 words wide, and every cut sits between two SOURCE rows -- a table row (segment) with per-table indices, a whole bank row
+    (the consecutive segments of one bank) with per-bank indices -- so that no row is fetched through two L2s; and the records of a
+    batch large enough to take that kernel (>= 1024 items) are still bit-exact against the oracle."""
+    imode = {"table": fr.INDEX_PER_TABLE, "bank": fr.INDEX_PER_BANK}[mode]
+    m = fr.Model.builtin(which).clone(max_rows=30000, index_mode=imode)
+    om = O.OracleModel(NAMES[which])
+    ctx = fr.Context(m, device=gpu)
+    ctx.fill_tables(fr.FILL_TAGGED, 0)
+    st = ctx.gather_groups()
+    n_words = m.record_len // 4
+    assert st[0] == 0 and st[8] == n_words and all(0 < st[g + 1] - st[g] <= 256 for g in range(8)), st
+    assert max(st[g + 1] - st[g] for g in range(8)) <= 1.15 * n_words / 8 + 16, st      # still balanced
+    bot, _ = m.bank_map()
+    allowed = {0, n_words}
+    prev = None
+    for sg in m.segments():
+        key = ("dense",) if sg.kind == fr.SEG_DENSE else (("bank", int(bot[sg.src])) if mode == "bank" and sg.kind == fr.SEG_TABLE else ("seg", sg.rec_offset))
+        if key != prev:
+            allowed.add(sg.rec_offset // 4)
+        if sg.kind == fr.SEG_DENSE:
+            allowed.update(range(sg.rec_offset // 4, (sg.rec_offset + sg.len) // 4 + 1, 8))   # the dense block may be cut every 128 bytes
+        prev = key
+    assert set(st) <= allowed, (st, sorted(set(st) - allowed))
+    B = 1024 + 37
+    rng = np.random.default_rng(99)
+    idx = uniform_idx(rng, m.index_ranges(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32) if m.dense_len else None
+    want = om.gather(idx, dense=dense, content_mode=O.FILL_TAGGED, per_bank=(mode == "bank"))
+    wk = fr.Worker(ctx, B)
+    assert np.array_equal(wk.gather_records(idx, dense).reshape(B, m.record_len), want)
+    wk.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("which,fname", [(0, "records_47.bin"), (1, "records_98.bin"), (2, "records_377x2.bin")])
 def test_gather_matches_committed_golden_records(fr, gpu, which, fname):
     """The device gather against COMMITTED bytes (tests/golden/records_*.bin, tagged tables: every float names its table / row /
