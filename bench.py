@@ -789,15 +789,19 @@ def main():
 
     if want("pcie"):
         # ---- PCIe-inclusive rates (index rows start in HOST memory, scores end in HOST memory; reported, never `value`) ----
-        hd = fr.Driver(ctx, args.threads, 4, B)
+        # host threads of these legs = the reference's THREAD_NUM = 4 (constant.h:42): every pushed batch is first copied into pinned
+        # staging by its driver thread (the counterpart of the reference's read() into pinned memory), and two threads cannot stage
+        # 13 GB/s of index rows (measured: 2 x 2 workers 60.7 M inf/s, 4 x 2 workers 67.1 M, profiles/r02_experiments.md section 5)
+        ht = max(args.threads, 4)
+        hd = fr.Driver(ctx, ht, 4, B)
         hd.run_host(B, 200, idx_host)
         n = steady_run(lambda k: hd.run_host(B, k, idx_host), 1.0, n_first=1000, quantum=64)
         el = hd.run_host(B, n, idx_host)
         hd.close()
         result["pcie_inclusive"] = {"value": n * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / n, "timed_batches": n, "timed_s": el,
                                     "what": "per batch: memcpy to pinned -> H2D -> 5 stage launches -> D2H -> sync (the reference's own per-batch "
-                                            "sequence, cuda_server.c:425-495), %d threads x 4 workers" % args.threads}
-        hs = fr.Driver(ctx, args.threads, args.depth, B)
+                                            "sequence, cuda_server.c:425-495), %d threads x 4 workers" % ht}
+        hs = fr.Driver(ctx, ht, args.depth, B)
         hs.run_host(B, 2048, idx_host, streaming=True)
         n = steady_run(lambda k: hs.run_host(B, k, idx_host, streaming=True), STEADY_S, n_first=8192)
         el = hs.run_host(B, n, idx_host, streaming=True)
@@ -806,7 +810,7 @@ def main():
         result["pcie_inclusive_streaming"] = {"value": n * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / n, "timed_batches": n, "timed_s": el,
                                               "what": "host-resident request stream, scores delivered to host memory: blocks of 64 batches staged in pinned "
                                                       "memory, one H2D + one fused launch + one D2H per block (fr_worker_push_host), %d threads x %d workers"
-                                                      % (args.threads, args.depth)}
+                                                      % (ht, args.depth)}
 
     if want("cpu"):
         try:

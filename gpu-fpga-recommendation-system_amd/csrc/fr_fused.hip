@@ -644,7 +644,7 @@ __device__ __forceinline__ void fth_store_tile(uint4 *img, int ld, const f32x16 
     }
 }
 
-template <int MT, int T2W, int KG, bool DB, int RD>
+template <int MT, int T2W, int KG, bool DB, int RD, bool SYNC = true>
 __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs a) {
     extern __shared__ uint4 lds[];
     constexpr int LD = 32 * MT + 1, TI = 32 * MT;
@@ -661,8 +661,8 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
     const int m0 = tile * TI;
     if (m0 >= bt.batch) return;
     int n_st = 0;
-    auto stamp = [&]() {  // diagnostic build aid (tools/experiments/fused_h_stamps.py); wave 0 lane 0 only, values never feed an output
-        if (a.stamps && tid == 0 && n_st < 14) a.stamps[16ull * blockIdx.x + n_st] = __builtin_amdgcn_s_memrealtime();
+    auto stamp = [&]() {  // diagnostic build aid (tools/experiments/fused_h_stamps.py); lane 0 of every wave, values never feed an output
+        if (a.stamps && lane == 0 && n_st < 14) a.stamps[16ull * (8ull * blockIdx.x + wave) + n_st] = __builtin_amdgcn_s_memrealtime();
         n_st++;
     };
     stamp();
@@ -759,10 +759,10 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
         }
         stamp();
         uint4 *R1 = R1b[DB ? (c & 1) : 0];
-        if (!DB && c > 0) __syncthreads();  // single R1 buffer: every wave must be done reading the previous chunk
+        if (SYNC && !DB && c > 0) __syncthreads();  // single R1 buffer: every wave must be done reading the previous chunk
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) fth_store_tile(R1, LD, acc1[0][mt], 32 * wave, 32 * mt, hk, lm);
-        __syncthreads();
+        if (SYNC) __syncthreads();  // !SYNC: timing experiment only (results are garbage)
         // FC2: K range [256 c, 256 c + 256) = 16 groups of 16 k; its tail requests the next stream: W1 chunk c + 1, or W3 after the last chunk
         const bool last = c + 1 == n_chunks;
         FtW WN = W1;
@@ -880,7 +880,18 @@ int frk_fused_h_launch(const FrFusedArgs &a, hipStream_t s) {
     if (a.K == 880) {
         const size_t lds = fused_h_lds_bytes(a.K, a.H2, a.H3, 2, false);
         if (ring == 32) return fused_h_launch_inst<2, 2, 55, false, 32>(a, grid, lds, s);
+        if (ring == -16) {  // timing experiment: the chunk loop without its barriers (wrong results)
+            static FrLdsAttrOnce once;
+            if (int rc_ = fr_allow_full_lds(&fr_fused_tile_h_kernel<2, 2, 55, false, 16, false>, once)) return rc_;
+            fr_fused_tile_h_kernel<2, 2, 55, false, 16, false><<<grid, dim3(512), lds, s>>>(a);
+            KCHECK();
+            return FR_OK;
+        }
         if (ring == 24) return fused_h_launch_inst<2, 2, 55, false, 24>(a, grid, lds, s);
+        if (ring == 20) return fused_h_launch_inst<2, 2, 55, false, 20>(a, grid, lds, s);
+        if (ring == 18) return fused_h_launch_inst<2, 2, 55, false, 18>(a, grid, lds, s);
+        if (ring == 12) return fused_h_launch_inst<2, 2, 55, false, 12>(a, grid, lds, s);
+        if (ring == 8) return fused_h_launch_inst<2, 2, 55, false, 8>(a, grid, lds, s);
         return fused_h_launch_inst<2, 2, 55, false, 16>(a, grid, lds, s);
     }
     FR_FAIL(FR_ERR_INVALID, "no bf16 fused instantiation for K=%d", a.K);

@@ -8,7 +8,7 @@ fr = g.load_package()
 m = fr.Model.builtin(fr.MODEL_B)
 ctx = fr.Context(m, 0); ctx.fill_tables(fr.FILL_HASH, 1); ctx.fill_weights(fr.WEIGHTS_UNIFORM, 2)
 ctx.set_fc_precision(fr.FC_BF16)
-B, NB = 1024, 16
+B, NB = 1024, (int(sys.argv[1]) if len(sys.argv) > 1 else 16)   # NB batches per launch = 16 NB workgroups of 64 items
 NWG = NB * B // 64
 rng = np.random.default_rng(0)
 pool = [fr.DeviceBuffer.from_numpy(ctx, (rng.random((B, m.n_tables)) * m.rows()[None, :]).astype(np.int32)) for _ in range(16)]
@@ -18,8 +18,8 @@ for rep in range(200):
     for i in range(NB):
         wk.push_device(B, pool[i % 16], None, sc[i % 32])
 wk.sync()
-stamps = fr.DeviceBuffer(ctx, 4096 * 16 * 8)
-stamps.upload(np.zeros(4096 * 16, np.uint64))
+stamps = fr.DeviceBuffer(ctx, 8 * 4096 * 16 * 8)
+stamps.upload(np.zeros(8 * 4096 * 16, np.uint64))
 lib = fr.lib()
 lib.fr_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
 lib.fr_debug_set_stamp_buffer(stamps.ptr)
@@ -27,7 +27,8 @@ for i in range(NB):
     wk.push_device(B, pool[i % 16], None, sc[i % 32])
 wk.sync()
 lib.fr_debug_set_stamp_buffer(None)
-s = stamps.download(np.uint64, 4096 * 16)[:16 * NWG].reshape(NWG, 16).astype(np.int64)
+sw = stamps.download(np.uint64, 8 * 4096 * 16)[:8 * 16 * NWG].reshape(NWG, 8, 16).astype(np.int64)   # [workgroup][wave][stamp]
+s = sw[:, 0, :]
 names = ["start", "gather done", "FC1 c0", "FC2 c0", "FC1 c1", "FC2 c1", "FC1 c2", "FC2 c2", "FC1 c3", "FC2 c3", "FC3 + R3"]
 t0 = s[:, 0].min()
 print("workgroups %d, launch span %.1f us (first start -> last FC3)" % (NWG, (s[:, 10].max() - t0) / 100.0))
@@ -36,3 +37,6 @@ for i, nme in enumerate(names):
     col = (s[:, i] - s[:, 0]) / 100.0
     print("%-12s median %6.1f us (+%.1f)   max %6.1f" % (nme, np.median(col), np.median(col) - prev, col.max()))
     prev = np.median(col)
+print("per wave (median over workgroups, us since the workgroup's wave 0 started): " + "  ".join(names[1:]))
+for w in range(8):
+    print("wave %d: " % w + "  ".join("%5.1f" % np.median((sw[:, w, i] - sw[:, 0, 0]) / 100.0) for i in range(1, 11)))
