@@ -644,7 +644,7 @@ __device__ __forceinline__ void fth_store_tile(uint4 *img, int ld, const f32x16 
     }
 }
 
-template <int MT, int T2W, int KG, bool DB, int RD, bool SYNC = true>
+template <int MT, int T2W, int KG, bool DB, int RD, int PD = 2, bool SYNC = true, bool W0 = false>  // !SYNC, W0: timing experiments (wrong results)
 __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs a) {
     extern __shared__ uint4 lds[];
     constexpr int LD = 32 * MT + 1, TI = 32 * MT;
@@ -662,7 +662,11 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
     if (m0 >= bt.batch) return;
     int n_st = 0;
     auto stamp = [&]() {  // diagnostic build aid (tools/experiments/fused_h_stamps.py); lane 0 of every wave, values never feed an output
-        if (a.stamps && lane == 0 && n_st < 14) a.stamps[16ull * (8ull * blockIdx.x + wave) + n_st] = __builtin_amdgcn_s_memrealtime();
+        if (a.stamps && lane == 0 && n_st < 14) {
+            a.stamps[16ull * (8ull * blockIdx.x + wave) + n_st] = __builtin_amdgcn_s_memrealtime();
+            if (n_st == 1) a.stamps[16ull * (8ull * blockIdx.x + wave) + 14] = __builtin_amdgcn_s_memtime();   // shader-clock cycles at "gather done"
+            if (n_st == 9) a.stamps[16ull * (8ull * blockIdx.x + wave) + 15] = __builtin_amdgcn_s_memtime();   // ... and at the end of the last chunk's FC2
+        }
         n_st++;
     };
     stamp();
@@ -732,13 +736,24 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
     static_assert(T2W == 2 && KG >= RD && RD >= 8 && RD <= 32 && RD % 2 == 0, "the stream ring assumes two n tiles per wave in FC2 (32 elements per chunk) and at least RD k groups in FC1");
     constexpr int OFF2 = KG % RD;
     uint4 ring[RD];
-    auto w1load = [&](int c, int g) { return __builtin_bit_cast(uint4, ft_wload(W1, (unsigned)g * W1.row2 + (unsigned)(c * 256 + 32 * wave) * 16u, 0)); };
+    auto w1load = [&](int c, int g) { return __builtin_bit_cast(uint4, ft_wload(W1, W0 ? 0u : (unsigned)g * W1.row2 + (unsigned)(c * 256 + 32 * wave) * 16u, 0)); };
     auto w2load = [&](int c, int e) {
+        if (W0) return __builtin_bit_cast(uint4, ft_wload(W2, 0u, 0));
         return __builtin_bit_cast(uint4, ft_wload(W2, (unsigned)(16 * c + (e >> 1)) * W2.row2 + (unsigned)(32 * T2W * wave) * 16u, 512 * (e & 1)));
     };
 #pragma unroll
     for (int g = 0; g < RD; g++) ring[g] = w1load(0, g);
     const uint4 *blx = Xh + (size_t)hk * LD + lm;
+    // B fragments (LDS reads) run PD groups ahead of the MFMAs that use them, in a ring of PD register slots refilled like the weight
+    // ring (group g lives in slot g % PD).  Read in place, a wave stalled ~90 cycles on the read before every pair of MFMAs (64
+    // cycles): per-wave stamps showed 154 cycles per FC1 group and the matrix pipe half idle in the FC phases.  The record image is
+    // static, so FC2's tail already fetches the first PD fragments of the next chunk's FC1 (16 % PD == 0 keeps the slots aligned).
+    static_assert(PD == 1 || PD == 2 || PD == 4, "B ring: 16 % PD must be 0");
+    uint4 bq[PD][MT];
+#pragma unroll
+    for (int i = 0; i < PD; i++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) bq[i][mt] = blx[(size_t)(2 * i) * LD + 32 * mt];
     for (int c = 0; c < n_chunks; c++) {
         f32x16 acc1[1][MT];
 #pragma unroll
@@ -747,14 +762,15 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
             for (int i = 0; i < 16; i++) acc1[0][mt][i] = 0.0f;
 #pragma unroll
         for (int g = 0; g < KG; g++) {  // FC1, chunk c: K / 16 groups
-            uint4 b8[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) b8[mt] = blx[(size_t)(2 * g) * LD + 32 * mt];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
-                acc1[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[g % RD]), __builtin_bit_cast(bf16x8, b8[mt]), acc1[0][mt], 0, 0, 0);
+                acc1[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[g % RD]), __builtin_bit_cast(bf16x8, bq[g % PD][mt]), acc1[0][mt], 0, 0, 0);
+            if (g + PD < KG) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) bq[g % PD][mt] = blx[(size_t)(2 * (g + PD)) * LD + 32 * mt];
+            }
             if (g + RD < KG) ring[g % RD] = w1load(c, g + RD);
-            else ring[g % RD] = w2load(c, (g % RD - OFF2 + RD) % RD);  // FC1's tail: the first 16 elements (8 groups) of this chunk's FC2 weights
+            else ring[g % RD] = w2load(c, (g % RD - OFF2 + RD) % RD);  // FC1's tail: the first RD elements of this chunk's FC2 weights
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp();
@@ -770,21 +786,25 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
         const unsigned nsoff = last ? (unsigned)(32 * wave) * 16u : (unsigned)((c + 1) * 256 + 32 * wave) * 16u;
         const uint4 *blr = R1 + (size_t)hk * LD + lm;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            uint4 b8[MT];
+        for (int i = 0; i < PD; i++)
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) b8[mt] = blr[(size_t)(2 * j) * LD + 32 * mt];
+            for (int mt = 0; mt < MT; mt++) bq[i][mt] = blr[(size_t)(2 * i) * LD + 32 * mt];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
 #pragma unroll
             for (int t = 0; t < T2W; t++)
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
-                    acc2[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[(2 * j + t + OFF2) % RD]), __builtin_bit_cast(bf16x8, b8[mt]),
+                    acc2[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[(2 * j + t + OFF2) % RD]), __builtin_bit_cast(bf16x8, bq[j % PD][mt]),
                                                                          acc2[t][mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)  // refill: FC2 group j + PD, or (tail) group j + PD - 16 of the next chunk's FC1 -- the record image is static
+                bq[j % PD][mt] = j + PD < 16 ? blr[(size_t)(2 * (j + PD)) * LD + 32 * mt] : blx[(size_t)(2 * (j + PD - 16)) * LD + 32 * mt];
 #pragma unroll
             for (int t = 0; t < T2W; t++) {
                 const int r = (2 * j + t + OFF2) % RD;
                 if (2 * j + t + RD < 32) ring[r] = w2load(c, 2 * j + t + RD);
-                else ring[r] = __builtin_bit_cast(uint4, ft_wload(WN, (unsigned)r * WN.row2 + nsoff, 0));  // group r of the next stream lives in slot r
+                else ring[r] = __builtin_bit_cast(uint4, ft_wload(WN, W0 ? 0u : (unsigned)r * WN.row2 + nsoff, 0));  // group r of the next stream lives in slot r
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -805,14 +825,19 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
     {   // FC3: H2 / 16 = 32 groups; groups 0..15 are already in (or on their way into) the ring
         const uint4 *bl3 = R2 + (size_t)hk * LD + lm;
 #pragma unroll
-        for (int g = 0; g < 16 * T2W; g++) {
-            uint4 b8[MT];
+        for (int i = 0; i < PD; i++)
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) b8[mt] = bl3[(size_t)(2 * g) * LD + 32 * mt];
+            for (int mt = 0; mt < MT; mt++) bq[i][mt] = bl3[(size_t)(2 * i) * LD + 32 * mt];
+#pragma unroll
+        for (int g = 0; g < 16 * T2W; g++) {
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
-                acc3[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[g % RD]), __builtin_bit_cast(bf16x8, b8[mt]), acc3[0][mt], 0, 0, 0);
-            if (g + RD < 16 * T2W) ring[g % RD] = __builtin_bit_cast(uint4, ft_wload(W3, (unsigned)(g + RD) * W3.row2 + (unsigned)(32 * wave) * 16u, 0));
+                acc3[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[g % RD]), __builtin_bit_cast(bf16x8, bq[g % PD][mt]), acc3[0][mt], 0, 0, 0);
+            if (g + PD < 16 * T2W) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) bq[g % PD][mt] = bl3[(size_t)(2 * (g + PD)) * LD + 32 * mt];
+            }
+            if (g + RD < 16 * T2W) ring[g % RD] = __builtin_bit_cast(uint4, ft_wload(W3, W0 ? 0u : (unsigned)(g + RD) * W3.row2 + (unsigned)(32 * wave) * 16u, 0));
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -863,11 +888,11 @@ bool frk_fused_h_ok(int K, int H1, int H2, int H3) {
 
 int frk_fused_h_items_per_wg() { return 64; }
 
-template <int MT, int T2W, int KG, bool DB, int RD>
+template <int MT, int T2W, int KG, bool DB, int RD, int PD, bool SYNC = true, bool W0 = false>
 static int fused_h_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     static FrLdsAttrOnce lds_once;  // per instantiation, per device
-    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_h_kernel<MT, T2W, KG, DB, RD>, lds_once)) return rc_;
-    fr_fused_tile_h_kernel<MT, T2W, KG, DB, RD><<<grid, dim3(512), lds, s>>>(a);
+    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_h_kernel<MT, T2W, KG, DB, RD, PD, SYNC, W0>, lds_once)) return rc_;
+    fr_fused_tile_h_kernel<MT, T2W, KG, DB, RD, PD, SYNC, W0><<<grid, dim3(512), lds, s>>>(a);
     KCHECK();
     return FR_OK;
 }
@@ -875,24 +900,23 @@ static int fused_h_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipS
 // a.w1q/w2q/w3q/wout must point at the bf16 q8 weights; a.tiles_per_batch counts 64-item tiles
 int frk_fused_h_launch(const FrFusedArgs &a, hipStream_t s) {
     dim3 grid(a.n_batches * a.tiles_per_batch);
-    static const int ring = [] { const char *e = getenv("FR_FUSED_H_RING"); return e ? atoi(e) : 16; }();  // experiment knob: weight-ring depth
-    if (a.K == 352) return fused_h_launch_inst<2, 2, 22, true, 16>(a, grid, fused_h_lds_bytes(a.K, a.H2, a.H3, 2, true), s);
+    // experiment knob: FR_FUSED_H_RING = 100 * (B-ring depth) + weight-ring depth (tools/experiments/fused_h_stamps.py); negative:
+    // timing-only variants that return wrong scores (-1: no barriers in the chunk loop, -2: every weight load hits the same 1 KiB)
+    static const int knob = [] { const char *e = getenv("FR_FUSED_H_RING"); return e ? atoi(e) : 0; }();
+    if (a.K == 352) return fused_h_launch_inst<2, 2, 22, true, 16, 2>(a, grid, fused_h_lds_bytes(a.K, a.H2, a.H3, 2, true), s);
     if (a.K == 880) {
         const size_t lds = fused_h_lds_bytes(a.K, a.H2, a.H3, 2, false);
-        if (ring == 32) return fused_h_launch_inst<2, 2, 55, false, 32>(a, grid, lds, s);
-        if (ring == -16) {  // timing experiment: the chunk loop without its barriers (wrong results)
-            static FrLdsAttrOnce once;
-            if (int rc_ = fr_allow_full_lds(&fr_fused_tile_h_kernel<2, 2, 55, false, 16, false>, once)) return rc_;
-            fr_fused_tile_h_kernel<2, 2, 55, false, 16, false><<<grid, dim3(512), lds, s>>>(a);
-            KCHECK();
-            return FR_OK;
+        switch (knob) {
+            case 108: return fused_h_launch_inst<2, 2, 55, false, 8, 1>(a, grid, lds, s);
+            case 112: return fused_h_launch_inst<2, 2, 55, false, 12, 1>(a, grid, lds, s);
+            case 208: return fused_h_launch_inst<2, 2, 55, false, 8, 2>(a, grid, lds, s);
+            case 212: return fused_h_launch_inst<2, 2, 55, false, 12, 2>(a, grid, lds, s);
+            case 408: return fused_h_launch_inst<2, 2, 55, false, 8, 4>(a, grid, lds, s);
+            case 412: return fused_h_launch_inst<2, 2, 55, false, 12, 4>(a, grid, lds, s);
+            case -1: return fused_h_launch_inst<2, 2, 55, false, 8, 4, false, false>(a, grid, lds, s);
+            case -2: return fused_h_launch_inst<2, 2, 55, false, 8, 4, true, true>(a, grid, lds, s);
+            default: return fused_h_launch_inst<2, 2, 55, false, 12, 2>(a, grid, lds, s);
         }
-        if (ring == 24) return fused_h_launch_inst<2, 2, 55, false, 24>(a, grid, lds, s);
-        if (ring == 20) return fused_h_launch_inst<2, 2, 55, false, 20>(a, grid, lds, s);
-        if (ring == 18) return fused_h_launch_inst<2, 2, 55, false, 18>(a, grid, lds, s);
-        if (ring == 12) return fused_h_launch_inst<2, 2, 55, false, 12>(a, grid, lds, s);
-        if (ring == 8) return fused_h_launch_inst<2, 2, 55, false, 8>(a, grid, lds, s);
-        return fused_h_launch_inst<2, 2, 55, false, 16>(a, grid, lds, s);
     }
     FR_FAIL(FR_ERR_INVALID, "no bf16 fused instantiation for K=%d", a.K);
 }
