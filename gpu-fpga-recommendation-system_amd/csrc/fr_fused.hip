@@ -644,7 +644,7 @@ __device__ __forceinline__ void fth_store_tile(uint4 *img, int ld, const f32x16 
     }
 }
 
-template <int MT, int T2W, int KG, bool DB, int RD, int PD = 2, bool SYNC = true, bool W0 = false>  // !SYNC, W0: timing experiments (wrong results)
+template <int MT, int T2W, int KG, bool DB, int RD, int PD>
 __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs a) {
     extern __shared__ uint4 lds[];
     constexpr int LD = 32 * MT + 1, TI = 32 * MT;
@@ -736,9 +736,8 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
     static_assert(T2W == 2 && KG >= RD && RD >= 8 && RD <= 32 && RD % 2 == 0, "the stream ring assumes two n tiles per wave in FC2 (32 elements per chunk) and at least RD k groups in FC1");
     constexpr int OFF2 = KG % RD;
     uint4 ring[RD];
-    auto w1load = [&](int c, int g) { return __builtin_bit_cast(uint4, ft_wload(W1, W0 ? 0u : (unsigned)g * W1.row2 + (unsigned)(c * 256 + 32 * wave) * 16u, 0)); };
+    auto w1load = [&](int c, int g) { return __builtin_bit_cast(uint4, ft_wload(W1, (unsigned)g * W1.row2 + (unsigned)(c * 256 + 32 * wave) * 16u, 0)); };
     auto w2load = [&](int c, int e) {
-        if (W0) return __builtin_bit_cast(uint4, ft_wload(W2, 0u, 0));
         return __builtin_bit_cast(uint4, ft_wload(W2, (unsigned)(16 * c + (e >> 1)) * W2.row2 + (unsigned)(32 * T2W * wave) * 16u, 512 * (e & 1)));
     };
 #pragma unroll
@@ -775,10 +774,10 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
         }
         stamp();
         uint4 *R1 = R1b[DB ? (c & 1) : 0];
-        if (SYNC && !DB && c > 0) __syncthreads();  // single R1 buffer: every wave must be done reading the previous chunk
+        if (!DB && c > 0) __syncthreads();  // single R1 buffer: every wave must be done reading the previous chunk
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) fth_store_tile(R1, LD, acc1[0][mt], 32 * wave, 32 * mt, hk, lm);
-        if (SYNC) __syncthreads();  // !SYNC: timing experiment only (results are garbage)
+        __syncthreads();
         // FC2: K range [256 c, 256 c + 256) = 16 groups of 16 k; its tail requests the next stream: W1 chunk c + 1, or W3 after the last chunk
         const bool last = c + 1 == n_chunks;
         FtW WN = W1;
@@ -804,7 +803,7 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
             for (int t = 0; t < T2W; t++) {
                 const int r = (2 * j + t + OFF2) % RD;
                 if (2 * j + t + RD < 32) ring[r] = w2load(c, 2 * j + t + RD);
-                else ring[r] = __builtin_bit_cast(uint4, ft_wload(WN, W0 ? 0u : (unsigned)r * WN.row2 + nsoff, 0));  // group r of the next stream lives in slot r
+                else ring[r] = __builtin_bit_cast(uint4, ft_wload(WN, (unsigned)r * WN.row2 + nsoff, 0));  // group r of the next stream lives in slot r
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -837,7 +836,7 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) bq[g % PD][mt] = bl3[(size_t)(2 * (g + PD)) * LD + 32 * mt];
             }
-            if (g + RD < 16 * T2W) ring[g % RD] = __builtin_bit_cast(uint4, ft_wload(W3, W0 ? 0u : (unsigned)(g + RD) * W3.row2 + (unsigned)(32 * wave) * 16u, 0));
+            if (g + RD < 16 * T2W) ring[g % RD] = __builtin_bit_cast(uint4, ft_wload(W3, (unsigned)(g + RD) * W3.row2 + (unsigned)(32 * wave) * 16u, 0));
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -888,11 +887,11 @@ bool frk_fused_h_ok(int K, int H1, int H2, int H3) {
 
 int frk_fused_h_items_per_wg() { return 64; }
 
-template <int MT, int T2W, int KG, bool DB, int RD, int PD, bool SYNC = true, bool W0 = false>
+template <int MT, int T2W, int KG, bool DB, int RD, int PD>
 static int fused_h_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     static FrLdsAttrOnce lds_once;  // per instantiation, per device
-    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_h_kernel<MT, T2W, KG, DB, RD, PD, SYNC, W0>, lds_once)) return rc_;
-    fr_fused_tile_h_kernel<MT, T2W, KG, DB, RD, PD, SYNC, W0><<<grid, dim3(512), lds, s>>>(a);
+    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_h_kernel<MT, T2W, KG, DB, RD, PD>, lds_once)) return rc_;
+    fr_fused_tile_h_kernel<MT, T2W, KG, DB, RD, PD><<<grid, dim3(512), lds, s>>>(a);
     KCHECK();
     return FR_OK;
 }
@@ -900,8 +899,9 @@ static int fused_h_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipS
 // a.w1q/w2q/w3q/wout must point at the bf16 q8 weights; a.tiles_per_batch counts 64-item tiles
 int frk_fused_h_launch(const FrFusedArgs &a, hipStream_t s) {
     dim3 grid(a.n_batches * a.tiles_per_batch);
-    // experiment knob: FR_FUSED_H_RING = 100 * (B-ring depth) + weight-ring depth (tools/experiments/fused_h_stamps.py); negative:
-    // timing-only variants that return wrong scores (-1: no barriers in the chunk loop, -2: every weight load hits the same 1 KiB)
+    // experiment knob: FR_FUSED_H_RING = 100 * (B-ring depth) + weight-ring depth (tools/experiments/fused_h_stamps.py); every
+    // variant returns the same bits.  (The timing-only ablations quoted in profiles/r02_experiments.md section 5.4 -- chunk loop without
+    // barriers, weight loads forced to one address -- returned wrong scores and are not kept in the product.)
     static const int knob = [] { const char *e = getenv("FR_FUSED_H_RING"); return e ? atoi(e) : 0; }();
     if (a.K == 352) return fused_h_launch_inst<2, 2, 22, true, 16, 2>(a, grid, fused_h_lds_bytes(a.K, a.H2, a.H3, 2, true), s);
     if (a.K == 880) {
@@ -913,8 +913,6 @@ int frk_fused_h_launch(const FrFusedArgs &a, hipStream_t s) {
             case 212: return fused_h_launch_inst<2, 2, 55, false, 12, 2>(a, grid, lds, s);
             case 408: return fused_h_launch_inst<2, 2, 55, false, 8, 4>(a, grid, lds, s);
             case 412: return fused_h_launch_inst<2, 2, 55, false, 12, 4>(a, grid, lds, s);
-            case -1: return fused_h_launch_inst<2, 2, 55, false, 8, 4, false, false>(a, grid, lds, s);
-            case -2: return fused_h_launch_inst<2, 2, 55, false, 8, 4, true, true>(a, grid, lds, s);
             default: return fused_h_launch_inst<2, 2, 55, false, 12, 2>(a, grid, lds, s);
         }
     }
