@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfleetrec.so")
+LIB_PATH = os.environ.get("FR_LIB") or os.path.join(_HERE, "libfleetrec.so")   # FR_LIB: A/B experiments load another build of the same ABI
 
 FR_OK, FR_ERR_INVALID, FR_ERR_NO_DEVICE, FR_ERR_OOM, FR_ERR_HIP, FR_ERR_INDEX_RANGE, FR_ERR_STATE, FR_ERR_COMM = 0, -1, -2, -3, -4, -5, -6, -7
 MODEL_A, MODEL_B, MODEL_C = 0, 1, 2
