@@ -30,4 +30,28 @@ for name, (M, N, K) in shapes.items():
         us = e0.elapsed_time(e1) * 1e3 / reps
         out[f"{name}_{tag}"] = {"us": round(us, 2), "tflops": round(2.0 * M * N * K / us / 1e6, 1)}
         print(name, tag, out[f"{name}_{tag}"], flush=True)
+# fp8 (OCP e4m3) through torch._scaled_mm (hipBLASLt): per-tensor scales, bf16 output
+try:
+    for name in ("C_FC1_b4096", "C_FC2_b4096", "B_FC1_16x1024", "square_8192"):
+        M, N, K = shapes[name]
+        Kp = (K + 15) // 16 * 16
+        x = ((torch.rand(M, Kp, device=dev) * 2 - 1)).to(torch.float8_e4m3fn)
+        w = ((torch.rand(N, Kp, device=dev) * 2 - 1)).to(torch.float8_e4m3fn)
+        one = torch.tensor(1.0, device=dev)
+        f = lambda: torch._scaled_mm(x, w.t(), scale_a=one, scale_b=one, out_dtype=torch.bfloat16)
+        for _ in range(20):
+            y = f()
+        torch.cuda.synchronize()
+        reps = 200 if M * N * K < 4e11 else 30
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            y = f()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        out[f"{name}_fp8"] = {"us": round(us, 2), "tflops": round(2.0 * M * N * K / us / 1e6, 1)}
+        print(name, "fp8", out[f"{name}_fp8"], flush=True)
+except Exception as ex:  # the fp8 path of this torch build may be missing: the bf16 / f32 rows stand on their own
+    out["fp8_error"] = repr(ex)[:300]
+    print("fp8 reference unavailable:", out["fp8_error"], flush=True)
 json.dump(out, open(sys.argv[1] if len(sys.argv) > 1 else "/dev/stdout", "w"), indent=1)
