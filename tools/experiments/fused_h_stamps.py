@@ -39,6 +39,9 @@ for i, nme in enumerate(names):
     prev = np.median(col)
 print("per wave (median over workgroups, us since the workgroup's wave 0 started): " + "  ".join(names[1:]))
 for w in range(8):
+    if not (sw[:, w, 1] > 0).any():
+        continue
     print("wave %d: " % w + "  ".join("%5.1f" % np.median((sw[:, w, i] - sw[:, 0, 0]) / 100.0) for i in range(1, 11)))
-clk = (sw[:, :, 15] - sw[:, :, 14]) / np.maximum(sw[:, :, 9] - sw[:, :, 1], 1) * 0.1   # shader cycles per 10 ns tick -> GHz
-print("in-kernel clock over the FC1 / FC2 chunks (s_memtime / s_memrealtime, median over waves): %.3f GHz; shader cycles there: %.0f (MFMA work per SIMD: 4 x 348 x 32 = 44544)" % (np.median(clk), np.median(sw[:, :, 15] - sw[:, :, 14])))
+live = sw[:, :, 1] > 0   # the 4-wave kernel stamps waves 0..3 only
+clk = ((sw[:, :, 15] - sw[:, :, 14]) / np.maximum(sw[:, :, 9] - sw[:, :, 1], 1) * 0.1)[live]   # shader cycles per 10 ns tick -> GHz
+print("in-kernel clock over the FC1 / FC2 chunks (s_memtime / s_memrealtime, median over waves): %.3f GHz; shader cycles there: %.0f (MFMA work per SIMD: 4 x 348 x 32 = 44544)" % (np.median(clk), np.median((sw[:, :, 15] - sw[:, :, 14])[live])))
