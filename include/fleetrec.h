@@ -252,7 +252,8 @@ int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_idx, const f
 int fr_ctx_stream_group(const fr_ctx *ctx);
 /* Throughput/latency knob of the fused streaming path, PER CONTEXT: batches per launch, 1..64.  64 batches of 256 items = one 64-item
  * workgroup per CU (fp32: fr_fused_tile_m2_kernel); <= 32 selects the 32-item kernel, halves the queueing latency of a pushed batch and
- * leaves CUs to other streams.  Scores are bit-identical for every group size.  May be called while workers are pushing (atomic); a
+ * leaves CUs to other streams (a partial launch -- fr_worker_sync with few batches queued -- whose 64-item tiles would cover at most half
+ * of the CUs takes the 32-item kernel too).  Scores are bit-identical for every group size.  May be called while workers are pushing (atomic); a
  * worker's queue that already holds >= the new size launches at its next push or sync. */
 int fr_ctx_set_stream_group(fr_ctx *ctx, int batches_per_launch);
 /* Host-fed streaming: like fr_worker_push_device for a batch that sits in (any) host memory.  The rows are copied into the worker's

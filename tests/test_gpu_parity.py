@@ -577,9 +577,9 @@ def test_size_independent_properties(fr, ctxs):
 
 
 def test_streaming_push_matches_submit(fr, O, ctxs):
-    """fr_worker_push_device: consecutive batches ride the stage pipeline (gather | FC1 | FC2 | FC3 | out of five
-    different batches in ONE launch).  Scores must equal the unpipelined submit()/sync() results bit for bit,
-    for ragged batch sizes, pipelines shorter and longer than its depth, and a sync in the middle."""
+    """fr_worker_push_device: pushed batches are queued and launched a group at a time through the fused item-tile kernels (32-item
+    kernel for small launches, 64-item kernel for launches that cover the chip).  Scores must equal the unpipelined submit()/sync()
+    results to 1e-5, and bit for bit from run to run, whatever the batch sizes, the sync points, the group size and the kernel."""
     m, ctx = ctxs(fr.MODEL_A)
     rng = np.random.default_rng(31)
     sizes = [256, 256, 1, 37, 256, 64, 200, 256, 255, 256, 33, 256]
@@ -621,6 +621,18 @@ def test_streaming_push_matches_submit(fr, O, ctxs):
     ctx.set_stream_group(g0)
     with pytest.raises(fr.FleetRecError):
         ctx.set_stream_group(0)
+    # the 64-item kernel (fr_fused_tile_m2_kernel) takes a launch only when its workgroups would cover more than half of the CUs
+    # (> 128 tiles of 64 items): 40 queued batches of 256 = 160 tiles.  Same bits as the 32-item kernel that ran everything above.
+    if g0 >= 64:
+        full = [j for j, b in enumerate(sizes) if b == 256]
+        many = [fr.DeviceBuffer(ctx, 256 * 4) for _ in range(40)]
+        for k_, buf in enumerate(many):
+            wk.push_device(256, d_idx[full[k_ % len(full)]], None, buf)
+        wk.sync()
+        for k_, buf in enumerate(many):
+            assert np.array_equal(buf.download(np.float32, 256), first_run[full[k_ % len(full)]]), k_
+        for buf in many:
+            buf.free()
     # mixing: a plain submit is refused while pushes are in flight, and works again after sync
     wk.push_device(256, d_idx[0], None, d_sc[0])
     with pytest.raises(fr.FleetRecError) as e:
