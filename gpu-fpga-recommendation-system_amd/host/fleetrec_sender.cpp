@@ -6,6 +6,8 @@
 //
 // Usage: fleetrec_sender --model A|B|C [--batch 256] [--threads 4] [--port 8080] [--host 127.0.0.1]
 //                        [--indices reference|uniform] [--per-item | --per-bank] [--row-cap N] [--max-blocks N] [--reply]
+//                        [--pool N]   (uniform indices: N distinct blocks per connection are generated up front and sent in rotation --
+//                                      drawing 12 k random indices per block is slower than the server; default 32, 0 = draw every block)
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
@@ -28,7 +30,7 @@ static const int kIdxRandom[32] = {3, 99, 38, 72, 29, 57, 1, 72, 36, 76, 35, 50,
 
 int main(int argc, char **argv) {
     int which = FR_MODEL_A, batch = 256, threads = 4, port = 8080;
-    long row_cap = 0, max_blocks = 1L << 40, interval_us = 0;
+    long row_cap = 0, max_blocks = 1L << 40, interval_us = 0, pool = 32;
     std::string host = "127.0.0.1", indices = "reference";
     bool per_item = false, per_bank = false, reply = false;
     for (int i = 1; i < argc; i++) {
@@ -46,6 +48,7 @@ int main(int argc, char **argv) {
         else if (a == "--row-cap") row_cap = atol(next());
         else if (a == "--max-blocks") max_blocks = atol(next());
         else if (a == "--interval-us") interval_us = atol(next());
+        else if (a == "--pool") pool = atol(next());
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     fr_model_desc *m = nullptr;
@@ -79,20 +82,35 @@ int main(int argc, char **argv) {
                 usleep(100000);
             }
             setsockopt(sock, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-            for (long blk = 0; blk < max_blocks; blk++) {
+            auto draw = [&](int32_t *ix, float *dn) {
                 for (int b = 0; b < batch; b++) {
                     for (size_t c = 0; c < cols; c++) {
                         int32_t v;
                         if (indices == "reference") v = kIdxRandom[b % 32];  // same index for every table of the item (F4)
                         else v = (int32_t)(rng() % (uint64_t)col_range[c]);
-                        idx[(size_t)b * cols + c] = v;
+                        ix[(size_t)b * cols + c] = v;
                     }
                     for (int d = 0; d < m->dense_len; d++)
-                        dense[(size_t)b * m->dense_len + d] = (indices == "reference") ? ((kIdxRandom[b % 32] % 2 == 0) ? 1.0f : 0.0f)
-                                                                                        : (float)((rng() >> 11) * (2.0 / 9007199254740992.0) - 1.0);
+                        dn[(size_t)b * m->dense_len + d] = (indices == "reference") ? ((kIdxRandom[b % 32] % 2 == 0) ? 1.0f : 0.0f)
+                                                                                     : (float)((rng() >> 11) * (2.0 / 9007199254740992.0) - 1.0);
                 }
-                if (send(sock, idx.data(), idx.size() * 4, MSG_NOSIGNAL) <= 0) break;
-                if (!dense.empty() && send(sock, dense.data(), dense.size() * 4, MSG_NOSIGNAL) <= 0) break;
+            };
+            // the reference pattern is one block; uniform indices: `pool` blocks drawn up front and sent in rotation
+            const long n_pool = indices == "reference" ? 1 : pool;
+            std::vector<int32_t> pidx((size_t)(n_pool > 0 ? n_pool : 0) * idx.size());
+            std::vector<float> pdense((size_t)(n_pool > 0 ? n_pool : 0) * dense.size());
+            for (long q = 0; q < n_pool; q++) draw(pidx.data() + (size_t)q * idx.size(), pdense.data() + (size_t)q * dense.size());
+            for (long blk = 0; blk < max_blocks; blk++) {
+                const int32_t *bi = idx.data();
+                const float *bd = dense.data();
+                if (n_pool > 0) {
+                    bi = pidx.data() + (size_t)(blk % n_pool) * idx.size();
+                    bd = pdense.data() + (size_t)(blk % n_pool) * dense.size();
+                } else {
+                    draw(idx.data(), dense.data());
+                }
+                if (send(sock, bi, idx.size() * 4, MSG_NOSIGNAL) <= 0) break;
+                if (!dense.empty() && send(sock, bd, dense.size() * 4, MSG_NOSIGNAL) <= 0) break;
                 sent[t]++;
                 if (interval_us > 0) usleep((useconds_t)interval_us);  // rate limit of the latency experiment (reference sender: usleep(useconds))
                 if (reply) {

@@ -41,6 +41,7 @@ def test_server_and_sender_known_answer(fr, gpu, model, val, extra):
     out = out.decode()
     assert srv.returncode == 0, out
     assert "processed %d batches" % total in out, out
+    assert re.search(r"first connection -> last scores: [0-9.]+ s = [0-9.]+ M inferences/s over TCP", out), out
     rows = re.findall(r"thread \d+ scores:((?: [-0-9.e+]+)+)", out)
     assert 1 <= len(rows) <= threads   # a thread that connected after the last batch was taken prints no scores
     assert len(rows) + out.count("took no batch") == threads
