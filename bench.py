@@ -296,6 +296,63 @@ def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# the request path over TCP: fleetrec_sender -> fleetrec_server --stream on loopback, own processes
+# ------------------------------------------------------------------------------------------------------------------
+def free_port_block(n):
+    import random
+    for _ in range(200):
+        base = random.randint(20000, 60000 - n)
+        socks = []
+        try:
+            for i in range(n):
+                sk = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                sk.bind(("0.0.0.0", base + i))
+                socks.append(sk)
+            return base
+        except OSError:
+            continue
+        finally:
+            for sk in socks:
+                sk.close()
+    raise RuntimeError("no free block of %d ports" % n)
+
+
+def leg_tcp(B, device, threads=4, total=1000000):
+    """Model-A batch B through the request path the reference has: `threads` TCP connections (the reference's THREAD_NUM = 4 on PORT+i),
+    fixed-size blocks of B x 47 int32 indices on the wire, the server's connection threads handing every block to fr_worker_push_host,
+    scores delivered to host memory.  The server (its own process and context on the same GPU) reports the rate from its first accept()
+    to the join of its threads."""
+    import re
+    host = os.path.join(ROOT, "gpu-fpga-recommendation-system_amd", "host")
+    srv_bin, snd_bin = os.path.join(host, "fleetrec_server"), os.path.join(host, "fleetrec_sender")
+    if not (os.path.exists(srv_bin) and os.path.exists(snd_bin)):
+        return {"skipped": "host programs not built (make -C gpu-fpga-recommendation-system_amd/host)"}
+    port = free_port_block(threads)
+    common = ["--model", "A", "--batch", str(B), "--threads", str(threads), "--port", str(port)]
+    srv = subprocess.Popen([srv_bin] + common + ["--total", str(total), "--device", str(device), "--tables", "hash", "--weights", "uniform", "--stream"],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    snd = None
+    try:
+        time.sleep(0.3)
+        snd = subprocess.Popen([snd_bin] + common + ["--indices", "uniform"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        out, _ = srv.communicate(timeout=120)
+    finally:
+        for p_ in (srv, snd):
+            if p_ is not None and p_.poll() is None:
+                p_.kill()
+                p_.wait()
+    out = out.decode(errors="replace")
+    m_ = re.search(r"first connection -> last scores: ([0-9.]+) s = ([0-9.]+) M inferences/s over TCP", out)
+    if srv.returncode != 0 or not m_:
+        return {"error": out[-400:]}
+    return {"value": float(m_.group(2)) * 1e6, "unit": "inferences/s", "timed_s": float(m_.group(1)), "timed_batches": total, "connections": threads,
+            "what": "fleetrec_sender -> fleetrec_server --stream over loopback TCP (own processes): %d connections, B x 47 int32 per batch on the wire "
+                    "(32 pre-drawn uniform blocks per connection in rotation), fr_worker_push_host per block, scores to host memory; the server's clock "
+                    "from its first accept() to the join of its connection threads" % threads}
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # GPU legs
 # ------------------------------------------------------------------------------------------------------------------
 def leg_group_table(fr, ctx, model, B, d_idx, threads, depth):
@@ -642,7 +699,7 @@ def main():
     ap.add_argument("--precision", choices=["f32", "bf16", "fp8"], default="f32",
                     help="FC chain arithmetic (bf16 = BASELINE configs[2], fp8 = configs[4]: e4m3, calibrated on the first batch)")
     ap.add_argument("--legs", default="all",
-                    help="comma list of the extra legs rank 0 runs at N = 1: roofline,groups,pcie,cpu,configs,gather,bank (default all; 'none' = headline only)")
+                    help="comma list of the extra legs rank 0 runs at N = 1: roofline,groups,pcie,tcp,cpu,configs,gather,bank (default all; 'none' = headline only)")
     ap.add_argument("--gather-law", choices=["all", "uniform", "zipf"], default="all", help="gather leg: per-table index law(s) to run (PMC passes: one law per kernel name)")
     ap.add_argument("--transport", choices=["f32", "lp"], default="lp",
                     help="sharded mode: slices travel as fp32, or (lp) in the chain's own operand type when --precision is bf16 / fp8")
@@ -833,6 +890,12 @@ def main():
                                               "what": "host-resident request stream, scores delivered to host memory: blocks of 64 batches staged in pinned "
                                                       "memory, one H2D + one fused launch + one D2H per block (fr_worker_push_host), %d threads x %d workers"
                                                       % (ht, args.depth)}
+
+    if want("tcp"):
+        try:
+            result["tcp_streaming"] = leg_tcp(B, local_rank)
+        except Exception as ex:
+            result["tcp_streaming"] = {"error": repr(ex)[:300]}
 
     if want("cpu"):
         try:
