@@ -725,14 +725,15 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
     const int n_chunks = a.H1 / 256;
     // q8 weights: (K / 8) rows of N 16-byte elements -> ft_w's K / 4 rows of the q4 layout is K / 2 here
     const FtW W1 = ft_w(a.w1q, a.K / 2, a.H1, hk, lm), W2 = ft_w(a.w2q, a.H1 / 2, a.H2, hk, lm), W3 = ft_w(a.w3q, a.H2 / 2, a.H3, hk, lm);
-    // ONE weight ring of 16 registers (16-byte fragments) feeds FC1, FC2 and FC3 as a continuous stream: a slot freed by the last 16
-    // groups of FC1 is refilled with the first elements of this chunk's FC2 weights, a slot freed by the last 8 groups of FC2 with the
+    // ONE weight ring of RD 16-byte register fragments feeds FC1, FC2 and FC3 as a continuous stream: a slot freed by the last RD
+    // groups of FC1 is refilled with the first elements of this chunk's FC2 weights, a slot freed by the last RD elements of FC2 with the
     // first groups of the next chunk's FC1 weights (or of W3 after the last chunk).  With a ring of its own every GEMM phase used to start
     // cold -- all 8 waves waiting for an L2 round trip at once: FC2's 16 groups took 5.4 us for 1.95 us of MFMA work, FC3 6.0 us
-    // (tools/experiments/fused_h_stamps.py).  FC1 group g lives in slot g % 16, W3 group g likewise, FC2 element e = 2 j + t (group j,
-    // n tile t) in slot (e + OFF2) % 16 with OFF2 = KG % 16 -- the slot FC1's tail frees first.  Every index is a compile-time
-    // constant (the bodies are unrolled), so the ring stays in registers and hipcc counts the vmcnt waits.  The order of the sums is
-    // unchanged: scores are bit-identical to the per-phase rings.
+    // (tools/experiments/fused_h_stamps.py).  FC1 group g lives in slot g % RD, W3 group g likewise, FC2 element e = 2 j + t (group j,
+    // n tile t) in slot (e + OFF2) % RD with OFF2 = KG % RD -- the slot FC1's tail frees first.  Every index is a compile-time
+    // constant (the bodies are unrolled), so the ring stays in registers and hipcc counts the vmcnt waits.  The order of the sums does
+    // not depend on RD: scores are bit-identical for every depth.  Depths of 8, 12 and 16 take the same time (the weight stream is not
+    // latency-bound, profiles/r02_experiments.md section 5.4); 12 leaves the registers for the B-fragment ring below.
     static_assert(T2W == 2 && KG >= RD && RD >= 8 && RD <= 32 && RD % 2 == 0, "the stream ring assumes two n tiles per wave in FC2 (32 elements per chunk) and at least RD k groups in FC1");
     constexpr int OFF2 = KG % RD;
     uint4 ring[RD];
