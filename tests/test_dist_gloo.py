@@ -188,3 +188,22 @@ def test_bench_two_ranks_on_one_gpu(gpu, extra):
             assert chk["bit_identical"] is True, c
     else:
         assert j["timed_batches"] >= 300 and j["timed_s"] >= 2.0 and j["scaling"] == "weak"
+
+
+def test_bench_tcp_leg_fails_cleanly_without_a_gpu():
+    """bench.py's tcp leg (fleetrec_sender -> fleetrec_server --stream in their own processes) on a host without a GPU: the server's
+    set-up fails loudly (no CPU fallback), the leg reports it and leaves no process behind instead of hanging."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    base = bench.free_port_block(4)
+    assert 20000 <= base < 60000
+    import __graft_entry__ as g
+    if g.load_package().device_count() > 0:
+        pytest.skip("a GPU is visible: the GPU suite covers the working path (tests/test_gpu_server.py)")
+    t0 = time.time()
+    r = bench.leg_tcp(256, 0, threads=2, total=64)
+    assert ("error" in r or "skipped" in r) and "value" not in r, r
+    assert time.time() - t0 < 60
