@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "fr_worker_submit_sharded", "fr_worker_calibrate_fp8_sharded", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
     "fr_ctx_fill_tables", "fr_ctx_upload_table", "fr_ctx_download_table", "fr_ctx_set_weights", "fr_ctx_fill_weights",
     "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_ctx_get_fp8_exponents", "fr_ctx_set_fp8_act_exponents",
-    "fr_worker_calibrate_fp8", "fr_worker_calibrate_fp8_slices", "fr_worker_push_host", "fr_worker_stream", "fr_worker_gather_slices", "fr_worker_fc_from_slices_lp", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
+    "fr_worker_calibrate_fp8", "fr_worker_calibrate_fp8_slices", "fr_worker_push_host", "fr_worker_stage_acquire", "fr_worker_push_staged", "fr_worker_stream", "fr_worker_gather_slices", "fr_worker_fc_from_slices_lp", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
     "fr_worker_dense_ptr", "fr_worker_score_ptr", "fr_worker_submit", "fr_worker_submit_device", "fr_worker_push_device", "fr_worker_sync",
     "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
@@ -99,6 +99,7 @@ def lib():
         "fr_ctx_get_weights": (i32, [vp, i32, vp, sz]), "fr_ctx_set_fc_precision": (i32, [vp, i32]),
         "fr_ctx_get_fp8_exponents": (i32, [vp, vp, vp]), "fr_ctx_set_fp8_act_exponents": (i32, [vp, vp]),
         "fr_worker_push_host": (i32, [vp, i32, vp, vp, vp]), "fr_worker_stream": (vp, [vp]),
+        "fr_worker_stage_acquire": (i32, [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp)]), "fr_worker_push_staged": (i32, [vp, i32, vp]),
         "fr_worker_gather_slices": (i32, [vp, i32, vp, vp, vp, i32]), "fr_worker_fc_from_slices_lp": (i32, [vp, i32, i32, i32, vp, i32, vp]),
         "fr_worker_calibrate_fp8": (i32, [vp, i32]), "fr_worker_calibrate_fp8_slices": (i32, [vp, i32, i32, i32, vp]),
         "fr_worker_create": (i32, [vp, i32, ctypes.POINTER(vp)]), "fr_worker_destroy": (None, [vp]),
@@ -538,6 +539,21 @@ class Worker:
         assert scores_out.dtype == np.float32 and scores_out.flags["C_CONTIGUOUS"] and scores_out.size >= B
         _check(lib().fr_worker_push_host(self._h, B, idx.ctypes.data_as(ctypes.c_void_p), None if d is None else d.ctypes.data_as(ctypes.c_void_p),
                                          scores_out.ctypes.data_as(ctypes.c_void_p)))
+
+    def stage_acquire(self, batch):
+        """Zero-copy host-fed push, step 1: numpy views (idx int32 [batch][idx_cols], dense float32 [batch][dense_len] or None) of the
+        worker's pinned staging slot for the NEXT pushed batch; fill them, then push_staged()."""
+        pi, pd = ctypes.c_void_p(), ctypes.c_void_p()
+        _check(lib().fr_worker_stage_acquire(self._h, batch, ctypes.byref(pi), ctypes.byref(pd)))
+        m = self.ctx.model
+        idx = np.ctypeslib.as_array(ctypes.cast(pi, ctypes.POINTER(ctypes.c_int32)), shape=(batch, m.idx_cols))
+        dense = np.ctypeslib.as_array(ctypes.cast(pd, ctypes.POINTER(ctypes.c_float)), shape=(batch, m.dense_len)) if (m.dense_len and pd.value) else None
+        return idx, dense
+
+    def push_staged(self, batch, scores_out):
+        """Step 2: queue the batch written into the acquired slot; scores_out as for push_host()."""
+        assert scores_out.dtype == np.float32 and scores_out.flags["C_CONTIGUOUS"] and scores_out.size >= batch
+        _check(lib().fr_worker_push_staged(self._h, batch, scores_out.ctypes.data_as(ctypes.c_void_p)))
 
     def push_device(self, batch, d_idx, d_dense, d_scores):
         _check(lib().fr_worker_push_device(self._h, batch, self._ptr(d_idx), self._ptr(d_dense), self._ptr(d_scores)))

@@ -1331,13 +1331,12 @@ static int host_block_launch(fr_worker *w) {
     return FR_OK;
 }
 
-extern "C" int fr_worker_push_host(fr_worker *w, int batch, const int32_t *h_idx, const float *h_dense, float *h_scores) {
+// The staging slot of the next pushed batch: the oldest block is delivered first if its staging memory is about to be reused.
+static int host_slot_prepare(fr_worker *w, int batch, int32_t **idx_slot, float **dense_slot) {
     int rc = check_ready(w, batch, true, true);
     if (rc) return rc;
     fr_ctx *c = w->ctx;
-    if (!h_idx || !h_scores) FR_FAIL(FR_ERR_INVALID, "NULL host pointer");
-    if (c->model.dense_len && !h_dense) FR_FAIL(FR_ERR_INVALID, "model has dense features but h_dense is NULL");
-    if (!fused_eligible(c)) FR_FAIL(FR_ERR_STATE, "fr_worker_push_host needs a model that streams through the fused item-tile kernel (use fr_worker_submit)");
+    if (!fused_eligible(c)) FR_FAIL(FR_ERR_STATE, "host-fed streaming needs a model that streams through the fused item-tile kernel (use fr_worker_submit)");
     FR_HIP(hipSetDevice(c->device));
     rc = host_ring_init(w);
     if (rc) return rc;
@@ -1348,8 +1347,15 @@ extern "C" int fr_worker_push_host(fr_worker *w, int batch, const int32_t *h_idx
         if (rc) return rc;
     }
     const int i = r.count[b];
-    memcpy(r.h_idx + ((size_t)b * r.g + i) * r.idx_slot, h_idx, (size_t)batch * idx_cols(c) * sizeof(int32_t));
-    if (r.dense_slot) memcpy(r.h_dense + ((size_t)b * r.g + i) * r.dense_slot, h_dense, (size_t)batch * c->model.dense_len * sizeof(float));
+    *idx_slot = r.h_idx + ((size_t)b * r.g + i) * r.idx_slot;
+    *dense_slot = r.dense_slot ? r.h_dense + ((size_t)b * r.g + i) * r.dense_slot : nullptr;
+    return FR_OK;
+}
+
+// The batch written into the current slot joins its block; a full block leaves (H2D, fused launch, D2H).
+static int host_slot_commit(fr_worker *w, int batch, float *h_scores) {
+    fr_worker::HostRing &r = w->hr;
+    const int b = r.cur, i = r.count[b];
     r.dst[b][i] = h_scores;
     r.bsz[b][i] = batch;
     r.count[b] = i + 1;
@@ -1357,9 +1363,48 @@ extern "C" int fr_worker_push_host(fr_worker *w, int batch, const int32_t *h_idx
     return (r.count[b] >= r.g) ? host_block_launch(w) : FR_OK;
 }
 
+extern "C" int fr_worker_push_host(fr_worker *w, int batch, const int32_t *h_idx, const float *h_dense, float *h_scores) {
+    if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
+    if (!h_idx || !h_scores) FR_FAIL(FR_ERR_INVALID, "NULL host pointer");
+    if (w->ctx->model.dense_len && !h_dense) FR_FAIL(FR_ERR_INVALID, "model has dense features but h_dense is NULL");
+    if (w->hr.staged) FR_FAIL(FR_ERR_STATE, "a staging slot is acquired: push it with fr_worker_push_staged first");
+    int32_t *si = nullptr;
+    float *sd = nullptr;
+    int rc = host_slot_prepare(w, batch, &si, &sd);
+    if (rc) return rc;
+    memcpy(si, h_idx, (size_t)batch * idx_cols(w->ctx) * sizeof(int32_t));
+    if (sd) memcpy(sd, h_dense, (size_t)batch * w->ctx->model.dense_len * sizeof(float));
+    return host_slot_commit(w, batch, h_scores);
+}
+
+extern "C" int fr_worker_stage_acquire(fr_worker *w, int batch, int32_t **h_idx, float **h_dense) {
+    if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
+    if (!h_idx) FR_FAIL(FR_ERR_INVALID, "h_idx is NULL");
+    if (w->ctx->model.dense_len && !h_dense) FR_FAIL(FR_ERR_INVALID, "model has dense features but h_dense is NULL");
+    if (w->hr.staged) FR_FAIL(FR_ERR_STATE, "a staging slot is already acquired");
+    int32_t *si = nullptr;
+    float *sd = nullptr;
+    int rc = host_slot_prepare(w, batch, &si, &sd);
+    if (rc) return rc;
+    *h_idx = si;
+    if (h_dense) *h_dense = sd;
+    w->hr.staged = batch;
+    return FR_OK;
+}
+
+extern "C" int fr_worker_push_staged(fr_worker *w, int batch, float *h_scores) {
+    if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
+    if (!h_scores) FR_FAIL(FR_ERR_INVALID, "h_scores is NULL");
+    if (!w->hr.staged) FR_FAIL(FR_ERR_STATE, "no staging slot acquired (fr_worker_stage_acquire)");
+    if (batch < 1 || batch > w->hr.staged) FR_FAIL(FR_ERR_INVALID, "batch %d outside (0, %d] acquired", batch, w->hr.staged);
+    w->hr.staged = 0;
+    return host_slot_commit(w, batch, h_scores);
+}
+
 static int host_ring_drain(fr_worker *w) {
     fr_worker::HostRing &r = w->hr;
     if (!r.g) return FR_OK;
+    r.staged = 0;                   // an acquired slot that was never pushed is dropped
     int rc = host_block_launch(w);  // partial block
     if (rc) return rc;
     for (int k = 0; k < FR_HOST_BLOCKS; k++) {

@@ -240,6 +240,7 @@ struct fr_worker {
         float *dst[4][FR_FUSED_MAX_BATCHES];  // where each batch's scores go
         int bsz[4][FR_FUSED_MAX_BATCHES];
         int cur = 0;               // block being filled
+        int staged = 0;            // batch size handed out by fr_worker_stage_acquire and not yet pushed (0: none)
     } hr;
     // table-sharded exchange (fr_worker_submit_sharded, fr_comm.cpp): this shard's slice, the all-gathered slices, score chunks
     void *d_slice = nullptr, *d_gathered = nullptr;

@@ -187,11 +187,9 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
             long long expect = 0;
             g_first_connection_ns.compare_exchange_strong(expect, std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count());
         }
-        // --stream: the socket is read into ordinary host memory and every batch is handed to fr_worker_push_host; scores come
-        // back in blocks, the last batch's are available after the final sync
+        // --stream: every batch is read into the worker's staging (fr_worker_stage_acquire / fr_worker_push_staged); scores come back
+        // in blocks, the last batch's are available after the final sync
         std::vector<float> stream_scores(o.stream ? (size_t)256 * o.batch : 0);
-        std::vector<int32_t> stream_idx(o.stream ? idx_bytes / sizeof(int32_t) : 0);
-        std::vector<float> stream_dense(o.stream ? dense_bytes / sizeof(float) : 0);
         std::vector<int32_t> sh_idx(g_engine ? idx_bytes / sizeof(int32_t) : 0);
         std::vector<float> sh_dense(g_engine ? dense_bytes / sizeof(float) : 0), sh_scores(g_engine ? (size_t)o.batch : 0);
         while (g_engine) {   // table-sharded mode: the whole batch is received here, then every shard works on it
@@ -231,13 +229,21 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
                 if (g_global_batch_count >= o.total) break;
                 g_global_batch_count++;
             }
-            if (!read_exact(sock, stream_idx.data(), idx_bytes) || (dense_bytes && !read_exact(sock, stream_dense.data(), dense_bytes))) {
+            // the socket is read straight into the worker's pinned staging slot (the reference reads into its pinned input_feature,
+            // cuda_server.c:437), then the slot is queued: no copy between the socket buffer and the H2D source
+            int32_t *slot_idx = nullptr;
+            float *slot_dense = nullptr;
+            if (fr_worker_stage_acquire(wk, o.batch, &slot_idx, &slot_dense) != FR_OK) {
+                t->status = -5;
+                t->error = fr_last_error();
+                break;
+            }
+            if (!read_exact(sock, slot_idx, idx_bytes) || (dense_bytes && !read_exact(sock, slot_dense, dense_bytes))) {
                 t->status = -4;
                 t->error = "Receiving data UNSUCCESSFUL (peer closed before the batch was complete)";
                 break;
             }
-            if (fr_worker_push_host(wk, o.batch, stream_idx.data(), dense_bytes ? stream_dense.data() : nullptr,
-                                    stream_scores.data() + (size_t)(t->batches % 256) * o.batch) != FR_OK) {
+            if (fr_worker_push_staged(wk, o.batch, stream_scores.data() + (size_t)(t->batches % 256) * o.batch) != FR_OK) {
                 t->status = -5;
                 t->error = fr_last_error();
                 break;

@@ -262,6 +262,14 @@ int fr_ctx_set_stream_group(fr_ctx *ctx, int batches_per_launch);
  * before its staging is reused, i.e. at the latest 4 blocks later -- but fr_worker_sync is the only completion point the API defines).
  * The streaming counterpart of the per-batch recv -> H2D -> GEMMs -> D2H sequence of cuda_server.c:425-495. */
 int fr_worker_push_host(fr_worker *w, int batch, const int32_t *h_idx, const float *h_dense, float *h_scores);
+/* The same without the copy into staging -- the reference's read() lands in pinned memory (cuda_server.c:136-160,437):
+ * fr_worker_stage_acquire hands out where the NEXT pushed batch of this worker has to be written (*h_idx: batch x index_cols int32,
+ * *h_dense: batch x dense_len floats or NULL; pinned, owned by the worker; it may first wait for the oldest block's scores and deliver
+ * them, exactly as fr_worker_push_host does), the caller fills it (e.g. reads the socket into it), fr_worker_push_staged queues it
+ * (batch <= the acquired size; h_scores as for fr_worker_push_host).  One slot at a time per worker; fr_worker_push_host between the
+ * two calls is FR_ERR_STATE; fr_worker_sync drops a slot that was acquired and never pushed. */
+int fr_worker_stage_acquire(fr_worker *w, int batch, int32_t **h_idx, float **h_dense);
+int fr_worker_push_staged(fr_worker *w, int batch, float *h_scores);
 /* Launches whatever is still queued, drains the pipeline and waits for everything enqueued on the worker; returns
  * FR_ERR_INDEX_RANGE if any index was out of range. */
 int fr_worker_sync(fr_worker *w);

@@ -709,6 +709,32 @@ def test_host_fed_streaming(fr, ctxs):
     for j, b in enumerate(sizes):
         assert np.array_equal(outs[j][:b], expect[j % 5]), j
         assert np.isnan(outs[j][b:]).all()
+    # the zero-copy form: the caller writes into the worker's pinned staging slot (fr_worker_stage_acquire) and queues it
+    # (fr_worker_push_staged), interleaved with copying pushes; same bits
+    outs2 = [np.full(256, np.nan, np.float32) for _ in sizes]
+    for j, b in enumerate(sizes):
+        if j % 3 == 2:
+            wk.push_host(pool[j % 5][:b], None, outs2[j])
+        else:
+            slot, dslot = wk.stage_acquire(256 if j % 2 else b)     # a slot may be acquired larger than what is pushed
+            assert dslot is None and slot.shape[1] == m.idx_cols
+            slot[:b] = pool[j % 5][:b]
+            if j == 7:
+                with pytest.raises(fr.FleetRecError) as e:          # one slot at a time; no copying push in between
+                    wk.push_host(pool[0], None, outs2[j])
+                assert e.value.status == fr.FR_ERR_STATE
+                with pytest.raises(fr.FleetRecError) as e:
+                    wk.stage_acquire(256)
+                assert e.value.status == fr.FR_ERR_STATE
+            wk.push_staged(b, outs2[j])
+    with pytest.raises(fr.FleetRecError) as e:
+        wk.push_staged(1, outs2[0])                                 # nothing acquired
+    assert e.value.status == fr.FR_ERR_STATE
+    wk.stage_acquire(256)                                           # acquired and never pushed: dropped by sync
+    wk.sync()
+    for j, b in enumerate(sizes):
+        assert np.array_equal(outs2[j][:b], expect[j % 5]), j
+        assert np.isnan(outs2[j][b:]).all()
     bad = pool[0].copy()
     bad[3, 5] = m.rows()[5]
     wk.push_host(bad, None, outs[0])
