@@ -1273,6 +1273,31 @@ def test_random_custom_models(fr, O, gpu, seed):
     wk = fr.Worker(ctx, B)
     got = wk.gather_records(idx, dense).reshape(B, m.record_len)
     assert np.array_equal(got, want.view(np.uint32))
+    # the XCD partition of the word-major gather (records of >= 64 words have one): covers the record, cuts between source rows only;
+    # and a batch large enough to take that kernel (>= 1024 items of a >= 512-word record) still gathers the same records
+    n_words = m.record_len // 4
+    if n_words >= 64:
+        st = ctx.gather_groups()
+        assert st[0] == 0 and st[8] == n_words and all(0 <= st[g + 1] - st[g] <= 256 for g in range(8)), st
+        cuts = {0, n_words}
+        for (k, src, c0, off, ln, _) in segs:
+            cuts.add(off // 4)
+            if k == fr.SEG_DENSE:
+                cuts.update(range(off // 4, (off + ln) // 4 + 1, 8))
+        assert set(st) <= cuts, (st, sorted(set(st) - cuts))
+    else:
+        with pytest.raises(fr.FleetRecError):
+            ctx.gather_groups()
+    if n_words >= 512:
+        B2 = 1024 + 77
+        idx2 = uniform_idx(rng, m.rows(), B2)
+        dense2 = rng.uniform(-1, 1, (B2, m.dense_len)).astype(np.float32) if m.dense_len else None
+        want2 = np.empty((B2, m.record_len), np.float32)
+        for (k, src, c0, off, ln, _) in segs:
+            want2[:, off:off + ln] = dense2[:, c0:c0 + ln] if k == fr.SEG_DENSE else host[src][idx2[:, src], c0:c0 + ln]
+        wk2 = fr.Worker(ctx, B2)
+        assert np.array_equal(wk2.gather_records(idx2, dense2).reshape(B2, m.record_len), want2.view(np.uint32))
+        wk2.close()
     scores = wk.infer(idx, dense)
     assert np.array_equal(wk.features(B), want.view(np.uint32).T)
     ref = O.OracleModel("A").fc_chain(want, ws, acc64=True, dims=fcw)
