@@ -900,23 +900,10 @@ static int fused_h_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipS
 // a.w1q/w2q/w3q/wout must point at the bf16 q8 weights; a.tiles_per_batch counts 64-item tiles
 int frk_fused_h_launch(const FrFusedArgs &a, hipStream_t s) {
     dim3 grid(a.n_batches * a.tiles_per_batch);
-    // experiment knob: FR_FUSED_H_RING = 100 * (B-ring depth) + weight-ring depth (tools/experiments/fused_h_stamps.py); every
-    // variant returns the same bits.  (The timing-only ablations quoted in profiles/r02_experiments.md section 5.4 -- chunk loop without
-    // barriers, weight loads forced to one address -- returned wrong scores and are not kept in the product.)
-    static const int knob = [] { const char *e = getenv("FR_FUSED_H_RING"); return e ? atoi(e) : 0; }();
+    // weight ring 16 (Model-A: 22 k groups per chunk) / 12 (Model-B) fragments, B fragments two groups ahead.  Ring depths 8 / 12 / 16 and
+    // B-ring depths 1 / 2 / 4 take the same time on the chip and return the same bits (profiles/r02_experiments.md section 5.4).
     if (a.K == 352) return fused_h_launch_inst<2, 2, 22, true, 16, 2>(a, grid, fused_h_lds_bytes(a.K, a.H2, a.H3, 2, true), s);
-    if (a.K == 880) {
-        const size_t lds = fused_h_lds_bytes(a.K, a.H2, a.H3, 2, false);
-        switch (knob) {
-            case 108: return fused_h_launch_inst<2, 2, 55, false, 8, 1>(a, grid, lds, s);
-            case 112: return fused_h_launch_inst<2, 2, 55, false, 12, 1>(a, grid, lds, s);
-            case 208: return fused_h_launch_inst<2, 2, 55, false, 8, 2>(a, grid, lds, s);
-            case 212: return fused_h_launch_inst<2, 2, 55, false, 12, 2>(a, grid, lds, s);
-            case 408: return fused_h_launch_inst<2, 2, 55, false, 8, 4>(a, grid, lds, s);
-            case 412: return fused_h_launch_inst<2, 2, 55, false, 12, 4>(a, grid, lds, s);
-            default: return fused_h_launch_inst<2, 2, 55, false, 12, 2>(a, grid, lds, s);
-        }
-    }
+    if (a.K == 880) return fused_h_launch_inst<2, 2, 55, false, 12, 2>(a, grid, fused_h_lds_bytes(a.K, a.H2, a.H3, 2, false), s);
     FR_FAIL(FR_ERR_INVALID, "no bf16 fused instantiation for K=%d", a.K);
 }
 
