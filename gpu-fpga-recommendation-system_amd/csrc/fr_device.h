@@ -52,11 +52,14 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d, float scale) {
-    const float lim = 448.0f;  // largest finite e4m3fn
-    a = fminf(fmaxf(a * scale, -lim), lim);
-    b = fminf(fmaxf(b * scale, -lim), lim);
-    c = fminf(fmaxf(c * scale, -lim), lim);
-    d = fminf(fmaxf(d * scale, -lim), lim);
+    const float lim = 448.0f;  // largest finite e4m3fn: values beyond it saturate (v_cvt_pk_fp8_f32 alone would return NaN above 448)
+    // compares, not fminf / fmaxf: a NaN fails both and stays a NaN (the conversion keeps it), as in the fp32 and bf16 chains --
+    // fminf(fmaxf(NaN, -448), 448) would quietly turn a corrupt table value into -448
+    auto sat = [lim](float x) { x = x > lim ? lim : x; return x < -lim ? -lim : x; };
+    a = sat(a * scale);
+    b = sat(b * scale);
+    c = sat(c * scale);
+    d = sat(d * scale);
     int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
     v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
     return (uint32_t)v;

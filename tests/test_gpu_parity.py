@@ -422,6 +422,48 @@ def test_blocked_layout_matches_3node_buffer(fr, O, gpu):
     ctx.close()
 
 
+def test_nan_in_a_table_reaches_the_score(fr, gpu):
+    """The reference's fp32 chain has no guard: a NaN in a looked-up row makes that item's score a NaN and nobody else's.  Same here in
+    all three precisions and on both paths (unpipelined submit, fused streaming kernels) -- the bf16 conversion keeps a NaN a NaN and
+    the fp8 saturation is done with compares so that a NaN is not clamped into -448."""
+    m = fr.Model.builtin(fr.MODEL_A).clone(max_rows=500)
+    ctx = fr.Context(m, device=gpu)
+    ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    t_bad, r_bad = 11, 7
+    dim = m.tables()[t_bad].dim
+    row = ctx.download_table(t_bad, r_bad, 1, dtype=np.float32).reshape(1, dim).copy()
+    row[0, 1] = np.nan
+    ctx.upload_table(t_bad, row, row0=r_bad)
+    rng = np.random.default_rng(5)
+    B = 256
+    idx = uniform_idx(rng, m.rows(), B)
+    idx[idx[:, t_bad] == r_bad, t_bad] = r_bad + 1      # nobody hits the bad row ...
+    clean = idx.copy()
+    hit = [3, 64, 200]
+    idx[hit, t_bad] = r_bad                             # ... except these items
+    wk = fr.Worker(ctx, B)
+    rec = wk.gather_records(idx).reshape(B, m.record_len).view(np.float32)
+    assert np.isnan(rec[hit]).sum() == len(hit) and not np.isnan(np.delete(rec, hit, axis=0)).any()
+    d_idx = fr.DeviceBuffer.from_numpy(ctx, idx)
+    d_sc = fr.DeviceBuffer(ctx, B * 4)
+    for prec in (fr.FC_FP32, fr.FC_BF16, fr.FC_FP8):
+        ctx.set_fc_precision(prec)
+        if prec == fr.FC_FP8:
+            wk.calibrate_fp8(clean)
+        for path in ("submit", "push"):
+            if path == "submit":
+                s = wk.infer(idx)
+            else:
+                wk.push_device(B, d_idx, None, d_sc)
+                wk.sync()
+                s = d_sc.download(np.float32, B)
+            assert np.isnan(s[hit]).all(), (prec, path, s[hit])
+            assert np.isfinite(np.delete(s, hit)).all(), (prec, path)
+    wk.close()
+    ctx.close()
+
+
 def test_index_out_of_range_is_reported(fr, gpu):
     m = fr.Model.builtin(fr.MODEL_A).clone(max_rows=1000)
     ctx = fr.Context(m, device=gpu)
