@@ -281,7 +281,25 @@ def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=
     cpu_scores = bufs[3].ravel()[:B].copy()
     err = float(np.abs(cpu_scores - gpu_scores_first).max() / max(np.abs(cpu_scores).max(), 1e-30)) if gpu_scores_first is not None else None
     gbytes = 1408 + 188 + 1408
-    return {"value": e_rate, "unit": "inferences/s", "cores": threads, "kind": "port",
+    # BASELINE configs[0] -- "Model-A batch 1 on the host CPU, no accelerator" (the reference's sw_emu plumbing case): one item through the
+    # memory-resident gather and the oracle's own fp32 chain (scalar loops, one thread), median of 200
+    b1 = None
+    try:
+        O.lib().oracle_set_num_threads(1)
+        one = np.ascontiguousarray(hidx[:1])
+        ts = []
+        for _ in range(200):
+            t1 = time.perf_counter()
+            r1 = h.gather_direct(one, True, imgs)
+            om.fc_chain(r1.view(np.float32), ws, acc64=False)
+            ts.append(time.perf_counter() - t1)
+        ts.sort()
+        b1 = {"us_p50": 1e6 * ts[len(ts) // 2], "us_p90": 1e6 * ts[9 * len(ts) // 10], "what": "BASELINE configs[0]: Model-A batch 1 on one host core through the checker "
+              "(memory-resident gather + scalar fp32 chain), ctypes call overhead included"}
+        O.lib().oracle_set_num_threads(threads)
+    except Exception as ex:
+        b1 = {"error": repr(ex)[:200]}
+    return {"value": e_rate, "unit": "inferences/s", "cores": threads, "kind": "port", "batch_1": b1,
             "gather_only": g_rate, "fc_only": f_rate, "end_to_end": e_rate,
             "gather_GBps_algorithmic": g_rate * gbytes / 1e9, "fc_GFLOPs": f_rate * fc_flops_per_inference(fc) / 1e9,
             "blas": blas["name"] if blas else "torch.mm (" + __import__("torch").__config__.parallel_info().split("\n")[0] + ")",
@@ -902,6 +920,22 @@ def main():
             result["cpu_baseline"] = leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first)
         except Exception as ex:
             result["cpu_baseline"] = {"error": repr(ex)}
+        try:   # the same single request on the GPU path: fr_worker_submit + sync of a batch of 1 (index row H2D, 5 stage launches, score D2H)
+            w1 = fr.Worker(ctx, 1)
+            one = idx_host[0][:1]
+            for _ in range(50):
+                w1.infer(one)
+            ts = []
+            for _ in range(300):
+                t1 = time.perf_counter()
+                w1.infer(one)
+                ts.append(time.perf_counter() - t1)
+            ts.sort()
+            w1.close()
+            result["batch_1_gpu"] = {"us_p50": 1e6 * ts[len(ts) // 2], "us_p90": 1e6 * ts[9 * len(ts) // 10],
+                                     "what": "Model-A batch 1 on the GPU path: fr_worker_submit + fr_worker_sync from the host (PCIe hops and the ctypes call included)"}
+        except Exception as ex:
+            result["batch_1_gpu"] = {"error": repr(ex)[:200]}
 
     driver.close()
     for b in d_idx:
