@@ -896,8 +896,8 @@ def main():
         el = hd.run_host(B, n, idx_host)
         hd.close()
         result["pcie_inclusive"] = {"value": n * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / n, "timed_batches": n, "timed_s": el,
-                                    "what": "per batch: memcpy to pinned -> H2D -> 5 stage launches -> D2H -> sync (the reference's own per-batch "
-                                            "sequence, cuda_server.c:425-495), %d threads x 4 workers" % ht}
+                                    "what": "per batch: memcpy to pinned -> fr_worker_submit (5 stage launches; index rows read from and scores written to the pinned "
+                                            "buffers over PCIe) -> sync (the reference's own per-batch sequence, cuda_server.c:425-495), %d threads x 4 workers" % ht}
         hs = fr.Driver(ctx, ht, args.depth, B)
         hs.run_host(B, 2048, idx_host, streaming=True)
         n = steady_run(lambda k: hs.run_host(B, k, idx_host, streaming=True), STEADY_S, n_first=8192)

@@ -1251,6 +1251,18 @@ extern "C" int fr_worker_submit(fr_worker *w, int batch) {
     if (w->in_flight) FR_FAIL(FR_ERR_STATE, "a batch is already in flight on this worker: call fr_worker_sync first");
     fr_ctx *c = w->ctx;
     FR_HIP(hipSetDevice(c->device));
+    // Default: no copy commands on the stream -- the gather stage reads the index rows (and dense features) straight from the worker's
+    // pinned host buffers over PCIe and the output layer writes the scores straight into the pinned score buffer.  Against the
+    // reference's H2D / D2H commands (cuda_server.c:460-461,494-495; FR_SUBMIT_ZEROCOPY=0 keeps them) that takes 4-8 us off a submit +
+    // sync at every batch size (batch 256: 46.1 -> 38.4 us p50) and costs 5 % of the rate of 16 workers submitting at once
+    // (profiles/r02_submit_latency.txt): this entry point is the latency path, the streaming entry points are the throughput path.
+    static const int zero_copy = getenv("FR_SUBMIT_ZEROCOPY") ? atoi(getenv("FR_SUBMIT_ZEROCOPY")) : 1;
+    if (zero_copy) {
+        rc = launch_pipeline(w, batch, w->h_idx, c->model.dense_len ? w->h_dense : nullptr, w->h_score);
+        if (rc) return rc;
+        w->in_flight = true;
+        return FR_OK;
+    }
     // input H2D (cuda_server.c:460-461) -- indices instead of the already-gathered features
     FR_HIP(hipMemcpyAsync(w->d_idx, w->h_idx, (size_t)batch * idx_cols(c) * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
     if (c->model.dense_len)
