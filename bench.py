@@ -13,7 +13,8 @@ value   : STEADY-STATE rate: whatever --steps says, the timed region runs back-t
           `pcie_inclusive_streaming` is the same request stream starting in HOST memory with scores delivered to HOST memory
           (the reference loop's H2D / D2H included, cuda_server.c:460-461,494-495): reported next to `value`, never as it.
 N > 1   : the path shards by independent request batches -> one replica per GPU, no data-path collective ("scaling":
-          "weak"); value = batches all ranks processed / max-over-ranks time.  Launched by torchrun (RANK / WORLD_SIZE in
+          "weak"); value = batches all ranks processed / max-over-ranks time.  The gather half of the metric follows as
+          `gather_per_bank_all_ranks` (every rank on its own Model-C replica at the same time, summed on rank 0).  Launched by torchrun (RANK / WORLD_SIZE in
           the environment) or, when WORLD_SIZE is unset, by this script itself: the parent starts N rank processes BEFORE
           anything touches the GPU and never touches it itself.
 
@@ -736,6 +737,7 @@ def main():
                          "multi-stream throughput loops, whose concurrent launches stretch each other, are skipped), so the profiler's average agrees with "
                          "the HIP-event figure on the bench line")
     ap.add_argument("--quick", action="store_true", help="profiling runs: 0.3 s instead of >= 2 s behind `value` (the legs are what is being profiled)")
+    ap.add_argument("--no-multi-gather", action="store_true", help="N > 1: skip the per-rank Model-C gather leg (gather_per_bank_all_ranks)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch / rendezvous / timing-rule check without touching a GPU or the library (CPU test of the multi-GPU launcher)")
     args = ap.parse_args()
@@ -1035,6 +1037,30 @@ def main():
                 cbk.close()
         except Exception as ex:  # the main metric must still be reported
             result.setdefault("gather", {})["error"] = repr(ex)
+
+    if world > 1 and not args.no_multi_gather:
+        # N > 1: the other half of BASELINE.json's metric ("embedding-gather HBM GB/s vs peak, 1 -> 8 MI355X") -- every rank runs the
+        # Model-C batch-4096 record-producing gather on its own replica (per-bank indices, the reference kernel's contract), rank 0 reports
+        # the sum.  Every rank takes part in the reductions whatever happens to its own leg.
+        ach, ok = 0.0, 1.0
+        try:
+            mcb = fr.Model.builtin(fr.MODEL_C).clone(index_mode=fr.INDEX_PER_BANK)
+            cbk = fr.Context(mcb, device=local_rank)
+            cbk.fill_tables(fr.FILL_HASH, SEED_TABLES)
+            cbk.synchronize()
+            env.barrier()
+            gl = leg_gather(fr, cbk, mcb, 4096, "uniform", reps=200, nbuf=32, seed=dist_mod.replica_seed(SEED_IDX, rank))
+            ach = gl["achieved"]
+            cbk.close()
+        except Exception as ex:
+            ok = 0.0
+            sys.stderr.write("rank %d: gather leg failed: %r\n" % (rank, ex))
+        tot, n_ok = env.sum_over_ranks(ach), env.sum_over_ranks(ok)
+        if rank == 0:
+            result["gather_per_bank_all_ranks"] = {"achieved": tot, "unit": "GB/s", "peak": HBM_PEAK_GBS * world, "frac": tot / (HBM_PEAK_GBS * world),
+                                                   "ranks_measured": int(n_ok), "bound": "hbm",
+                                                   "what": "sum over the ranks of the algorithmic GB/s of fr_worker_gather_only, Model-C batch 4096, one index per bank, "
+                                                           "every rank on its own replica at the same time (HIP events on each rank's stream)"}
 
     if rank == 0:
         print(json.dumps(result))

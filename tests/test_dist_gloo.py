@@ -188,6 +188,8 @@ def test_bench_two_ranks_on_one_gpu(gpu, extra):
             assert chk["bit_identical"] is True, c
     else:
         assert j["timed_batches"] >= 300 and j["timed_s"] >= 2.0 and j["scaling"] == "weak"
+        g = j["gather_per_bank_all_ranks"]     # N > 1: every rank gathers on its own Model-C replica, rank 0 reports the sum
+        assert g["ranks_measured"] == 2 and g["achieved"] > 0 and g["peak"] == 16000.0, g
 
 
 def test_bench_tcp_leg_fails_cleanly_without_a_gpu():
