@@ -972,6 +972,20 @@ def main():
             cb.close()
         except Exception as ex:
             cfgs.append({"workload": "Model-B", "error": repr(ex)})
+        try:   # the headline workload in the low-precision chains (reported beside `value`, never as it: BASELINE configs[1] says fp32 FC)
+            ma = fr.Model.builtin(fr.MODEL_A)
+            ca = fr.Context(ma, device=local_rank)
+            ca.fill_tables(fr.FILL_HASH, SEED_TABLES)
+            ca.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+            rnga = np.random.default_rng(SEED_IDX)
+            iha = [uniform_idx(rnga, ma.rows(), B) for _ in range(N_IDX_BUFFERS)]
+            dia = [fr.DeviceBuffer.from_numpy(ca, a_) for a_ in iha]
+            for prec in ("bf16", "fp8"):
+                cfgs.append(leg_config(fr, ca, ma, B, prec, dia, None, iha[0], None, args.threads, args.depth,
+                                       "Model-A batch=%d (the headline workload), %s FC chain through the fused item-tile kernel" % (B, prec)))
+            ca.close()
+        except Exception as ex:
+            cfgs.append({"workload": "Model-A low precision", "error": repr(ex)})
         result["configs"] = cfgs
 
     if want("gather") or want("configs") or want("bank"):
