@@ -810,6 +810,63 @@ def test_host_fed_streaming(fr, ctxs):
     wc.close()
 
 
+@pytest.mark.parametrize("prec,seed", [("f32", 1), ("f32", 2), ("bf16", 3)])
+def test_random_streaming_sequences(fr, gpu, prec, seed):
+    """State machine of the streaming entry points under a random schedule: device pushes, copying host pushes, zero-copy staged
+    pushes, syncs and changes of the launch group in any order, ragged batches.  Every batch's scores must come out bit-identical to the
+    first (all-device, one group size) run of the same index rows -- whatever was queued around it."""
+    m = fr.Model.builtin(fr.MODEL_A).clone(max_rows=20000)
+    ctx = fr.Context(m, device=gpu)
+    ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    ctx.set_fc_precision({"f32": fr.FC_FP32, "bf16": fr.FC_BF16}[prec])
+    rng = np.random.default_rng(900 + seed)
+    pool = [uniform_idx(rng, m.rows(), 256) for _ in range(6)]
+    d_pool = [fr.DeviceBuffer.from_numpy(ctx, p_) for p_ in pool]
+    wk = fr.Worker(ctx, 256)
+    ref_buf = [fr.DeviceBuffer(ctx, 256 * 4) for _ in pool]
+    for j in range(len(pool)):
+        wk.push_device(256, d_pool[j], None, ref_buf[j])
+    wk.sync()
+    ref = [b.download(np.float32, 256) for b in ref_buf]
+    n_ops = 260
+    dev_out, host_out, plan = [], [], []
+    g0 = ctx.stream_group()
+    for op in range(n_ops):
+        r = rng.random()
+        j, b = int(rng.integers(0, len(pool))), int(rng.choice([1, 7, 64, 200, 256]))
+        if r < 0.35:
+            buf = fr.DeviceBuffer(ctx, 256 * 4)
+            buf.upload(np.full(256, np.nan, np.float32))
+            wk.push_device(b, d_pool[j], None, buf)
+            dev_out.append((buf, j, b))
+        elif r < 0.60:
+            out = np.full(256, np.nan, np.float32)
+            wk.push_host(pool[j][:b], None, out)
+            host_out.append((out, j, b))
+        elif r < 0.85:
+            out = np.full(256, np.nan, np.float32)
+            slot, _ = wk.stage_acquire(b)
+            slot[:b] = pool[j][:b]
+            wk.push_staged(b, out)
+            host_out.append((out, j, b))
+        elif r < 0.93:
+            wk.sync()
+        else:
+            ctx.set_stream_group(int(rng.choice([1, 3, 16, 64])))
+    wk.sync()
+    ctx.set_stream_group(g0)
+    for buf, j, b in dev_out:
+        got = buf.download(np.float32, 256)
+        assert np.array_equal(got[:b], ref[j][:b]) and np.isnan(got[b:]).all()
+        buf.free()
+    for out, j, b in host_out:
+        assert np.array_equal(out[:b], ref[j][:b]) and np.isnan(out[b:]).all()
+    assert len(dev_out) > 50 and len(host_out) > 80
+    wk.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("which,G", [(0, 2), (1, 4), (2, 8)])
 def test_table_sharded_mode_single_device_emulation(fr, O, gpu, which, G):
     """BASELINE config 4 on one GPU: G table-sharded contexts (each holds only its tables), every shard gathers its
