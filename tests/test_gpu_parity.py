@@ -867,6 +867,48 @@ def test_random_streaming_sequences(fr, gpu, prec, seed):
     ctx.close()
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16", "fp8"])
+def test_random_stage_pipeline_sequences(fr, gpu, prec):
+    """The same for a model that streams through the STAGE pipeline (Model-C: launch L = gather(L) | FC1(L-1) | ... | out(L-4), two
+    activation sets alternating by launch parity): random ragged batches and syncs; every pushed batch equals the unpipelined
+    submit() of the same rows bit for bit (same stage bodies, same split-K plan for the same batch size)."""
+    m = fr.Model.builtin(fr.MODEL_C).clone(max_rows=5000)
+    ctx = fr.Context(m, device=gpu)
+    ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    ctx.set_fc_precision({"f32": fr.FC_FP32, "bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[prec])
+    rng = np.random.default_rng(4242)
+    MAXB = 192
+    pool = [uniform_idx(rng, m.rows(), MAXB) for _ in range(4)]
+    dpool = [rng.uniform(-1, 1, (MAXB, m.dense_len)).astype(np.float32) for _ in range(4)]
+    wk = fr.Worker(ctx, MAXB)
+    if prec == "fp8":
+        wk.calibrate_fp8(pool[0], dpool[0])
+    sizes = [1, 33, 64, 100, 192]
+    ref = {(j, b): wk.infer(pool[j][:b], dpool[j][:b]).copy() for j in range(4) for b in sizes}
+    d_idx = {(j, b): fr.DeviceBuffer.from_numpy(ctx, pool[j][:b]) for j in range(4) for b in sizes}
+    d_dense = {(j, b): fr.DeviceBuffer.from_numpy(ctx, dpool[j][:b]) for j in range(4) for b in sizes}
+    outs = []
+    for op in range(120):
+        if rng.random() < 0.12:
+            wk.sync()
+            continue
+        j, b = int(rng.integers(0, 4)), int(rng.choice(sizes))
+        buf = fr.DeviceBuffer(ctx, MAXB * 4)
+        buf.upload(np.full(MAXB, np.nan, np.float32))
+        wk.push_device(b, d_idx[(j, b)], d_dense[(j, b)], buf)
+        outs.append((buf, j, b))
+    wk.sync()
+    for buf, j, b in outs:
+        got = buf.download(np.float32, MAXB)
+        assert np.array_equal(got[:b], ref[(j, b)]), (prec, j, b)
+        assert np.isnan(got[b:]).all()
+        buf.free()
+    assert len(outs) > 80
+    wk.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("which,G", [(0, 2), (1, 4), (2, 8)])
 def test_table_sharded_mode_single_device_emulation(fr, O, gpu, which, G):
     """BASELINE config 4 on one GPU: G table-sharded contexts (each holds only its tables), every shard gathers its
