@@ -727,6 +727,56 @@ def test_driver_loop(fr, ctxs):
     drv.close()
 
 
+def test_two_contexts_driven_concurrently(fr, gpu):
+    """Two contexts of one process -- Model-A in fp32 with launch group 64 and Model-B in bf16 with launch group 8 -- each driven by its
+    own native driver loop AT THE SAME TIME (the library keeps the launch group, the LDS attribute and the error state per context /
+    per device / per thread, not per process): both loops finish and every score left in their rings is a correct one."""
+    import threading
+    ma = fr.Model.builtin(fr.MODEL_A).clone(max_rows=50000)
+    mb = fr.Model.builtin(fr.MODEL_B).clone(max_rows=50000)
+    ca, cb = fr.Context(ma, device=gpu), fr.Context(mb, device=gpu)
+    for c in (ca, cb):
+        c.fill_tables(fr.FILL_HASH, SEED_TABLES)
+        c.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    cb.set_fc_precision(fr.FC_BF16)
+    cb.set_stream_group(8)
+    assert ca.stream_group() == 64 and cb.stream_group() == 8
+    rng = np.random.default_rng(8)
+    ia = [uniform_idx(rng, ma.rows(), 256) for _ in range(4)]
+    ib = [uniform_idx(rng, mb.rows(), 512) for _ in range(4)]
+    wa, wb = fr.Worker(ca, 256), fr.Worker(cb, 512)
+    d_ia = [fr.DeviceBuffer.from_numpy(ca, x) for x in ia]
+    d_ib = [fr.DeviceBuffer.from_numpy(cb, x) for x in ib]
+    sa = [fr.DeviceBuffer(ca, 256 * 4) for _ in ia]
+    sb = [fr.DeviceBuffer(cb, 512 * 4) for _ in ib]
+    for j in range(4):            # reference results through the same streaming kernels, one context at a time
+        wa.push_device(256, d_ia[j], None, sa[j])
+        wb.push_device(512, d_ib[j], None, sb[j])
+    wa.sync()
+    wb.sync()
+    ea = [b_.download(np.float32, 256) for b_ in sa]
+    eb = [b_.download(np.float32, 512) for b_ in sb]
+    wa.close()
+    wb.close()
+    da, db = fr.Driver(ca, 2, 2, 256), fr.Driver(cb, 2, 2, 512)
+    res = {}
+    ta = threading.Thread(target=lambda: res.__setitem__("a", da.run_resident(256, 3000, d_ia)))
+    tb = threading.Thread(target=lambda: res.__setitem__("b", db.run_resident(512, 600, d_ib)))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert res["a"] > 0 and res["b"] > 0
+    assert ca.stream_group() == 64 and cb.stream_group() == 8
+    for drv, exp, B in ((da, ea, 256), (db, eb, 512)):
+        seen = 0
+        for t in range(2):
+            for sl in range(2):
+                for row in drv.score_ring(t, sl, B):
+                    if row.any():
+                        assert any(np.array_equal(row, e_) for e_ in exp)     # bit for bit: same kernels, items independent of the launch mix
+                        seen += 1
+        assert seen >= 100
+    da.close(); db.close(); ca.close(); cb.close()
+
+
 def test_host_fed_streaming(fr, ctxs):
     """fr_worker_push_host / fr_driver_run_host_streaming: batches that sit in host memory are staged in pinned blocks and travel as
     one H2D + one fused launch + one D2H per block; scores equal the device-resident streaming path bit for bit, ragged batches,
