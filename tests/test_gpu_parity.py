@@ -777,6 +777,60 @@ def test_two_contexts_driven_concurrently(fr, gpu):
     da.close(); db.close(); ca.close(); cb.close()
 
 
+def test_streaming_with_dense_features_on_a_user_model(fr, gpu):
+    """A user-defined model WITH dense request features that streams through the fused item-tile kernel (K = 160, hidden widths
+    256 / 512 / 256): the dense block travels through every streaming entry point -- device pushes, copying host pushes and the
+    zero-copy staging slot (whose dense pointer none of the three reference models exercises: A and B have no dense features, C does
+    not stream through the fused kernel) -- and the scores equal the unpipelined submit."""
+    spec = {"name": "dense_user", "dense_len": 32, "dense_at": 3, "fc": [256, 512, 256],
+            "tables": [{"dim": 8, "rows": 900}, {"dim": 16, "rows": 70}, {"dim": 4, "rows": 5000, "class": "PLRAM"}, {"dim": 32, "rows": 333},
+                       {"dim": 64, "rows": 1200, "class": "DDR"}, {"dim": 4, "rows": 17}]}
+    m = fr.Model.from_spec(spec)
+    assert m.record_len == 160 and m.dense_len == 32
+    ctx = fr.Context(m, device=gpu)
+    ctx.fill_tables(fr.FILL_HASH, 11)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, 12)
+    assert ctx.stream_group() > 1          # eligible for the fused streaming path
+    rng = np.random.default_rng(13)
+    B = 200
+    wk = fr.Worker(ctx, B)
+    pool = [(uniform_idx(rng, m.rows(), B), rng.uniform(-1, 1, (B, 32)).astype(np.float32)) for _ in range(3)]
+    expect = [wk.infer(i_, d_).copy() for i_, d_ in pool]
+    scale = max(np.abs(e_).max() for e_ in expect)
+    outs = []
+    for rep in range(30):
+        j, b = rep % 3, [200, 1, 77][rep % 3]
+        idx, dense = pool[j]
+        out = np.full(B, np.nan, np.float32)
+        if rep % 3 == 0:
+            d_i, d_d, d_s = fr.DeviceBuffer.from_numpy(ctx, idx[:b]), fr.DeviceBuffer.from_numpy(ctx, dense[:b]), fr.DeviceBuffer(ctx, B * 4)
+            wk.push_device(b, d_i, d_d, d_s)
+            outs.append(("dev", d_s, j, b, (d_i, d_d)))
+        elif rep % 3 == 1:
+            wk.push_host(idx[:b], dense[:b], out)
+            outs.append(("host", out, j, b, None))
+        else:
+            si, sd = wk.stage_acquire(b)
+            assert sd is not None and sd.shape == (b, 32)
+            si[:], sd[:] = idx[:b], dense[:b]
+            wk.push_staged(b, out)
+            outs.append(("staged", out, j, b, None))
+    wk.sync()
+    ref_first = {}
+    for kind, o, j, b, _ in outs:
+        got = o.download(np.float32, B)[:b] if kind == "dev" else o[:b]
+        assert np.abs(got - expect[j][:b]).max() <= 1e-5 * scale, (kind, j, b)      # fused kernel: whole-K sums vs the stage launches' split-K order
+        key = (j, b)
+        if key in ref_first:
+            assert np.array_equal(got, ref_first[key]), (kind, j, b)               # and bitwise the same through every entry point
+        else:
+            ref_first[key] = got.copy()
+    with pytest.raises(fr.FleetRecError):
+        wk.push_host(pool[0][0], None, np.zeros(B, np.float32))                    # dense features are mandatory for this model
+    wk.close()
+    ctx.close()
+
+
 def test_host_fed_streaming(fr, ctxs):
     """fr_worker_push_host / fr_driver_run_host_streaming: batches that sit in host memory are staged in pinned blocks and travel as
     one H2D + one fused launch + one D2H per block; scores equal the device-resident streaming path bit for bit, ragged batches,
