@@ -405,7 +405,7 @@ def leg_group_table(fr, ctx, model, B, d_idx, threads, depth):
     return out
 
 
-def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_host0, threads, depth, label, min_s=1.0):
+def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_host0, threads, depth, label, min_s=1.0, pmc_key=None):
     """One non-headline BASELINE configuration: steady-state throughput (>= 1 s) + an in-run roofline object for its dominant
     kernel from HIP events on one worker's stream."""
     prec_enum = {"f32": fr.FC_FP32, "bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[precision]
@@ -461,8 +461,12 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
         d_sc.free()
     wk.close()
     ach = flops / (ms * 1e-3) / 1e12
+    pm = (pmc(pmc_key) or {}) if pmc_key else {}
     res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TF[precision], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TF[precision],
-                       "traffic": None, "kernel": what, "avg_launch_ms": ms, "algorithmic_flops_per_launch": flops}
+                       "traffic": pm.get("traffic_bytes_per_launch"), "kernel": what, "avg_launch_ms": ms, "algorithmic_flops_per_launch": flops}
+    if pm:
+        res["roofline"]["pmc_mfma_busy_fraction"] = pm.get("mfma_busy_fraction")
+        res["roofline"]["traffic_source"] = "profiles/r02_pmc.json[%s]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE x2 gfx950 correction), bytes per launch" % pmc_key
     return res
 
 
@@ -958,7 +962,8 @@ def main():
             for prec in ("bf16", "f32"):
                 cfgs.append(leg_config(fr, cb, mb, 1024, prec, di, None, ih[0], None, args.threads, args.depth,
                                        "BASELINE configs[2]: Model-B (embedding_98_krnl, 15.1 GB) batch=1024, %s FC, fused concat + FC chain, per-table indices" % prec
-                                       if prec == "bf16" else "Model-B batch=1024, f32 FC (the reference's own precision), per-table indices"))
+                                       if prec == "bf16" else "Model-B batch=1024, f32 FC (the reference's own precision), per-table indices",
+                                       pmc_key="fused_h_B1024_bf16" if prec == "bf16" else None))
             cb.close()
             # the same configuration under the reference kernel's index contract: one index per bank (49 banks of 2 tables), bank rows in HBM
             mbb = mb.clone(index_mode=fr.INDEX_PER_BANK)
@@ -1022,7 +1027,7 @@ def main():
                 for prec in ("f32", "bf16", "fp8"):
                     result["configs"].append(leg_config(fr, cc, mc, BC, prec, di, dd, ih[0], dh[0], args.threads, args.depth,
                                                         "Model-C (63.2 GB, unsharded replica) batch=4096, %s FC chain end to end "
-                                                        "(BASELINE configs[3]/[4] shapes on one GPU)" % prec))
+                                                        "(BASELINE configs[3]/[4] shapes on one GPU)" % prec, pmc_key="gemm_C4096_%s" % prec))
             if want("gather") or want("configs"):
                 cc.close()
             if want("bank"):
