@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "fr_worker_submit_sharded", "fr_worker_calibrate_fp8_sharded", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
     "fr_ctx_fill_tables", "fr_ctx_upload_table", "fr_ctx_download_table", "fr_ctx_set_weights", "fr_ctx_fill_weights",
     "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_ctx_get_fp8_exponents", "fr_ctx_set_fp8_act_exponents",
-    "fr_worker_calibrate_fp8", "fr_worker_calibrate_fp8_slices", "fr_worker_push_host", "fr_worker_stage_acquire", "fr_worker_push_staged", "fr_worker_stream", "fr_worker_gather_slices", "fr_worker_fc_from_slices_lp", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
+    "fr_worker_calibrate_fp8", "fr_worker_calibrate_fp8_slices", "fr_worker_push_host", "fr_worker_stage_acquire", "fr_worker_push_staged", "fr_worker_flush", "fr_worker_host_poll", "fr_worker_host_pending", "fr_worker_stream", "fr_worker_gather_slices", "fr_worker_fc_from_slices_lp", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
     "fr_worker_dense_ptr", "fr_worker_score_ptr", "fr_worker_submit", "fr_worker_submit_device", "fr_worker_push_device", "fr_worker_sync",
     "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
@@ -100,6 +100,8 @@ def lib():
         "fr_ctx_get_fp8_exponents": (i32, [vp, vp, vp]), "fr_ctx_set_fp8_act_exponents": (i32, [vp, vp]),
         "fr_worker_push_host": (i32, [vp, i32, vp, vp, vp]), "fr_worker_stream": (vp, [vp]),
         "fr_worker_stage_acquire": (i32, [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp)]), "fr_worker_push_staged": (i32, [vp, i32, vp]),
+        "fr_worker_flush": (i32, [vp]), "fr_worker_host_poll": (i32, [vp, ctypes.POINTER(ctypes.c_longlong)]),
+        "fr_worker_host_pending": (i32, [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]),
         "fr_worker_gather_slices": (i32, [vp, i32, vp, vp, vp, i32]), "fr_worker_fc_from_slices_lp": (i32, [vp, i32, i32, i32, vp, i32, vp]),
         "fr_worker_calibrate_fp8": (i32, [vp, i32]), "fr_worker_calibrate_fp8_slices": (i32, [vp, i32, i32, i32, vp]),
         "fr_worker_create": (i32, [vp, i32, ctypes.POINTER(vp)]), "fr_worker_destroy": (None, [vp]),
@@ -554,6 +556,22 @@ class Worker:
         """Step 2: queue the batch written into the acquired slot; scores_out as for push_host()."""
         assert scores_out.dtype == np.float32 and scores_out.flags["C_CONTIGUOUS"] and scores_out.size >= batch
         _check(lib().fr_worker_push_staged(self._h, batch, scores_out.ctypes.data_as(ctypes.c_void_p)))
+
+    def flush(self):
+        """Launch what is queued on the worker now, without waiting (fr_worker_flush)."""
+        _check(lib().fr_worker_flush(self._h))
+
+    def host_pending(self):
+        """-> (queued, in_flight, blocks_in_flight): host-fed batches in the block being filled / launched and not delivered yet / launched blocks."""
+        q, f, nb = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        _check(lib().fr_worker_host_pending(self._h, ctypes.byref(q), ctypes.byref(f), ctypes.byref(nb)))
+        return q.value, f.value, nb.value
+
+    def host_poll(self):
+        """Deliver the scores of finished host-fed blocks (no waiting); -> host-fed batches delivered so far, in push order."""
+        n = ctypes.c_longlong()
+        _check(lib().fr_worker_host_poll(self._h, ctypes.byref(n)))
+        return n.value
 
     def push_device(self, batch, d_idx, d_dense, d_scores):
         _check(lib().fr_worker_push_device(self._h, batch, self._ptr(d_idx), self._ptr(d_dense), self._ptr(d_scores)))

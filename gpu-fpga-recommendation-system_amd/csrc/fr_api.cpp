@@ -1311,6 +1311,7 @@ static int host_block_deliver(fr_worker *w, int b) {
     FR_HIP(hipEventSynchronize(r.ev[b]));
     for (int i = 0; i < r.count[b]; i++)
         memcpy(r.dst[b][i], r.h_sc + ((size_t)b * r.g + i) * r.score_slot, (size_t)r.bsz[b][i] * sizeof(float));
+    r.delivered += r.count[b];
     r.inflight[b] = false;
     r.count[b] = 0;
     return FR_OK;
@@ -1504,6 +1505,55 @@ extern "C" int fr_worker_calibrate_fp8_slices(fr_worker *w, int batch_total, int
     w->calibrating = false;
     if (rc) return rc;
     return f8_calibrate_finish(w, L1 - 1, n_items);
+}
+
+// Launch what is queued -- the partially filled host block, the batches queued by fr_worker_push_device -- without waiting for it.
+extern "C" int fr_worker_flush(fr_worker *w) {
+    if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
+    if (w->hr.staged) FR_FAIL(FR_ERR_STATE, "a staging slot is acquired: push it with fr_worker_push_staged first");
+    FR_HIP(hipSetDevice(w->ctx->device));
+    if (w->hr.g) {
+        int rc = host_block_launch(w);
+        if (rc) return rc;
+    }
+    return fused_flush(w);
+}
+
+// Hand out the scores of the host-fed blocks that have finished, oldest first, WITHOUT waiting for the others; *delivered = host-fed
+// batches delivered since the worker was created (they are delivered in push order).
+extern "C" int fr_worker_host_poll(fr_worker *w, long long *delivered) {
+    if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
+    fr_worker::HostRing &r = w->hr;
+    if (r.g) {
+        FR_HIP(hipSetDevice(w->ctx->device));
+        for (int k = 0; k < FR_HOST_BLOCKS; k++) {
+            const int b = (r.cur + k) % FR_HOST_BLOCKS;  // oldest first
+            if (!r.inflight[b]) continue;
+            const hipError_t q = hipEventQuery(r.ev[b]);
+            if (q == hipErrorNotReady) break;
+            if (q != hipSuccess) FR_FAIL(FR_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
+            int rc = host_block_deliver(w, b);
+            if (rc) return rc;
+        }
+    }
+    if (delivered) *delivered = r.delivered;
+    return FR_OK;
+}
+
+// Host-fed batches that are queued in the block being filled (not launched yet) and that are launched but not delivered yet.
+extern "C" int fr_worker_host_pending(const fr_worker *w, int *queued, int *in_flight, int *blocks_in_flight) {
+    if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
+    const fr_worker::HostRing &r = w->hr;
+    int q = 0, f = 0, nb = 0;
+    if (r.g)
+        for (int b = 0; b < FR_HOST_BLOCKS; b++) {
+            (r.inflight[b] ? f : q) += r.count[b];
+            nb += r.inflight[b] ? 1 : 0;
+        }
+    if (queued) *queued = q;
+    if (in_flight) *in_flight = f;
+    if (blocks_in_flight) *blocks_in_flight = nb;
+    return FR_OK;
 }
 
 extern "C" int fr_worker_sync(fr_worker *w) {

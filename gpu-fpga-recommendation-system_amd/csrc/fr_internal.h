@@ -241,6 +241,7 @@ struct fr_worker {
         int bsz[4][FR_FUSED_MAX_BATCHES];
         int cur = 0;               // block being filled
         int staged = 0;            // batch size handed out by fr_worker_stage_acquire and not yet pushed (0: none)
+        long long delivered = 0;   // host-fed batches whose scores have been copied to their h_scores so far (fr_worker_host_poll)
     } hr;
     // table-sharded exchange (fr_worker_submit_sharded, fr_comm.cpp): this shard's slice, the all-gathered slices, score chunks
     void *d_slice = nullptr, *d_gathered = nullptr;

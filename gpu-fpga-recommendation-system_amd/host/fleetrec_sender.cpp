@@ -6,6 +6,8 @@
 //
 // Usage: fleetrec_sender --model A|B|C [--batch 256] [--threads 4] [--port 8080] [--host 127.0.0.1]
 //                        [--indices reference|uniform] [--per-item | --per-bank] [--row-cap N] [--max-blocks N] [--reply]
+//                        [--window W] (with --reply: up to W requests in flight per connection -- a reader thread takes the score replies and
+//                                      times request -> reply; W = 1 waits for every reply before the next request, the default)
 //                        [--pool N]   (uniform indices: N distinct blocks per connection are generated up front and sent in rotation --
 //                                      drawing 12 k random indices per block is slower than the server; default 32, 0 = draw every block)
 #include <arpa/inet.h>
@@ -14,6 +16,9 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -30,7 +35,7 @@ static const int kIdxRandom[32] = {3, 99, 38, 72, 29, 57, 1, 72, 36, 76, 35, 50,
 
 int main(int argc, char **argv) {
     int which = FR_MODEL_A, batch = 256, threads = 4, port = 8080;
-    long row_cap = 0, max_blocks = 1L << 40, interval_us = 0, pool = 32;
+    long row_cap = 0, max_blocks = 1L << 40, interval_us = 0, pool = 32, window = 1;
     std::string host = "127.0.0.1", indices = "reference";
     bool per_item = false, per_bank = false, reply = false;
     for (int i = 1; i < argc; i++) {
@@ -49,6 +54,7 @@ int main(int argc, char **argv) {
         else if (a == "--max-blocks") max_blocks = atol(next());
         else if (a == "--interval-us") interval_us = atol(next());
         else if (a == "--pool") pool = atol(next());
+        else if (a == "--window") window = atol(next());
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     fr_model_desc *m = nullptr;
@@ -66,6 +72,7 @@ int main(int argc, char **argv) {
     }
     std::vector<std::thread> th;
     std::vector<long> sent(threads, 0);
+    std::vector<std::vector<double>> lat_us(threads);  // --reply --window W: request sent -> reply received, per request
     for (int t = 0; t < threads; t++) {
         th.emplace_back([&, t]() {
             std::vector<int32_t> idx((size_t)batch * cols);
@@ -100,6 +107,28 @@ int main(int argc, char **argv) {
             std::vector<int32_t> pidx((size_t)(n_pool > 0 ? n_pool : 0) * idx.size());
             std::vector<float> pdense((size_t)(n_pool > 0 ? n_pool : 0) * dense.size());
             for (long q = 0; q < n_pool; q++) draw(pidx.data() + (size_t)q * idx.size(), pdense.data() + (size_t)q * dense.size());
+            const bool async_reply = reply && window > 1;
+            std::atomic<long> n_sent{0}, n_recv{0};
+            std::atomic<bool> reader_done{false};
+            std::vector<std::chrono::steady_clock::time_point> t_send((size_t)(window > 1 ? window : 1));
+            std::thread reader;
+            if (async_reply)
+                reader = std::thread([&]() {  // score replies arrive in request order
+                    std::vector<float> sc(batch);
+                    for (;;) {
+                        size_t got = 0;
+                        while (got < sc.size() * 4) {
+                            ssize_t r = read(sock, (char *)sc.data() + got, sc.size() * 4 - got);
+                            if (r <= 0) break;
+                            got += (size_t)r;
+                        }
+                        if (got < sc.size() * 4) break;
+                        const long k = n_recv.load(std::memory_order_relaxed);
+                        lat_us[t].push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_send[(size_t)(k % window)]).count());
+                        n_recv.store(k + 1, std::memory_order_release);
+                    }
+                    reader_done.store(true);
+                });
             for (long blk = 0; blk < max_blocks; blk++) {
                 const int32_t *bi = idx.data();
                 const float *bd = dense.data();
@@ -109,11 +138,17 @@ int main(int argc, char **argv) {
                 } else {
                     draw(idx.data(), dense.data());
                 }
+                if (async_reply) {  // at most `window` requests without a reply
+                    while (n_sent.load(std::memory_order_relaxed) - n_recv.load(std::memory_order_acquire) >= window && !reader_done.load()) usleep(5);
+                    if (reader_done.load()) break;
+                    t_send[(size_t)(n_sent.load(std::memory_order_relaxed) % window)] = std::chrono::steady_clock::now();
+                }
                 if (send(sock, bi, idx.size() * 4, MSG_NOSIGNAL) <= 0) break;
                 if (!dense.empty() && send(sock, bd, dense.size() * 4, MSG_NOSIGNAL) <= 0) break;
                 sent[t]++;
+                n_sent.fetch_add(1, std::memory_order_release);
                 if (interval_us > 0) usleep((useconds_t)interval_us);  // rate limit of the latency experiment (reference sender: usleep(useconds))
-                if (reply) {
+                if (reply && !async_reply) {
                     size_t got = 0;
                     while (got < scores.size() * 4) {
                         ssize_t r = read(sock, (char *)scores.data() + got, scores.size() * 4 - got);
@@ -123,6 +158,10 @@ int main(int argc, char **argv) {
                     if (got < scores.size() * 4) break;
                 }
             }
+            if (async_reply) {
+                shutdown(sock, SHUT_WR);  // no more requests; the reader runs until the server has answered what it took and closes
+                reader.join();
+            }
             close(sock);
         });
     }
@@ -130,6 +169,16 @@ int main(int argc, char **argv) {
     long tot = 0;
     for (long s : sent) tot += s;
     printf("sender: %ld blocks sent over %d connections\n", tot, threads);
+    std::vector<double> all;
+    for (auto &v : lat_us) all.insert(all.end(), v.begin() + (long)(v.size() / 20), v.end());  // the first 5 % of every connection are warm-up
+    if (!all.empty()) {
+        std::sort(all.begin(), all.end());
+        double sum = 0;
+        for (double v : all) sum += v;
+        auto pct = [&](double q) { return all[(size_t)(q * (all.size() - 1))]; };
+        printf("latency request sent -> scores received  n=%zu avg %.1f us  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f (window %ld per connection)\n", all.size(),
+               sum / all.size(), pct(0.50), pct(0.90), pct(0.99), all.back(), window);
+    }
     fr_model_free(m);
     return 0;
 }

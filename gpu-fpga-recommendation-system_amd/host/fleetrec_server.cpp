@@ -11,6 +11,7 @@
 // (--reply), which the reference never did (its "Finish receiving." message is defined but never sent, :363).
 //
 // Usage: fleetrec_server --model A|B|C [--batch 256] [--threads 4] [--port 8080] [--total 1024] [--device 0]
+//        [--stream [--reply [--flush-us 50] [--flush-min 32]]]: streaming with score replies and adaptive batching -- see thread_consume
 //                        [--tables evenodd|hash] [--weights ones|uniform] [--per-item | --per-bank] [--reply] [--row-cap N]
 //                        [--shards G [--precision f32|bf16|fp8]]
 // --shards G: BASELINE configs[3]/[4] -- the tables are sharded by table-ID over GPUs device .. device + G - 1 of this node (one
@@ -20,6 +21,7 @@
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
@@ -45,6 +47,8 @@ struct Options {
     int shards = 0;            // > 0: table-sharded over `shards` GPUs
     int precision = FR_FC_FP32;
     bool stream = false;   // throughput mode: fr_worker_push_host (blocks of batches per launch) instead of submit + sync per batch
+    long flush_us = 50;    // --stream --reply: how long the socket must stay dry before a partial block is launched
+    int flush_min = 32;    // ... while earlier blocks are still in flight: only once this many requests are queued (with nothing in flight: any number)
     bool latency = false;  // latency-measurement mode: per-batch recv -> enqueued -> scores times (measure_network_cuda_cp_latency_*/cuda_server.c)
     long row_cap = 0;
 };
@@ -189,7 +193,8 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
         }
         // --stream: every batch is read into the worker's staging (fr_worker_stage_acquire / fr_worker_push_staged); scores come back
         // in blocks, the last batch's are available after the final sync
-        std::vector<float> stream_scores(o.stream ? (size_t)256 * o.batch : 0);
+        constexpr long long kStreamRing = 512;  // score slots per connection: at most 4 blocks x 64 batches are undelivered at any time
+        std::vector<float> stream_scores(o.stream ? (size_t)kStreamRing * o.batch : 0);
         std::vector<int32_t> sh_idx(g_engine ? idx_bytes / sizeof(int32_t) : 0);
         std::vector<float> sh_dense(g_engine ? dense_bytes / sizeof(float) : 0), sh_scores(g_engine ? (size_t)o.batch : 0);
         while (g_engine) {   // table-sharded mode: the whole batch is received here, then every shard works on it
@@ -223,11 +228,64 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
         }
         if (g_engine)
             for (int j = 0; j < 5 && j < o.batch && t->batches > 0; j++) t->first_scores.push_back(sh_scores[j]);
+        // --stream --reply: scores go back over the socket, block by block, in request order.  fr_worker_host_poll says how many of the
+        // pushed batches have their scores; when the socket has nothing to read and requests are still queued, fr_worker_flush launches the
+        // partial block instead of waiting for it to fill (light load: latency of one launch; heavy load: full blocks).
+        long long replied = 0;
+        auto send_ready = [&]() -> bool {
+            long long delivered = 0;
+            if (fr_worker_host_poll(wk, &delivered) != FR_OK) {
+                t->status = -5;
+                t->error = fr_last_error();
+                return false;
+            }
+            for (; replied < delivered; replied++)
+                if (!write_exact(sock, stream_scores.data() + (size_t)(replied % kStreamRing) * o.batch, (size_t)o.batch * sizeof(float))) {
+                    t->status = -7;
+                    t->error = "sending scores failed";
+                    return false;
+                }
+            return true;
+        };
         while (o.stream && !g_engine) {
             {
                 std::lock_guard<std::mutex> g(g_mtx);
                 if (g_global_batch_count >= o.total) break;
                 g_global_batch_count++;
+            }
+            if (o.reply) {  // wait for the next request without letting queued ones sit
+                // Requests of a burst arrive microseconds apart: the socket must stay dry for --flush-us (default 50 us) before the partial
+                // block is launched, or every request of the burst would become its own launch.
+                bool flushed = false;
+                const auto t_dry = std::chrono::steady_clock::now();
+                for (;;) {
+                    pollfd pfd{sock, POLLIN, 0};
+                    const bool waiting = t->batches > replied;
+                    const int pr = poll(&pfd, 1, waiting ? 0 : -1);
+                    if (pr != 0) break;  // data, EOF or an error: the read below sorts it out
+                    if (!flushed) {
+                        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_dry).count() < (double)o.flush_us) continue;  // spin
+                        // adaptive batching: a launch costs the worker's stream >= 150 us whatever it carries.  With nothing in flight the
+                        // queued requests leave at once (latency); with blocks in flight they leave once they are worth a launch of their own
+                        // (--flush-min, default half a block) -- fewer would only queue behind the running ones, so they keep collecting
+                        int queued = 0, blocks = 0;
+                        fr_worker_host_pending(wk, &queued, nullptr, &blocks);
+                        if (blocks == 0 || queued >= o.flush_min || queued == 0) {
+                            if (fr_worker_flush(wk) != FR_OK) {
+                                t->status = -5;
+                                t->error = fr_last_error();
+                                break;
+                            }
+                            flushed = true;
+                        }
+                    }
+                    if (!send_ready()) break;
+                    if (t->batches > replied) {
+                        pollfd p2{sock, POLLIN, 0};
+                        if (poll(&p2, 1, 0) == 0) usleep(20);  // scores still on their way and nothing to read: yield briefly
+                    }
+                }
+                if (t->status) break;
             }
             // the socket is read straight into the worker's pinned staging slot (the reference reads into its pinned input_feature,
             // cuda_server.c:437), then the slot is queued: no copy between the socket buffer and the H2D source
@@ -243,20 +301,22 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
                 t->error = "Receiving data UNSUCCESSFUL (peer closed before the batch was complete)";
                 break;
             }
-            if (fr_worker_push_staged(wk, o.batch, stream_scores.data() + (size_t)(t->batches % 256) * o.batch) != FR_OK) {
+            if (fr_worker_push_staged(wk, o.batch, stream_scores.data() + (size_t)(t->batches % kStreamRing) * o.batch) != FR_OK) {
                 t->status = -5;
                 t->error = fr_last_error();
                 break;
             }
             t->batches++;
+            if (o.reply && !send_ready()) break;
         }
         if (o.stream && !g_engine) {
             if (t->status == 0 && fr_worker_sync(wk) != FR_OK) {
                 t->status = -6;
                 t->error = fr_last_error();
             }
+            if (t->status == 0 && o.reply) send_ready();  // everything is delivered after the sync: the rest of the replies
             if (t->batches > 0)
-                for (int j = 0; j < 5 && j < o.batch; j++) t->first_scores.push_back(stream_scores[(size_t)((t->batches - 1) % 256) * o.batch + j]);
+                for (int j = 0; j < 5 && j < o.batch; j++) t->first_scores.push_back(stream_scores[(size_t)((t->batches - 1) % kStreamRing) * o.batch + j]);
         }
         while (!o.stream && !g_engine) {
             {
@@ -320,6 +380,8 @@ int main(int argc, char **argv) {
         else if (a == "--reply") o.reply = true;
         else if (a == "--latency") o.latency = true;
         else if (a == "--stream") o.stream = true;
+        else if (a == "--flush-us") o.flush_us = atol(next());
+        else if (a == "--flush-min") o.flush_min = atoi(next());
         else if (a == "--row-cap") o.row_cap = atol(next());
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }

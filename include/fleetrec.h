@@ -272,6 +272,17 @@ int fr_worker_push_host(fr_worker *w, int batch, const int32_t *h_idx, const flo
  * two calls is FR_ERR_STATE; fr_worker_sync drops a slot that was acquired and never pushed. */
 int fr_worker_stage_acquire(fr_worker *w, int batch, int32_t **h_idx, float **h_dense);
 int fr_worker_push_staged(fr_worker *w, int batch, float *h_scores);
+/* Serving with replies (fleetrec_server --stream --reply): fr_worker_flush launches what is queued on the worker right now -- a
+ * partially filled host block, queued device pushes -- without waiting (the latency knob under light load: call it when the request
+ * source runs dry); fr_worker_host_poll delivers the scores of the host-fed blocks that have FINISHED (oldest first, no waiting) and
+ * reports how many host-fed batches have been delivered since the worker was created: batches are delivered in push order, so the
+ * caller knows exactly which h_scores buffers are valid. */
+int fr_worker_flush(fr_worker *w);
+int fr_worker_host_poll(fr_worker *w, long long *delivered);
+/* Host-fed batches queued in the block being filled (not launched yet) / launched and not delivered yet, and the number of launched
+ * blocks not delivered yet (at most 4) -- what an adaptive batcher needs: flush when the request source is dry AND at most one block is
+ * still in flight; while more are running, let the next block fill (any output pointer may be NULL). */
+int fr_worker_host_pending(const fr_worker *w, int *queued, int *in_flight, int *blocks_in_flight);
 /* Launches whatever is still queued, drains the pipeline and waits for everything enqueued on the worker; returns
  * FR_ERR_INDEX_RANGE if any index was out of range. */
 int fr_worker_sync(fr_worker *w);

@@ -881,6 +881,24 @@ def test_host_fed_streaming(fr, ctxs):
     for j, b in enumerate(sizes):
         assert np.array_equal(outs2[j][:b], expect[j % 5]), j
         assert np.isnan(outs2[j][b:]).all()
+    # serving with replies: fr_worker_flush launches a partial block without waiting, fr_worker_host_poll delivers finished blocks (in
+    # push order) and counts them -- no fr_worker_sync anywhere in this stretch
+    import time
+    base = wk.host_poll()
+    outs3 = [np.full(256, np.nan, np.float32) for _ in range(10)]
+    for j in range(10):
+        wk.push_host(pool[j % 5], None, outs3[j])
+    assert wk.host_poll() == base          # 10 batches do not fill a block of 64: nothing has been launched
+    wk.flush()
+    t0 = time.time()
+    while wk.host_poll() < base + 10:
+        assert time.time() - t0 < 30
+        time.sleep(0.0005)
+    for j in range(10):
+        assert np.array_equal(outs3[j], expect[j % 5]) if sizes[j % 5] == 256 else True
+        assert np.array_equal(outs3[j][:sizes[j % 5]], expect[j % 5])
+    wk.flush()                             # nothing queued: a no-op
+    assert wk.host_poll() == base + 10
     bad = pool[0].copy()
     bad[3, 5] = m.rows()[5]
     wk.push_host(bad, None, outs[0])

@@ -15,6 +15,7 @@ HOST = os.path.join(ROOT, "gpu-fpga-recommendation-system_amd", "host")
 
 @pytest.mark.parametrize("model,val,extra", [("A", 352.0 * 2 ** 27, []), ("C", 3968.0 * 2 ** 28, ["--row-cap", "200"]),
                                              ("A", 352.0 * 2 ** 27, ["--stream"]),
+                                             ("A", 352.0 * 2 ** 27, ["--stream", "--reply"]),   # scores back over the socket, sender window 64
                                              ("B", 880.0 * 2 ** 27, ["--per-bank", "--row-cap", "200"]),          # the kernel's own index contract on the wire
                                              ("C", 3968.0 * 2 ** 28, ["--row-cap", "200", "--shards", "1"])])     # sharded engine + RCCL (one-rank communicator)
 def test_server_and_sender_known_answer(fr, gpu, model, val, extra):
@@ -29,7 +30,8 @@ def test_server_and_sender_known_answer(fr, gpu, model, val, extra):
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     time.sleep(0.5)
     snd = subprocess.Popen([os.path.join(HOST, "fleetrec_sender"), "--model", model, "--batch", "128", "--threads", str(threads),
-                            "--port", str(port), "--indices", "reference"] + [e_ for e_ in extra if e_ not in ("--stream", "--shards", "1")],
+                            "--port", str(port), "--indices", "reference"] + [e_ for e_ in extra if e_ not in ("--stream", "--shards", "1")]
+                           + (["--window", "64"] if "--reply" in extra else []),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     try:
         out, _ = srv.communicate(timeout=300)
@@ -53,6 +55,9 @@ def test_server_and_sender_known_answer(fr, gpu, model, val, extra):
     if "--shards" in extra:
         assert "table-sharded over 1 GPUs" in out
     assert "blocks sent" in sout.decode()
+    if "--reply" in extra:      # every request the server took was answered, and the sender timed the round trips
+        m_ = re.search(r"latency request sent -> scores received  n=(\d+) avg ([0-9.]+) us", sout.decode())
+        assert m_ and int(m_.group(1)) >= 16, sout.decode()
 
 
 def test_latency_measurement_mode(fr, gpu):
