@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "fr_worker_submit_sharded", "fr_worker_calibrate_fp8_sharded", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
     "fr_ctx_fill_tables", "fr_ctx_upload_table", "fr_ctx_download_table", "fr_ctx_set_weights", "fr_ctx_fill_weights",
     "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_ctx_get_fp8_exponents", "fr_ctx_set_fp8_act_exponents",
-    "fr_worker_calibrate_fp8", "fr_worker_calibrate_fp8_slices", "fr_worker_push_host", "fr_worker_stage_acquire", "fr_worker_push_staged", "fr_worker_flush", "fr_worker_host_poll", "fr_worker_host_pending", "fr_worker_stream", "fr_worker_gather_slices", "fr_worker_fc_from_slices_lp", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
+    "fr_worker_calibrate_fp8", "fr_worker_calibrate_fp8_slices", "fr_worker_push_host", "fr_worker_stage_acquire", "fr_worker_push_staged", "fr_worker_flush", "fr_worker_host_poll", "fr_worker_host_pending", "fr_ctx_set_small_block", "fr_worker_stream", "fr_worker_gather_slices", "fr_worker_fc_from_slices_lp", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
     "fr_worker_dense_ptr", "fr_worker_score_ptr", "fr_worker_submit", "fr_worker_submit_device", "fr_worker_push_device", "fr_worker_sync",
     "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
@@ -100,7 +100,7 @@ def lib():
         "fr_ctx_get_fp8_exponents": (i32, [vp, vp, vp]), "fr_ctx_set_fp8_act_exponents": (i32, [vp, vp]),
         "fr_worker_push_host": (i32, [vp, i32, vp, vp, vp]), "fr_worker_stream": (vp, [vp]),
         "fr_worker_stage_acquire": (i32, [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp)]), "fr_worker_push_staged": (i32, [vp, i32, vp]),
-        "fr_worker_flush": (i32, [vp]), "fr_worker_host_poll": (i32, [vp, ctypes.POINTER(ctypes.c_longlong)]),
+        "fr_ctx_set_small_block": (i32, [vp, i32]), "fr_worker_flush": (i32, [vp]), "fr_worker_host_poll": (i32, [vp, ctypes.POINTER(ctypes.c_longlong)]),
         "fr_worker_host_pending": (i32, [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]),
         "fr_worker_gather_slices": (i32, [vp, i32, vp, vp, vp, i32]), "fr_worker_fc_from_slices_lp": (i32, [vp, i32, i32, i32, vp, i32, vp]),
         "fr_worker_calibrate_fp8": (i32, [vp, i32]), "fr_worker_calibrate_fp8_slices": (i32, [vp, i32, i32, i32, vp]),
@@ -430,6 +430,10 @@ class Context:
 
     def set_stream_group(self, batches_per_launch):
         _check(lib().fr_ctx_set_stream_group(self._h, batches_per_launch))
+
+    def set_small_block(self, max_batches):
+        """Host-fed blocks of at most max_batches batches take fr_worker_submit's stage launches instead of the fused kernel (latency)."""
+        _check(lib().fr_ctx_set_small_block(self._h, max_batches))
 
     def set_gather_variant(self, variant):
         """GATHER_WORD_MAJOR (default) / GATHER_ITEM_TILE / GATHER_ITEM_TILE_DEDUP(_COUNT): which kernel fr_worker_gather_only runs."""

@@ -959,6 +959,13 @@ extern "C" int fr_ctx_set_stream_group(fr_ctx *ctx, int batches_per_launch) {
     return FR_OK;
 }
 
+extern "C" int fr_ctx_set_small_block(fr_ctx *ctx, int max_batches) {
+    if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
+    if (max_batches < 0 || max_batches > 8) FR_FAIL(FR_ERR_INVALID, "max_batches %d outside [0, 8]", max_batches);
+    ctx->small_block.store(max_batches, std::memory_order_relaxed);
+    return FR_OK;
+}
+
 extern "C" int fr_ctx_stream_group(const fr_ctx *ctx) { return (ctx && fused_eligible(ctx)) ? fused_group(ctx) : 1; }
 
 static int fused_flush(fr_worker *w) {
@@ -1325,6 +1332,21 @@ static int host_block_launch(fr_worker *w) {
     int rc = fused_flush(w);  // batches queued by fr_worker_push_device go first
     if (rc) return rc;
     const size_t s0 = (size_t)b * r.g;
+    if (n <= w->ctx->small_block.load(std::memory_order_relaxed) && w->n_active == 0) {
+        // A block of very few batches (fr_worker_flush on a nearly idle server): one batch through the fused kernel is 8 workgroups working
+        // through the whole chain for 133 us; the stage launches of fr_worker_submit spread the same batch over the chip in ~25 us.  The
+        // kernels read the staged rows and write the scores in the pinned staging itself (no copy commands), exactly as fr_worker_submit
+        // does; the scores are fr_worker_submit's, bit for bit (not the fused kernel's: another fp32 summation order, equal to ~1e-6).
+        for (int i = 0; i < n; i++) {
+            rc = launch_pipeline(w, r.bsz[b][i], r.h_idx + (s0 + i) * r.idx_slot, r.dense_slot ? r.h_dense + (s0 + i) * r.dense_slot : nullptr,
+                                 r.h_sc + (s0 + i) * r.score_slot);
+            if (rc) return rc;
+        }
+        FR_HIP(hipEventRecord(r.ev[b], w->stream));
+        r.inflight[b] = true;
+        r.cur = (b + 1) % FR_HOST_BLOCKS;
+        return FR_OK;
+    }
     FR_HIP(hipMemcpyAsync(r.d_idx + s0 * r.idx_slot, r.h_idx + s0 * r.idx_slot, (size_t)n * r.idx_slot * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
     if (r.dense_slot)
         FR_HIP(hipMemcpyAsync(r.d_dense + s0 * r.dense_slot, r.h_dense + s0 * r.dense_slot, (size_t)n * r.dense_slot * sizeof(float), hipMemcpyHostToDevice, w->stream));

@@ -190,6 +190,8 @@ struct fr_ctx {
     hipStream_t setup_stream = nullptr;
     // batches one fused streaming launch carries (fr_ctx_set_stream_group): per context; read by every driver thread
     std::atomic<int> stream_group{FR_FUSED_DEFAULT_BATCHES};
+    // host-fed blocks of at most this many batches take the stage pipeline instead of the fused kernel (fr_ctx_set_small_block; 0: never)
+    std::atomic<int> small_block{0};
 };
 
 struct fr_worker {

@@ -49,6 +49,7 @@ struct Options {
     bool stream = false;   // throughput mode: fr_worker_push_host (blocks of batches per launch) instead of submit + sync per batch
     long flush_us = 50;    // --stream --reply: how long the socket must stay dry before a partial block is launched
     int flush_min = 32;    // ... while earlier blocks are still in flight: only once this many requests are queued (with nothing in flight: any number)
+    int small_block = 4;   // --stream --reply: blocks of at most this many batches take fr_worker_submit's stage launches (fr_ctx_set_small_block)
     bool latency = false;  // latency-measurement mode: per-batch recv -> enqueued -> scores times (measure_network_cuda_cp_latency_*/cuda_server.c)
     long row_cap = 0;
 };
@@ -382,6 +383,7 @@ int main(int argc, char **argv) {
         else if (a == "--stream") o.stream = true;
         else if (a == "--flush-us") o.flush_us = atol(next());
         else if (a == "--flush-min") o.flush_min = atoi(next());
+        else if (a == "--small-block") o.small_block = atoi(next());
         else if (a == "--row-cap") o.row_cap = atol(next());
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -418,6 +420,10 @@ int main(int argc, char **argv) {
         printf("table-sharded over %d GPUs (RCCL all-gather of the looked-up slices)\n", o.shards);
     } else if (fr_ctx_create(model, o.device, &ctx) != FR_OK || fr_ctx_fill_tables(ctx, o.tables, 0xF1EE7) != FR_OK ||
                fr_ctx_fill_weights(ctx, o.weights, 99) != FR_OK || fr_ctx_set_fc_precision(ctx, o.precision) != FR_OK) {
+        fprintf(stderr, "set-up failed: %s\n", fr_last_error());
+        return 1;
+    }
+    if (o.stream && o.reply && !g_engine && fr_ctx_set_small_block(ctx, o.small_block) != FR_OK) {
         fprintf(stderr, "set-up failed: %s\n", fr_last_error());
         return 1;
     }

@@ -899,6 +899,30 @@ def test_host_fed_streaming(fr, ctxs):
         assert np.array_equal(outs3[j][:sizes[j % 5]], expect[j % 5])
     wk.flush()                             # nothing queued: a no-op
     assert wk.host_poll() == base + 10
+    assert wk.host_pending() == (0, 0, 0)
+    # fr_ctx_set_small_block: a block that leaves with <= 2 batches takes fr_worker_submit's stage launches (latency of a nearly idle
+    # server) and gets submit's scores bit for bit; a bigger block still takes the fused kernel
+    wk.sync()                              # (fr_worker_submit wants an idle worker: the polls above delivered everything but did not sync)
+    sub = [wk.infer(p_) for p_ in pool[:2]]
+    ctx.set_small_block(2)
+    o1 = [np.full(256, np.nan, np.float32) for _ in range(5)]
+    wk.push_host(pool[0], None, o1[0])
+    wk.push_host(pool[1], None, o1[1])
+    assert wk.host_pending()[0] == 2
+    wk.flush()
+    for j in (2, 3, 4):
+        wk.push_host(pool[j][:sizes[j]], None, o1[j])
+    wk.flush()
+    t0 = time.time()
+    while wk.host_poll() < base + 15:
+        assert time.time() - t0 < 30
+        time.sleep(0.0005)
+    assert np.array_equal(o1[0], sub[0]) and np.array_equal(o1[1], sub[1])
+    for j in (2, 3, 4):
+        assert np.array_equal(o1[j][:sizes[j]], expect[j])
+    ctx.set_small_block(0)
+    with pytest.raises(fr.FleetRecError):
+        ctx.set_small_block(9)
     bad = pool[0].copy()
     bad[3, 5] = m.rows()[5]
     wk.push_host(bad, None, outs[0])
