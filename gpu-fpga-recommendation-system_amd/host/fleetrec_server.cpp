@@ -265,7 +265,13 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
                     const int pr = poll(&pfd, 1, waiting ? 0 : -1);
                     if (pr != 0) break;  // data, EOF or an error: the read below sorts it out
                     if (!flushed) {
-                        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_dry).count() < (double)o.flush_us) continue;  // spin
+                        int queued0 = 0, blocks0 = 0;
+                        fr_worker_host_pending(wk, &queued0, nullptr, &blocks0);
+                        // an idle worker with only a few requests queued waits a fifth of --flush-us (they take the stage launches, there is
+                        // little to gain from collecting more); otherwise the socket must stay dry for --flush-us first
+                        const bool few_and_idle = blocks0 == 0 && queued0 > 0 && queued0 <= o.small_block;
+                        const double grace = few_and_idle ? (double)o.flush_us / 5.0 : (double)o.flush_us;  // 10 us is enough to see the rest of a burst coming
+                        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_dry).count() < grace) continue;  // spin
                         // adaptive batching: a launch costs the worker's stream >= 150 us whatever it carries.  With nothing in flight the
                         // queued requests leave at once (latency); with blocks in flight they leave once they are worth a launch of their own
                         // (--flush-min, default half a block) -- fewer would only queue behind the running ones, so they keep collecting

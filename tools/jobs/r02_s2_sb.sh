@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 H=gpu-fpga-recommendation-system_amd/host
 O=gpurun_out/s2_reply; mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_server.py -q -x -k "host_fed or server" 2>&1 | tail -3
+
 run() {  # threads total window interval small
   T=$1; TOTAL=$2; W=$3; IV=$4; SB=$5
   PORT=$((20000 + RANDOM % 20000))
@@ -13,7 +13,7 @@ run() {  # threads total window interval small
   wait $SP; wait $NP 2>/dev/null
   echo "small-block $SB window $W interval $IV us: $(grep 'first connection' $O/srv.txt | sed 's/first connection -> last scores: //') | $(grep '^latency' $O/snd.txt | sed 's/latency request sent -> scores received //')"
 }
-for SB in 0 2 4; do
+for SB in 4; do
 run 4 400000 256 0 $SB
 run 4 150000 16 0 $SB
 run 4 60000 4 0 $SB
