@@ -337,6 +337,47 @@ def free_port_block(n):
     raise RuntimeError("no free block of %d ports" % n)
 
 
+def leg_tcp_reply(B, device, threads=4):
+    """The same path as a SERVICE: fleetrec_server --stream --reply sends the scores back over the socket block by block (adaptive batching,
+    small blocks through the stage launches), fleetrec_sender --reply --window W times request sent -> scores received.  Two operating points:
+    saturated (256 requests in flight per connection) and light (one request per 500 us per connection)."""
+    import re
+    host = os.path.join(ROOT, "gpu-fpga-recommendation-system_amd", "host")
+    srv_bin, snd_bin = os.path.join(host, "fleetrec_server"), os.path.join(host, "fleetrec_sender")
+    if not (os.path.exists(srv_bin) and os.path.exists(snd_bin)):
+        return {"skipped": "host programs not built (make -C gpu-fpga-recommendation-system_amd/host)"}
+    out = {}
+    for name, total, window, interval in (("saturated", 400000, 256, 0), ("light_load", 6000, 256, 500)):
+        port = free_port_block(threads)
+        common = ["--model", "A", "--batch", str(B), "--threads", str(threads), "--port", str(port)]
+        srv = subprocess.Popen([srv_bin] + common + ["--total", str(total), "--device", str(device), "--tables", "hash", "--weights", "uniform", "--stream", "--reply"],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        snd = None
+        try:
+            time.sleep(0.3)
+            snd = subprocess.Popen([snd_bin] + common + ["--indices", "uniform", "--reply", "--window", str(window), "--interval-us", str(interval)],
+                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            so, _ = srv.communicate(timeout=120)
+            no, _ = snd.communicate(timeout=30)
+        finally:
+            for p_ in (srv, snd):
+                if p_ is not None and p_.poll() is None:
+                    p_.kill()
+                    p_.wait()
+        so, no = so.decode(errors="replace"), no.decode(errors="replace")
+        m1 = re.search(r"first connection -> last scores: ([0-9.]+) s = ([0-9.]+) M inferences/s over TCP", so)
+        m2 = re.search(r"latency request sent -> scores received  n=(\d+) avg ([0-9.]+) us  p50 ([0-9.]+)  p90 ([0-9.]+)  p99 ([0-9.]+)", no)
+        if srv.returncode != 0 or not (m1 and m2):
+            out[name] = {"error": (so + no)[-300:]}
+            continue
+        out[name] = {"inferences_per_s": float(m1.group(2)) * 1e6, "requests_timed": int(m2.group(1)), "request_to_reply_us_p50": float(m2.group(3)),
+                     "request_to_reply_us_p90": float(m2.group(4)), "request_to_reply_us_p99": float(m2.group(5)),
+                     "offered": "%d requests in flight per connection" % window if interval == 0 else "one request per %d us per connection" % interval}
+    out["what"] = ("fleetrec_sender --reply --window 256 -> fleetrec_server --stream --reply over loopback TCP, %d connections, batch %d: scores sent back over the "
+                   "socket; latency measured at the sender (request sent -> its scores received), first 5 %% of every connection dropped" % (threads, B))
+    return out
+
+
 def leg_tcp(B, device, threads=4, total=1000000):
     """Model-A batch B through the request path the reference has: `threads` TCP connections (the reference's THREAD_NUM = 4 on PORT+i),
     fixed-size blocks of B x 47 int32 indices on the wire, the server's connection threads handing every block to fr_worker_push_host,
@@ -920,6 +961,10 @@ def main():
             result["tcp_streaming"] = leg_tcp(B, local_rank)
         except Exception as ex:
             result["tcp_streaming"] = {"error": repr(ex)[:300]}
+        try:
+            result["tcp_serving_with_replies"] = leg_tcp_reply(B, local_rank)
+        except Exception as ex:
+            result["tcp_serving_with_replies"] = {"error": repr(ex)[:300]}
 
     if want("cpu"):
         try:
