@@ -314,7 +314,7 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
                 break;
             }
             t->batches++;
-            if (o.reply && !send_ready()) break;
+            if (o.reply && (t->batches & 15) == 0 && !send_ready()) break;  // (the dry-socket path above polls too: nothing waits on this one)
         }
         if (o.stream && !g_engine) {
             if (t->status == 0 && fr_worker_sync(wk) != FR_OK) {
