@@ -287,9 +287,9 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
                         }
                     }
                     if (!send_ready()) break;
-                    if (t->batches > replied) {
-                        pollfd p2{sock, POLLIN, 0};
-                        if (poll(&p2, 1, 0) == 0) usleep(20);  // scores still on their way and nothing to read: yield briefly
+                    if (t->batches > replied) {  // scores still on their way and nothing to read: spin for the first 200 us (a small block is
+                        pollfd p2{sock, POLLIN, 0};  // back in < 100 us and a sleep's granularity is ~60 us), then yield
+                        if (poll(&p2, 1, 0) == 0 && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_dry).count() > 200.0) usleep(20);
                     }
                 }
                 if (t->status) break;
