@@ -143,11 +143,12 @@ int main(int argc, char **argv) {
                     if (reader_done.load()) break;
                     t_send[(size_t)(n_sent.load(std::memory_order_relaxed) % window)] = std::chrono::steady_clock::now();
                 }
+                const auto t_req = std::chrono::steady_clock::now();
                 if (send(sock, bi, idx.size() * 4, MSG_NOSIGNAL) <= 0) break;
                 if (!dense.empty() && send(sock, bd, dense.size() * 4, MSG_NOSIGNAL) <= 0) break;
                 sent[t]++;
                 n_sent.fetch_add(1, std::memory_order_release);
-                if (interval_us > 0) usleep((useconds_t)interval_us);  // rate limit of the latency experiment (reference sender: usleep(useconds))
+                if (interval_us > 0 && !(reply && !async_reply)) usleep((useconds_t)interval_us);  // rate limit of the latency experiment (reference sender: usleep(useconds))
                 if (reply && !async_reply) {
                     size_t got = 0;
                     while (got < scores.size() * 4) {
@@ -156,6 +157,8 @@ int main(int argc, char **argv) {
                         got += (size_t)r;
                     }
                     if (got < scores.size() * 4) break;
+                    lat_us[t].push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_req).count());
+                    if (interval_us > 0) usleep((useconds_t)interval_us);  // (the wait for the reply comes first: it is what is timed)
                 }
             }
             if (async_reply) {
