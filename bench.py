@@ -446,7 +446,7 @@ def leg_group_table(fr, ctx, model, B, d_idx, threads, depth):
     return out
 
 
-def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_host0, threads, depth, label, min_s=1.0, pmc_key=None):
+def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_host0, threads, depth, label, min_s=1.0, pmc_key=None, env=None):
     """One non-headline BASELINE configuration: steady-state throughput (>= 1 s) + an in-run roofline object for its dominant
     kernel from HIP events on one worker's stream."""
     prec_enum = {"f32": fr.FC_FP32, "bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[precision]
@@ -460,11 +460,20 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
     if min_s > 0:
         dv = fr.Driver(ctx, threads, depth, B)
         dv.run_resident(B, 256, d_idx, d_dense)
-        n = steady_run(lambda k: dv.run_resident(B, k, d_idx, d_dense), min_s, n_first=512 if min_s >= 1.0 else 64, quantum=64)
-        el = dv.run_resident(B, n, d_idx, d_dense)
+        n = steady_run(lambda k: dv.run_resident(B, k, d_idx, d_dense), min_s, n_first=512 if min_s >= 1.0 else 64, quantum=64, env=env)
+        world = env.world if env is not None else 1
+        if world > 1:   # replicas: every rank times the SAME number of batches between barriers; the slowest rank's time counts
+            env.barrier()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            dv.run_resident(B, n, d_idx, d_dense)
+            env.barrier()
+            el = env.max_over_ranks(time.perf_counter() - t0)
+        else:
+            el = dv.run_resident(B, n, d_idx, d_dense)
         dv.close()
-        res = {"workload": label, "dtype": precision, "value": n * B / el, "unit": "inferences/s", "timed_batches": n, "timed_s": el,
-               "ms_per_step": 1e3 * el / n, "fc_tflops_end_to_end": flops_inf * B * n / el / 1e12,
+        res = {"workload": label, "dtype": precision, "value": world * n * B / el, "unit": "inferences/s", "timed_batches": n, "timed_s": el,
+               "ms_per_step": 1e3 * el / n, "fc_tflops_end_to_end": flops_inf * B * n * world / el / 1e12,
                "frac_of_mfma_peak_end_to_end": flops_inf * B * n / el / 1e12 / MFMA_PEAK_TF[precision]}
     else:   # --roofline-only: no multi-stream loop
         res = {"workload": label, "dtype": precision, "value": None, "unit": "inferences/s", "timed_batches": 0, "timed_s": 0.0, "ms_per_step": None,
@@ -835,7 +844,7 @@ def main():
         # one non-headline configuration on its own: throughput + its roofline leg
         res = leg_config(fr, ctx, model, B, args.precision, d_idx, d_dense, idx_host[0], dense_host[0] if dense_host else None, args.threads, args.depth,
                          "Model-%s batch=%d %s FC chain, index rows resident in HBM" % (args.model, B, args.precision),
-                         min_s=0.0 if args.roofline_only else (0.05 if args.quick else 1.0))
+                         min_s=0.0 if args.roofline_only else (0.05 if args.quick else 1.0), env=env)
         if rank == 0:
             print(json.dumps({"metric": "inferences/sec", "value": res["value"], "unit": "inferences/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

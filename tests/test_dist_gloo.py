@@ -192,6 +192,20 @@ def test_bench_two_ranks_on_one_gpu(gpu, extra):
         assert g["ranks_measured"] == 2 and g["achieved"] > 0 and g["peak"] == 16000.0, g
 
 
+@pytest.mark.gpu
+def test_bench_two_ranks_other_configuration(gpu):
+    """`bench.py --gpus 2 --model B --batch 1024 --precision bf16`: the non-headline configurations aggregate over the ranks too (same number
+    of batches on every rank, barriers on both sides, slowest rank's time)."""
+    import json
+    rc, out, err = _run_bench(["--gpus", "2", "--backend", "gloo", "--share-device", "--model", "B", "--batch", "1024", "--precision", "bf16", "--quick"], timeout=900)
+    assert rc == 0, err[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["dtype"] == "bf16" and j["timed_batches"] > 0
+    assert abs(j["value"] - 2 * j["timed_batches"] * 1024 / j["timed_s"]) <= 1e-6 * j["value"]
+
+
 def test_bench_tcp_leg_fails_cleanly_without_a_gpu():
     """bench.py's tcp leg (fleetrec_sender -> fleetrec_server --stream in their own processes) on a host without a GPU: the server's
     set-up fails loudly (no CPU fallback), the leg reports it and leaves no process behind instead of hanging."""
