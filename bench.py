@@ -791,7 +791,8 @@ def main():
                          "multi-stream throughput loops, whose concurrent launches stretch each other, are skipped), so the profiler's average agrees with "
                          "the HIP-event figure on the bench line")
     ap.add_argument("--quick", action="store_true", help="profiling runs: 0.3 s instead of >= 2 s behind `value` (the legs are what is being profiled)")
-    ap.add_argument("--no-multi-gather", action="store_true", help="N > 1: skip the per-rank Model-C gather leg (gather_per_bank_all_ranks)")
+    ap.add_argument("--no-multi-gather", action="store_true", help="N > 1: skip the per-rank legs (gather_per_bank_all_ranks, configs_all_ranks)")
+    ap.add_argument("--no-multi-configs", action="store_true", help="N > 1: skip configs_all_ranks (Model-B bf16, Model-C bf16 / fp8 on every rank)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch / rendezvous / timing-rule check without touching a GPU or the library (CPU test of the multi-GPU launcher)")
     args = ap.parse_args()
@@ -1112,28 +1113,95 @@ def main():
             result.setdefault("gather", {})["error"] = repr(ex)
 
     if world > 1 and not args.no_multi_gather:
-        # N > 1: the other half of BASELINE.json's metric ("embedding-gather HBM GB/s vs peak, 1 -> 8 MI355X") -- every rank runs the
-        # Model-C batch-4096 record-producing gather on its own replica (per-bank indices, the reference kernel's contract), rank 0 reports
-        # the sum.  Every rank takes part in the reductions whatever happens to its own leg.
-        ach, ok = 0.0, 1.0
-        try:
+        # N > 1: the other half of BASELINE.json's metric ("embedding-gather HBM GB/s vs peak, 1 -> 8 MI355X") and BASELINE.md section 3's
+        # other models -- every rank runs the legs below on its own replicas at the same time, rank 0 reports the SUM of the per-rank rates.
+        # Collectives sit OUTSIDE the try blocks and every rank reaches every one of them whatever happens to its own leg: a rank that
+        # fails contributes 0 and is counted out in `ranks_measured`; a leg whose set-up fails on any rank is skipped by all of them.
+        def all_ranks(setup, measure):
+            state, ok = None, 1.0
+            try:
+                state = setup()
+            except Exception as ex:
+                ok = 0.0
+                sys.stderr.write("rank %d: set-up failed: %r\n" % (rank, ex))
+            if env.sum_over_ranks(ok) < world:       # collective 1
+                return None
+            val, ok = 0.0, 1.0
+            env.barrier()                            # collective 2: start together
+            try:
+                val = measure(state)
+            except Exception as ex:
+                ok = 0.0
+                sys.stderr.write("rank %d: leg failed: %r\n" % (rank, ex))
+            return env.sum_over_ranks(val), int(env.sum_over_ranks(ok))   # collectives 3, 4
+
+        holder = {}
+
+        def gather_setup():
             mcb = fr.Model.builtin(fr.MODEL_C).clone(index_mode=fr.INDEX_PER_BANK)
             cbk = fr.Context(mcb, device=local_rank)
             cbk.fill_tables(fr.FILL_HASH, SEED_TABLES)
+            cbk.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
             cbk.synchronize()
-            env.barrier()
-            gl = leg_gather(fr, cbk, mcb, 4096, "uniform", reps=200, nbuf=32, seed=dist_mod.replica_seed(SEED_IDX, rank))
-            ach = gl["achieved"]
-            cbk.close()
-        except Exception as ex:
-            ok = 0.0
-            sys.stderr.write("rank %d: gather leg failed: %r\n" % (rank, ex))
-        tot, n_ok = env.sum_over_ranks(ach), env.sum_over_ranks(ok)
-        if rank == 0:
-            result["gather_per_bank_all_ranks"] = {"achieved": tot, "unit": "GB/s", "peak": HBM_PEAK_GBS * world, "frac": tot / (HBM_PEAK_GBS * world),
-                                                   "ranks_measured": int(n_ok), "bound": "hbm",
+            holder["c"] = (mcb, cbk)
+            return mcb, cbk
+
+        r_ = all_ranks(gather_setup, lambda st: leg_gather(fr, st[1], st[0], 4096, "uniform", reps=200, nbuf=32, seed=dist_mod.replica_seed(SEED_IDX, rank))["achieved"])
+        if rank == 0 and r_ is not None:
+            result["gather_per_bank_all_ranks"] = {"achieved": r_[0], "unit": "GB/s", "peak": HBM_PEAK_GBS * world, "frac": r_[0] / (HBM_PEAK_GBS * world),
+                                                   "ranks_measured": r_[1], "bound": "hbm",
                                                    "what": "sum over the ranks of the algorithmic GB/s of fr_worker_gather_only, Model-C batch 4096, one index per bank, "
                                                            "every rank on its own replica at the same time (HIP events on each rank's stream)"}
+
+        def config_rate(ctx_, model_, Bc, prec):
+            rngc = np.random.default_rng(dist_mod.replica_seed(SEED_IDX + 5, rank))
+            ih = [uniform_idx(rngc, model_.index_ranges(), Bc) for _ in range(8)]
+            dh = [rngc.uniform(-1, 1, (Bc, model_.dense_len)).astype(np.float32) for _ in range(8)] if model_.dense_len else None
+            di = [fr.DeviceBuffer.from_numpy(ctx_, a_) for a_ in ih]
+            dd = [fr.DeviceBuffer.from_numpy(ctx_, a_) for a_ in dh] if dh else None
+            ctx_.set_fc_precision({"bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[prec])
+            if prec == "fp8":
+                cal = fr.Worker(ctx_, Bc)
+                cal.calibrate_fp8(ih[0], dh[0] if dh else None)
+                cal.close()
+            dv = fr.Driver(ctx_, args.threads, args.depth, Bc)
+            dv.run_resident(Bc, 128, di, dd)
+            n_ = steady_run(lambda k: dv.run_resident(Bc, k, di, dd), 1.0, n_first=256, quantum=64)
+            el_ = dv.run_resident(Bc, n_, di, dd)
+            dv.close()
+            for b_ in di + (dd or []):
+                b_.free()
+            return n_ * Bc / el_
+
+        if not args.no_multi_configs:
+            cfg_all = []
+            for prec in ("bf16", "fp8"):   # Model-C per-bank replicas (the context of the gather leg)
+                r_ = all_ranks(lambda: holder["c"], lambda st, p_=prec: config_rate(st[1], st[0], 4096, p_))
+                if rank == 0 and r_ is not None:
+                    cfg_all.append({"workload": "Model-C batch=4096, %s FC chain end to end, one index per bank, one replica per rank" % prec, "dtype": prec,
+                                    "value": r_[0], "unit": "inferences/s", "ranks_measured": r_[1], "how": "sum of the per-rank rates measured at the same time (>= 1 s each)"})
+            if "c" in holder:
+                holder["c"][1].close()
+                del holder["c"]
+
+            def b_setup():
+                mbb = fr.Model.builtin(fr.MODEL_B)
+                cbb = fr.Context(mbb, device=local_rank)
+                cbb.fill_tables(fr.FILL_HASH, SEED_TABLES)
+                cbb.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+                holder["b"] = (mbb, cbb)
+                return mbb, cbb
+
+            r_ = all_ranks(b_setup, lambda st: config_rate(st[1], st[0], 1024, "bf16"))
+            if rank == 0 and r_ is not None:
+                cfg_all.append({"workload": "BASELINE configs[2]: Model-B batch=1024, bf16 FC, fused concat + FC chain, one replica per rank", "dtype": "bf16",
+                                "value": r_[0], "unit": "inferences/s", "ranks_measured": r_[1], "how": "sum of the per-rank rates measured at the same time (>= 1 s each)"})
+            if "b" in holder:
+                holder["b"][1].close()
+            if rank == 0:
+                result["configs_all_ranks"] = cfg_all
+        elif "c" in holder:
+            holder["c"][1].close()
 
     if rank == 0:
         print(json.dumps(result))

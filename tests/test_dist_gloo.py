@@ -190,6 +190,8 @@ def test_bench_two_ranks_on_one_gpu(gpu, extra):
         assert j["timed_batches"] >= 300 and j["timed_s"] >= 2.0 and j["scaling"] == "weak"
         g = j["gather_per_bank_all_ranks"]     # N > 1: every rank gathers on its own Model-C replica, rank 0 reports the sum
         assert g["ranks_measured"] == 2 and g["achieved"] > 0 and g["peak"] == 16000.0, g
+        ca = j["configs_all_ranks"]            # ... and Model-C bf16 / fp8 and Model-B bf16 on every rank's replica
+        assert [c_["dtype"] for c_ in ca] == ["bf16", "fp8", "bf16"] and all(c_["ranks_measured"] == 2 and c_["value"] > 0 for c_ in ca), ca
 
 
 @pytest.mark.gpu
