@@ -746,6 +746,7 @@ def main_sharded(args, graft):
                                                                  B, G, F, "all-to-all" if a2a else "all-gather"), "parallelism": "table-sharded x%d" % G,
                        "shard_table_bytes_this_rank": int(sum(t.rows * t.dim * 4 for si in model.segments() if si.kind == fr.SEG_TABLE and offs[r] <= si.rec_offset < offs[r] + lens[r]
                                                             for t in [model.tables()[si.src]])),
+                       "min_shards_for_288GB": model.min_shards(),   # north_star: shard ONLY when the tables outgrow one GPU (1 = replicas would do)
                        "exchange": args.exchange, "backend": args.backend if world > 1 else None,
                        "slice_transport": args.precision if lp else "f32", "pipelined_equals_stepwise": verified,
                        "sharded_vs_unsharded_context": vs_unsharded,

@@ -321,6 +321,33 @@ class Model:
         return list(off), list(ln), pad.value
 
 
+    def shard_table_bytes(self, n_shards):
+        """Table bytes every shard of the n_shards-way plan would hold (host only): a table belongs to the shard whose record slice its
+        segments fall in."""
+        offs, lens, _ = self.shard_plan(n_shards)
+        tabs = self.tables()
+        out = [0] * n_shards
+        seen = set()
+        for sg in self.segments():
+            if sg.kind == SEG_DENSE:
+                continue
+            g = max(i for i in range(n_shards) if offs[i] <= sg.rec_offset)
+            if (g, sg.src) not in seen:
+                seen.add((g, sg.src))
+                out[g] += int(tabs[sg.src].rows) * int(tabs[sg.src].dim) * 4
+        return out
+
+    def min_shards(self, hbm_bytes=288e9, reserve=0.10, candidates=(1, 2, 4, 8)):
+        """BASELINE.json north_star's rule: tables shard by table-ID over the GPUs of a node ONLY when they do not fit one GPU's HBM.
+        -> the smallest G of `candidates` whose largest shard fits (1 - reserve) * hbm_bytes, or None when even the last one does not
+        (table-ID sharding cannot split a table)."""
+        budget = (1.0 - reserve) * hbm_bytes
+        for G in candidates:
+            if G <= self.desc.n_segments and max(self.shard_table_bytes(G)) <= budget:
+                return G
+        return None
+
+
 class DeviceBuffer:
     """Raw HBM allocation made through the C-ABI (no torch involved)."""
 

@@ -111,6 +111,27 @@ def test_shard_plan_properties(fr):
         fr.Model.builtin(fr.MODEL_A).shard_plan(48)           # more shards than segments
 
 
+def test_sharding_only_when_the_tables_do_not_fit(fr):
+    """north_star: "tables shard by table-ID across the 8 GPUs of one node ... only when total table bytes exceed one GPU's 288 GB".
+    Model.min_shards applies that rule on the host: the three reference models need no sharding, Model-C with its tables inflated 5 x
+    (322 GB: BASELINE configs[4]) needs 2 shards (configs[4] uses all 8), and a model with one table larger than a GPU cannot be served by table-ID sharding."""
+    for which in (fr.MODEL_A, fr.MODEL_B, fr.MODEL_C):
+        m = fr.Model.builtin(which)
+        assert m.min_shards() == 1
+        assert sum(m.shard_table_bytes(1)) == m.table_bytes()
+        assert sum(m.shard_table_bytes(8)) >= m.table_bytes()      # a COPY pad may pull a table into a second shard
+    big = fr.Model.builtin(fr.MODEL_C).clone(row_scale=5.0)       # BASELINE configs[4]: 322 GB of tables
+    assert big.table_bytes() > 288e9
+    G = big.min_shards()
+    assert G == 2 and max(big.shard_table_bytes(2)) < 0.9 * 288e9 < max(big.shard_table_bytes(1))   # 159 + 163 GB: two GPUs hold it
+    assert max(big.shard_table_bytes(8)) < max(big.shard_table_bytes(2))     # configs[4] runs it 8-way; the rule's minimum is 2
+    bigger = fr.Model.builtin(fr.MODEL_C).clone(row_scale=9.0)
+    assert bigger.min_shards() in (4, 8) and max(bigger.shard_table_bytes(bigger.min_shards())) <= 0.9 * 288e9
+    assert max(bigger.shard_table_bytes(bigger.min_shards() // 2)) > 0.9 * 288e9
+    huge = fr.Model.builtin(fr.MODEL_C).clone(row_scale=40.0)     # one table alone outgrows a GPU: table-ID sharding cannot split it
+    assert huge.min_shards() is None
+
+
 def test_single_rank_exchange_fills_the_callers_buffer(fr):
     """world == 1: the exchange is the identity, but a caller-supplied output buffer must still receive the slice (bench.py's
     sharded mode reads ITS buffer; round 1 left it uninitialised -- ADVICE r01)."""
