@@ -1060,7 +1060,7 @@ def main():
             if want("gather"):
                 g = {"workload": "Model-C (2x embedding_377_krnl + 64 dense: 376 tables, 63.2 GB) batch=4096, record-producing gather "
                                  "(fr_worker_gather_only), per-table indices", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "kernel": "gather_pack_xcd_kernel<8>"}
+                     "kernel": "gather_pack_stream_kernel<4, 2, 0, 16>"}
                 if args.gather_law in ("all", "uniform"):
                     g.update(leg_gather(fr, cc, mc, BC, "uniform", variants=not args.no_gather_ab))
                     pm = pmc("gather_C4096_per_table_uniform") or {}
@@ -1093,7 +1093,7 @@ def main():
                 cbk.fill_tables(fr.FILL_HASH, SEED_TABLES)
                 gb = {"workload": "Model-C batch=4096, FR_INDEX_PER_BANK: one index per memory bank per item (82 banks; embedding_377_krnl.cpp:1261-1290), "
                                   "tables of a bank row-interleaved in HBM; uniform indices over each bank's valid range", "bound": "hbm",
-                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "gather_pack_xcd_kernel<8>"}
+                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "gather_pack_stream_kernel<4, 2, 0, 16>"}
                 gb.update(leg_gather(fr, cbk, mcb, BC, "uniform", variants=not args.no_gather_ab))
                 pm = pmc("gather_C4096_per_bank_uniform") or {}
                 gb["traffic"] = pm.get("traffic_bytes_per_launch")

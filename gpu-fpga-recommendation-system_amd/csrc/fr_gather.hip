@@ -14,9 +14,16 @@
 // TP = what a record word is stored as: 0 fp32 (16 bytes, a bit copy), 1 bf16 (8 bytes, RNE), 2 e4m3 (4 bytes, x scale, saturated).
 // The low-precision forms are the sharded mode's slice TRANSPORT formats: half / a quarter of the all-gather bytes, and exactly the
 // values the bf16 / fp8 chain would have made of the fp32 slice on arrival.
-template <int TP>
+// AUX = the cache-policy bits of a buffer store (gfx950: 1 sc0, 2 nt, 16 sc1; 16 = write-through): only the fp32 record stores of
+// gather_pack_xcd_kernel use it, through a resource over `out` (the launcher keeps AUX = 0 when the records exceed 4 GiB)
+template <int TP, int AUX = 0>
 __device__ __forceinline__ void store_word(void *out, size_t word, const uint4 &v, float scale) {
-    if constexpr (TP == 0) {
+    if constexpr (TP == 0 && AUX != 0) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0xffffffffu, 0x00020000);
+        u32x4_t q;
+        q.x = v.x, q.y = v.y, q.z = v.z, q.w = v.w;
+        __builtin_amdgcn_raw_buffer_store_b128(q, rs, (unsigned)(word * 16), 0, AUX);
+    } else if constexpr (TP == 0) {
         reinterpret_cast<uint4 *>(out)[word] = v;
     } else if constexpr (TP == 1) {
         reinterpret_cast<uint2 *>(out)[word] = make_uint2(pack_bf16x2(__uint_as_float(v.x), __uint_as_float(v.y)), pack_bf16x2(__uint_as_float(v.z), __uint_as_float(v.w)));
@@ -73,7 +80,7 @@ __global__ void __launch_bounds__(256) gather_pack_kernel(const FrWordDesc *__re
 // ALL items (FrGatherGroups: cut on source-row boundaries, so no table row / bank row is fetched by two XCDs).  Every table is then
 // touched from ONE XCD only, so the 8 x 4 MiB L2s cache 8 different table sets instead of 8 copies of the same hottest 4 MiB --
 // rows served by L2 cost ~5 cycles/CU instead of ~12 from the fabric (profiles/r01_experiments.md, ta_cost2).
-template <int ITEMS, int TP>
+template <int ITEMS, int TP, int AUX = 0>
 __global__ void __launch_bounds__(256) gather_pack_xcd_kernel(const FrWordDesc *__restrict__ words, const FrGatherGroups groups,
                                                               const int32_t *__restrict__ idx, int idx_stride,
                                                               const float *__restrict__ dense, void *__restrict__ out,
@@ -114,20 +121,150 @@ __global__ void __launch_bounds__(256) gather_pack_xcd_kernel(const FrWordDesc *
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
             const int b = b0 + i;
-            if (b < batch) store_word<TP>(out, blk + (size_t)b * dst_stride, v[i], scale);
+            if (b < batch) store_word<TP, AUX>(out, blk + (size_t)b * dst_stride, v[i], scale);
         }
+    }
+    if (bad) atomicOr_system(err_flag, 1);
+}
+
+// Software-pipelined form of gather_pack_xcd_kernel: a workgroup keeps its descriptors and walks NSTEP chunks of ITEMS items
+// (chunks j, j + cs, j + 2 cs, ... of its XCD group) with the index loads TWO chunks ahead and the row loads ONE chunk ahead of the
+// record stores.  A chunk's dependent chain (descriptor -> index -> row -> store) is then paid once per workgroup of NSTEP chunks, and
+// every wave mixes loads and stores from its first stored chunk on (the one-chunk-per-workgroup form starts with a read-only phase
+// of every resident workgroup at once).  Straight-line code (NSTEP is a template parameter), so every s_waitcnt is a counted one;
+// items past the batch cost no branch: their index loads and record stores go through buffer resources whose bounds drop them.
+// Needs batch * idx_stride * 4 and the record bytes below 4 GiB (the launcher falls back to gather_pack_xcd_kernel otherwise).
+template <int ITEMS, int NSTEP, int TP, int AUX>
+__global__ void __launch_bounds__(256) gather_pack_stream_kernel(const FrWordDesc *__restrict__ words, const FrGatherGroups groups,
+                                                                 const int32_t *__restrict__ idx, int idx_stride,
+                                                                 const float *__restrict__ dense, void *__restrict__ out,
+                                                                 int batch, int *__restrict__ err_flag, float scale, unsigned out_bytes) {
+    const int group = blockIdx.x & 7;
+    const int w0 = groups.start[group];
+    if ((int)threadIdx.x >= groups.start[group + 1] - w0) return;
+    const int w = w0 + threadIdx.x;
+    const uint4 d0 = reinterpret_cast<const uint4 *>(words)[2 * w];
+    const uint4 d1 = reinterpret_cast<const uint4 *>(words)[2 * w + 1];
+    const uint64_t src = ((uint64_t)d0.y << 32) | d0.x;
+    const uint32_t stride = d0.z, idx_col = d0.w;
+    const uint32_t rows = d1.x, dst_off = d1.y, dst_stride = d1.z, dst_blk = d1.w;
+    const bool is_dense = (idx_col & FR_DESC_DENSE) != 0;
+    const uint64_t base = (is_dense ? (uint64_t)reinterpret_cast<uintptr_t>(dense) : 0ull) + src;
+    constexpr unsigned ESZ = TP == 0 ? 16u : TP == 1 ? 8u : 4u;   // bytes a record word is stored as
+    const unsigned blk = (dst_blk * (unsigned)batch + dst_off) * ESZ;
+    const unsigned ostride = dst_stride * ESZ;
+    const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(idx), 0, (unsigned)batch * (unsigned)idx_stride * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, out_bytes, 0x00020000);
+    const unsigned icol = is_dense ? 0u : idx_col * 4u;
+    bool bad = false;
+    const int cs = gridDim.x >> 3, c0 = blockIdx.x >> 3;
+    uint32_t id[NSTEP][ITEMS];
+    uint4 v[NSTEP][ITEMS];
+    auto load_idx = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const unsigned b = (unsigned)(c0 + st * cs) * ITEMS + i;
+            // an item past the batch reads past the resource: 0, no branch (dense words do not use the value)
+            id[st][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_idx, b * (unsigned)idx_stride * 4u + icol, 0, 0);
+        }
+    };
+    auto load_rows = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const unsigned b = (unsigned)(c0 + st * cs) * ITEMS + i;
+            uint32_t r = id[st][i];
+            const bool oob = !is_dense & (r >= rows);  // reference: silent out-of-bounds read (embedding_47_krnl.cpp:927-933)
+            bad |= oob;
+            r = oob ? 0u : r;
+            r = is_dense ? (b < (unsigned)batch ? b : 0u) : r;
+            typedef const u32x4_t __attribute__((address_space(1))) * gptr_t;   // a global_load (not a flat one: no lgkmcnt, no aperture check)
+            const u32x4_t q = *(gptr_t)(base + (uint64_t)r * stride);
+            v[st][i] = make_uint4(q.x, q.y, q.z, q.w);
+        }
+    };
+    auto store_rows = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const unsigned b = (unsigned)(c0 + st * cs) * ITEMS + i;
+            const unsigned off = b < (unsigned)batch ? blk + b * ostride : 0xffffffffu;   // past the batch: dropped by the resource's bounds
+            const uint4 &q = v[st][i];
+            if constexpr (TP == 0) {
+                u32x4_t x;
+                x.x = q.x, x.y = q.y, x.z = q.z, x.w = q.w;
+                __builtin_amdgcn_raw_buffer_store_b128(x, rs_out, off, 0, AUX);
+            } else if constexpr (TP == 1) {
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                u32x2_t x;
+                x.x = pack_bf16x2(__uint_as_float(q.x), __uint_as_float(q.y)), x.y = pack_bf16x2(__uint_as_float(q.z), __uint_as_float(q.w));
+                __builtin_amdgcn_raw_buffer_store_b64(x, rs_out, off, 0, AUX);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(pack_fp8_word(q, scale), rs_out, off, 0, AUX);
+            }
+        }
+    };
+    load_idx(0);
+    if constexpr (NSTEP > 1) load_idx(1);
+    load_rows(0);
+#pragma unroll
+    for (int st = 0; st < NSTEP; st++) {
+        if (st + 2 < NSTEP) load_idx(st + 2);
+        if (st + 1 < NSTEP) load_rows(st + 1);
+        store_rows(st);
     }
     if (bad) atomicOr_system(err_flag, 1);
 }
 
 template <int ITEMS, int TP>
 static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &groups, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch,
-                             int *err_flag, float scale, hipStream_t s) {
+                             int *err_flag, float scale, hipStream_t s, int n_words) {
+    const size_t n_rec_bytes = (size_t)n_words * 16;
     const int bx = ((groups.max_words + 63) / 64) * 64;
     const int n_chunks = (batch + ITEMS - 1) / ITEMS;
     const char *e_loop = getenv("FR_GATHER_LOOP");  // experiment knob: chunks a workgroup walks (1 = one chunk per workgroup)
     const int per_wg = e_loop ? (atoi(e_loop) > 0 ? atoi(e_loop) : 1) : 1;
     dim3 grid(8 * ((n_chunks + per_wg - 1) / per_wg));
+    if constexpr (ITEMS == 4 || ITEMS == 2) {
+        // default: the software-pipelined form, 2 chunks per workgroup, write-through record stores while the records fit the Infinity
+        // Cache with room to spare (profiles/r02_gather_stream_sweep.txt: Model-C batch 4096 per-bank 25.2 -> 22.0 us; beyond ~200 MB of
+        // records write-back stores are as fast or 1-2 % faster).  Experiment knobs, read per launch: FR_GATHER_STREAM = chunks per
+        // workgroup (0 = the one-chunk form below), FR_GATHER_STORE = 0 write-back / 16 write-through.
+        const char *e_stream = getenv("FR_GATHER_STREAM"), *e_st = getenv("FR_GATHER_STORE");
+        const int nstep = e_stream ? atoi(e_stream) : 2;
+        const size_t esz = TP == 0 ? 16 : TP == 1 ? 8 : 4;
+        const size_t out_bytes = (size_t)batch * (size_t)n_words * esz, idx_bytes = (size_t)batch * (size_t)idx_stride * 4;
+        if (nstep > 0 && out_bytes < ((size_t)1 << 32) && idx_bytes < ((size_t)1 << 32)) {
+            const bool wt = e_st ? atoi(e_st) == 16 : out_bytes <= ((size_t)200 << 20);
+#define FR_G_STREAM(NS)                                                                                                                     \
+    case NS: {                                                                                                                              \
+        dim3 g2(8 * ((n_chunks + NS - 1) / NS));                                                                                            \
+        if (wt) gather_pack_stream_kernel<ITEMS, NS, TP, 16><<<g2, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, (unsigned)out_bytes); \
+        else gather_pack_stream_kernel<ITEMS, NS, TP, 0><<<g2, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, (unsigned)out_bytes);    \
+        KCHECK();                                                                                                                           \
+        return FR_OK;                                                                                                                       \
+    }
+            switch (nstep) {
+                FR_G_STREAM(1)
+                FR_G_STREAM(2)
+                FR_G_STREAM(4)
+                FR_G_STREAM(8)
+                default: break;
+            }
+#undef FR_G_STREAM
+        }
+    }
+    if constexpr (ITEMS == 4 && TP == 0) {
+        const char *e_st = getenv("FR_GATHER_STORE");  // experiment knob: cache policy of the record stores (0 plain, 16 sc1, 2 nt) of the one-chunk form
+        const int st = e_st ? atoi(e_st) : 0;
+        if (st && (size_t)batch * (size_t)n_rec_bytes < ((size_t)1 << 32)) {
+#define FR_G_ST(A) case A: gather_pack_xcd_kernel<4, 0, A><<<grid, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, n_chunks); KCHECK(); return FR_OK;
+            switch (st) {
+                FR_G_ST(16)
+                FR_G_ST(2)
+                default: break;
+            }
+#undef FR_G_ST
+        }
+    }
     gather_pack_xcd_kernel<ITEMS, TP><<<grid, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, n_chunks);
     KCHECK();
     return FR_OK;
@@ -150,11 +287,11 @@ static int gather_launch(const FrWordDesc *words, int n_words, const FrGatherGro
         }
         if (groups.max_words <= 256) {
             switch (e_items ? atoi(e_items) : 4) {  // 4 items per thread: fastest in the r02 sweep (profiles/r02_gather_sweep.txt)
-                case 1: return gather_launch_xcd<1, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s);
-                case 2: return gather_launch_xcd<2, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s);
-                case 8: return gather_launch_xcd<8, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s);
-                case 16: return gather_launch_xcd<16, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s);
-                default: return gather_launch_xcd<4, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s);
+                case 1: return gather_launch_xcd<1, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words);
+                case 2: return gather_launch_xcd<2, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words);
+                case 8: return gather_launch_xcd<8, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words);
+                case 16: return gather_launch_xcd<16, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words);
+                default: return gather_launch_xcd<4, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words);
             }
         }
     }

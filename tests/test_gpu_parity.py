@@ -101,6 +101,102 @@ def test_gather_tagged_wire_order(fr, O, gpu, which):
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", ["table", "bank", "item"])
+def test_wide_record_gather_ragged_batches_and_transports(fr, O, gpu, mode):
+    """gather_pack_stream_kernel (records of >= 512 words at batch >= 1024: the software-pipelined, XCD-partitioned form whose index
+    loads and record stores are bounded by buffer resources instead of branches): batches that end inside a chunk, inside a
+    workgroup's second chunk and exactly on one, in every index mode; bit-exact against the oracle.  The bf16 / e4m3 transport forms
+    of the same launch against RNE of the fp32 records and against the narrow-batch kernel (batch < 1024 takes gather_pack_kernel)
+    on the same items; an out-of-range index in the ragged tail is reported."""
+    imode = {"table": fr.INDEX_PER_TABLE, "bank": fr.INDEX_PER_BANK, "item": fr.INDEX_PER_ITEM}[mode]
+    m = fr.Model.builtin(fr.MODEL_C).clone(max_rows=30000, index_mode=imode)
+    om = O.OracleModel("C")
+    ctx = fr.Context(m, device=gpu)
+    ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    rng = np.random.default_rng(4242)
+    BMAX = 2056
+    wk = fr.Worker(ctx, BMAX)
+    dense = rng.uniform(-1, 1, (BMAX, m.dense_len)).astype(np.float32)
+    if mode == "table":
+        idx = uniform_idx(rng, m.rows(), BMAX)
+        want = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES)
+    elif mode == "bank":
+        _, brows = m.bank_map()
+        idx = uniform_idx(rng, brows, BMAX)
+        want = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES, per_bank=True)
+    else:
+        idx = rng.integers(0, int(m.rows().min()), (BMAX, 1), dtype=np.int32)
+        want = om.gather(np.repeat(idx, m.n_tables, axis=1), dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES)
+    for B in (1024, 1027, 1029, 2050, BMAX):
+        got = wk.gather_records(idx[:B], dense[:B]).reshape(B, m.record_len)
+        assert np.array_equal(got, want[:B]), (mode, B)
+    f32 = want.view(np.float32)
+    d_i = fr.DeviceBuffer.from_numpy(ctx, idx)
+    d_d = fr.DeviceBuffer.from_numpy(ctx, dense)
+    for B in (1027, BMAX):
+        d_sl = fr.DeviceBuffer(ctx, B * m.record_len * 2)
+        wk.gather_slices(B, d_i, d_d, d_sl, fr.FC_BF16)
+        wk.sync()
+        got16 = d_sl.download(np.uint16, B * m.record_len).reshape(B, m.record_len)
+        assert np.array_equal(got16, (bf16_round(f32[:B]).view(np.uint32) >> 16).astype(np.uint16)), (mode, B)
+        d_sl.free()
+    # an out-of-range index in the ragged tail is seen (and the flag is cleared once reported)
+    bad = idx[:1027].copy()
+    bad[1026, -1] = 2 ** 30
+    d_bad = fr.DeviceBuffer.from_numpy(ctx, bad)
+    d_rec = fr.DeviceBuffer(ctx, 1027 * m.record_len * 4)
+    with pytest.raises(fr.FleetRecError) as e:
+        wk.gather_only(1027, d_bad, d_d, d_rec)
+        wk.sync()
+    assert e.value.status == fr.FR_ERR_INDEX_RANGE
+    wk.gather_only(1027, d_i, d_d, d_rec)
+    wk.sync()
+    assert np.array_equal(d_rec.download(np.uint32, 1027 * m.record_len).reshape(1027, -1), want[:1027])
+    wk.close()
+    # e4m3 transport: the same bytes as the narrow-batch kernel writes for the same items
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    ctx.set_fc_precision(fr.FC_FP8)
+    wk8 = fr.Worker(ctx, BMAX)
+    wk8.calibrate_fp8(idx[:256], dense[:256])
+    d_a, d_b = fr.DeviceBuffer(ctx, BMAX * m.record_len), fr.DeviceBuffer(ctx, 1000 * m.record_len)
+    wk8.gather_slices(BMAX, d_i, d_d, d_a, fr.FC_FP8)
+    wk8.sync()
+    wk8.gather_slices(1000, d_i, d_d, d_b, fr.FC_FP8)
+    wk8.sync()
+    a8 = d_a.download(np.uint8, BMAX * m.record_len).reshape(BMAX, m.record_len)
+    assert np.array_equal(a8[:1000], d_b.download(np.uint8, 1000 * m.record_len).reshape(1000, m.record_len))
+    act_exp, _ = ctx.fp8_exponents()
+    assert np.array_equal(a8, e4m3_encode(f32 * np.float32(2.0 ** act_exp[0])))
+    wk8.close()
+    ctx.close()
+
+
+def test_wide_record_gather_with_a_dense_block(fr, gpu):
+    """The same kernel on a user-defined model whose 648-word record carries a dense block between two table sources (dense words
+    take their item number, not an index): ragged batch >= 1024, against the segment-by-segment definition of the record."""
+    rng = np.random.default_rng(77)
+    tabs = [{"dim": int(rng.choice([16, 32, 64])), "rows": int(rng.integers(50, 5000))} for _ in range(72)]
+    m = fr.Model.from_spec({"name": "wide_dense", "tables": tabs, "dense_len": 24, "dense_at": 31, "fc": [1024, 512, 256]})
+    assert m.record_len // 4 >= 512
+    ctx = fr.Context(m, device=gpu)
+    host = [rng.standard_normal((t["rows"], t["dim"])).astype(np.float32) for t in tabs]
+    for t, a in enumerate(host):
+        ctx.upload_table(t, a)
+    B = 1024 + 203
+    idx = uniform_idx(rng, m.rows(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+    want = np.empty((B, m.record_len), np.float32)
+    for sg in m.segments():
+        if sg.kind == fr.SEG_DENSE:
+            want[:, sg.rec_offset:sg.rec_offset + sg.len] = dense[:, sg.src_col:sg.src_col + sg.len]
+        else:
+            want[:, sg.rec_offset:sg.rec_offset + sg.len] = host[sg.src][idx[:, sg.src], sg.src_col:sg.src_col + sg.len]
+    wk = fr.Worker(ctx, B)
+    assert np.array_equal(wk.gather_records(idx, dense).reshape(B, m.record_len), want.view(np.uint32))
+    wk.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("which,mode", [(0, "table"), (1, "table"), (2, "table"), (2, "bank"), (1, "item")])
 def test_gather_kernel_variants_are_bit_identical(fr, O, gpu, which, mode):
     """fr_ctx_set_gather_variant: the item-tile gather (LDS-staged row packing) with and without the wave-level merge of duplicate
