@@ -844,9 +844,10 @@ static int pipeline_step(fr_worker *w) {
                 st.out = wr.x;
                 st.K = fc[0];
                 w->last_x_parity = par;
-                const int trb = frk_gather_tr_blocks(c->n_words, ldm);
+                const int trv = frk_gather_tr_variant(sl.batch, a.idx_stride);
+                const int trb = frk_gather_tr_blocks(c->n_words, ldm, trv);
                 if (trb > 0) {  // large batch: LDS-transposing gather
-                    st.variant = 1;
+                    st.variant = trv;
                     blocks += (trb + 7) / 8 * 8;
                     n_stages++;
                     only = s;

@@ -83,7 +83,7 @@ struct FrStageArgs {
     int nsplit;       // FC stages: workgroups along K per output tile (partials written to out + p*part_stride);
                       // K % (8 * nsplit) == 0 is required (groups of 8 k)
     int nparts_in;    // FC/out stages: partial inputs to add while loading (1 or 2)
-    int variant;      // gather stage: 1 = LDS-transposing form for large batches (see gather_tr_body)
+    int variant;      // gather stage: LDS-transposing forms for large batches, 1 = gather_tr_body, 2 = gather_tr_stream_body
     int part_stride;  // floats between the partial OUTPUT buffers
     int in_part_stride;  // floats between the partial INPUT buffers
     int e_w, e_in, e_out;  // fp8 chain: power-of-two quantisation exponents of the weights, the input and the output activations
@@ -284,7 +284,8 @@ int frk_q4_to_lp(int precision, const float *Xq, void *Xo, int K, int ldm, int e
 int frk_stage_blocks_f8_gather(int K, int ldm);
 int frk_pack_weights_q4(const float *W, float *Wq, int K, int H, hipStream_t s);
 int frk_stage_blocks(int stage, int n_words, int K, int N, int ldm, int nsplit);
-int frk_gather_tr_blocks(int n_words, int ldm);
+int frk_gather_tr_blocks(int n_words, int ldm, int variant);
+int frk_gather_tr_variant(int batch, int idx_stride);
 bool frk_fused_ok(int K, int H1, int H2, int H3);
 int frk_fused_launch(const FrFusedArgs &a, hipStream_t s);
 bool frk_fused_m2_ok(int K, int H1, int H2, int H3);

@@ -173,9 +173,122 @@ __device__ __forceinline__ void gather_tr_body(const FrPipeArgs &a, const FrStag
     }
 }
 
-int frk_gather_tr_blocks(int n_words, int ldm) {
+// Software-pipelined form of gather_tr_body (the same lesson as gather_pack_stream_kernel): a workgroup owns NT consecutive item
+// tiles of one 64-word block; it keeps its descriptors, issues the index loads of ALL its tiles first and the row loads of all of
+// them next, and transposes / stores tile t while the rows of tile t + 1 are still in flight.  Straight-line and branch-free in the
+// load phase: items past the batch read index 0 through the bounds of a buffer resource; the image stores go through a resource
+// over the workgroup's word block with the cache policy AUX (16 = write-through: the image is not left dirty in L2 for the
+// end-of-kernel write-back).  Needs batch * idx_stride * 4 < 4 GiB (variant chosen by the host).
+template <int PREC, int NT, int AUX>
+__device__ __forceinline__ void gather_tr_stream_body(const FrPipeArgs &a, const FrStageArgs &st, int local, uint4 *tile /* [32][64], swizzled */) {
+    const int m_tiles = st.ldm / FR_GT_ITEMS, m_groups = (m_tiles + NT - 1) / NT;
+    const int mg = local % m_groups, wb = local / m_groups;
+    const int w0 = wb * FR_GT_WORDS;
+    if (w0 >= a.n_words) return;  // padding workgroup
+    const int wl = threadIdx.x & 63, ig = threadIdx.x >> 6;
+    const int w = w0 + wl < a.n_words ? w0 + wl : a.n_words - 1;   // a lane past the record repeats the last word (its tile column is never read)
+    const uint4 d0 = reinterpret_cast<const uint4 *>(a.words)[2 * w];
+    const uint4 d1 = reinterpret_cast<const uint4 *>(a.words)[2 * w + 1];
+    const uint32_t stride = d0.z, idx_col = d0.w, rows = d1.x;
+    const bool is_dense = (idx_col & FR_DESC_DENSE) != 0;
+    const uint64_t base = (is_dense ? (uint64_t)reinterpret_cast<uintptr_t>(a.dense) : 0ull) + (((uint64_t)d0.y << 32) | d0.x);
+    const unsigned icol = is_dense ? 0u : idx_col * 4u;
+    const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.idx), 0, (unsigned)st.batch * (unsigned)a.idx_stride * 4u, 0x00020000);
+    uint32_t id[NT][4];
+    uint4 v[NT][4];
+    bool bad = false;
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const unsigned m = (unsigned)((mg * NT + t) * FR_GT_ITEMS + 4 * ig + i);
+            id[t][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_idx, m * (unsigned)a.idx_stride * 4u + icol, 0, 0);
+        }
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const unsigned m = (unsigned)((mg * NT + t) * FR_GT_ITEMS + 4 * ig + i);
+            uint32_t r = id[t][i];
+            const bool oob = !is_dense & (r >= rows);  // reference: silent out-of-bounds read (embedding_47_krnl.cpp:927-933)
+            bad |= oob;
+            r = oob ? 0u : r;
+            r = is_dense ? (m < (unsigned)st.batch ? m : 0u) : r;
+            typedef const u32x4_t __attribute__((address_space(1))) * gptr_t;
+            const u32x4_t q = *(gptr_t)(base + (uint64_t)r * stride);
+            v[t][i] = make_uint4(q.x, q.y, q.z, q.w);
+        }
+    constexpr unsigned OSZ = 16;  // every image element (q4 word, q8 pair, q16 quad) is 16 bytes per item
+    const int il = threadIdx.x & 31, ws = threadIdx.x >> 5;  // phase 2: lanes along items, 16 word slots
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int m0 = (mg * NT + t) * FR_GT_ITEMS;
+        if (m0 >= st.ldm) break;  // workgroup-uniform: the last group of an odd tile count
+        if (t > 0) __syncthreads();   // the previous tile has been read out
+#pragma unroll
+        for (int i = 0; i < 4; i++) tile[gt_at(4 * ig + i, wl)] = (m0 + 4 * ig + i < st.batch) ? v[t][i] : make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        const int m = m0 + il;
+        auto put = [&](size_t elem_row, const uint4 &x) {   // image element row (word / pair / quad index) of item m
+            if constexpr (AUX == 0) {
+                reinterpret_cast<uint4 *>(st.out)[elem_row * st.ldm + m] = x;
+            } else {
+                const size_t row0 = PREC == 0 ? (size_t)w0 : PREC == 1 ? (size_t)(w0 >> 1) : (size_t)(w0 >> 2);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(st.out) + row0 * st.ldm * OSZ, 0, 0xffffffffu, 0x00020000);
+                u32x4_t q;
+                q.x = x.x, q.y = x.y, q.z = x.z, q.w = x.w;
+                __builtin_amdgcn_raw_buffer_store_b128(q, rs, (unsigned)(((elem_row - row0) * st.ldm + m) * OSZ), 0, AUX);
+            }
+        };
+        if constexpr (PREC == 0) {
+#pragma unroll
+            for (int j = 0; j < FR_GT_WORDS / 16; j++) {
+                const int wl2 = ws + 16 * j, w2 = w0 + wl2;
+                if (w2 < a.n_words) put((size_t)w2, tile[gt_at(il, wl2)]);
+            }
+        } else if constexpr (PREC == 2) {
+            const float scale = __builtin_ldexpf(1.0f, st.e_out);
+            const int KE = (st.K + 63) / 64 * 4;
+            const int el = ws, e = (w0 >> 2) + el;
+            if (e < KE) {
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int wl2 = 4 * el + j;
+                    o[j] = (w0 + wl2 < a.n_words) ? pack_fp8_word(tile[gt_at(il, wl2)], scale) : 0u;
+                }
+                put((size_t)e, make_uint4(o[0], o[1], o[2], o[3]));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < FR_GT_WORDS / 32; j++) {
+                const int pl = ws + 16 * j, w2 = w0 + 2 * pl;
+                if (w2 < a.n_words) {
+                    const uint4 lo = tile[gt_at(il, 2 * pl)], hi = tile[gt_at(il, 2 * pl + 1)];
+                    uint4 h;
+                    h.x = pack_bf16x2(__uint_as_float(lo.x), __uint_as_float(lo.y));
+                    h.y = pack_bf16x2(__uint_as_float(lo.z), __uint_as_float(lo.w));
+                    h.z = pack_bf16x2(__uint_as_float(hi.x), __uint_as_float(hi.y));
+                    h.w = pack_bf16x2(__uint_as_float(hi.z), __uint_as_float(hi.w));
+                    put((size_t)(w2 >> 1), h);
+                }
+            }
+        }
+    }
+    if (bad) atomicOr_system(a.err_flag, 1);
+}
+
+// 2 = gather_tr_stream_body (two tiles per workgroup, write-through image stores: Model-C batch 4096 chain 55 -> 58 M inf/s in fp8,
+// 35.7 -> 37 M in bf16, profiles/r02_gather_tr_variants.txt); 1 = gather_tr_body (FR_GATHER_TR_VARIANT=1, and index buffers >= 4 GiB)
+int frk_gather_tr_variant(int batch, int idx_stride) {
+    static const int v = getenv("FR_GATHER_TR_VARIANT") ? atoi(getenv("FR_GATHER_TR_VARIANT")) : 2;  // experiment knob
+    return (v == 1 || (size_t)batch * (size_t)idx_stride * 4 >= ((size_t)1 << 32)) ? 1 : 2;
+}
+
+int frk_gather_tr_blocks(int n_words, int ldm, int variant) {
     if (ldm % FR_GT_ITEMS || (n_words & 1)) return 0;
-    const int blocks = (ldm / FR_GT_ITEMS) * ((n_words + FR_GT_WORDS - 1) / FR_GT_WORDS);
+    const int nt = variant == 2 ? 2 : 1;
+    const int blocks = ((ldm / FR_GT_ITEMS + nt - 1) / nt) * ((n_words + FR_GT_WORDS - 1) / FR_GT_WORDS);
     static const int forced = getenv("FR_GATHER_TR") ? atoi(getenv("FR_GATHER_TR")) : -1;  // experiment knob
     if (forced == 0) return 0;
     if (forced == 1) return blocks;
@@ -744,6 +857,8 @@ __global__ void __launch_bounds__(FR_PIPE_THREADS) fr_pipeline_kernel(const FrPi
     if (a.stamps) t_in = __builtin_amdgcn_s_memrealtime();  // diagnostics only; the values never feed an output
     if (s == 0 && st.variant == 1) {
         gather_tr_body<PREC>(a, st, local, smem);
+    } else if (s == 0 && st.variant == 2) {
+        gather_tr_stream_body<PREC, 2, 16>(a, st, local, smem);
     } else if constexpr (PREC == 1) {
         if (s == 0) gather_h_body(a, st, local);
         else if (s == 4) fc_out_h_body(st, local, red);
