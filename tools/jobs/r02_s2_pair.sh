@@ -1,7 +1,7 @@
 # the driver's bench command and the rocprofv3 kernel stats of the roofline leg on ONE box (the pair profiles/README.md quotes)
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/s2_pair; mkdir -p $O
+O=$R/gpurun_out/pair; mkdir -p $O
 timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_line.err
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_roofline -- python3 $R/bench.py --roofline-only > $O/stats_roofline.log 2>&1
