@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) gather_pack_xcd_kernel(const FrWordDesc *
 // every wave mixes loads and stores from its first stored chunk on (the one-chunk-per-workgroup form starts with a read-only phase
 // of every resident workgroup at once).  Straight-line code (NSTEP is a template parameter), so every s_waitcnt is a counted one;
 // items past the batch cost no branch: their index loads and record stores go through buffer resources whose bounds drop them.
-// Needs batch * idx_stride * 4 and the record bytes below 4 GiB (the launcher falls back to gather_pack_xcd_kernel otherwise).
+// Needs batch * idx_stride * 4 and the record bytes below 4000 MiB (the launcher falls back to gather_pack_xcd_kernel otherwise).
 template <int ITEMS, int NSTEP, int TP, int AUX>
 __global__ void __launch_bounds__(256) gather_pack_stream_kernel(const FrWordDesc *__restrict__ words, const FrGatherGroups groups,
                                                                  const int32_t *__restrict__ idx, int idx_stride,
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) gather_pack_stream_kernel(const FrWordDes
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
             const unsigned b = (unsigned)(c0 + st * cs) * ITEMS + i;
-            const unsigned off = b < (unsigned)batch ? blk + b * ostride : 0xffffffffu;   // past the batch: dropped by the resource's bounds
+            const unsigned off = b < (unsigned)batch ? blk + b * ostride : out_bytes;   // past the batch: offset == num_records, dropped by the resource's bounds (no 32-bit wrap)
             const uint4 &q = v[st][i];
             if constexpr (TP == 0) {
                 u32x4_t x;
@@ -232,7 +232,7 @@ static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &grou
         const int nstep = e_stream ? atoi(e_stream) : 2;
         const size_t esz = TP == 0 ? 16 : TP == 1 ? 8 : 4;
         const size_t out_bytes = (size_t)batch * (size_t)n_words * esz, idx_bytes = (size_t)batch * (size_t)idx_stride * 4;
-        if (nstep > 0 && out_bytes < ((size_t)1 << 32) && idx_bytes < ((size_t)1 << 32)) {
+        if (nstep > 0 && out_bytes < ((size_t)4000 << 20) && idx_bytes < ((size_t)4000 << 20)) {  // 32-bit resource offsets, with room for the chunk past the batch
             const bool wt = e_st ? atoi(e_st) == 16 : out_bytes <= ((size_t)200 << 20);
 #define FR_G_STREAM(NS)                                                                                                                     \
     case NS: {                                                                                                                              \

@@ -178,7 +178,7 @@ __device__ __forceinline__ void gather_tr_body(const FrPipeArgs &a, const FrStag
 // them next, and transposes / stores tile t while the rows of tile t + 1 are still in flight.  Straight-line and branch-free in the
 // load phase: items past the batch read index 0 through the bounds of a buffer resource; the image stores go through a resource
 // over the workgroup's word block with the cache policy AUX (16 = write-through: the image is not left dirty in L2 for the
-// end-of-kernel write-back).  Needs batch * idx_stride * 4 < 4 GiB (variant chosen by the host).
+// end-of-kernel write-back).  Needs batch * idx_stride * 4 < 4000 MiB (variant chosen by the host).
 template <int PREC, int NT, int AUX>
 __device__ __forceinline__ void gather_tr_stream_body(const FrPipeArgs &a, const FrStageArgs &st, int local, uint4 *tile /* [32][64], swizzled */) {
     const int m_tiles = st.ldm / FR_GT_ITEMS, m_groups = (m_tiles + NT - 1) / NT;
@@ -279,10 +279,10 @@ __device__ __forceinline__ void gather_tr_stream_body(const FrPipeArgs &a, const
 }
 
 // 2 = gather_tr_stream_body (two tiles per workgroup, write-through image stores: Model-C batch 4096 chain 55 -> 58 M inf/s in fp8,
-// 35.7 -> 37 M in bf16, profiles/r02_gather_tr_variants.txt); 1 = gather_tr_body (FR_GATHER_TR_VARIANT=1, and index buffers >= 4 GiB)
+// 35.7 -> 37 M in bf16, profiles/r02_gather_tr_variants.txt); 1 = gather_tr_body (FR_GATHER_TR_VARIANT=1, and index buffers >= 4000 MiB)
 int frk_gather_tr_variant(int batch, int idx_stride) {
     static const int v = getenv("FR_GATHER_TR_VARIANT") ? atoi(getenv("FR_GATHER_TR_VARIANT")) : 2;  // experiment knob
-    return (v == 1 || (size_t)batch * (size_t)idx_stride * 4 >= ((size_t)1 << 32)) ? 1 : 2;
+    return (v == 1 || (size_t)batch * (size_t)idx_stride * 4 >= ((size_t)4000 << 20)) ? 1 : 2;
 }
 
 int frk_gather_tr_blocks(int n_words, int ldm, int variant) {

@@ -6,6 +6,7 @@ Tolerance definition for scores (written here as the north star requires):
 where ref = the oracle's chain with fp64 accumulation and fp32 intermediates.  (Per-element relative
 error is meaningless for scores that cancel to ~0; cuBLASLt's own summation order is unknowable.)
 """
+import os
 import threading
 
 import numpy as np
@@ -130,6 +131,12 @@ def test_wide_record_gather_ragged_batches_and_transports(fr, O, gpu, mode):
     for B in (1024, 1027, 1029, 2050, BMAX):
         got = wk.gather_records(idx[:B], dense[:B]).reshape(B, m.record_len)
         assert np.array_equal(got, want[:B]), (mode, B)
+    # the one-chunk-per-workgroup kernel (what records or index buffers of >= 4000 MiB fall back to; the knob is read per launch)
+    os.environ["FR_GATHER_STREAM"] = "0"
+    try:
+        assert np.array_equal(wk.gather_records(idx[:1027], dense[:1027]).reshape(1027, m.record_len), want[:1027]), mode
+    finally:
+        del os.environ["FR_GATHER_STREAM"]
     f32 = want.view(np.float32)
     d_i = fr.DeviceBuffer.from_numpy(ctx, idx)
     d_d = fr.DeviceBuffer.from_numpy(ctx, dense)
