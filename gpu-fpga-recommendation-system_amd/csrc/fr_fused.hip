@@ -183,6 +183,61 @@ __device__ __forceinline__ void ft_store_tile(uint4 *img, const f32x16 &acc, int
 // (<= 128 VGPRs, <= 80 KiB LDS, half-depth rings -- the same bytes in flight per CU) so that one workgroup's gather / barrier /
 // epilogue phases run under the other one's MFMAs.  DB: double-buffered R1 (one barrier per chunk); !DB: single R1 buffer and
 // R3 overlaying R2 -- the small-LDS layout that WPE 4 needs and that lets a K = 880 record (Model-B) fit at WPE 2.
+// The gather phase of an item tile, software-pipelined (the code shape of gather_pack_stream_kernel): NB passes of 64 record words, IPT
+// items per thread.  Every pass's descriptors first, then every pass's index loads (through a buffer resource whose bounds return 0 for
+// the items past the batch: no branches), then the row loads with the next pass in flight while a pass is handed to `sink(w, i, v)`
+// (w = record word, i = 0 .. IPT-1 the thread's item, v zeroed past the batch; lanes past the record are masked off).  Straight-line
+// code: the chain descriptor -> index -> row is paid once per tile, not once per pass.  Returns the out-of-range flag.
+template <int NB, int IPT, typename Sink>
+__device__ __forceinline__ bool ft_gather_tile(const FrFusedArgs &a, const FrFusedBatch &bt, int m0, int wl, int ig, Sink &&sink) {
+    uint64_t base[NB];
+    uint32_t stride[NB], rows[NB], icol[NB];
+    bool dense[NB];
+#pragma unroll
+    for (int p = 0; p < NB; p++) {
+        const int w = 64 * p + wl < a.n_words ? 64 * p + wl : a.n_words - 1;   // a lane past the record repeats the last word (never stored)
+        const uint4 d0 = reinterpret_cast<const uint4 *>(a.words)[2 * w];
+        const uint4 d1 = reinterpret_cast<const uint4 *>(a.words)[2 * w + 1];
+        dense[p] = (d0.w & FR_DESC_DENSE) != 0;
+        base[p] = (dense[p] ? (uint64_t)reinterpret_cast<uintptr_t>(bt.dense) : 0ull) + (((uint64_t)d0.y << 32) | d0.x);
+        stride[p] = d0.z, rows[p] = d1.x, icol[p] = dense[p] ? 0u : d0.w * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(bt.idx), 0, (unsigned)bt.batch * (unsigned)a.idx_stride * 4u, 0x00020000);
+    uint32_t id[NB][IPT];
+#pragma unroll
+    for (int p = 0; p < NB; p++)
+#pragma unroll
+        for (int i = 0; i < IPT; i++)
+            id[p][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_idx, (unsigned)(m0 + IPT * ig + i) * (unsigned)a.idx_stride * 4u + icol[p], 0, 0);
+    bool bad = false;
+    uint4 v[NB][IPT];
+    auto load_rows = [&](int p) {
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            const unsigned m = (unsigned)(m0 + IPT * ig + i);
+            uint32_t r = id[p][i];
+            const bool oob = !dense[p] & (r >= rows[p]);  // reference: silent out-of-bounds read (embedding_47_krnl.cpp:927-933)
+            bad |= oob;
+            r = oob ? 0u : r;
+            r = dense[p] ? (m < (unsigned)bt.batch ? m : 0u) : r;
+            typedef const u32x4_t __attribute__((address_space(1))) * gptr_t;
+            const u32x4_t q = *(gptr_t)(base[p] + (uint64_t)r * stride[p]);
+            v[p][i] = make_uint4(q.x, q.y, q.z, q.w);
+        }
+    };
+    load_rows(0);
+#pragma unroll
+    for (int p = 0; p < NB; p++) {
+        if (p + 1 < NB) load_rows(p + 1);
+        const int w = 64 * p + wl;
+        if (w < a.n_words) {
+#pragma unroll
+            for (int i = 0; i < IPT; i++) sink(w, i, (m0 + IPT * ig + i < bt.batch) ? v[p][i] : make_uint4(0u, 0u, 0u, 0u));
+        }
+    }
+    return bad;
+}
+
 template <int T2W, int KG, int WPE, bool DB>
 __global__ void __launch_bounds__(512, WPE) fr_fused_tile_kernel(const FrFusedArgs a) {
     extern __shared__ uint4 lds[];
@@ -221,7 +276,12 @@ __global__ void __launch_bounds__(512, WPE) fr_fused_tile_kernel(const FrFusedAr
     if constexpr (KG > 0) ft_ring_fill<1, RA, KG1>(ring1, W1, 32 * wave, 0);
 
     // ---- gather: lanes along record words (a row is read by dim/4 adjacent lanes), 4 items per thread ----
-    {
+    if constexpr (KG > 0) {
+        const int wl = tid & 63, ig = tid >> 6;
+        constexpr int NB = (2 * KG1 + 63) / 64;   // K = 8 KG floats = 2 KG record words
+        const bool bad = ft_gather_tile<NB, 4>(a, bt, m0, wl, ig, [&](int w, int i, const uint4 &x) { Xq[(size_t)w * FR_FT_LD + 4 * ig + i] = x; });
+        if (bad) atomicOr_system(a.err_flag, 1);
+    } else {
         const int wl = tid & 63, ig = tid >> 6;
         bool bad = false;
         for (int w0 = 0; w0 < a.n_words; w0 += 64) {
@@ -479,34 +539,8 @@ __global__ void __launch_bounds__(512) fr_fused_tile_m2_kernel(const FrFusedArgs
 
     {   // ---- gather: lanes along record words, 8 items per thread ----
         const int wl = tid & 63, ig = tid >> 6;
-        bool bad = false;
-        for (int w0 = 0; w0 < a.n_words; w0 += 64) {
-            const int w = w0 + wl;
-            if (w < a.n_words) {
-                const uint4 d0 = reinterpret_cast<const uint4 *>(a.words)[2 * w];
-                const uint4 d1 = reinterpret_cast<const uint4 *>(a.words)[2 * w + 1];
-                const uint64_t src = ((uint64_t)d0.y << 32) | d0.x;
-                const uint32_t stride = d0.z, idx_col = d0.w, rows = d1.x;
-                const bool is_dense = (idx_col & FR_DESC_DENSE) != 0;
-                const char *base = is_dense ? reinterpret_cast<const char *>(bt.dense) + src : reinterpret_cast<const char *>(src);
-                uint32_t id[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int m = m0 + 8 * ig + i;
-                    id[i] = 0;
-                    if (m < bt.batch) id[i] = is_dense ? (uint32_t)m : (uint32_t)bt.idx[(size_t)m * a.idx_stride + idx_col];
-                    if (!is_dense && id[i] >= rows) {
-                        bad = true;
-                        id[i] = 0;
-                    }
-                }
-                uint4 v[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = *reinterpret_cast<const uint4 *>(base + (uint64_t)id[i] * stride);
-#pragma unroll
-                for (int i = 0; i < 8; i++) Xq[(size_t)w * LD + 8 * ig + i] = (m0 + 8 * ig + i < bt.batch) ? v[i] : make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
+        constexpr int NB = (2 * KG + 63) / 64;   // K = 8 KG floats = 2 KG record words
+        const bool bad = ft_gather_tile<NB, 8>(a, bt, m0, wl, ig, [&](int w, int i, const uint4 &x) { Xq[(size_t)w * LD + 8 * ig + i] = x; });
         if (bad) atomicOr_system(a.err_flag, 1);
     }
     __syncthreads();
@@ -673,43 +707,14 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
 
     {   // ---- gather + bf16 conversion: lanes along record words, TI / 8 items per thread ----
         const int wl = tid & 63, ig = tid >> 6;
-        constexpr int IPT = TI / 8;
+        constexpr int IPT = TI / 8, NB = (4 * KG + 63) / 64;   // K = 16 KG floats = 4 KG record words
         uint2 *Xh2 = reinterpret_cast<uint2 *>(Xh);
-        bool bad = false;
-        for (int w0 = 0; w0 < a.n_words; w0 += 64) {
-            const int w = w0 + wl;
-            if (w < a.n_words) {
-                const uint4 d0 = reinterpret_cast<const uint4 *>(a.words)[2 * w];
-                const uint4 d1 = reinterpret_cast<const uint4 *>(a.words)[2 * w + 1];
-                const uint64_t src = ((uint64_t)d0.y << 32) | d0.x;
-                const uint32_t stride = d0.z, idx_col = d0.w, rows = d1.x;
-                const bool is_dense = (idx_col & FR_DESC_DENSE) != 0;
-                const char *base = is_dense ? reinterpret_cast<const char *>(bt.dense) + src : reinterpret_cast<const char *>(src);
-                uint32_t id[IPT];
-#pragma unroll
-                for (int i = 0; i < IPT; i++) {
-                    const int m = m0 + IPT * ig + i;
-                    id[i] = 0;
-                    if (m < bt.batch) id[i] = is_dense ? (uint32_t)m : (uint32_t)bt.idx[(size_t)m * a.idx_stride + idx_col];
-                    if (!is_dense && id[i] >= rows) {
-                        bad = true;
-                        id[i] = 0;
-                    }
-                }
-                uint4 v[IPT];
-#pragma unroll
-                for (int i = 0; i < IPT; i++) v[i] = *reinterpret_cast<const uint4 *>(base + (uint64_t)id[i] * stride);
-#pragma unroll
-                for (int i = 0; i < IPT; i++) {
-                    uint2 hv = make_uint2(0u, 0u);
-                    if (m0 + IPT * ig + i < bt.batch) {
-                        hv.x = pack_bf16x2(__uint_as_float(v[i].x), __uint_as_float(v[i].y));
-                        hv.y = pack_bf16x2(__uint_as_float(v[i].z), __uint_as_float(v[i].w));
-                    }
-                    Xh2[((size_t)(w >> 1) * LD + IPT * ig + i) * 2 + (w & 1)] = hv;  // record word w = half (w & 1) of q8 element w / 2
-                }
-            }
-        }
+        const bool bad = ft_gather_tile<NB, IPT>(a, bt, m0, wl, ig, [&](int w, int i, const uint4 &x) {
+            uint2 hv;
+            hv.x = pack_bf16x2(__uint_as_float(x.x), __uint_as_float(x.y));
+            hv.y = pack_bf16x2(__uint_as_float(x.z), __uint_as_float(x.w));
+            Xh2[((size_t)(w >> 1) * LD + IPT * ig + i) * 2 + (w & 1)] = hv;  // record word w = half (w & 1) of q8 element w / 2
+        });
         if (bad) atomicOr_system(a.err_flag, 1);
     }
     __syncthreads();
@@ -997,38 +1002,13 @@ __global__ void __launch_bounds__(512) fr_fused_tile_f8_kernel(const FrFusedArgs
         const int wl = tid & 63, ig = tid >> 6;
         uint32_t *Xw = reinterpret_cast<uint32_t *>(Xf);
         const float scale = __builtin_ldexpf(1.0f, a.e_act[0]);
-        bool bad = false;
-        for (int w0 = 0; w0 < 4 * KE1; w0 += 64) {
-            const int w = w0 + wl;
-            if (w < a.n_words) {
-                const uint4 d0 = reinterpret_cast<const uint4 *>(a.words)[2 * w];
-                const uint4 d1 = reinterpret_cast<const uint4 *>(a.words)[2 * w + 1];
-                const uint64_t src = ((uint64_t)d0.y << 32) | d0.x;
-                const uint32_t stride = d0.z, idx_col = d0.w, rows = d1.x;
-                const bool is_dense = (idx_col & FR_DESC_DENSE) != 0;
-                const char *base = is_dense ? reinterpret_cast<const char *>(bt.dense) + src : reinterpret_cast<const char *>(src);
-                uint32_t id[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int m = m0 + 8 * ig + i;
-                    id[i] = 0;
-                    if (m < bt.batch) id[i] = is_dense ? (uint32_t)m : (uint32_t)bt.idx[(size_t)m * a.idx_stride + idx_col];
-                    if (!is_dense && id[i] >= rows) {
-                        bad = true;
-                        id[i] = 0;
-                    }
-                }
-                uint4 v[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = *reinterpret_cast<const uint4 *>(base + (uint64_t)id[i] * stride);
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-                    Xw[((size_t)(w >> 2) * LD + 8 * ig + i) * 4 + (w & 3)] = (m0 + 8 * ig + i < bt.batch) ? pack_fp8_word(v[i], scale) : 0u;
-            } else if (w < 4 * KE1) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) Xw[((size_t)(w >> 2) * LD + 8 * ig + i) * 4 + (w & 3)] = 0u;  // pad up to a multiple of 64 k
-            }
-        }
+        constexpr int NB = (4 * KE1 + 63) / 64;
+        const bool bad = ft_gather_tile<NB, 8>(a, bt, m0, wl, ig, [&](int w, int i, const uint4 &x) {
+            Xw[((size_t)(w >> 2) * LD + 8 * ig + i) * 4 + (w & 3)] = pack_fp8_word(x, scale);   // a zero row (item past the batch) packs to 0
+        });
+        for (int w = a.n_words + tid; w < 4 * KE1; w += 512)   // pad up to a multiple of 64 k
+#pragma unroll 1
+            for (int i = 0; i < TI; i++) Xw[((size_t)(w >> 2) * LD + i) * 4 + (w & 3)] = 0u;
         if (bad) atomicOr_system(a.err_flag, 1);
     }
     __syncthreads();
