@@ -792,6 +792,7 @@ def main():
                          "multi-stream throughput loops, whose concurrent launches stretch each other, are skipped), so the profiler's average agrees with "
                          "the HIP-event figure on the bench line")
     ap.add_argument("--quick", action="store_true", help="profiling runs: 0.3 s instead of >= 2 s behind `value` (the legs are what is being profiled)")
+    ap.add_argument("--per-bank", action="store_true", help="single-configuration runs (--model / --precision): FR_INDEX_PER_BANK context and indices")
     ap.add_argument("--no-multi-gather", action="store_true", help="N > 1: skip the per-rank legs (gather_per_bank_all_ranks, configs_all_ranks)")
     ap.add_argument("--no-multi-configs", action="store_true", help="N > 1: skip configs_all_ranks (Model-B bf16, Model-C bf16 / fp8 on every rank)")
     ap.add_argument("--plumbing-only", action="store_true",
@@ -825,11 +826,15 @@ def main():
     B = args.batch
     which = {"A": fr.MODEL_A, "B": fr.MODEL_B, "C": fr.MODEL_C}[args.model]
     model = fr.Model.builtin(which)
+    if args.per_bank:   # the reference kernel's index contract: one index per memory bank per item, bank-interleaved tables
+        if args.model == "A" and args.precision == "f32":
+            raise SystemExit("--per-bank: with --model B/C or a --precision other than f32 (the headline's 47 tables are 47 banks)")
+        model = model.clone(index_mode=fr.INDEX_PER_BANK)
     ctx = fr.Context(model, device=local_rank)
     ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
     ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
     rng = np.random.default_rng(dist_mod.replica_seed(SEED_IDX, rank))
-    rows = model.rows()
+    rows = model.bank_map()[1] if args.per_bank else model.rows()
     n_bufs = N_IDX_BUFFERS if args.model == "A" else 16
     idx_host = [uniform_idx(rng, rows, B) for _ in range(n_bufs)]
     d_idx = [fr.DeviceBuffer.from_numpy(ctx, a) for a in idx_host]
@@ -845,7 +850,7 @@ def main():
     if args.model != "A" or args.precision != "f32":
         # one non-headline configuration on its own: throughput + its roofline leg
         res = leg_config(fr, ctx, model, B, args.precision, d_idx, d_dense, idx_host[0], dense_host[0] if dense_host else None, args.threads, args.depth,
-                         "Model-%s batch=%d %s FC chain, index rows resident in HBM" % (args.model, B, args.precision),
+                         "Model-%s batch=%d %s FC chain, %s, index rows resident in HBM" % (args.model, B, args.precision, "one index per bank" if args.per_bank else "per-table indices"),
                          min_s=0.0 if args.roofline_only else (0.05 if args.quick else 1.0), env=env)
         if rank == 0:
             print(json.dumps({"metric": "inferences/sec", "value": res["value"], "unit": "inferences/s", "n_gpus": world, "steps": args.steps,

@@ -892,10 +892,40 @@ __global__ void __launch_bounds__(FR_PIPE_THREADS) fr_pipeline_kernel(const FrPi
     }
 }
 
+// The gather | out launch of a chain whose FC layers run as GEMM kernels (Model-C at batch 4096), as a kernel of its own with a small
+// register budget: fr_pipeline_kernel<-1, P> carries the FC stage bodies (86-90 VGPRs), and two waves of that size per SIMD do not fit
+// beside a resident workgroup of the bf16 FC1 GEMM (2 x 200 of a SIMD's 512 registers: 112 left), so the gather could only start on a CU
+// once its GEMM workgroup had gone.  FR_GO_VGPRS registers per wave (2 x 56 = 112) lets the two kernels share the CU.
+#ifndef FR_GO_VGPRS
+#define FR_GO_VGPRS 56
+#endif
+template <int PREC>
+__global__ void __launch_bounds__(FR_PIPE_THREADS) __attribute__((amdgpu_num_vgpr(FR_GO_VGPRS))) fr_gather_out_kernel(const FrPipeArgs a) {
+    __shared__ uint4 smem[FR_GT_ITEMS * FR_GT_WORDS];
+    float *red = reinterpret_cast<float *>(smem);
+    const int b = blockIdx.x;
+    if (b < a.st[1].block_begin) {   // stage 0 (stages 1-3 are empty in this launch: their begins equal stage 4's)
+        gather_tr_stream_body<PREC, 2, 16>(a, a.st[0], b - a.st[0].block_begin, smem);
+    } else {
+        const FrStageArgs &st = a.st[4];
+        const int local = b - st.block_begin;
+        if constexpr (PREC == 1) fc_out_h_body(st, local, red);
+        else if constexpr (PREC == 2) fc_out_f_body(st, local, red);
+        else fc_out_q_body(st, local, red);
+    }
+}
+
 // Launch one pipeline step.  `single_stage` >= 0 launches only that stage (its block_begin must be 0).
 template <int PREC>
 static int pipeline_launch_prec(const FrPipeArgs &a, int single_stage, hipStream_t s) {
     dim3 grid(a.n_blocks), block(FR_PIPE_THREADS);
+    static const int light = getenv("FR_GATHER_OUT_KERNEL") ? atoi(getenv("FR_GATHER_OUT_KERNEL")) : 1;  // experiment knob: 0 = always fr_pipeline_kernel<-1>
+    if (single_stage == -1 && light && a.st[0].variant == 2 && a.st[1].block_begin > a.st[0].block_begin && a.st[1].block_begin == a.st[2].block_begin &&
+        a.st[2].block_begin == a.st[3].block_begin && a.st[3].block_begin == a.st[4].block_begin) {
+        fr_gather_out_kernel<PREC><<<grid, block, 0, s>>>(a);
+        KCHECK();
+        return FR_OK;
+    }
     switch (single_stage) {
         case -1: fr_pipeline_kernel<-1, PREC><<<grid, block, 0, s>>>(a); break;
         case 0: fr_pipeline_kernel<0, PREC><<<grid, block, 0, s>>>(a); break;
