@@ -1,7 +1,7 @@
 # session 2 evidence run: full GPU suite, smoke, the driver's bench command, rocprofv3 kernel stats of the roofline legs, PMC passes
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/s2_evidence
+O=$R/gpurun_out/evidence
 mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -6 | tee $O/pytest_tail.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
