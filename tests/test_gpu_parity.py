@@ -934,6 +934,72 @@ def test_streaming_with_dense_features_on_a_user_model(fr, gpu):
     ctx.close()
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16", "fp8"])
+def test_dense_block_through_the_fused_tile_kernels(fr, gpu, prec):
+    """ft_gather_tile (the software-pipelined gather phase of the straight-line fused kernels) with a DENSE block in the record: a user
+    model of Model-A's shape (K = 352 floats, 1024 / 512 / 256) whose record carries 32 request features between its tables, so that
+    it streams through fr_fused_tile_kernel<2, 44, ...> (partial launches), fr_fused_tile_m2_kernel<44> (full launch groups) and the
+    bf16 / fp8 64-item kernels -- none of the reference models sends dense words down that path (A and B have none, C does not stream
+    through the fused kernels).  Ragged batches; scores against the unpipelined submit of the same rows."""
+    rng = np.random.default_rng(31)
+    dims = [8, 16, 4, 32, 64, 4, 12, 20, 8, 16, 24, 32, 48, 32]
+    assert sum(dims) == 320
+    spec = {"name": "dense_352", "dense_len": 32, "dense_at": 5, "fc": [1024, 512, 256],
+            "tables": [{"dim": d_, "rows": int(rng.integers(40, 30000))} for d_ in dims]}
+    m = fr.Model.from_spec(spec)
+    assert m.record_len == 352 and m.dense_len == 32
+    ctx = fr.Context(m, device=gpu)
+    ctx.fill_tables(fr.FILL_HASH, 5)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, 6)
+    ctx.set_fc_precision({"f32": fr.FC_FP32, "bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[prec])
+    B = 200
+    wk = fr.Worker(ctx, B)
+    pool = [(uniform_idx(rng, m.rows(), B), rng.uniform(-1, 1, (B, 32)).astype(np.float32)) for _ in range(4)]
+    if prec == "fp8":
+        wk.calibrate_fp8(pool[0][0], pool[0][1])
+    assert ctx.stream_group() == 64
+    expect = [wk.infer(i_, d_).copy() for i_, d_ in pool]
+    d_pool = [(fr.DeviceBuffer.from_numpy(ctx, i_), fr.DeviceBuffer.from_numpy(ctx, d_)) for i_, d_ in pool]
+    outs = []
+    for rep in range(64 * 2 + 9):      # two full launch groups (64-item kernel: 64 x 4 tiles > 128) and a partial one (32-item kernel)
+        j, b = rep % 4, [200, 200, 77, 200, 1][rep % 5]
+        buf = fr.DeviceBuffer(ctx, B * 4)
+        buf.upload(np.full(B, np.nan, np.float32))
+        wk.push_device(b, d_pool[j][0], d_pool[j][1], buf)
+        outs.append((buf, j, b))
+    wk.sync()
+    tol = {"f32": 1e-5, "bf16": 5e-3, "fp8": 3e-2}[prec]
+    first = {}
+    for buf, j, b in outs:
+        got = buf.download(np.float32, B)
+        assert np.isnan(got[b:]).all()
+        assert np.abs(got[:b] - expect[j][:b]).max() <= tol * np.abs(expect[j]).max(), (prec, j, b)
+        if (j, b) in first:
+            assert np.array_equal(got[:b], first[(j, b)])      # the 32- and 64-item kernels and every position in a group agree to the bit
+        first.setdefault((j, b), got[:b].copy())
+        if (j, 200) in first and b < 200:
+            assert np.array_equal(got[:b], first[(j, 200)][:b])
+        buf.free()
+    # an out-of-range index and a NaN feature are seen through this path too
+    bad = pool[0][0].copy()
+    bad[199, 3] = m.rows()[3]
+    d_bad = fr.DeviceBuffer.from_numpy(ctx, bad)
+    d_s = fr.DeviceBuffer(ctx, B * 4)
+    with pytest.raises(fr.FleetRecError) as e:
+        wk.push_device(B, d_bad, d_pool[0][1], d_s)
+        wk.sync()
+    assert e.value.status == fr.FR_ERR_INDEX_RANGE
+    dn = pool[1][1].copy()
+    dn[17, 9] = np.nan
+    d_dn = fr.DeviceBuffer.from_numpy(ctx, dn)
+    wk.push_device(B, d_pool[1][0], d_dn, d_s)
+    wk.sync()
+    sc = d_s.download(np.float32, B)
+    assert np.isnan(sc[17]) and np.isfinite(np.delete(sc, 17)).all()
+    wk.close()
+    ctx.close()
+
+
 def test_host_fed_streaming(fr, ctxs):
     """fr_worker_push_host / fr_driver_run_host_streaming: batches that sit in host memory are staged in pinned blocks and travel as
     one H2D + one fused launch + one D2H per block; scores equal the device-resident streaming path bit for bit, ragged batches,
