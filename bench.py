@@ -416,10 +416,11 @@ def leg_tcp(B, device, threads=4, total=1000000):
 # GPU legs
 # ------------------------------------------------------------------------------------------------------------------
 def leg_group_table(fr, ctx, model, B, d_idx, threads, depth):
-    """Model-A batch 256 fp32: throughput and latency against the launch group (batches per fused launch)."""
+    """Model-A batch 256 fp32: throughput and latency against the launch group (fr_ctx_set_stream_group): groups below 12 ride the stage
+    pipeline (one launch per push, five stages in flight), larger ones the fused item-tile kernels (one launch per group)."""
     out = []
     flops = fc_flops_per_inference(model.fc) * B
-    for g in (1, 8, 32, 64):
+    for g in (1, 8, 16, 32, 64):
         ctx.set_stream_group(g)
         dv = fr.Driver(ctx, threads, depth, B)
         dv.run_resident(B, 2048, d_idx)
@@ -440,7 +441,8 @@ def leg_group_table(fr, ctx, model, B, d_idx, threads, depth):
         wk.close()
         for b_ in ring:
             b_.free()
-        out.append({"group": g, "inferences_per_s": n * B / el, "launch_ms_one_stream": ms, "tflops_one_stream": flops * g / (ms * 1e-3) / 1e12,
+        out.append({"group": g, "path": "stage pipeline (one launch per push)" if g < 12 else "fused item-tile kernel (one launch per group)",
+                    "inferences_per_s": n * B / el, "launch_ms_one_stream": ms, "tflops_one_stream": flops * g / (ms * 1e-3) / 1e12,
                     "push_to_scores_ms_p50": 1e3 * float(np.median(lat)), "push_to_scores_ms_p90": 1e3 * float(np.percentile(lat, 90))})
     ctx.set_stream_group(64)
     return out
@@ -943,8 +945,9 @@ def main():
             b_.free()
 
     if want("groups"):
-        result["launch_group_table"] = {"workload": "Model-A batch 256 fp32, %d threads x %d workers; group = batches per fused launch "
-                                                    "(fr_ctx_set_stream_group)" % (args.threads, args.depth),
+        result["launch_group_table"] = {"workload": "Model-A batch 256 fp32, %d threads x %d workers; group = fr_ctx_set_stream_group: below 12 every push is one "
+                                                    "stage-pipeline launch, from 12 up a group is one fused launch; launch_ms_one_stream = time per group of pushes"
+                                                    % (args.threads, args.depth),
                                         "rows": leg_group_table(fr, ctx, model, B, d_idx, args.threads, args.depth)}
 
     if want("pcie"):

@@ -1222,7 +1222,19 @@ extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_i
     rc = check_gather_args(w, d_idx, d_dense);
     if (rc) return rc;
     FR_HIP(hipSetDevice(c->device));
-    if (fused_eligible(c)) {
+    // Launch groups below FR_FUSED_MIN_GROUP ride the stage pipeline even on a fused-eligible context: a fused launch of g batches takes
+    // one item tile's time (~130 us for Model-A) whatever g is, so small groups give 7 M (g = 1) .. 35 M inferences/s (g = 8) at 145 us,
+    // where the pipelined stage launches give 43 M at 36 us (profiles/r02_launch_group_paths.txt).
+    const bool fused = fused_eligible(c) && fused_group(c) >= FR_FUSED_MIN_GROUP;
+    if (fused && w->n_active > 0) {          // the group was raised while batches were riding the stage pipeline: drain them first
+        rc = pipeline_flush(w);
+        if (rc) return rc;
+    }
+    if (!fused && w->n_pending > 0) {        // ... or lowered with batches queued for a fused launch
+        rc = fused_flush(w);
+        if (rc) return rc;
+    }
+    if (fused) {
         // whole-path-per-item-tile kernel: queue the batch, launch when a group is full (fr_worker_sync launches the rest)
         FrFusedBatch &fb = w->pending[w->n_pending++];
         fb.idx = d_idx;

@@ -109,6 +109,7 @@ struct FrPipeArgs {
 // ---- fused item-tile kernel: launch arguments (see fr_fused.hip) -------------------------------------
 constexpr int FR_FUSED_MAX_BATCHES = 64;   // kernel-argument array size (64 x 32 B)
 constexpr int FR_FUSED_DEFAULT_BATCHES = 64;
+constexpr int FR_FUSED_MIN_GROUP = 12;       // fr_worker_push_device: smaller launch groups ride the stage pipeline (one launch per push)
 constexpr int FR_HOST_BLOCKS = 4;  // 64 batches of 256 = one 64-item workgroup per CU (fr_fused_tile_m2_kernel)
 struct FrFusedBatch {
     const int32_t *idx;

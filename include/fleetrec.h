@@ -248,15 +248,21 @@ int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d_idx, const
  * R >= 2 * max(fr_ctx_stream_group(ctx), 5) buffer sets and calls fr_worker_sync once per trip round the ring (what
  * fr_driver_run_resident does with R = 256). */
 int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores);
-/* How many pushed batches one streaming launch carries on this context: 1 when fr_worker_push_device rides the stage pipeline,
- * G (1..64, default 64; env FR_FUSED_GROUP overrides the default of new contexts) when the model streams through the fused
- * item-tile kernel. */
+/* How many pushed batches one streaming launch carries on this context: 1 when fr_worker_push_device rides the stage pipeline
+ * (models that do not fit the fused kernel), G (1..64, default 64; env FR_FUSED_GROUP overrides the default of new contexts) when
+ * the model streams through the fused item-tile kernel -- the value fr_ctx_set_stream_group set, also when it is below 12 and the
+ * pushes ride the stage pipeline. */
 int fr_ctx_stream_group(const fr_ctx *ctx);
 /* Throughput/latency knob of the fused streaming path, PER CONTEXT: batches per launch, 1..64.  64 batches of 256 items = one 64-item
  * workgroup per CU (fp32: fr_fused_tile_m2_kernel); <= 32 selects the 32-item kernel, halves the queueing latency of a pushed batch and
  * leaves CUs to other streams (a partial launch -- fr_worker_sync with few batches queued -- whose 64-item tiles would cover at most half
- * of the CUs takes the 32-item kernel too).  Scores are bit-identical for every group size.  May be called while workers are pushing (atomic); a
- * worker's queue that already holds >= the new size launches at its next push or sync. */
+ * of the CUs takes the 32-item kernel too).  Scores are bit-identical for every group size from 12 up.  Groups below 12 make
+ * fr_worker_push_device ride the stage pipeline instead (one launch per push; the batch's scores are complete four pushes later or at
+ * fr_worker_sync): a fused launch costs one item tile's time however few batches it carries, so small groups are both slower and later
+ * than the pipelined stage launches (Model-A batch 256: group 8 = 35 M inferences/s at 148 us, stage pipeline = 43 M at 36 us); the
+ * pipeline's fp32 sums run in another order (scores agree to 1e-5 relative, not to the bit).  May be called while workers are pushing
+ * (atomic); a worker's queue that already holds >= the new size launches at its next push or sync, and a worker whose path changes
+ * drains the other path first. */
 int fr_ctx_set_stream_group(fr_ctx *ctx, int batches_per_launch);
 /* Host-fed streaming: like fr_worker_push_device for a batch that sits in (any) host memory.  The rows are copied into the worker's
  * pinned staging before the call returns (h_idx / h_dense may be reused at once); batches travel in groups as one H2D copy + one

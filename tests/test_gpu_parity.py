@@ -752,17 +752,27 @@ def test_streaming_push_matches_submit(fr, O, ctxs):
                 first_run[j] = got[:b].copy()
             else:
                 assert np.array_equal(got[:b], first_run[j]), (cut, j)
-    # the launch-group knob: any group size gives the same scores bit for bit (items are independent)
+    # the launch-group knob: any group size from 12 up gives the same scores bit for bit (items are independent); smaller groups ride
+    # the stage pipeline (one launch per push) and give the unpipelined submit's scores bit for bit (same stage kernels)
     g0 = ctx.stream_group()
     assert g0 >= 1
-    for grp in (1, 5, 32):
+    for grp in (1, 5, 12, 32):
         ctx.set_stream_group(grp)
         assert ctx.stream_group() in (grp, 1)
         for j, b in enumerate(sizes):
             wk.push_device(b, d_idx[j], None, d_sc[j])
         wk.sync()
         for j, b in enumerate(sizes):
-            assert np.array_equal(d_sc[j].download(np.float32, 256)[:b], first_run[j])
+            want = first_run[j] if (grp >= 12 and g0 > 1) else expect[j][:b]
+            assert np.array_equal(d_sc[j].download(np.float32, 256)[:b], want), (grp, j)
+    # a group change in mid-stream drains the other path first: every batch still comes out as one of the two
+    for j, b in enumerate(sizes):
+        ctx.set_stream_group(3 if j % 5 < 2 else 64)
+        wk.push_device(b, d_idx[j], None, d_sc[j])
+    wk.sync()
+    for j, b in enumerate(sizes):
+        got = d_sc[j].download(np.float32, 256)[:b]
+        assert np.array_equal(got, expect[j][:b] if j % 5 < 2 else first_run[j]), j
     ctx.set_stream_group(g0)
     with pytest.raises(fr.FleetRecError):
         ctx.set_stream_group(0)
@@ -1144,6 +1154,8 @@ def test_random_streaming_sequences(fr, gpu, prec, seed):
         wk.push_device(256, d_pool[j], None, ref_buf[j])
     wk.sync()
     ref = [b.download(np.float32, 256) for b in ref_buf]
+    # device pushes under a launch group below 12 ride the stage pipeline: the unpipelined submit's bits for the same batch size (same split-K plan)
+    ref_pipe = {(j, b): wk.infer(pool[j][:b]).copy() for j in range(len(pool)) for b in (1, 7, 64, 200, 256)}
     n_ops = 260
     dev_out, host_out, plan = [], [], []
     g0 = ctx.stream_group()
@@ -1154,7 +1166,7 @@ def test_random_streaming_sequences(fr, gpu, prec, seed):
             buf = fr.DeviceBuffer(ctx, 256 * 4)
             buf.upload(np.full(256, np.nan, np.float32))
             wk.push_device(b, d_pool[j], None, buf)
-            dev_out.append((buf, j, b))
+            dev_out.append((buf, j, b, ctx.stream_group() < 12))
         elif r < 0.60:
             out = np.full(256, np.nan, np.float32)
             wk.push_host(pool[j][:b], None, out)
@@ -1171,9 +1183,9 @@ def test_random_streaming_sequences(fr, gpu, prec, seed):
             ctx.set_stream_group(int(rng.choice([1, 3, 16, 64])))
     wk.sync()
     ctx.set_stream_group(g0)
-    for buf, j, b in dev_out:
+    for buf, j, b, piped in dev_out:
         got = buf.download(np.float32, 256)
-        assert np.array_equal(got[:b], ref[j][:b]) and np.isnan(got[b:]).all()
+        assert np.array_equal(got[:b], ref_pipe[(j, b)] if piped else ref[j][:b]) and np.isnan(got[b:]).all(), (j, b, piped)
         buf.free()
     for out, j, b in host_out:
         assert np.array_equal(out[:b], ref[j][:b]) and np.isnan(out[b:]).all()
