@@ -1350,11 +1350,17 @@ static int host_block_launch(fr_worker *w) {
         // through the whole chain for 133 us; the stage launches of fr_worker_submit spread the same batch over the chip in ~25 us.  The
         // kernels read the staged rows and write the scores in the pinned staging itself (no copy commands), exactly as fr_worker_submit
         // does; the scores are fr_worker_submit's, bit for bit (not the fused kernel's: another fp32 summation order, equal to ~1e-6).
+        // The block's batches follow each other through the stage pipeline (launch L = gather of batch L | FC1 of L-1 | ... | out of L-4) and
+        // four more launches drain it: n + 4 launches for the block, not 5 n.
+        static const int serial = getenv("FR_SMALL_BLOCK_SERIAL") ? atoi(getenv("FR_SMALL_BLOCK_SERIAL")) : 0;  // experiment knob: 1 = five launches per batch
         for (int i = 0; i < n; i++) {
-            rc = launch_pipeline(w, r.bsz[b][i], r.h_idx + (s0 + i) * r.idx_slot, r.dense_slot ? r.h_dense + (s0 + i) * r.dense_slot : nullptr,
-                                 r.h_sc + (s0 + i) * r.score_slot);
+            rc = pipeline_push(w, r.bsz[b][i], 0, r.h_idx + (s0 + i) * r.idx_slot, r.dense_slot ? r.h_dense + (s0 + i) * r.dense_slot : nullptr,
+                               r.h_sc + (s0 + i) * r.score_slot);
+            if (rc == FR_OK && serial) rc = pipeline_flush(w);
             if (rc) return rc;
         }
+        rc = pipeline_flush(w);
+        if (rc) return rc;
         FR_HIP(hipEventRecord(r.ev[b], w->stream));
         r.inflight[b] = true;
         r.cur = (b + 1) % FR_HOST_BLOCKS;

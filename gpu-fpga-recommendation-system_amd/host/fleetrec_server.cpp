@@ -49,7 +49,7 @@ struct Options {
     bool stream = false;   // throughput mode: fr_worker_push_host (blocks of batches per launch) instead of submit + sync per batch
     long flush_us = 50;    // --stream --reply: how long the socket must stay dry before a partial block is launched
     int flush_min = 32;    // ... while earlier blocks are still in flight: only once this many requests are queued (with nothing in flight: any number)
-    int small_block = 4;   // --stream --reply: blocks of at most this many batches take fr_worker_submit's stage launches (fr_ctx_set_small_block)
+    int small_block = 8;   // --stream --reply: blocks of at most this many batches ride the stage pipeline, n + 4 launches (fr_ctx_set_small_block)
     bool latency = false;  // latency-measurement mode: per-batch recv -> enqueued -> scores times (measure_network_cuda_cp_latency_*/cuda_server.c)
     long row_cap = 0;
 };

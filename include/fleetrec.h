@@ -284,10 +284,12 @@ int fr_worker_push_staged(fr_worker *w, int batch, float *h_scores);
  * reports how many host-fed batches have been delivered since the worker was created: batches are delivered in push order, so the
  * caller knows exactly which h_scores buffers are valid. */
 int fr_worker_flush(fr_worker *w);
-/* Latency of nearly empty host-fed blocks, PER CONTEXT: a block that leaves with at most max_batches batches (0..8; default 0 = never) runs
- * through the stage launches of fr_worker_submit -- ~25 us per batch on the device, the whole chip per layer -- instead of the fused
- * item-tile kernel (133 us for any number of batches up to a chip-full).  Such batches get fr_worker_submit's scores bit for bit (the
- * fused kernel sums in another order: equal to ~1e-6, not bit for bit).  fleetrec_server --stream --reply sets 4. */
+/* Latency of nearly empty host-fed blocks, PER CONTEXT: a block that leaves with at most max_batches batches (0..8; default 0 = never) rides
+ * the stage pipeline of fr_worker_submit -- its n batches follow each other through the five stage launches, n + 4 launches of ~10 us,
+ * the whole chip per layer -- instead of the fused item-tile kernel (133 us for any number of batches up to a chip-full).  Such batches
+ * get fr_worker_submit's scores bit for bit (the fused kernel sums in another order: equal to ~1e-6, not bit for bit).
+ * fleetrec_server --stream --reply sets 8 (4 requests in flight per connection: 18 M inferences/s at 185 us request -> reply, against
+ * 14 M at 245 us with five launches per batch; profiles/r02_tcp_reply_small_blocks.txt). */
 int fr_ctx_set_small_block(fr_ctx *ctx, int max_batches);
 int fr_worker_host_poll(fr_worker *w, long long *delivered);
 /* Host-fed batches queued in the block being filled (not launched yet) / launched and not delivered yet, and the number of launched
