@@ -339,15 +339,15 @@ def free_port_block(n):
 
 def leg_tcp_reply(B, device, threads=4):
     """The same path as a SERVICE: fleetrec_server --stream --reply sends the scores back over the socket block by block (adaptive batching,
-    small blocks through the stage launches), fleetrec_sender --reply --window W times request sent -> scores received.  Two operating points:
-    saturated (256 requests in flight per connection) and light (one request per 500 us per connection)."""
+    small blocks through the stage pipeline), fleetrec_sender --reply --window W times request sent -> scores received.  Three operating points:
+    saturated (256 requests in flight per connection), a few in flight (4 per connection) and light (one request per 500 us per connection)."""
     import re
     host = os.path.join(ROOT, "gpu-fpga-recommendation-system_amd", "host")
     srv_bin, snd_bin = os.path.join(host, "fleetrec_server"), os.path.join(host, "fleetrec_sender")
     if not (os.path.exists(srv_bin) and os.path.exists(snd_bin)):
         return {"skipped": "host programs not built (make -C gpu-fpga-recommendation-system_amd/host)"}
     out = {}
-    for name, total, window, interval in (("saturated", 400000, 256, 0), ("light_load", 6000, 256, 500)):
+    for name, total, window, interval in (("saturated", 400000, 256, 0), ("four_in_flight", 40000, 4, 0), ("light_load", 6000, 256, 500)):
         port = free_port_block(threads)
         common = ["--model", "A", "--batch", str(B), "--threads", str(threads), "--port", str(port)]
         srv = subprocess.Popen([srv_bin] + common + ["--total", str(total), "--device", str(device), "--tables", "hash", "--weights", "uniform", "--stream", "--reply"],
@@ -373,7 +373,7 @@ def leg_tcp_reply(B, device, threads=4):
         out[name] = {"inferences_per_s": float(m1.group(2)) * 1e6, "requests_timed": int(m2.group(1)), "request_to_reply_us_p50": float(m2.group(3)),
                      "request_to_reply_us_p90": float(m2.group(4)), "request_to_reply_us_p99": float(m2.group(5)),
                      "offered": "%d requests in flight per connection" % window if interval == 0 else "one request per %d us per connection" % interval}
-    out["what"] = ("fleetrec_sender --reply --window 256 -> fleetrec_server --stream --reply over loopback TCP, %d connections, batch %d: scores sent back over the "
+    out["what"] = ("fleetrec_sender --reply --window W -> fleetrec_server --stream --reply over loopback TCP, %d connections, batch %d: scores sent back over the "
                    "socket; latency measured at the sender (request sent -> its scores received), first 5 %% of every connection dropped" % (threads, B))
     return out
 
