@@ -735,7 +735,8 @@ static int launch_gather(fr_worker *w, int batch, const int32_t *d_idx, const fl
     if (variant != FR_GATHER_WORD_MAJOR && transport == FR_FC_FP32 && c->n_chunks > 0)
         return frk_gather_tile(c->d_passes, c->d_chunks, c->n_chunks, d_idx, (int)idx_cols(c), d_dense, d_records, c->slice_padded / 4, batch, w->d_err,
                                variant != FR_GATHER_ITEM_TILE, variant == FR_GATHER_ITEM_TILE_DEDUP_COUNT ? c->d_merged : nullptr, w->stream);
-    return frk_gather(c->d_words, c->n_words, c->gather_groups, d_idx, (int)idx_cols(c), d_dense, d_records, batch, w->d_err, transport, c->f8_e_act[0], w->stream);
+    return frk_gather(c->d_words, c->n_words, c->gather_groups, d_idx, (int)idx_cols(c), d_dense, d_records, batch, w->d_err, transport, c->f8_e_act[0], w->stream,
+                      c->slice_padded / 4);  // words per item of the destination: the record (any layout) or the shard's padded slice
 }
 
 extern "C" int fr_ctx_set_gather_variant(fr_ctx *ctx, int variant) {

@@ -216,8 +216,8 @@ __global__ void __launch_bounds__(256) gather_pack_stream_kernel(const FrWordDes
 
 template <int ITEMS, int TP>
 static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &groups, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch,
-                             int *err_flag, float scale, hipStream_t s, int n_words) {
-    const size_t n_rec_bytes = (size_t)n_words * 16;
+                             int *err_flag, float scale, hipStream_t s, int n_words, int out_words) {
+    const size_t n_rec_bytes = (size_t)out_words * 16;
     const int bx = ((groups.max_words + 63) / 64) * 64;
     const int n_chunks = (batch + ITEMS - 1) / ITEMS;
     const char *e_loop = getenv("FR_GATHER_LOOP");  // experiment knob: chunks a workgroup walks (1 = one chunk per workgroup)
@@ -231,7 +231,7 @@ static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &grou
         const char *e_stream = getenv("FR_GATHER_STREAM"), *e_st = getenv("FR_GATHER_STORE");
         const int nstep = e_stream ? atoi(e_stream) : 2;
         const size_t esz = TP == 0 ? 16 : TP == 1 ? 8 : 4;
-        const size_t out_bytes = (size_t)batch * (size_t)n_words * esz, idx_bytes = (size_t)batch * (size_t)idx_stride * 4;
+        const size_t out_bytes = (size_t)batch * (size_t)out_words * esz, idx_bytes = (size_t)batch * (size_t)idx_stride * 4;
         if (nstep > 0 && out_bytes < ((size_t)4000 << 20) && idx_bytes < ((size_t)4000 << 20)) {  // 32-bit resource offsets, with room for the chunk past the batch
             const bool wt = e_st ? atoi(e_st) == 16 : out_bytes <= ((size_t)200 << 20);
 #define FR_G_STREAM(NS)                                                                                                                     \
@@ -272,7 +272,7 @@ static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &grou
 
 template <int TP>
 static int gather_launch(const FrWordDesc *words, int n_words, const FrGatherGroups &planned, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
-                         float scale, hipStream_t s) {
+                         float scale, hipStream_t s, int out_words) {
     // experiment knobs (tools/experiments/gather_sweep.py), read per launch: FR_GATHER_XCD = 0 / 1 forces the kernel form,
     // FR_GATHER_ITEMS = items per thread of the XCD-partitioned form
     const char *e_xcd = getenv("FR_GATHER_XCD"), *e_items = getenv("FR_GATHER_ITEMS");
@@ -287,11 +287,11 @@ static int gather_launch(const FrWordDesc *words, int n_words, const FrGatherGro
         }
         if (groups.max_words <= 256) {
             switch (e_items ? atoi(e_items) : 4) {  // 4 items per thread: fastest in the r02 sweep (profiles/r02_gather_sweep.txt)
-                case 1: return gather_launch_xcd<1, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words);
-                case 2: return gather_launch_xcd<2, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words);
-                case 8: return gather_launch_xcd<8, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words);
-                case 16: return gather_launch_xcd<16, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words);
-                default: return gather_launch_xcd<4, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words);
+                case 1: return gather_launch_xcd<1, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words);
+                case 2: return gather_launch_xcd<2, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words);
+                case 8: return gather_launch_xcd<8, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words);
+                case 16: return gather_launch_xcd<16, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words);
+                default: return gather_launch_xcd<4, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words);
             }
         }
     }
@@ -313,11 +313,14 @@ static int gather_launch(const FrWordDesc *words, int n_words, const FrGatherGro
 
 // transport: FR_FC_FP32 (fp32 records, the reference's wire format), FR_FC_BF16 or FR_FC_FP8 (slice transport of the sharded mode)
 int frk_gather(const FrWordDesc *words, int n_words, const FrGatherGroups &groups, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
-               int transport, int e_x, hipStream_t s) {
+               int transport, int e_x, hipStream_t s, int out_words) {
+    // out_words = 16-byte words per item of the DESTINATION (the record, or a shard's padded slice: >= n_words): the bounds of the
+    // software-pipelined kernel's store resource
     if (n_words <= 0 || batch <= 0) return FR_OK;
-    if (transport == FR_FC_BF16) return gather_launch<1>(words, n_words, groups, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s);
-    if (transport == FR_FC_FP8) return gather_launch<2>(words, n_words, groups, idx, idx_stride, dense, out, batch, err_flag, ldexpf(1.0f, e_x), s);
-    return gather_launch<0>(words, n_words, groups, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s);
+    if (out_words < n_words) out_words = n_words;
+    if (transport == FR_FC_BF16) return gather_launch<1>(words, n_words, groups, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s, out_words);
+    if (transport == FR_FC_FP8) return gather_launch<2>(words, n_words, groups, idx, idx_stride, dense, out, batch, err_flag, ldexpf(1.0f, e_x), s, out_words);
+    return gather_launch<0>(words, n_words, groups, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s, out_words);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -267,7 +267,7 @@ static inline uint32_t fr_table_uid(const fr_table_desc &t) {
 int frk_fill_table(float *base, int64_t row0, int64_t rows, int dim, int64_t row_stride_bytes, int mode, uint32_t seed, uint32_t uid, hipStream_t s);
 int frk_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t layer, float scale, hipStream_t s);
 int frk_gather(const FrWordDesc *words, int n_words, const FrGatherGroups &groups, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
-               int transport, int e_x, hipStream_t s);
+               int transport, int e_x, hipStream_t s, int out_words);
 int frk_gather_tile(const FrPassDesc *passes, const FrChunkDesc *chunks, int n_chunks, const int32_t *idx, int idx_stride, const float *dense, void *out,
                     int out_stride_words, int batch, int *err_flag, bool dedup, unsigned long long *dup_counter, hipStream_t s);
 int frk_transpose_slices_lp(int precision, const void *gathered, int n_shards, int batch_total, int slice_padded, const int *h_offsets, const int *h_lens,

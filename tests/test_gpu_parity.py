@@ -178,6 +178,41 @@ def test_wide_record_gather_ragged_batches_and_transports(fr, O, gpu, mode):
     ctx.close()
 
 
+def test_wide_shard_slices_keep_their_padding(fr, gpu):
+    """The software-pipelined gather on SHARD slices of >= 512 words whose lengths differ: the slice buffer is [batch][padded slice], wider
+    than the shard's own words, and the kernel's store resource must be bounded by that buffer, not by the words the shard writes (a
+    bound of batch x own words would silently drop the last items' stores).  Two shards of a 76-table user model, batch >= 1024,
+    both slices against the segment-by-segment definition; the pad columns of the shorter slice stay untouched."""
+    rng = np.random.default_rng(99)
+    dims = [64] * 33 + [32] * 2 + [64] * 41          # 4800 floats; the float-balanced cut leaves two slices of different length
+    tabs = [{"dim": d_, "rows": int(rng.integers(30, 3000))} for d_ in dims]
+    m = fr.Model.from_spec({"name": "wide_shards", "tables": tabs, "fc": [1024, 512, 256]})
+    offs, lens, F = m.shard_plan(2)
+    assert min(lens) // 4 >= 512 and lens[0] != lens[1] and F == max(lens)
+    host = [rng.standard_normal((t["rows"], t["dim"])).astype(np.float32) for t in tabs]
+    B = 1024 + 37
+    idx = uniform_idx(rng, m.rows(), B)
+    want = np.empty((B, m.record_len), np.float32)
+    for sg in m.segments():
+        want[:, sg.rec_offset:sg.rec_offset + sg.len] = host[sg.src][idx[:, sg.src], sg.src_col:sg.src_col + sg.len]
+    for r in range(2):
+        ctx = fr.Context(m, device=gpu, shard_rank=r, n_shards=2)
+        for sg in m.segments():
+            if offs[r] <= sg.rec_offset < offs[r] + lens[r]:
+                ctx.upload_table(sg.src, host[sg.src])
+        wk = fr.Worker(ctx, B)
+        d_i = fr.DeviceBuffer.from_numpy(ctx, idx)
+        d_sl = fr.DeviceBuffer(ctx, B * F * 4)
+        d_sl.upload(np.full(B * F, 0x7fc01234, np.uint32))
+        wk.gather_only(B, d_i, None, d_sl)
+        wk.sync()
+        sl = d_sl.download(np.uint32, B * F).reshape(B, F)
+        assert np.array_equal(sl[:, :lens[r]], want[:, offs[r]:offs[r] + lens[r]].view(np.uint32)), r
+        assert (sl[:, lens[r]:] == 0x7fc01234).all()
+        wk.close()
+        ctx.close()
+
+
 def test_wide_record_gather_with_a_dense_block(fr, gpu):
     """The same kernel on a user-defined model whose 648-word record carries a dense block between two table sources (dense words
     take their item number, not an index): ragged batch >= 1024, against the segment-by-segment definition of the record."""
