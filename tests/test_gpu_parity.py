@@ -557,6 +557,13 @@ def test_blocked_layout_matches_3node_buffer(fr, O, gpu):
     ref = om.fc_chain(blk.view(np.float32).reshape(B, m.record_len), ws, acc64=True)
     assert rel_err(scores, ref) <= 1e-3
     wk.close()
+    # a ragged batch >= 1024: the blocked destination ([source block][item][word]: dst_blk x batch + dst_off) through gather_pack_stream_kernel
+    B2 = 1024 + 29
+    idx2 = uniform_idx(rng, m.rows(), B2)
+    dense2 = rng.uniform(-1, 1, (B2, 64)).astype(np.float32)
+    wk2 = fr.Worker(ctx, B2)
+    assert np.array_equal(wk2.gather_records(idx2, dense2), om.block_records(om.gather(idx2, dense=dense2, content_mode=O.FILL_HASH, seed=3)))
+    wk2.close()
     ctx.close()
 
 
