@@ -878,7 +878,8 @@ def main():
     driver.run_resident(B, max(args.steps, 1), d_idx)            # exactly --steps batches: the burst figure
     barrier()
     burst_dt = env.max_over_ranks(time.perf_counter() - t0)
-    n_timed = args.steps if args.roofline_only else max(steady_run(lambda k: driver.run_resident(B, k, d_idx), 0.3 if args.quick else 1.12 * STEADY_S, n_first=8192, env=env)   # the calibration run includes the ramp: it overestimates the time per batch by ~8 %,
+    # (the calibration run inside steady_run includes the ramp and overestimates the time per batch by ~8 %: size for 1.12 x the target)
+    n_timed = args.steps if args.roofline_only else max(steady_run(lambda k: driver.run_resident(B, k, d_idx), 0.3 if args.quick else 1.12 * STEADY_S, n_first=8192, env=env),
                                                         args.steps)
     barrier()
     t0 = time.perf_counter()
