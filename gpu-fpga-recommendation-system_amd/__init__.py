@@ -24,7 +24,8 @@ FC_FP32, FC_BF16, FC_FP8 = 0, 1, 2
 LAYOUT_SEMANTIC, LAYOUT_BLOCKED = 0, 1
 INDEX_PER_TABLE, INDEX_PER_ITEM, INDEX_PER_BANK = 0, 1, 2
 SEG_TABLE, SEG_COPY, SEG_DENSE = 0, 1, 2
-GATHER_WORD_MAJOR, GATHER_ITEM_TILE, GATHER_ITEM_TILE_DEDUP, GATHER_ITEM_TILE_DEDUP_COUNT = 0, 1, 2, 3
+GATHER_WORD_MAJOR, GATHER_ITEM_TILE, GATHER_ITEM_TILE_DEDUP, GATHER_ITEM_TILE_DEDUP_COUNT, GATHER_WORD_MAJOR_ONE_CHUNK = 0, 1, 2, 3, 4
+ABI_VERSION = 2   # include/fleetrec.h FR_ABI_VERSION this binding was written against
 MEM_CLASS_NAMES = {0: "HBM", 1: "DDR", 2: "PLRAM"}
 
 
@@ -134,6 +135,9 @@ def lib():
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
+    got = L.fr_abi_version()
+    if got != ABI_VERSION:   # an FR_LIB build of another ABI would be called with the wrong contract
+        raise FleetRecError(FR_ERR_STATE, "%s reports ABI version %d, this binding needs %d" % (LIB_PATH, got, ABI_VERSION))
     _lib = L
     return L
 

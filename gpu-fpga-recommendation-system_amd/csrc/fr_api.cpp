@@ -21,6 +21,13 @@ void fr_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+#ifdef FR_EXPERIMENTS
+int fr_knob_env(const char *name, int dflt) {  // experiments build only: the product library reads no environment variable
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#endif
+
 extern "C" const char *fr_last_error(void) { return g_err; }
 extern "C" int fr_abi_version(void) { return FR_ABI_VERSION; }
 
@@ -104,7 +111,9 @@ static void plan_gather_groups(fr_ctx *c) {
     const int n = c->n_words;
     if (n < 64) return;
     double wt[4] = {1.0, 0.0, 0.0, 0.0};  // write, fetch from L2-class, cache-class, HBM-class tables
+#ifdef FR_EXPERIMENTS
     if (const char *e = getenv("FR_GATHER_COST")) sscanf(e, "%lf,%lf,%lf,%lf", &wt[0], &wt[1], &wt[2], &wt[3]);
+#endif
     struct Atom { int w0, nw; double cost; };
     std::vector<Atom> atoms;
     auto close_atom = [&](int w0, int w1) {
@@ -732,17 +741,18 @@ static int launch_gather(fr_worker *w, int batch, const int32_t *d_idx, const fl
         if (needs) FR_FAIL(FR_ERR_INVALID, "model has dense features but d_dense is NULL");
     }
     const int variant = c->gather_variant.load(std::memory_order_relaxed);
-    if (variant != FR_GATHER_WORD_MAJOR && transport == FR_FC_FP32 && c->n_chunks > 0)
+    const bool one_chunk = variant == FR_GATHER_WORD_MAJOR_ONE_CHUNK;
+    if (variant != FR_GATHER_WORD_MAJOR && !one_chunk && transport == FR_FC_FP32 && c->n_chunks > 0)
         return frk_gather_tile(c->d_passes, c->d_chunks, c->n_chunks, d_idx, (int)idx_cols(c), d_dense, d_records, c->slice_padded / 4, batch, w->d_err,
                                variant != FR_GATHER_ITEM_TILE, variant == FR_GATHER_ITEM_TILE_DEDUP_COUNT ? c->d_merged : nullptr, w->stream);
     return frk_gather(c->d_words, c->n_words, c->gather_groups, d_idx, (int)idx_cols(c), d_dense, d_records, batch, w->d_err, transport, c->f8_e_act[0], w->stream,
-                      c->slice_padded / 4);  // words per item of the destination: the record (any layout) or the shard's padded slice
+                      c->slice_padded / 4, one_chunk);  // words per item of the destination: the record (any layout) or the shard's padded slice
 }
 
 extern "C" int fr_ctx_set_gather_variant(fr_ctx *ctx, int variant) {
     if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
-    if (variant < FR_GATHER_WORD_MAJOR || variant > FR_GATHER_ITEM_TILE_DEDUP_COUNT) FR_FAIL(FR_ERR_INVALID, "bad gather variant %d", variant);
-    if (variant != FR_GATHER_WORD_MAJOR && ctx->n_chunks == 0) FR_FAIL(FR_ERR_STATE, "the item-tile gather needs the SEMANTIC layout (or a shard slice)");
+    if (variant < FR_GATHER_WORD_MAJOR || variant > FR_GATHER_WORD_MAJOR_ONE_CHUNK) FR_FAIL(FR_ERR_INVALID, "bad gather variant %d", variant);
+    if (variant != FR_GATHER_WORD_MAJOR && variant != FR_GATHER_WORD_MAJOR_ONE_CHUNK && ctx->n_chunks == 0) FR_FAIL(FR_ERR_STATE, "the item-tile gather needs the SEMANTIC layout (or a shard slice)");
     ctx->gather_variant.store(variant, std::memory_order_relaxed);
     return FR_OK;
 }
@@ -935,17 +945,13 @@ static int pipeline_flush(fr_worker *w) {
 // context).  64 batches of 256 = one 64-item workgroup per CU, so ONE stream's launch fills the chip; lower it to trade throughput
 // for latency.  Atomic: driver threads read it while a control thread may change it.
 static int fused_group_initial() {
-    static const int v = [] {
-        const char *e = getenv("FR_FUSED_GROUP");
-        int g = e ? atoi(e) : FR_FUSED_DEFAULT_BATCHES;
-        return g < 1 ? 1 : (g > FR_FUSED_MAX_BATCHES ? FR_FUSED_MAX_BATCHES : g);
-    }();
-    return v;
+    const int g = FR_KNOB_ONCE("FUSED_GROUP", FR_FUSED_DEFAULT_BATCHES);
+    return g < 1 ? 1 : (g > FR_FUSED_MAX_BATCHES ? FR_FUSED_MAX_BATCHES : g);
 }
 static int fused_group(const fr_ctx *c) { return c->stream_group.load(std::memory_order_relaxed); }
 
 static bool fused_eligible(const fr_ctx *c) {
-    static const int enabled = getenv("FR_FUSED") ? atoi(getenv("FR_FUSED")) : 1;  // experiment knob
+    const int enabled = FR_KNOB_ONCE("FUSED", 1);  // experiment knob
     const int32_t *fc = c->model.fc;
     if (!enabled || c->n_shards != 1 || c->model.layout != FR_LAYOUT_SEMANTIC) return false;
     if (c->fc_precision == FR_FC_FP8) return frk_fused_f8_ok(fc[0], fc[1], fc[2], fc[3]);
@@ -976,7 +982,7 @@ static int fused_flush(fr_worker *w) {
     FrFusedArgs a{};
     const bool bf16 = c->fc_precision == FR_FC_BF16;
     // fp32: the 64-item kernel needs 64 queued batches to cover the chip; smaller groups keep the 32-item kernel (env FR_FUSED_M2=0/1 forces)
-    static const int m2_forced = getenv("FR_FUSED_M2") ? atoi(getenv("FR_FUSED_M2")) : -1;
+    const int m2_forced = FR_KNOB_ONCE("FUSED_M2", -1);
     // ... and a PARTIAL launch (fr_worker_sync with a few batches queued) that would put 64-item workgroups on at most half of the CUs
     // takes the 32-item kernel as well: twice the workgroups, 133 instead of 236 us each, bit-identical scores
     int tiles64 = 0;
@@ -1277,7 +1283,7 @@ extern "C" int fr_worker_submit(fr_worker *w, int batch) {
     // reference's H2D / D2H commands (cuda_server.c:460-461,494-495; FR_SUBMIT_ZEROCOPY=0 keeps them) that takes 4-8 us off a submit +
     // sync at every batch size (batch 256: 46.1 -> 38.4 us p50) and costs 5 % of the rate of 16 workers submitting at once
     // (profiles/r02_submit_latency.txt): this entry point is the latency path, the streaming entry points are the throughput path.
-    static const int zero_copy = getenv("FR_SUBMIT_ZEROCOPY") ? atoi(getenv("FR_SUBMIT_ZEROCOPY")) : 1;
+    const int zero_copy = FR_KNOB_ONCE("SUBMIT_ZEROCOPY", 1);
     if (zero_copy) {
         rc = launch_pipeline(w, batch, w->h_idx, c->model.dense_len ? w->h_dense : nullptr, w->h_score);
         if (rc) return rc;
@@ -1353,7 +1359,7 @@ static int host_block_launch(fr_worker *w) {
         // does; the scores are fr_worker_submit's, bit for bit (not the fused kernel's: another fp32 summation order, equal to ~1e-6).
         // The block's batches follow each other through the stage pipeline (launch L = gather of batch L | FC1 of L-1 | ... | out of L-4) and
         // four more launches drain it: n + 4 launches for the block, not 5 n.
-        static const int serial = getenv("FR_SMALL_BLOCK_SERIAL") ? atoi(getenv("FR_SMALL_BLOCK_SERIAL")) : 0;  // experiment knob: 1 = five launches per batch
+        const int serial = FR_KNOB_ONCE("SMALL_BLOCK_SERIAL", 0);  // experiment knob: 1 = five launches per batch
         for (int i = 0; i < n; i++) {
             rc = pipeline_push(w, r.bsz[b][i], 0, r.h_idx + (s0 + i) * r.idx_slot, r.dense_slot ? r.h_dense + (s0 + i) * r.dense_slot : nullptr,
                                r.h_sc + (s0 + i) * r.score_slot);

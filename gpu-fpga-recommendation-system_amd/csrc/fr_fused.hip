@@ -409,10 +409,7 @@ bool frk_fused_ok(int K, int H1, int H2, int H3) {
 
 // two workgroups per CU need <= 80 KiB each (FR_FUSED_WPE=2 forces the one-workgroup build, for A/B measurements)
 static int fused_wpe(int K, int H2) {
-    static const int forced = [] {
-        const char *e = getenv("FR_FUSED_WPE");
-        return e ? atoi(e) : 0;
-    }();
+    const int forced = FR_KNOB_ONCE("FUSED_WPE", 0);
     if (forced == 2 || forced == 4) return forced == 4 && frk_fused_lds_bytes(K, H2, 4) > 80 * 1024 ? 2 : forced;
     return frk_fused_lds_bytes(K, H2, 4) <= 80 * 1024 ? 4 : 2;
 }

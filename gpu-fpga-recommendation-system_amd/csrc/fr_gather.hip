@@ -214,26 +214,29 @@ __global__ void __launch_bounds__(256) gather_pack_stream_kernel(const FrWordDes
     if (bad) atomicOr_system(err_flag, 1);
 }
 
+// stream_form: 0 = the one-chunk-per-workgroup kernel (gather_pack_xcd_kernel; also what records or index buffers of >= 4000 MiB take),
+// n > 0 = gather_pack_stream_kernel with n chunks per workgroup (the product launches 2)
 template <int ITEMS, int TP>
 static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &groups, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch,
-                             int *err_flag, float scale, hipStream_t s, int n_words, int out_words) {
+                             int *err_flag, float scale, hipStream_t s, int n_words, int out_words, int stream_form) {
     const size_t n_rec_bytes = (size_t)out_words * 16;
     const int bx = ((groups.max_words + 63) / 64) * 64;
     const int n_chunks = (batch + ITEMS - 1) / ITEMS;
-    const char *e_loop = getenv("FR_GATHER_LOOP");  // experiment knob: chunks a workgroup walks (1 = one chunk per workgroup)
-    const int per_wg = e_loop ? (atoi(e_loop) > 0 ? atoi(e_loop) : 1) : 1;
+    const int per_wg_knob = FR_KNOB("GATHER_LOOP", 1);  // experiment knob: chunks a workgroup of the one-chunk form walks
+    const int per_wg = per_wg_knob > 0 ? per_wg_knob : 1;
     dim3 grid(8 * ((n_chunks + per_wg - 1) / per_wg));
+    (void)n_rec_bytes;
     if constexpr (ITEMS == 4 || ITEMS == 2) {
         // default: the software-pipelined form, 2 chunks per workgroup, write-through record stores while the records fit the Infinity
         // Cache with room to spare (profiles/r02_gather_stream_sweep.txt: Model-C batch 4096 per-bank 25.2 -> 22.0 us; beyond ~200 MB of
-        // records write-back stores are as fast or 1-2 % faster).  Experiment knobs, read per launch: FR_GATHER_STREAM = chunks per
-        // workgroup (0 = the one-chunk form below), FR_GATHER_STORE = 0 write-back / 16 write-through.
-        const char *e_stream = getenv("FR_GATHER_STREAM"), *e_st = getenv("FR_GATHER_STORE");
-        const int nstep = e_stream ? atoi(e_stream) : 2;
+        // records write-back stores are as fast or 1-2 % faster).  Experiments build only: FR_GATHER_STREAM = chunks per workgroup,
+        // FR_GATHER_STORE = 0 write-back / 16 write-through, both read per launch.
+        const int nstep = FR_KNOB("GATHER_STREAM", stream_form);
         const size_t esz = TP == 0 ? 16 : TP == 1 ? 8 : 4;
         const size_t out_bytes = (size_t)batch * (size_t)out_words * esz, idx_bytes = (size_t)batch * (size_t)idx_stride * 4;
         if (nstep > 0 && out_bytes < ((size_t)4000 << 20) && idx_bytes < ((size_t)4000 << 20)) {  // 32-bit resource offsets, with room for the chunk past the batch
-            const bool wt = e_st ? atoi(e_st) == 16 : out_bytes <= ((size_t)200 << 20);
+            const int st_knob = FR_KNOB("GATHER_STORE", -1);
+            const bool wt = st_knob >= 0 ? st_knob == 16 : out_bytes <= ((size_t)200 << 20);
 #define FR_G_STREAM(NS)                                                                                                                     \
     case NS: {                                                                                                                              \
         dim3 g2(8 * ((n_chunks + NS - 1) / NS));                                                                                            \
@@ -243,18 +246,20 @@ static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &grou
         return FR_OK;                                                                                                                       \
     }
             switch (nstep) {
-                FR_G_STREAM(1)
                 FR_G_STREAM(2)
+#ifdef FR_EXPERIMENTS
+                FR_G_STREAM(1)
                 FR_G_STREAM(4)
                 FR_G_STREAM(8)
+#endif
                 default: break;
             }
 #undef FR_G_STREAM
         }
     }
+#ifdef FR_EXPERIMENTS
     if constexpr (ITEMS == 4 && TP == 0) {
-        const char *e_st = getenv("FR_GATHER_STORE");  // experiment knob: cache policy of the record stores (0 plain, 16 sc1, 2 nt) of the one-chunk form
-        const int st = e_st ? atoi(e_st) : 0;
+        const int st = FR_KNOB("GATHER_STORE", 0);  // experiment knob: cache policy of the record stores (0 plain, 16 sc1, 2 nt) of the one-chunk form
         if (st && (size_t)batch * (size_t)n_rec_bytes < ((size_t)1 << 32)) {
 #define FR_G_ST(A) case A: gather_pack_xcd_kernel<4, 0, A><<<grid, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, n_chunks); KCHECK(); return FR_OK;
             switch (st) {
@@ -265,6 +270,7 @@ static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &grou
 #undef FR_G_ST
         }
     }
+#endif
     gather_pack_xcd_kernel<ITEMS, TP><<<grid, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, n_chunks);
     KCHECK();
     return FR_OK;
@@ -272,26 +278,27 @@ static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &grou
 
 template <int TP>
 static int gather_launch(const FrWordDesc *words, int n_words, const FrGatherGroups &planned, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
-                         float scale, hipStream_t s, int out_words) {
-    // experiment knobs (tools/experiments/gather_sweep.py), read per launch: FR_GATHER_XCD = 0 / 1 forces the kernel form,
-    // FR_GATHER_ITEMS = items per thread of the XCD-partitioned form
-    const char *e_xcd = getenv("FR_GATHER_XCD"), *e_items = getenv("FR_GATHER_ITEMS");
-    const int force = e_xcd ? atoi(e_xcd) : -1;
+                         float scale, hipStream_t s, int out_words, int stream_form) {
+    // experiments build only (tools/experiments/gather_sweep.py), read per launch: FR_GATHER_XCD = 0 / 1 forces the kernel form,
+    // FR_GATHER_ITEMS = items per thread of the XCD-partitioned form, FR_GATHER_UNIFORM_GROUPS = n_words / 8 words per XCD group
+    const int force = FR_KNOB("GATHER_XCD", -1);
     const bool xcd = force >= 0 ? force != 0 : (n_words >= 512 && batch >= 1024);
     if (xcd) {
         FrGatherGroups groups = planned;
-        if (groups.max_words <= 0 || (getenv("FR_GATHER_UNIFORM_GROUPS") && atoi(getenv("FR_GATHER_UNIFORM_GROUPS")))) {  // no plan (or the experiment knob): n_words / 8 each
+        if (groups.max_words <= 0 || FR_KNOB("GATHER_UNIFORM_GROUPS", 0)) {  // no plan (or the experiment knob): n_words / 8 each
             const int wpg = (n_words + 7) / 8;
             for (int g = 0; g <= 8; g++) groups.start[g] = g * wpg < n_words ? g * wpg : n_words;
             groups.max_words = wpg;
         }
         if (groups.max_words <= 256) {
-            switch (e_items ? atoi(e_items) : 4) {  // 4 items per thread: fastest in the r02 sweep (profiles/r02_gather_sweep.txt)
-                case 1: return gather_launch_xcd<1, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words);
-                case 2: return gather_launch_xcd<2, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words);
-                case 8: return gather_launch_xcd<8, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words);
-                case 16: return gather_launch_xcd<16, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words);
-                default: return gather_launch_xcd<4, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words);
+            switch (FR_KNOB("GATHER_ITEMS", 4)) {  // 4 items per thread: fastest in the r02 sweep (profiles/r02_gather_sweep.txt)
+#ifdef FR_EXPERIMENTS
+                case 1: return gather_launch_xcd<1, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words, stream_form);
+                case 2: return gather_launch_xcd<2, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words, stream_form);
+                case 8: return gather_launch_xcd<8, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words, stream_form);
+                case 16: return gather_launch_xcd<16, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words, stream_form);
+#endif
+                default: return gather_launch_xcd<4, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words, stream_form);
             }
         }
     }
@@ -313,14 +320,15 @@ static int gather_launch(const FrWordDesc *words, int n_words, const FrGatherGro
 
 // transport: FR_FC_FP32 (fp32 records, the reference's wire format), FR_FC_BF16 or FR_FC_FP8 (slice transport of the sharded mode)
 int frk_gather(const FrWordDesc *words, int n_words, const FrGatherGroups &groups, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
-               int transport, int e_x, hipStream_t s, int out_words) {
+               int transport, int e_x, hipStream_t s, int out_words, bool one_chunk) {
     // out_words = 16-byte words per item of the DESTINATION (the record, or a shard's padded slice: >= n_words): the bounds of the
-    // software-pipelined kernel's store resource
+    // software-pipelined kernel's store resource.  one_chunk: the FR_GATHER_WORD_MAJOR_ONE_CHUNK variant (gather_pack_xcd_kernel).
     if (n_words <= 0 || batch <= 0) return FR_OK;
     if (out_words < n_words) out_words = n_words;
-    if (transport == FR_FC_BF16) return gather_launch<1>(words, n_words, groups, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s, out_words);
-    if (transport == FR_FC_FP8) return gather_launch<2>(words, n_words, groups, idx, idx_stride, dense, out, batch, err_flag, ldexpf(1.0f, e_x), s, out_words);
-    return gather_launch<0>(words, n_words, groups, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s, out_words);
+    const int stream_form = one_chunk ? 0 : 2;
+    if (transport == FR_FC_BF16) return gather_launch<1>(words, n_words, groups, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s, out_words, stream_form);
+    if (transport == FR_FC_FP8) return gather_launch<2>(words, n_words, groups, idx, idx_stride, dense, out, batch, err_flag, ldexpf(1.0f, e_x), s, out_words, stream_form);
+    return gather_launch<0>(words, n_words, groups, idx, idx_stride, dense, out, batch, err_flag, 1.0f, s, out_words, stream_form);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -242,6 +242,9 @@ __device__ __forceinline__ void pipe_read_frags(FrPipeFrag<PREC> &f, const uint4
 template <int PREC, int NS, int G>
 __global__ void __launch_bounds__(512) fc_gemm_pipe_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
                                                            int N, int ldm, int sc_a, int sc_b, float oscale, int ablate) {
+#ifndef FR_EXPERIMENTS
+    ablate = 0x110;  // product build: staggered issue order, wave priority 1, NO timing ablation can reach the kernel (the branches below fold away)
+#endif
     extern __shared__ uint4 glds[];
     typedef __attribute__((address_space(3))) void *lds_ptr;
     constexpr int GM = 256, ROW = FR_GN + GM, STAGE = G * FR_PR * ROW;
@@ -458,8 +461,7 @@ __global__ void __launch_bounds__(512) fc_gemm_pipe_kernel(const uint4 *__restri
 // Pipeline shape (experiment knob FR_GEMM_PIPE = 10 * G + NS; 0 = fc_lp_gemm_kernel): G row groups of 4 element rows per sub-step, NS
 // sub-steps in LDS.  Default: see pipe_shape().
 static int pipe_shape() {
-    static const int v = getenv("FR_GEMM_PIPE") ? atoi(getenv("FR_GEMM_PIPE")) : 15;
-    return v;
+    return FR_KNOB_ONCE("GEMM_PIPE", 15);
 }
 
 template <int PREC, int NS, int G>
@@ -468,8 +470,8 @@ static int pipe_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, in
     const size_t lds = (size_t)NS * G * FR_PR * (FR_GN + 256) * 16;
     if (int rc_ = fr_allow_full_lds(&fc_gemm_pipe_kernel<PREC, NS, G>, lds_once)) return rc_;
     dim3 grid((N / FR_GN) * (ldm / 256));
-    static const int ablate = (getenv("FR_GEMM_ABLATE") ? atoi(getenv("FR_GEMM_ABLATE")) : 0) |   // timing experiments only
-                              ((getenv("FR_GEMM_ORDER") ? atoi(getenv("FR_GEMM_ORDER")) : 1) << 4) | ((getenv("FR_GEMM_PRIO") ? atoi(getenv("FR_GEMM_PRIO")) : 1) << 8);
+    // bits 0-3: timing-only ablations (wrong results; experiments build only), bit 4: issue order, bit 8: wave priority
+    const int ablate = FR_KNOB_ONCE("GEMM_ABLATE", 0) | (FR_KNOB_ONCE("GEMM_ORDER", 1) << 4) | (FR_KNOB_ONCE("GEMM_PRIO", 1) << 8);
     fc_gemm_pipe_kernel<PREC, NS, G><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale, ablate);
     KCHECK();
     return FR_OK;
@@ -496,14 +498,14 @@ static int pipe_gemm_dispatch(int shape, const void *Wp, const void *Xp, void *Y
 // with few outputs (Model-C FC2 / FC3 at batch 4096: 512 / 256 outputs -> 256 / 128 tiles instead of 128 / 64), 0 = not worth a GEMM
 // launch (the stage pipeline's per-tile body takes it).
 static int lp_gemm_mu(int precision, int K, int N, int ldm) {
-    static const int forced = getenv("FR_LP_GEMM") ? atoi(getenv("FR_LP_GEMM")) : -1;  // experiment knob: 0 = never, 1 / 2 / 3 = only that tile
+    const int forced = FR_KNOB_ONCE("LP_GEMM", -1);  // experiment knob: 0 = never, 1 / 2 / 3 = only that tile
     const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : (precision == FR_FC_BF16 ? K / 8 : K / 4);
     if ((precision == FR_FC_BF16 && K % 8) || (precision == FR_FC_FP32 && K % 4) || KE % FR_GR || KE / FR_GR < 2 || N % 64 || ldm % 128) return 0;
     if (forced == 0) return 0;
     const long t256 = (N % 128 || ldm % 256) ? 0 : (long)(N / 128) * (ldm / 256), t128 = N % 128 ? 0 : (long)(N / 128) * (ldm / 128),
                t64 = (long)(N / 64) * (ldm / 128);
     if (forced > 0) return ((forced == 2 && t256) || (forced == 1 && t128) || forced == 3) ? forced : 0;
-    static const int small_tile = getenv("FR_LP_GEMM_SMALL") ? atoi(getenv("FR_LP_GEMM_SMALL")) : 3;  // experiment knob: 1 = no 64 x 128 tiles
+    const int small_tile = FR_KNOB_ONCE("LP_GEMM_SMALL", 3);  // experiment knob: 1 = no 64 x 128 tiles
     if (t256 >= 192) return 2;
     if (t128 >= 192) return 1;
     if (t64 >= 128 && small_tile == 3) return 3;
@@ -530,7 +532,7 @@ static int lp_gemm_tile(int mu, const void *Wp, const void *Xp, void *Yp, int KE
     if (mu == 3) {
         // 4 stages pay in bf16 only (Model-C FC2 19.8 -> 14.7 us, end to end +2.5 %); in fp8 / f32 the larger LDS footprint costs more
         // beside the other streams' kernels than the deeper prefetch gains (fp8 end to end 57.3 -> 52.8 M inf/s).  Knob: FR_LP_GEMM_STAGES
-        static const int deep = getenv("FR_LP_GEMM_STAGES") ? atoi(getenv("FR_LP_GEMM_STAGES")) : (PREC == 1 ? 4 : 2);
+        const int deep = FR_KNOB_ONCE("LP_GEMM_STAGES", (PREC == 1 ? 4 : 2));
         return deep == 2 ? lp_gemm_launch<PREC, 1, 64, 2>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s)
                          : lp_gemm_launch<PREC, 1, 64, 4>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
     }
@@ -544,7 +546,7 @@ int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int 
     if (precision == FR_FC_FP32) return lp_gemm_tile<0>(mu, Wp, Xp, Yp, KE, N, ldm, 0, 0, 1.0f, s);
     // bf16 128 x 256 layers run the software-pipelined kernel; fp8 stays on fc_lp_gemm_kernel, which measured faster there (29.4 vs
     // 32.9 us on Model-C FC1: its 8-row steps halve the barriers per 64-cycle MFMA) unless FR_GEMM_PIPE_FP8=1 asks for the experiment
-    static const bool pipe_fp8 = getenv("FR_GEMM_PIPE_FP8") && atoi(getenv("FR_GEMM_PIPE_FP8")) != 0;
+    const bool pipe_fp8 = FR_KNOB_ONCE("GEMM_PIPE_FP8", 0) != 0;
     if (mu == 2 && (precision == FR_FC_BF16 || (precision == FR_FC_FP8 && pipe_fp8)) && pipe_shape_ok(pipe_shape(), KE)) {
         if (precision == FR_FC_FP8) return pipe_gemm_dispatch<2>(pipe_shape(), Wp, Xp, Yp, KE, N, ldm, 127 - e_w, 127 - e_in, ldexpf(1.0f, e_out), s);
         return pipe_gemm_dispatch<1>(pipe_shape(), Wp, Xp, Yp, KE, N, ldm, 0, 0, 1.0f, s);

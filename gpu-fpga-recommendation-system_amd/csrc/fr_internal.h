@@ -29,6 +29,19 @@ void fr_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
         }                                                                                            \
     } while (0)
 
+// ---- experiment knobs ---------------------------------------------------------------------------
+// The product library reads NO environment variable: FR_KNOB folds to its default and the variable's name is not even in the
+// binary.  `make exp` builds libfleetrec_exp.so with -DFR_EXPERIMENTS, where FR_KNOB("X", d) reads the environment variable FR_X
+// (FR_KNOB: at every call -- in-process sweeps; FR_KNOB_ONCE: once per process); A/B runs load that build through FR_LIB.
+#ifdef FR_EXPERIMENTS
+int fr_knob_env(const char *name, int dflt);
+#define FR_KNOB(name, dflt) fr_knob_env("FR_" name, (dflt))
+#define FR_KNOB_ONCE(name, dflt) ([]() -> int { static const int v_ = fr_knob_env("FR_" name, (dflt)); return v_; }())
+#else
+#define FR_KNOB(name, dflt) (dflt)
+#define FR_KNOB_ONCE(name, dflt) (dflt)
+#endif
+
 // ---- device-side descriptors --------------------------------------------------------------------
 // One per 16-byte word of the per-item record (the unit the reference's packers move:
 // `typedef ap_uint<128> axi_t`, constants.hpp:4).  32 bytes = two dwordx4 loads, read once per thread.
@@ -267,7 +280,7 @@ static inline uint32_t fr_table_uid(const fr_table_desc &t) {
 int frk_fill_table(float *base, int64_t row0, int64_t rows, int dim, int64_t row_stride_bytes, int mode, uint32_t seed, uint32_t uid, hipStream_t s);
 int frk_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t layer, float scale, hipStream_t s);
 int frk_gather(const FrWordDesc *words, int n_words, const FrGatherGroups &groups, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
-               int transport, int e_x, hipStream_t s, int out_words);
+               int transport, int e_x, hipStream_t s, int out_words, bool one_chunk = false);
 int frk_gather_tile(const FrPassDesc *passes, const FrChunkDesc *chunks, int n_chunks, const int32_t *idx, int idx_stride, const float *dense, void *out,
                     int out_stride_words, int batch, int *err_flag, bool dedup, unsigned long long *dup_counter, hipStream_t s);
 int frk_transpose_slices_lp(int precision, const void *gathered, int n_shards, int batch_total, int slice_padded, const int *h_offsets, const int *h_lens,

@@ -281,7 +281,7 @@ __device__ __forceinline__ void gather_tr_stream_body(const FrPipeArgs &a, const
 // 2 = gather_tr_stream_body (two tiles per workgroup, write-through image stores: Model-C batch 4096 chain 55 -> 58 M inf/s in fp8,
 // 35.7 -> 37 M in bf16, profiles/r02_gather_tr_variants.txt); 1 = gather_tr_body (FR_GATHER_TR_VARIANT=1, and index buffers >= 4000 MiB)
 int frk_gather_tr_variant(int batch, int idx_stride) {
-    static const int v = getenv("FR_GATHER_TR_VARIANT") ? atoi(getenv("FR_GATHER_TR_VARIANT")) : 2;  // experiment knob
+    const int v = FR_KNOB_ONCE("GATHER_TR_VARIANT", 2);  // experiment knob
     return (v == 1 || (size_t)batch * (size_t)idx_stride * 4 >= ((size_t)4000 << 20)) ? 1 : 2;
 }
 
@@ -289,7 +289,7 @@ int frk_gather_tr_blocks(int n_words, int ldm, int variant) {
     if (ldm % FR_GT_ITEMS || (n_words & 1)) return 0;
     const int nt = variant == 2 ? 2 : 1;
     const int blocks = ((ldm / FR_GT_ITEMS + nt - 1) / nt) * ((n_words + FR_GT_WORDS - 1) / FR_GT_WORDS);
-    static const int forced = getenv("FR_GATHER_TR") ? atoi(getenv("FR_GATHER_TR")) : -1;  // experiment knob
+    const int forced = FR_KNOB_ONCE("GATHER_TR", -1);  // experiment knob
     if (forced == 0) return 0;
     if (forced == 1) return blocks;
     return blocks >= 128 ? blocks : 0;  // needs enough workgroups to cover the chip; small batches keep the simple form
@@ -919,7 +919,7 @@ __global__ void __launch_bounds__(FR_PIPE_THREADS) __attribute__((amdgpu_num_vgp
 template <int PREC>
 static int pipeline_launch_prec(const FrPipeArgs &a, int single_stage, hipStream_t s) {
     dim3 grid(a.n_blocks), block(FR_PIPE_THREADS);
-    static const int light = getenv("FR_GATHER_OUT_KERNEL") ? atoi(getenv("FR_GATHER_OUT_KERNEL")) : 1;  // experiment knob: 0 = always fr_pipeline_kernel<-1>
+    const int light = FR_KNOB_ONCE("GATHER_OUT_KERNEL", 1);  // experiment knob: 0 = always fr_pipeline_kernel<-1>
     if (single_stage == -1 && light && a.st[0].variant == 2 && a.st[1].block_begin > a.st[0].block_begin && a.st[1].block_begin == a.st[2].block_begin &&
         a.st[2].block_begin == a.st[3].block_begin && a.st[3].block_begin == a.st[4].block_begin) {
         fr_gather_out_kernel<PREC><<<grid, block, 0, s>>>(a);

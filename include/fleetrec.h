@@ -31,7 +31,11 @@ extern "C" {
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 #endif
 
-#define FR_ABI_VERSION 1
+/* 2 (round 3): fr_ctx_set_stream_group is per context (1..64) and groups below 12 ride the stage pipeline; fr_worker_submit reads /
+ * writes the worker's pinned buffers from the kernels; FR_INDEX_PER_BANK stores bank-interleaved tables; FR_GATHER_WORD_MAJOR_ONE_CHUNK;
+ * the library reads no environment variable.  A binding must refuse a library whose fr_abi_version() differs from the header it was
+ * written against (the Python binding does, also for a build loaded through FR_LIB). */
+#define FR_ABI_VERSION 2
 
 typedef enum fr_status {
     FR_OK = 0,
@@ -229,7 +233,8 @@ void *fr_worker_stream(fr_worker *w);
  * stream.  Exactly one batch may be in flight per worker: fr_worker_sync() must be called before the
  * pinned buffers are touched again (this fixes the reference's unsynchronised reuse, cuda_server.c:406-497).
  * The two PCIe hops are not copy commands by default: the gather stage reads the pinned index rows and the output layer writes the
- * pinned score buffer directly (4-8 us less per submit + sync; env FR_SUBMIT_ZEROCOPY=0 restores the reference's H2D / D2H commands). */
+ * pinned score buffer directly (4-8 us less per submit + sync than the reference's H2D / D2H commands; the experiments build of the
+ * library -- `make -C csrc exp` -- keeps them behind FR_SUBMIT_ZEROCOPY=0 for A/B timing). */
 int fr_worker_submit(fr_worker *w, int batch);
 /* Same, with inputs/outputs already resident in HBM (device pointers; no PCIe traffic):
  * d_idx int32 [batch][fr_model_index_cols(model)]; d_dense float [batch][dense_len] or NULL;
@@ -249,12 +254,13 @@ int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d_idx, const
  * fr_driver_run_resident does with R = 256). */
 int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores);
 /* How many pushed batches one streaming launch carries on this context: 1 when fr_worker_push_device rides the stage pipeline
- * (models that do not fit the fused kernel), G (1..64, default 64; env FR_FUSED_GROUP overrides the default of new contexts) when
+ * (models that do not fit the fused kernel), G (1..64, default 64) when
  * the model streams through the fused item-tile kernel -- the value fr_ctx_set_stream_group set, also when it is below 12 and the
  * pushes ride the stage pipeline. */
 int fr_ctx_stream_group(const fr_ctx *ctx);
 /* Throughput/latency knob of the fused streaming path, PER CONTEXT: batches per launch, 1..64.  64 batches of 256 items = one 64-item
- * workgroup per CU (fp32: fr_fused_tile_m2_kernel); <= 32 selects the 32-item kernel, halves the queueing latency of a pushed batch and
+ * workgroup per CU (fp32: fr_fused_tile_m2_kernel, used only for a group of 64 AND a launch of more than 128 such tiles); smaller groups
+ * take the 32-item kernel, which halves the queueing latency of a pushed batch and
  * leaves CUs to other streams (a partial launch -- fr_worker_sync with few batches queued -- whose 64-item tiles would cover at most half
  * of the CUs takes the 32-item kernel too).  Scores are bit-identical for every group size from 12 up.  Groups below 12 make
  * fr_worker_push_device ride the stage pipeline instead (one launch per push; the batch's scores are complete four pushes later or at
@@ -324,10 +330,14 @@ int fr_worker_fc_layer_only(fr_worker *w, int batch, int layer);
  *                        out as whole 1 KiB record pieces (gather_tile_kernel<false>);
  *  ITEM_TILE_DEDUP     : the same with a wave-level merge of duplicate lookups (LDS hash + __shfl: only one lane per distinct
  *                        index loads the row) -- BASELINE.json north_star's "ballot/shuffle index dedup";
- *  ..._DEDUP_COUNT     : DEDUP + a __ballot count of the merged lookups (diagnostic; fr_ctx_gather_merged_lookups).
+ *  ..._DEDUP_COUNT     : DEDUP + a __ballot count of the merged lookups (diagnostic; fr_ctx_gather_merged_lookups);
+ *  WORD_MAJOR_ONE_CHUNK: the word-major mapping with one chunk of items per workgroup and no software pipeline
+ *                        (gather_pack_xcd_kernel) -- what WORD_MAJOR itself falls back to when the records or the index buffer
+ *                        of a launch reach 4000 MiB; selectable so that the fallback is parity-tested at ordinary sizes.
  * All variants produce bit-identical records.  DESIGN.md section 3.1 holds the measured A/B. */
 typedef enum fr_gather_variant {
-    FR_GATHER_WORD_MAJOR = 0, FR_GATHER_ITEM_TILE = 1, FR_GATHER_ITEM_TILE_DEDUP = 2, FR_GATHER_ITEM_TILE_DEDUP_COUNT = 3
+    FR_GATHER_WORD_MAJOR = 0, FR_GATHER_ITEM_TILE = 1, FR_GATHER_ITEM_TILE_DEDUP = 2, FR_GATHER_ITEM_TILE_DEDUP_COUNT = 3,
+    FR_GATHER_WORD_MAJOR_ONE_CHUNK = 4
 } fr_gather_variant;
 int fr_ctx_set_gather_variant(fr_ctx *ctx, int variant);
 int fr_ctx_gather_variant(const fr_ctx *ctx);

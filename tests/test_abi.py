@@ -18,7 +18,7 @@ def declared_symbols():
 
 def test_header_is_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "fleetrec.h"\nint main(void){ fr_model_desc d; (void)d; return FR_ABI_VERSION - 1; }\n')
+    src.write_text('#include "fleetrec.h"\nint main(void){ fr_model_desc d; (void)d; return FR_ABI_VERSION - 2; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
                            "-c", str(src), "-o", str(tmp_path / "t.o")])
 
@@ -29,11 +29,23 @@ def test_exports_every_declared_symbol(fr):
     L = ctypes.CDLL(fr.LIB_PATH)
     for s in syms:
         assert hasattr(L, s), "libfleetrec.so does not export %s" % s
-    assert fr.lib().fr_abi_version() == 1
+    assert fr.lib().fr_abi_version() == fr.ABI_VERSION == 2
     # nothing but the fr_* API is exported
     out = subprocess.check_output(["nm", "-D", "--defined-only", fr.LIB_PATH]).decode()
     exported = [l.split()[-1] for l in out.splitlines() if " T " in l]
     assert all(e.startswith("fr_") for e in exported), exported
+
+
+def test_product_library_reads_no_environment_variable(fr):
+    """the experiment knobs (FR_GEMM_ABLATE -- wrong results by design --, FR_GATHER_*, FR_FUSED_*, ...) exist only
+    in the -DFR_EXPERIMENTS build (`make -C csrc exp` -> libfleetrec_exp.so); the shipped library carries none of their names and does
+    not import getenv at all (the GPU suite additionally checks that setting them changes no score bit)."""
+    blob = open(fr.LIB_PATH, "rb").read()
+    for name in (b"FR_GEMM_ABLATE", b"FR_GEMM_ORDER", b"FR_GEMM_PRIO", b"FR_GEMM_PIPE", b"FR_GATHER_", b"FR_FUSED", b"FR_LP_GEMM", b"FR_SUBMIT_ZEROCOPY",
+                 b"FR_SMALL_BLOCK_SERIAL"):
+        assert name not in blob, name
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", fr.LIB_PATH]).decode()
+    assert "getenv" not in und, "libfleetrec.so imports getenv"
 
 
 def test_struct_layout_matches_header(fr, tmp_path):

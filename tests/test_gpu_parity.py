@@ -131,12 +131,12 @@ def test_wide_record_gather_ragged_batches_and_transports(fr, O, gpu, mode):
     for B in (1024, 1027, 1029, 2050, BMAX):
         got = wk.gather_records(idx[:B], dense[:B]).reshape(B, m.record_len)
         assert np.array_equal(got, want[:B]), (mode, B)
-    # the one-chunk-per-workgroup kernel (what records or index buffers of >= 4000 MiB fall back to; the knob is read per launch)
-    os.environ["FR_GATHER_STREAM"] = "0"
+    # the one-chunk-per-workgroup kernel (what records or index buffers of >= 4000 MiB fall back to), selected explicitly
+    ctx.set_gather_variant(fr.GATHER_WORD_MAJOR_ONE_CHUNK)
     try:
         assert np.array_equal(wk.gather_records(idx[:1027], dense[:1027]).reshape(1027, m.record_len), want[:1027]), mode
     finally:
-        del os.environ["FR_GATHER_STREAM"]
+        ctx.set_gather_variant(fr.GATHER_WORD_MAJOR)
     f32 = want.view(np.float32)
     d_i = fr.DeviceBuffer.from_numpy(ctx, idx)
     d_d = fr.DeviceBuffer.from_numpy(ctx, dense)
