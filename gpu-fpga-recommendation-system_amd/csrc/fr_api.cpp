@@ -1030,7 +1030,19 @@ static int fused_flush(fr_worker *w) {
     w->pending_items = 0;
     if (fp8) return frk_fused_f8_launch(a, w->stream);
     if (m2) return frk_fused_m2_launch(a, w->stream);
-    return bf16 ? frk_fused_h_launch(a, w->stream) : frk_fused_launch(a, w->stream);
+    if (bf16) {
+        // the K-outer persistent kernel (fr_fused_ko.hip) whenever the context's descriptors fit its packed form; experiments build:
+        // FR_FUSED_HK=0 keeps the chunked kernel for A/B runs
+        if (c->hk_ok < 0) {
+            int n_cu = 0;
+            FR_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
+            c->n_cu = n_cu > 0 ? n_cu : 256;
+            c->hk_ok = frk_fused_hk_ok(a.K, a.H1, a.H2, a.H3, c->h_words.data(), c->n_words) ? 1 : 0;
+        }
+        if (c->hk_ok == 1 && FR_KNOB_ONCE("FUSED_HK", 1)) return frk_fused_hk_launch(a, c->n_cu, w->stream);
+        return frk_fused_h_launch(a, w->stream);
+    }
+    return frk_fused_launch(a, w->stream);
 }
 
 static int check_gather_args(fr_worker *w, const int32_t *d_idx, const float *d_dense) {
@@ -1252,7 +1264,7 @@ extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_i
         w->in_flight = true;
         // a launch is due when the group is full or when the queue already covers the chip (256 CUs x 64 items): large batches
         // need fewer of them per launch
-        return (w->n_pending >= fused_group(c) || w->pending_items >= 256 * 64) ? fused_flush(w) : FR_OK;
+        return (w->n_pending >= fused_group(c) || w->pending_items >= FR_KNOB_ONCE("FUSED_ITEMS", 256 * 64)) ? fused_flush(w) : FR_OK;
     }
     rc = pipeline_push(w, batch, 0, d_idx, d_dense, d_scores);
     if (rc) return rc;

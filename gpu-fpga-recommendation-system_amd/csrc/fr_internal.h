@@ -206,6 +206,8 @@ struct fr_ctx {
     std::atomic<int> stream_group{FR_FUSED_DEFAULT_BATCHES};
     // host-fed blocks of at most this many batches take the stage pipeline instead of the fused kernel (fr_ctx_set_small_block; 0: never)
     std::atomic<int> small_block{0};
+    int n_cu = 0;                          // compute units of the device (grid of the persistent fused kernel)
+    int hk_ok = -1;                        // fr_fused_tile_hk_kernel applies to this context's descriptors (-1: not examined yet)
 };
 
 struct fr_worker {
@@ -308,7 +310,9 @@ bool frk_fused_h_ok(int K, int H1, int H2, int H3);
 bool frk_fused_f8_ok(int K, int H1, int H2, int H3);
 int frk_fused_f8_launch(const FrFusedArgs &a, hipStream_t s);
 int frk_fused_h_items_per_wg();
-int frk_fused_h_launch(const FrFusedArgs &a, hipStream_t s);  // 0 when the transposing gather does not apply
+int frk_fused_h_launch(const FrFusedArgs &a, hipStream_t s);
+bool frk_fused_hk_ok(int K, int H1, int H2, int H3, const FrWordDesc *h_words, int n_words);  // the K-outer persistent bf16 kernel (fr_fused_ko.hip)
+int frk_fused_hk_launch(const FrFusedArgs &a, int n_cu, hipStream_t s);  // 0 when the transposing gather does not apply
 int frk_transpose_records(const float *X, float *Xt, int batch, int K, int ldm, hipStream_t s);
 int frk_transpose_slices(const float *gathered, int n_shards, int batch_total, int slice_padded, const int *h_offsets, const int *h_lens,
                          int item0, int n_items, float *Xq, int ldm, hipStream_t s);

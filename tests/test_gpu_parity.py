@@ -1834,3 +1834,64 @@ def test_random_custom_models(fr, O, gpu, seed):
             ctx.set_fc_precision(fr.FC_FP8)
     wk.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_bf16_persistent_fused_kernel_many_tiles(fr, O, ctxs):
+    """fr_fused_tile_hk_kernel (fr_fused_ko.hip), BASELINE configs[2]'s kernel: more 64-item tiles than compute units in one launch, so
+    that every persistent workgroup walks several tiles with the next tile's gather running under the current tile's FC phases;
+    batches of unequal size in one launch (tiles past a batch's end are skipped), ragged tails, a one-item batch.  Every batch's scores
+    against the host restatement of the bf16 arithmetic (5e-3) and against the fp64-accumulating oracle (3e-2), equal rows give equal
+    bits wherever they sit in the launch, and an out-of-range index in the LAST tile of a workgroup's walk is reported."""
+    m, ctx = ctxs(fr.MODEL_B)
+    om = O.OracleModel("B")
+    rng = np.random.default_rng(77)
+    B = 1024
+    pool_idx = [uniform_idx(rng, m.rows(), B) for _ in range(3)]
+    ws = [ctx.get_weights(l) for l in range(4)]
+    refs = []
+    for idx in pool_idx:
+        rec = om.gather(idx, content_mode=O.FILL_HASH, seed=SEED_TABLES).view(np.float32)
+        refs.append((chain_bf16_reference(rec, ws, m.fc), om.fc_chain(rec, ws, acc64=True)))
+    ctx.set_fc_precision(fr.FC_BF16)
+    try:
+        wk = fr.Worker(ctx, B)
+        d_pool = [fr.DeviceBuffer.from_numpy(ctx, i_) for i_ in pool_idx]
+        sizes = [1024, 1024, 1000, 64, 1, 130, 1024, 577]
+        outs = []
+        for rep in range(64):                  # one launch group: 64 batches, ~ 700 tiles on 256 compute units
+            j, b = rep % 3, sizes[rep % len(sizes)]
+            buf = fr.DeviceBuffer(ctx, B * 4)
+            buf.upload(np.full(B, np.nan, np.float32))
+            wk.push_device(b, d_pool[j], None, buf)
+            outs.append((buf, j, b))
+        wk.sync()
+        first = {}
+        for buf, j, b in outs:
+            got = buf.download(np.float32, B)
+            assert np.isnan(got[b:]).all(), (j, b)
+            refh, ref32 = refs[j]
+            assert np.abs(got[:b] - refh[:b]).max() <= 5e-3 * np.abs(refh).max(), (j, b)
+            assert np.abs(got[:b] - ref32[:b]).max() <= 3e-2 * np.abs(ref32).max(), (j, b)
+            if j in first:
+                assert np.array_equal(got[:b], first[j][:b]), (j, b)
+            elif b == 1024:
+                first[j] = got.copy()
+            buf.free()
+        # an out-of-range index in the last batch of a full group (a late tile of some workgroup's walk)
+        bad = pool_idx[0].copy()
+        bad[1023, 7] = m.rows()[7]
+        d_bad = fr.DeviceBuffer.from_numpy(ctx, bad)
+        d_s = [fr.DeviceBuffer(ctx, B * 4) for _ in range(20)]
+        for i in range(19):
+            wk.push_device(B, d_pool[0], None, d_s[i])
+        wk.push_device(B, d_bad, None, d_s[19])
+        with pytest.raises(fr.FleetRecError) as e:
+            wk.sync()
+        assert e.value.status == fr.FR_ERR_INDEX_RANGE
+        assert np.array_equal(d_s[0].download(np.float32, B), first[0])
+        for d in d_s + [d_bad] + d_pool:
+            d.free()
+        wk.close()
+    finally:
+        ctx.set_fc_precision(fr.FC_FP32)
