@@ -1039,7 +1039,13 @@ static int fused_flush(fr_worker *w) {
             c->n_cu = n_cu > 0 ? n_cu : 256;
             c->hk_ok = frk_fused_hk_ok(a.K, a.H1, a.H2, a.H3, c->h_words.data(), c->n_words) ? 1 : 0;
         }
-        if (c->hk_ok == 1 && FR_KNOB_ONCE("FUSED_HK", 1)) return frk_fused_hk_launch(a, c->n_cu, w->stream);
+        // ... and the launch gives every workgroup at least two tiles: the persistent kernel's first tile per workgroup pays the whole
+        // dependent chain index -> row -> LDS (13-14 us, all workgroups at once), which only a second tile amortises.  Smaller launches
+        // (Model-A's 64 batches of 256 = one tile per compute unit, partial groups at fr_worker_sync) keep the chunked kernel.
+        int tiles = 0;
+        for (int i = 0; i < a.n_batches; i++) tiles += (a.b[i].batch + 63) / 64;
+        const int hk = FR_KNOB_ONCE("FUSED_HK", -1);  // experiments build: 0 = never, 1 = whenever it applies
+        if (c->hk_ok == 1 && hk != 0 && (hk == 1 || tiles >= 2 * c->n_cu)) return frk_fused_hk_launch(a, c->n_cu, w->stream);
         return frk_fused_h_launch(a, w->stream);
     }
     return frk_fused_launch(a, w->stream);
@@ -1264,7 +1270,10 @@ extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_i
         w->in_flight = true;
         // a launch is due when the group is full or when the queue already covers the chip (256 CUs x 64 items): large batches
         // need fewer of them per launch
-        return (w->n_pending >= fused_group(c) || w->pending_items >= FR_KNOB_ONCE("FUSED_ITEMS", 256 * 64)) ? fused_flush(w) : FR_OK;
+        // a launch carries at most 16384 items (one 64-item tile per compute unit) -- 65536 through the persistent bf16 kernel, whose
+        // workgroups overlap the gather of their next tile with the FC phases of the current one (4 tiles per workgroup)
+        const int64_t max_items = FR_KNOB_ONCE("FUSED_ITEMS", 0) ? FR_KNOB_ONCE("FUSED_ITEMS", 0) : (c->fc_precision == FR_FC_BF16 ? 1024 * 64 : 256 * 64);
+        return (w->n_pending >= fused_group(c) || w->pending_items >= max_items) ? fused_flush(w) : FR_OK;
     }
     rc = pipeline_push(w, batch, 0, d_idx, d_dense, d_scores);
     if (rc) return rc;

@@ -1,22 +1,27 @@
 #include "fr_device.h"
 
 // ===================================================================================================
-// fr_fused_tile_hk_kernel: the bf16 fused item-tile kernel, K-OUTER and persistent (BASELINE configs[2]: Model-B 1024, "bf16 MFMA FC,
-// fused concat + first FC").  It replaces fr_fused_tile_h_kernel (fr_fused.hip), whose workgroup first gathered its 64 records with
-// the matrix pipes idle (21-23 of 63-68 us per launch) and then walked FC1 in four chunks of 256 outputs, re-reading the whole record
-// image from LDS per chunk.
+// fr_fused_tile_hs_kernel: the bf16 fused item-tile kernel -- K-OUTER, PERSISTENT and WAVE-SPECIALISED (BASELINE configs[2]: Model-B
+// 1024, "bf16 MFMA FC, fused concat + first FC").  It replaces fr_fused_tile_h_kernel (fr_fused.hip), whose workgroup first gathered
+// its 64 records with the matrix pipes idle (21-23 of 63-68 us per launch) and then walked FC1 in four chunks of 256 outputs,
+// re-reading the whole record image from LDS per chunk.
 //
-// Here FC1 runs over K ONCE with all 1024 outputs of the 64 items in accumulators (a wave owns 128 outputs x 64 items = 128
-// registers), so the record is consumed in K order -- which is the order the gather produces it in.  The record image therefore never
-// exists as a whole: a ring of TWO slices of KGS k-groups (14 q8 rows = 14.2 KiB for Model-B) sits in LDS, and while the MFMAs of slice
-// s run, the same waves write slice s + 1 into the other buffer and have the row loads of slices s + 2, s + 3 and the index loads of
-// slice s + 4 in flight in registers.  The gather is spread over the whole tile instead of preceding it, and it keeps running through FC2 /
-// FC3 for the NEXT tile of the workgroup (persistent: a workgroup walks tiles b, b + grid, ...), so a tile starts with its first two
-// slices in LDS and two more on their way.  What the freed LDS pays for: the complete bf16 R1 image (1024 x 64 = 128 KiB) as FC2's B
-// operand, so FC2 is one K-outer pass as well (64 outputs x 64 items per wave) and the chunk loop with its eight barriers is gone.
+// A workgroup is 12 waves: 8 CONSUMERS (MFMA) and 4 PRODUCERS (gather), three per SIMD (two consumers + one producer), 168 registers
+// each.  Why separate waves: a wave's vector-memory operations return IN ORDER (one vmcnt), so a wave that streams weights from L2
+// through a register ring AND has HBM-latency row loads outstanding waits for the rows every time it waits for a weight fragment --
+// the 8-symmetric-wave form of this kernel (round 3, profiles/r03_fused_hk_8wave_stamps.txt) spent 31-36 us in an FC1 whose MFMA
+// work is 11.7 us.  The producers have nothing but the gather in their queue, and their registers ARE the in-flight window: 4 row
+// sets x 8 items x 16 B per thread = 128 KiB of rows on their way per CU, all the time, through every phase of the consumers.
+//
+// Consumers: FC1 runs over K ONCE with all 1024 outputs of the 64 items in accumulators (128 outputs x 64 items = 128 registers per
+// wave), so the record is consumed in K order -- the order the gather produces it in.  The record image never exists as a whole: a
+// ring of TWO slices of KGS k-groups sits in LDS; while the consumers multiply slice s, the producers convert the rows of slice s + 1
+// to bf16 into the other buffer (one s_barrier per slice for all 12 waves).  The freed LDS holds the complete bf16 R1 image
+// (1024 x 64 = 128 KiB), so FC2 is one K-outer pass as well (64 outputs x 64 items per wave): no chunk loop.  The producers keep
+// running through FC2 / FC3 / the output layer for the NEXT tile (persistent: a workgroup walks tiles b, b + grid, ...): a tile
+// starts with its first two slices in LDS and D more in registers.
 //   LDS  [ R1 128 KiB | X ring 2 x 2 KGS rows x 65 x 16 B | packed word descriptors 16 B each ]   (R2 / R3 / scratch overlay R1)
-//   per k-group and wave: FC1 4 weight fragments + 2 B fragments -> 8 MFMAs (the chunked kernel: 1 + 2 -> 2: a quarter of its LDS reads)
-// Weights stream from L2 through ONE register ring across FC1 -> FC2 -> FC3 -> the next tile's FC1 (all slot indices compile-time).
+//   per k-group and consumer: FC1 4 weight fragments + 2 B fragments -> 8 MFMAs (the chunked kernel: 1 + 2 -> 2: a quarter of its LDS reads)
 // Arithmetic per output: fp32 accumulation over k in ascending order, one bf16 rounding per activation -- the same values as the
 // chunked kernel, bit for bit (the order of the sums inside an output is unchanged; only the order of the outputs moved).
 // ===================================================================================================
@@ -63,19 +68,16 @@ __device__ __forceinline__ void hk_store_tile(uint4 *img, const f32x16 &acc, int
     }
 }
 
-// KG = K / 16 k-groups; KGS = k-groups per slice (4 KGS record words <= LW lanes); LW = lanes along the words of a slice (16 or 32);
-// RD = weight ring slots.
-template <int KG, int KGS, int LW, int RD>
-__global__ void __launch_bounds__(512) fr_fused_tile_hk_kernel(const FrFusedArgs a) {
+// KG = K / 16 k-groups; KGS = k-groups per slice (4 KGS record words <= LW lanes); LW = producer lanes along the words of a slice
+// (16 or 32); D = row sets a producer thread keeps in flight (NSL % D == 0: the set of a slice is a compile-time index).
+template <int KG, int KGS, int LW, int D, int R1D>
+__global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs a) {
     extern __shared__ uint4 lds[];
     constexpr int NSL = (KG + KGS - 1) / KGS;          // slices per tile
-    constexpr int IPT = LW / 8;                        // items per thread in the gather (512 threads = LW x 64 / IPT)
+    constexpr int IPT = LW / 4;                        // items per producer thread (256 threads = LW words x 64 / IPT item slots)
     constexpr int XROWS = 2 * KGS;                     // q8 rows of one X ring buffer
-    constexpr int Q1 = 4 * KG, Q2 = Q1 + 128, Q = Q2 + 32;  // weight fragments of a tile: FC1 | FC2 | FC3
-    constexpr int QP = (Q + RD - 1) / RD * RD;         // padded to a multiple of the ring: every tile starts at slot 0
-    static_assert(NSL >= 6 && NSL % 2 == 0, "the gather pipeline runs 4 slices ahead and alternates two buffers: even NSL >= 6");
+    static_assert(NSL % 2 == 0 && NSL % D == 0 && NSL >= D + 3, "two X buffers, D row sets, and the run-ahead stays inside the next tile");
     static_assert(4 * KGS <= LW && (LW == 16 || LW == 32), "a slice's record words ride the lanes of one half / quarter wave");
-    static_assert(RD % 4 == 0 && RD >= 8, "FC1 consumes 4 fragments per k-group");
     uint4 *R1 = lds;                                   // [128][64]
     uint4 *R2 = lds;                                   // [64][64], overlays R1 once FC2 has read it
     uint4 *R3 = lds + 64 * HK_LD;                      // [32][64]
@@ -84,7 +86,7 @@ __global__ void __launch_bounds__(512) fr_fused_tile_hk_kernel(const FrFusedArgs
     uint4 *Dsc = Xr + 2 * XROWS * HK_LDX;              // [n_words] packed descriptors
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hk = lane >> 5, lm = lane & 31;
+    const bool producer = wave >= 8;                   // waves 8..11: one per SIMD beside two consumers (waves are dealt to SIMDs cyclically)
     const int n_tiles = a.n_batches * a.tiles_per_batch;
 
     auto tile_at = [&](int t) {
@@ -104,32 +106,27 @@ __global__ void __launch_bounds__(512) fr_fused_tile_hk_kernel(const FrFusedArgs
     int t_cur = next_tile((int)blockIdx.x - (int)gridDim.x);
     if (t_cur >= n_tiles) return;
 
-    unsigned long long *st = a.stamps ? a.stamps + 16ull * (8ull * blockIdx.x + wave) : nullptr;
-    auto stamp = [&](int k) {  // diagnostic build aid (tools/experiments/fused_hk_stamps.py); values never feed an output
+    // Diagnostic build aid (tools/experiments/fused_hk_stamps.py; a.stamps is NULL in normal operation, values never feed an output): 64
+    // s_memrealtime slots per wave.  0 start, 1 set-up done, 2 / 3 s_memtime around tile 0's FC1; the barriers of the workgroup's first two
+    // tiles: 4 + 28 tile + 2 b = arrival at barrier b, + 1 = release (b = slice s for the step barriers, NSL_MAX + p for the five phase
+    // barriers R1 stored / FC2 done / R2 stored / R3 stored / partial scores); 62 kernel end.
+    unsigned long long *st = a.stamps ? a.stamps + 64ull * (12ull * blockIdx.x + wave) : nullptr;
+    auto stamp = [&](int k) {
         if (st && lane == 0) st[k] = __builtin_amdgcn_s_memrealtime();
     };
     auto cstamp = [&](int k) {
         if (st && lane == 0) st[k] = __builtin_amdgcn_s_memtime();
     };
+    int tile_no = 0;
+    auto bar = [&](int b) {  // the workgroup barrier, stamped on both sides for the first two tiles
+        if (st && tile_no < 2) stamp(4 + 28 * tile_no + 2 * b);
+        __syncthreads();
+        if (st && tile_no < 2) stamp(5 + 28 * tile_no + 2 * b);
+    };
     stamp(0);
 
-    // ---- weights: one ring of RD fragments across FC1 -> FC2 -> FC3 -> next tile ----
-    const FtWk W1 = ftk_w(a.w1q, KG * 2, HK_H1, hk, lm), W2 = ftk_w(a.w2q, HK_H1 / 8, HK_H2, hk, lm), W3 = ftk_w(a.w3q, HK_H2 / 8, HK_H3, hk, lm);
-    // n1 / n2 / n3 and the lane offsets below are re-declared opaque at the top of every tile: everything derived from them is tile-loop
-    // invariant, and hoisted out of the loop the 380 SGPR offsets of the weight stream alone spilled 200 scalars into vector registers
-    unsigned n1 = (unsigned)(128 * wave) * 16u, n2 = (unsigned)(64 * wave) * 16u, n3 = (unsigned)(32 * wave) * 16u;
-    auto wfrag = [&](int q) -> uint4 {  // fragment q of the tile's weight stream (q compile-time after unrolling)
-        if (q < Q1) return ftk_load(W1, (unsigned)(q >> 2) * W1.row2 + n1, 512 * (q & 3));                  // FC1: k-group q / 4, n tile q % 4
-        if (q < Q2) return ftk_load(W2, (unsigned)((q - Q1) >> 1) * W2.row2 + n2, 512 * ((q - Q1) & 1));    // FC2: k-group, n tile
-        if (q < Q) return ftk_load(W3, (unsigned)(q - Q2) * W3.row2 + n3, 0);                               // FC3: k-group
-        return ftk_load(W3, n3, 0);                                                                         // pad: never consumed
-    };
-    uint4 ring[RD];
-#pragma unroll
-    for (int i = 0; i < RD; i++) ring[i] = wfrag(i);
-
-    // ---- packed word descriptors -> LDS (read just in time by the gather: no registers, no vector-memory queue slots) ----
-    for (int w = tid; w < a.n_words; w += 512) {
+    // ---- packed word descriptors -> LDS (read just in time by the producers: no registers, no vector-memory queue slots) ----
+    for (int w = tid; w < a.n_words; w += 768) {
         const uint4 d0 = reinterpret_cast<const uint4 *>(a.words)[2 * w];
         const uint4 d1 = reinterpret_cast<const uint4 *>(a.words)[2 * w + 1];
         // {src[31:0], src[47:32] | stride << 16, rows, idx byte offset | DENSE}
@@ -137,90 +134,150 @@ __global__ void __launch_bounds__(512) fr_fused_tile_hk_kernel(const FrFusedArgs
     }
     __syncthreads();
 
-    // ---- gather pipeline state ----
-    int wl = tid & (LW - 1);                    // word of the slice this thread moves            } re-derived per tile from the opaque
-    int it0 = (tid / LW) * IPT;                 // first of its IPT items inside the tile         } thread id (see the tile loop)
-    uint32_t idxr[IPT];                         // index values of the slice whose rows are loaded next
-    uint4 rows[2][IPT];                         // row words in flight: two slices
-    unsigned bad = 0u;                         // out-of-range index seen (a lane flag, OR-ed: no compare mask is kept)
-    uint2 *Xh2 = reinterpret_cast<uint2 *>(Xr);
-    auto slice_word = [&](int s) {  // this thread's record word in slice s; lanes past the slice repeat its last word (same row as their
-        const int nw = 4 * (KG - KGS * s < KGS ? KG - KGS * s : KGS);  // neighbour: no extra line is fetched) and never store it
-        return 4 * KGS * s + (wl < nw ? wl : nw - 1);
-    };
-    auto I_op = [&](const HkTile &t, int s) {  // index loads of slice s
-        const uint4 d = Dsc[slice_word(s)];
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(t.idx), 0, (unsigned)t.batch * (unsigned)a.idx_stride * 4u, 0x00020000);
+    if (producer) {
+        // =========================================== PRODUCERS: the gather ===========================================
+        int wl = 0, it0 = 0;                        // word of the slice this thread moves; first of its IPT items inside the tile
+        uint32_t idxr[IPT];                         // index values of the slice whose rows are loaded next
+        uint4 rows[D][IPT];                         // row words in flight: D slices
+        unsigned bad = 0u;                          // out-of-range index seen (a lane flag, OR-ed: no compare mask is kept)
+        uint2 *Xh2 = reinterpret_cast<uint2 *>(Xr);
+        auto slice_word = [&](int s) {  // this thread's record word in slice s; lanes past the slice repeat its last word (same row as their
+            const int nw = 4 * (KG - KGS * s < KGS ? KG - KGS * s : KGS);  // neighbour: no extra line is fetched) and never store it
+            return 4 * KGS * s + (wl < nw ? wl : nw - 1);
+        };
+        auto I_op = [&](const HkTile &t, int s) {  // index loads of slice s
+            const uint4 d = Dsc[slice_word(s)];
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(t.idx), 0, (unsigned)t.batch * (unsigned)a.idx_stride * 4u, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < IPT; i++)   // items past the batch: out of the resource's bounds, 0 comes back (no branch)
-            idxr[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)(t.m0 + it0 + i) * (unsigned)a.idx_stride * 4u + (d.w & 0x7FFFFFFFu), 0, 0);
-    };
-    auto R_op = [&](const HkTile &t, int s, uint4 (&r)[IPT]) {  // row loads of slice s (its indices are in idxr)
-        const uint4 d = Dsc[slice_word(s)];
-        const bool dense = (d.w >> 31) != 0;
-        const uint64_t base = (((uint64_t)(d.y & 0xFFFFu) << 32) | d.x) + (dense ? (uint64_t)reinterpret_cast<uintptr_t>(t.dense) : 0ull);
-        const uint32_t stride = d.y >> 16, nrows = d.z;
-#pragma unroll
-        for (int i = 0; i < IPT; i++) {
-            const unsigned m = (unsigned)(t.m0 + it0 + i);
-            uint32_t x = idxr[i];
-            const bool oob = !dense & (x >= nrows);  // reference: silent out-of-bounds read (embedding_47_krnl.cpp:927-933); here reported
-            bad |= oob ? 1u : 0u;
-            x = oob ? 0u : x;
-            x = dense ? (m < (unsigned)t.batch ? m : 0u) : x;
-            typedef const u32x4_t __attribute__((address_space(1))) * gptr_t;
-            const u32x4_t q = *(gptr_t)(base + (uint64_t)x * stride);
-            r[i] = make_uint4(q.x, q.y, q.z, q.w);
-        }
-    };
-    auto W_op = [&](const HkTile &t, int s, const uint4 (&r)[IPT]) {  // slice s: fp32 rows -> bf16 -> X ring buffer s % 2
-        const int nw = 4 * (KG - KGS * s < KGS ? KG - KGS * s : KGS);  // words of this slice
-        if (wl < nw) {
-            uint2 *xb = Xh2 + (size_t)(s & 1) * (XROWS * HK_LDX * 2);
+            for (int i = 0; i < IPT; i++)   // items past the batch: out of the resource's bounds, 0 comes back (no branch)
+                idxr[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)(t.m0 + it0 + i) * (unsigned)a.idx_stride * 4u + (d.w & 0x7FFFFFFFu), 0, 0);
+        };
+        auto R_op = [&](const HkTile &t, int s, uint4 (&r)[IPT]) {  // row loads of slice s (its indices are in idxr)
+            const uint4 d = Dsc[slice_word(s)];
+            const bool dense = (d.w >> 31) != 0;
+            const uint64_t base = (((uint64_t)(d.y & 0xFFFFu) << 32) | d.x) + (dense ? (uint64_t)reinterpret_cast<uintptr_t>(t.dense) : 0ull);
+            const uint32_t stride = d.y >> 16, nrows = d.z;
 #pragma unroll
             for (int i = 0; i < IPT; i++) {
-                const uint32_t in = 0u - (uint32_t)(t.m0 + it0 + i < t.batch);  // all ones / zero: items past the batch are zero rows, branch-free
-                uint2 hv;
-                hv.x = pack_bf16x2(__uint_as_float(r[i].x), __uint_as_float(r[i].y)) & in;
-                hv.y = pack_bf16x2(__uint_as_float(r[i].z), __uint_as_float(r[i].w)) & in;
-                xb[((size_t)(wl >> 1) * HK_LDX + it0 + i) * 2 + (wl & 1)] = hv;  // slice word wl = half (wl & 1) of q8 row wl / 2
+                const unsigned m = (unsigned)(t.m0 + it0 + i);
+                uint32_t x = idxr[i];
+                const bool oob = !dense & (x >= nrows);  // reference: silent out-of-bounds read (embedding_47_krnl.cpp:927-933); here reported
+                bad |= oob ? 1u : 0u;
+                x = oob ? 0u : x;
+                x = dense ? (m < (unsigned)t.batch ? m : 0u) : x;
+                typedef const u32x4_t __attribute__((address_space(1))) * gptr_t;
+                const u32x4_t q = *(gptr_t)(base + (uint64_t)x * stride);
+                r[i] = make_uint4(q.x, q.y, q.z, q.w);
             }
+        };
+        auto W_op = [&](const HkTile &t, int s, const uint4 (&r)[IPT]) {  // slice s: fp32 rows -> bf16 -> X ring buffer s % 2
+            const int nw = 4 * (KG - KGS * s < KGS ? KG - KGS * s : KGS);  // words of this slice
+            if (wl < nw) {
+                uint2 *xb = Xh2 + (size_t)(s & 1) * (XROWS * HK_LDX * 2);
+#pragma unroll
+                for (int i = 0; i < IPT; i++) {
+                    const uint32_t in = 0u - (uint32_t)(t.m0 + it0 + i < t.batch);  // all ones / zero: items past the batch are zero rows, branch-free
+                    uint2 hv;
+                    hv.x = pack_bf16x2(__uint_as_float(r[i].x), __uint_as_float(r[i].y)) & in;
+                    hv.y = pack_bf16x2(__uint_as_float(r[i].z), __uint_as_float(r[i].w)) & in;
+                    xb[((size_t)(wl >> 1) * HK_LDX + it0 + i) * 2 + (wl & 1)] = hv;  // slice word wl = half (wl & 1) of q8 row wl / 2
+                }
+            }
+        };
+        HkTile cur = tile_at(t_cur);
+        {   // prologue: the first tile's slices 0, 1 into LDS, 2 .. D + 1 requested, the indices of D + 2 requested (every tile starts so).
+            // Two dependent latencies, not D + 2: every index load of slices 0 .. D + 1 first (their registers are free: no rows yet), then
+            // the row loads of 0 .. D - 1, and slices D, D + 1 as sets 0, 1 come free.
+            wl = tid & (LW - 1), it0 = ((tid - 512) / LW) * IPT;
+            uint32_t idx0[D + 2][IPT];
+#pragma unroll
+            for (int j = 0; j < D + 2; j++) {
+                I_op(cur, j);
+#pragma unroll
+                for (int i = 0; i < IPT; i++) idx0[j][i] = idxr[i];
+            }
+            auto R_from = [&](int j, uint4 (&r)[IPT]) {
+#pragma unroll
+                for (int i = 0; i < IPT; i++) idxr[i] = idx0[j][i];
+                R_op(cur, j, r);
+            };
+#pragma unroll
+            for (int j = 0; j < D; j++) R_from(j, rows[j]);
+            W_op(cur, 0, rows[0]);
+            R_from(D, rows[0]);
+            W_op(cur, 1, rows[1]);
+            R_from(D + 1, rows[1]);
+            I_op(cur, D + 2);
         }
+        while (true) {
+            const int t_nxt = next_tile(t_cur);
+            const bool has_next = t_nxt < n_tiles;
+            HkTile nxt = cur;
+            if (has_next) nxt = tile_at(t_nxt);
+            else nxt.batch = 0;  // no next tile: the run-ahead gather reads row 0 of every table (index loads out of bounds return 0) into buffers nobody consumes
+            int tid_o = tid;     // lane geometry re-derived per tile from an opaque copy of the thread id: nothing of it is hoisted and kept live
+            asm volatile("" : "+v"(tid_o));
+            wl = tid_o & (LW - 1), it0 = (((tid_o - 512) & 255) / LW) * IPT;
+            auto tref = [&](int s) -> const HkTile & { return s >= NSL ? nxt : cur; };
+#pragma unroll
+            for (int s = 0; s < NSL; s++) {
+                bar(s);           // consumers start slice s; X[(s + 1) % 2] is free
+                if (s >= 1) {     // write slice s + 1, request the rows of s + 1 + D and the indices of s + 2 + D (slices >= NSL: the next tile's)
+                    W_op(tref(s + 1), (s + 1) % NSL, rows[(s + 1) % D]);
+                    R_op(tref(s + 1 + D), (s + 1 + D) % NSL, rows[(s + 1) % D]);
+                    I_op(tref(s + 2 + D), (s + 2 + D) % NSL);
+                }
+            }
+            bar(8);               // R1 stored, every consumer is past the last slice: X[1] is free
+            W_op(nxt, 1, rows[1 % D]);
+            R_op(nxt, 1 + D, rows[1 % D]);
+            I_op(nxt, 2 + D);
+            bar(9);               // FC2 done
+            bar(10);              // R2 stored
+            bar(11);              // R3 stored
+            bar(12);              // partial scores
+            tile_no++;
+            if (!has_next) break;
+            cur = nxt;
+            t_cur = t_nxt;
+        }
+        stamp(62);
+        if (bad) atomicOr_system(a.err_flag, 1);
+        return;
+    }
+
+    // =============================================== CONSUMERS: the FC chain ===============================================
+    // n1 / n2 / n3 and the lane offsets are re-declared opaque at the top of every tile: everything derived from them is tile-loop
+    // invariant, and hoisted out of the loop the SGPR offsets of the weight stream alone spilled 200 scalars into vector registers
+    unsigned n1 = (unsigned)(128 * wave) * 16u, n2 = (unsigned)(64 * wave) * 16u, n3 = (unsigned)(32 * wave) * 16u;
+    FtWk W1 = ftk_w(a.w1q, KG * 2, HK_H1, lane >> 5, lane & 31), W2 = ftk_w(a.w2q, HK_H1 / 8, HK_H2, lane >> 5, lane & 31), W3 = ftk_w(a.w3q, HK_H2 / 8, HK_H3, lane >> 5, lane & 31);
+    // The SGPR offset of a fragment is kept as a RUNNING value (one s_add per k-group) that is re-declared opaque once per slice / per
+    // 8 k-groups: written as g * row2 + n1, hipcc computes dozens of them ahead of their loads and spills scalars into vector registers.
+    unsigned so1 = 0, so2 = 0;   // byte offset of FC1's NEXT k-group; of the k-group FC2's current block of refills counts from
+    auto w2load = [&](int dq) { return ftk_load(W2, so2 + (unsigned)(dq >> 1) * W2.row2, 512 * (dq & 1)); };  // FC2: fragment dq past so2's k-group
+    auto w3load = [&](int g) { return ftk_load(W3, (unsigned)g * W3.row2 + n3, 0); };                        // FC3: k-group g
+    uint4 ring1[R1D]; // FC1: the weight fragments of R1D / 4 k-groups (fragment 4 g + t in slot (4 g + t) % R1D), each refilled right after its second MFMA
+    static_assert(R1D == 4 || R1D == 6 || R1D == 8, "one, one and a half or two k-groups of FC1 weights in registers");
+    constexpr int RB = 16;  // FC2 / FC3: 16 fragments (their accumulators are 64 / 32 registers: room for a deep ring)
+    uint4 ringb[RB];
+    auto w1frag = [&](int q) {  // fragment q = 4 g + t of FC1, addressed from n1 (prologues only; the loop uses the running so1)
+        return ftk_load(W1, n1 + (unsigned)(q >> 2) * W1.row2, 512 * (q & 3));
     };
-
+    auto ring1_fill = [&]() {  // fragments 0 .. R1D - 1
+#pragma unroll
+        for (int i = 0; i < R1D; i++) ring1[i] = w1frag(i);
+    };
+    ring1_fill();
     HkTile cur = tile_at(t_cur);
-    // prologue: the first tile's slices 0, 1 into LDS, 2 and 3 requested, the indices of 4 requested (the state every tile starts in)
-    I_op(cur, 0);
-    R_op(cur, 0, rows[0]);
-    I_op(cur, 1);
-    R_op(cur, 1, rows[1]);
-    W_op(cur, 0, rows[0]);
-    I_op(cur, 2);
-    R_op(cur, 2, rows[0]);
-    W_op(cur, 1, rows[1]);
-    I_op(cur, 3);
-    R_op(cur, 3, rows[1]);
-    I_op(cur, 4);
     stamp(1);
-    cstamp(14);
-
-    bool first = true;
     while (true) {
         const int t_nxt = next_tile(t_cur);
         const bool has_next = t_nxt < n_tiles;
-        HkTile nxt = cur;
-        if (has_next) nxt = tile_at(t_nxt);
-        else nxt.batch = 0;  // no next tile: the run-ahead gather reads row 0 of every table (index loads out of bounds return 0) into buffers nobody consumes
         asm volatile("" : "+s"(n1), "+s"(n2), "+s"(n3));
-        // lane geometry, re-derived per tile from an opaque copy of the thread id: hoisted out of the tile loop (they are all loop
-        // invariant) the lane-constant LDS addresses of every phase were live through FC1 and spilled
         int tid_o = tid;
         asm volatile("" : "+v"(tid_o));
         const int hk = (tid_o >> 5) & 1, lm = tid_o & 31;
-        wl = tid_o & (LW - 1), it0 = ((tid_o & 511) / LW) * IPT;
         const unsigned xlane = (unsigned)(128 * HK_LD + hk * HK_LDX + lm), rlane = (unsigned)(hk * HK_LD + lm);  // B-fragment lane bases (16-byte units): X ring, R1 / R2
-        // gather slot of step s (s >= 1): write slice s + 1, request the rows of s + 3 and the indices of s + 4; slices >= NSL are the next tile's
-        auto tref = [&](int s) -> const HkTile & { return s >= NSL ? nxt : cur; };
 
         // ---- FC1, K-outer: 128 outputs x 64 items per wave ----
         f32x16 acc1[4][2];
@@ -233,39 +290,55 @@ __global__ void __launch_bounds__(512) fr_fused_tile_hk_kernel(const FrFusedArgs
 #pragma unroll
         for (int s = 0; s < NSL; s++) {
             const int kgs = KG - KGS * s < KGS ? KG - KGS * s : KGS;
-            __syncthreads();  // slice s is complete in X[s % 2]; everybody is done reading slice s - 1
+            bar(s);           // slice s is complete in X[s % 2]; everybody is done reading slice s - 1
+            if (s == 0 && tile_no == 0) cstamp(2);
+            if (s == 0) so1 = n1;  // k-group 0; advanced once per k-group: inside k-group g it points at g + 1
+            asm volatile("" : "+s"(so1));
             const uint4 *xb = lds + xlane + (s & 1) * (XROWS * HK_LDX);
             uint4 b0 = xb[0], b1 = xb[32];
 #pragma unroll
             for (int gl = 0; gl < kgs; gl++) {
                 const int g = KGS * s + gl;
-                const int gn = gl + 1 < kgs ? gl + 1 : gl;
-                const uint4 bn0 = xb[(size_t)(2 * gn) * HK_LDX], bn1 = xb[(size_t)(2 * gn) * HK_LDX + 32];
-                if (s >= 1 && gl == 0) W_op(tref(s + 1), (s + 1) % NSL, rows[(s + 1) & 1]);  // requested two steps ago; frees the register set for ...
-                if (s >= 1 && gl == 1) {  // ... the loads of the run-ahead gather, issued together (one exposure of their latency to the ring's waits)
-                    R_op(tref(s + 3), (s + 3) % NSL, rows[(s + 3) & 1]);
-                    I_op(tref(s + 4), (s + 4) % NSL);
-                }
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const int p = 4 * g + t;
-                    acc1[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[p % RD]), __builtin_bit_cast(bf16x8, b0), acc1[t][0], 0, 0, 0);
-                    acc1[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[p % RD]), __builtin_bit_cast(bf16x8, b1), acc1[t][1], 0, 0, 0);
-                    ring[p % RD] = wfrag((p + RD) % QP);
-                }
+                // Issue order inside a k-group (pinned by the sched_barriers): every fragment register is refilled for the next k-group right
+                // after its second MFMA and every B register right after its fourth, so each load has 5-6 MFMAs (plus the partner wave's)
+                // to land and no second register set is needed -- the consumers have 168 registers, 128 of them accumulators.
+                auto mm = [&](int t, int mt, const uint4 &b) {
+                    acc1[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring1[(4 * g + t) % R1D]), __builtin_bit_cast(bf16x8, b), acc1[t][mt], 0, 0, 0);
+                };
+                // the slot of fragment q = 4 g + t takes fragment q + R1D: k-group g + (t + R1D) / 4 (so1 + ((t + R1D) / 4 - 1) row2), n tile (t + R1D) % 4
+                auto refill = [&](int t) {
+                    const int q2 = 4 * g + t + R1D;
+                    if (q2 < 4 * KG) ring1[(4 * g + t) % R1D] = ftk_load(W1, so1 + (unsigned)((t + R1D) / 4 - 1) * W1.row2, 512 * (q2 & 3));
+                };
+                const bool more_b = gl + 1 < kgs;
+                mm(0, 0, b0), mm(1, 0, b0), mm(0, 1, b1);
+                so1 += W1.row2;
+                refill(0);
                 __builtin_amdgcn_sched_barrier(0);
-                b0 = bn0, b1 = bn1;
+                mm(1, 1, b1);
+                refill(1);
+                mm(2, 0, b0), mm(3, 0, b0);
+                if (more_b) b0 = xb[(size_t)(2 * (gl + 1)) * HK_LDX];
+                __builtin_amdgcn_sched_barrier(0);
+                mm(2, 1, b1);
+                refill(2);
+                mm(3, 1, b1);
+                refill(3);
+                if (more_b) b1 = xb[(size_t)(2 * (gl + 1)) * HK_LDX + 32];
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (first) stamp(2), cstamp(15);
+        if (tile_no == 0) cstamp(3);
 
         // ---- R1 -> LDS (bf16), FC2 K-outer over it: 64 outputs x 64 items per wave ----
+        so2 = n2;
+#pragma unroll
+        for (int i = 0; i < RB; i++) ringb[i] = w2load(i);  // FC2's first fragments: requested before the R1 store and the barrier
 #pragma unroll
         for (int t = 0; t < 4; t++)
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) hk_store_tile(R1, acc1[t][mt], 128 * wave + 32 * t, 32 * mt, hk, lm);
-        __syncthreads();  // R1 complete; the X ring is free (every wave is past the last slice)
-        if (first) stamp(3);
+        bar(8);           // R1 complete; the X ring is free (every consumer is past the last slice)
         f32x16 acc2[2][2];
 #pragma unroll
         for (int t = 0; t < 2; t++)
@@ -280,29 +353,27 @@ __global__ void __launch_bounds__(512) fr_fused_tile_hk_kernel(const FrFusedArgs
             for (int j = 0; j < 64; j++) {
                 const int jn = j + 1 < 64 ? j + 1 : j;
                 const uint4 bn0 = bl[(size_t)(2 * jn) * HK_LD], bn1 = bl[(size_t)(2 * jn) * HK_LD + 32];
-                if (j == 2) {  // the next tile's gather: slice 1 to LDS (buffer 1 is free now), rows of 3, indices of 4
-                    R_op(nxt, 3, rows[1]);
-                    I_op(nxt, 4);
+                if (j % 8 == 0) {  // so2 = k-group j + RB / 2: the refills of this block of 8 k-groups are fragments 0 .. 15 past it
+                    so2 = n2 + (unsigned)(j + RB / 2) * W2.row2;
+                    asm volatile("" : "+s"(so2));
                 }
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
-                    const int p = Q1 + 2 * j + t;
-                    acc2[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[p % RD]), __builtin_bit_cast(bf16x8, b0), acc2[t][0], 0, 0, 0);
-                    acc2[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[p % RD]), __builtin_bit_cast(bf16x8, b1), acc2[t][1], 0, 0, 0);
-                    ring[p % RD] = wfrag((p + RD) % QP);
+                    const int q = 2 * j + t;
+                    acc2[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ringb[q % RB]), __builtin_bit_cast(bf16x8, b0), acc2[t][0], 0, 0, 0);
+                    acc2[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ringb[q % RB]), __builtin_bit_cast(bf16x8, b1), acc2[t][1], 0, 0, 0);
+                    ringb[q % RB] = q + RB < 128 ? w2load(q - 16 * (j / 8)) : w3load(q + RB - 128);  // fragment q + RB = (q - 16 (j / 8)) past so2; FC2's tail: the first RB k-groups of W3
                 }
-                if (j == 1) W_op(nxt, 1, rows[1]);
                 __builtin_amdgcn_sched_barrier(0);
                 b0 = bn0, b1 = bn1;
             }
         }
-        __syncthreads();  // every wave is done reading R1: R2 may overlay it
-        if (first) stamp(4);
+        bar(9);           // every wave is done reading R1: R2 may overlay it
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) hk_store_tile(R2, acc2[t][mt], 64 * wave + 32 * t, 32 * mt, hk, lm);
-        __syncthreads();
+        bar(10);
 
         // ---- FC3: 32 outputs x 64 items per wave ----
         f32x16 acc3[2];
@@ -317,36 +388,33 @@ __global__ void __launch_bounds__(512) fr_fused_tile_hk_kernel(const FrFusedArgs
             for (int j = 0; j < 32; j++) {
                 const int jn = j + 1 < 32 ? j + 1 : j;
                 const uint4 bn0 = bl[(size_t)(2 * jn) * HK_LD], bn1 = bl[(size_t)(2 * jn) * HK_LD + 32];
-                const int p = Q2 + j;
-                acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[p % RD]), __builtin_bit_cast(bf16x8, b0), acc3[0], 0, 0, 0);
-                acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[p % RD]), __builtin_bit_cast(bf16x8, b1), acc3[1], 0, 0, 0);
-                ring[p % RD] = wfrag((p + RD) % QP);
+                acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ringb[j % RB]), __builtin_bit_cast(bf16x8, b0), acc3[0], 0, 0, 0);
+                acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ringb[j % RB]), __builtin_bit_cast(bf16x8, b1), acc3[1], 0, 0, 0);
+                if (j + RB < 32) ringb[j % RB] = w3load(j + RB);
                 __builtin_amdgcn_sched_barrier(0);
                 b0 = bn0, b1 = bn1;
             }
-#pragma unroll
-            for (int p = Q; p < QP; p++) ring[p % RD] = wfrag((p + RD) % QP);  // the pad positions pass their slots on to the next tile's FC1
         }
+        ring1_fill();  // the next tile's first k-group(s) of FC1: requested before the R3 store and the barriers
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) hk_store_tile(R3, acc3[mt], 32 * wave, 32 * mt, hk, lm);
-        __syncthreads();
-        if (first) stamp(5);
+        bar(11);
         {   // score[m] = sum_n wout[n] * R3[n][m] (bf16 x bf16, fp32 sum): 64 items x 8 slices of 4 q8 rows, fixed-order reduction
-            const int il = tid & 63, sl = tid >> 6;
+            const int il = tid_o & 63, sl = (tid_o >> 6) & 7;
             const uint4 *wh = reinterpret_cast<const uint4 *>(a.wout);  // bf16 vector w[k], 8 per element
-            float s = 0.0f;
+            float sc = 0.0f;
             for (int q = 4 * sl; q < 4 * sl + 4; q++) {
                 const uint4 r = R3[(size_t)q * HK_LD + il];
                 const uint4 w = wh[q];
                 const uint32_t rr[4] = {r.x, r.y, r.z, r.w}, ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    s = fmaf(__uint_as_float(ww[e] << 16), __uint_as_float(rr[e] << 16), s);
-                    s = fmaf(__uint_as_float(ww[e] & 0xFFFF0000u), __uint_as_float(rr[e] & 0xFFFF0000u), s);
+                    sc = fmaf(__uint_as_float(ww[e] << 16), __uint_as_float(rr[e] << 16), sc);
+                    sc = fmaf(__uint_as_float(ww[e] & 0xFFFF0000u), __uint_as_float(rr[e] & 0xFFFF0000u), sc);
                 }
             }
-            part[sl * 64 + il] = s;
-            __syncthreads();
+            part[sl * 64 + il] = sc;
+            bar(12);
             if (tid < 64 && cur.m0 + tid < cur.batch) {
                 float t = part[tid];
 #pragma unroll
@@ -354,14 +422,12 @@ __global__ void __launch_bounds__(512) fr_fused_tile_hk_kernel(const FrFusedArgs
                 cur.scores[cur.m0 + tid] = t;
             }
         }
-        if (first) stamp(6);
-        first = false;
+        tile_no++;
         if (!has_next) break;
-        cur = nxt;
+        cur = tile_at(t_nxt);
         t_cur = t_nxt;
     }
-    stamp(7);
-    if (bad) atomicOr_system(a.err_flag, 1);
+    stamp(62);
 }
 
 }  // namespace
@@ -374,20 +440,23 @@ bool frk_fused_hk_ok(int K, int H1, int H2, int H3, const FrWordDesc *h_words, i
     return true;
 }
 
-template <int KG, int KGS, int LW, int RD>
+template <int KG, int KGS, int LW, int D, int R1D>
 static int fused_hk_launch_inst(const FrFusedArgs &a, int n_cu, hipStream_t s) {
     static FrLdsAttrOnce lds_once;  // per instantiation, per device
-    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_hk_kernel<KG, KGS, LW, RD>, lds_once)) return rc_;
+    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_hs_kernel<KG, KGS, LW, D, R1D>, lds_once)) return rc_;
     const size_t lds = ((size_t)128 * HK_LD + (size_t)2 * 2 * KGS * HK_LDX + (size_t)a.n_words) * 16;
     const int tiles = a.n_batches * a.tiles_per_batch;
-    fr_fused_tile_hk_kernel<KG, KGS, LW, RD><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(512), lds, s>>>(a);
+    fr_fused_tile_hs_kernel<KG, KGS, LW, D, R1D><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(768), lds, s>>>(a);
     KCHECK();
     return FR_OK;
 }
 
 // a.w1q/w2q/w3q/wout point at the bf16 q8 weights; a.tiles_per_batch counts 64-item tiles; one persistent workgroup per CU
 int frk_fused_hk_launch(const FrFusedArgs &a, int n_cu, hipStream_t s) {
-    if (a.K == 880) return fused_hk_launch_inst<55, 4, 16, 8>(a, n_cu, s);   // Model-B: 14 slices of 4 (3) k-groups
-    if (a.K == 352) return fused_hk_launch_inst<22, 4, 16, 8>(a, n_cu, s);   // Model-A: 6 slices of 4 (2) k-groups
+#ifdef FR_EXPERIMENTS
+    if (a.K == 880 && FR_KNOB_ONCE("FUSED_R1D", 6) == 4) return fused_hk_launch_inst<55, 7, 32, 2, 4>(a, n_cu, s);
+#endif
+    if (a.K == 880) return fused_hk_launch_inst<55, 7, 32, 2, 6>(a, n_cu, s);   // Model-B: 8 slices of 7 (6) k-groups, 2 row sets in flight, 6 FC1 fragments
+    if (a.K == 352) return fused_hk_launch_inst<22, 4, 16, 3, 4>(a, n_cu, s);   // Model-A: 6 slices of 4 (2) k-groups, 3 row sets in flight, 4 FC1 fragments
     FR_FAIL(FR_ERR_INVALID, "no K-outer bf16 fused instantiation for K=%d", a.K);
 }

@@ -1837,14 +1837,17 @@ def test_random_custom_models(fr, O, gpu, seed):
 
 
 @pytest.mark.gpu
-def test_bf16_persistent_fused_kernel_many_tiles(fr, O, ctxs):
-    """fr_fused_tile_hk_kernel (fr_fused_ko.hip), BASELINE configs[2]'s kernel: more 64-item tiles than compute units in one launch, so
-    that every persistent workgroup walks several tiles with the next tile's gather running under the current tile's FC phases;
-    batches of unequal size in one launch (tiles past a batch's end are skipped), ragged tails, a one-item batch.  Every batch's scores
-    against the host restatement of the bf16 arithmetic (5e-3) and against the fp64-accumulating oracle (3e-2), equal rows give equal
-    bits wherever they sit in the launch, and an out-of-range index in the LAST tile of a workgroup's walk is reported."""
-    m, ctx = ctxs(fr.MODEL_B)
-    om = O.OracleModel("B")
+@pytest.mark.parametrize("which", [1, 0])
+def test_bf16_persistent_fused_kernel_many_tiles(fr, O, ctxs, which):
+    """fr_fused_tile_hs_kernel (fr_fused_ko.hip), BASELINE configs[2]'s kernel: 8 MFMA waves + 4 gather waves per workgroup, one persistent
+    workgroup per compute unit.  A launch with more than two 64-item tiles per compute unit (what selects it), so that every workgroup
+    walks several tiles with the next tile's gather running under the current tile's FC phases; batches of unequal size in one launch
+    (tiles past a batch's end are skipped), ragged tails, a one-item batch.  Every batch's scores against the host restatement of the
+    bf16 arithmetic (5e-3) and against the fp64-accumulating oracle (3e-2); equal rows give equal bits wherever they sit in the launch
+    AND whichever kernel ran (a small launch takes the chunked fr_fused_tile_h_kernel: same sums in the same order); an out-of-range
+    index in the last batch of a launch is reported.  Model-B (K = 880, 8 slices) and Model-A at batch 1024 (K = 352, 6 slices)."""
+    m, ctx = ctxs(which)
+    om = O.OracleModel(NAMES[which])
     rng = np.random.default_rng(77)
     B = 1024
     pool_idx = [uniform_idx(rng, m.rows(), B) for _ in range(3)]
@@ -1857,6 +1860,12 @@ def test_bf16_persistent_fused_kernel_many_tiles(fr, O, ctxs):
     try:
         wk = fr.Worker(ctx, B)
         d_pool = [fr.DeviceBuffer.from_numpy(ctx, i_) for i_ in pool_idx]
+        # a small launch first: 3 batches = 48 tiles -> the chunked kernel
+        small = [fr.DeviceBuffer(ctx, B * 4) for _ in range(3)]
+        for j in range(3):
+            wk.push_device(B, d_pool[j], None, small[j])
+        wk.sync()
+        chunked = [b_.download(np.float32, B) for b_ in small]
         sizes = [1024, 1024, 1000, 64, 1, 130, 1024, 577]
         outs = []
         for rep in range(64):                  # one launch group: 64 batches, ~ 700 tiles on 256 compute units
@@ -1866,31 +1875,27 @@ def test_bf16_persistent_fused_kernel_many_tiles(fr, O, ctxs):
             wk.push_device(b, d_pool[j], None, buf)
             outs.append((buf, j, b))
         wk.sync()
-        first = {}
         for buf, j, b in outs:
             got = buf.download(np.float32, B)
             assert np.isnan(got[b:]).all(), (j, b)
             refh, ref32 = refs[j]
             assert np.abs(got[:b] - refh[:b]).max() <= 5e-3 * np.abs(refh).max(), (j, b)
             assert np.abs(got[:b] - ref32[:b]).max() <= 3e-2 * np.abs(ref32).max(), (j, b)
-            if j in first:
-                assert np.array_equal(got[:b], first[j][:b]), (j, b)
-            elif b == 1024:
-                first[j] = got.copy()
+            assert np.array_equal(got[:b], chunked[j][:b]), (j, b)     # the persistent kernel == the chunked kernel, bit for bit
             buf.free()
         # an out-of-range index in the last batch of a full group (a late tile of some workgroup's walk)
         bad = pool_idx[0].copy()
         bad[1023, 7] = m.rows()[7]
         d_bad = fr.DeviceBuffer.from_numpy(ctx, bad)
-        d_s = [fr.DeviceBuffer(ctx, B * 4) for _ in range(20)]
-        for i in range(19):
+        d_s = [fr.DeviceBuffer(ctx, B * 4) for _ in range(40)]
+        for i in range(39):
             wk.push_device(B, d_pool[0], None, d_s[i])
-        wk.push_device(B, d_bad, None, d_s[19])
+        wk.push_device(B, d_bad, None, d_s[39])
         with pytest.raises(fr.FleetRecError) as e:
             wk.sync()
         assert e.value.status == fr.FR_ERR_INDEX_RANGE
-        assert np.array_equal(d_s[0].download(np.float32, B), first[0])
-        for d in d_s + [d_bad] + d_pool:
+        assert np.array_equal(d_s[0].download(np.float32, B), chunked[0])
+        for d in d_s + [d_bad] + d_pool + small:
             d.free()
         wk.close()
     finally:

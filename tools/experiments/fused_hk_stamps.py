@@ -1,6 +1,7 @@
-"""Phase timing inside fr_fused_tile_hk_kernel (the K-outer persistent bf16 fused kernel; Model-B batch 1024 by default): diagnostic
-stamps of every wave's lane 0 (s_memrealtime at 100 MHz) of the FIRST tile of every workgroup, and the kernel end.
-usage: fused_hk_stamps.py [batches per launch = 16] [model B|A]"""
+"""Barrier-by-barrier timing inside fr_fused_tile_hs_kernel (the K-outer, persistent, wave-specialised bf16 fused kernel): every wave's
+lane 0 stamps s_memrealtime (100 MHz) when it ARRIVES at each workgroup barrier of the workgroup's first two tiles and when the barrier
+RELEASES it.  Who arrives last says who the step waited for: the consumers (MFMA waves 0-7) or the producers (gather waves 8-11).
+usage: fused_hk_stamps.py [batches per launch = 16] [model B|A]     (more than 16384 items per launch need FR_LIB=libfleetrec_exp.so FR_FUSED_ITEMS=...)"""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -11,6 +12,7 @@ m = fr.Model.builtin(fr.MODEL_B if which == "B" else fr.MODEL_A)
 ctx = fr.Context(m, 0); ctx.fill_tables(fr.FILL_HASH, 1); ctx.fill_weights(fr.WEIGHTS_UNIFORM, 2)
 ctx.set_fc_precision(fr.FC_BF16)
 B, NB = (1024 if which == "B" else 256), (int(sys.argv[1]) if len(sys.argv) > 1 else 16)
+NSL = 8 if which == "B" else 6
 tiles = NB * B // 64
 NWG = min(tiles, 256)
 rng = np.random.default_rng(0)
@@ -21,8 +23,9 @@ for rep in range(200):
     for i in range(NB):
         wk.push_device(B, pool[i % 16], None, sc[i % 64])
 wk.sync()
-stamps = fr.DeviceBuffer(ctx, 8 * 4096 * 16 * 8)
-stamps.upload(np.zeros(8 * 4096 * 16, np.uint64))
+NST = 12 * 256 * 64
+stamps = fr.DeviceBuffer(ctx, NST * 8)
+stamps.upload(np.zeros(NST, np.uint64))
 lib = fr.lib()
 lib.fr_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
 lib.fr_debug_set_stamp_buffer(stamps.ptr)
@@ -30,20 +33,28 @@ for i in range(NB):
     wk.push_device(B, pool[i % 16], None, sc[i % 64])
 wk.sync()
 lib.fr_debug_set_stamp_buffer(None)
-sw = stamps.download(np.uint64, 8 * 4096 * 16)[:8 * 16 * NWG].reshape(NWG, 8, 16).astype(np.int64)   # [workgroup][wave][stamp]
-s = sw[:, 0, :]
-names = ["start", "prologue (slices 0,1 in LDS)", "FC1 done", "R1 stored", "FC2 done", "FC3 + R3", "scores (tile 0 end)", "kernel end"]
-t0 = s[:, 0].min()
-print("model %s, %d batches per launch = %d tiles on %d workgroups (%.1f tiles each); launch span %.1f us" % (which, NB, tiles, NWG, tiles / NWG, (s[:, 7].max() - t0) / 100.0))
-prev = 0.0
-for i, nme in enumerate(names):
-    col = (s[:, i] - s[:, 0]) / 100.0
-    print("%-30s median %6.1f us (+%.1f)   min %6.1f max %6.1f" % (nme, np.median(col), np.median(col) - prev, col.min(), col.max()))
-    prev = np.median(col)
-print("per wave (median over workgroups, us since the workgroup's wave 0 started):")
-for w in range(8):
-    print("wave %d: " % w + "  ".join("%5.1f" % np.median((sw[:, w, i] - sw[:, 0, 0]) / 100.0) for i in range(1, 8)))
-clk = (sw[:, :, 15] - sw[:, :, 14]) / np.maximum(sw[:, :, 2] - sw[:, :, 1], 1) * 0.1   # shader cycles per 10 ns tick -> GHz
+sw = stamps.download(np.uint64, NST)[:12 * 64 * NWG].reshape(NWG, 12, 64).astype(np.int64)   # [workgroup][wave][slot]
+t0 = sw[:, :, 0].min(axis=1)                       # the workgroup's first wave start
+rel = lambda x: (x - t0[:, None]) / 100.0          # us since the workgroup started
+end = rel(sw[:, :, 62])
+print("model %s, %d batches per launch = %d tiles on %d workgroups (%.1f tiles each); launch span %.1f us, workgroup end median %.1f us" % (
+    which, NB, tiles, NWG, tiles / NWG, (sw[:, :, 62].max() - sw[:, :, 0].min()) / 100.0, np.median(end.max(axis=1))))
+print("set-up done (descriptors in LDS, rings / prologue): consumers %.1f us, producers (tile 0 slices 0, 1 in LDS, D more requested) see barrier 0" % np.median(rel(sw[:, :8, 1]).max(axis=1)))
+names = ["slice %d" % s for s in range(NSL)] + [None] * (8 - NSL) + ["R1 stored", "FC2 done", "R2 stored", "R3 stored", "partials"]
+for tile in range(2):
+    if tiles / NWG <= tile:
+        break
+    print("tile %d: barrier            consumers arrive   producers arrive   released   (median over workgroups of the LAST wave of each role, us)" % tile)
+    prev = None
+    for b, nme in enumerate(names):
+        if nme is None:
+            continue
+        arr = rel(sw[:, :, 4 + 28 * tile + 2 * b]); out = rel(sw[:, :, 5 + 28 * tile + 2 * b])
+        ca, pa, ro = np.median(arr[:, :8].max(axis=1)), np.median(arr[:, 8:].max(axis=1)), np.median(out.max(axis=1))
+        print("        %-18s %8.1f %s        %8.1f %s        %8.1f   %s" % (nme, ca, "*" if ca >= pa else " ", pa, "*" if pa > ca else " ", ro, "" if prev is None else "(+%.1f)" % (ro - prev)))
+        prev = ro
+cyc = (sw[:, :8, 3] - sw[:, :8, 2]).astype(np.float64)
+fc1 = (sw[:, :8, 4 + 2 * 8] - sw[:, :8, 5]).astype(np.float64)   # release of barrier 0 .. arrival at "R1 stored" of tile 0 (10 ns ticks)
 kg = 55 if which == "B" else 22
 print("in-kernel clock over FC1 of tile 0: %.3f GHz; shader cycles there: %.0f (MFMA work per SIMD: 2 waves x %d x 8 x 32 = %d)" % (
-    np.median(clk), np.median(sw[:, :, 15] - sw[:, :, 14]), kg, 2 * kg * 8 * 32))
+    np.median(cyc / np.maximum(fc1, 1) * 0.1), np.median(cyc), kg, 2 * kg * 8 * 32))
