@@ -40,7 +40,7 @@ MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0}   # dense MFMA peak
 SEED_TABLES, SEED_IDX, SEED_WEIGHTS = 0xF1EE7, 1234, 99
 N_IDX_BUFFERS = 64           # distinct index buffers rotated through (>= 32), so caches are not re-hit artificially
 STEADY_S = 2.2               # minimum wall clock of the timed region behind `value`
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")   # falls back to r02_pmc.json entry by entry (see pmc())
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -56,7 +56,10 @@ def free_port():
 
 def self_launch(n):
     """`python bench.py --gpus N` with no WORLD_SIZE: start N fresh rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_* set) and wait for them.  The parent has not imported the library or torch.cuda at this point and never does."""
+    MASTER_* set) and wait for them.  The parent has not imported the library or torch.cuda at this point and never does.
+    FAIL FAST: the children are polled; the first one that exits non-zero (or dies on a signal) takes the others down within a
+    second -- a rank that is gone can never reach the next barrier, and its peers would otherwise sit in the collective until the
+    backend's timeout (minutes).  Only processes this function started are ever signalled (their own Popen handles)."""
     port = free_port()
     procs = []
     for r in range(n):
@@ -65,10 +68,28 @@ def self_launch(n):
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "FR_BENCH_SELF_LAUNCHED": "1"})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    rc, live = 0, set(range(n))
+    while live and rc == 0:
+        time.sleep(0.05)
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc = code if code > 0 else 128 - code
+                sys.stderr.write("bench.py: rank %d exited with status %d: stopping the other %d rank(s)\n" % (r, code, len(live)))
+                break
+    if rc != 0:
+        for r in live:
+            procs[r].terminate()
+        deadline = time.time() + 5.0
+        for r in live:
+            try:
+                procs[r].wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
     return rc
 
 
@@ -88,11 +109,33 @@ def fc_flops_per_inference(fc):
 def pmc(key, field=None):
     """Committed PMC summary (tools/pmc_passes.sh -> profiles/r02_pmc.json): separate rocprofv3 --pmc passes of this script's legs,
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md.  -> the entry, one field of it, or None."""
+    for path in (PMC_FILE, os.path.join(ROOT, "profiles", "r02_pmc.json")):
+        try:
+            e = json.load(open(path)).get(key)
+        except Exception:
+            e = None
+        if e is not None:
+            e = dict(e, pmc_file="profiles/" + os.path.basename(path))
+            return e if field is None else e.get(field)
+    return None
+
+
+def profiled_avg_us(csv_name, kernel):
+    """Average duration (us) rocprofv3 --kernel-trace --stats recorded for `kernel` in profiles/<csv_name> (the committed summary of the
+    same command): the figure every roofline object quotes beside its live HIP-event time.  None when the file or the kernel is absent."""
+    import csv
+    path = os.path.join(ROOT, "profiles", csv_name)
+    if not kernel or not os.path.exists(path):
+        return None
+    key = kernel.split("(")[0].strip()
     try:
-        e = json.load(open(PMC_FILE)).get(key)
-        return e if (field is None or e is None) else e.get(field)
+        for row in csv.DictReader(open(path)):
+            name = row.get("Name", "")
+            if name.startswith(key) or ("void " + key) in name or key in name:
+                return float(row["AverageNs"]) / 1e3
     except Exception:
         return None
+    return None
 
 
 def uniform_idx(rng, ranges, B):
@@ -448,7 +491,7 @@ def leg_group_table(fr, ctx, model, B, d_idx, threads, depth):
     return out
 
 
-def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_host0, threads, depth, label, min_s=1.0, pmc_key=None, env=None):
+def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_host0, threads, depth, label, min_s=1.0, pmc_key=None, env=None, profile_csv=None):
     """One non-headline BASELINE configuration: steady-state throughput (>= 1 s) + an in-run roofline object for its dominant
     kernel from HIP events on one worker's stream."""
     prec_enum = {"f32": fr.FC_FP32, "bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[precision]
@@ -482,13 +525,13 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
                "fc_tflops_end_to_end": None, "frac_of_mfma_peak_end_to_end": None}
     wk = fr.Worker(ctx, B)
     group = ctx.stream_group()
-    if group > 1:   # fused item-tile kernel: one launch = the whole hot path of min(group, 16384 / B) queued batches
-        per_launch = max(1, min(group, 16384 // B))
+    if group > 1:   # fused item-tile kernel: one launch = the whole hot path of min(group, items per launch / B) queued batches
+        per_launch = max(1, min(group, (65536 if precision == "bf16" else 16384) // B))   # bf16: the persistent kernel's launches carry up to 65536 items
         ring = [fr.DeviceBuffer(ctx, B * 4) for _ in range(2 * per_launch)]
         push = lambda i: wk.push_device(B, d_idx[i % len(d_idx)], d_dense[i % len(d_dense)] if d_dense else None, ring[i % len(ring)])
         ms = time_launches(wk, push, per_launch, 100, warm_launches=30)
         flops = flops_inf * B * per_launch
-        kname = {"f32": "fr_fused_tile_kernel / fr_fused_tile_m2_kernel", "bf16": "fr_fused_tile_h_kernel", "fp8": "fr_fused_tile_f8_kernel"}[precision]
+        kname = wk.last_kernel()   # the kernel that carried these launches, as the library reports it (fr_worker_last_kernel)
         what = "%s: one launch = gather + 4-GEMM chain of %d queued batches of %d, back-to-back on ONE stream" % (kname, per_launch, B)
         for b_ in ring:
             b_.free()
@@ -496,10 +539,11 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
         d_sc = fr.DeviceBuffer(ctx, B * 4)
         wk.submit_device(B, d_idx[0], d_dense[0] if d_dense else None, d_sc)
         wk.sync()
-        layer_ms = []
+        layer_ms, layer_kernels = [], []
         for layer in range(4):
             for _ in range(10):
                 wk.fc_layer_only(B, layer)
+            layer_kernels.append(wk.last_kernel())
             wk.sync()
             wk.timer_start()
             for _ in range(50):
@@ -508,17 +552,22 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
             wk.sync()
         ms = layer_ms[0]
         flops = 2 * fc[0] * fc[1] * B
-        what = "fc_lp_gemm_kernel<%d, 2> (FC1: %d x %d x %d) alone on ONE stream" % (prec_enum, fc[0], fc[1], B)
+        kname = layer_kernels[0]
+        what = "%s (FC1: %d x %d x %d) alone on ONE stream" % (kname, fc[0], fc[1], B)
         res["layer_launch_ms"] = layer_ms
+        res["layer_kernels"] = layer_kernels
         d_sc.free()
     wk.close()
     ach = flops / (ms * 1e-3) / 1e12
     pm = (pmc(pmc_key) or {}) if pmc_key else {}
     res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TF[precision], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TF[precision],
-                       "traffic": pm.get("traffic_bytes_per_launch"), "kernel": what, "avg_launch_ms": ms, "algorithmic_flops_per_launch": flops}
+                       "traffic": pm.get("traffic_bytes_per_launch"), "kernel": what, "kernel_name": kname, "avg_launch_ms": ms, "algorithmic_flops_per_launch": flops}
+    if profile_csv:   # the committed rocprofv3 --kernel-trace --stats summary of this leg's own command: must agree with avg_launch_ms
+        res["roofline"]["profiled_avg_launch_us"] = profiled_avg_us(profile_csv, kname)
+        res["roofline"]["profile"] = "profiles/" + profile_csv
     if pm:
         res["roofline"]["pmc_mfma_busy_fraction"] = pm.get("mfma_busy_fraction")
-        res["roofline"]["traffic_source"] = "profiles/r02_pmc.json[%s]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE x2 gfx950 correction), bytes per launch" % pmc_key
+        res["roofline"]["traffic_source"] = "%s[%s]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE x2 gfx950 correction), bytes per launch" % (pm.get("pmc_file"), pmc_key)
     return res
 
 
@@ -543,6 +592,7 @@ def leg_gather(fr, ctx, model, B, law, reps=200, nbuf=32, seed=SEED_IDX, variant
         wk.gather_only(B, idxs[i % nbuf], dns[i % nbuf] if dns else None, rec)
     ms = wk.timer_stop_ms() / reps
     wk.sync()
+    kernel_name = wk.last_kernel()   # what fr_worker_gather_only launched (fr_worker_last_kernel)
     ab = None
     if variants:
         ab = {}
@@ -568,7 +618,7 @@ def leg_gather(fr, ctx, model, B, law, reps=200, nbuf=32, seed=SEED_IDX, variant
     for b_ in idxs + (dns or []):
         b_.free()
     gb = gather_bytes_per_inference(model, fr) * B
-    out = {"avg_launch_ms": ms, "achieved": gb / (ms * 1e-3) / 1e9, "frac": gb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    out = {"kernel": kernel_name, "kernel_name": kernel_name, "avg_launch_ms": ms, "achieved": gb / (ms * 1e-3) / 1e9, "frac": gb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "algorithmic_bytes_per_launch": gb, "inferences_per_s": B / (ms * 1e-3), "index_buffers": nbuf, "timed_launches": reps}
     if ab is not None:
         out["kernel_ab"] = ab
@@ -582,19 +632,34 @@ def leg_gather(fr, ctx, model, B, law, reps=200, nbuf=32, seed=SEED_IDX, variant
 # sharded mode (BASELINE configs[3] / [4])
 # ------------------------------------------------------------------------------------------------------------------
 def main_sharded(args, graft):
-    """Model-C, batch 4096, tables sharded by table-ID over the ranks; per step every rank gathers its [B x F] slice, ONE RCCL
-    all-gather (or all-to-all) over xGMI delivers the slices, rank r runs the FC chain on its B/G items.
-    value = B x steps / max-over-ranks time (one batch per step for the whole job: "scaling": "strong")."""
+    """`--mode sharded`: the table-sharded configuration alone (see run_sharded); prints its own JSON line."""
     import importlib
-    import torch
     fr = graft.load_package()
     dist_mod = importlib.import_module("fleetrec_amd.dist")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     env = dist_mod.DistEnv(args.backend if world > 1 else None)
-    G, r = env.world, env.rank
     n_dev = max(fr.device_count(), 1)
     dev_id = env.local_rank % n_dev if args.share_device else env.local_rank
-    B = 4096 if args.batch == 256 else args.batch
+    if args.batch == 256:
+        args.batch = 4096
+    res = run_sharded(fr, dist_mod, env, dev_id, args)
+    if env.rank == 0:
+        print(json.dumps(res))
+    env.close()
+
+
+def run_sharded(fr, dist_mod, env, dev_id, args, auto_steps_s=0.0):
+    """Model-C, batch 4096, tables sharded by table-ID over the ranks (BASELINE configs[3] / [4]; the reference's counterpart is the
+    3-source ingest of GPU/final_network_cublasLt_3_nodes_no_FIFO_scatter/cuda_server.c:513-591); per step every rank gathers its
+    [B x F] slice, ONE RCCL all-gather (or all-to-all) over xGMI delivers the slices, rank r runs the FC chain on its B/G items.
+    value = B x steps / max-over-ranks time (one batch per step for the whole job: "scaling": "strong").
+    args: batch, steps, warmup, precision, transport, exchange, backend, rows_cap, row_scale, no_unsharded_check.  auto_steps_s > 0
+    sizes the timed region to that many seconds from the warm-up steps (the same count on every rank: MAX over ranks).
+    Every rank calls this with the same arguments; the contexts are created and closed inside.  -> the result dict (every rank)."""
+    import torch
+    world = env.world
+    G, r = env.world, env.rank
+    B = args.batch
     steps, warmup = max(args.steps, 1), args.warmup
     model = fr.Model.builtin(fr.MODEL_C)
     if args.rows_cap or args.row_scale != 1.0:
@@ -701,9 +766,13 @@ def main_sharded(args, graft):
             act, _ = ctx.fp8_exponents()
             ctx.set_fp8_act_exponents(env.min_over_ranks_int(act))
             del cal_l, cal_g
+    tw = time.perf_counter()
     for i in range(warmup):
         step(i)
     drain()
+    if auto_steps_s > 0:   # size the timed region from the warm-up's rate; every rank must run the same number of steps
+        per = (time.perf_counter() - tw) / max(warmup, 1)
+        steps = int(env.max_over_ranks(float(min(max(int(auto_steps_s / max(per, 1e-6)), 5), 4000))))
     env.barrier(); torch.cuda.synchronize(); ctx.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -738,25 +807,28 @@ def main_sharded(args, graft):
         vs_unsharded = {"max_rel_err": float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)), "bit_identical": bool(np.array_equal(got, ref))}
         fw.close()
         full.close()
-    if r == 0:
-        print(json.dumps({
-            "metric": "inferences/sec, Model-C batch 4096, tables sharded by table-ID", "value": B * steps / dt, "unit": "inferences/s",
-            "n_gpus": G, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "Model-C%s batch=%d, %d-way table-ID shards (slice F=%d floats), 1 %s of [B x F] per step, "
-                                   "FC on B/G items per rank" % (" (rows x %g: %.0f GB of tables)" % (args.row_scale, model.table_bytes() / 1e9) if args.row_scale != 1.0 else "",
-                                                                 B, G, F, "all-to-all" if a2a else "all-gather"), "parallelism": "table-sharded x%d" % G,
-                       "shard_table_bytes_this_rank": int(sum(t.rows * t.dim * 4 for si in model.segments() if si.kind == fr.SEG_TABLE and offs[r] <= si.rec_offset < offs[r] + lens[r]
-                                                            for t in [model.tables()[si.src]])),
-                       "min_shards_for_288GB": model.min_shards(),   # north_star: shard ONLY when the tables outgrow one GPU (1 = replicas would do)
-                       "exchange": args.exchange, "backend": args.backend if world > 1 else None,
-                       "slice_transport": args.precision if lp else "f32", "pipelined_equals_stepwise": verified,
-                       "sharded_vs_unsharded_context": vs_unsharded,
-                       "exchange_bytes_in_per_rank_per_step": int(G * (B // G if a2a else B) * F * esz)}}))
+    res = {
+        "metric": "inferences/sec, Model-C batch %d, tables sharded by table-ID" % B, "value": B * steps / dt, "unit": "inferences/s",
+        "n_gpus": G, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": "Model-C%s batch=%d, %d-way table-ID shards (slice F=%d floats), 1 %s of [B x F] per step, "
+                               "FC on B/G items per rank" % (" (rows x %g: %.0f GB of tables)" % (args.row_scale, model.table_bytes() / 1e9) if args.row_scale != 1.0 else "",
+                                                             B, G, F, "all-to-all" if a2a else "all-gather"), "parallelism": "table-sharded x%d" % G,
+                   "shard_table_bytes_this_rank": int(sum(t.rows * t.dim * 4 for si in model.segments() if si.kind == fr.SEG_TABLE and offs[r] <= si.rec_offset < offs[r] + lens[r]
+                                                        for t in [model.tables()[si.src]])),
+                   "min_shards_for_288GB": model.min_shards(),   # north_star: shard ONLY when the tables outgrow one GPU (1 = replicas would do)
+                   "exchange": args.exchange, "backend": args.backend if world > 1 else None,
+                   "slice_transport": args.precision if lp else "f32", "pipelined_equals_stepwise": verified,
+                   "sharded_vs_unsharded_context": vs_unsharded,
+                   "exchange_bytes_in_per_rank_per_step": int(G * (B // G if a2a else B) * F * esz)}}
     wk.close()
     wk_fc.close()
+    for b_ in idxs + dns:
+        b_.free()
     ctx.close()
-    env.close()
+    del local, gathered, scores
+    torch.cuda.empty_cache()
+    return res
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -797,6 +869,8 @@ def main():
     ap.add_argument("--per-bank", action="store_true", help="single-configuration runs (--model / --precision): FR_INDEX_PER_BANK context and indices")
     ap.add_argument("--no-multi-gather", action="store_true", help="N > 1: skip the per-rank legs (gather_per_bank_all_ranks, configs_all_ranks)")
     ap.add_argument("--no-multi-configs", action="store_true", help="N > 1: skip configs_all_ranks (Model-B bf16, Model-C bf16 / fp8 on every rank)")
+    ap.add_argument("--no-multi-sharded", action="store_true", help="N > 1: skip the table-sharded legs (`sharded`, `sharded_inflated_fp8`) of the default line")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="--plumbing-only: this rank exits with status 3 before the first barrier (launcher fail-fast test)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch / rendezvous / timing-rule check without touching a GPU or the library (CPU test of the multi-GPU launcher)")
     args = ap.parse_args()
@@ -823,7 +897,9 @@ def main():
     n_dev = fr.device_count()
     local_rank = env.local_rank % n_dev if args.share_device else env.local_rank  # --share-device: plumbing test on one GPU
     legs = set() if args.legs == "none" else set(args.legs.split(","))
-    want = lambda name: rank == 0 and world == 1 and ("all" in legs or name in legs)
+    # N > 1: the line carries the `roofline` object as well -- rank 0's HIP-event leg of the dominant kernel on its own replica while the
+    # other ranks wait at the next barrier (one rank's launches on one stream: the same measurement as at N = 1); the other rank-0 legs are N = 1 only
+    want = lambda name: rank == 0 and ("all" in legs or name in legs) and (world == 1 or name == "roofline")
 
     B = args.batch
     which = {"A": fr.MODEL_A, "B": fr.MODEL_B, "C": fr.MODEL_C}[args.model]
@@ -923,14 +999,18 @@ def main():
         pipe_ms = time_launches(wk, push, group, 200, warm_launches=4)
         flops = fc_flops_per_inference(model.fc) * B * group
         ach = flops / (pipe_ms * 1e-3) / 1e12
-        kname = "fr_fused_tile_m2_kernel<44>" if group >= 64 else "fr_fused_tile_kernel"
+        kname = wk.last_kernel()   # the kernel that carried these launches, as the library reports it
         pm = pmc("fused_m2_A256") or {}
         result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TF["f32"], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TF["f32"],
                               "traffic": pm.get("traffic_bytes_per_launch"),
-                              "traffic_source": "profiles/r02_pmc.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --legs roofline`; "
-                                                "FETCH_SIZE x2 gfx950 correction), bytes per launch",
+                              "traffic_source": "%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --legs roofline`; "
+                                                "FETCH_SIZE x2 gfx950 correction), bytes per launch; read from the committed file, not measured in this run" % pm.get("pmc_file"),
                               "kernel": "%s: one launch = the whole hot path (gather + the 4-GEMM chain) of %d queued batches of %d, "
                                         "back-to-back on ONE stream" % (kname, group, B),
+                              "kernel_name": kname, "profiled_avg_launch_us": profiled_avg_us("r03_roofline_kernel_stats.csv", kname),
+                              "profile": "profiles/r03_roofline_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --roofline-only`); "
+                                         "profiles/r03_value_4streams_kernel_stats.csv is the same kernel under the DEFAULT four-stream `value` run",
+                              "profiled_avg_launch_us_4streams": profiled_avg_us("r03_value_4streams_kernel_stats.csv", kname),
                               "batches_per_launch": group, "avg_launch_ms": pipe_ms, "algorithmic_flops_per_launch": flops,
                               "pmc_mfma_busy_fraction": pm.get("mfma_busy_fraction"), "pmc_mfma_f32_flops_per_launch": pm.get("mfma_f32_flops_per_launch"),
                               "note": "`value` above runs %d such streams concurrently" % (args.threads * args.depth)}
@@ -1028,7 +1108,7 @@ def main():
                 cfgs.append(leg_config(fr, cb, mb, 1024, prec, di, None, ih[0], None, args.threads, args.depth,
                                        "BASELINE configs[2]: Model-B (embedding_98_krnl, 15.1 GB) batch=1024, %s FC, fused concat + FC chain, per-table indices" % prec
                                        if prec == "bf16" else "Model-B batch=1024, f32 FC (the reference's own precision), per-table indices",
-                                       pmc_key="fused_h_B1024_bf16" if prec == "bf16" else None))
+                                       pmc_key="fused_h_B1024_bf16" if prec == "bf16" else None, profile_csv="r03_B1024_%s_kernel_stats.csv" % prec))
             cb.close()
             # the same configuration under the reference kernel's index contract: one index per bank (49 banks of 2 tables), bank rows in HBM
             mbb = mb.clone(index_mode=fr.INDEX_PER_BANK)
@@ -1068,19 +1148,22 @@ def main():
                 cc.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
             if want("gather"):
                 g = {"workload": "Model-C (2x embedding_377_krnl + 64 dense: 376 tables, 63.2 GB) batch=4096, record-producing gather "
-                                 "(fr_worker_gather_only), per-table indices", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "kernel": "gather_pack_stream_kernel<4, 2, 0, 16>"}
+                                 "(fr_worker_gather_only), per-table indices", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"}
                 if args.gather_law in ("all", "uniform"):
                     g.update(leg_gather(fr, cc, mc, BC, "uniform", variants=not args.no_gather_ab))
                     pm = pmc("gather_C4096_per_table_uniform") or {}
                     g["traffic"] = pm.get("traffic_bytes_per_launch")
                     g["l2_hit_rate"] = pm.get("l2_hit_rate")
-                    g["traffic_source"] = "profiles/r02_pmc.json (PMC passes of `bench.py --legs gather --gather-law uniform`, FETCH_SIZE x2 correction), bytes per launch"
+                    g["traffic_source"] = "%s (PMC passes of `bench.py --legs gather --gather-law uniform`, FETCH_SIZE x2 correction), bytes per launch" % pm.get("pmc_file")
+                    g["profiled_avg_launch_us"] = profiled_avg_us("r03_gather_per_table_uniform_kernel_stats.csv", g.get("kernel_name"))
+                    g["profile"] = "profiles/r03_gather_per_table_uniform_kernel_stats.csv"
                 if args.gather_law in ("all", "zipf"):
                     z = leg_gather(fr, cc, mc, BC, "zipf", seed=SEED_IDX + 1, variants=not args.no_gather_ab)
                     pm = pmc("gather_C4096_per_table_zipf") or {}
                     z["traffic"] = pm.get("traffic_bytes_per_launch")
                     z["l2_hit_rate"] = pm.get("l2_hit_rate")
+                    z["profiled_avg_launch_us"] = profiled_avg_us("r03_gather_per_table_zipf_kernel_stats.csv", z.get("kernel_name"))
+                    z["profile"] = "profiles/r03_gather_per_table_zipf_kernel_stats.csv"
                     g["zipf_1.05"] = z
                 result["gather"] = g
             if want("configs"):
@@ -1092,7 +1175,7 @@ def main():
                 for prec in ("f32", "bf16", "fp8"):
                     result["configs"].append(leg_config(fr, cc, mc, BC, prec, di, dd, ih[0], dh[0], args.threads, args.depth,
                                                         "Model-C (63.2 GB, unsharded replica) batch=4096, %s FC chain end to end "
-                                                        "(BASELINE configs[3]/[4] shapes on one GPU)" % prec, pmc_key="gemm_C4096_%s" % prec))
+                                                        "(BASELINE configs[3]/[4] shapes on one GPU)" % prec, pmc_key="gemm_C4096_%s" % prec, profile_csv="r03_C4096_%s_kernel_stats.csv" % prec))
             if want("gather") or want("configs"):
                 cc.close()
             if want("bank"):
@@ -1102,11 +1185,13 @@ def main():
                 cbk.fill_tables(fr.FILL_HASH, SEED_TABLES)
                 gb = {"workload": "Model-C batch=4096, FR_INDEX_PER_BANK: one index per memory bank per item (82 banks; embedding_377_krnl.cpp:1261-1290), "
                                   "tables of a bank row-interleaved in HBM; uniform indices over each bank's valid range", "bound": "hbm",
-                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "gather_pack_stream_kernel<4, 2, 0, 16>"}
+                      "peak": HBM_PEAK_GBS, "unit": "GB/s"}
                 gb.update(leg_gather(fr, cbk, mcb, BC, "uniform", variants=not args.no_gather_ab))
                 pm = pmc("gather_C4096_per_bank_uniform") or {}
                 gb["traffic"] = pm.get("traffic_bytes_per_launch")
                 gb["l2_hit_rate"] = pm.get("l2_hit_rate")
+                gb["profiled_avg_launch_us"] = profiled_avg_us("r03_gather_per_bank_uniform_kernel_stats.csv", gb.get("kernel_name"))
+                gb["profile"] = "profiles/r03_gather_per_bank_uniform_kernel_stats.csv"
                 result["gather_per_bank"] = gb
                 if want("configs"):   # Model-C end to end under the bank contract (82 bank fetches per item instead of 376 rows)
                     cbk.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
@@ -1213,6 +1298,32 @@ def main():
         elif "c" in holder:
             holder["c"][1].close()
 
+    if world > 1 and not args.no_multi_sharded:
+        # N > 1: the table-sharded split north_star names (BASELINE configs[3] / [4]) on the DEFAULT line -- Model-C batch 4096, tables
+        # sharded by table-ID over the N ranks, one all-gather of the looked-up slices per step (bf16 transport), FC on B / N items per rank;
+        # and, when the node holds it, configs[4]: every table 5 x its rows (316 GB: past one GPU's 288 GB), fp8 FC.  Fresh contexts (the
+        # replicas above are closed).  Set-up failures are voted on before the first data-path collective; a rank that dies inside the
+        # step loop takes the job down through the launcher (self_launch / torchrun stop the other ranks), it cannot hang the line.
+        import types
+        cases = [("configs[3]", dict(precision="bf16", row_scale=1.0))]
+        m5 = fr.Model.builtin(fr.MODEL_C).clone(row_scale=5.0)
+        offs5, lens5, _ = m5.shard_plan(world)
+        shard5 = max(sum(t.rows * t.dim * 4 for si in m5.segments() if si.kind == fr.SEG_TABLE and offs5[k] <= si.rec_offset < offs5[k] + lens5[k]
+                         for t in [m5.tables()[si.src]]) for k in range(world))
+        if not args.share_device and m5.min_shards() is not None and m5.min_shards() <= world and shard5 <= 0.85 * 288e9:
+            cases.append(("configs[4]", dict(precision="fp8", row_scale=5.0)))
+        sharded = []
+        for name, kw in cases:
+            sa = types.SimpleNamespace(batch=4096, steps=50, warmup=10, transport="lp", exchange="allgather", backend=args.backend, rows_cap=args.rows_cap,
+                                       no_unsharded_check=False, **kw)
+            res = run_sharded(fr, dist_mod, env, local_rank, sa, auto_steps_s=1.0)
+            res["baseline_config"] = name
+            sharded.append(res)
+        if rank == 0:
+            result["sharded"] = sharded[0]
+            if len(sharded) > 1:
+                result["sharded_inflated_fp8"] = sharded[1]
+
     if rank == 0:
         print(json.dumps(result))
     env.close()
@@ -1225,6 +1336,9 @@ def main_plumbing(args, graft):
     spec = importlib.util.spec_from_file_location("fleetrec_dist_only", os.path.join(fr_dir, "dist.py"))
     dist_mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(dist_mod)
+    if args.fail_rank >= 0 and int(os.environ.get("RANK", "0")) == args.fail_rank:
+        sys.stderr.write("rank %d: injected failure before the rendezvous\n" % args.fail_rank)
+        sys.exit(3)
     env = dist_mod.DistEnv("gloo" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     env.barrier()
     t0 = time.perf_counter()

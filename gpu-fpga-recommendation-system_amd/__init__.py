@@ -68,7 +68,7 @@ ABI_SYMBOLS = [
     "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
     "fr_device_synchronize", "fr_ctx_shard_info", "fr_driver_create", "fr_driver_destroy", "fr_driver_run_resident",
-    "fr_driver_worker", "fr_driver_score_ring", "fr_driver_run_host", "fr_driver_run_host_streaming", "fr_driver_host_score_ring", "fr_ctx_stream_group", "fr_ctx_set_stream_group", "fr_model_shard_plan", "fr_worker_fc_from_slices",
+    "fr_driver_worker", "fr_driver_score_ring", "fr_driver_run_host", "fr_driver_run_host_streaming", "fr_driver_host_score_ring", "fr_ctx_stream_group", "fr_ctx_set_stream_group", "fr_model_shard_plan", "fr_worker_fc_from_slices", "fr_worker_last_kernel",
 ]
 
 
@@ -131,6 +131,7 @@ def lib():
         "fr_driver_host_score_ring": (vp, [vp, i32, i32, ctypes.POINTER(ctypes.c_int)]),
         "fr_model_shard_plan": (i32, [ctypes.POINTER(ModelDesc), i32, pi, pi, ctypes.POINTER(ctypes.c_int)]),
         "fr_worker_fc_from_slices": (i32, [vp, i32, i32, i32, vp, vp]),
+        "fr_worker_last_kernel": (ctypes.c_char_p, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -619,6 +620,10 @@ class Worker:
 
     def fc_layer_only(self, batch, layer):
         _check(lib().fr_worker_fc_layer_only(self._h, batch, layer))
+
+    def last_kernel(self):
+        """The kernel (instantiation included) of this worker's most recent fused / layer / gather launch (fr_worker_last_kernel)."""
+        return (lib().fr_worker_last_kernel(self._h) or b"").decode()
 
     def fc_from_slices(self, batch_total, item0, n_items, d_gathered, d_scores):
         _check(lib().fr_worker_fc_from_slices(self._h, batch_total, item0, n_items, self._ptr(d_gathered), self._ptr(d_scores)))

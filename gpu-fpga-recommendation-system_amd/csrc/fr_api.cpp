@@ -28,6 +28,17 @@ int fr_knob_env(const char *name, int dflt) {  // experiments build only: the pr
 }
 #endif
 
+static thread_local char g_kernel[96] = "";
+void fr_note_kernel(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+const char *fr_noted_kernel() { return g_kernel; }
+static void keep_kernel(fr_worker *w) { snprintf(w->last_kernel, sizeof(w->last_kernel), "%s", g_kernel); }
+extern "C" const char *fr_worker_last_kernel(const fr_worker *w) { return w ? w->last_kernel : ""; }
+
 extern "C" const char *fr_last_error(void) { return g_err; }
 extern "C" int fr_abi_version(void) { return FR_ABI_VERSION; }
 
@@ -1028,6 +1039,10 @@ static int fused_flush(fr_worker *w) {
     a.stamps = g_stamp_buffer;
     w->n_pending = 0;
     w->pending_items = 0;
+    struct Keep {  // whichever launcher returns below, the worker remembers the kernel it enqueued
+        fr_worker *w;
+        ~Keep() { keep_kernel(w); }
+    } keep{w};
     if (fp8) return frk_fused_f8_launch(a, w->stream);
     if (m2) return frk_fused_m2_launch(a, w->stream);
     if (bf16) {
@@ -1141,6 +1156,7 @@ extern "C" int fr_worker_gather_only(fr_worker *w, int batch, const int32_t *d_i
     if (!d_records) FR_FAIL(FR_ERR_INVALID, "d_records is NULL");
     FR_HIP(hipSetDevice(w->ctx->device));
     rc = launch_gather(w, batch, d_idx, d_dense, d_records);
+    keep_kernel(w);
     if (rc) return rc;
     w->in_flight = true;
     return FR_OK;
@@ -1156,6 +1172,7 @@ extern "C" int fr_worker_gather_slices(fr_worker *w, int batch, const int32_t *d
     if (transport != FR_FC_FP32 && w->ctx->model.layout != FR_LAYOUT_SEMANTIC) FR_FAIL(FR_ERR_STATE, "low-precision transport: SEMANTIC layout only");
     FR_HIP(hipSetDevice(w->ctx->device));
     rc = launch_gather(w, batch, d_idx, d_dense, d_slice, transport);
+    keep_kernel(w);
     if (rc) return rc;
     w->in_flight = true;
     return FR_OK;
@@ -1223,6 +1240,7 @@ extern "C" int fr_worker_fc_layer_only(fr_worker *w, int batch, int layer) {
     sl.d_scores = w->d_score;
     w->n_active++;
     rc = pipeline_step(w);
+    keep_kernel(w);  // the layer's kernel, as launched (fr_worker_last_kernel)
     if (sl.active) {  // stages 1..3 leave the batch in flight: retire it by hand
         sl.active = false;
         w->n_active--;
@@ -1250,7 +1268,10 @@ extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_i
     // Launch groups below FR_FUSED_MIN_GROUP ride the stage pipeline even on a fused-eligible context: a fused launch of g batches takes
     // one item tile's time (~130 us for Model-A) whatever g is, so small groups give 7 M (g = 1) .. 35 M inferences/s (g = 8) at 145 us,
     // where the pipelined stage launches give 43 M at 36 us (profiles/r02_launch_group_paths.txt).
-    const bool fused = fused_eligible(c) && fused_group(c) >= FR_FUSED_MIN_GROUP;
+    // the fused kernels read the index rows through a buffer resource with 32-bit offsets (out-of-range items come back as 0 without a
+    // branch): an index buffer of 4000 MiB or more rides the stage pipeline, whose gather stage has a 64-bit fallback
+    const bool idx_fits = (size_t)batch * idx_cols(c) * sizeof(int32_t) < ((size_t)4000 << 20);
+    const bool fused = fused_eligible(c) && fused_group(c) >= FR_FUSED_MIN_GROUP && idx_fits;
     if (fused && w->n_active > 0) {          // the group was raised while batches were riding the stage pipeline: drain them first
         rc = pipeline_flush(w);
         if (rc) return rc;

@@ -24,6 +24,7 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;  // optional: a rank that cannot take part in a collective aborts the communicator
 };
 Rccl g_rccl;
 std::once_flag g_rccl_once;
@@ -51,6 +52,7 @@ int rccl_load() {
         FR_SYM(AllGather, "ncclAllGather")
         FR_SYM(GetErrorString, "ncclGetErrorString")
 #undef FR_SYM
+        g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(g_rccl.handle, "ncclCommAbort"));
         g_rccl_ok = true;
     });
     if (!g_rccl_ok) FR_FAIL(FR_ERR_COMM, "librccl.so could not be loaded (dlopen / dlsym): %s", g_rccl_why);
@@ -68,7 +70,31 @@ struct fr_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, n_ranks = 1;
     fr_ctx *ctx = nullptr;
+    bool broken = false;  // a collective step failed on this rank: the communicator was aborted, every later call returns FR_ERR_COMM
 };
+
+// A collective step that fails on ONE rank must not leave the others inside the collective for ever (fr_worker_submit_sharded
+// used to return early between its two all-gathers; the peers then spun in ncclAllGather and ShardedEngine::run waited for them
+// indefinitely).  The failing rank ABORTS the communicator: the peers' pending and later collectives return an error (FR_ERR_COMM on
+// their side) instead of hanging.  The error text of the failure itself (already in fr_last_error) is kept.
+static int comm_fail(fr_comm *comm, int rc) {
+    if (comm && !comm->broken) {
+        comm->broken = true;
+        if (comm->comm && g_rccl.CommAbort) {
+            (void)g_rccl.CommAbort(comm->comm);
+            comm->comm = nullptr;  // aborted communicators are already destroyed
+        }
+    }
+    return rc;
+}
+#define FR_NCCL_OR_ABORT(comm_, call)                                                          \
+    do {                                                                                       \
+        ncclResult_t r_ = (call);                                                              \
+        if (r_ != ncclSuccess) {                                                               \
+            fr_set_error("%s failed: %s", #call, g_rccl.GetErrorString(r_));                   \
+            return comm_fail(comm_, FR_ERR_COMM);                                              \
+        }                                                                                      \
+    } while (0)
 
 static_assert(sizeof(ncclUniqueId) == 128, "fr_comm_unique_id hands out 128 bytes");
 
@@ -195,23 +221,28 @@ static int sharded_prologue(fr_worker *w, fr_comm *comm, int batch) {
 }
 
 extern "C" int fr_worker_submit_sharded(fr_worker *w, fr_comm *comm, int batch) {
+    if (comm && comm->broken) FR_FAIL(FR_ERR_COMM, "the communicator was aborted by an earlier failure on this rank");
+    // every state and argument check (and the H2D copies) BEFORE the first collective; whatever fails from here on aborts the
+    // communicator, so that the peers get FR_ERR_COMM instead of waiting in a collective this rank will never join
     int rc = sharded_prologue(w, comm, batch);
-    if (rc) return rc;
+    if (rc) return (w && comm && comm->ctx == w->ctx) ? comm_fail(comm, rc) : rc;
     fr_ctx *c = w->ctx;
     const int G = comm->n_ranks, r = comm->rank;
     const int transport = c->fc_precision;  // slices travel in the chain's own operand type: fp32, bf16 (half) or e4m3 (a quarter of the bytes)
     const size_t esz = transport == FR_FC_FP32 ? 4 : (transport == FR_FC_BF16 ? 2 : 1);
     rc = fr_worker_gather_slices(w, batch, w->d_idx, w->d_dense, w->d_slice, transport);
-    if (rc) return rc;
-    FR_NCCL(g_rccl.AllGather(w->d_slice, w->d_gathered, (size_t)batch * c->slice_padded * esz, ncclChar, comm->comm, w->stream));
+    if (rc) return comm_fail(comm, rc);
+    FR_NCCL_OR_ABORT(comm, g_rccl.AllGather(w->d_slice, w->d_gathered, (size_t)batch * c->slice_padded * esz, ncclChar, comm->comm, w->stream));
     const int base = batch / G, rem = batch % G, chunk = base + (rem ? 1 : 0);
     const int lo = r * base + (r < rem ? r : rem), n_mine = base + (r < rem ? 1 : 0);
+    int fc_rc = FR_OK;
     if (n_mine > 0) {
         w->in_flight = false;  // fr_worker_fc_from_slices_lp is a public entry point with its own state checks
-        rc = fr_worker_fc_from_slices_lp(w, batch, lo, n_mine, w->d_gathered, transport, w->d_score_part);
-        if (rc) return rc;
+        fc_rc = fr_worker_fc_from_slices_lp(w, batch, lo, n_mine, w->d_gathered, transport, w->d_score_part);
     }
-    FR_NCCL(g_rccl.AllGather(w->d_score_part, w->d_score_all, (size_t)chunk, ncclFloat, comm->comm, w->stream));
+    // the second collective is issued whatever the local FC chain returned: the peers are already on their way into it
+    FR_NCCL_OR_ABORT(comm, g_rccl.AllGather(w->d_score_part, w->d_score_all, (size_t)chunk, ncclFloat, comm->comm, w->stream));
+    if (fc_rc) return fc_rc;  // (its text is the last error set before the all-gather succeeded)
     for (int q = 0; q < G; q++) {  // every rank ends up with all B scores in its pinned score buffer
         const int qlo = q * base + (q < rem ? q : rem), qn = base + (q < rem ? 1 : 0);
         if (qn > 0) FR_HIP(hipMemcpyAsync(w->h_score + qlo, w->d_score_all + (size_t)q * chunk, (size_t)qn * sizeof(float), hipMemcpyDeviceToHost, w->stream));
@@ -223,12 +254,13 @@ extern "C" int fr_worker_submit_sharded(fr_worker *w, fr_comm *comm, int batch) 
 // fp8 chain on sharded contexts: every rank calibrates on the SAME all-gathered fp32 slices of the whole batch with the same
 // (replicated) weights, so all ranks arrive at identical activation exponents without a further reduction.
 extern "C" int fr_worker_calibrate_fp8_sharded(fr_worker *w, fr_comm *comm, int batch) {
+    if (comm && comm->broken) FR_FAIL(FR_ERR_COMM, "the communicator was aborted by an earlier failure on this rank");
     int rc = sharded_prologue(w, comm, batch);
-    if (rc) return rc;
+    if (rc) return (w && comm && comm->ctx == w->ctx) ? comm_fail(comm, rc) : rc;
     fr_ctx *c = w->ctx;
     rc = fr_worker_gather_only(w, batch, w->d_idx, w->d_dense, reinterpret_cast<float *>(w->d_slice));
-    if (rc) return rc;
-    FR_NCCL(g_rccl.AllGather(w->d_slice, w->d_gathered, (size_t)batch * c->slice_padded * sizeof(float), ncclChar, comm->comm, w->stream));
+    if (rc) return comm_fail(comm, rc);
+    FR_NCCL_OR_ABORT(comm, g_rccl.AllGather(w->d_slice, w->d_gathered, (size_t)batch * c->slice_padded * sizeof(float), ncclChar, comm->comm, w->stream));
     w->in_flight = false;
     return fr_worker_calibrate_fp8_slices(w, batch, 0, batch, reinterpret_cast<const float *>(w->d_gathered));
 }

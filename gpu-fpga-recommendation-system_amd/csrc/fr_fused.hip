@@ -419,6 +419,7 @@ static int fused_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipStr
     static FrLdsAttrOnce lds_once;  // per instantiation, per device
     if (int rc_ = fr_allow_full_lds(&fr_fused_tile_kernel<T2W, KG, WPE, DB>, lds_once)) return rc_;
     fr_fused_tile_kernel<T2W, KG, WPE, DB><<<grid, dim3(512), lds, s>>>(a);
+    fr_note_kernel("fr_fused_tile_kernel<%d, %d, %d, %s>", T2W, KG, WPE, DB ? "true" : "false");
     KCHECK();
     return FR_OK;
 }
@@ -624,6 +625,7 @@ int frk_fused_m2_launch(const FrFusedArgs &a, hipStream_t s) {
     const size_t rows1 = (size_t)(a.K / 4) + 64, rows2 = (size_t)(a.H2 / 4), rows3 = 64 + 4;  // R3 + 4 KiB of reduction scratch
     const size_t rows = rows1 > rows2 ? (rows1 > rows3 ? rows1 : rows3) : (rows2 > rows3 ? rows2 : rows3);
     fr_fused_tile_m2_kernel<44><<<dim3(a.n_batches * a.tiles_per_batch), dim3(512), rows * FR_M2_LD * 16, s>>>(a);
+    fr_note_kernel("fr_fused_tile_m2_kernel<44>");
     KCHECK();
     return FR_OK;
 }
@@ -895,6 +897,7 @@ static int fused_h_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipS
     static FrLdsAttrOnce lds_once;  // per instantiation, per device
     if (int rc_ = fr_allow_full_lds(&fr_fused_tile_h_kernel<MT, T2W, KG, DB, RD, PD>, lds_once)) return rc_;
     fr_fused_tile_h_kernel<MT, T2W, KG, DB, RD, PD><<<grid, dim3(512), lds, s>>>(a);
+    fr_note_kernel("fr_fused_tile_h_kernel<%d, %d, %d, %s, %d, %d>", MT, T2W, KG, DB ? "true" : "false", RD, PD);
     KCHECK();
     return FR_OK;
 }
@@ -1086,6 +1089,7 @@ static int fused_f8_launch_inst(const FrFusedArgs &a, hipStream_t s) {
     if (int rc_ = fr_allow_full_lds(&fr_fused_tile_f8_kernel<G1>, lds_once)) return rc_;
     const size_t rows1 = 4 * G1 + 32, rows2 = (size_t)(a.H2 / 16) + (size_t)(a.H3 / 16) + 2;  // + 2 rows: 512 floats of reduction scratch
     fr_fused_tile_f8_kernel<G1><<<dim3(a.n_batches * a.tiles_per_batch), dim3(512), (rows1 > rows2 ? rows1 : rows2) * 65 * 16, s>>>(a);
+    fr_note_kernel("fr_fused_tile_f8_kernel<%d>", G1);
     KCHECK();
     return FR_OK;
 }

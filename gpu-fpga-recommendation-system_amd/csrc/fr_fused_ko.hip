@@ -447,6 +447,7 @@ static int fused_hk_launch_inst(const FrFusedArgs &a, int n_cu, hipStream_t s) {
     const size_t lds = ((size_t)128 * HK_LD + (size_t)2 * 2 * KGS * HK_LDX + (size_t)a.n_words) * 16;
     const int tiles = a.n_batches * a.tiles_per_batch;
     fr_fused_tile_hs_kernel<KG, KGS, LW, D, R1D><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(768), lds, s>>>(a);
+    fr_note_kernel("fr_fused_tile_hs_kernel<%d, %d, %d, %d, %d>", KG, KGS, LW, D, R1D);
     KCHECK();
     return FR_OK;
 }

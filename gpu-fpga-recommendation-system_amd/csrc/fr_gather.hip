@@ -243,6 +243,7 @@ static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &grou
         if (wt) gather_pack_stream_kernel<ITEMS, NS, TP, 16><<<g2, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, (unsigned)out_bytes); \
         else gather_pack_stream_kernel<ITEMS, NS, TP, 0><<<g2, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, (unsigned)out_bytes);    \
         KCHECK();                                                                                                                           \
+        fr_note_kernel("gather_pack_stream_kernel<%d, %d, %d, %d>", ITEMS, NS, TP, wt ? 16 : 0);                                            \
         return FR_OK;                                                                                                                       \
     }
             switch (nstep) {
@@ -273,6 +274,7 @@ static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &grou
 #endif
     gather_pack_xcd_kernel<ITEMS, TP><<<grid, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, n_chunks);
     KCHECK();
+    fr_note_kernel("gather_pack_xcd_kernel<%d, %d>", ITEMS, TP);
     return FR_OK;
 }
 
@@ -309,10 +311,12 @@ static int gather_launch(const FrWordDesc *words, int n_words, const FrGatherGro
         constexpr int ITEMS = 8;
         dim3 grid((n_words + bx - 1) / bx, (batch + ITEMS - 1) / ITEMS);
         gather_pack_kernel<ITEMS, TP><<<grid, block, 0, s>>>(words, n_words, idx, idx_stride, dense, out, batch, err_flag, scale);
+        fr_note_kernel("gather_pack_kernel<%d, %d>", ITEMS, TP);
     } else {
         constexpr int ITEMS = 4;
         dim3 grid((n_words + bx - 1) / bx, (batch + ITEMS - 1) / ITEMS);
         gather_pack_kernel<ITEMS, TP><<<grid, block, 0, s>>>(words, n_words, idx, idx_stride, dense, out, batch, err_flag, scale);
+        fr_note_kernel("gather_pack_kernel<%d, %d>", ITEMS, TP);
     }
     KCHECK();
     return FR_OK;
@@ -455,5 +459,6 @@ int frk_gather_tile(const FrPassDesc *passes, const FrChunkDesc *chunks, int n_c
         gather_tile_kernel<false><<<grid, dim3(256), 0, s>>>(passes, chunks, n_chunks, cpg, idx, idx_stride, dense, reinterpret_cast<uint4 *>(out), out_stride_words, batch,
                                                             err_flag, nullptr);
     KCHECK();
+    fr_note_kernel("gather_tile_kernel<%s>", dedup ? "true" : "false");
     return FR_OK;
 }

@@ -474,6 +474,7 @@ static int pipe_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, in
     const int ablate = FR_KNOB_ONCE("GEMM_ABLATE", 0) | (FR_KNOB_ONCE("GEMM_ORDER", 1) << 4) | (FR_KNOB_ONCE("GEMM_PRIO", 1) << 8);
     fc_gemm_pipe_kernel<PREC, NS, G><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale, ablate);
     KCHECK();
+    fr_note_kernel("fc_gemm_pipe_kernel<%d, %d, %d>", PREC, NS, G);
     return FR_OK;
 }
 
@@ -523,6 +524,7 @@ static int lp_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int 
     dim3 grid((N / GN) * (ldm / (128 * MU)));
     fc_lp_gemm_kernel<PREC, MU, GN, S><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale);
     KCHECK();
+    fr_note_kernel("fc_lp_gemm_kernel<%d, %d, %d, %d>", PREC, MU, GN, S);
     return FR_OK;
 }
 

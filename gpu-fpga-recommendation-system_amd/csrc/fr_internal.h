@@ -42,6 +42,13 @@ int fr_knob_env(const char *name, int dflt);
 #define FR_KNOB_ONCE(name, dflt) (dflt)
 #endif
 
+// ---- which kernel ran ---------------------------------------------------------------------------
+// Every launcher names the kernel it just enqueued (instantiation included, as rocprofv3 prints it) in a thread-local note; the entry
+// points of the C-ABI copy the note of their dominant launch into the worker (fr_worker_last_kernel), so that bench.py's roofline
+// objects name the kernel that actually ran instead of the one the author expected.
+void fr_note_kernel(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+const char *fr_noted_kernel();
+
 // ---- device-side descriptors --------------------------------------------------------------------
 // One per 16-byte word of the per-item record (the unit the reference's packers move:
 // `typedef ap_uint<128> axi_t`, constants.hpp:4).  32 bytes = two dwordx4 loads, read once per thread.
@@ -268,6 +275,7 @@ struct fr_worker {
     int *h_err = nullptr;  // sticky index-range flag: pinned host word ...
     int *d_err = nullptr;  // ... and its device-side alias
     bool in_flight = false;
+    char last_kernel[96] = "";  // fr_worker_last_kernel: the dominant kernel of the most recent launch this worker enqueued
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 

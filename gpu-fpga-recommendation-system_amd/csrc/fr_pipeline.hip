@@ -924,6 +924,7 @@ static int pipeline_launch_prec(const FrPipeArgs &a, int single_stage, hipStream
         a.st[2].block_begin == a.st[3].block_begin && a.st[3].block_begin == a.st[4].block_begin) {
         fr_gather_out_kernel<PREC><<<grid, block, 0, s>>>(a);
         KCHECK();
+        fr_note_kernel("fr_gather_out_kernel<%d>", PREC);
         return FR_OK;
     }
     switch (single_stage) {
@@ -936,6 +937,7 @@ static int pipeline_launch_prec(const FrPipeArgs &a, int single_stage, hipStream
         default: FR_FAIL(FR_ERR_INVALID, "bad stage %d", single_stage);
     }
     KCHECK();
+    fr_note_kernel("fr_pipeline_kernel<%d, %d>", single_stage, PREC);
     return FR_OK;
 }
 

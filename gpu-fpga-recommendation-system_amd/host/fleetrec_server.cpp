@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -249,10 +250,9 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
             return true;
         };
         while (o.stream && !g_engine) {
-            {
+            {   // (a full counter ends the loop before anything is read; the slot itself is taken below, once a request is known to be coming)
                 std::lock_guard<std::mutex> g(g_mtx);
                 if (g_global_batch_count >= o.total) break;
-                g_global_batch_count++;
             }
             if (o.reply) {  // wait for the next request without letting queued ones sit
                 // Requests of a burst arrive microseconds apart: the socket must stay dry for --flush-us (default 50 us) before the partial
@@ -293,6 +293,27 @@ static void thread_consume(ThreadInfo *t, const Options &o) {
                     }
                 }
                 if (t->status) break;
+            }
+            // End of stream?  A sender that is done half-closes its side (fleetrec_sender --window W: shutdown(SHUT_WR)) and still expects
+            // the replies of everything it sent.  EOF with ZERO bytes of the next request is therefore a clean end: no counter slot is
+            // taken, no staging slot is acquired, the requests already accepted are synchronised and answered below, and the thread ends
+            // with status 0.  (-4 stays for a request that is cut off part-way.)  ADVICE r02: the slot used to be taken before the read, so a
+            // fast connection that hit EOF dropped up to W pending replies and left a slower connection one request short.
+            {
+                char probe;
+                ssize_t pk;
+                do pk = recv(sock, &probe, 1, MSG_PEEK); while (pk < 0 && errno == EINTR);
+                if (pk == 0) break;   // orderly shutdown, nothing pending on the wire
+                if (pk < 0) {
+                    t->status = -4;
+                    t->error = "Receiving data UNSUCCESSFUL (socket error)";
+                    break;
+                }
+            }
+            {
+                std::lock_guard<std::mutex> g(g_mtx);
+                if (g_global_batch_count >= o.total) break;   // another connection took the last slot meanwhile: its request stays unread
+                g_global_batch_count++;
             }
             // the socket is read straight into the worker's pinned staging slot (the reference reads into its pinned input_feature,
             // cuda_server.c:437), then the slot is queued: no copy between the socket buffer and the H2D source

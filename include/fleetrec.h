@@ -258,6 +258,11 @@ int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_idx, const f
  * the model streams through the fused item-tile kernel -- the value fr_ctx_set_stream_group set, also when it is below 12 and the
  * pushes ride the stage pipeline. */
 int fr_ctx_stream_group(const fr_ctx *ctx);
+/* The kernel (instantiation included, as rocprofv3 prints it) of the most recent launch this worker enqueued through
+ * fr_worker_push_device / fr_worker_sync (the fused item-tile kernel that carried the group), fr_worker_fc_layer_only (that layer's
+ * kernel) or fr_worker_gather_only / fr_worker_gather_slices (the gather kernel).  "" before the first such launch.  The pointer
+ * stays valid for the worker's lifetime; measurement code uses it so that a roofline figure names the kernel that actually ran. */
+const char *fr_worker_last_kernel(const fr_worker *w);
 /* Throughput/latency knob of the fused streaming path, PER CONTEXT: batches per launch, 1..64.  64 batches of 256 items = one 64-item
  * workgroup per CU (fp32: fr_fused_tile_m2_kernel, used only for a group of 64 AND a launch of more than 128 such tiles); smaller groups
  * take the 32-item kernel, which halves the queueing latency of a pushed batch and

@@ -181,6 +181,19 @@ def test_bench_self_launches_ranks_and_refuses_a_wrong_world():
     assert p.returncode != 0 and b"refusing" in p.stderr and b"{" not in p.stdout
 
 
+def test_bench_launcher_fails_fast_when_a_rank_dies():
+    """a rank that dies before a barrier must not leave its peers in the collective until the backend's timeout.
+    `--fail-rank 1` makes rank 1 exit with status 3 before the rendezvous; the launcher sees it, stops the other ranks and exits
+    non-zero within seconds (it used to wait for the ranks one by one)."""
+    import time
+    t0 = time.time()
+    rc, out, err = _run_bench(["--gpus", "3", "--plumbing-only", "--fail-rank", "1"], timeout=120)
+    dt = time.time() - t0
+    assert rc == 3, (rc, err[-2000:])
+    assert dt < 30.0, dt
+    assert "rank 1 exited with status 3" in err and "{" not in out
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--mode", "sharded", "--rows-cap", "20000", "--steps", "3", "--warmup", "1"],
                                    ["--mode", "sharded", "--rows-cap", "20000", "--steps", "3", "--warmup", "1", "--precision", "fp8", "--exchange", "alltoall"],
@@ -190,8 +203,9 @@ def test_bench_two_ranks_on_one_gpu(gpu, extra):
     (--share-device).  Replicas: value aggregates both ranks.  Sharded: 2-way table-ID shards, the exchange through gloo, scores
     of rank 0's items equal to an unsharded context (1e-5 in fp32, bit-identical in fp8) and the pipelined run equal to the stepwise one."""
     import json
-    args = ["--gpus", "2", "--backend", "gloo", "--share-device", "--legs", "none"] + (extra or ["--steps", "300", "--warmup", "100"])
-    rc, out, err = _run_bench(args, timeout=900)
+    # the DEFAULT line (extra == []) keeps its roofline leg: at N > 1 rank 0 prices the dominant kernel on its own replica
+    args = ["--gpus", "2", "--backend", "gloo", "--share-device", "--legs", "none" if extra else "roofline"] + (extra or ["--steps", "300", "--warmup", "100"])
+    rc, out, err = _run_bench(args, timeout=1200)
     assert rc == 0, err[-3000:]
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out
@@ -213,6 +227,15 @@ def test_bench_two_ranks_on_one_gpu(gpu, extra):
         assert g["ranks_measured"] == 2 and g["achieved"] > 0 and g["peak"] == 16000.0, g
         ca = j["configs_all_ranks"]            # ... and Model-C bf16 / fp8 and Model-B bf16 on every rank's replica
         assert [c_["dtype"] for c_ in ca] == ["bf16", "fp8", "bf16"] and all(c_["ranks_measured"] == 2 and c_["value"] > 0 for c_ in ca), ca
+        # the driver's own command measures the table-sharded split (BASELINE configs[3]): Model-C batch 4096, 2-way
+        # table-ID shards, one all-gather per step, bf16 transport -- on the default line, against an unsharded context
+        sh = j["sharded"]
+        assert sh["value"] > 0 and sh["n_gpus"] == 2 and sh["dtype"] == "bf16" and sh["scaling"] == "strong" and sh["baseline_config"] == "configs[3]", sh
+        c = sh["config"]
+        assert c["pipelined_equals_stepwise"] is True and c["sharded_vs_unsharded_context"]["bit_identical"] is True and c["slice_transport"] == "bf16", c
+        assert "sharded_inflated_fp8" not in j      # 316 GB do not fit the one GPU both ranks share here
+        rf = j["roofline"]                          # the N > 1 line carries the roofline object too
+        assert rf["bound"] == "mfma" and 0.3 < rf["frac"] <= 1.0 and rf["avg_launch_ms"] > 0, rf
 
 
 @pytest.mark.gpu

@@ -1477,6 +1477,76 @@ def test_submit_sharded_through_rccl_one_rank(fr, O, gpu, prec):
     ctx.close()
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_submit_sharded_through_rccl_two_ranks(fr, O, gpu, prec):
+    """The G > 1 path of fr_comm_* + fr_worker_submit_sharded, which the one-GPU test boxes cannot run: two table-ID shards
+    on two devices, fr_comm_init_all, one thread per rank, an UNEVEN split (B = 301: ranks take 151 and 150 items), the score all-gather.
+    Skipped where fewer than two GPUs are visible -- the G > 1 RCCL path stays unmeasured on such boxes and DESIGN.md says so.
+    Second half: a rank that cannot take part (bad batch size) aborts the communicator; its peer's collective returns FR_ERR_COMM
+    instead of hanging."""
+    import threading
+    if fr.device_count() < 2:
+        pytest.skip("needs two GPUs: the G > 1 RCCL path is unmeasured on one-GPU boxes")
+    G = 2
+    m = fr.Model.builtin(fr.MODEL_C).clone(max_rows=30000)
+    om = O.OracleModel("C")
+    P = {"f32": fr.FC_FP32, "bf16": fr.FC_BF16}[prec]
+    ctxs_ = []
+    for r in range(G):
+        c = fr.Context(m, device=r, shard_rank=r, n_shards=G)
+        c.fill_tables(fr.FILL_HASH, SEED_TABLES)
+        c.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+        c.set_fc_precision(P)
+        ctxs_.append(c)
+    comms = fr.Comm.init_all(ctxs_)
+    rng = np.random.default_rng(32)
+    B = 301
+    idx = uniform_idx(rng, m.rows(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+    wks = [fr.Worker(ctxs_[r], 512) for r in range(G)]
+    got, errs = [None] * G, [None] * G
+
+    def run(r, b):
+        try:
+            got[r] = wks[r].infer_sharded(comms[r], idx[:b], dense[:b])
+        except Exception as ex:   # noqa: BLE001
+            errs[r] = ex
+
+    th = [threading.Thread(target=run, args=(r, B)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert errs == [None, None], errs
+    assert np.array_equal(got[0], got[1])             # every rank ends with all B scores
+    rec = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES).view(np.float32)
+    ref = om.fc_chain(rec, [ctxs_[0].get_weights(l) for l in range(4)], acc64=True)
+    assert rel_err(got[0], ref) <= {"f32": 1e-3, "bf16": 3e-2}[prec]
+    # failure on one rank: rank 1 is handed a batch larger than its worker allows -> it aborts the communicator, rank 0 gets FR_ERR_COMM
+    errs = [None] * G
+    small = fr.Worker(ctxs_[1], 16)
+    wks_bad = [wks[0], small]
+
+    def run_bad(r):
+        try:
+            wks_bad[r].idx[:] = 0
+            fr._check(fr.lib().fr_worker_submit_sharded(wks_bad[r]._h, comms[r]._h, 300))
+            wks_bad[r].sync()
+        except Exception as ex:   # noqa: BLE001
+            errs[r] = ex
+
+    th = [threading.Thread(target=run_bad, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert not any(t.is_alive() for t in th), "a rank hung in the collective"
+    assert errs[1] is not None and errs[1].status == fr.FR_ERR_INVALID
+    assert errs[0] is not None and errs[0].status in (fr.FR_ERR_COMM, fr.FR_ERR_HIP), errs[0]
+    for w_ in wks + [small]:
+        w_.close()
+    for c_ in comms:
+        c_.close()
+    for c_ in ctxs_:
+        c_.close()
+
+
 @pytest.mark.parametrize("rank", [1, 6])
 def test_config5_inflated_shard_gather(fr, O, gpu, rank):
     """BASELINE configs[4] on one GPU: one of the 8 table-ID shards of Model-C inflated 5x (316 GB in total, 30-60 GB per shard).
@@ -1900,3 +1970,54 @@ def test_bf16_persistent_fused_kernel_many_tiles(fr, O, ctxs, which):
         wk.close()
     finally:
         ctx.set_fc_precision(fr.FC_FP32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", [0, 1, 2])
+def test_committed_fc_fixtures_on_device(fr, O, ctxs, which):
+    """tests/golden/fc_cases_*.npz (made by tests/golden/make_fc_cases.py): the device's procedural weights are the
+    fixture's weights bit for bit, its gathered records are the fixture's records, and the scores of the committed index rows land on
+    the COMMITTED float64 numbers -- through fr_worker_submit, the streaming push (fused item-tile kernels for A / B, stage pipeline +
+    GEMM kernels for C) and fr_worker_fc_only, in all three precisions: 1e-3 f32 (BASELINE.json's tolerance; measured ~1e-6), 3e-2 bf16,
+    0.15 fp8, relative to max|expected|."""
+    import hashlib
+    m, ctx = ctxs(which)
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fc_cases_%s.npz" % NAMES[which]))
+    assert SEED_TABLES == int(fx["seed_tables"]) and SEED_WEIGHTS == int(fx["seed_weights"])
+    idx, dense, ref = fx["idx"], (fx["dense"] if m.dense_len else None), fx["expected"]
+    n = len(idx)
+    for l in range(4):
+        assert hashlib.sha256(ctx.get_weights(l).tobytes()).hexdigest() == str(fx["weights_sha256"][l]), l
+    scale = np.abs(ref).max()
+    wk = fr.Worker(ctx, n)
+    rec = wk.gather_records(idx, dense).reshape(n, -1)
+    assert hashlib.sha256(rec.tobytes()).hexdigest() == str(fx["records_sha256"])
+    wk.close()
+    d_i = fr.DeviceBuffer.from_numpy(ctx, idx)
+    d_d = fr.DeviceBuffer.from_numpy(ctx, dense) if dense is not None else None
+    try:
+        for prec, enum, tol in (("f32", fr.FC_FP32, 1e-3), ("bf16", fr.FC_BF16, 3e-2), ("fp8", fr.FC_FP8, 0.15)):
+            ctx.set_fc_precision(enum)
+            wk = fr.Worker(ctx, n)
+            if prec == "fp8":
+                wk.calibrate_fp8(idx, dense)
+            got = wk.infer(idx, dense)
+            assert np.abs(got - ref).max() <= tol * scale, (prec, "submit", np.abs(got - ref).max() / scale)
+            if prec == "f32":
+                assert np.abs(got - ref).max() <= 2e-5 * scale      # what the exact-f32 MFMA chain actually reaches
+            got = wk.fc_scores(rec.view(np.float32))
+            assert np.abs(got - ref).max() <= tol * scale, (prec, "fc_only", np.abs(got - ref).max() / scale)
+            outs = [fr.DeviceBuffer(ctx, n * 4) for _ in range(3)]
+            for o in outs:
+                wk.push_device(n, d_i, d_d, o)
+            wk.sync()
+            for o in outs:
+                got = o.download(np.float32, n)
+                assert np.abs(got - ref).max() <= tol * scale, (prec, "push", np.abs(got - ref).max() / scale)
+                o.free()
+            wk.close()
+    finally:
+        ctx.set_fc_precision(fr.FC_FP32)
+        d_i.free()
+        if d_d is not None:
+            d_d.free()

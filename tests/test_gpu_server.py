@@ -88,3 +88,34 @@ def test_latency_measurement_mode(fr, gpu):
     assert float(m1.group(2)) <= float(m2.group(2))          # enqueue returns before the scores exist
     assert 0.0 < float(m2.group(3)) < 20000.0, out           # a batch of 256 answers within 20 ms even on a cold box
     assert "i = 0 recv->enqueued" in out
+
+
+def test_stream_reply_answers_everything_before_a_clean_eof(fr, gpu):
+    """a sender that is done half-closes its connections (--window W > 1: shutdown(SHUT_WR)) and still expects the replies of
+    every request it sent.  With fewer requests than the server's --total (--max-blocks below the per-connection share), every
+    connection ends on EOF: the server must treat EOF-before-a-request as a clean end of stream -- answer all accepted requests, take
+    no counter slot for a request that never comes, exit 0."""
+    if not os.path.exists(os.path.join(HOST, "fleetrec_server")):
+        subprocess.check_call(["make", "-s", "-C", HOST])
+    threads, total, per_conn = 4, 64, 10
+    port = free_port_block(threads)
+    srv = subprocess.Popen([os.path.join(HOST, "fleetrec_server"), "--model", "A", "--batch", "128", "--threads", str(threads), "--port", str(port),
+                            "--total", str(total), "--tables", "evenodd", "--weights", "ones", "--stream", "--reply"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    time.sleep(0.5)
+    snd = subprocess.Popen([os.path.join(HOST, "fleetrec_sender"), "--model", "A", "--batch", "128", "--threads", str(threads), "--port", str(port),
+                            "--indices", "reference", "--reply", "--window", "4", "--max-blocks", str(per_conn)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    try:
+        out, _ = srv.communicate(timeout=300)
+        sout, _ = snd.communicate(timeout=60)
+    finally:
+        for p in (srv, snd):
+            if p.poll() is None:
+                p.kill()
+    out, sout = out.decode(), sout.decode()
+    assert srv.returncode == 0, out
+    assert "processed %d batches" % (threads * per_conn) in out, out
+    assert "sender: %d blocks sent" % (threads * per_conn) in sout, sout
+    m_ = re.search(r"latency request sent -> scores received  n=(\d+) avg", sout)
+    assert m_ and int(m_.group(1)) == threads * per_conn, sout     # every request was answered
+    for r in re.findall(r"thread \d+ scores:((?: [-0-9.e+]+)+)", out):
+        assert [float(x) for x in r.split()] == [0.0, 0.0, 352.0 * 2 ** 27, 352.0 * 2 ** 27, 0.0], out

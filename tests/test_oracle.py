@@ -224,3 +224,30 @@ def test_golden_tagged_records_fixture(O, fr):
             tag = (np.uint32(t.source) << np.uint32(31)) | (np.uint32(t.mem_class) << np.uint32(29)) | (np.uint32(t.table_id) << np.uint32(21))
             want = tag | (idx[:, s.src].astype(np.uint32)[:, None] << np.uint32(5)) | (np.arange(s.src_col, s.src_col + s.len, dtype=np.uint32)[None, :] & np.uint32(31))
             assert np.array_equal(got, want), (which, s.src, s.rec_offset)
+
+
+@pytest.mark.parametrize("which", ["A", "B", "C"])
+def test_committed_fc_fixtures(O, which):
+    """tests/golden/fc_cases_*.npz: random-data FC cases with committed float64 expected scores.  The generator is
+    reproducible (same records, same weights, same expected numbers), and the oracle's fp64-accumulating chain -- the restatement of
+    cuda_server.c:211-217,468-491 -- lands on the committed numbers."""
+    import hashlib
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_fc_cases", os.path.join(ROOT, "tests", "golden", "make_fc_cases.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "fc_cases_%s.npz" % which))
+    again = mk.build(which)
+    assert again["records_sha256"] == str(fx["records_sha256"]) and list(again["weights_sha256"]) == list(fx["weights_sha256"])
+    assert np.array_equal(again["expected"], fx["expected"])
+    om = O.OracleModel(which)
+    fc = [int(v) for v in fx["fc"]]
+    assert fc == [int(v) for v in om.fc]
+    rec = om.gather(fx["idx"], dense=fx["dense"] if om.dense_len else None, content_mode=O.FILL_HASH, seed=int(fx["seed_tables"])).view(np.float32)
+    assert hashlib.sha256(rec.tobytes()).hexdigest() == str(fx["records_sha256"])
+    ws = [mk.uniform_weights(int(fx["seed_weights"]), l, fc[l], fc[l + 1]) for l in range(4)]
+    got = om.fc_chain(rec, ws, acc64=True)
+    ref = fx["expected"]
+    assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+    got32 = om.fc_chain(rec, ws, acc64=False)     # fp32 accumulation in the reference's k order: inside BASELINE.json's 1e-3
+    assert np.abs(got32 - ref).max() <= 1e-3 * np.abs(ref).max()

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for pass in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
   tag=$(echo $pass | tr ' ' '_' | cut -c1-60)
-  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/$tag -- python3 $ROOT/bench.py --model C --batch 4096 --precision $PREC --quick > $OUT/$tag.log 2>&1 || echo "pass $tag failed"
+  timeout -k 10 240 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/$tag -- python3 $ROOT/bench.py --model C --batch 4096 --precision $PREC --quick > $OUT/$tag.log 2>&1 || echo "pass $tag failed"
 done
 python3 - $OUT <<'PY'
 import csv, glob, collections, json, sys
