@@ -232,7 +232,9 @@ def test_bench_two_ranks_on_one_gpu(gpu, extra):
         sh = j["sharded"]
         assert sh["value"] > 0 and sh["n_gpus"] == 2 and sh["dtype"] == "bf16" and sh["scaling"] == "strong" and sh["baseline_config"] == "configs[3]", sh
         c = sh["config"]
-        assert c["pipelined_equals_stepwise"] is True and c["sharded_vs_unsharded_context"]["bit_identical"] is True and c["slice_transport"] == "bf16", c
+        # (B / G items per rank take other GEMM tiles than the unsharded batch of 4096 -- 16x16x32 vs 32x32x16 MFMAs sum the k of an
+        # instruction in another order -- so a bf16 rounding of an activation may flip: the bf16 chain's own 5e-3, not bit identity)
+        assert c["pipelined_equals_stepwise"] is True and c["sharded_vs_unsharded_context"]["max_rel_err"] <= 5e-3 and c["slice_transport"] == "bf16", c
         assert "sharded_inflated_fp8" not in j      # 316 GB do not fit the one GPU both ranks share here
         rf = j["roofline"]                          # the N > 1 line carries the roofline object too
         assert rf["bound"] == "mfma" and 0.3 < rf["frac"] <= 1.0 and rf["avg_launch_ms"] > 0, rf
