@@ -25,8 +25,6 @@
 // Arithmetic per output: fp32 accumulation over k in ascending order, one bf16 rounding per activation -- the same values as the
 // chunked kernel, bit for bit (the order of the sums inside an output is unchanged; only the order of the outputs moved).
 // ===================================================================================================
-namespace {
-
 constexpr int HK_LD = 64;   // R1 / R2 / R3 images: 64 items per q8 row, no pad (fragment reads and tile stores are whole 512-byte runs)
 constexpr int HK_LDX = 65;  // X ring: + 1 pad, the gather writes a column of rows per item
 constexpr int HK_H1 = 1024, HK_H2 = 512, HK_H3 = 256;
@@ -429,8 +427,6 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     }
     stamp(62);
 }
-
-}  // namespace
 
 // Every word descriptor must fit the packed 16-byte form: 48-bit source address, 16-bit row stride.
 bool frk_fused_hk_ok(int K, int H1, int H2, int H3, const FrWordDesc *h_words, int n_words) {

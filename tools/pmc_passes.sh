@@ -6,9 +6,9 @@
 #   gather_C4096_per_table_uniform   bench.py --legs gather --gather-law uniform   gather_pack_xcd_kernel
 #   gather_C4096_per_table_zipf      bench.py --legs gather --gather-law zipf      gather_pack_xcd_kernel
 #   gather_C4096_per_bank_uniform    bench.py --legs bank                          gather_pack_xcd_kernel
-#   fused_h_B1024_bf16               bench.py --roofline-only --model B --batch 1024 --precision bf16    fr_fused_tile_h_kernel
+#   fused_h_B1024_bf16               bench.py --roofline-only --model B --batch 1024 --precision bf16    fr_fused_tile_hs_kernel (round 3; fr_fused_tile_h_kernel before)
 #   gemm_C4096_{f32,bf16,fp8}        bench.py --roofline-only --model C --batch 4096 --precision P       the FC1 GEMM kernel of that precision
-# Run on the GPU box from the repo root:  bash tools/pmc_passes.sh [key ...]   -> gpurun_out/pmc/<key>/<pass>/ + gpurun_out/pmc/r02_pmc.json
+# Run on the GPU box from the repo root:  bash tools/pmc_passes.sh [key ...]   -> gpurun_out/pmc/<key>/<pass>/ + gpurun_out/pmc/r03_pmc.json
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc
@@ -21,7 +21,7 @@ for key in $KEYS; do
     gather_C4096_per_table_uniform) ARGS="--legs gather --gather-law uniform"; KERNEL="gather_pack"; EXTRA=();;
     gather_C4096_per_table_zipf) ARGS="--legs gather --gather-law zipf"; KERNEL="gather_pack"; EXTRA=();;
     gather_C4096_per_bank_uniform) ARGS="--legs bank"; KERNEL="gather_pack"; EXTRA=();;
-    fused_h_B1024_bf16) ARGS="--roofline-only --model B --batch 1024 --precision bf16"; KERNEL="fr_fused_tile_h_kernel"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
+    fused_h_B1024_bf16) ARGS="--roofline-only --model B --batch 1024 --precision bf16"; KERNEL="fr_fused_tile_h"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
     gemm_C4096_f32) ARGS="--roofline-only --model C --batch 4096 --precision f32"; KERNEL="fc_lp_gemm_kernel<0, 2"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
     gemm_C4096_bf16) ARGS="--roofline-only --model C --batch 4096 --precision bf16"; KERNEL="fc_gemm_pipe_kernel"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
     gemm_C4096_fp8) ARGS="--roofline-only --model C --batch 4096 --precision fp8"; KERNEL="fc_lp_gemm_kernel<2, 2"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
@@ -32,6 +32,6 @@ for key in $KEYS; do
     tag=$(echo $pass | tr ' ' '_')
     timeout -k 10 240 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/$key/$tag -- python3 $ROOT/bench.py --quick --no-gather-ab $ARGS > $OUT/$key/$tag.log 2>&1 || echo "pass $key/$tag failed"
   done
-  python3 $ROOT/tools/pmc_summarize.py $OUT/$key $key "$KERNEL" $OUT/r02_pmc.json
+  python3 $ROOT/tools/pmc_summarize.py $OUT/$key $key "$KERNEL" $OUT/r03_pmc.json
 done
-cat $OUT/r02_pmc.json
+cat $OUT/r03_pmc.json
