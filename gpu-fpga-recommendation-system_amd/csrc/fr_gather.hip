@@ -134,7 +134,10 @@ __global__ void __launch_bounds__(256) gather_pack_xcd_kernel(const FrWordDesc *
 // of every resident workgroup at once).  Straight-line code (NSTEP is a template parameter), so every s_waitcnt is a counted one;
 // items past the batch cost no branch: their index loads and record stores go through buffer resources whose bounds drop them.
 // Needs batch * idx_stride * 4 and the record bytes below 4000 MiB (the launcher falls back to gather_pack_xcd_kernel otherwise).
-template <int ITEMS, int NSTEP, int TP, int AUX>
+// LEAD: one index load per RUN of adjacent lanes that share an index column (a bank row of a bank-interleaved context is 7-16 record
+// words, a table row 1-8): only the run's first lane loads (the others are masked off the instruction), everybody takes the value
+// from that lane through ds_bpermute -- the texture path sees an eighth to a half of the index lanes.
+template <int ITEMS, int NSTEP, int TP, int AUX, bool LEAD>
 __global__ void __launch_bounds__(256) gather_pack_stream_kernel(const FrWordDesc *__restrict__ words, const FrGatherGroups groups,
                                                                  const int32_t *__restrict__ idx, int idx_stride,
                                                                  const float *__restrict__ dense, void *__restrict__ out,
@@ -160,12 +163,27 @@ __global__ void __launch_bounds__(256) gather_pack_stream_kernel(const FrWordDes
     const int cs = gridDim.x >> 3, c0 = blockIdx.x >> 3;
     uint32_t id[NSTEP][ITEMS];
     uint4 v[NSTEP][ITEMS];
+    // run leaders (LEAD): lane l leads when it is the wave's first lane or its index column differs from lane l - 1's
+    bool leader = true;
+    int lead_byte = 0;   // 4 x the lane that holds this lane's index value
+    if constexpr (LEAD) {
+        const int lane = threadIdx.x & 63;
+        const unsigned prev = (unsigned)__shfl_up((int)idx_col, 1);
+        leader = lane == 0 || prev != idx_col;
+        const unsigned long long lm = __ballot(leader);
+        lead_byte = 4 * (63 - __builtin_clzll(lm & ((2ull << lane) - 1ull)));
+    }
     auto load_idx = [&](int st) {
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
             const unsigned b = (unsigned)(c0 + st * cs) * ITEMS + i;
             // an item past the batch reads past the resource: 0, no branch (dense words do not use the value)
-            id[st][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_idx, b * (unsigned)idx_stride * 4u + icol, 0, 0);
+            if constexpr (LEAD) {
+                id[st][i] = 0;
+                if (leader) id[st][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_idx, b * (unsigned)idx_stride * 4u + icol, 0, 0);
+            } else {
+                id[st][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_idx, b * (unsigned)idx_stride * 4u + icol, 0, 0);
+            }
         }
     };
     auto load_rows = [&](int st) {
@@ -173,6 +191,7 @@ __global__ void __launch_bounds__(256) gather_pack_stream_kernel(const FrWordDes
         for (int i = 0; i < ITEMS; i++) {
             const unsigned b = (unsigned)(c0 + st * cs) * ITEMS + i;
             uint32_t r = id[st][i];
+            if constexpr (LEAD) r = (uint32_t)__builtin_amdgcn_ds_bpermute(lead_byte, (int)r);   // the run leader's value
             const bool oob = !is_dense & (r >= rows);  // reference: silent out-of-bounds read (embedding_47_krnl.cpp:927-933)
             bad |= oob;
             r = oob ? 0u : r;
@@ -237,13 +256,25 @@ static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &grou
         if (nstep > 0 && out_bytes < ((size_t)4000 << 20) && idx_bytes < ((size_t)4000 << 20)) {  // 32-bit resource offsets, with room for the chunk past the batch
             const int st_knob = FR_KNOB("GATHER_STORE", -1);
             const bool wt = st_knob >= 0 ? st_knob == 16 : out_bytes <= ((size_t)200 << 20);
+            const bool lead = FR_KNOB("GATHER_LEAD", 0) != 0;   // experiments build: one index load per run of lanes sharing an index column (slower: 22.3 -> 22.9 us)
+#ifdef FR_EXPERIMENTS   /* the LEAD instantiations exist in the experiments build only (measured slower: profiles/r03_experiments.md) */
+#define FR_G_LEAD(NS)                                                                                                                       \
+            if (wt) gather_pack_stream_kernel<ITEMS, NS, TP, 16, true><<<g2, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, (unsigned)out_bytes); \
+            else gather_pack_stream_kernel<ITEMS, NS, TP, 0, true><<<g2, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, (unsigned)out_bytes);
+#else
+#define FR_G_LEAD(NS)
+#endif
 #define FR_G_STREAM(NS)                                                                                                                     \
     case NS: {                                                                                                                              \
         dim3 g2(8 * ((n_chunks + NS - 1) / NS));                                                                                            \
-        if (wt) gather_pack_stream_kernel<ITEMS, NS, TP, 16><<<g2, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, (unsigned)out_bytes); \
-        else gather_pack_stream_kernel<ITEMS, NS, TP, 0><<<g2, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, (unsigned)out_bytes);    \
+        if (lead) {                                                                                                                         \
+            FR_G_LEAD(NS)                                                                                                                   \
+        } else {                                                                                                                            \
+            if (wt) gather_pack_stream_kernel<ITEMS, NS, TP, 16, false><<<g2, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, (unsigned)out_bytes); \
+            else gather_pack_stream_kernel<ITEMS, NS, TP, 0, false><<<g2, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, (unsigned)out_bytes);    \
+        }                                                                                                                                   \
         KCHECK();                                                                                                                           \
-        fr_note_kernel("gather_pack_stream_kernel<%d, %d, %d, %d>", ITEMS, NS, TP, wt ? 16 : 0);                                            \
+        fr_note_kernel("gather_pack_stream_kernel<%d, %d, %d, %d, %s>", ITEMS, NS, TP, wt ? 16 : 0, lead ? "true" : "false");               \
         return FR_OK;                                                                                                                       \
     }
             switch (nstep) {
@@ -256,6 +287,7 @@ static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &grou
                 default: break;
             }
 #undef FR_G_STREAM
+#undef FR_G_LEAD
         }
     }
 #ifdef FR_EXPERIMENTS
