@@ -1312,17 +1312,36 @@ def main():
                          for t in [m5.tables()[si.src]]) for k in range(world))
         if not args.share_device and m5.min_shards() is not None and m5.min_shards() <= world and shard5 <= 0.85 * 288e9:
             cases.append(("configs[4]", dict(precision="fp8", row_scale=5.0)))
-        sharded = []
+        # These legs have data-path collectives INSIDE their step loop: a rank that fails there leaves its peers in a collective.  The headline
+        # must not be lost to that: every rank runs a leg under a watchdog; when a leg raises, or does not finish within its limit, rank 0
+        # prints the line as it stands (with `sharded_error`) and every rank leaves through os._exit(0) without another collective.
+        import threading
+        keys = {"configs[3]": "sharded", "configs[4]": "sharded_inflated_fp8"}
+
+        def bail(why):
+            if rank == 0:
+                result["sharded_error"] = why
+                print(json.dumps(result), flush=True)
+            sys.stderr.write("rank %d: %s\n" % (rank, why))
+            sys.stderr.flush()
+            os._exit(0)
+
         for name, kw in cases:
             sa = types.SimpleNamespace(batch=4096, steps=50, warmup=10, transport="lp", exchange="allgather", backend=args.backend, rows_cap=args.rows_cap,
                                        no_unsharded_check=False, **kw)
-            res = run_sharded(fr, dist_mod, env, local_rank, sa, auto_steps_s=1.0)
+            done = threading.Event()
+            limit = 300.0
+            dog = threading.Thread(target=lambda: None if done.wait(limit) else bail("%s leg (%s) did not finish within %.0f s" % (keys[name], name, limit)), daemon=True)
+            dog.start()
+            try:
+                res = run_sharded(fr, dist_mod, env, local_rank, sa, auto_steps_s=1.0)
+            except BaseException as ex:   # noqa: BLE001 -- whatever it was, the peers are waiting in a collective: report and leave
+                done.set()
+                bail("%s leg (%s) failed on rank %d: %r" % (keys[name], name, rank, ex))
+            done.set()
             res["baseline_config"] = name
-            sharded.append(res)
-        if rank == 0:
-            result["sharded"] = sharded[0]
-            if len(sharded) > 1:
-                result["sharded_inflated_fp8"] = sharded[1]
+            if rank == 0:
+                result[keys[name]] = res
 
     if rank == 0:
         print(json.dumps(result))
