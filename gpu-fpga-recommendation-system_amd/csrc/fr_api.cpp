@@ -660,6 +660,10 @@ extern "C" void fr_worker_destroy(fr_worker *w) {
         if (p) (void)hipFree(p);
     for (hipEvent_t e : w->hr.ev)
         if (e) (void)hipEventDestroy(e);
+    if (w->h_blist) (void)hipHostFree(w->h_blist);
+    if (w->d_blist) (void)hipFree(w->d_blist);
+    for (hipEvent_t e : w->ev_blist)
+        if (e) (void)hipEventDestroy(e);
     if (w->ev_start) (void)hipEventDestroy(w->ev_start);
     if (w->ev_stop) (void)hipEventDestroy(w->ev_stop);
     if (w->stream) (void)hipStreamDestroy(w->stream);
@@ -957,7 +961,7 @@ static int pipeline_flush(fr_worker *w) {
 // for latency.  Atomic: driver threads read it while a control thread may change it.
 static int fused_group_initial() {
     const int g = FR_KNOB_ONCE("FUSED_GROUP", FR_FUSED_DEFAULT_BATCHES);
-    return g < 1 ? 1 : (g > FR_FUSED_MAX_BATCHES ? FR_FUSED_MAX_BATCHES : g);
+    return g < 1 ? 1 : (g > FR_FUSED_MAX_QUEUE ? FR_FUSED_MAX_QUEUE : g);
 }
 static int fused_group(const fr_ctx *c) { return c->stream_group.load(std::memory_order_relaxed); }
 
@@ -972,8 +976,8 @@ static bool fused_eligible(const fr_ctx *c) {
 // Batches one streaming launch carries on this context: 1 for the stage pipeline, the fused kernel's group otherwise.
 extern "C" int fr_ctx_set_stream_group(fr_ctx *ctx, int batches_per_launch) {
     if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
-    if (batches_per_launch < 1 || batches_per_launch > FR_FUSED_MAX_BATCHES)
-        FR_FAIL(FR_ERR_INVALID, "batches_per_launch %d outside [1, %d]", batches_per_launch, FR_FUSED_MAX_BATCHES);
+    if (batches_per_launch < 1 || batches_per_launch > FR_FUSED_MAX_QUEUE)
+        FR_FAIL(FR_ERR_INVALID, "batches_per_launch %d outside [1, %d]", batches_per_launch, FR_FUSED_MAX_QUEUE);
     ctx->stream_group.store(batches_per_launch, std::memory_order_relaxed);  // queues already holding more are launched by their next push / sync
     return FR_OK;
 }
@@ -987,29 +991,39 @@ extern "C" int fr_ctx_set_small_block(fr_ctx *ctx, int max_batches) {
 
 extern "C" int fr_ctx_stream_group(const fr_ctx *ctx) { return (ctx && fused_eligible(ctx)) ? fused_group(ctx) : 1; }
 
-static int fused_flush(fr_worker *w) {
-    if (w->n_pending == 0) return FR_OK;
+// One launch of the kernarg-fed fused kernels: batches [first, first + n) of the worker's queue (n <= FR_FUSED_MAX_BATCHES).
+static int fused_launch_slice(fr_worker *w, FrFusedArgs &a, int first, int n) {
     fr_ctx *c = w->ctx;
-    FrFusedArgs a{};
-    const bool bf16 = c->fc_precision == FR_FC_BF16;
-    // fp32: the 64-item kernel needs 64 queued batches to cover the chip; smaller groups keep the 32-item kernel (env FR_FUSED_M2=0/1 forces)
+    const bool bf16 = c->fc_precision == FR_FC_BF16, fp8 = c->fc_precision == FR_FC_FP8;
+    // fp32: the 64-item kernel needs 64 queued batches to cover the chip; smaller groups keep the 32-item kernel (experiments: FR_FUSED_M2=0/1 forces)
     const int m2_forced = FR_KNOB_ONCE("FUSED_M2", -1);
     // ... and a PARTIAL launch (fr_worker_sync with a few batches queued) that would put 64-item workgroups on at most half of the CUs
     // takes the 32-item kernel as well: twice the workgroups, 133 instead of 236 us each, bit-identical scores
     int tiles64 = 0;
-    for (int i = 0; i < w->n_pending; i++) tiles64 += (w->pending[i].batch + 63) / 64;
+    for (int i = 0; i < n; i++) tiles64 += (w->pending[first + i].batch + 63) / 64;
     const bool m2 = !bf16 && c->fc_precision == FR_FC_FP32 && frk_fused_m2_ok(c->model.fc[0], c->model.fc[1], c->model.fc[2], c->model.fc[3]) &&
                     (m2_forced == 1 || (m2_forced != 0 && fused_group(c) >= 64 && tiles64 > 128));
-    const bool fp8 = c->fc_precision == FR_FC_FP8;
     const int per_wg = (bf16 || fp8) ? frk_fused_h_items_per_wg() : (m2 ? 64 : 32);  // items per workgroup
     int max_tiles = 0;
-    for (int i = 0; i < w->n_pending; i++) {
-        a.b[i] = w->pending[i];
-        const int tiles = (w->pending[i].batch + per_wg - 1) / per_wg;
+    for (int i = 0; i < n; i++) {
+        a.b[i] = w->pending[first + i];
+        const int tiles = (a.b[i].batch + per_wg - 1) / per_wg;
         if (tiles > max_tiles) max_tiles = tiles;
     }
-    a.n_batches = w->n_pending;
+    a.n_batches = n;
     a.tiles_per_batch = max_tiles;
+    a.blist = nullptr;
+    if (fp8) return frk_fused_f8_launch(a, w->stream);
+    if (m2) return frk_fused_m2_launch(a, w->stream);
+    if (bf16) return frk_fused_h_launch(a, w->stream);
+    return frk_fused_launch(a, w->stream);
+}
+
+static int fused_flush(fr_worker *w) {
+    if (w->n_pending == 0) return FR_OK;
+    fr_ctx *c = w->ctx;
+    FrFusedArgs a{};
+    const bool bf16 = c->fc_precision == FR_FC_BF16, fp8 = c->fc_precision == FR_FC_FP8;
     a.words = c->d_words;
     a.n_words = c->n_words;
     a.idx_stride = (int)idx_cols(c);
@@ -1021,7 +1035,7 @@ static int fused_flush(fr_worker *w) {
         a.wout = c->d_w[3];
         for (int l = 0; l < 3; l++) a.e_w[l] = c->f8_e_w[l];
         for (int l = 0; l < 4; l++) a.e_act[l] = c->f8_e_act[l];
-    } else if (bf16) {  // the bf16 kernel reads the q8-packed bf16 copies through the same argument slots
+    } else if (bf16) {  // the bf16 kernels read the q8-packed bf16 copies through the same argument slots
         a.w1q = reinterpret_cast<const float4 *>(c->d_w_bf16[0]);
         a.w2q = reinterpret_cast<const float4 *>(c->d_w_bf16[1]);
         a.w3q = reinterpret_cast<const float4 *>(c->d_w_bf16[2]);
@@ -1037,33 +1051,58 @@ static int fused_flush(fr_worker *w) {
     a.H2 = c->model.fc[2];
     a.H3 = c->model.fc[3];
     a.stamps = g_stamp_buffer;
+    const int n_all = w->n_pending;
     w->n_pending = 0;
     w->pending_items = 0;
     struct Keep {  // whichever launcher returns below, the worker remembers the kernel it enqueued
         fr_worker *w;
         ~Keep() { keep_kernel(w); }
     } keep{w};
-    if (fp8) return frk_fused_f8_launch(a, w->stream);
-    if (m2) return frk_fused_m2_launch(a, w->stream);
     if (bf16) {
-        // the K-outer persistent kernel (fr_fused_ko.hip) whenever the context's descriptors fit its packed form; experiments build:
-        // FR_FUSED_HK=0 keeps the chunked kernel for A/B runs
+        // The K-outer, persistent, wave-specialised kernel (fr_fused_ko.hip) whenever the context's descriptors fit its packed form AND the
+        // launch gives every workgroup at least two tiles: the first tile of a workgroup pays the whole dependent chain index -> row -> LDS
+        // (13-14 us, all workgroups at once), which only a second tile amortises.  Smaller launches (64 batches of 256 items = one tile per
+        // compute unit, partial groups at fr_worker_sync) keep the chunked kernel.  Its batch list travels through device memory, so one
+        // launch carries up to FR_FUSED_MAX_QUEUE batches (fr_ctx_set_stream_group above 64).
         if (c->hk_ok < 0) {
             int n_cu = 0;
             FR_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
             c->n_cu = n_cu > 0 ? n_cu : 256;
             c->hk_ok = frk_fused_hk_ok(a.K, a.H1, a.H2, a.H3, c->h_words.data(), c->n_words) ? 1 : 0;
         }
-        // ... and the launch gives every workgroup at least two tiles: the persistent kernel's first tile per workgroup pays the whole
-        // dependent chain index -> row -> LDS (13-14 us, all workgroups at once), which only a second tile amortises.  Smaller launches
-        // (Model-A's 64 batches of 256 = one tile per compute unit, partial groups at fr_worker_sync) keep the chunked kernel.
-        int tiles = 0;
-        for (int i = 0; i < a.n_batches; i++) tiles += (a.b[i].batch + 63) / 64;
+        int tiles = 0, max_tiles = 0;
+        for (int i = 0; i < n_all; i++) {
+            const int t_ = (w->pending[i].batch + 63) / 64;
+            tiles += t_;
+            if (t_ > max_tiles) max_tiles = t_;
+        }
         const int hk = FR_KNOB_ONCE("FUSED_HK", -1);  // experiments build: 0 = never, 1 = whenever it applies
-        if (c->hk_ok == 1 && hk != 0 && (hk == 1 || tiles >= 2 * c->n_cu)) return frk_fused_hk_launch(a, c->n_cu, w->stream);
-        return frk_fused_h_launch(a, w->stream);
+        if (c->hk_ok == 1 && hk != 0 && (hk == 1 || tiles >= 2 * c->n_cu)) {
+            if (!w->h_blist) {
+                FR_HIP(hipHostMalloc((void **)&w->h_blist, sizeof(FrFusedBatch) * FR_FUSED_MAX_QUEUE * FR_BLIST_RING, hipHostMallocDefault));
+                FR_HIP(hipMalloc((void **)&w->d_blist, sizeof(FrFusedBatch) * FR_FUSED_MAX_QUEUE * FR_BLIST_RING));
+                for (int k = 0; k < FR_BLIST_RING; k++) FR_HIP(hipEventCreateWithFlags(&w->ev_blist[k], hipEventDisableTiming));
+            }
+            const int k = w->blist_cur;
+            w->blist_cur = (k + 1) % FR_BLIST_RING;
+            if (w->blist_busy[k]) FR_HIP(hipEventSynchronize(w->ev_blist[k]));  // the copy that read this host block four launches ago has executed
+            FrFusedBatch *hb = w->h_blist + (size_t)k * FR_FUSED_MAX_QUEUE, *db = w->d_blist + (size_t)k * FR_FUSED_MAX_QUEUE;
+            memcpy(hb, w->pending, sizeof(FrFusedBatch) * n_all);
+            FR_HIP(hipMemcpyAsync(db, hb, sizeof(FrFusedBatch) * n_all, hipMemcpyHostToDevice, w->stream));
+            FR_HIP(hipEventRecord(w->ev_blist[k], w->stream));
+            w->blist_busy[k] = true;
+            a.blist = db;
+            a.n_batches = n_all;
+            a.tiles_per_batch = max_tiles;
+            return frk_fused_hk_launch(a, c->n_cu, w->stream);
+        }
     }
-    return frk_fused_launch(a, w->stream);
+    for (int first = 0; first < n_all; first += FR_FUSED_MAX_BATCHES) {  // the kernarg-fed kernels: slices of at most 64 batches
+        const int n = n_all - first < FR_FUSED_MAX_BATCHES ? n_all - first : FR_FUSED_MAX_BATCHES;
+        int rc = fused_launch_slice(w, a, first, n);
+        if (rc) return rc;
+    }
+    return FR_OK;
 }
 
 static int check_gather_args(fr_worker *w, const int32_t *d_idx, const float *d_dense) {
@@ -1294,7 +1333,7 @@ extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_i
         // a launch carries at most 16384 items (one 64-item tile per compute unit) -- 65536 through the persistent bf16 kernel, whose
         // workgroups overlap the gather of their next tile with the FC phases of the current one (4 tiles per workgroup)
         const int64_t max_items = FR_KNOB_ONCE("FUSED_ITEMS", 0) ? FR_KNOB_ONCE("FUSED_ITEMS", 0) : (c->fc_precision == FR_FC_BF16 ? 1024 * 64 : 256 * 64);
-        return (w->n_pending >= fused_group(c) || w->pending_items >= max_items) ? fused_flush(w) : FR_OK;
+        return (w->n_pending >= fused_group(c) || w->pending_items >= max_items || w->n_pending >= FR_FUSED_MAX_QUEUE) ? fused_flush(w) : FR_OK;
     }
     rc = pipeline_push(w, batch, 0, d_idx, d_dense, d_scores);
     if (rc) return rc;
@@ -1356,6 +1395,7 @@ static int host_ring_init(fr_worker *w) {
     int g = 16384 / (w->max_batch > 0 ? w->max_batch : 1);  // the queue launches once it holds 256 x 64 items
     if (g < 1) g = 1;
     if (g > fused_group(c)) g = fused_group(c);
+    if (g > FR_FUSED_MAX_BATCHES) g = FR_FUSED_MAX_BATCHES;   // the host-fed blocks stay within one kernarg-fed launch
     r.idx_slot = (size_t)w->max_batch * idx_cols(c);
     r.dense_slot = (size_t)w->max_batch * c->model.dense_len;
     r.score_slot = (size_t)w->max_batch;

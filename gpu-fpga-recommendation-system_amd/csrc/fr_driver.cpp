@@ -17,7 +17,7 @@
 
 #include "fr_internal.h"
 
-constexpr int FR_SCORE_RING = 256;  // four launches of 64 batches per worker between two syncs
+constexpr int FR_SCORE_RING = 512;  // eight launches of 64 batches (two of 256: the largest group) per worker between two syncs
 
 struct fr_driver {
     fr_ctx *ctx = nullptr;
@@ -214,7 +214,7 @@ extern "C" int fr_driver_run_host_streaming(fr_driver *d, int batch, int64_t tot
                 }
                 const int slot = (int)(local % d->depth);
                 // at most 4 blocks x 64 batches of a worker are in flight, and a block is delivered before its staging is refilled:
-                // a ring of FR_SCORE_RING = 256 destinations per worker is never overwritten before delivery
+                // a ring of FR_SCORE_RING = 512 destinations per worker is never overwritten before delivery
                 float *scores = d->host_rings[(size_t)t * d->depth + slot].data() + (size_t)((local / d->depth) % FR_SCORE_RING) * d->max_batch;
                 local++;
                 const int p = (int)(id % n_pool);

@@ -87,17 +87,18 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     const bool producer = wave >= 8;                   // waves 8..11: one per SIMD beside two consumers (waves are dealt to SIMDs cyclically)
     const int n_tiles = a.n_batches * a.tiles_per_batch;
 
+    const FrFusedBatch *bl = a.blist;   // the launch's batches: device memory (up to FR_FUSED_MAX_QUEUE of them), read with scalar loads
     auto tile_at = [&](int t) {
         const int bi = t / a.tiles_per_batch;
         HkTile r;
-        r.idx = a.b[bi].idx, r.dense = a.b[bi].dense, r.scores = a.b[bi].scores, r.batch = a.b[bi].batch;
+        r.idx = bl[bi].idx, r.dense = bl[bi].dense, r.scores = bl[bi].scores, r.batch = bl[bi].batch;
         r.m0 = (t - bi * a.tiles_per_batch) * 64;
         return r;
     };
     auto next_tile = [&](int t) {  // the workgroup's next non-empty tile after t (n_tiles: none); wave-uniform
         for (t += gridDim.x; t < n_tiles; t += gridDim.x) {
             const int bi = t / a.tiles_per_batch;
-            if ((t - bi * a.tiles_per_batch) * 64 < a.b[bi].batch) break;
+            if ((t - bi * a.tiles_per_batch) * 64 < bl[bi].batch) break;
         }
         return t;
     };
@@ -108,18 +109,30 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     // s_memrealtime slots per wave.  0 start, 1 set-up done, 2 / 3 s_memtime around tile 0's FC1; the barriers of the workgroup's first two
     // tiles: 4 + 28 tile + 2 b = arrival at barrier b, + 1 = release (b = slice s for the step barriers, NSL_MAX + p for the five phase
     // barriers R1 stored / FC2 done / R2 stored / R3 stored / partial scores); 62 kernel end.
-    unsigned long long *st = a.stamps ? a.stamps + 64ull * (12ull * blockIdx.x + wave) : nullptr;
+    // The stamps are compiled into the EXPERIMENTS build only: in the product kernel their pointer and tile counter cost registers the
+    // consumers do not have (168, 128 of them accumulators) -- with them in, hipcc spilled 11-18 registers to scratch, and a kernel that
+    // uses scratch pays for its set-up at every dispatch.
+#ifdef FR_EXPERIMENTS
+    constexpr bool kStamps = true;
+#else
+    constexpr bool kStamps = false;
+#endif
+    unsigned long long *st = (kStamps && a.stamps) ? a.stamps + 64ull * (12ull * blockIdx.x + wave) : nullptr;
     auto stamp = [&](int k) {
-        if (st && lane == 0) st[k] = __builtin_amdgcn_s_memrealtime();
+        if constexpr (kStamps)
+            if (st && lane == 0) st[k] = __builtin_amdgcn_s_memrealtime();
     };
     auto cstamp = [&](int k) {
-        if (st && lane == 0) st[k] = __builtin_amdgcn_s_memtime();
+        if constexpr (kStamps)
+            if (st && lane == 0) st[k] = __builtin_amdgcn_s_memtime();
     };
     int tile_no = 0;
     auto bar = [&](int b) {  // the workgroup barrier, stamped on both sides for the first two tiles
-        if (st && tile_no < 2) stamp(4 + 28 * tile_no + 2 * b);
+        if constexpr (kStamps)
+            if (st && tile_no < 2) stamp(4 + 28 * tile_no + 2 * b);
         __syncthreads();
-        if (st && tile_no < 2) stamp(5 + 28 * tile_no + 2 * b);
+        if constexpr (kStamps)
+            if (st && tile_no < 2) stamp(5 + 28 * tile_no + 2 * b);
     };
     stamp(0);
 
@@ -184,27 +197,20 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
         };
         HkTile cur = tile_at(t_cur);
         {   // prologue: the first tile's slices 0, 1 into LDS, 2 .. D + 1 requested, the indices of D + 2 requested (every tile starts so).
-            // Two dependent latencies, not D + 2: every index load of slices 0 .. D + 1 first (their registers are free: no rows yet), then
-            // the row loads of 0 .. D - 1, and slices D, D + 1 as sets 0, 1 come free.
+            // (Issuing every index load first -- two dependent latencies instead of D + 2 -- measured no different: at launch start, with
+            // every workgroup in its prologue, the chain takes 13-14 us either way, and the extra index registers spill.)
             wl = tid & (LW - 1), it0 = ((tid - 512) / LW) * IPT;
-            uint32_t idx0[D + 2][IPT];
 #pragma unroll
-            for (int j = 0; j < D + 2; j++) {
+            for (int j = 0; j < D; j++) {
                 I_op(cur, j);
-#pragma unroll
-                for (int i = 0; i < IPT; i++) idx0[j][i] = idxr[i];
+                R_op(cur, j, rows[j]);
             }
-            auto R_from = [&](int j, uint4 (&r)[IPT]) {
-#pragma unroll
-                for (int i = 0; i < IPT; i++) idxr[i] = idx0[j][i];
-                R_op(cur, j, r);
-            };
-#pragma unroll
-            for (int j = 0; j < D; j++) R_from(j, rows[j]);
             W_op(cur, 0, rows[0]);
-            R_from(D, rows[0]);
+            I_op(cur, D);
+            R_op(cur, D, rows[0]);
             W_op(cur, 1, rows[1]);
-            R_from(D + 1, rows[1]);
+            I_op(cur, D + 1);
+            R_op(cur, D + 1, rows[1]);
             I_op(cur, D + 2);
         }
         while (true) {
@@ -272,10 +278,10 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
         const int t_nxt = next_tile(t_cur);
         const bool has_next = t_nxt < n_tiles;
         asm volatile("" : "+s"(n1), "+s"(n2), "+s"(n3));
-        int tid_o = tid;
+        int tid_o = tid;     // lane geometry re-derived per tile from an opaque copy of the thread id: nothing of it is hoisted out of the tile loop
         asm volatile("" : "+v"(tid_o));
         const int hk = (tid_o >> 5) & 1, lm = tid_o & 31;
-        const unsigned xlane = (unsigned)(128 * HK_LD + hk * HK_LDX + lm), rlane = (unsigned)(hk * HK_LD + lm);  // B-fragment lane bases (16-byte units): X ring, R1 / R2
+        const unsigned xlane = (unsigned)(128 * HK_LD + hk * HK_LDX + lm);  // B-fragment lane base of FC1 (16-byte units): the X ring
 
         // ---- FC1, K-outer: 128 outputs x 64 items per wave ----
         f32x16 acc1[4][2];
@@ -289,7 +295,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
         for (int s = 0; s < NSL; s++) {
             const int kgs = KG - KGS * s < KGS ? KG - KGS * s : KGS;
             bar(s);           // slice s is complete in X[s % 2]; everybody is done reading slice s - 1
-            if (s == 0 && tile_no == 0) cstamp(2);
+            if (kStamps && s == 0 && tile_no == 0) cstamp(2);
             if (s == 0) so1 = n1;  // k-group 0; advanced once per k-group: inside k-group g it points at g + 1
             asm volatile("" : "+s"(so1));
             const uint4 *xb = lds + xlane + (s & 1) * (XROWS * HK_LDX);
@@ -326,7 +332,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (tile_no == 0) cstamp(3);
+        if (kStamps && tile_no == 0) cstamp(3);
 
         // ---- R1 -> LDS (bf16), FC2 K-outer over it: 64 outputs x 64 items per wave ----
         so2 = n2;
@@ -337,6 +343,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) hk_store_tile(R1, acc1[t][mt], 128 * wave + 32 * t, 32 * mt, hk, lm);
         bar(8);           // R1 complete; the X ring is free (every consumer is past the last slice)
+        const unsigned rlane = (unsigned)(hk * HK_LD + lm);  // B-fragment lane base of FC2 / FC3 (R1 / R2)
         f32x16 acc2[2][2];
 #pragma unroll
         for (int t = 0; t < 2; t++)
@@ -413,11 +420,12 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             }
             part[sl * 64 + il] = sc;
             bar(12);
-            if (tid < 64 && cur.m0 + tid < cur.batch) {
-                float t = part[tid];
+            const int tl = tid_o & 1023;  // (the opaque copy: the score address is computed here, not at the top of the tile)
+            if (tl < 64 && cur.m0 + tl < cur.batch) {
+                float t = part[tl];
 #pragma unroll
-                for (int i = 1; i < 8; i++) t += part[i * 64 + tid];
-                cur.scores[cur.m0 + tid] = t;
+                for (int i = 1; i < 8; i++) t += part[i * 64 + tl];
+                cur.scores[cur.m0 + tl] = t;
             }
         }
         tile_no++;

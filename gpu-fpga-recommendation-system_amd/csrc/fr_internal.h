@@ -127,7 +127,9 @@ struct FrPipeArgs {
 };
 
 // ---- fused item-tile kernel: launch arguments (see fr_fused.hip) -------------------------------------
-constexpr int FR_FUSED_MAX_BATCHES = 64;   // kernel-argument array size (64 x 32 B)
+constexpr int FR_FUSED_MAX_BATCHES = 64;   // kernel-argument array size (64 x 32 B): what one launch of the kernarg-fed kernels carries
+constexpr int FR_FUSED_MAX_QUEUE = 256;    // batches a worker queues / the persistent bf16 kernel carries per launch (its list lives in device memory)
+constexpr int FR_BLIST_RING = 4;           // staging blocks of that list per worker
 constexpr int FR_FUSED_DEFAULT_BATCHES = 64;
 constexpr int FR_FUSED_MIN_GROUP = 12;       // fr_worker_push_device: smaller launch groups ride the stage pipeline (one launch per push)
 constexpr int FR_HOST_BLOCKS = 4;  // 64 batches of 256 = one 64-item workgroup per CU (fr_fused_tile_m2_kernel)
@@ -146,6 +148,7 @@ struct FrFusedArgs {
     int n_words;
     int idx_stride;
     int *err_flag;
+    const FrFusedBatch *blist;      // fr_fused_tile_hs_kernel: the launch's batches in device memory (up to FR_FUSED_MAX_QUEUE; b[] is unused then)
     const float4 *w1q, *w2q, *w3q;  // q4-packed weights
     const float *wout;
     int K, H1, H2, H3;
@@ -248,8 +251,14 @@ struct fr_worker {
     bool calibrating = false;   // fr_worker_calibrate_fp8: the pushed batch runs the fp32 stages without K-split partials
     int last_x_parity = 0;      // which activation set holds Xt of the most recently pushed batch (debug hook)
     // fused item-tile path: batches queued by fr_worker_push_device until a launch group is full
-    FrFusedBatch pending[FR_FUSED_MAX_BATCHES];
+    FrFusedBatch pending[FR_FUSED_MAX_QUEUE];
     int n_pending = 0;
+    // batch lists of the persistent kernel's launches: FR_BLIST_RING pinned host blocks + device copies, one H2D copy per launch on the
+    // worker's stream; a block is rewritten only after the copy that read it has executed (its event)
+    FrFusedBatch *h_blist = nullptr, *d_blist = nullptr;
+    hipEvent_t ev_blist[FR_BLIST_RING] = {nullptr, nullptr, nullptr, nullptr};
+    bool blist_busy[FR_BLIST_RING] = {false, false, false, false};
+    int blist_cur = 0;
     int64_t pending_items = 0;
     float *d_score = nullptr;
     // host-fed streaming (fr_worker_push_host): FR_HOST_BLOCKS staging blocks of `g` batches each; a block is filled by CPU copies

@@ -244,17 +244,17 @@ int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d_idx, const
 /* Streaming form of the hot loop: enqueue batch after batch WITHOUT synchronising, as the reference's loop does
  * (cuda_server.c:406-497).  Any FC precision; needs an unsharded, SEMANTIC-layout context.  Two execution forms, chosen per context:
  *  - models whose activations fit in LDS (A, B) stream through the fused item-tile kernel: pushed batches are QUEUED on the worker and
- *    one launch carries fr_ctx_stream_group(ctx) of them (or fewer once 16384 items are queued); nothing runs before the group is full
+ *    one launch carries fr_ctx_stream_group(ctx) of them (or fewer once 16384 items are queued; 65536 in the bf16 chain); nothing runs before the group is full
  *    or fr_worker_sync() is called;
  *  - every other model rides the stage pipeline: each push issues one launch in which this batch is gathered while the previous four
  *    batches of the worker advance through FC1, FC2, FC3 and the output layer.
  * BUFFER LIFETIME (both forms): d_idx / d_dense / d_scores of a pushed batch must stay valid, distinct and untouched until
  * fr_worker_sync(w) returns -- the only completion point this API defines.  A caller that wants to bound its buffer count rotates
  * R >= 2 * max(fr_ctx_stream_group(ctx), 5) buffer sets and calls fr_worker_sync once per trip round the ring (what
- * fr_driver_run_resident does with R = 256). */
+ * fr_driver_run_resident does with R = 512). */
 int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores);
 /* How many pushed batches one streaming launch carries on this context: 1 when fr_worker_push_device rides the stage pipeline
- * (models that do not fit the fused kernel), G (1..64, default 64) when
+ * (models that do not fit the fused kernel), G (1..256, default 64) when
  * the model streams through the fused item-tile kernel -- the value fr_ctx_set_stream_group set, also when it is below 12 and the
  * pushes ride the stage pipeline. */
 int fr_ctx_stream_group(const fr_ctx *ctx);
@@ -263,7 +263,11 @@ int fr_ctx_stream_group(const fr_ctx *ctx);
  * kernel) or fr_worker_gather_only / fr_worker_gather_slices (the gather kernel).  "" before the first such launch.  The pointer
  * stays valid for the worker's lifetime; measurement code uses it so that a roofline figure names the kernel that actually ran. */
 const char *fr_worker_last_kernel(const fr_worker *w);
-/* Throughput/latency knob of the fused streaming path, PER CONTEXT: batches per launch, 1..64.  64 batches of 256 items = one 64-item
+/* Throughput/latency knob of the fused streaming path, PER CONTEXT: batches per launch, 1..256 (default 64).  Groups above 64 exist for
+ * the bf16 chain: its persistent kernel (fr_fused_tile_hs_kernel: one workgroup per compute unit walks several 64-item tiles, the gather
+ * of the next tile under the FC phases of the current one) takes a launch with at least two tiles per compute unit and up to 256 batches
+ * (Model-A's batches of 256 items need a group of 128+ for that; batches of 1024 reach it at the default); every other kernel carries at
+ * most 64 batches per launch and a larger group is launched in slices of 64.  64 batches of 256 items = one 64-item
  * workgroup per CU (fp32: fr_fused_tile_m2_kernel, used only for a group of 64 AND a launch of more than 128 such tiles); smaller groups
  * take the 32-item kernel, which halves the queueing latency of a pushed batch and
  * leaves CUs to other streams (a partial launch -- fr_worker_sync with few batches queued -- whose 64-item tiles would cover at most half

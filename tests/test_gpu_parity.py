@@ -1935,6 +1935,7 @@ def test_bf16_persistent_fused_kernel_many_tiles(fr, O, ctxs, which):
         for j in range(3):
             wk.push_device(B, d_pool[j], None, small[j])
         wk.sync()
+        assert wk.last_kernel().startswith("fr_fused_tile_h_kernel<"), wk.last_kernel()      # fr_worker_last_kernel: fewer than two tiles per CU
         chunked = [b_.download(np.float32, B) for b_ in small]
         sizes = [1024, 1024, 1000, 64, 1, 130, 1024, 577]
         outs = []
@@ -1945,6 +1946,7 @@ def test_bf16_persistent_fused_kernel_many_tiles(fr, O, ctxs, which):
             wk.push_device(b, d_pool[j], None, buf)
             outs.append((buf, j, b))
         wk.sync()
+        assert wk.last_kernel().startswith("fr_fused_tile_hs_kernel<"), wk.last_kernel()     # ... the persistent wave-specialised kernel from there on
         for buf, j, b in outs:
             got = buf.download(np.float32, B)
             assert np.isnan(got[b:]).all(), (j, b)
@@ -2021,3 +2023,103 @@ def test_committed_fc_fixtures_on_device(fr, O, ctxs, which):
         d_i.free()
         if d_d is not None:
             d_d.free()
+
+
+@pytest.mark.gpu
+def test_environment_cannot_change_a_score(fr, ctxs):
+    """the shipped library reads no environment variable -- the experiment knobs (among them FR_GEMM_ABLATE, whose
+    values make fc_gemm_pipe_kernel compute WRONG results on purpose) are compiled into libfleetrec_exp.so only.  Model-C batch 4096 bf16
+    (the path through that GEMM kernel) and Model-B bf16 through the fused kernels, with the variables set to their most destructive
+    values: bit-identical scores."""
+    if os.path.basename(fr.LIB_PATH) != "libfleetrec.so":
+        pytest.skip("FR_LIB points at another build")
+    rng = np.random.default_rng(5)
+    knobs = {"FR_GEMM_ABLATE": "2", "FR_GEMM_ORDER": "0", "FR_GEMM_PRIO": "0", "FR_GEMM_PIPE": "0", "FR_LP_GEMM": "0", "FR_GATHER_STREAM": "0", "FR_GATHER_ITEMS": "16",
+             "FR_GATHER_XCD": "0", "FR_FUSED": "0", "FR_FUSED_HK": "0", "FR_FUSED_GROUP": "1", "FR_SUBMIT_ZEROCOPY": "0", "FR_GATHER_TR": "0"}
+    for which, B in ((2, 4096), (1, 1024)):
+        m, ctx = ctxs(which)
+        idx = uniform_idx(rng, m.rows(), B)
+        dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32) if m.dense_len else None
+        ctx.set_fc_precision(fr.FC_BF16)
+        try:
+            def run():
+                wk = fr.Worker(ctx, B)
+                a = wk.infer(idx, dense)
+                d_i = fr.DeviceBuffer.from_numpy(ctx, idx)
+                d_d = fr.DeviceBuffer.from_numpy(ctx, dense) if dense is not None else None
+                o = fr.DeviceBuffer(ctx, B * 4)
+                wk.push_device(B, d_i, d_d, o)
+                wk.sync()
+                b = o.download(np.float32, B)
+                for x in (d_i, d_d, o):
+                    if x is not None:
+                        x.free()
+                wk.close()
+                return a, b
+            base = run()
+            old = {k: os.environ.get(k) for k in knobs}
+            os.environ.update(knobs)
+            try:
+                again = run()
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            assert np.array_equal(base[0], again[0]) and np.array_equal(base[1], again[1]), which
+        finally:
+            ctx.set_fc_precision(fr.FC_FP32)
+
+
+@pytest.mark.gpu
+def test_launch_groups_above_64(fr, O, ctxs):
+    """fr_ctx_set_stream_group above 64 (round 3): the persistent bf16 kernel takes its batch list from device memory, so ONE launch carries
+    up to 256 batches -- Model-A's batches of 256 items reach "two tiles per compute unit" at a group of 128+ and then stream through
+    fr_fused_tile_hs_kernel<22, ...>; every other kernel carries at most 64 batches per launch and a larger group leaves in slices of 64.
+    Scores are the same bits whichever group size / kernel carried a batch; 257 is refused."""
+    m, ctx = ctxs(fr.MODEL_A)
+    rng = np.random.default_rng(91)
+    B = 256
+    pool = [uniform_idx(rng, m.rows(), B) for _ in range(5)]
+    d_pool = [fr.DeviceBuffer.from_numpy(ctx, i_) for i_ in pool]
+    g0 = ctx.stream_group()
+    try:
+        for prec, enum, kernel_big in (("bf16", fr.FC_BF16, "fr_fused_tile_hs_kernel<22,"), ("f32", fr.FC_FP32, "fr_fused_tile_")):   # (fp32 launches at 16384 queued items: slices of <= 64 batches through the kernarg-fed kernels)
+            ctx.set_fc_precision(enum)
+            wk = fr.Worker(ctx, B)
+            ctx.set_stream_group(64)
+            base = []
+            for j in range(5):
+                o = fr.DeviceBuffer(ctx, B * 4)
+                wk.push_device(B, d_pool[j], None, o)
+                base.append(o)
+            wk.sync()
+            small_kernel = wk.last_kernel()
+            want = [o.download(np.float32, B) for o in base]
+            ctx.set_stream_group(256)
+            assert ctx.stream_group() == 256
+            outs = [fr.DeviceBuffer(ctx, B * 4) for _ in range(256 + 37)]
+            sizes = [256, 256, 200, 256, 1, 256, 64]
+            for i, o in enumerate(outs):
+                o.upload(np.full(B, np.nan, np.float32))
+                wk.push_device(sizes[i % len(sizes)], d_pool[i % 5], None, o)
+                if i == 255:
+                    assert wk.last_kernel().startswith(kernel_big), (prec, wk.last_kernel())   # the full group of 256 has just been launched
+            wk.sync()
+            assert wk.last_kernel() != "" and (prec == "f32" or wk.last_kernel() == small_kernel or wk.last_kernel().startswith("fr_fused_tile_h"))
+            for i, o in enumerate(outs):
+                b = sizes[i % len(sizes)]
+                got = o.download(np.float32, B)
+                assert np.isnan(got[b:]).all() and np.array_equal(got[:b], want[i % 5][:b]), (prec, i, b)
+                o.free()
+            for o in base:
+                o.free()
+            wk.close()
+        with pytest.raises(fr.FleetRecError):
+            ctx.set_stream_group(257)
+    finally:
+        ctx.set_stream_group(g0)
+        ctx.set_fc_precision(fr.FC_FP32)
+        for d in d_pool:
+            d.free()
