@@ -1048,6 +1048,24 @@ def test_dense_block_through_the_fused_tile_kernels(fr, gpu, prec):
     wk.sync()
     sc = d_s.download(np.float32, B)
     assert np.isnan(sc[17]) and np.isfinite(np.delete(sc, 17)).all()
+    if prec == "bf16":
+        # ... and through the persistent wave-specialised kernel (fr_fused_tile_hs_kernel<22, ...>): a group of 256 batches of 200 items =
+        # 1024 tiles, i.e. four per compute unit; its producers read the DENSE words from the request's feature rows.  Same bits as above.
+        ctx.set_stream_group(256)
+        outs = []
+        for rep in range(256):
+            j, b = rep % 4, [200, 200, 77, 200, 1][rep % 5]
+            buf = fr.DeviceBuffer(ctx, B * 4)
+            buf.upload(np.full(B, np.nan, np.float32))
+            wk.push_device(b, d_pool[j][0], d_pool[j][1], buf)
+            outs.append((buf, j, b))
+        assert wk.last_kernel().startswith("fr_fused_tile_hs_kernel<22,"), wk.last_kernel()
+        wk.sync()
+        for buf, j, b in outs:
+            got = buf.download(np.float32, B)
+            assert np.isnan(got[b:]).all() and np.array_equal(got[:b], first[(j, 200)][:b]), (j, b)
+            buf.free()
+        ctx.set_stream_group(64)
     wk.close()
     ctx.close()
 
@@ -1907,24 +1925,33 @@ def test_random_custom_models(fr, O, gpu, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", [1, 0])
-def test_bf16_persistent_fused_kernel_many_tiles(fr, O, ctxs, which):
+@pytest.mark.parametrize("which", [1, 0, "B-per-bank"])
+def test_bf16_persistent_fused_kernel_many_tiles(fr, O, ctxs, gpu, which):
     """fr_fused_tile_hs_kernel (fr_fused_ko.hip), BASELINE configs[2]'s kernel: 8 MFMA waves + 4 gather waves per workgroup, one persistent
     workgroup per compute unit.  A launch with more than two 64-item tiles per compute unit (what selects it), so that every workgroup
     walks several tiles with the next tile's gather running under the current tile's FC phases; batches of unequal size in one launch
     (tiles past a batch's end are skipped), ragged tails, a one-item batch.  Every batch's scores against the host restatement of the
     bf16 arithmetic (5e-3) and against the fp64-accumulating oracle (3e-2); equal rows give equal bits wherever they sit in the launch
     AND whichever kernel ran (a small launch takes the chunked fr_fused_tile_h_kernel: same sums in the same order); an out-of-range
-    index in the last batch of a launch is reported.  Model-B (K = 880, 8 slices) and Model-A at batch 1024 (K = 352, 6 slices)."""
-    m, ctx = ctxs(which)
-    om = O.OracleModel(NAMES[which])
+    index in the last batch of a launch is reported.  Model-B (K = 880, 8 slices), Model-A at batch 1024 (K = 352, 6 slices), and Model-B
+    under the reference kernel's index contract (FR_INDEX_PER_BANK: bank-interleaved tables, 49 index columns, bank-row strides)."""
+    own_ctx = None
+    if which == "B-per-bank":
+        m = fr.Model.builtin(fr.MODEL_B).clone(index_mode=fr.INDEX_PER_BANK)
+        own_ctx = ctx = fr.Context(m, device=gpu)
+        ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+        ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+        om = O.OracleModel("B")
+    else:
+        m, ctx = ctxs(which)
+        om = O.OracleModel(NAMES[which])
     rng = np.random.default_rng(77)
     B = 1024
-    pool_idx = [uniform_idx(rng, m.rows(), B) for _ in range(3)]
+    pool_idx = [uniform_idx(rng, m.index_ranges(), B) for _ in range(3)]
     ws = [ctx.get_weights(l) for l in range(4)]
     refs = []
     for idx in pool_idx:
-        rec = om.gather(idx, content_mode=O.FILL_HASH, seed=SEED_TABLES).view(np.float32)
+        rec = om.gather(idx, content_mode=O.FILL_HASH, seed=SEED_TABLES, per_bank=(own_ctx is not None)).view(np.float32)
         refs.append((chain_bf16_reference(rec, ws, m.fc), om.fc_chain(rec, ws, acc64=True)))
     ctx.set_fc_precision(fr.FC_BF16)
     try:
@@ -1957,7 +1984,7 @@ def test_bf16_persistent_fused_kernel_many_tiles(fr, O, ctxs, which):
             buf.free()
         # an out-of-range index in the last batch of a full group (a late tile of some workgroup's walk)
         bad = pool_idx[0].copy()
-        bad[1023, 7] = m.rows()[7]
+        bad[1023, 7] = m.index_ranges()[7]
         d_bad = fr.DeviceBuffer.from_numpy(ctx, bad)
         d_s = [fr.DeviceBuffer(ctx, B * 4) for _ in range(40)]
         for i in range(39):
@@ -1972,6 +1999,8 @@ def test_bf16_persistent_fused_kernel_many_tiles(fr, O, ctxs, which):
         wk.close()
     finally:
         ctx.set_fc_precision(fr.FC_FP32)
+        if own_ctx is not None:
+            own_ctx.close()
 
 
 @pytest.mark.gpu
