@@ -84,6 +84,7 @@ static void ctx_free(fr_ctx *c) {
         if (i < 3 && c->d_wq[i]) (void)hipFree(c->d_wq[i]);
         if (c->d_w_bf16[i]) (void)hipFree(c->d_w_bf16[i]);
         if (i < 3 && c->d_w_fp8[i]) (void)hipFree(c->d_w_fp8[i]);
+        if (i < 3 && c->d_w_fp8h[i]) (void)hipFree(c->d_w_fp8h[i]);
     }
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->setup_stream) (void)hipStreamDestroy(c->setup_stream);
@@ -559,7 +560,16 @@ static int refresh_fp8(fr_ctx *ctx, int layer) {
     ctx->f8_e_w[layer] = absmax > 0.0f ? floor_log2f(448.0f / absmax) : 0;  // max |W| * 2^e_w lands in (224, 448]
     ctx->f8_w_rms_gain[layer] = std::sqrt(sumsq / (float)H);
     f8_estimate_act_exponents(ctx);
-    return frk_pack_weights_q16_fp8(ctx->d_w[layer], ctx->d_w_fp8[layer], K, H, ctx->f8_e_w[layer], ctx->setup_stream);
+    rc = frk_pack_weights_q16_fp8(ctx->d_w[layer], ctx->d_w_fp8[layer], K, H, ctx->f8_e_w[layer], ctx->setup_stream);
+    if (rc) return rc;
+#ifdef FR_EXPERIMENTS
+    if (frk_fused_f8_ok(ctx->model.fc[0], ctx->model.fc[1], ctx->model.fc[2], ctx->model.fc[3])) {  // the persistent kernel's fp8 form (experiments build only)
+        const int KP32 = (K + 31) / 32 * 32;
+        if (!ctx->d_w_fp8h[layer]) FR_HIP(hipMalloc(&ctx->d_w_fp8h[layer], (size_t)KP32 * H));
+        rc = frk_pack_weights_q16h_fp8(ctx->d_w[layer], ctx->d_w_fp8h[layer], K, H, ctx->f8_e_w[layer], ctx->setup_stream);
+    }
+#endif
+    return rc;
 }
 
 // derived copies of one layer's weights: the q4 re-pack for the fp32 chain, the bf16 / fp8 casts for the low-precision chains
@@ -1058,8 +1068,9 @@ static int fused_flush(fr_worker *w) {
         fr_worker *w;
         ~Keep() { keep_kernel(w); }
     } keep{w};
-    if (bf16) {
-        // The K-outer, persistent, wave-specialised kernel (fr_fused_ko.hip) whenever the context's descriptors fit its packed form AND the
+    // (fp8: the persistent kernel's fp8 form exists in the experiments build only and is opt-in there, FR_FUSED_HK=1 -- it is slower than the chunked fp8 kernel)
+    if (bf16 || (fp8 && FR_KNOB_ONCE("FUSED_HK", -1) == 1 && c->d_w_fp8h[0] && c->d_w_fp8h[1] && c->d_w_fp8h[2])) {
+        // The K-outer, persistent, wave-specialised kernel (fr_fused_ko.hip; bf16 and fp8 forms) whenever the context's descriptors fit its packed form AND the
         // launch gives every workgroup at least two tiles: the first tile of a workgroup pays the whole dependent chain index -> row -> LDS
         // (13-14 us, all workgroups at once), which only a second tile amortises.  Smaller launches (64 batches of 256 items = one tile per
         // compute unit, partial groups at fr_worker_sync) keep the chunked kernel.  Its batch list travels through device memory, so one
@@ -1094,7 +1105,12 @@ static int fused_flush(fr_worker *w) {
             a.blist = db;
             a.n_batches = n_all;
             a.tiles_per_batch = max_tiles;
-            return frk_fused_hk_launch(a, c->n_cu, w->stream);
+            if (fp8) {  // the "q16h" copies of the weights (the non-scaled fp8 MFMA's operand layout)
+                a.w1q = reinterpret_cast<const float4 *>(c->d_w_fp8h[0]);
+                a.w2q = reinterpret_cast<const float4 *>(c->d_w_fp8h[1]);
+                a.w3q = reinterpret_cast<const float4 *>(c->d_w_fp8h[2]);
+            }
+            return frk_fused_hk_launch(a, c->n_cu, c->fc_precision, w->stream);
         }
     }
     for (int first = 0; first < n_all; first += FR_FUSED_MAX_BATCHES) {  // the kernarg-fed kernels: slices of at most 64 batches
@@ -1330,9 +1346,10 @@ extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_i
         w->in_flight = true;
         // a launch is due when the group is full or when the queue already covers the chip (256 CUs x 64 items): large batches
         // need fewer of them per launch
-        // a launch carries at most 16384 items (one 64-item tile per compute unit) -- 65536 through the persistent bf16 kernel, whose
+        // a launch carries at most 16384 items (one 64-item tile per compute unit) -- 65536 in the bf16 chain, whose persistent kernel's
         // workgroups overlap the gather of their next tile with the FC phases of the current one (4 tiles per workgroup)
-        const int64_t max_items = FR_KNOB_ONCE("FUSED_ITEMS", 0) ? FR_KNOB_ONCE("FUSED_ITEMS", 0) : (c->fc_precision == FR_FC_BF16 ? 1024 * 64 : 256 * 64);
+        const bool big = c->fc_precision == FR_FC_BF16 || (c->fc_precision == FR_FC_FP8 && FR_KNOB_ONCE("FUSED_HK", -1) == 1);
+        const int64_t max_items = FR_KNOB_ONCE("FUSED_ITEMS", 0) ? FR_KNOB_ONCE("FUSED_ITEMS", 0) : (big ? 1024 * 64 : 256 * 64);
         return (w->n_pending >= fused_group(c) || w->pending_items >= max_items || w->n_pending >= FR_FUSED_MAX_QUEUE) ? fused_flush(w) : FR_OK;
     }
     rc = pipeline_push(w, batch, 0, d_idx, d_dense, d_scores);

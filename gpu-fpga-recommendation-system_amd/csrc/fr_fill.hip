@@ -297,6 +297,39 @@ int frk_pack_weights_q16_fp8(const float *W, void *Wf, int K, int H, int e_w, hi
     return FR_OK;
 }
 
+// fp32 master weights (column-major H x K) -> "q16h" Wg[2 (k / 32) + kh][h][16 B], K zero-padded to a multiple of 32: the operand layout
+// of the NON-scaled fp8 MFMA (v_mfma_f32_32x32x16_fp8_fp8: lane half kh supplies k 8 kh .. 8 kh + 7 of a 16-k step).  The 16 bytes of
+// (row 2 j + kh, h) are the lane's 8 bytes of step 2 j followed by its 8 bytes of step 2 j + 1: byte b holds k = 32 j + 16 (b / 8) + 8 kh + b % 8.
+// One 16-byte load per lane then feeds two MFMAs, with the addressing of the bf16 q8 layout (fr_fused_tile_hs_kernel, fp8 form).
+__global__ void __launch_bounds__(256) pack_weights_q16h_fp8_kernel(const float *__restrict__ W, uint4 *__restrict__ Wg, int K, int KP, int H, float scale) {
+    const size_t n = (size_t)(KP / 16) * H;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = e / H, h = e - row * H;
+        const size_t j = row >> 1, kh = row & 1;
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {   // dword q: bytes 4 q .. 4 q + 3 -> step q / 2, position 4 (q % 2) ..
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const size_t k = 32 * j + 16 * (size_t)(q >> 1) + 8 * kh + 4 * (size_t)(q & 1) + c;
+                v[c] = (k < (size_t)K) ? W[h + k * H] : 0.0f;
+            }
+            o[q] = pack_fp8x4(v[0], v[1], v[2], v[3], scale);
+        }
+        Wg[e] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+int frk_pack_weights_q16h_fp8(const float *W, void *Wg, int K, int H, int e_w, hipStream_t s) {
+    const int KP = (K + 31) / 32 * 32;
+    size_t n = (size_t)(KP / 16) * H;
+    unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    pack_weights_q16h_fp8_kernel<<<dim3(blocks ? blocks : 1), dim3(256), 0, s>>>(W, reinterpret_cast<uint4 *>(Wg), K, KP, H, ldexpf(1.0f, e_w));
+    KCHECK();
+    return FR_OK;
+}
+
 // item-major fp32 records [B][K] -> Xf[KP/16][ldm][16] e4m3(x * scale) (fc_only diagnostic / BLOCKED layout in fp8 mode)
 __global__ void __launch_bounds__(256) records_to_q16_fp8_kernel(const float *__restrict__ X, uint4 *__restrict__ Xf, int batch, int K, int KE, int ldm, float scale) {
     const size_t n = (size_t)KE * ldm;

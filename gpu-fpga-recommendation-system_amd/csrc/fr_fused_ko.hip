@@ -66,21 +66,51 @@ __device__ __forceinline__ void hk_store_tile(uint4 *img, const f32x16 &acc, int
     }
 }
 
-// KG = K / 16 k-groups; KGS = k-groups per slice (4 KGS record words <= LW lanes); LW = producer lanes along the words of a slice
-// (16 or 32); D = row sets a producer thread keeps in flight (NSL % D == 0: the set of a slice is a compile-time index).
-template <int KG, int KGS, int LW, int D, int R1D>
+// fp8 form of the tile store: 32(n) x 32(m) fp32 accumulators -> e4m3 (x oscale, saturated) in the "q16h" operand layout of the non-scaled
+// fp8 MFMA: element (row 2 (n / 32) + ((n % 16) / 8), m), byte 8 ((n % 32) / 16) + n % 8.  A lane's four consecutive n are one dword.
+__device__ __forceinline__ void hk_store_tile_f8(uint4 *img, const f32x16 &acc, int n_local, int m_local, int hk, int lm, float oscale) {
+    uint32_t *q = reinterpret_cast<uint32_t *>(img);
+#pragma unroll
+    for (int i = 0; i < 4; i++)   // n = n_local + 8 i + 4 hk + c, n_local a multiple of 32: step i / 2, lane half i % 2, position 4 hk + c
+        q[((size_t)(2 * (n_local >> 5) + (i & 1)) * HK_LD + m_local + lm) * 4 + 2 * (i >> 1) + hk] = pack_fp8x4(acc[4 * i + 0], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3], oscale);
+}
+
+// one "k-group" = the k one 16-byte operand fragment per lane covers: 16 (bf16: one v_mfma_f32_32x32x16_bf16) or 32 (fp8: two
+// v_mfma_f32_32x32x16_fp8_fp8, the fragment's low and high 8 bytes).  acc += A(fragment) x B(fragment), k ascending.
+template <int PREC>
+__device__ __forceinline__ void hk_mma(f32x16 &acc, const uint4 &a4, const uint4 &b4) {
+    if constexpr (PREC == 1) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a4), __builtin_bit_cast(bf16x8, b4), acc, 0, 0, 0);
+    } else {
+        const long a_lo = (long)(((unsigned long long)a4.y << 32) | a4.x), a_hi = (long)(((unsigned long long)a4.w << 32) | a4.z);
+        const long b_lo = (long)(((unsigned long long)b4.y << 32) | b4.x), b_hi = (long)(((unsigned long long)b4.w << 32) | b4.z);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a_lo, b_lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a_hi, b_hi, acc, 0, 0, 0);
+    }
+}
+
+// PREC = 1 bf16 (q8 operands), 2 fp8 (e4m3 "q16h" operands on the NON-scaled fp8 MFMA: operand registers as in bf16 -- the scaled
+// 32x32x64 form needs 8 registers per fragment, which the consumers' 168 do not have beside 128 accumulators; the power-of-two
+// exponents are folded into the scale of the next activation's quantisation, exactly).  KG = k-groups of the (zero-padded) record (16 k
+// each in bf16, 32 k in fp8); KGS = k-groups per slice; LW = producer lanes along the record words of a slice (16 or 32); D = row sets
+// a producer thread keeps in flight (NSL % D == 0: the set of a slice is a compile-time index); R1D = FC1 weight fragments in registers.
+template <int PREC, int KG, int KGS, int LW, int D, int R1D>
 __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs a) {
     extern __shared__ uint4 lds[];
+    constexpr int WPG = PREC == 2 ? 8 : 4;             // record words (4 floats each) per k-group
+    constexpr int KPG = 4 * WPG;                       // k per k-group
+    constexpr int KG2 = HK_H1 / KPG, KG3 = HK_H2 / KPG, KG4 = HK_H3 / KPG;   // k-groups of FC2 / FC3 / the output layer
     constexpr int NSL = (KG + KGS - 1) / KGS;          // slices per tile
     constexpr int IPT = LW / 4;                        // items per producer thread (256 threads = LW words x 64 / IPT item slots)
-    constexpr int XROWS = 2 * KGS;                     // q8 rows of one X ring buffer
+    constexpr int XROWS = 2 * KGS;                     // operand rows of one X ring buffer
+    constexpr int NBAR = NSL + 5;                      // barriers per tile (stamp slots)
     static_assert(NSL % 2 == 0 && NSL % D == 0 && NSL >= D + 3, "two X buffers, D row sets, and the run-ahead stays inside the next tile");
-    static_assert(4 * KGS <= LW && (LW == 16 || LW == 32), "a slice's record words ride the lanes of one half / quarter wave");
-    uint4 *R1 = lds;                                   // [128][64]
-    uint4 *R2 = lds;                                   // [64][64], overlays R1 once FC2 has read it
-    uint4 *R3 = lds + 64 * HK_LD;                      // [32][64]
-    float *part = reinterpret_cast<float *>(lds + 96 * HK_LD);  // 8 x 64 partial scores
-    uint4 *Xr = lds + 128 * HK_LD;                     // [2][XROWS][65]
+    static_assert(WPG * KGS <= LW && (LW == 16 || LW == 32), "a slice's record words ride the lanes of one half / quarter wave");
+    uint4 *R1 = lds;                                   // [2 KG2][64]: bf16 128 KiB, fp8 64 KiB
+    uint4 *R2 = lds;                                   // [2 KG3][64], overlays R1 once FC2 has read it
+    uint4 *R3 = lds + 2 * KG3 * HK_LD;                 // [2 KG4][64]
+    float *part = reinterpret_cast<float *>(lds + (2 * KG3 + 2 * KG4) * HK_LD);  // 8 x 64 partial scores
+    uint4 *Xr = lds + 2 * KG2 * HK_LD;                 // [2][XROWS][65]
     uint4 *Dsc = Xr + 2 * XROWS * HK_LDX;              // [n_words] packed descriptors
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,10 +135,10 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     int t_cur = next_tile((int)blockIdx.x - (int)gridDim.x);
     if (t_cur >= n_tiles) return;
 
-    // Diagnostic build aid (tools/experiments/fused_hk_stamps.py; a.stamps is NULL in normal operation, values never feed an output): 64
+    // Diagnostic build aid (tools/experiments/fused_hk_stamps.py; a.stamps is NULL in normal operation, values never feed an output): 128
     // s_memrealtime slots per wave.  0 start, 1 set-up done, 2 / 3 s_memtime around tile 0's FC1; the barriers of the workgroup's first two
-    // tiles: 4 + 28 tile + 2 b = arrival at barrier b, + 1 = release (b = slice s for the step barriers, NSL_MAX + p for the five phase
-    // barriers R1 stored / FC2 done / R2 stored / R3 stored / partial scores); 62 kernel end.
+    // tiles: 4 + 2 NBAR tile + 2 b = arrival at barrier b, + 1 = release (b = slice s for the step barriers, NSL + p for the five phase
+    // barriers R1 stored / FC2 done / R2 stored / R3 stored / partial scores; NBAR = NSL + 5); 126 kernel end.
     // The stamps are compiled into the EXPERIMENTS build only: in the product kernel their pointer and tile counter cost registers the
     // consumers do not have (168, 128 of them accumulators) -- with them in, hipcc spilled 11-18 registers to scratch, and a kernel that
     // uses scratch pays for its set-up at every dispatch.
@@ -117,7 +147,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
 #else
     constexpr bool kStamps = false;
 #endif
-    unsigned long long *st = (kStamps && a.stamps) ? a.stamps + 64ull * (12ull * blockIdx.x + wave) : nullptr;
+    unsigned long long *st = (kStamps && a.stamps) ? a.stamps + 128ull * (12ull * blockIdx.x + wave) : nullptr;
     auto stamp = [&](int k) {
         if constexpr (kStamps)
             if (st && lane == 0) st[k] = __builtin_amdgcn_s_memrealtime();
@@ -129,10 +159,10 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     int tile_no = 0;
     auto bar = [&](int b) {  // the workgroup barrier, stamped on both sides for the first two tiles
         if constexpr (kStamps)
-            if (st && tile_no < 2) stamp(4 + 28 * tile_no + 2 * b);
+            if (st && tile_no < 2) stamp(4 + 2 * NBAR * tile_no + 2 * b);
         __syncthreads();
         if constexpr (kStamps)
-            if (st && tile_no < 2) stamp(5 + 28 * tile_no + 2 * b);
+            if (st && tile_no < 2) stamp(5 + 2 * NBAR * tile_no + 2 * b);
     };
     stamp(0);
 
@@ -152,9 +182,12 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
         uint4 rows[D][IPT];                         // row words in flight: D slices
         unsigned bad = 0u;                          // out-of-range index seen (a lane flag, OR-ed: no compare mask is kept)
         uint2 *Xh2 = reinterpret_cast<uint2 *>(Xr);
-        auto slice_word = [&](int s) {  // this thread's record word in slice s; lanes past the slice repeat its last word (same row as their
-            const int nw = 4 * (KG - KGS * s < KGS ? KG - KGS * s : KGS);  // neighbour: no extra line is fetched) and never store it
-            return 4 * KGS * s + (wl < nw ? wl : nw - 1);
+        uint32_t *Xw = reinterpret_cast<uint32_t *>(Xr);
+        const float xscale = PREC == 2 ? __builtin_ldexpf(1.0f, a.e_act[0]) : 1.0f;   // fp8: features are stored as e4m3(sat(x 2^e_x))
+        auto slice_word = [&](int s) {  // this thread's record word in slice s; lanes past the slice (or, fp8, past the record: the zero pad
+            const int nw = WPG * (KG - KGS * s < KGS ? KG - KGS * s : KGS);  // up to a whole k-group) repeat the last valid word -- the same row
+            const int w = WPG * KGS * s + (wl < nw ? wl : nw - 1);           // as their neighbour, no extra line is fetched -- and never store it
+            return w < a.n_words ? w : a.n_words - 1;
         };
         auto I_op = [&](const HkTile &t, int s) {  // index loads of slice s
             const uint4 d = Dsc[slice_word(s)];
@@ -181,17 +214,24 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
                 r[i] = make_uint4(q.x, q.y, q.z, q.w);
             }
         };
-        auto W_op = [&](const HkTile &t, int s, const uint4 (&r)[IPT]) {  // slice s: fp32 rows -> bf16 -> X ring buffer s % 2
-            const int nw = 4 * (KG - KGS * s < KGS ? KG - KGS * s : KGS);  // words of this slice
+        auto W_op = [&](const HkTile &t, int s, const uint4 (&r)[IPT]) {  // slice s: fp32 rows -> bf16 / e4m3 -> X ring buffer s % 2
+            const int nw = WPG * (KG - KGS * s < KGS ? KG - KGS * s : KGS);  // words of this slice
             if (wl < nw) {
-                uint2 *xb = Xh2 + (size_t)(s & 1) * (XROWS * HK_LDX * 2);
+                const uint32_t real = 0u - (uint32_t)(WPG * KGS * s + wl < a.n_words);  // fp8: words past the record are the zero pad of its last k-group
 #pragma unroll
                 for (int i = 0; i < IPT; i++) {
-                    const uint32_t in = 0u - (uint32_t)(t.m0 + it0 + i < t.batch);  // all ones / zero: items past the batch are zero rows, branch-free
-                    uint2 hv;
-                    hv.x = pack_bf16x2(__uint_as_float(r[i].x), __uint_as_float(r[i].y)) & in;
-                    hv.y = pack_bf16x2(__uint_as_float(r[i].z), __uint_as_float(r[i].w)) & in;
-                    xb[((size_t)(wl >> 1) * HK_LDX + it0 + i) * 2 + (wl & 1)] = hv;  // slice word wl = half (wl & 1) of q8 row wl / 2
+                    const uint32_t in = (0u - (uint32_t)(t.m0 + it0 + i < t.batch)) & real;  // all ones / zero: items past the batch are zero rows, branch-free
+                    if constexpr (PREC == 1) {
+                        uint2 *xb = Xh2 + (size_t)(s & 1) * (XROWS * HK_LDX * 2);
+                        uint2 hv;
+                        hv.x = pack_bf16x2(__uint_as_float(r[i].x), __uint_as_float(r[i].y)) & in;
+                        hv.y = pack_bf16x2(__uint_as_float(r[i].z), __uint_as_float(r[i].w)) & in;
+                        xb[((size_t)(wl >> 1) * HK_LDX + it0 + i) * 2 + (wl & 1)] = hv;  // slice word wl = half (wl & 1) of q8 row wl / 2
+                    } else {
+                        // word wl = k 4 wl .. 4 wl + 3 of the slice: k-group wl / 8, step (wl % 8) / 4, lane half ((wl % 8) % 4) / 2, dword wl % 2
+                        uint32_t *xb = Xw + (size_t)(s & 1) * (XROWS * HK_LDX * 4);
+                        xb[((size_t)(2 * (wl >> 3) + ((wl >> 1) & 1)) * HK_LDX + it0 + i) * 4 + 2 * ((wl >> 2) & 1) + (wl & 1)] = pack_fp8_word(r[i], xscale) & in;
+                    }
                 }
             }
         };
@@ -232,20 +272,20 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
                     I_op(tref(s + 2 + D), (s + 2 + D) % NSL);
                 }
             }
-            bar(8);               // R1 stored, every consumer is past the last slice: X[1] is free
+            bar(NSL);             // R1 stored, every consumer is past the last slice: X[1] is free
             W_op(nxt, 1, rows[1 % D]);
             R_op(nxt, 1 + D, rows[1 % D]);
             I_op(nxt, 2 + D);
-            bar(9);               // FC2 done
-            bar(10);              // R2 stored
-            bar(11);              // R3 stored
-            bar(12);              // partial scores
+            bar(NSL + 1);         // FC2 done
+            bar(NSL + 2);         // R2 stored
+            bar(NSL + 3);         // R3 stored
+            bar(NSL + 4);         // partial scores
             tile_no++;
             if (!has_next) break;
             cur = nxt;
             t_cur = t_nxt;
         }
-        stamp(62);
+        stamp(126);
         if (bad) atomicOr_system(a.err_flag, 1);
         return;
     }
@@ -254,7 +294,15 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     // n1 / n2 / n3 and the lane offsets are re-declared opaque at the top of every tile: everything derived from them is tile-loop
     // invariant, and hoisted out of the loop the SGPR offsets of the weight stream alone spilled 200 scalars into vector registers
     unsigned n1 = (unsigned)(128 * wave) * 16u, n2 = (unsigned)(64 * wave) * 16u, n3 = (unsigned)(32 * wave) * 16u;
-    FtWk W1 = ftk_w(a.w1q, KG * 2, HK_H1, lane >> 5, lane & 31), W2 = ftk_w(a.w2q, HK_H1 / 8, HK_H2, lane >> 5, lane & 31), W3 = ftk_w(a.w3q, HK_H2 / 8, HK_H3, lane >> 5, lane & 31);
+    FtWk W1 = ftk_w(a.w1q, KG * 2, HK_H1, lane >> 5, lane & 31), W2 = ftk_w(a.w2q, KG2 * 2, HK_H2, lane >> 5, lane & 31), W3 = ftk_w(a.w3q, KG3 * 2, HK_H3, lane >> 5, lane & 31);
+    // fp8: the accumulators hold sums of (w 2^e_w)(x 2^e_x); the next activation is quantised as e4m3(sat(value 2^e_next)), so the store
+    // scales by 2^(e_next - e_w - e_x) -- powers of two, exact
+    const float os1 = PREC == 2 ? __builtin_ldexpf(1.0f, a.e_act[1] - a.e_w[0] - a.e_act[0]) : 1.0f, os2 = PREC == 2 ? __builtin_ldexpf(1.0f, a.e_act[2] - a.e_w[1] - a.e_act[1]) : 1.0f,
+                os3 = PREC == 2 ? __builtin_ldexpf(1.0f, a.e_act[3] - a.e_w[2] - a.e_act[2]) : 1.0f;
+    auto store_tile = [&](uint4 *img, const f32x16 &acc, int n_local, int m_local, int hk_, int lm_, float os) {
+        if constexpr (PREC == 1) hk_store_tile(img, acc, n_local, m_local, hk_, lm_);
+        else hk_store_tile_f8(img, acc, n_local, m_local, hk_, lm_, os);
+    };
     // The SGPR offset of a fragment is kept as a RUNNING value (one s_add per k-group) that is re-declared opaque once per slice / per
     // 8 k-groups: written as g * row2 + n1, hipcc computes dozens of them ahead of their loads and spills scalars into vector registers.
     unsigned so1 = 0, so2 = 0;   // byte offset of FC1's NEXT k-group; of the k-group FC2's current block of refills counts from
@@ -263,6 +311,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     uint4 ring1[R1D]; // FC1: the weight fragments of R1D / 4 k-groups (fragment 4 g + t in slot (4 g + t) % R1D), each refilled right after its second MFMA
     static_assert(R1D == 4 || R1D == 6 || R1D == 8, "one, one and a half or two k-groups of FC1 weights in registers");
     constexpr int RB = 16;  // FC2 / FC3: 16 fragments (their accumulators are 64 / 32 registers: room for a deep ring)
+    static_assert(2 * KG2 >= RB && KG3 >= 8 && KG2 % 8 == 0, "the FC2 / FC3 ring arithmetic below");
     uint4 ringb[RB];
     auto w1frag = [&](int q) {  // fragment q = 4 g + t of FC1, addressed from n1 (prologues only; the loop uses the running so1)
         return ftk_load(W1, n1 + (unsigned)(q >> 2) * W1.row2, 512 * (q & 3));
@@ -281,7 +330,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
         int tid_o = tid;     // lane geometry re-derived per tile from an opaque copy of the thread id: nothing of it is hoisted out of the tile loop
         asm volatile("" : "+v"(tid_o));
         const int hk = (tid_o >> 5) & 1, lm = tid_o & 31;
-        const unsigned xlane = (unsigned)(128 * HK_LD + hk * HK_LDX + lm);  // B-fragment lane base of FC1 (16-byte units): the X ring
+        const unsigned xlane = (unsigned)(2 * KG2 * HK_LD + hk * HK_LDX + lm);  // B-fragment lane base of FC1 (16-byte units): the X ring
 
         // ---- FC1, K-outer: 128 outputs x 64 items per wave ----
         f32x16 acc1[4][2];
@@ -306,9 +355,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
                 // Issue order inside a k-group (pinned by the sched_barriers): every fragment register is refilled for the next k-group right
                 // after its second MFMA and every B register right after its fourth, so each load has 5-6 MFMAs (plus the partner wave's)
                 // to land and no second register set is needed -- the consumers have 168 registers, 128 of them accumulators.
-                auto mm = [&](int t, int mt, const uint4 &b) {
-                    acc1[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring1[(4 * g + t) % R1D]), __builtin_bit_cast(bf16x8, b), acc1[t][mt], 0, 0, 0);
-                };
+                auto mm = [&](int t, int mt, const uint4 &b) { hk_mma<PREC>(acc1[t][mt], ring1[(4 * g + t) % R1D], b); };
                 // the slot of fragment q = 4 g + t takes fragment q + R1D: k-group g + (t + R1D) / 4 (so1 + ((t + R1D) / 4 - 1) row2), n tile (t + R1D) % 4
                 auto refill = [&](int t) {
                     const int q2 = 4 * g + t + R1D;
@@ -341,8 +388,8 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
 #pragma unroll
         for (int t = 0; t < 4; t++)
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++) hk_store_tile(R1, acc1[t][mt], 128 * wave + 32 * t, 32 * mt, hk, lm);
-        bar(8);           // R1 complete; the X ring is free (every consumer is past the last slice)
+            for (int mt = 0; mt < 2; mt++) store_tile(R1, acc1[t][mt], 128 * wave + 32 * t, 32 * mt, hk, lm, os1);
+        bar(NSL);         // R1 complete; the X ring is free (every consumer is past the last slice)
         const unsigned rlane = (unsigned)(hk * HK_LD + lm);  // B-fragment lane base of FC2 / FC3 (R1 / R2)
         f32x16 acc2[2][2];
 #pragma unroll
@@ -355,8 +402,8 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             const uint4 *bl = lds + rlane;
             uint4 b0 = bl[0], b1 = bl[32];
 #pragma unroll
-            for (int j = 0; j < 64; j++) {
-                const int jn = j + 1 < 64 ? j + 1 : j;
+            for (int j = 0; j < KG2; j++) {
+                const int jn = j + 1 < KG2 ? j + 1 : j;
                 const uint4 bn0 = bl[(size_t)(2 * jn) * HK_LD], bn1 = bl[(size_t)(2 * jn) * HK_LD + 32];
                 if (j % 8 == 0) {  // so2 = k-group j + RB / 2: the refills of this block of 8 k-groups are fragments 0 .. 15 past it
                     so2 = n2 + (unsigned)(j + RB / 2) * W2.row2;
@@ -365,20 +412,22 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
                     const int q = 2 * j + t;
-                    acc2[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ringb[q % RB]), __builtin_bit_cast(bf16x8, b0), acc2[t][0], 0, 0, 0);
-                    acc2[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ringb[q % RB]), __builtin_bit_cast(bf16x8, b1), acc2[t][1], 0, 0, 0);
-                    ringb[q % RB] = q + RB < 128 ? w2load(q - 16 * (j / 8)) : w3load(q + RB - 128);  // fragment q + RB = (q - 16 (j / 8)) past so2; FC2's tail: the first RB k-groups of W3
+                    hk_mma<PREC>(acc2[t][0], ringb[q % RB], b0);
+                    hk_mma<PREC>(acc2[t][1], ringb[q % RB], b1);
+                    // fragment q + RB = (q - 16 (j / 8)) past so2; FC2's tail requests W3's first k-groups (as many as it has, up to RB)
+                    if (q + RB < 2 * KG2) ringb[q % RB] = w2load(q - 16 * (j / 8));
+                    else if (q + RB - 2 * KG2 < KG3) ringb[q % RB] = w3load(q + RB - 2 * KG2);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 b0 = bn0, b1 = bn1;
             }
         }
-        bar(9);           // every wave is done reading R1: R2 may overlay it
+        bar(NSL + 1);     // every wave is done reading R1: R2 may overlay it
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++) hk_store_tile(R2, acc2[t][mt], 64 * wave + 32 * t, 32 * mt, hk, lm);
-        bar(10);
+            for (int mt = 0; mt < 2; mt++) store_tile(R2, acc2[t][mt], 64 * wave + 32 * t, 32 * mt, hk, lm, os2);
+        bar(NSL + 2);
 
         // ---- FC3: 32 outputs x 64 items per wave ----
         f32x16 acc3[2];
@@ -390,41 +439,58 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             const uint4 *bl = lds + rlane;  // R2 overlays R1
             uint4 b0 = bl[0], b1 = bl[32];
 #pragma unroll
-            for (int j = 0; j < 32; j++) {
-                const int jn = j + 1 < 32 ? j + 1 : j;
+            for (int j = 0; j < KG3; j++) {
+                const int jn = j + 1 < KG3 ? j + 1 : j;
                 const uint4 bn0 = bl[(size_t)(2 * jn) * HK_LD], bn1 = bl[(size_t)(2 * jn) * HK_LD + 32];
-                acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ringb[j % RB]), __builtin_bit_cast(bf16x8, b0), acc3[0], 0, 0, 0);
-                acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ringb[j % RB]), __builtin_bit_cast(bf16x8, b1), acc3[1], 0, 0, 0);
-                if (j + RB < 32) ringb[j % RB] = w3load(j + RB);
+                hk_mma<PREC>(acc3[0], ringb[j % RB], b0);
+                hk_mma<PREC>(acc3[1], ringb[j % RB], b1);
+                if (j + RB < KG3) ringb[j % RB] = w3load(j + RB);
                 __builtin_amdgcn_sched_barrier(0);
                 b0 = bn0, b1 = bn1;
             }
         }
         ring1_fill();  // the next tile's first k-group(s) of FC1: requested before the R3 store and the barriers
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++) hk_store_tile(R3, acc3[mt], 32 * wave, 32 * mt, hk, lm);
-        bar(11);
-        {   // score[m] = sum_n wout[n] * R3[n][m] (bf16 x bf16, fp32 sum): 64 items x 8 slices of 4 q8 rows, fixed-order reduction
+        for (int mt = 0; mt < 2; mt++) store_tile(R3, acc3[mt], 32 * wave, 32 * mt, hk, lm, os3);
+        bar(NSL + 3);
+        {   // score[m] = sum_n wout[n] * R3[n][m], fp32 sum: 64 items x 8 slices of the image's rows, fixed-order reduction
             const int il = tid_o & 63, sl = (tid_o >> 6) & 7;
-            const uint4 *wh = reinterpret_cast<const uint4 *>(a.wout);  // bf16 vector w[k], 8 per element
             float sc = 0.0f;
-            for (int q = 4 * sl; q < 4 * sl + 4; q++) {
-                const uint4 r = R3[(size_t)q * HK_LD + il];
-                const uint4 w = wh[q];
-                const uint32_t rr[4] = {r.x, r.y, r.z, r.w}, ww[4] = {w.x, w.y, w.z, w.w};
+            if constexpr (PREC == 1) {   // bf16 x bf16: 4 q8 rows per slice
+                const uint4 *wh = reinterpret_cast<const uint4 *>(a.wout);  // bf16 vector w[k], 8 per element
+                for (int q = 4 * sl; q < 4 * sl + 4; q++) {
+                    const uint4 r = R3[(size_t)q * HK_LD + il];
+                    const uint4 w = wh[q];
+                    const uint32_t rr[4] = {r.x, r.y, r.z, r.w}, ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    sc = fmaf(__uint_as_float(ww[e] << 16), __uint_as_float(rr[e] << 16), sc);
-                    sc = fmaf(__uint_as_float(ww[e] & 0xFFFF0000u), __uint_as_float(rr[e] & 0xFFFF0000u), sc);
+                    for (int e = 0; e < 4; e++) {
+                        sc = fmaf(__uint_as_float(ww[e] << 16), __uint_as_float(rr[e] << 16), sc);
+                        sc = fmaf(__uint_as_float(ww[e] & 0xFFFF0000u), __uint_as_float(rr[e] & 0xFFFF0000u), sc);
+                    }
+                }
+            } else {                     // fp32 master weights x decoded e4m3: 2 "q16h" rows per slice; byte b of (row 2 j + kh) is n = 32 j + 16 (b / 8) + 8 kh + b % 8
+                for (int row = 2 * sl; row < 2 * sl + 2; row++) {
+                    const uint4 r = R3[(size_t)row * HK_LD + il];
+                    const int rr[4] = {(int)r.x, (int)r.y, (int)r.z, (int)r.w};
+                    const float *w = a.wout + 32 * (row >> 1) + 8 * (row & 1);
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {   // dword d: step d / 2, positions 4 (d % 2) .. + 3
+                        const float *wd = w + 16 * (d >> 1) + 4 * (d & 1);
+                        sc = fmaf(wd[0], __builtin_amdgcn_cvt_f32_fp8(rr[d], 0), sc);
+                        sc = fmaf(wd[1], __builtin_amdgcn_cvt_f32_fp8(rr[d], 1), sc);
+                        sc = fmaf(wd[2], __builtin_amdgcn_cvt_f32_fp8(rr[d], 2), sc);
+                        sc = fmaf(wd[3], __builtin_amdgcn_cvt_f32_fp8(rr[d], 3), sc);
+                    }
                 }
             }
             part[sl * 64 + il] = sc;
-            bar(12);
+            bar(NSL + 4);
             const int tl = tid_o & 1023;  // (the opaque copy: the score address is computed here, not at the top of the tile)
             if (tl < 64 && cur.m0 + tl < cur.batch) {
                 float t = part[tl];
 #pragma unroll
                 for (int i = 1; i < 8; i++) t += part[i * 64 + tl];
+                if constexpr (PREC == 2) t *= __builtin_ldexpf(1.0f, -a.e_act[3]);
                 cur.scores[cur.m0 + tl] = t;
             }
         }
@@ -433,7 +499,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
         cur = tile_at(t_nxt);
         t_cur = t_nxt;
     }
-    stamp(62);
+    stamp(126);
 }
 
 // Every word descriptor must fit the packed 16-byte form: 48-bit source address, 16-bit row stride.
@@ -444,24 +510,38 @@ bool frk_fused_hk_ok(int K, int H1, int H2, int H3, const FrWordDesc *h_words, i
     return true;
 }
 
-template <int KG, int KGS, int LW, int D, int R1D>
+template <int PREC, int KG, int KGS, int LW, int D, int R1D>
 static int fused_hk_launch_inst(const FrFusedArgs &a, int n_cu, hipStream_t s) {
     static FrLdsAttrOnce lds_once;  // per instantiation, per device
-    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_hs_kernel<KG, KGS, LW, D, R1D>, lds_once)) return rc_;
-    const size_t lds = ((size_t)128 * HK_LD + (size_t)2 * 2 * KGS * HK_LDX + (size_t)a.n_words) * 16;
+    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, D, R1D>, lds_once)) return rc_;
+    const size_t r1_rows = 2 * (HK_H1 / (PREC == 2 ? 32 : 16));
+    const size_t lds = (r1_rows * HK_LD + (size_t)2 * 2 * KGS * HK_LDX + (size_t)a.n_words) * 16;
     const int tiles = a.n_batches * a.tiles_per_batch;
-    fr_fused_tile_hs_kernel<KG, KGS, LW, D, R1D><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(768), lds, s>>>(a);
-    fr_note_kernel("fr_fused_tile_hs_kernel<%d, %d, %d, %d, %d>", KG, KGS, LW, D, R1D);
+    fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, D, R1D><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(768), lds, s>>>(a);
+    fr_note_kernel("fr_fused_tile_hs_kernel<%d, %d, %d, %d, %d, %d>", PREC, KG, KGS, LW, D, R1D);
     KCHECK();
     return FR_OK;
 }
 
-// a.w1q/w2q/w3q/wout point at the bf16 q8 weights; a.tiles_per_batch counts 64-item tiles; one persistent workgroup per CU
-int frk_fused_hk_launch(const FrFusedArgs &a, int n_cu, hipStream_t s) {
+// a.w1q/w2q/w3q point at the bf16 q8 weights (+ a.wout the bf16 output vector) or at the e4m3 "q16h" weights (+ fp32 a.wout, a.e_w /
+// a.e_act the exponents); a.blist the launch's batches in device memory; a.tiles_per_batch counts 64-item tiles; one persistent
+// workgroup per CU
+int frk_fused_hk_launch(const FrFusedArgs &a, int n_cu, int precision, hipStream_t s) {
+    if (precision == FR_FC_FP8) {
+        // The fp8 form is built into the EXPERIMENTS library only: it is correct (tests/test_gpu_parity.py::test_fp8_persistent_fused_kernel_many_tiles
+        // under FR_LIB=libfleetrec_exp.so FR_FUSED_HK=1) and SLOWER than the chunked fr_fused_tile_f8_kernel (Model-B 1024: 312-315 vs
+        // 384-385 M inf/s, profiles/r03_fused_hs_fp8_ab.txt) -- with the consumers twice as fast as in bf16, the gather, which only runs
+        // under FC1, is what a tile waits for.
 #ifdef FR_EXPERIMENTS
-    if (a.K == 880 && FR_KNOB_ONCE("FUSED_R1D", 6) == 4) return fused_hk_launch_inst<55, 7, 32, 2, 4>(a, n_cu, s);
+        if (a.K == 880) return fused_hk_launch_inst<2, 28, 2, 16, 2, 4>(a, n_cu, s);   // Model-B: K 880 -> 896 = 28 k-groups of 32, 14 slices of 2
+        if (a.K == 352) return fused_hk_launch_inst<2, 11, 2, 16, 3, 4>(a, n_cu, s);   // Model-A: K 352 = 11 k-groups of 32, 6 slices of 2 (1)
 #endif
-    if (a.K == 880) return fused_hk_launch_inst<55, 7, 32, 2, 6>(a, n_cu, s);   // Model-B: 8 slices of 7 (6) k-groups, 2 row sets in flight, 6 FC1 fragments
-    if (a.K == 352) return fused_hk_launch_inst<22, 4, 16, 3, 4>(a, n_cu, s);   // Model-A: 6 slices of 4 (2) k-groups, 3 row sets in flight, 4 FC1 fragments
+        FR_FAIL(FR_ERR_INVALID, "no K-outer fp8 fused instantiation for K=%d in this build", a.K);
+    }
+#ifdef FR_EXPERIMENTS
+    if (a.K == 880 && FR_KNOB_ONCE("FUSED_R1D", 6) == 4) return fused_hk_launch_inst<1, 55, 7, 32, 2, 4>(a, n_cu, s);
+#endif
+    if (a.K == 880) return fused_hk_launch_inst<1, 55, 7, 32, 2, 6>(a, n_cu, s);   // Model-B: 8 slices of 7 (6) k-groups, 2 row sets in flight, 6 FC1 fragments
+    if (a.K == 352) return fused_hk_launch_inst<1, 22, 4, 16, 3, 4>(a, n_cu, s);   // Model-A: 6 slices of 4 (2) k-groups, 3 row sets in flight, 4 FC1 fragments
     FR_FAIL(FR_ERR_INVALID, "no K-outer bf16 fused instantiation for K=%d", a.K);
 }

@@ -200,6 +200,7 @@ struct fr_ctx {
     uint16_t *d_w_bf16[4] = {nullptr, nullptr, nullptr, nullptr};
     // fp8 chain: e4m3 q16 copies of FC1..FC3 and the power-of-two exponents (weights per layer; activations X, R1, R2, R3)
     void *d_w_fp8[3] = {nullptr, nullptr, nullptr};
+    void *d_w_fp8h[3] = {nullptr, nullptr, nullptr};  // the same weights in the "q16h" layout of the non-scaled fp8 MFMA (fr_fused_tile_hs_kernel<2, ...>); fused-eligible models only
     int f8_e_w[3] = {0, 0, 0};
     int f8_e_act[4] = {0, 0, 0, 0};
     float f8_w_rms_gain[3] = {1.0f, 1.0f, 1.0f};  // ||W_l||_F / sqrt(N_l): rms growth of layer l under uncorrelated inputs
@@ -311,6 +312,7 @@ bool frk_fc_lp_gemm_ok(int precision, int K, int N, int ldm);
 int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, hipStream_t s);
 int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, hipStream_t s);
 int frk_pack_weights_q16_fp8(const float *W, void *Wf, int K, int H, int e_w, hipStream_t s);
+int frk_pack_weights_q16h_fp8(const float *W, void *Wg, int K, int H, int e_w, hipStream_t s);  // the persistent fp8 kernel's operand layout
 int frk_records_to_q16_fp8(const float *X, void *Xf, int batch, int K, int ldm, int e_x, hipStream_t s);
 int frk_stats(const float *p, size_t n, void *d_out, hipStream_t s);
 int frk_q4_to_lp(int precision, const float *Xq, void *Xo, int K, int ldm, int e_x, hipStream_t s);
@@ -328,8 +330,8 @@ bool frk_fused_f8_ok(int K, int H1, int H2, int H3);
 int frk_fused_f8_launch(const FrFusedArgs &a, hipStream_t s);
 int frk_fused_h_items_per_wg();
 int frk_fused_h_launch(const FrFusedArgs &a, hipStream_t s);
-bool frk_fused_hk_ok(int K, int H1, int H2, int H3, const FrWordDesc *h_words, int n_words);  // the K-outer persistent bf16 kernel (fr_fused_ko.hip)
-int frk_fused_hk_launch(const FrFusedArgs &a, int n_cu, hipStream_t s);  // 0 when the transposing gather does not apply
+bool frk_fused_hk_ok(int K, int H1, int H2, int H3, const FrWordDesc *h_words, int n_words);  // the K-outer persistent kernel (fr_fused_ko.hip), bf16 and fp8 forms
+int frk_fused_hk_launch(const FrFusedArgs &a, int n_cu, int precision, hipStream_t s);  // 0 when the transposing gather does not apply
 int frk_transpose_records(const float *X, float *Xt, int batch, int K, int ldm, hipStream_t s);
 int frk_transpose_slices(const float *gathered, int n_shards, int batch_total, int slice_padded, const int *h_offsets, const int *h_lens,
                          int item0, int n_items, float *Xq, int ldm, hipStream_t s);
