@@ -196,6 +196,11 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             for (int i = 0; i < IPT; i++)   // items past the batch: out of the resource's bounds, 0 comes back (no branch)
                 idxr[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)(t.m0 + it0 + i) * (unsigned)a.idx_stride * 4u + (d.w & 0x7FFFFFFFu), 0, 0);
         };
+#ifdef FR_EXPERIMENTS
+        const bool no_rows = PREC == 1 && a.e_act[3] == -777;   // timing ablation (FR_FUSED_HS_ABLATE=1, wrong scores): the producers load no rows -- the consumers' own pace
+#else
+        constexpr bool no_rows = false;
+#endif
         auto R_op = [&](const HkTile &t, int s, uint4 (&r)[IPT]) {  // row loads of slice s (its indices are in idxr)
             const uint4 d = Dsc[slice_word(s)];
             const bool dense = (d.w >> 31) != 0;
@@ -209,6 +214,10 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
                 bad |= oob ? 1u : 0u;
                 x = oob ? 0u : x;
                 x = dense ? (m < (unsigned)t.batch ? m : 0u) : x;
+                if (no_rows) {
+                    r[i] = make_uint4(x, x, x, x);
+                    continue;
+                }
                 typedef const u32x4_t __attribute__((address_space(1))) * gptr_t;
                 const u32x4_t q = *(gptr_t)(base + (uint64_t)x * stride);
                 r[i] = make_uint4(q.x, q.y, q.z, q.w);

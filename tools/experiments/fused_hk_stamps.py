@@ -23,7 +23,7 @@ for rep in range(200):
     for i in range(NB):
         wk.push_device(B, pool[i % 16], None, sc[i % 64])
 wk.sync()
-NST = 12 * 256 * 64
+NST = 12 * 256 * 128
 stamps = fr.DeviceBuffer(ctx, NST * 8)
 stamps.upload(np.zeros(NST, np.uint64))
 lib = fr.lib()
@@ -33,28 +33,27 @@ for i in range(NB):
     wk.push_device(B, pool[i % 16], None, sc[i % 64])
 wk.sync()
 lib.fr_debug_set_stamp_buffer(None)
-sw = stamps.download(np.uint64, NST)[:12 * 64 * NWG].reshape(NWG, 12, 64).astype(np.int64)   # [workgroup][wave][slot]
+sw = stamps.download(np.uint64, NST)[:12 * 128 * NWG].reshape(NWG, 12, 128).astype(np.int64)   # [workgroup][wave][slot]
+NBAR = NSL + 5
 t0 = sw[:, :, 0].min(axis=1)                       # the workgroup's first wave start
 rel = lambda x: (x - t0[:, None]) / 100.0          # us since the workgroup started
-end = rel(sw[:, :, 62])
+end = rel(sw[:, :, 126])
 print("model %s, %d batches per launch = %d tiles on %d workgroups (%.1f tiles each); launch span %.1f us, workgroup end median %.1f us" % (
-    which, NB, tiles, NWG, tiles / NWG, (sw[:, :, 62].max() - sw[:, :, 0].min()) / 100.0, np.median(end.max(axis=1))))
+    which, NB, tiles, NWG, tiles / NWG, (sw[:, :, 126].max() - sw[:, :, 0].min()) / 100.0, np.median(end.max(axis=1))))
 print("set-up done (descriptors in LDS, rings / prologue): consumers %.1f us, producers (tile 0 slices 0, 1 in LDS, D more requested) see barrier 0" % np.median(rel(sw[:, :8, 1]).max(axis=1)))
-names = ["slice %d" % s for s in range(NSL)] + [None] * (8 - NSL) + ["R1 stored", "FC2 done", "R2 stored", "R3 stored", "partials"]
+names = ["slice %d" % s for s in range(NSL)] + ["R1 stored", "FC2 done", "R2 stored", "R3 stored", "partials"]
 for tile in range(2):
     if tiles / NWG <= tile:
         break
     print("tile %d: barrier            consumers arrive   producers arrive   released   (median over workgroups of the LAST wave of each role, us)" % tile)
     prev = None
     for b, nme in enumerate(names):
-        if nme is None:
-            continue
-        arr = rel(sw[:, :, 4 + 28 * tile + 2 * b]); out = rel(sw[:, :, 5 + 28 * tile + 2 * b])
+        arr = rel(sw[:, :, 4 + 2 * NBAR * tile + 2 * b]); out = rel(sw[:, :, 5 + 2 * NBAR * tile + 2 * b])
         ca, pa, ro = np.median(arr[:, :8].max(axis=1)), np.median(arr[:, 8:].max(axis=1)), np.median(out.max(axis=1))
         print("        %-18s %8.1f %s        %8.1f %s        %8.1f   %s" % (nme, ca, "*" if ca >= pa else " ", pa, "*" if pa > ca else " ", ro, "" if prev is None else "(+%.1f)" % (ro - prev)))
         prev = ro
 cyc = (sw[:, :8, 3] - sw[:, :8, 2]).astype(np.float64)
-fc1 = (sw[:, :8, 4 + 2 * 8] - sw[:, :8, 5]).astype(np.float64)   # release of barrier 0 .. arrival at "R1 stored" of tile 0 (10 ns ticks)
+fc1 = (sw[:, :8, 4 + 2 * NSL] - sw[:, :8, 5]).astype(np.float64)   # release of barrier 0 .. arrival at "R1 stored" of tile 0 (10 ns ticks)
 kg = 55 if which == "B" else 22
 print("in-kernel clock over FC1 of tile 0: %.3f GHz; shader cycles there: %.0f (MFMA work per SIMD: 2 waves x %d x 8 x 32 = %d)" % (
     np.median(cyc / np.maximum(fc1, 1) * 0.1), np.median(cyc), kg, 2 * kg * 8 * 32))
