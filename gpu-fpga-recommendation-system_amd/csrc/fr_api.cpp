@@ -1105,7 +1105,7 @@ static int fused_flush(fr_worker *w) {
             a.blist = db;
             a.n_batches = n_all;
             a.tiles_per_batch = max_tiles;
-            if (bf16 && FR_KNOB_ONCE("FUSED_HS_ABLATE", 0)) a.e_act[3] = -777;   // experiments build: the kernel's no-row-loads timing ablation
+            if (bf16 && FR_KNOB_ONCE("FUSED_HS_ABLATE", 0)) a.e_act[3] = -776 - FR_KNOB_ONCE("FUSED_HS_ABLATE", 0);   // experiments build: the kernel's timing ablations (1: no row loads, 2: every row load reads row 0)
             if (fp8) {  // the "q16h" copies of the weights (the non-scaled fp8 MFMA's operand layout)
                 a.w1q = reinterpret_cast<const float4 *>(c->d_w_fp8h[0]);
                 a.w2q = reinterpret_cast<const float4 *>(c->d_w_fp8h[1]);

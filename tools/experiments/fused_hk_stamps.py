@@ -34,26 +34,47 @@ for i in range(NB):
 wk.sync()
 lib.fr_debug_set_stamp_buffer(None)
 sw = stamps.download(np.uint64, NST)[:12 * 128 * NWG].reshape(NWG, 12, 128).astype(np.int64)   # [workgroup][wave][slot]
-NBAR = NSL + 5
-t0 = sw[:, :, 0].min(axis=1)                       # the workgroup's first wave start
+NBAR = NSL + 7
+t0 = sw[:, 8:, 0].min(axis=1)                      # the workgroup's first wave start
 rel = lambda x: (x - t0[:, None]) / 100.0          # us since the workgroup started
-end = rel(sw[:, :, 126])
+end = rel(sw[:, 8:, 126])
 print("model %s, %d batches per launch = %d tiles on %d workgroups (%.1f tiles each); launch span %.1f us, workgroup end median %.1f us" % (
-    which, NB, tiles, NWG, tiles / NWG, (sw[:, :, 126].max() - sw[:, :, 0].min()) / 100.0, np.median(end.max(axis=1))))
-print("set-up done (descriptors in LDS, rings / prologue): consumers %.1f us, producers (tile 0 slices 0, 1 in LDS, D more requested) see barrier 0" % np.median(rel(sw[:, :8, 1]).max(axis=1)))
-names = ["slice %d" % s for s in range(NSL)] + ["R1 stored", "FC2 done", "R2 stored", "R3 stored", "partials"]
+    which, NB, tiles, NWG, tiles / NWG, (sw[:, 8:, 126].max() - sw[:, 8:, 0].min()) / 100.0, np.median(end.max(axis=1))))
+cons = bool(sw[:, :8, 126].any())   # the consumers stamp only in a -DFR_STAMP_CONSUMERS build (their code is then not the product's)
+if cons:
+    print("set-up done (descriptors in LDS, rings / prologue): consumers %.1f us" % np.median(rel(sw[:, :8, 1]).max(axis=1)))
+names = ["slice %d" % s for s in range(NSL)] + ["R1 stored", "FC2 1/4", "FC2 1/2", "FC2 done", "R2 stored", "R3 stored", "partials"]
 for tile in range(2):
     if tiles / NWG <= tile:
         break
-    print("tile %d: barrier            consumers arrive   producers arrive   released   (median over workgroups of the LAST wave of each role, us)" % tile)
+    print("tile %d: barrier            %sproducers arrive   released   producers waited   (median over workgroups of the LAST wave of each role, us)" % (tile, "consumers arrive   " if cons else ""))
     prev = None
     for b, nme in enumerate(names):
         arr = rel(sw[:, :, 4 + 2 * NBAR * tile + 2 * b]); out = rel(sw[:, :, 5 + 2 * NBAR * tile + 2 * b])
-        ca, pa, ro = np.median(arr[:, :8].max(axis=1)), np.median(arr[:, 8:].max(axis=1)), np.median(out.max(axis=1))
-        print("        %-18s %8.1f %s        %8.1f %s        %8.1f   %s" % (nme, ca, "*" if ca >= pa else " ", pa, "*" if pa > ca else " ", ro, "" if prev is None else "(+%.1f)" % (ro - prev)))
+        pa, ro = np.median(arr[:, 8:].max(axis=1)), np.median(out[:, 8:].max(axis=1))
+        wait = np.median(out[:, 8:].max(axis=1) - arr[:, 8:].max(axis=1))
+        ctext = ""
+        if cons:
+            ca = np.median(arr[:, :8].max(axis=1))
+            ctext = "%8.1f %s        " % (ca, "*" if ca >= pa else " ")
+        print("        %-18s %s%8.1f        %8.1f   %8.1f       %s" % (nme, ctext, pa, ro, wait, "" if prev is None else "(+%.1f)" % (ro - prev)))
         prev = ro
-cyc = (sw[:, :8, 3] - sw[:, :8, 2]).astype(np.float64)
-fc1 = (sw[:, :8, 4 + 2 * NSL] - sw[:, :8, 5]).astype(np.float64)   # release of barrier 0 .. arrival at "R1 stored" of tile 0 (10 ns ticks)
-kg = 55 if which == "B" else 22
-print("in-kernel clock over FC1 of tile 0: %.3f GHz; shader cycles there: %.0f (MFMA work per SIMD: 2 waves x %d x 8 x 32 = %d)" % (
-    np.median(cyc / np.maximum(fc1, 1) * 0.1), np.median(cyc), kg, 2 * kg * 8 * 32))
+if cons:
+    cyc = (sw[:, :8, 3] - sw[:, :8, 2]).astype(np.float64)
+    fc1 = (sw[:, :8, 4 + 2 * NSL] - sw[:, :8, 5]).astype(np.float64)   # release of barrier 0 .. arrival at "R1 stored" of tile 0 (10 ns ticks)
+    kg = 55 if which == "B" else 22
+    print("in-kernel clock over FC1 of tile 0: %.3f GHz; shader cycles there: %.0f (MFMA work per SIMD: 2 waves x %d x 8 x 32 = %d)" % (
+        np.median(cyc / np.maximum(fc1, 1) * 0.1), np.median(cyc), kg, 2 * kg * 8 * 32))
+
+if sw[:, 8:, 64].any():   # inside the producers' slots of tile 1 (us after the slot's barrier released; median over workgroups of the last producer wave)
+    fire = {0: 1, 1: 2}
+    for u in range(2, NSL - 4): fire[u] = u + 3
+    fire[NSL - 4] = NSL - 1
+    for k in range(1, 4): fire[NSL - 4 + k] = NSL - 1 + k
+    print("tile 1, producers' slots: after the barrier ->  indices requested   slice written (= its rows had landed)   rows requested")
+    for u in range(NSL):
+        if 66 + 4 * u >= 126: break
+        b = fire[u]
+        t_rel = sw[:, 8:, 5 + 2 * NBAR * 1 + 2 * b]
+        d = [np.median(((sw[:, 8:, 64 + 4 * u + k] - t_rel) / 100.0).max(axis=1)) for k in range(3)]
+        print("        slot %d (barrier %-9s)      %6.2f               %6.2f                                %6.2f" % (u, names[b], d[0], d[1], d[2]))
