@@ -92,9 +92,9 @@ __device__ __forceinline__ void hk_mma(f32x16 &acc, const uint4 &a4, const uint4
 // PREC = 1 bf16 (q8 operands), 2 fp8 (e4m3 "q16h" operands on the NON-scaled fp8 MFMA: operand registers as in bf16 -- the scaled
 // 32x32x64 form needs 8 registers per fragment, which the consumers' 168 do not have beside 128 accumulators; the power-of-two
 // exponents are folded into the scale of the next activation's quantisation, exactly).  KG = k-groups of the (zero-padded) record (16 k
-// each in bf16, 32 k in fp8); KGS = k-groups per slice; LW = producer lanes along the record words of a slice (16 or 32); R1D = FC1 weight
-// fragments in registers.  A producer thread keeps D = 2 row sets (slices) in flight.
-template <int PREC, int KG, int KGS, int LW, int R1D>
+// each in bf16, 32 k in fp8); KGS = k-groups per slice; LW = producer lanes along the record words of a slice (16 or 32); D = row sets
+// a producer thread keeps in flight (NSL % D == 0: the set of a slice is a compile-time index); R1D = FC1 weight fragments in registers.
+template <int PREC, int KG, int KGS, int LW, int D, int R1D>
 __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs a) {
     extern __shared__ uint4 lds[];
     constexpr int WPG = PREC == 2 ? 8 : 4;             // record words (4 floats each) per k-group
@@ -103,26 +103,15 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     constexpr int NSL = (KG + KGS - 1) / KGS;          // slices per tile
     constexpr int IPT = LW / 4;                        // items per producer thread (256 threads = LW words x 64 / IPT item slots)
     constexpr int XROWS = 2 * KGS;                     // operand rows of one X ring buffer
-    constexpr int D = 2;                               // row sets (slices) a producer thread keeps in flight
-    constexpr int NBAR = NSL + 7;                      // barriers per tile (stamp slots): NSL steps, R1 stored, two inside FC2, FC2 done, R2, R3, partial scores
-    static_assert(NSL % 2 == 0 && NSL >= 6, "two X buffers alternate; the production schedule below needs slices 4, 5 and a next tile's 0 .. 3");
+    constexpr int NBAR = NSL + 5;                      // barriers per tile (stamp slots)
+    static_assert(NSL % 2 == 0 && NSL % D == 0 && NSL >= D + 3, "two X buffers, D row sets, and the run-ahead stays inside the next tile");
     static_assert(WPG * KGS <= LW && (LW == 16 || LW == 32), "a slice's record words ride the lanes of one half / quarter wave");
-    // LDS map, in 16-byte units.  Region A = the R1 image's rows ([2 KG2][64]: bf16 128 KiB, fp8 64 KiB).  Besides R1 it holds, at other
-    // times of a tile: the two PARKED slices P0, P1 of the NEXT tile (rows 0 .. PROWS - 1, written by the producers once FC2 has consumed
-    // those R1 rows; read by the next tile's FC1 steps 2 and 3), the partial scores (2 rows behind them), R2 (rows 32 ..) and R3.
-    constexpr int XBUF = XROWS * HK_LDX;               // one slice buffer (X0, X1, P0, P1 all have this shape)
-    constexpr int PROWS = (2 * XBUF + HK_LD - 1) / HK_LD;   // R1 rows the two parked slices cover
-    constexpr int R2_ROW = 32, R3_ROW = PREC == 1 ? 96 : 16, PART_ROW = PROWS;
-    static_assert(PART_ROW + 2 <= (PREC == 1 ? R2_ROW : R3_ROW) && R2_ROW + 2 * KG3 <= 2 * KG2 && R3_ROW + 2 * KG4 <= (PREC == 1 ? 2 * KG2 : R2_ROW), "region A overlays");
-    static_assert(PROWS <= 2 * (KG2 / 4) - 2, "the parked slices' rows are consumed by FC2's first quarter (its fragments are read one k-group ahead)");
-    uint4 *R1 = lds;                                   // [2 KG2][64]
-    uint4 *R2 = lds + R2_ROW * HK_LD;                  // [2 KG3][64], written once FC2 has read all of R1
-    uint4 *R3 = lds + R3_ROW * HK_LD;                  // [2 KG4][64]
-    float *part = reinterpret_cast<float *>(lds + PART_ROW * HK_LD);  // 8 x 64 partial scores
-    constexpr int XOFF = 2 * KG2 * HK_LD;              // X0, X1 follow region A
-    uint4 *Dsc = lds + XOFF + 2 * XBUF;                // [n_words] packed descriptors
-    // where slice s of a tile lives: 0, 1 -> X0, X1; 2, 3 -> P0, P1 (parked in region A by the previous tile's producers); s >= 4 -> X[s % 2]
-    auto slice_off = [](int s) constexpr { return s < 2 ? XOFF + s * XBUF : (s < 4 ? (s - 2) * XBUF : XOFF + (s & 1) * XBUF); };
+    uint4 *R1 = lds;                                   // [2 KG2][64]: bf16 128 KiB, fp8 64 KiB
+    uint4 *R2 = lds;                                   // [2 KG3][64], overlays R1 once FC2 has read it
+    uint4 *R3 = lds + 2 * KG3 * HK_LD;                 // [2 KG4][64]
+    float *part = reinterpret_cast<float *>(lds + (2 * KG3 + 2 * KG4) * HK_LD);  // 8 x 64 partial scores
+    uint4 *Xr = lds + 2 * KG2 * HK_LD;                 // [2][XROWS][65]
+    uint4 *Dsc = Xr + 2 * XROWS * HK_LDX;              // [n_words] packed descriptors
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wave >= 8;                   // waves 8..11: one per SIMD beside two consumers (waves are dealt to SIMDs cyclically)
@@ -201,34 +190,35 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     if (producer) {
         // =========================================== PRODUCERS: the gather ===========================================
         int wl = 0, it0 = 0;                        // word of the slice this thread moves; first of its IPT items inside the tile
-        uint32_t idxr[2][IPT];                      // index values of the two slices whose rows are loaded next (set = production index % 2)
+        uint32_t idxr[IPT];                         // index values of the slice whose rows are loaded next
         uint4 rows[D][IPT];                         // row words in flight: D slices
         unsigned bad = 0u;                          // out-of-range index seen (a lane flag, OR-ed: no compare mask is kept)
-        uint2 *Xh2 = reinterpret_cast<uint2 *>(lds);
-        uint32_t *Xw = reinterpret_cast<uint32_t *>(lds);
+        uint2 *Xh2 = reinterpret_cast<uint2 *>(Xr);
+        uint32_t *Xw = reinterpret_cast<uint32_t *>(Xr);
         const float xscale = PREC == 2 ? __builtin_ldexpf(1.0f, a.e_act[0]) : 1.0f;   // fp8: features are stored as e4m3(sat(x 2^e_x))
         auto slice_word = [&](int s) {  // this thread's record word in slice s; lanes past the slice (or, fp8, past the record: the zero pad
             const int nw = WPG * (KG - KGS * s < KGS ? KG - KGS * s : KGS);  // up to a whole k-group) repeat the last valid word -- the same row
             const int w = WPG * KGS * s + (wl < nw ? wl : nw - 1);           // as their neighbour, no extra line is fetched -- and never store it
             return w < a.n_words ? w : a.n_words - 1;
         };
-        auto I_op = [&](const HkTile &t, int s, uint32_t (&ix)[IPT]) {  // index loads of slice s
+        auto I_op = [&](const HkTile &t, int s) {  // index loads of slice s
             const uint4 d = Dsc[slice_word(s)];
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(t.idx), 0, (unsigned)t.batch * (unsigned)a.idx_stride * 4u, 0x00020000);
 #pragma unroll
             for (int i = 0; i < IPT; i++)   // items past the batch: out of the resource's bounds, 0 comes back (no branch)
-                ix[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)(t.m0 + it0 + i) * (unsigned)a.idx_stride * 4u + (d.w & 0x7FFFFFFFu), 0, 0);
+                idxr[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)(t.m0 + it0 + i) * (unsigned)a.idx_stride * 4u + (d.w & 0x7FFFFFFFu), 0, 0);
         };
 #ifdef FR_EXPERIMENTS
-        const bool no_rows = PREC == 1 && a.e_act[3] == -777;   // timing ablation (FR_FUSED_HS_ABLATE=1, wrong scores): the producers load no rows -- the consumers' own pace
-        const bool nt_rows = PREC == 1 && a.e_act[3] == -779;   // FR_FUSED_HS_ABLATE=3 (right scores): the row loads carry the non-temporal hint
-        // FR_FUSED_HS_ABLATE=4 / 5 / 6 / 7 (wrong scores): row 0 for the tables of >= 10 M / 1 M / 500 k / 100 k rows only
-        const uint32_t zero_above = PREC != 1 ? 0u : a.e_act[3] == -780 ? 10000000u : a.e_act[3] == -781 ? 1000000u : a.e_act[3] == -782 ? 500000u : a.e_act[3] == -783 ? 100000u : 0u;
-        const bool row_zero = PREC == 1 && a.e_act[3] == -778;  // timing ablation (FR_FUSED_HS_ABLATE=2, wrong scores): every row load reads row 0 of its table -- the same instructions, all cache hits
+        // timing ablations (FR_FUSED_HS_ABLATE, wrong scores).  1: the producers load no rows -- the consumers' own pace.  2: every row load reads
+        // row 0 of its table (the same instructions; all lanes of a table share one line).  4 / 5 / 6 / 7: row 0 for the tables of >= 10 M / 1 M /
+        // 500 k / 100 k rows only (which table class the producers wait for)
+        const bool no_rows = PREC == 1 && a.e_act[3] == -777;
+        const uint32_t zero_above = PREC != 1 ? 0u : a.e_act[3] == -778 ? 1u : a.e_act[3] == -780 ? 10000000u : a.e_act[3] == -781 ? 1000000u : a.e_act[3] == -782 ? 500000u : a.e_act[3] == -783 ? 100000u : 0u;
 #else
-        constexpr bool no_rows = false, row_zero = false;
+        constexpr bool no_rows = false;
+        constexpr uint32_t zero_above = 0u;
 #endif
-        auto R_op = [&](const HkTile &t, int s, uint4 (&r)[IPT], const uint32_t (&ix)[IPT]) {  // row loads of slice s (its indices are in ix)
+        auto R_op = [&](const HkTile &t, int s, uint4 (&r)[IPT]) {  // row loads of slice s (its indices are in idxr)
             const uint4 d = Dsc[slice_word(s)];
             const bool dense = (d.w >> 31) != 0;
             const uint64_t base = (((uint64_t)(d.y & 0xFFFFu) << 32) | d.x) + (dense ? (uint64_t)reinterpret_cast<uintptr_t>(t.dense) : 0ull);
@@ -236,29 +226,22 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
 #pragma unroll
             for (int i = 0; i < IPT; i++) {
                 const unsigned m = (unsigned)(t.m0 + it0 + i);
-                uint32_t x = ix[i];
+                uint32_t x = idxr[i];
                 const bool oob = !dense & (x >= nrows);  // reference: silent out-of-bounds read (embedding_47_krnl.cpp:927-933); here reported
                 bad |= oob ? 1u : 0u;
                 x = oob ? 0u : x;
                 x = dense ? (m < (unsigned)t.batch ? m : 0u) : x;
-                if (row_zero) x = 0u;
-#ifdef FR_EXPERIMENTS
                 if (zero_above && nrows >= zero_above) x = 0u;
-#endif
                 if (no_rows) {
                     r[i] = make_uint4(x, x, x, x);
                     continue;
                 }
                 typedef const u32x4_t __attribute__((address_space(1))) * gptr_t;
-#ifdef FR_EXPERIMENTS
-                const u32x4_t q = nt_rows ? __builtin_nontemporal_load((gptr_t)(base + (uint64_t)x * stride)) : *(gptr_t)(base + (uint64_t)x * stride);
-#else
                 const u32x4_t q = *(gptr_t)(base + (uint64_t)x * stride);
-#endif
                 r[i] = make_uint4(q.x, q.y, q.z, q.w);
             }
         };
-        auto W_op = [&](const HkTile &t, int s, const uint4 (&r)[IPT]) {  // slice s: fp32 rows -> bf16 / e4m3 -> its buffer (slice_off)
+        auto W_op = [&](const HkTile &t, int s, const uint4 (&r)[IPT]) {  // slice s: fp32 rows -> bf16 / e4m3 -> X ring buffer s % 2
             const int nw = WPG * (KG - KGS * s < KGS ? KG - KGS * s : KGS);  // words of this slice
             if (wl < nw) {
                 const uint32_t real = 0u - (uint32_t)(WPG * KGS * s + wl < a.n_words);  // fp8: words past the record are the zero pad of its last k-group
@@ -266,102 +249,68 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
                 for (int i = 0; i < IPT; i++) {
                     const uint32_t in = (0u - (uint32_t)(t.m0 + it0 + i < t.batch)) & real;  // all ones / zero: items past the batch are zero rows, branch-free
                     if constexpr (PREC == 1) {
-                        uint2 *xb = Xh2 + (size_t)slice_off(s) * 2;
+                        uint2 *xb = Xh2 + (size_t)(s & 1) * (XROWS * HK_LDX * 2);
                         uint2 hv;
                         hv.x = pack_bf16x2(__uint_as_float(r[i].x), __uint_as_float(r[i].y)) & in;
                         hv.y = pack_bf16x2(__uint_as_float(r[i].z), __uint_as_float(r[i].w)) & in;
                         xb[((size_t)(wl >> 1) * HK_LDX + it0 + i) * 2 + (wl & 1)] = hv;  // slice word wl = half (wl & 1) of q8 row wl / 2
                     } else {
                         // word wl = k 4 wl .. 4 wl + 3 of the slice: k-group wl / 8, step (wl % 8) / 4, lane half ((wl % 8) % 4) / 2, dword wl % 2
-                        uint32_t *xb = Xw + (size_t)slice_off(s) * 4;
+                        uint32_t *xb = Xw + (size_t)(s & 1) * (XROWS * HK_LDX * 4);
                         xb[((size_t)(2 * (wl >> 3) + ((wl >> 1) & 1)) * HK_LDX + it0 + i) * 4 + 2 * ((wl >> 2) & 1) + (wl & 1)] = pack_fp8_word(r[i], xscale) & in;
                     }
                 }
             }
         };
-        // PRODUCTION ORDER of a tile's NSL gather slots: u = 0 .. NSL - 5 are the tile's own slices 4 .. NSL - 1 (slices 0 .. 3 were produced
-        // during the previous tile), u = NSL - 4 .. NSL - 1 the NEXT tile's slices 0 .. 3.  Slot u = request the indices of slot u + 3, write
-        // slot u's slice (rows requested two slots ago, register set u % 2), request the rows of slot u + 2 into the freed set.  IN THAT
-        // ORDER: a wave's vector-memory counter retires in order, so a wait for the indices of slot u + 2 (requested one slot ago) also waits
-        // for everything requested before them -- with the index request issued BEFORE its slot's row request, that is only the rows of slot
-        // u (needed now anyway); issued after (rounds 3's first form), every slot waited out the full latency of the previous slot's rows.
-        // A slot fires at the barrier after which its destination is free:
-        //   own slice j = 4, 5 -> X[j % 2] once slices 0, 1 are consumed: steps 1, 2;   own slice j >= 6 -> X[j % 2] once slice j - 2 is: step j - 1;
-        //   next 0 -> X0 at step NSL - 1;  next 1 -> X1 at the "R1 stored" barrier;  next 2, 3 -> P0, P1 at the two barriers inside FC2.
-        // So the gather runs under FC1 AND under FC2, and a tile starts with four of its slices in LDS and two more in registers.
-        // With NSL = 6 the index loads of the last slot would reach the tile AFTER the next one (production index 2 NSL - 4 = the next tile's
-        // first run-ahead slot): those are issued at step 0 of the next tile instead, when that tile is known.
-        constexpr bool kLateIdx = NSL - 1 + 3 >= 2 * NSL - 4;
-        HkTile cur = tile_at(t_cur), nxt = cur;
-        int t_nxt = next_tile(t_cur);
-        bool has_next = t_nxt < n_tiles;
-        auto set_next = [&]() {
-            nxt = cur;
-            if (has_next) nxt = tile_at(t_nxt);
-            else nxt.batch = 0;  // no next tile: the run-ahead gather reads row 0 of every table (index loads out of bounds return 0) into buffers nobody consumes
-        };
-        set_next();
-        auto slot_slice = [](int v) constexpr { return v < NSL - 4 ? 4 + v : (v < NSL ? v - (NSL - 4) : 4 + (v - NSL)); };   // slice id of production index v (v may run into the next tile)
-        auto slot_next = [](int v) constexpr { return v >= NSL - 4; };                                                    // ... and whether it belongs to the next tile
-        auto sstamp = [&](int k) {   // experiments build: inside the slots of the workgroup's second tile (slots 64 + 4 u ..: indices requested, slice written, rows requested)
-            if constexpr (kStamps) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (st && tile_no == 1 && k < 126) stamp(k);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        auto slot = [&](int u) {
-            if (u + 3 < 2 * NSL - 4) I_op(slot_next(u + 3) ? nxt : cur, slot_slice(u + 3), idxr[(u + 3) % 2]);
-            sstamp(64 + 4 * u);
-            W_op(slot_next(u) ? nxt : cur, slot_slice(u), rows[u % D]);
-            sstamp(65 + 4 * u);
-            R_op(slot_next(u + 2) ? nxt : cur, slot_slice(u + 2), rows[u % D], idxr[(u + 2) % 2]);
-            sstamp(66 + 4 * u);
-        };
-        {   // prologue: the first tile's slices 0 .. 3 into LDS (X0, X1, P0, P1), 4 and 5 requested, the indices of production index 2 requested (every tile starts so)
+        HkTile cur = tile_at(t_cur);
+        {   // prologue: the first tile's slices 0, 1 into LDS, 2 .. D + 1 requested, the indices of D + 2 requested (every tile starts so).
+            // (Issuing every index load first -- two dependent latencies instead of D + 2 -- measured no different: at launch start, with
+            // every workgroup in its prologue, the chain takes 13-14 us either way, and the extra index registers spill.)
             wl = tid & (LW - 1), it0 = ((tid - 512) / LW) * IPT;
-            I_op(cur, 0, idxr[0]);
-            I_op(cur, 1, idxr[1]);
-            R_op(cur, 0, rows[0], idxr[0]);
-            R_op(cur, 1, rows[1], idxr[1]);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                I_op(cur, j + 2, idxr[j % 2]);
-                W_op(cur, j, rows[j % D]);
-                R_op(cur, j + 2, rows[j % D], idxr[j % 2]);
+            for (int j = 0; j < D; j++) {
+                I_op(cur, j);
+                R_op(cur, j, rows[j]);
             }
-            if (!kLateIdx) I_op(cur, 6, idxr[0]);
+            W_op(cur, 0, rows[0]);
+            I_op(cur, D);
+            R_op(cur, D, rows[0]);
+            W_op(cur, 1, rows[1]);
+            I_op(cur, D + 1);
+            R_op(cur, D + 1, rows[1]);
+            I_op(cur, D + 2);
         }
         while (true) {
+            const int t_nxt = next_tile(t_cur);
+            const bool has_next = t_nxt < n_tiles;
+            HkTile nxt = cur;
+            if (has_next) nxt = tile_at(t_nxt);
+            else nxt.batch = 0;  // no next tile: the run-ahead gather reads row 0 of every table (index loads out of bounds return 0) into buffers nobody consumes
             int tid_o = tid;     // lane geometry re-derived per tile from an opaque copy of the thread id: nothing of it is hoisted and kept live
             asm volatile("" : "+v"(tid_o));
             wl = tid_o & (LW - 1), it0 = (((tid_o - 512) & 255) / LW) * IPT;
+            auto tref = [&](int s) -> const HkTile & { return s >= NSL ? nxt : cur; };
 #pragma unroll
             for (int s = 0; s < NSL; s++) {
-                pbar(s);           // consumers start slice s
-                if (s == 0 && kLateIdx) I_op(slot_next(2) ? nxt : cur, slot_slice(2), idxr[0]);
-                if (s == 1) slot(0);
-                else if (s == 2) slot(1);
-                else if (s >= 5 && s <= NSL - 2) slot(s - 3);   // own slice j = s + 1 >= 6: u = j - 4
-                else if (s == NSL - 1) slot(NSL - 4);            // next tile's slice 0 -> X0
+                pbar(s);           // consumers start slice s; X[(s + 1) % 2] is free
+                if (s >= 1) {     // write slice s + 1, request the rows of s + 1 + D and the indices of s + 2 + D (slices >= NSL: the next tile's)
+                    W_op(tref(s + 1), (s + 1) % NSL, rows[(s + 1) % D]);
+                    R_op(tref(s + 1 + D), (s + 1 + D) % NSL, rows[(s + 1) % D]);
+                    I_op(tref(s + 2 + D), (s + 2 + D) % NSL);
+                }
             }
-            pbar(NSL);             // R1 stored, every consumer is past the last slice: X1 is free
-            slot(NSL - 3);        // next tile's slice 1
-            pbar(NSL + 1);         // FC2 has consumed the R1 rows under P0 / P1
-            slot(NSL - 2);        // next tile's slice 2 -> P0
-            pbar(NSL + 2);         // (FC2 half way)
-            slot(NSL - 1);        // next tile's slice 3 -> P1
-            pbar(NSL + 3);         // FC2 done
-            pbar(NSL + 4);         // R2 stored
-            pbar(NSL + 5);         // R3 stored
-            pbar(NSL + 6);         // partial scores
+            pbar(NSL);             // R1 stored, every consumer is past the last slice: X[1] is free
+            W_op(nxt, 1, rows[1 % D]);
+            R_op(nxt, 1 + D, rows[1 % D]);
+            I_op(nxt, 2 + D);
+            pbar(NSL + 1);         // FC2 done
+            pbar(NSL + 2);         // R2 stored
+            pbar(NSL + 3);         // R3 stored
+            pbar(NSL + 4);         // partial scores
             tile_no++;
             if (!has_next) break;
             cur = nxt;
             t_cur = t_nxt;
-            t_nxt = next_tile(t_cur);
-            has_next = t_nxt < n_tiles;
-            set_next();
         }
         stamp(126);
         if (bad) atomicOr_system(a.err_flag, 1);
@@ -408,7 +357,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
         int tid_o = tid;     // lane geometry re-derived per tile from an opaque copy of the thread id: nothing of it is hoisted out of the tile loop
         asm volatile("" : "+v"(tid_o));
         const int hk = (tid_o >> 5) & 1, lm = tid_o & 31;
-        const unsigned xlane = (unsigned)(hk * HK_LDX + lm);  // B-fragment lane offset inside a slice buffer (16-byte units)
+        const unsigned xlane = (unsigned)(2 * KG2 * HK_LD + hk * HK_LDX + lm);  // B-fragment lane base of FC1 (16-byte units): the X ring
 
         // ---- FC1, K-outer: 128 outputs x 64 items per wave ----
         f32x16 acc1[4][2];
@@ -425,9 +374,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             if (kCStamps && s == 0 && tile_no == 0) cstamp(2);
             if (s == 0) so1 = n1;  // k-group 0; advanced once per k-group: inside k-group g it points at g + 1
             asm volatile("" : "+s"(so1));
-            unsigned xo = xlane + (unsigned)slice_off(s);   // opaque per slice: the four buffers are > 64 KiB apart (no common base + immediate), and
-            asm volatile("" : "+v"(xo));                    // left visible, hipcc keeps an address register per buffer live across the tile
-            const uint4 *xb = lds + xo;
+            const uint4 *xb = lds + xlane + (s & 1) * (XROWS * HK_LDX);
             uint4 b0 = xb[0], b1 = xb[32];
 #pragma unroll
             for (int gl = 0; gl < kgs; gl++) {
@@ -479,24 +426,15 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
 #pragma unroll
                 for (int i = 0; i < 16; i++) acc2[t][mt][i] = 0.0f;
         {
-            // the B-fragment address is re-based (opaque) every 8 k-groups: the reads are then base + immediate, and hipcc does not keep
-            // (spill) the absolute addresses past 64 KiB to share them with FC3's reads of R2
-            unsigned rb = rlane;
-            asm volatile("" : "+v"(rb));
-            uint4 b0 = lds[rb], b1 = lds[rb + 32];
+            const uint4 *bl = lds + rlane;
+            uint4 b0 = bl[0], b1 = bl[32];
 #pragma unroll
             for (int j = 0; j < KG2; j++) {
                 const int jn = j + 1 < KG2 ? j + 1 : j;
-                const uint4 bn0 = lds[rb + (unsigned)(2 * (jn - (j & ~7))) * HK_LD], bn1 = lds[rb + (unsigned)(2 * (jn - (j & ~7))) * HK_LD + 32];
-                if (j == KG2 / 4) bar(NSL + 1);       // rows 0 .. KG2 / 2 + 1 of R1 have been read by every consumer: the parked slices' rows are free
-                if (j == KG2 / 2) bar(NSL + 2);       // (a second producer slot half way through FC2)
+                const uint4 bn0 = bl[(size_t)(2 * jn) * HK_LD], bn1 = bl[(size_t)(2 * jn) * HK_LD + 32];
                 if (j % 8 == 0) {  // so2 = k-group j + RB / 2: the refills of this block of 8 k-groups are fragments 0 .. 15 past it
                     so2 = n2 + (unsigned)(j + RB / 2) * W2.row2;
                     asm volatile("" : "+s"(so2));
-                }
-                if (j % 8 == 7) {  // (the next k-group's fragments were just read through the old base)
-                    rb += 16 * HK_LD;
-                    asm volatile("" : "+v"(rb));
                 }
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
@@ -511,12 +449,12 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
                 b0 = bn0, b1 = bn1;
             }
         }
-        bar(NSL + 3);     // every wave is done reading R1: R2 may overlay its rows 32 ..
+        bar(NSL + 1);     // every wave is done reading R1: R2 may overlay it
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) store_tile(R2, acc2[t][mt], 64 * wave + 32 * t, 32 * mt, hk, lm, os2);
-        bar(NSL + 4);
+        bar(NSL + 2);
 
         // ---- FC3: 32 outputs x 64 items per wave ----
         f32x16 acc3[2];
@@ -525,9 +463,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
 #pragma unroll
             for (int i = 0; i < 16; i++) acc3[mt][i] = 0.0f;
         {
-            unsigned rb = rlane + R2_ROW * HK_LD;   // R2 (opaque, as in FC2)
-            asm volatile("" : "+v"(rb));
-            const uint4 *bl = lds + rb;
+            const uint4 *bl = lds + rlane;  // R2 overlays R1
             uint4 b0 = bl[0], b1 = bl[32];
 #pragma unroll
             for (int j = 0; j < KG3; j++) {
@@ -543,7 +479,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
         ring1_fill();  // the next tile's first k-group(s) of FC1: requested before the R3 store and the barriers
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) store_tile(R3, acc3[mt], 32 * wave, 32 * mt, hk, lm, os3);
-        bar(NSL + 5);
+        bar(NSL + 3);
         {   // score[m] = sum_n wout[n] * R3[n][m], fp32 sum: 64 items x 8 slices of the image's rows, fixed-order reduction
             const int il = tid_o & 63, sl = (tid_o >> 6) & 7;
             float sc = 0.0f;
@@ -575,7 +511,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
                 }
             }
             part[sl * 64 + il] = sc;
-            bar(NSL + 6);
+            bar(NSL + 4);
             const int tl = tid_o & 1023;  // (the opaque copy: the score address is computed here, not at the top of the tile)
             if (tl < 64 && cur.m0 + tl < cur.batch) {
                 float t = part[tl];
@@ -601,15 +537,15 @@ bool frk_fused_hk_ok(int K, int H1, int H2, int H3, const FrWordDesc *h_words, i
     return true;
 }
 
-template <int PREC, int KG, int KGS, int LW, int R1D>
+template <int PREC, int KG, int KGS, int LW, int D, int R1D>
 static int fused_hk_launch_inst(const FrFusedArgs &a, int n_cu, hipStream_t s) {
     static FrLdsAttrOnce lds_once;  // per instantiation, per device
-    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, R1D>, lds_once)) return rc_;
+    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, D, R1D>, lds_once)) return rc_;
     const size_t r1_rows = 2 * (HK_H1 / (PREC == 2 ? 32 : 16));
     const size_t lds = (r1_rows * HK_LD + (size_t)2 * 2 * KGS * HK_LDX + (size_t)a.n_words) * 16;
     const int tiles = a.n_batches * a.tiles_per_batch;
-    fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, R1D><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(768), lds, s>>>(a);
-    fr_note_kernel("fr_fused_tile_hs_kernel<%d, %d, %d, %d, %d>", PREC, KG, KGS, LW, R1D);
+    fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, D, R1D><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(768), lds, s>>>(a);
+    fr_note_kernel("fr_fused_tile_hs_kernel<%d, %d, %d, %d, %d, %d>", PREC, KG, KGS, LW, D, R1D);
     KCHECK();
     return FR_OK;
 }
@@ -624,15 +560,15 @@ int frk_fused_hk_launch(const FrFusedArgs &a, int n_cu, int precision, hipStream
         // 384-385 M inf/s, profiles/r03_fused_hs_fp8_ab.txt) -- with the consumers twice as fast as in bf16, the gather, which only runs
         // under FC1, is what a tile waits for.
 #ifdef FR_EXPERIMENTS
-        if (a.K == 880) return fused_hk_launch_inst<2, 28, 2, 16, 4>(a, n_cu, s);   // Model-B: K 880 -> 896 = 28 k-groups of 32, 14 slices of 2
-        if (a.K == 352) return fused_hk_launch_inst<2, 11, 2, 16, 4>(a, n_cu, s);   // Model-A: K 352 = 11 k-groups of 32, 6 slices of 2 (1)
+        if (a.K == 880) return fused_hk_launch_inst<2, 28, 2, 16, 2, 4>(a, n_cu, s);   // Model-B: K 880 -> 896 = 28 k-groups of 32, 14 slices of 2
+        if (a.K == 352) return fused_hk_launch_inst<2, 11, 2, 16, 3, 4>(a, n_cu, s);   // Model-A: K 352 = 11 k-groups of 32, 6 slices of 2 (1)
 #endif
         FR_FAIL(FR_ERR_INVALID, "no K-outer fp8 fused instantiation for K=%d in this build", a.K);
     }
 #ifdef FR_EXPERIMENTS
-    if (a.K == 880 && FR_KNOB_ONCE("FUSED_R1D", 6) == 4) return fused_hk_launch_inst<1, 55, 7, 32, 4>(a, n_cu, s);
+    if (a.K == 880 && FR_KNOB_ONCE("FUSED_R1D", 6) == 4) return fused_hk_launch_inst<1, 55, 7, 32, 2, 4>(a, n_cu, s);
 #endif
-    if (a.K == 880) return fused_hk_launch_inst<1, 55, 7, 32, 6>(a, n_cu, s);   // Model-B: 8 slices of 7 (6) k-groups, 2 row sets in flight, 6 FC1 fragments
-    if (a.K == 352) return fused_hk_launch_inst<1, 22, 4, 16, 4>(a, n_cu, s);   // Model-A: 6 slices of 4 (2) k-groups, 3 row sets in flight, 4 FC1 fragments
+    if (a.K == 880) return fused_hk_launch_inst<1, 55, 7, 32, 2, 6>(a, n_cu, s);   // Model-B: 8 slices of 7 (6) k-groups, 2 row sets in flight, 6 FC1 fragments
+    if (a.K == 352) return fused_hk_launch_inst<1, 22, 4, 16, 3, 4>(a, n_cu, s);   // Model-A: 6 slices of 4 (2) k-groups, 3 row sets in flight, 4 FC1 fragments
     FR_FAIL(FR_ERR_INVALID, "no K-outer bf16 fused instantiation for K=%d", a.K);
 }

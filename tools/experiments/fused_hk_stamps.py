@@ -34,7 +34,7 @@ for i in range(NB):
 wk.sync()
 lib.fr_debug_set_stamp_buffer(None)
 sw = stamps.download(np.uint64, NST)[:12 * 128 * NWG].reshape(NWG, 12, 128).astype(np.int64)   # [workgroup][wave][slot]
-NBAR = NSL + 7
+NBAR = NSL + 5
 t0 = sw[:, 8:, 0].min(axis=1)                      # the workgroup's first wave start
 rel = lambda x: (x - t0[:, None]) / 100.0          # us since the workgroup started
 end = rel(sw[:, 8:, 126])
@@ -43,7 +43,7 @@ print("model %s, %d batches per launch = %d tiles on %d workgroups (%.1f tiles e
 cons = bool(sw[:, :8, 126].any())   # the consumers stamp only in a -DFR_STAMP_CONSUMERS build (their code is then not the product's)
 if cons:
     print("set-up done (descriptors in LDS, rings / prologue): consumers %.1f us" % np.median(rel(sw[:, :8, 1]).max(axis=1)))
-names = ["slice %d" % s for s in range(NSL)] + ["R1 stored", "FC2 1/4", "FC2 1/2", "FC2 done", "R2 stored", "R3 stored", "partials"]
+names = ["slice %d" % s for s in range(NSL)] + ["R1 stored", "FC2 done", "R2 stored", "R3 stored", "partials"]
 for tile in range(2):
     if tiles / NWG <= tile:
         break
@@ -66,15 +66,3 @@ if cons:
     print("in-kernel clock over FC1 of tile 0: %.3f GHz; shader cycles there: %.0f (MFMA work per SIMD: 2 waves x %d x 8 x 32 = %d)" % (
         np.median(cyc / np.maximum(fc1, 1) * 0.1), np.median(cyc), kg, 2 * kg * 8 * 32))
 
-if sw[:, 8:, 64].any():   # inside the producers' slots of tile 1 (us after the slot's barrier released; median over workgroups of the last producer wave)
-    fire = {0: 1, 1: 2}
-    for u in range(2, NSL - 4): fire[u] = u + 3
-    fire[NSL - 4] = NSL - 1
-    for k in range(1, 4): fire[NSL - 4 + k] = NSL - 1 + k
-    print("tile 1, producers' slots: after the barrier ->  indices requested   slice written (= its rows had landed)   rows requested")
-    for u in range(NSL):
-        if 66 + 4 * u >= 126: break
-        b = fire[u]
-        t_rel = sw[:, 8:, 5 + 2 * NBAR * 1 + 2 * b]
-        d = [np.median(((sw[:, 8:, 64 + 4 * u + k] - t_rel) / 100.0).max(axis=1)) for k in range(3)]
-        print("        slot %d (barrier %-9s)      %6.2f               %6.2f                                %6.2f" % (u, names[b], d[0], d[1], d[2]))
