@@ -458,6 +458,148 @@ __global__ void __launch_bounds__(512) fc_gemm_pipe_kernel(const uint4 *__restri
     }
 }
 
+// ===================================================================================================
+// fc_splitk_gemm_kernel<PREC, NT, MT, PD>: the narrow layers of a large batch (Model-C FC2 1024 -> 512 and FC3 512 -> 256 at batch
+// 4096: 4.3 + 1.1 GFLOP over 8 + 4 MB of activations).  Such a layer is a stream of operand bytes from L2 with a short K; an LDS-tiled
+// block (fc_lp_gemm_kernel<., 1, 64, .>: 32 x 32 wave tiles) reads a 1 KiB fragment pair from LDS per MFMA -- twice what LDS
+// delivers -- and pays a barrier every 64 k.  Here:
+//   * a workgroup is 4 waves that SPLIT K: wave w takes element rows [w KE / 4, (w + 1) KE / 4) of the whole 32 NT (n) x 32 MT (m)
+//     block tile, so every operand byte of the tile is loaded by exactly one wave, once;
+//   * fragments go L2 -> registers directly in MFMA layout (the q8 / q16 images ARE fragment-major: lane (h, r) of k-step j reads
+//     element row 2 j + h (bf16) / 4 j + 2 h, + 1 (fp8), column r of its 32-wide tile: one 16-byte buffer load, 512 contiguous bytes
+//     per half wave) through a ring of PD k-steps per wave: no LDS staging, no barrier in the K loop, (NT + MT) KiB in flight per
+//     k-step per wave;
+//   * the four partial tiles are summed through LDS in wave (= k) order, each wave finishing NT MT / 4 of the tiles: one rounding per
+//     output, as in the other GEMM kernels; fp32 sums of four in-order partial sums instead of one in-order sum (same tolerance class).
+// EXPERIMENTS build only (see lp_gemm_mu: not faster end to end).  One workgroup per CU (256 tiles for FC2 as 128 x 64, for FC3 as 64 x 64), XCD-aware tile map: the workgroups of an XCD share its
+// L2's copy of the weights and own a contiguous range of activation columns.
+// ===================================================================================================
+#ifdef FR_EXPERIMENTS
+template <int PREC, int NT, int MT, int PD>
+__global__ void __launch_bounds__(256) fc_splitk_gemm_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
+                                                             int N, int ldm, int sc_a, int sc_b, float oscale) {
+    static_assert(PREC == 1 || PREC == 2, "bf16 / fp8 only: the fp32 chain keeps whole-K in-order sums");
+    static_assert((NT * MT) % 4 == 0, "each wave finishes NT MT / 4 tiles");
+    extern __shared__ float sk_red[];             // [tile][3 foreign waves][16 registers][64 lanes]
+    constexpr int RPS = PREC == 2 ? 4 : 2;        // element rows per k-step (16 k of bf16 x 2 halves; 64 k of e4m3 = 2 halves x 2 rows)
+    constexpr int FR = PREC == 2 ? 2 : 1;         // 16-byte loads per fragment
+    constexpr int T = NT * MT;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tn = N / (32 * NT), tm = ldm / (32 * MT);
+    int n_tile, m_tile;
+    if (tm % 8 == 0) {  // workgroup b runs on XCD b % 8: XCD x owns the activation columns of m tiles [x tm / 8, (x + 1) tm / 8) and walks all n tiles over them
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        n_tile = j % tn;
+        m_tile = x * (tm / 8) + j / tn;
+    } else {
+        n_tile = blockIdx.x % tn;
+        m_tile = blockIdx.x / tn;
+    }
+    const int n0 = n_tile * 32 * NT, m0 = m_tile * 32 * MT;
+    const int rows = KE / 4, k0 = wave * rows, nk = rows / RPS;   // this wave's element rows and k-steps
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(W), 0, (unsigned)KE * (unsigned)N * 16u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(X), 0, (unsigned)KE * (unsigned)ldm * 16u, 0x00020000);
+    const unsigned hrow = PREC == 2 ? 2u * h : (unsigned)h;
+    const unsigned vW = (hrow * (unsigned)N + (unsigned)(n0 + r)) * 16u, vX = (hrow * (unsigned)ldm + (unsigned)(m0 + r)) * 16u;
+    const unsigned rowW = (unsigned)N * 16u, rowX = (unsigned)ldm * 16u;   // byte step of one element row
+    uint4 ra[PD][NT][FR], rb[PD][MT][FR];
+    auto load_step = [&](int j, int slot) {   // k-step j of this wave -> ring slot
+        const unsigned sW = (unsigned)(k0 + RPS * j) * rowW, sX = (unsigned)(k0 + RPS * j) * rowX;
+#pragma unroll
+        for (int f = 0; f < FR; f++) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) ra[slot][t][f] = bload4u(rsW, vW + 512u * t, sW + f * rowW);
+#pragma unroll
+            for (int u = 0; u < MT; u++) rb[slot][u][f] = bload4u(rsX, vX + 512u * u, sX + f * rowX);
+        }
+    };
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int u = 0; u < MT; u++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[t][u][i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PD; i++)
+        if (i < nk) load_step(i, i);
+    for (int jb = 0; jb < nk; jb += PD) {
+#pragma unroll
+        for (int i = 0; i < PD; i++) {
+            if (jb + i < nk) {
+#pragma unroll
+                for (int u = 0; u < MT; u++)
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        if constexpr (PREC == 1) {
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[i][t][0]), __builtin_bit_cast(bf16x8, rb[i][u][0]), acc[t][u], 0, 0, 0);
+                        } else {
+                            i32x8 a8, b8;
+                            a8[0] = (int)ra[i][t][0].x; a8[1] = (int)ra[i][t][0].y; a8[2] = (int)ra[i][t][0].z; a8[3] = (int)ra[i][t][0].w;
+                            a8[4] = (int)ra[i][t][FR - 1].x; a8[5] = (int)ra[i][t][FR - 1].y; a8[6] = (int)ra[i][t][FR - 1].z; a8[7] = (int)ra[i][t][FR - 1].w;
+                            b8[0] = (int)rb[i][u][0].x; b8[1] = (int)rb[i][u][0].y; b8[2] = (int)rb[i][u][0].z; b8[3] = (int)rb[i][u][0].w;
+                            b8[4] = (int)rb[i][u][FR - 1].x; b8[5] = (int)rb[i][u][FR - 1].y; b8[6] = (int)rb[i][u][FR - 1].z; b8[7] = (int)rb[i][u][FR - 1].w;
+                            acc[t][u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[t][u], 0, 0, 0, sc_a, 0, sc_b);
+                        }
+                    }
+                if (jb + i + PD < nk) load_step(jb + i + PD, i);
+            }
+        }
+    }
+    // ---- the four K partials -> one tile: tile q is finished by wave q % 4; the other three park their partial in LDS ----
+#pragma unroll
+    for (int q = 0; q < T; q++) {
+        const int o = q % 4;
+        if (wave != o) {
+            const int p = wave < o ? wave : wave - 1;
+            float *dst = sk_red + ((size_t)(q * 3 + p) * 16) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 16; i++) dst[i * 64] = acc[q / MT][q % MT][i];
+        }
+    }
+    __syncthreads();
+    auto finish = [&](auto wv) {
+        constexpr int w = decltype(wv)::value;
+#pragma unroll
+        for (int q = w; q < T; q += 4) {
+            const int t = q / MT, u = q % MT;
+            float c[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                float sum = 0.0f;   // wave (= k) order: ((p0 + p1) + p2) + p3
+#pragma unroll
+                for (int src = 0; src < 4; src++) {
+                    const int p = src < w ? src : src - 1;
+                    const float v = src == w ? acc[t][u][i] : sk_red[((size_t)(q * 3 + p) * 16 + i) * 64 + lane];
+                    sum = src == 0 ? v : sum + v;
+                }
+                c[i] = sum;
+            }
+            const int m = m0 + 32 * u + r;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {   // registers 4 i .. 4 i + 3 of a tile are 4 consecutive n
+                const int n = n0 + 32 * t + 8 * i + 4 * h;
+                if constexpr (PREC == 1) {
+                    uint2 hv;
+                    hv.x = pack_bf16x2(c[4 * i + 0], c[4 * i + 1]);
+                    hv.y = pack_bf16x2(c[4 * i + 2], c[4 * i + 3]);
+                    reinterpret_cast<uint2 *>(Y)[((size_t)(n >> 3) * ldm + m) * 2 + ((n & 7) >> 2)] = hv;
+                } else {
+                    reinterpret_cast<uint32_t *>(Y)[((size_t)(n >> 4) * ldm + m) * 4 + ((n & 15) >> 2)] = pack_fp8x4(c[4 * i + 0], c[4 * i + 1], c[4 * i + 2], c[4 * i + 3], oscale);
+                }
+            }
+        }
+    };
+    switch (wave) {
+        case 0: finish(std::integral_constant<int, 0>{}); break;
+        case 1: finish(std::integral_constant<int, 1>{}); break;
+        case 2: finish(std::integral_constant<int, 2>{}); break;
+        default: finish(std::integral_constant<int, 3>{}); break;
+    }
+}
+#endif  // FR_EXPERIMENTS
+
 // Pipeline shape (experiment knob FR_GEMM_PIPE = 10 * G + NS; 0 = fc_lp_gemm_kernel): G row groups of 4 element rows per sub-step, NS
 // sub-steps in LDS.  Default: see pipe_shape().
 static int pipe_shape() {
@@ -505,8 +647,24 @@ static int lp_gemm_mu(int precision, int K, int N, int ldm) {
     if (forced == 0) return 0;
     const long t256 = (N % 128 || ldm % 256) ? 0 : (long)(N / 128) * (ldm / 256), t128 = N % 128 ? 0 : (long)(N / 128) * (ldm / 128),
                t64 = (long)(N / 64) * (ldm / 128);
+    // split-K direct tiles of the narrow layers (bf16 / fp8, N <= 512, K <= 2048: what a 4-wave ring can stream in a few us): 4 = 128 (n) x 64 (m),
+    // 5 = 64 x 64; the layer must give every wave whole k-steps and fill at least half the chip
+    const int rps = precision == FR_FC_FP8 ? 4 : 2;
+    const bool sk_ok = precision != FR_FC_FP32 && N <= 512 && K <= 2048 && KE % (4 * rps) == 0 && ldm % 64 == 0;
+    const long s128 = (sk_ok && N % 128 == 0) ? (long)(N / 128) * (ldm / 64) : 0, s64 = sk_ok ? (long)(N / 64) * (ldm / 64) : 0;
+#ifdef FR_EXPERIMENTS
+    if ((forced == 4 && s128) || (forced == 5 && s64)) return forced;
+#endif
     if (forced > 0) return ((forced == 2 && t256) || (forced == 1 && t128) || forced == 3) ? forced : 0;
     const int small_tile = FR_KNOB_ONCE("LP_GEMM_SMALL", 3);  // experiment knob: 1 = no 64 x 128 tiles
+    // EXPERIMENTS build only (FR_LP_GEMM_SPLITK=1): measured on Model-C 4096 with four streams, the split-K kernels are no faster end to
+    // end in bf16 (37.0 vs 37.2 M inf/s) and slower in fp8 (55 vs 58-60 M): alone on the chip they would stream a layer's bytes once, but
+    // one wave per SIMD with 320-490 registers shares a CU with nothing, and this chain lives on four streams' kernels sharing CUs
+    // (profiles/r03_experiments.md section 4)
+    if (FR_KNOB_ONCE("LP_GEMM_SPLITK", 0)) {
+        if (s128 >= 192 && s128 <= 512) return 4;
+        if (s64 >= 128 && s64 <= 512) return 5;
+    }
     if (t256 >= 192) return 2;
     if (t128 >= 192) return 1;
     if (t64 >= 128 && small_tile == 3) return 3;
@@ -528,9 +686,29 @@ static int lp_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int 
     return FR_OK;
 }
 
+#ifdef FR_EXPERIMENTS
+template <int PREC, int NT, int MT, int PD>
+static int splitk_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
+    static FrLdsAttrOnce lds_once;
+    const size_t lds = (size_t)NT * MT * 3 * 16 * 64 * sizeof(float);
+    if (int rc_ = fr_allow_full_lds(&fc_splitk_gemm_kernel<PREC, NT, MT, PD>, lds_once)) return rc_;
+    dim3 grid((N / (32 * NT)) * (ldm / (32 * MT)));
+    fc_splitk_gemm_kernel<PREC, NT, MT, PD><<<grid, dim3(256), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale);
+    KCHECK();
+    fr_note_kernel("fc_splitk_gemm_kernel<%d, %d, %d, %d>", PREC, NT, MT, PD);
+    return FR_OK;
+}
+#endif
+
 template <int PREC>
 static int lp_gemm_tile(int mu, const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
     if (mu == 2) return lp_gemm_launch<PREC, 2, 128, FR_GSTAGES>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+#ifdef FR_EXPERIMENTS
+    if constexpr (PREC != 0) {   // ring depth: 4 k-steps of 16 k (bf16) / 2 of 64 k (fp8) = 24 / 48 KiB in flight per wave at 128 x 64
+        if (mu == 4) return splitk_gemm_launch<PREC, 4, 2, (PREC == 1 ? 8 : 4)>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+        if (mu == 5) return splitk_gemm_launch<PREC, 2, 2, (PREC == 1 ? 8 : 4)>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+    }
+#endif
     if (mu == 3) {
         // 4 stages pay in bf16 only (Model-C FC2 19.8 -> 14.7 us, end to end +2.5 %); in fp8 / f32 the larger LDS footprint costs more
         // beside the other streams' kernels than the deeper prefetch gains (fp8 end to end 57.3 -> 52.8 M inf/s).  Knob: FR_LP_GEMM_STAGES

@@ -41,7 +41,7 @@ def test_product_library_reads_no_environment_variable(fr):
     in the -DFR_EXPERIMENTS build (`make -C csrc exp` -> libfleetrec_exp.so); the shipped library carries none of their names and does
     not import getenv at all (the GPU suite additionally checks that setting them changes no score bit)."""
     blob = open(fr.LIB_PATH, "rb").read()
-    for name in (b"FR_GEMM_ABLATE", b"FR_GEMM_ORDER", b"FR_GEMM_PRIO", b"FR_GEMM_PIPE", b"FR_GATHER_", b"FR_FUSED\0", b"FR_FUSED_HK", b"FR_FUSED_GROUP", b"FR_FUSED_ITEMS",
+    for name in (b"FR_GEMM_ABLATE", b"FR_GEMM_ORDER", b"FR_GEMM_PRIO", b"FR_GEMM_PIPE", b"FR_GATHER_", b"FR_FUSED\0", b"FR_FUSED_HK", b"FR_FUSED_HS_ABLATE", b"FR_LP_GEMM_SPLITK", b"fc_splitk_gemm", b"FR_FUSED_GROUP", b"FR_FUSED_ITEMS",
                  b"FR_FUSED_M2", b"FR_FUSED_WPE", b"FR_FUSED_R1D", b"FR_LP_GEMM", b"FR_SUBMIT_ZEROCOPY", b"FR_SMALL_BLOCK_SERIAL"):
         assert name not in blob, name     # (FR_FUSED_MAX_QUEUE, a constant's name inside an error string, is not a variable)
     und = subprocess.check_output(["nm", "-D", "--undefined-only", fr.LIB_PATH]).decode()
