@@ -43,8 +43,12 @@ __device__ __forceinline__ FtWk ftk_w(const float4 *wq, int rows, int N, int hk,
     w.row2 = 2u * (unsigned)N * 16u;
     return w;
 }
+// FR_HS_W_AUX (hand-built experiment variants only, tools/jobs/r03_waux.sh): cache-policy bits of the consumers' weight loads
+#ifndef FR_HS_W_AUX
+#define FR_HS_W_AUX 0
+#endif
 __device__ __forceinline__ uint4 ftk_load(const FtWk &w, unsigned soff, int imm) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.voff + imm, soff, 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.voff + imm, soff, FR_HS_W_AUX);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
@@ -139,10 +143,13 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     // s_memrealtime slots per wave.  0 start, 1 set-up done, 2 / 3 s_memtime around tile 0's FC1; the barriers of the workgroup's first two
     // tiles: 4 + 2 NBAR tile + 2 b = arrival at barrier b, + 1 = release (b = slice s for the step barriers, NSL + p for the five phase
     // barriers R1 stored / FC2 done / R2 stored / R3 stored / partial scores; NBAR = NSL + 5); 126 kernel end.
-    // The stamps are compiled into the EXPERIMENTS build only: in the product kernel their pointer and tile counter cost registers the
+    // The stamps (and the producers' timing ablations below) are compiled into the DIAGNOSTIC build only (`make -C csrc diag` ->
+    // libfleetrec_diag.so = the experiments build + -DFR_HS_DIAG on this file): even on the producer side alone they cost 30 more spilled
+    // registers and 17 % of the kernel's speed (Model-B 1024: 272 vs 225 us per launch), so an A/B taken in a build that has them says
+    // little about the product kernel.  Previously they were part of every EXPERIMENTS build: in the product kernel their pointer and tile counter cost registers the
     // consumers do not have (168, 128 of them accumulators) -- with them in, hipcc spilled 11-18 registers to scratch, and a kernel that
     // uses scratch pays for its set-up at every dispatch.
-#ifdef FR_EXPERIMENTS
+#ifdef FR_HS_DIAG
     constexpr bool kStamps = true;
 #else
     constexpr bool kStamps = false;
@@ -160,7 +167,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     // The workgroup barrier; the PRODUCERS' copy is stamped on both sides for the first two tiles (a release is common to all waves, and a
     // step the producers did not arrive last at waited for the consumers).  The consumers stamp only under FR_STAMP_CONSUMERS: their code is
     // then not the product's -- the stamp pointer and tile counter cost registers, hipcc spills, and the spills show up as slow steps.
-#if defined(FR_EXPERIMENTS) && defined(FR_STAMP_CONSUMERS)
+#if defined(FR_HS_DIAG) && defined(FR_STAMP_CONSUMERS)
     constexpr bool kCStamps = true;
 #else
     constexpr bool kCStamps = false;
@@ -208,7 +215,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             for (int i = 0; i < IPT; i++)   // items past the batch: out of the resource's bounds, 0 comes back (no branch)
                 idxr[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)(t.m0 + it0 + i) * (unsigned)a.idx_stride * 4u + (d.w & 0x7FFFFFFFu), 0, 0);
         };
-#ifdef FR_EXPERIMENTS
+#ifdef FR_HS_DIAG
         // timing ablations (FR_FUSED_HS_ABLATE, wrong scores).  1: the producers load no rows -- the consumers' own pace.  2: every row load reads
         // row 0 of its table (the same instructions; all lanes of a table share one line).  4 / 5 / 6 / 7: row 0 for the tables of >= 10 M / 1 M /
         // 500 k / 100 k rows only (which table class the producers wait for)
@@ -556,8 +563,8 @@ static int fused_hk_launch_inst(const FrFusedArgs &a, int n_cu, hipStream_t s) {
 int frk_fused_hk_launch(const FrFusedArgs &a, int n_cu, int precision, hipStream_t s) {
     if (precision == FR_FC_FP8) {
         // The fp8 form is built into the EXPERIMENTS library only: it is correct (tests/test_gpu_parity.py::test_fp8_persistent_fused_kernel_many_tiles
-        // under FR_LIB=libfleetrec_exp.so FR_FUSED_HK=1) and SLOWER than the chunked fr_fused_tile_f8_kernel (Model-B 1024: 312-315 vs
-        // 384-385 M inf/s, profiles/r03_fused_hs_fp8_ab.txt) -- with the consumers twice as fast as in bf16, the gather, which only runs
+        // under FR_LIB=libfleetrec_exp.so FR_FUSED_HK=1) and SLOWER than the chunked fr_fused_tile_f8_kernel (Model-B 1024: 340 vs
+        // 398-400 M inf/s, profiles/r03_fused_hs_fp8_ab.txt) -- with the consumers twice as fast as in bf16, the gather, which only runs
         // under FC1, is what a tile waits for.
 #ifdef FR_EXPERIMENTS
         if (a.K == 880) return fused_hk_launch_inst<2, 28, 2, 16, 2, 4>(a, n_cu, s);   // Model-B: K 880 -> 896 = 28 k-groups of 32, 14 slices of 2

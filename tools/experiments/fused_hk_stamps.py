@@ -1,7 +1,9 @@
 """Barrier-by-barrier timing inside fr_fused_tile_hs_kernel (the K-outer, persistent, wave-specialised bf16 fused kernel): every wave's
 lane 0 stamps s_memrealtime (100 MHz) when it ARRIVES at each workgroup barrier of the workgroup's first two tiles and when the barrier
 RELEASES it.  Who arrives last says who the step waited for: the consumers (MFMA waves 0-7) or the producers (gather waves 8-11).
-usage: fused_hk_stamps.py [batches per launch = 16] [model B|A]     (more than 16384 items per launch need FR_LIB=libfleetrec_exp.so FR_FUSED_ITEMS=...)"""
+The stamps exist in the DIAGNOSTIC build only: FR_LIB=<package>/libfleetrec_diag.so (make -C csrc diag); that build's kernel is ~17 % slower
+than the product's (spilled registers), so read the pattern, not the absolute times.
+usage: FR_LIB=.../libfleetrec_diag.so fused_hk_stamps.py [batches per launch = 16] [model B|A]"""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -1,7 +1,7 @@
 # the persistent bf16 kernel with and without the producers' row loads (timing ablation, wrong scores): the consumers' own pace
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03_abl; mkdir -p $O
-export FR_LIB=$GRAFT_REPO_ROOT/gpu-fpga-recommendation-system_amd/libfleetrec_exp.so
+export FR_LIB=$GRAFT_REPO_ROOT/gpu-fpga-recommendation-system_amd/libfleetrec_diag.so
 for abl in 0 1; do
 echo "=== FR_FUSED_HS_ABLATE=$abl" | tee -a $O/stamps.txt
 FR_FUSED_HS_ABLATE=$abl timeout -k 10 200 python tools/experiments/fused_hk_stamps.py 64 B 2>&1 | tail -36 | tee -a $O/stamps.txt
