@@ -1131,8 +1131,13 @@ def main():
             iha = [uniform_idx(rnga, ma.rows(), B) for _ in range(N_IDX_BUFFERS)]
             dia = [fr.DeviceBuffer.from_numpy(ca, a_) for a_ in iha]
             for prec in ("bf16", "fp8"):
+                # bf16: a launch group of 256 batches = four 64-item tiles per compute unit per launch, which is what the persistent kernel
+                # (fr_fused_tile_hs_kernel) needs to overlap one tile's gather with another's FC phases; at the default 64 (one tile per compute
+                # unit, the chunked kernel) the same leg gives 434-436 M inf/s against 489 M (profiles/r03_group_above_64_ab.txt)
+                ga = 256 if prec == "bf16" and B * 256 <= 65536 else 64
+                ca.set_stream_group(ga)
                 cfgs.append(leg_config(fr, ca, ma, B, prec, dia, None, iha[0], None, args.threads, args.depth,
-                                       "Model-A batch=%d (the headline workload), %s FC chain through the fused item-tile kernel" % (B, prec)))
+                                       "Model-A batch=%d (the headline workload), %s FC chain through the fused item-tile kernel, %d batches per launch (fr_ctx_set_stream_group)" % (B, prec, ga)))
             ca.close()
         except Exception as ex:
             cfgs.append({"workload": "Model-A low precision", "error": repr(ex)})
