@@ -20,6 +20,8 @@ NWG = min(tiles, 256)
 rng = np.random.default_rng(0)
 pool = [fr.DeviceBuffer.from_numpy(ctx, (rng.random((B, m.n_tables)) * m.rows()[None, :]).astype(np.int32)) for _ in range(16)]
 sc = [fr.DeviceBuffer(ctx, B * 4) for _ in range(64)]
+if NB > 64:
+    ctx.set_stream_group(min(NB, 256))   # one launch carries the whole list (the persistent kernel reads it from device memory)
 wk = fr.Worker(ctx, B)
 for rep in range(200):
     for i in range(NB):
