@@ -158,9 +158,21 @@ def steady_run(run_fn, min_s, n_first=4096, env=None, quantum=256):
     return n
 
 
-def time_launches(wk, push, per_launch, launches, warm_launches=4):
+def time_launches(wk, push, per_launch, launches, warm_launches=4, push_launch=None):
     """HIP events on the worker's own stream around `launches` launches (push(i) enqueues one batch; per_launch of them make
-    one launch).  -> average launch duration in ms."""
+    one launch).  -> average launch duration in ms.  With push_launch (launch_pusher below) a launch's batches are pushed by ONE
+    native call: a Python push costs ~0.7 us, which is a batch's whole share of a launch for the small-batch low-precision rows
+    (Model-A fp8: 64 pushes per 35 us kernel) -- the stream, not the interpreter, must set the pace of a roofline figure."""
+    if push_launch is not None:
+        for l in range(warm_launches):
+            push_launch(l)
+        wk.sync()
+        wk.timer_start()
+        for l in range(launches):
+            push_launch(l)
+        ms = wk.timer_stop_ms() / launches
+        wk.sync()
+        return ms
     for i in range(warm_launches * per_launch):
         push(i)
     wk.sync()
@@ -170,6 +182,17 @@ def time_launches(wk, push, per_launch, launches, warm_launches=4):
     ms = wk.timer_stop_ms() / launches
     wk.sync()
     return ms
+
+
+def launch_pusher(wk, B, d_idx, d_dense, ring, per_launch, n_lists=8):
+    """push_launch(l) for time_launches: launch l's per_launch batches through fr_worker_push_device_list, the same buffers in the same
+    order as `push(l * per_launch + k)` would take (index buffers rotate through d_idx, score buffers through the two halves of `ring`)."""
+    lists = []
+    for l in range(n_lists):
+        ii = [l * per_launch + k for k in range(per_launch)]
+        lists.append(wk.make_push_list([B] * per_launch, [d_idx[i % len(d_idx)] for i in ii],
+                                       [d_dense[i % len(d_dense)] for i in ii] if d_dense else None, [ring[i % len(ring)] for i in ii]))
+    return lambda l: wk.push_device_list(lists[l % n_lists])
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -473,7 +496,7 @@ def leg_group_table(fr, ctx, model, B, d_idx, threads, depth):
         wk = fr.Worker(ctx, B)
         ring = [fr.DeviceBuffer(ctx, B * 4) for _ in range(2 * g)]
         push = lambda i: wk.push_device(B, d_idx[i % len(d_idx)], None, ring[i % len(ring)])
-        ms = time_launches(wk, push, g, 200 if g > 1 else 1000, warm_launches=50)
+        ms = time_launches(wk, push, g, 200 if g > 1 else 1000, warm_launches=50, push_launch=launch_pusher(wk, B, d_idx, None, ring, g))
         lat = []
         for _ in range(40):                      # idle worker: first push -> all g batches' scores complete (queueing + launch + sync)
             t0 = time.perf_counter()
@@ -529,7 +552,7 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
         per_launch = max(1, min(group, (65536 if precision == "bf16" else 16384) // B))   # bf16: the persistent kernel's launches carry up to 65536 items
         ring = [fr.DeviceBuffer(ctx, B * 4) for _ in range(2 * per_launch)]
         push = lambda i: wk.push_device(B, d_idx[i % len(d_idx)], d_dense[i % len(d_dense)] if d_dense else None, ring[i % len(ring)])
-        ms = time_launches(wk, push, per_launch, 100, warm_launches=30)
+        ms = time_launches(wk, push, per_launch, 100, warm_launches=30, push_launch=launch_pusher(wk, B, d_idx, d_dense, ring, per_launch))
         flops = flops_inf * B * per_launch
         kname = wk.last_kernel()   # the kernel that carried these launches, as the library reports it (fr_worker_last_kernel)
         what = "%s: one launch = gather + 4-GEMM chain of %d queued batches of %d, back-to-back on ONE stream" % (kname, per_launch, B)
@@ -996,7 +1019,7 @@ def main():
             for i in range(4 * group):
                 push(i)
             wk.sync()
-        pipe_ms = time_launches(wk, push, group, 200, warm_launches=4)
+        pipe_ms = time_launches(wk, push, group, 200, warm_launches=4, push_launch=launch_pusher(wk, B, d_idx[:n_bufs], None, ring, group))
         flops = fc_flops_per_inference(model.fc) * B * group
         ach = flops / (pipe_ms * 1e-3) / 1e12
         kname = wk.last_kernel()   # the kernel that carried these launches, as the library reports it

@@ -25,7 +25,7 @@ LAYOUT_SEMANTIC, LAYOUT_BLOCKED = 0, 1
 INDEX_PER_TABLE, INDEX_PER_ITEM, INDEX_PER_BANK = 0, 1, 2
 SEG_TABLE, SEG_COPY, SEG_DENSE = 0, 1, 2
 GATHER_WORD_MAJOR, GATHER_ITEM_TILE, GATHER_ITEM_TILE_DEDUP, GATHER_ITEM_TILE_DEDUP_COUNT, GATHER_WORD_MAJOR_ONE_CHUNK = 0, 1, 2, 3, 4
-ABI_VERSION = 2   # include/fleetrec.h FR_ABI_VERSION this binding was written against
+ABI_VERSION = 3   # include/fleetrec.h FR_ABI_VERSION this binding was written against
 MEM_CLASS_NAMES = {0: "HBM", 1: "DDR", 2: "PLRAM"}
 
 
@@ -64,7 +64,7 @@ ABI_SYMBOLS = [
     "fr_ctx_fill_tables", "fr_ctx_upload_table", "fr_ctx_download_table", "fr_ctx_set_weights", "fr_ctx_fill_weights",
     "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_ctx_get_fp8_exponents", "fr_ctx_set_fp8_act_exponents",
     "fr_worker_calibrate_fp8", "fr_worker_calibrate_fp8_slices", "fr_worker_push_host", "fr_worker_stage_acquire", "fr_worker_push_staged", "fr_worker_flush", "fr_worker_host_poll", "fr_worker_host_pending", "fr_ctx_set_small_block", "fr_worker_stream", "fr_worker_gather_slices", "fr_worker_fc_from_slices_lp", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
-    "fr_worker_dense_ptr", "fr_worker_score_ptr", "fr_worker_submit", "fr_worker_submit_device", "fr_worker_push_device", "fr_worker_sync",
+    "fr_worker_dense_ptr", "fr_worker_score_ptr", "fr_worker_submit", "fr_worker_submit_device", "fr_worker_push_device", "fr_worker_push_device_list", "fr_worker_sync",
     "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
     "fr_device_synchronize", "fr_ctx_shard_info", "fr_driver_create", "fr_driver_destroy", "fr_driver_run_resident",
@@ -107,7 +107,7 @@ def lib():
         "fr_worker_calibrate_fp8": (i32, [vp, i32]), "fr_worker_calibrate_fp8_slices": (i32, [vp, i32, i32, i32, vp]),
         "fr_worker_create": (i32, [vp, i32, ctypes.POINTER(vp)]), "fr_worker_destroy": (None, [vp]),
         "fr_worker_idx_ptr": (pi, [vp]), "fr_worker_dense_ptr": (pf, [vp]), "fr_worker_score_ptr": (pf, [vp]),
-        "fr_worker_submit": (i32, [vp, i32]), "fr_worker_submit_device": (i32, [vp, i32, vp, vp, vp]), "fr_worker_push_device": (i32, [vp, i32, vp, vp, vp]),
+        "fr_worker_submit": (i32, [vp, i32]), "fr_worker_submit_device": (i32, [vp, i32, vp, vp, vp]), "fr_worker_push_device": (i32, [vp, i32, vp, vp, vp]), "fr_worker_push_device_list": (i32, [vp, i32, vp, vp, vp, vp]),
         "fr_worker_sync": (i32, [vp]), "fr_worker_gather_only": (i32, [vp, i32, vp, vp, vp]),
         "fr_worker_fc_only": (i32, [vp, i32, vp, vp]), "fr_worker_fc_layer_only": (i32, [vp, i32, i32]), "fr_worker_records_dptr": (vp, [vp]),
         "fr_worker_features_dptr": (vp, [vp, ctypes.POINTER(ctypes.c_int)]),
@@ -611,6 +611,18 @@ class Worker:
 
     def push_device(self, batch, d_idx, d_dense, d_scores):
         _check(lib().fr_worker_push_device(self._h, batch, self._ptr(d_idx), self._ptr(d_dense), self._ptr(d_scores)))
+
+    def make_push_list(self, batches, d_idx, d_dense, d_scores):
+        """Pre-built argument arrays for push_device_list: batches [n] ints, d_idx / d_scores [n] DeviceBuffers (or pointers), d_dense [n] or None."""
+        n = len(batches)
+        vp = ctypes.c_void_p
+        arr = lambda xs: (vp * n)(*[self._ptr(x) for x in xs])
+        return (n, (ctypes.c_int * n)(*[int(b) for b in batches]), arr(d_idx), arr(d_dense) if d_dense is not None else None, arr(d_scores),
+                (d_idx, d_dense, d_scores))   # (the buffers stay referenced as long as the list does)
+
+    def push_device_list(self, plist):
+        """n consecutive push_device calls in one native call (fr_worker_push_device_list); plist from make_push_list."""
+        _check(lib().fr_worker_push_device_list(self._h, plist[0], plist[1], plist[2], plist[3], plist[4]))
 
     def gather_only(self, batch, d_idx, d_dense, d_records):
         _check(lib().fr_worker_gather_only(self._h, batch, self._ptr(d_idx), self._ptr(d_dense), self._ptr(d_records)))

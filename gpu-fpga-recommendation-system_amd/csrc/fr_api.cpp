@@ -1359,6 +1359,17 @@ extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_i
     return FR_OK;
 }
 
+extern "C" int fr_worker_push_device_list(fr_worker *w, int n, const int *batch, const int32_t *const *d_idx, const float *const *d_dense,
+                                          float *const *d_scores) {
+    if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
+    if (n < 0 || (n > 0 && (!batch || !d_idx || !d_scores))) FR_FAIL(FR_ERR_INVALID, "push_device_list: n = %d needs batch, d_idx and d_scores arrays", n);
+    for (int i = 0; i < n; i++) {
+        const int rc = fr_worker_push_device(w, batch[i], d_idx[i], d_dense ? d_dense[i] : nullptr, d_scores[i]);
+        if (rc) return rc;
+    }
+    return FR_OK;
+}
+
 extern "C" int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores) {
     int rc = check_ready(w, batch, true, true);
     if (rc) return rc;

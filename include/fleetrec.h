@@ -35,7 +35,7 @@ extern "C" {
  * writes the worker's pinned buffers from the kernels; FR_INDEX_PER_BANK stores bank-interleaved tables; FR_GATHER_WORD_MAJOR_ONE_CHUNK;
  * the library reads no environment variable.  A binding must refuse a library whose fr_abi_version() differs from the header it was
  * written against (the Python binding does, also for a build loaded through FR_LIB). */
-#define FR_ABI_VERSION 2
+#define FR_ABI_VERSION 3
 
 typedef enum fr_status {
     FR_OK = 0,
@@ -253,6 +253,13 @@ int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d_idx, const
  * R >= 2 * max(fr_ctx_stream_group(ctx), 5) buffer sets and calls fr_worker_sync once per trip round the ring (what
  * fr_driver_run_resident does with R = 512). */
 int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores);
+/* n consecutive fr_worker_push_device calls in one: batch[i], d_idx[i], d_dense[i] (the array or any entry may be NULL for a model
+ * without dense features), d_scores[i] for i = 0 .. n-1, in that order, stopping at the first error (its status is returned; the
+ * batches before it stay pushed).  For callers whose per-call cost is comparable to a batch's share of a launch -- a language
+ * binding feeding 256 batches of a 0.5 us share each -- so that the stream, not the caller, sets the pace (bench.py's one-stream
+ * roofline legs).  Same buffer-lifetime rule as fr_worker_push_device.  The reference's loop is the n = 1 case (cuda_server.c:406-497). */
+int fr_worker_push_device_list(fr_worker *w, int n, const int *batch, const int32_t *const *d_idx, const float *const *d_dense,
+                               float *const *d_scores);
 /* How many pushed batches one streaming launch carries on this context: 1 when fr_worker_push_device rides the stage pipeline
  * (models that do not fit the fused kernel), G (1..256, default 64) when
  * the model streams through the fused item-tile kernel -- the value fr_ctx_set_stream_group set, also when it is below 12 and the

@@ -1070,6 +1070,43 @@ def test_dense_block_through_the_fused_tile_kernels(fr, gpu, prec):
     ctx.close()
 
 
+def test_push_device_list_equals_single_pushes(fr, ctxs):
+    """fr_worker_push_device_list: n pushes in one native call.  Same scores, bit for bit, as the same batches pushed one by one; an
+    invalid entry stops the list at that entry with its status, the batches before it stay pushed and complete at the next sync."""
+    m, ctx = ctxs(fr.MODEL_A)
+    rng = np.random.default_rng(77)
+    sizes = [256, 1, 200, 256, 37, 256, 255, 64] * 9     # 72 batches: one full launch group and a partial one
+    idx = [uniform_idx(rng, m.rows(), b) for b in sizes[:8]]
+    d_idx = [fr.DeviceBuffer.from_numpy(ctx, i) for i in idx]
+    wk = fr.Worker(ctx, 256)
+    one, lst = [fr.DeviceBuffer(ctx, 256 * 4) for _ in sizes], [fr.DeviceBuffer(ctx, 256 * 4) for _ in sizes]
+    for b_ in one + lst:
+        b_.upload(np.full(256, np.nan, np.float32))
+    for j, b in enumerate(sizes):
+        wk.push_device(b, d_idx[j % 8], None, one[j])
+    wk.sync()
+    pl = wk.make_push_list(sizes, [d_idx[j % 8] for j in range(len(sizes))], None, lst)
+    wk.push_device_list(pl)
+    wk.sync()
+    for j, b in enumerate(sizes):
+        a, c = one[j].download(np.float32, 256), lst[j].download(np.float32, 256)
+        assert np.isfinite(a[:b]).all() and np.isnan(a[b:]).all() and np.array_equal(a[:b], c[:b]) and np.isnan(c[b:]).all(), j
+    # an entry with a batch above the worker's capacity: the call stops there
+    bad = wk.make_push_list([256, 256, 257, 256], [d_idx[0]] * 4, None, lst[:4])
+    for b_ in lst[:4]:
+        b_.upload(np.full(256, np.nan, np.float32))
+    with pytest.raises(fr.FleetRecError) as e:
+        wk.push_device_list(bad)
+    assert e.value.status == fr.FR_ERR_INVALID
+    wk.sync()
+    got = [b_.download(np.float32, 256) for b_ in lst[:4]]
+    assert np.isfinite(got[0]).all() and np.isfinite(got[1]).all() and np.isnan(got[2]).all() and np.isnan(got[3]).all()
+    wk.push_device_list(wk.make_push_list([], [], None, []))   # n = 0: nothing
+    wk.close()
+    for b_ in one + lst + d_idx:
+        b_.free()
+
+
 def test_host_fed_streaming(fr, ctxs):
     """fr_worker_push_host / fr_driver_run_host_streaming: batches that sit in host memory are staged in pinned blocks and travel as
     one H2D + one fused launch + one D2H per block; scores equal the device-resident streaming path bit for bit, ragged batches,
