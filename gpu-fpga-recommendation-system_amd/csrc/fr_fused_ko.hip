@@ -98,10 +98,6 @@ __device__ __forceinline__ void hk_mma(f32x16 &acc, const uint4 &a4, const uint4
 // exponents are folded into the scale of the next activation's quantisation, exactly).  KG = k-groups of the (zero-padded) record (16 k
 // each in bf16, 32 k in fp8); KGS = k-groups per slice; LW = producer lanes along the record words of a slice (16 or 32); D = row sets
 // a producer thread keeps in flight (NSL % D == 0: the set of a slice is a compile-time index); R1D = FC1 weight fragments in registers.
-// D < 0 (fp8 only: R1 is 64 KiB there) = the WHOLE-IMAGE form, -D row sets in flight: LDS holds all NSL slices of a tile's record image
-// instead of a ring of two, every slice has its own buffer, and the producers write the NEXT tile's slice u into it any time after the
-// current tile's FC1 step u -- so their gather runs under FC1, FC2, FC3 and the output layer alike (a static schedule of NSL slots over
-// the tile's NSL + 7 barriers), one tile ahead of the consumers.
 template <int PREC, int KG, int KGS, int LW, int D, int R1D>
 __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs a) {
     extern __shared__ uint4 lds[];
@@ -111,21 +107,15 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     constexpr int NSL = (KG + KGS - 1) / KGS;          // slices per tile
     constexpr int IPT = LW / 4;                        // items per producer thread (256 threads = LW words x 64 / IPT item slots)
     constexpr int XROWS = 2 * KGS;                     // operand rows of one X ring buffer
-    constexpr bool IMG = D < 0;                        // whole-image form
-    constexpr int DS = IMG ? -D : D;                   // row sets in flight
-    constexpr int XBUFS = IMG ? NSL : 2;               // slice buffers in LDS
-    constexpr int NBAR = NSL + (IMG ? 7 : 5);          // barriers per tile (stamp slots): the whole-image form has two more inside FC2
-    constexpr int B_FC2 = NSL + (IMG ? 3 : 1);         // barrier numbers after "R1 stored" (= NSL): FC2 done, R2 stored, R3 stored, partial scores
-    static_assert(IMG || (NSL % 2 == 0 && NSL % D == 0 && NSL >= D + 3), "two X buffers, D row sets, and the run-ahead stays inside the next tile");
-    static_assert(!IMG || (PREC == 2 && DS == 2 && NSL >= 6), "whole-image form: fp8, two row sets");
+    constexpr int NBAR = NSL + 5;                      // barriers per tile (stamp slots)
+    static_assert(NSL % 2 == 0 && NSL % D == 0 && NSL >= D + 3, "two X buffers, D row sets, and the run-ahead stays inside the next tile");
     static_assert(WPG * KGS <= LW && (LW == 16 || LW == 32), "a slice's record words ride the lanes of one half / quarter wave");
     uint4 *R1 = lds;                                   // [2 KG2][64]: bf16 128 KiB, fp8 64 KiB
     uint4 *R2 = lds;                                   // [2 KG3][64], overlays R1 once FC2 has read it
     uint4 *R3 = lds + 2 * KG3 * HK_LD;                 // [2 KG4][64]
     float *part = reinterpret_cast<float *>(lds + (2 * KG3 + 2 * KG4) * HK_LD);  // 8 x 64 partial scores
-    uint4 *Xr = lds + 2 * KG2 * HK_LD;                 // [XBUFS][XROWS][65]
-    uint4 *Dsc = Xr + XBUFS * XROWS * HK_LDX;          // [n_words] packed descriptors
-    auto xbuf = [](int s) constexpr { return IMG ? s : (s & 1); };   // the buffer of slice s
+    uint4 *Xr = lds + 2 * KG2 * HK_LD;                 // [2][XROWS][65]
+    uint4 *Dsc = Xr + 2 * XROWS * HK_LDX;              // [n_words] packed descriptors
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wave >= 8;                   // waves 8..11: one per SIMD beside two consumers (waves are dealt to SIMDs cyclically)
@@ -207,8 +197,8 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     if (producer) {
         // =========================================== PRODUCERS: the gather ===========================================
         int wl = 0, it0 = 0;                        // word of the slice this thread moves; first of its IPT items inside the tile
-        uint32_t idxr[IMG ? 2 : 1][IPT];            // index values of the slice(s) whose rows are loaded next
-        uint4 rows[DS][IPT];                        // row words in flight: DS slices
+        uint32_t idxr[IPT];                         // index values of the slice whose rows are loaded next
+        uint4 rows[D][IPT];                         // row words in flight: D slices
         unsigned bad = 0u;                          // out-of-range index seen (a lane flag, OR-ed: no compare mask is kept)
         uint2 *Xh2 = reinterpret_cast<uint2 *>(Xr);
         uint32_t *Xw = reinterpret_cast<uint32_t *>(Xr);
@@ -218,12 +208,12 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             const int w = WPG * KGS * s + (wl < nw ? wl : nw - 1);           // as their neighbour, no extra line is fetched -- and never store it
             return w < a.n_words ? w : a.n_words - 1;
         };
-        auto I_op = [&](const HkTile &t, int s, int set = 0) {  // index loads of slice s
+        auto I_op = [&](const HkTile &t, int s) {  // index loads of slice s
             const uint4 d = Dsc[slice_word(s)];
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(t.idx), 0, (unsigned)t.batch * (unsigned)a.idx_stride * 4u, 0x00020000);
 #pragma unroll
             for (int i = 0; i < IPT; i++)   // items past the batch: out of the resource's bounds, 0 comes back (no branch)
-                idxr[set][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)(t.m0 + it0 + i) * (unsigned)a.idx_stride * 4u + (d.w & 0x7FFFFFFFu), 0, 0);
+                idxr[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)(t.m0 + it0 + i) * (unsigned)a.idx_stride * 4u + (d.w & 0x7FFFFFFFu), 0, 0);
         };
 #ifdef FR_HS_DIAG
         // timing ablations (FR_FUSED_HS_ABLATE, wrong scores).  1: the producers load no rows -- the consumers' own pace.  2: every row load reads
@@ -235,7 +225,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
         constexpr bool no_rows = false;
         constexpr uint32_t zero_above = 0u;
 #endif
-        auto R_op = [&](const HkTile &t, int s, uint4 (&r)[IPT], int set = 0) {  // row loads of slice s (its indices are in idxr[set])
+        auto R_op = [&](const HkTile &t, int s, uint4 (&r)[IPT]) {  // row loads of slice s (its indices are in idxr)
             const uint4 d = Dsc[slice_word(s)];
             const bool dense = (d.w >> 31) != 0;
             const uint64_t base = (((uint64_t)(d.y & 0xFFFFu) << 32) | d.x) + (dense ? (uint64_t)reinterpret_cast<uintptr_t>(t.dense) : 0ull);
@@ -243,7 +233,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
 #pragma unroll
             for (int i = 0; i < IPT; i++) {
                 const unsigned m = (unsigned)(t.m0 + it0 + i);
-                uint32_t x = idxr[set][i];
+                uint32_t x = idxr[i];
                 const bool oob = !dense & (x >= nrows);  // reference: silent out-of-bounds read (embedding_47_krnl.cpp:927-933); here reported
                 bad |= oob ? 1u : 0u;
                 x = oob ? 0u : x;
@@ -266,76 +256,20 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
                 for (int i = 0; i < IPT; i++) {
                     const uint32_t in = (0u - (uint32_t)(t.m0 + it0 + i < t.batch)) & real;  // all ones / zero: items past the batch are zero rows, branch-free
                     if constexpr (PREC == 1) {
-                        uint2 *xb = Xh2 + (size_t)xbuf(s) * (XROWS * HK_LDX * 2);
+                        uint2 *xb = Xh2 + (size_t)(s & 1) * (XROWS * HK_LDX * 2);
                         uint2 hv;
                         hv.x = pack_bf16x2(__uint_as_float(r[i].x), __uint_as_float(r[i].y)) & in;
                         hv.y = pack_bf16x2(__uint_as_float(r[i].z), __uint_as_float(r[i].w)) & in;
                         xb[((size_t)(wl >> 1) * HK_LDX + it0 + i) * 2 + (wl & 1)] = hv;  // slice word wl = half (wl & 1) of q8 row wl / 2
                     } else {
                         // word wl = k 4 wl .. 4 wl + 3 of the slice: k-group wl / 8, step (wl % 8) / 4, lane half ((wl % 8) % 4) / 2, dword wl % 2
-                        uint32_t *xb = Xw + (size_t)xbuf(s) * (XROWS * HK_LDX * 4);
+                        uint32_t *xb = Xw + (size_t)(s & 1) * (XROWS * HK_LDX * 4);
                         xb[((size_t)(2 * (wl >> 3) + ((wl >> 1) & 1)) * HK_LDX + it0 + i) * 4 + 2 * ((wl >> 2) & 1) + (wl & 1)] = pack_fp8_word(r[i], xscale) & in;
                     }
                 }
             }
         };
         HkTile cur = tile_at(t_cur);
-        if constexpr (IMG) {
-            // ---- whole-image form ----
-            // slot u = the NEXT tile's slice u: request the indices of u + 3, write u (rows requested two slots ago), request the rows of
-            // u + 2 -- indices before rows, so that a wait for the indices of u + 2 does not also wait for the rows of u + 1 (in-order
-            // vector-memory counter).  Slot u may fire once the current tile's FC1 step u is over (barrier u + 1 or later); the table
-            // spreads the NSL slots over the tile: FC1 steps first (they are short: 2 k-groups), then every barrier up to "R3 stored".
-            auto fire = [](int u) constexpr {   // the barrier after which slot u runs
-                constexpr int POST = 6;                      // barriers NSL .. NSL + 5 each take one slot
-                constexpr int NF = NSL - POST;               // slots under FC1: at steps 1 + u * (NSL - 1) / NF, never before step u + 1
-                if (u >= NF) return NSL + (u - NF);
-                const int st = 1 + (u * (NSL - 1)) / NF;
-                return st > u + 1 ? st : u + 1;
-            };
-            wl = tid & (LW - 1), it0 = ((tid - 512) / LW) * IPT;
-            auto begin_tile = [&](const HkTile &t) {   // rows of slices 0, 1 and the indices of slice 2 requested
-                I_op(t, 0, 0);
-                I_op(t, 1, 1);
-                R_op(t, 0, rows[0], 0);
-                R_op(t, 1, rows[1], 1);
-                I_op(t, 2, 0);
-            };
-            auto slot = [&](const HkTile &t, int u) {
-                if (u + 3 < NSL) I_op(t, u + 3, (u + 3) % 2);
-                W_op(t, u, rows[u % 2]);
-                if (u + 2 < NSL) R_op(t, u + 2, rows[u % 2], (u + 2) % 2);
-            };
-            begin_tile(cur);   // the workgroup's first tile: its whole image before the consumers' first step
-#pragma unroll
-            for (int u = 0; u < NSL; u++) slot(cur, u);
-            while (true) {
-                const int t_nxt = next_tile(t_cur);
-                const bool has_next = t_nxt < n_tiles;
-                HkTile nxt = cur;
-                if (has_next) nxt = tile_at(t_nxt);
-                else nxt.batch = 0;  // no next tile: row 0 of every table (index loads out of bounds return 0) into an image nobody consumes
-                int tid_o = tid;
-                asm volatile("" : "+v"(tid_o));
-                wl = tid_o & (LW - 1), it0 = (((tid_o - 512) & 255) / LW) * IPT;
-                begin_tile(nxt);
-#pragma unroll
-                for (int b = 0; b < NBAR; b++) {
-                    pbar(b);
-#pragma unroll
-                    for (int u = 0; u < NSL; u++)
-                        if (fire(u) == b) slot(nxt, u);
-                }
-                tile_no++;
-                if (!has_next) break;
-                cur = nxt;
-                t_cur = t_nxt;
-            }
-            stamp(126);
-            if (bad) atomicOr_system(a.err_flag, 1);
-            return;
-        }
-        if constexpr (!IMG) {
         {   // prologue: the first tile's slices 0, 1 into LDS, 2 .. D + 1 requested, the indices of D + 2 requested (every tile starts so).
             // (Issuing every index load first -- two dependent latencies instead of D + 2 -- measured no different: at launch start, with
             // every workgroup in its prologue, the chain takes 13-14 us either way, and the extra index registers spill.)
@@ -376,16 +310,15 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             W_op(nxt, 1, rows[1 % D]);
             R_op(nxt, 1 + D, rows[1 % D]);
             I_op(nxt, 2 + D);
-            pbar(B_FC2);           // FC2 done
-            pbar(B_FC2 + 1);       // R2 stored
-            pbar(B_FC2 + 2);       // R3 stored
-            pbar(B_FC2 + 3);       // partial scores
+            pbar(NSL + 1);         // FC2 done
+            pbar(NSL + 2);         // R2 stored
+            pbar(NSL + 3);         // R3 stored
+            pbar(NSL + 4);         // partial scores
             tile_no++;
             if (!has_next) break;
             cur = nxt;
             t_cur = t_nxt;
         }
-        }   // !IMG
         stamp(126);
         if (bad) atomicOr_system(a.err_flag, 1);
         return;
@@ -448,9 +381,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             if (kCStamps && s == 0 && tile_no == 0) cstamp(2);
             if (s == 0) so1 = n1;  // k-group 0; advanced once per k-group: inside k-group g it points at g + 1
             asm volatile("" : "+s"(so1));
-            unsigned xo = xlane + (unsigned)xbuf(s) * (XROWS * HK_LDX);
-            if constexpr (IMG) asm volatile("" : "+v"(xo));   // NSL buffers: left visible, hipcc keeps an address register per buffer live across the tile
-            const uint4 *xb = lds + xo;
+            const uint4 *xb = lds + xlane + (s & 1) * (XROWS * HK_LDX);
             uint4 b0 = xb[0], b1 = xb[32];
 #pragma unroll
             for (int gl = 0; gl < kgs; gl++) {
@@ -508,10 +439,6 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             for (int j = 0; j < KG2; j++) {
                 const int jn = j + 1 < KG2 ? j + 1 : j;
                 const uint4 bn0 = bl[(size_t)(2 * jn) * HK_LD], bn1 = bl[(size_t)(2 * jn) * HK_LD + 32];
-                if constexpr (IMG) {   // two producer slots inside FC2 (nothing of LDS changes hands here: the barriers only pace the gather)
-                    if (j == KG2 / 4) bar(NSL + 1);
-                    if (j == KG2 / 2) bar(NSL + 2);
-                }
                 if (j % 8 == 0) {  // so2 = k-group j + RB / 2: the refills of this block of 8 k-groups are fragments 0 .. 15 past it
                     so2 = n2 + (unsigned)(j + RB / 2) * W2.row2;
                     asm volatile("" : "+s"(so2));
@@ -529,12 +456,12 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
                 b0 = bn0, b1 = bn1;
             }
         }
-        bar(B_FC2);       // every wave is done reading R1: R2 may overlay it
+        bar(NSL + 1);     // every wave is done reading R1: R2 may overlay it
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) store_tile(R2, acc2[t][mt], 64 * wave + 32 * t, 32 * mt, hk, lm, os2);
-        bar(B_FC2 + 1);
+        bar(NSL + 2);
 
         // ---- FC3: 32 outputs x 64 items per wave ----
         f32x16 acc3[2];
@@ -559,7 +486,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
         ring1_fill();  // the next tile's first k-group(s) of FC1: requested before the R3 store and the barriers
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) store_tile(R3, acc3[mt], 32 * wave, 32 * mt, hk, lm, os3);
-        bar(B_FC2 + 2);
+        bar(NSL + 3);
         {   // score[m] = sum_n wout[n] * R3[n][m], fp32 sum: 64 items x 8 slices of the image's rows, fixed-order reduction
             const int il = tid_o & 63, sl = (tid_o >> 6) & 7;
             float sc = 0.0f;
@@ -591,7 +518,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
                 }
             }
             part[sl * 64 + il] = sc;
-            bar(B_FC2 + 3);
+            bar(NSL + 4);
             const int tl = tid_o & 1023;  // (the opaque copy: the score address is computed here, not at the top of the tile)
             if (tl < 64 && cur.m0 + tl < cur.batch) {
                 float t = part[tl];
@@ -622,8 +549,7 @@ static int fused_hk_launch_inst(const FrFusedArgs &a, int n_cu, hipStream_t s) {
     static FrLdsAttrOnce lds_once;  // per instantiation, per device
     if (int rc_ = fr_allow_full_lds(&fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, D, R1D>, lds_once)) return rc_;
     const size_t r1_rows = 2 * (HK_H1 / (PREC == 2 ? 32 : 16));
-    constexpr int NSL_ = (KG + KGS - 1) / KGS;
-    const size_t lds = (r1_rows * HK_LD + (size_t)(D < 0 ? NSL_ : 2) * 2 * KGS * HK_LDX + (size_t)a.n_words) * 16;
+    const size_t lds = (r1_rows * HK_LD + (size_t)2 * 2 * KGS * HK_LDX + (size_t)a.n_words) * 16;
     const int tiles = a.n_batches * a.tiles_per_batch;
     fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, D, R1D><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(768), lds, s>>>(a);
     fr_note_kernel("fr_fused_tile_hs_kernel<%d, %d, %d, %d, %d, %d>", PREC, KG, KGS, LW, D, R1D);
@@ -641,10 +567,6 @@ int frk_fused_hk_launch(const FrFusedArgs &a, int n_cu, int precision, hipStream
         // 398-400 M inf/s, profiles/r03_fused_hs_fp8_ab.txt) -- with the consumers twice as fast as in bf16, the gather, which only runs
         // under FC1, is what a tile waits for.
 #ifdef FR_EXPERIMENTS
-        if (FR_KNOB_ONCE("FUSED_HS_IMG", 1)) {   // whole-image form (D = -2): the gather runs under every phase of the tile
-            if (a.K == 880) return fused_hk_launch_inst<2, 28, 2, 16, -2, 4>(a, n_cu, s);
-            if (a.K == 352) return fused_hk_launch_inst<2, 11, 2, 16, -2, 4>(a, n_cu, s);
-        }
         if (a.K == 880) return fused_hk_launch_inst<2, 28, 2, 16, 2, 4>(a, n_cu, s);   // Model-B: K 880 -> 896 = 28 k-groups of 32, 14 slices of 2
         if (a.K == 352) return fused_hk_launch_inst<2, 11, 2, 16, 3, 4>(a, n_cu, s);   // Model-A: K 352 = 11 k-groups of 32, 6 slices of 2 (1)
 #endif
