@@ -1088,7 +1088,12 @@ static int fused_flush(fr_worker *w) {
             if (t_ > max_tiles) max_tiles = t_;
         }
         const int hk = FR_KNOB_ONCE("FUSED_HK", -1);  // experiments build: 0 = never, 1 = whenever it applies
-        if (c->hk_ok == 1 && hk != 0 && (hk == 1 || tiles >= 2 * c->n_cu)) {
+        // The persistent kernel pays once a workgroup walks more than one tile; where exactly depends on the record: K = 880 (Model-B) from
+        // two tiles per compute unit (at 1.25 / 1.5 the chunked kernel is level / 3 % ahead), K = 352 (Model-A) from 1.25 (371-377 vs
+        // 460-463 M inf/s, at 1.5: 424 vs 452-455 M; with ONE tile per unit the chunked kernel leads 449 vs 409 M) --
+        // profiles/r03_fused_hs_modelA_one_tile_ab.txt
+        const int hs_from = a.K <= 352 ? c->n_cu + c->n_cu / 4 : 2 * c->n_cu;
+        if (c->hk_ok == 1 && hk != 0 && (hk == 1 || tiles >= hs_from)) {
             if (!w->h_blist) {
                 FR_HIP(hipHostMalloc((void **)&w->h_blist, sizeof(FrFusedBatch) * FR_FUSED_MAX_QUEUE * FR_BLIST_RING, hipHostMallocDefault));
                 FR_HIP(hipMalloc((void **)&w->d_blist, sizeof(FrFusedBatch) * FR_FUSED_MAX_QUEUE * FR_BLIST_RING));
