@@ -158,6 +158,13 @@ def steady_run(run_fn, min_s, n_first=4096, env=None, quantum=256):
     return n
 
 
+def bf16_launch_group(B):
+    """Batches per launch of the bf16 rows (fr_ctx_set_stream_group; the context's default is 64): 131072 items, at most 256 batches -- Model-B
+    batch 1024: 128 (8 tiles per persistent workgroup: 340 M inf/s against 330 M at 64), Model-A batch 256: 256 (489 against 435 M);
+    profiles/r03_fused_hs_items_ab.txt, profiles/r03_group_above_64_ab.txt.  Every row says which group it ran at."""
+    return max(64, min(256, 131072 // B))
+
+
 def time_launches(wk, push, per_launch, launches, warm_launches=4, push_launch=None):
     """HIP events on the worker's own stream around `launches` launches (push(i) enqueues one batch; per_launch of them make
     one launch).  -> average launch duration in ms.  With push_launch (launch_pusher below) a launch's batches are pushed by ONE
@@ -549,7 +556,7 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
     wk = fr.Worker(ctx, B)
     group = ctx.stream_group()
     if group > 1:   # fused item-tile kernel: one launch = the whole hot path of min(group, items per launch / B) queued batches
-        per_launch = max(1, min(group, (65536 if precision == "bf16" else 16384) // B))   # bf16: the persistent kernel's launches carry up to 65536 items
+        per_launch = max(1, min(group, (262144 if precision == "bf16" else 16384) // B))   # bf16: the persistent kernel's launches carry as many items as the group allows
         ring = [fr.DeviceBuffer(ctx, B * 4) for _ in range(2 * per_launch)]
         push = lambda i: wk.push_device(B, d_idx[i % len(d_idx)], d_dense[i % len(d_dense)] if d_dense else None, ring[i % len(ring)])
         ms = time_launches(wk, push, per_launch, 100, warm_launches=30, push_launch=launch_pusher(wk, B, d_idx, d_dense, ring, per_launch))
@@ -948,10 +955,12 @@ def main():
 
     if args.group > 0:
         ctx.set_stream_group(args.group)
+    elif args.precision == "bf16" and args.model in ("A", "B"):
+        ctx.set_stream_group(bf16_launch_group(B))   # the group the default line's bf16 rows run at (so that profiled single-configuration runs match them)
     if args.model != "A" or args.precision != "f32":
         # one non-headline configuration on its own: throughput + its roofline leg
         res = leg_config(fr, ctx, model, B, args.precision, d_idx, d_dense, idx_host[0], dense_host[0] if dense_host else None, args.threads, args.depth,
-                         "Model-%s batch=%d %s FC chain, %s, index rows resident in HBM" % (args.model, B, args.precision, "one index per bank" if args.per_bank else "per-table indices"),
+                         "Model-%s batch=%d %s FC chain, %s, index rows resident in HBM, %d batches per launch" % (args.model, B, args.precision, "one index per bank" if args.per_bank else "per-table indices", ctx.stream_group()),
                          min_s=0.0 if args.roofline_only else (0.05 if args.quick else 1.0), env=env)
         if rank == 0:
             print(json.dumps({"metric": "inferences/sec", "value": res["value"], "unit": "inferences/s", "n_gpus": world, "steps": args.steps,
@@ -1128,8 +1137,9 @@ def main():
             ih = [uniform_idx(rngb, mb.rows(), 1024) for _ in range(32)]
             di = [fr.DeviceBuffer.from_numpy(cb, a) for a in ih]
             for prec in ("bf16", "f32"):
+                cb.set_stream_group(bf16_launch_group(1024) if prec == "bf16" else 64)
                 cfgs.append(leg_config(fr, cb, mb, 1024, prec, di, None, ih[0], None, args.threads, args.depth,
-                                       "BASELINE configs[2]: Model-B (embedding_98_krnl, 15.1 GB) batch=1024, %s FC, fused concat + FC chain, per-table indices" % prec
+                                       "BASELINE configs[2]: Model-B (embedding_98_krnl, 15.1 GB) batch=1024, %s FC, fused concat + FC chain, per-table indices, %d batches per launch (fr_ctx_set_stream_group)" % (prec, bf16_launch_group(1024))
                                        if prec == "bf16" else "Model-B batch=1024, f32 FC (the reference's own precision), per-table indices",
                                        pmc_key="fused_h_B1024_bf16" if prec == "bf16" else None, profile_csv="r03_B1024_%s_kernel_stats.csv" % prec))
             cb.close()
@@ -1140,8 +1150,9 @@ def main():
             cb.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
             ihb = [uniform_idx(rngb, mbb.index_ranges(), 1024) for _ in range(32)]
             dib = [fr.DeviceBuffer.from_numpy(cb, a) for a in ihb]
+            cb.set_stream_group(bf16_launch_group(1024))
             cfgs.append(leg_config(fr, cb, mbb, 1024, "bf16", dib, None, ihb[0], None, args.threads, args.depth,
-                                   "BASELINE configs[2] under the kernel's index contract: Model-B batch=1024, bf16 FC, ONE index per bank (FR_INDEX_PER_BANK, 49 banks)"))
+                                   "BASELINE configs[2] under the kernel's index contract: Model-B batch=1024, bf16 FC, ONE index per bank (FR_INDEX_PER_BANK, 49 banks), %d batches per launch" % bf16_launch_group(1024)))
             cb.close()
         except Exception as ex:
             cfgs.append({"workload": "Model-B", "error": repr(ex)})
@@ -1157,7 +1168,7 @@ def main():
                 # bf16: a launch group of 256 batches = four 64-item tiles per compute unit per launch, which is what the persistent kernel
                 # (fr_fused_tile_hs_kernel) needs to overlap one tile's gather with another's FC phases; at the default 64 (one tile per compute
                 # unit, the chunked kernel) the same leg gives 434-436 M inf/s against 489 M (profiles/r03_group_above_64_ab.txt)
-                ga = 256 if prec == "bf16" and B * 256 <= 65536 else 64
+                ga = bf16_launch_group(B) if prec == "bf16" else 64
                 ca.set_stream_group(ga)
                 cfgs.append(leg_config(fr, ca, ma, B, prec, dia, None, iha[0], None, args.threads, args.depth,
                                        "Model-A batch=%d (the headline workload), %s FC chain through the fused item-tile kernel, %d batches per launch (fr_ctx_set_stream_group)" % (B, prec, ga)))
@@ -1312,6 +1323,7 @@ def main():
                 cbb = fr.Context(mbb, device=local_rank)
                 cbb.fill_tables(fr.FILL_HASH, SEED_TABLES)
                 cbb.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+                cbb.set_stream_group(bf16_launch_group(1024))   # as the N = 1 line's configs[2] row
                 holder["b"] = (mbb, cbb)
                 return mbb, cbb
 

@@ -1352,10 +1352,12 @@ extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_i
         w->in_flight = true;
         // a launch is due when the group is full or when the queue already covers the chip (256 CUs x 64 items): large batches
         // need fewer of them per launch
-        // a launch carries at most 16384 items (one 64-item tile per compute unit) -- 65536 in the bf16 chain, whose persistent kernel's
-        // workgroups overlap the gather of their next tile with the FC phases of the current one (4 tiles per workgroup)
+        // a launch carries at most 16384 items (one 64-item tile per compute unit) -- in the bf16 chain, whose persistent kernel's workgroups
+        // overlap the gather of their next tile with the FC phases of the current one, as many as the launch group allows (up to 256 batches
+        // of 1024 items): every launch exposes its first tile's gather once (13-14 us), so more tiles per workgroup amortise it -- Model-B
+        // 1024: 330 M inf/s at 4 tiles per workgroup (group 64), 340 M at 8 (group 128), 342 M at 16 (profiles/r03_fused_hs_items_ab.txt)
         const bool big = c->fc_precision == FR_FC_BF16 || (c->fc_precision == FR_FC_FP8 && FR_KNOB_ONCE("FUSED_HK", -1) == 1);
-        const int64_t max_items = FR_KNOB_ONCE("FUSED_ITEMS", 0) ? FR_KNOB_ONCE("FUSED_ITEMS", 0) : (big ? 1024 * 64 : 256 * 64);
+        const int64_t max_items = FR_KNOB_ONCE("FUSED_ITEMS", 0) ? FR_KNOB_ONCE("FUSED_ITEMS", 0) : (big ? 4096 * 64 : 256 * 64);
         return (w->n_pending >= fused_group(c) || w->pending_items >= max_items || w->n_pending >= FR_FUSED_MAX_QUEUE) ? fused_flush(w) : FR_OK;
     }
     rc = pipeline_push(w, batch, 0, d_idx, d_dense, d_scores);

@@ -244,7 +244,7 @@ int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d_idx, const
 /* Streaming form of the hot loop: enqueue batch after batch WITHOUT synchronising, as the reference's loop does
  * (cuda_server.c:406-497).  Any FC precision; needs an unsharded, SEMANTIC-layout context.  Two execution forms, chosen per context:
  *  - models whose activations fit in LDS (A, B) stream through the fused item-tile kernel: pushed batches are QUEUED on the worker and
- *    one launch carries fr_ctx_stream_group(ctx) of them (or fewer once 16384 items are queued; 65536 in the bf16 chain); nothing runs before the group is full
+ *    one launch carries fr_ctx_stream_group(ctx) of them (or fewer once 16384 items are queued; 262144 in the bf16 chain); nothing runs before the group is full
  *    or fr_worker_sync() is called;
  *  - every other model rides the stage pipeline: each push issues one launch in which this batch is gathered while the previous four
  *    batches of the worker advance through FC1, FC2, FC3 and the output layer.

@@ -2184,6 +2184,41 @@ def test_launch_groups_above_64(fr, O, ctxs):
             wk.close()
         with pytest.raises(fr.FleetRecError):
             ctx.set_stream_group(257)
+        # Model-B, batches of 1024: a group of 128 = 131 072 items = 2 048 tiles in ONE launch (8 per persistent workgroup) -- more than the
+        # 65 536 items a bf16 launch carried before the item cap followed the group.  Same bits as the chunked kernel's small launch.
+        mb, cb = ctxs(fr.MODEL_B)
+        gb = cb.stream_group()
+        cb.set_fc_precision(fr.FC_BF16)
+        try:
+            poolb = [fr.DeviceBuffer.from_numpy(cb, uniform_idx(rng, mb.rows(), 1024)) for _ in range(3)]
+            wkb = fr.Worker(cb, 1024)
+            cb.set_stream_group(64)
+            baseb = [fr.DeviceBuffer(cb, 1024 * 4) for _ in range(3)]
+            for j in range(3):
+                wkb.push_device(1024, poolb[j], None, baseb[j])
+            wkb.sync()
+            assert wkb.last_kernel().startswith("fr_fused_tile_h_kernel<"), wkb.last_kernel()
+            wantb = [o.download(np.float32, 1024) for o in baseb]
+            cb.set_stream_group(128)
+            outb = [fr.DeviceBuffer(cb, 1024 * 4) for _ in range(128)]
+            szb = [1024, 1024, 1000, 1024, 513]
+            for i, o in enumerate(outb):
+                o.upload(np.full(1024, np.nan, np.float32))
+                wkb.push_device(szb[i % 5], poolb[i % 3], None, o)
+                assert wkb.last_kernel().startswith("fr_fused_tile_h_kernel<") or i == 127, (i, wkb.last_kernel())   # nothing leaves before the 128th push
+            assert wkb.last_kernel().startswith("fr_fused_tile_hs_kernel<1, 55,"), wkb.last_kernel()
+            wkb.sync()
+            for i, o in enumerate(outb):
+                b = szb[i % 5]
+                got = o.download(np.float32, 1024)
+                assert np.isnan(got[b:]).all() and np.array_equal(got[:b], wantb[i % 3][:b]), (i, b)
+                o.free()
+            for o in baseb + poolb:
+                o.free()
+            wkb.close()
+        finally:
+            cb.set_stream_group(gb)
+            cb.set_fc_precision(fr.FC_FP32)
     finally:
         ctx.set_stream_group(g0)
         ctx.set_fc_precision(fr.FC_FP32)
