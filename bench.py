@@ -40,7 +40,8 @@ MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0}   # dense MFMA peak
 SEED_TABLES, SEED_IDX, SEED_WEIGHTS = 0xF1EE7, 1234, 99
 N_IDX_BUFFERS = 64           # distinct index buffers rotated through (>= 32), so caches are not re-hit artificially
 STEADY_S = 2.2               # minimum wall clock of the timed region behind `value`
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")   # falls back to r02_pmc.json entry by entry (see pmc())
+PROFILE_ROUND = "r04"       # prefix of the committed rocprofv3 summaries the roofline objects quote (profiles/<round>_*_kernel_stats.csv)
+PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json")]   # newest first, entry by entry (see pmc())
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -93,6 +94,156 @@ def self_launch(n):
     return rc
 
 
+
+# ------------------------------------------------------------------------------------------------------------------
+# output: ONE compact JSON line on stdout (the driver parses it; VERDICT r03: a 21.7 KB line did not parse), everything else in a file
+# ------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+DETAIL_FILE = os.environ.get("FR_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _r(x, sig=6):
+    """Round floats to `sig` significant digits (the line is a summary; the detail file keeps every digit)."""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x))
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def compact_line(result):
+    """The line the driver reads: the contract keys + `roofline` + `cpu_baseline` + the few figures the reference's own one-screen
+    report would carry (cuda_server.c:565-591).  Everything else of `result` lives in the detail file."""
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: result.get(k) for k in keys}
+    cfg = dict(result.get("config") or {})
+    line["config"] = cfg
+    for k in ("timed_batches", "timed_s", "value_pcie_inclusive", "sharded_error"):
+        if result.get(k) is not None:
+            line[k] = result[k]
+    rf = result.get("roofline")
+    if rf:
+        line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_name", "avg_launch_ms", "batches_per_launch",
+                                      "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch", "profiled_avg_launch_us", "profile", "pmc_mfma_busy_fraction"))
+        line["roofline"].setdefault("traffic", None)
+    cb = result.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "gather_only", "fc_only", "end_to_end", "gather_threads", "fc_threads", "host_cpus_usable",
+                                          "blas", "sample", "error"))
+        for k, n in (("blas", 56), ("sample", 230)):   # the long forms are in the detail file
+            if isinstance(line["cpu_baseline"].get(k), str) and len(line["cpu_baseline"][k]) > n:
+                line["cpu_baseline"][k] = line["cpu_baseline"][k][:n - 3] + "..."
+    for gk in ("gather_per_bank", "gather"):
+        g = result.get(gk)
+        if g and "achieved" in g:
+            line[gk] = _pick(g, ("achieved", "frac", "traffic", "unit", "kernel_name", "avg_launch_ms"))
+    rows = {}
+    for c in result.get("configs") or []:
+        if "tag" in c and c.get("value") is not None:
+            rows[c["tag"]] = _r({"inf_per_s": c["value"], "kernel_frac": (c.get("roofline") or {}).get("frac")}, 4)
+    if rows:
+        line["other_configs"] = rows
+    for k in ("gather_per_bank_all_ranks",):
+        if result.get(k):
+            line[k] = _pick(result[k], ("achieved", "frac", "unit", "ranks_measured"))
+    if result.get("configs_all_ranks"):
+        line["configs_all_ranks"] = {c.get("tag", str(i)): _r({"inf_per_s": c["value"], "ranks": c.get("ranks_measured")}, 4) for i, c in enumerate(result["configs_all_ranks"])}
+    for k in ("sharded", "sharded_inflated_fp8"):
+        sh = result.get(k)
+        if sh:
+            c_ = sh.get("config") or {}
+            line[k] = _r({"value": sh.get("value"), "ms_per_step": sh.get("ms_per_step"), "dtype": sh.get("dtype"), "n_gpus": sh.get("n_gpus"), "scaling": sh.get("scaling"),
+                          "exchange": c_.get("exchange"), "ok": bool(c_.get("pipelined_equals_stepwise"))}, 5)
+    line["detail"] = os.path.relpath(DETAIL_FILE, ROOT)
+    line = _r(line)
+    s = json.dumps(line, separators=(",", ":"))
+    if len(s) >= LINE_LIMIT:   # never let a growing leg list break the parser again: drop the optional summaries, largest first
+        for k in ("other_configs", "configs_all_ranks", "gather", "sharded_inflated_fp8", "sharded", "gather_per_bank_all_ranks"):
+            line.pop(k, None)
+            s = json.dumps(line, separators=(",", ":"))
+            if len(s) < LINE_LIMIT:
+                break
+    return s
+
+
+def emit(result, final=True):
+    """Write the full result to the detail file, print the compact line (rank 0 only calls this)."""
+    try:
+        os.makedirs(os.path.dirname(DETAIL_FILE), exist_ok=True)
+        with open(DETAIL_FILE + ".tmp", "w") as f:
+            json.dump(result, f, indent=1)
+        os.replace(DETAIL_FILE + ".tmp", DETAIL_FILE)
+    except OSError as ex:
+        sys.stderr.write("bench.py: detail file not written: %r\n" % ex)
+    if final:
+        sys.stdout.write(compact_line(result) + "\n")
+        sys.stdout.flush()
+
+
+class LineGuard:
+    """Legs with data-path collectives inside their step loop: a rank that fails there leaves its peers in a collective.  The headline
+    must not be lost to that, and the exit status must say what happened (the reference exits with
+    EXIT_FAILURE on socket errors, cuda_server.c:366-398).  While armed, whatever happens -- the leg raises, it exceeds its limit, or
+    the launcher terminates this rank because a peer died (SIGTERM; seen through signal.set_wakeup_fd by a helper thread, since the main
+    thread may sit inside a collective's C code where Python handlers do not run) -- rank 0 prints the line as it stands with
+    `sharded_error`, and the process leaves through os._exit(4).  Never a re-exec: this process has touched the GPU."""
+    STATUS = 4
+
+    def __init__(self, rank, result):
+        import signal
+        import threading
+        self.rank, self.result = rank, result
+        self.lock = threading.Lock()
+        self.done = None
+        self.leg = None
+        self.rfd, self.wfd = os.pipe()
+        os.set_blocking(self.wfd, False)
+        self.old_handler = signal.signal(signal.SIGTERM, lambda *_: None)   # a Python-level handler must exist for the wake-up fd to be written
+        self.old_fd = signal.set_wakeup_fd(self.wfd, warn_on_full_buffer=False)
+        threading.Thread(target=self._watch_signal, daemon=True).start()
+
+    def _watch_signal(self):
+        try:
+            if os.read(self.rfd, 1):
+                self.bail("%s: this rank was terminated by the launcher (a peer rank failed)" % (self.leg or "collective leg"))
+        except OSError:
+            pass
+
+    def bail(self, why):
+        with self.lock:   # first caller wins, and never returns
+            if self.rank == 0 and self.result is not None:
+                self.result["sharded_error"] = why
+                emit(self.result)
+            sys.stderr.write("rank %d: %s\n" % (self.rank, why))
+            sys.stderr.flush()
+            os._exit(self.STATUS)
+
+    def run(self, name, limit, fn):
+        import threading
+        self.leg = name
+        done = threading.Event()
+        threading.Thread(target=lambda: None if done.wait(limit) else self.bail("%s did not finish within %.0f s" % (name, limit)), daemon=True).start()
+        try:
+            return fn()
+        except BaseException as ex:   # noqa: BLE001 -- whatever it was, the peers are waiting in a collective: report and leave
+            done.set()
+            self.bail("%s failed on rank %d: %r" % (name, self.rank, ex))
+        finally:
+            done.set()
+
+    def close(self):
+        import signal
+        signal.set_wakeup_fd(self.old_fd)
+        signal.signal(signal.SIGTERM, self.old_handler)
+        os.close(self.wfd)   # the watcher's read returns b"" and it ends
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # helpers
 # ------------------------------------------------------------------------------------------------------------------
@@ -109,7 +260,7 @@ def fc_flops_per_inference(fc):
 def pmc(key, field=None):
     """Committed PMC summary (tools/pmc_passes.sh -> profiles/r02_pmc.json): separate rocprofv3 --pmc passes of this script's legs,
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md.  -> the entry, one field of it, or None."""
-    for path in (PMC_FILE, os.path.join(ROOT, "profiles", "r02_pmc.json")):
+    for path in PMC_FILES:
         try:
             e = json.load(open(path)).get(key)
         except Exception:
@@ -118,6 +269,14 @@ def pmc(key, field=None):
             e = dict(e, pmc_file="profiles/" + os.path.basename(path))
             return e if field is None else e.get(field)
     return None
+
+
+def find_profile(suffix):
+    """Newest committed rocprofv3 summary profiles/rNN_<suffix> (this round's, else an earlier round's for legs whose kernel did not change)."""
+    for rnd in ("r04", "r03", "r02"):
+        if os.path.exists(os.path.join(ROOT, "profiles", "%s_%s" % (rnd, suffix))):
+            return "%s_%s" % (rnd, suffix)
+    return "%s_%s" % (PROFILE_ROUND, suffix)
 
 
 def profiled_avg_us(csv_name, kernel):
@@ -373,7 +532,12 @@ def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=
         O.lib().oracle_set_num_threads(threads)
     except Exception as ex:
         b1 = {"error": repr(ex)[:200]}
-    return {"value": e_rate, "unit": "inferences/s", "cores": threads, "kind": "port", "batch_1": b1,
+    fc_threads = (alt or {}).get("threads") if blas_used is None else blas["threads"]
+    # `cores` = the most host threads any phase of the end-to-end figure ran on: the gather's OpenMP team (`gather_threads`, the fastest of the
+    # probe above -- all cores is not the fastest: hyper-threads / cgroup quotas) and the FC engine's pool (`fc_threads`: OpenBLAS builds cap
+    # at 64, torch.mm takes its own default) run one after the other, never at the same time
+    return {"value": e_rate, "unit": "inferences/s", "cores": max(threads, fc_threads or 0), "gather_threads": threads, "fc_threads": fc_threads,
+            "kind": "port", "batch_1": b1,
             "gather_only": g_rate, "fc_only": f_rate, "end_to_end": e_rate,
             "gather_GBps_algorithmic": g_rate * gbytes / 1e9, "fc_GFLOPs": f_rate * fc_flops_per_inference(fc) / 1e9,
             "blas": blas["name"] if blas else "torch.mm (" + __import__("torch").__config__.parallel_info().split("\n")[0] + ")",
@@ -381,10 +545,9 @@ def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=
             "fc_engine_of_end_to_end": "torch.mm" if blas_used is None else blas_used["symbol"], "fc_second_engine": alt,
             "gather_thread_probe_s": {str(k): v for k, v in probe.items()}, "host_cpus_usable": usable,
             "gpu_vs_cpu_max_rel_err_first_batch": err, "host_table_bytes": int(sum(im.nbytes for im in imgs)), "host_table_fill_s": t_fill,
-            "sample": "Model-A, %d items per call (64 batches of 256, the grouping one fused GPU launch gets), same seeded tables / weights / index law, 8 index "
-                      "groups rotated (the first = the GPU run's buffers); "
-                      "gather-only %d calls, FC-only %d, end-to-end %d (>= %.1f s each); gather = OpenMP over items reading bank images in host RAM "
-                      "(oracle_gather_banks_direct), FC = 4 chained column-major sgemm calls" % (n, g_reps, f_reps, e_reps, budget_s)}
+            "sample": "Model-A, %d items per call (64 batches of 256 = one fused GPU launch), gather-only %d calls, FC-only %d, end-to-end %d (>= %.1f s each); "
+                      "same seeded tables / weights / index law, 8 index groups rotated (the first = the GPU run's buffers); gather = OpenMP over items reading "
+                      "bank images in host RAM (oracle_gather_banks_direct), FC = 4 chained column-major sgemm calls" % (n, g_reps, f_reps, e_reps, budget_s)}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -521,7 +684,7 @@ def leg_group_table(fr, ctx, model, B, d_idx, threads, depth):
     return out
 
 
-def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_host0, threads, depth, label, min_s=1.0, pmc_key=None, env=None, profile_csv=None):
+def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_host0, threads, depth, label, min_s=1.0, pmc_key=None, env=None, profile_csv=None, tag=None):
     """One non-headline BASELINE configuration: steady-state throughput (>= 1 s) + an in-run roofline object for its dominant
     kernel from HIP events on one worker's stream."""
     prec_enum = {"f32": fr.FC_FP32, "bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[precision]
@@ -547,11 +710,11 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
         else:
             el = dv.run_resident(B, n, d_idx, d_dense)
         dv.close()
-        res = {"workload": label, "dtype": precision, "value": world * n * B / el, "unit": "inferences/s", "timed_batches": n, "timed_s": el,
+        res = {"tag": tag, "workload": label, "dtype": precision, "value": world * n * B / el, "unit": "inferences/s", "timed_batches": n, "timed_s": el,
                "ms_per_step": 1e3 * el / n, "fc_tflops_end_to_end": flops_inf * B * n * world / el / 1e12,
                "frac_of_mfma_peak_end_to_end": flops_inf * B * n / el / 1e12 / MFMA_PEAK_TF[precision]}
     else:   # --roofline-only: no multi-stream loop
-        res = {"workload": label, "dtype": precision, "value": None, "unit": "inferences/s", "timed_batches": 0, "timed_s": 0.0, "ms_per_step": None,
+        res = {"tag": tag, "workload": label, "dtype": precision, "value": None, "unit": "inferences/s", "timed_batches": 0, "timed_s": 0.0, "ms_per_step": None,
                "fc_tflops_end_to_end": None, "frac_of_mfma_peak_end_to_end": None}
     wk = fr.Worker(ctx, B)
     group = ctx.stream_group()
@@ -901,6 +1064,7 @@ def main():
     ap.add_argument("--no-multi-configs", action="store_true", help="N > 1: skip configs_all_ranks (Model-B bf16, Model-C bf16 / fp8 on every rank)")
     ap.add_argument("--no-multi-sharded", action="store_true", help="N > 1: skip the table-sharded legs (`sharded`, `sharded_inflated_fp8`) of the default line")
     ap.add_argument("--fail-rank", type=int, default=-1, help="--plumbing-only: this rank exits with status 3 before the first barrier (launcher fail-fast test)")
+    ap.add_argument("--fail-sharded-rank", type=int, default=-1, help="--plumbing-only: this rank raises inside a guarded collective leg (line + non-zero exit status test)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch / rendezvous / timing-rule check without touching a GPU or the library (CPU test of the multi-GPU launcher)")
     args = ap.parse_args()
@@ -1001,11 +1165,12 @@ def main():
             "metric": "inferences/sec at batch 256", "value": world * n_timed * B / dt, "unit": "inferences/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / n_timed, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Model-A (embedding_47_krnl: 47 tables, 1.415 GB) batch=%d, fp32 FC 352-1024-512-256-1, "
-                                   "all tables resident in one GPU's HBM; hash-filled tables, uniform per-table indices, "
-                                   "index rows resident in HBM (%d rotating buffers), scores left in HBM" % (B, n_bufs),
+            "config": {"workload": "Model-A (embedding_47_krnl: 47 tables, 1.415 GB) batch=%d, fp32 FC 352-1024-512-256-1, all tables resident in "
+                                   "one GPU's HBM; hash-filled tables, uniform per-table indices; index rows resident in HBM when the timed region "
+                                   "starts (%d rotating buffers), scores left in HBM (bench contract); value_pcie_inclusive = the same stream fed "
+                                   "from host memory with scores delivered to host memory" % (B, n_bufs),
                        "batch": B, "driver_threads": args.threads, "workers_per_thread": args.depth,
-                       "batches_per_fused_launch": ctx.stream_group(), "parallelism": "replicas x%d" % world},
+                       "batches_per_launch": ctx.stream_group(), "parallelism": "replicas x%d" % world},
             "timed_batches": n_timed, "timed_s": dt,
             "value_is": "steady state: %d back-to-back batches per rank over %.2f s (sized for >= %.1f s from a calibration run, whatever --steps says)" % (n_timed, dt, STEADY_S),
             "burst": {"steps": args.steps, "warmup": args.warmup, "value": world * args.steps * B / burst_dt, "unit": "inferences/s",
@@ -1039,10 +1204,11 @@ def main():
                                                 "FETCH_SIZE x2 gfx950 correction), bytes per launch; read from the committed file, not measured in this run" % pm.get("pmc_file"),
                               "kernel": "%s: one launch = the whole hot path (gather + the 4-GEMM chain) of %d queued batches of %d, "
                                         "back-to-back on ONE stream" % (kname, group, B),
-                              "kernel_name": kname, "profiled_avg_launch_us": profiled_avg_us("r03_roofline_kernel_stats.csv", kname),
-                              "profile": "profiles/r03_roofline_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --roofline-only`); "
-                                         "profiles/r03_value_4streams_kernel_stats.csv is the same kernel under the DEFAULT four-stream `value` run",
-                              "profiled_avg_launch_us_4streams": profiled_avg_us("r03_value_4streams_kernel_stats.csv", kname),
+                              "kernel_name": kname, "profiled_avg_launch_us": profiled_avg_us(find_profile("roofline_kernel_stats.csv"), kname),
+                              "profile": "profiles/" + find_profile("roofline_kernel_stats.csv"),
+                              "profile_what": "rocprofv3 --kernel-trace --stats of `bench.py --roofline-only`; *_value_4streams_kernel_stats.csv is the same kernel "
+                                              "under the DEFAULT four-stream `value` run",
+                              "profiled_avg_launch_us_4streams": profiled_avg_us(find_profile("value_4streams_kernel_stats.csv"), kname),
                               "batches_per_launch": group, "avg_launch_ms": pipe_ms, "algorithmic_flops_per_launch": flops,
                               "pmc_mfma_busy_fraction": pm.get("mfma_busy_fraction"), "pmc_mfma_f32_flops_per_launch": pm.get("mfma_f32_flops_per_launch"),
                               "note": "`value` above runs %d such streams concurrently" % (args.threads * args.depth)}
@@ -1062,6 +1228,9 @@ def main():
                                                     "stage-pipeline launch, from 12 up a group is one fused launch; launch_ms_one_stream = time per group of pushes"
                                                     % (args.threads, args.depth),
                                         "rows": leg_group_table(fr, ctx, model, B, d_idx, args.threads, args.depth)}
+        for row in result["launch_group_table"]["rows"]:   # latency price of the launch group `value` runs at: first push -> all scores, idle worker
+            if row["group"] == result["config"]["batches_per_launch"]:
+                result["config"]["push_to_scores_us_p50"] = 1e3 * row["push_to_scores_ms_p50"]
 
     if want("pcie"):
         # ---- PCIe-inclusive rates (index rows start in HOST memory, scores end in HOST memory; reported, never `value`) ----
@@ -1141,7 +1310,7 @@ def main():
                 cfgs.append(leg_config(fr, cb, mb, 1024, prec, di, None, ih[0], None, args.threads, args.depth,
                                        "BASELINE configs[2]: Model-B (embedding_98_krnl, 15.1 GB) batch=1024, %s FC, fused concat + FC chain, per-table indices, %d batches per launch (fr_ctx_set_stream_group)" % (prec, bf16_launch_group(1024))
                                        if prec == "bf16" else "Model-B batch=1024, f32 FC (the reference's own precision), per-table indices",
-                                       pmc_key="fused_h_B1024_bf16" if prec == "bf16" else None, profile_csv="r03_B1024_%s_kernel_stats.csv" % prec))
+                                       pmc_key="fused_h_B1024_bf16" if prec == "bf16" else None, profile_csv=find_profile("B1024_%s_kernel_stats.csv" % prec), tag="B1024_" + prec))
             cb.close()
             # the same configuration under the reference kernel's index contract: one index per bank (49 banks of 2 tables), bank rows in HBM
             mbb = mb.clone(index_mode=fr.INDEX_PER_BANK)
@@ -1152,7 +1321,7 @@ def main():
             dib = [fr.DeviceBuffer.from_numpy(cb, a) for a in ihb]
             cb.set_stream_group(bf16_launch_group(1024))
             cfgs.append(leg_config(fr, cb, mbb, 1024, "bf16", dib, None, ihb[0], None, args.threads, args.depth,
-                                   "BASELINE configs[2] under the kernel's index contract: Model-B batch=1024, bf16 FC, ONE index per bank (FR_INDEX_PER_BANK, 49 banks), %d batches per launch" % bf16_launch_group(1024)))
+                                   "BASELINE configs[2] under the kernel's index contract: Model-B batch=1024, bf16 FC, ONE index per bank (FR_INDEX_PER_BANK, 49 banks), %d batches per launch" % bf16_launch_group(1024), tag="B1024_bf16_per_bank"))
             cb.close()
         except Exception as ex:
             cfgs.append({"workload": "Model-B", "error": repr(ex)})
@@ -1171,7 +1340,7 @@ def main():
                 ga = bf16_launch_group(B) if prec == "bf16" else 64
                 ca.set_stream_group(ga)
                 cfgs.append(leg_config(fr, ca, ma, B, prec, dia, None, iha[0], None, args.threads, args.depth,
-                                       "Model-A batch=%d (the headline workload), %s FC chain through the fused item-tile kernel, %d batches per launch (fr_ctx_set_stream_group)" % (B, prec, ga)))
+                                       "Model-A batch=%d (the headline workload), %s FC chain through the fused item-tile kernel, %d batches per launch (fr_ctx_set_stream_group)" % (B, prec, ga), tag="A%d_%s" % (B, prec)))
             ca.close()
         except Exception as ex:
             cfgs.append({"workload": "Model-A low precision", "error": repr(ex)})
@@ -1194,15 +1363,15 @@ def main():
                     g["traffic"] = pm.get("traffic_bytes_per_launch")
                     g["l2_hit_rate"] = pm.get("l2_hit_rate")
                     g["traffic_source"] = "%s (PMC passes of `bench.py --legs gather --gather-law uniform`, FETCH_SIZE x2 correction), bytes per launch" % pm.get("pmc_file")
-                    g["profiled_avg_launch_us"] = profiled_avg_us("r03_gather_per_table_uniform_kernel_stats.csv", g.get("kernel_name"))
-                    g["profile"] = "profiles/r03_gather_per_table_uniform_kernel_stats.csv"
+                    g["profiled_avg_launch_us"] = profiled_avg_us(find_profile("gather_per_table_uniform_kernel_stats.csv"), g.get("kernel_name"))
+                    g["profile"] = "profiles/" + find_profile("gather_per_table_uniform_kernel_stats.csv")
                 if args.gather_law in ("all", "zipf"):
                     z = leg_gather(fr, cc, mc, BC, "zipf", seed=SEED_IDX + 1, variants=not args.no_gather_ab)
                     pm = pmc("gather_C4096_per_table_zipf") or {}
                     z["traffic"] = pm.get("traffic_bytes_per_launch")
                     z["l2_hit_rate"] = pm.get("l2_hit_rate")
-                    z["profiled_avg_launch_us"] = profiled_avg_us("r03_gather_per_table_zipf_kernel_stats.csv", z.get("kernel_name"))
-                    z["profile"] = "profiles/r03_gather_per_table_zipf_kernel_stats.csv"
+                    z["profiled_avg_launch_us"] = profiled_avg_us(find_profile("gather_per_table_zipf_kernel_stats.csv"), z.get("kernel_name"))
+                    z["profile"] = "profiles/" + find_profile("gather_per_table_zipf_kernel_stats.csv")
                     g["zipf_1.05"] = z
                 result["gather"] = g
             if want("configs"):
@@ -1214,7 +1383,7 @@ def main():
                 for prec in ("f32", "bf16", "fp8"):
                     result["configs"].append(leg_config(fr, cc, mc, BC, prec, di, dd, ih[0], dh[0], args.threads, args.depth,
                                                         "Model-C (63.2 GB, unsharded replica) batch=4096, %s FC chain end to end "
-                                                        "(BASELINE configs[3]/[4] shapes on one GPU)" % prec, pmc_key="gemm_C4096_%s" % prec, profile_csv="r03_C4096_%s_kernel_stats.csv" % prec))
+                                                        "(BASELINE configs[3]/[4] shapes on one GPU)" % prec, pmc_key="gemm_C4096_%s" % prec, profile_csv=find_profile("C4096_%s_kernel_stats.csv" % prec), tag="C4096_" + prec))
             if want("gather") or want("configs"):
                 cc.close()
             if want("bank"):
@@ -1229,8 +1398,8 @@ def main():
                 pm = pmc("gather_C4096_per_bank_uniform") or {}
                 gb["traffic"] = pm.get("traffic_bytes_per_launch")
                 gb["l2_hit_rate"] = pm.get("l2_hit_rate")
-                gb["profiled_avg_launch_us"] = profiled_avg_us("r03_gather_per_bank_uniform_kernel_stats.csv", gb.get("kernel_name"))
-                gb["profile"] = "profiles/r03_gather_per_bank_uniform_kernel_stats.csv"
+                gb["profiled_avg_launch_us"] = profiled_avg_us(find_profile("gather_per_bank_uniform_kernel_stats.csv"), gb.get("kernel_name"))
+                gb["profile"] = "profiles/" + find_profile("gather_per_bank_uniform_kernel_stats.csv")
                 result["gather_per_bank"] = gb
                 if want("configs"):   # Model-C end to end under the bank contract (82 bank fetches per item instead of 376 rows)
                     cbk.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
@@ -1241,7 +1410,7 @@ def main():
                     ddk = [fr.DeviceBuffer.from_numpy(cbk, a) for a in dhk]
                     for prec in ("bf16", "fp8"):
                         result["configs"].append(leg_config(fr, cbk, mcb, BC, prec, dik, ddk, ihk[0], dhk[0], args.threads, args.depth,
-                                                            "Model-C batch=4096, %s FC chain end to end, ONE index per bank (FR_INDEX_PER_BANK, 82 banks)" % prec))
+                                                            "Model-C batch=4096, %s FC chain end to end, ONE index per bank (FR_INDEX_PER_BANK, 82 banks)" % prec, tag="C4096_%s_per_bank" % prec))
                 cbk.close()
         except Exception as ex:  # the main metric must still be reported
             result.setdefault("gather", {})["error"] = repr(ex)
@@ -1312,7 +1481,7 @@ def main():
             for prec in ("bf16", "fp8"):   # Model-C per-bank replicas (the context of the gather leg)
                 r_ = all_ranks(lambda: holder["c"], lambda st, p_=prec: config_rate(st[1], st[0], 4096, p_))
                 if rank == 0 and r_ is not None:
-                    cfg_all.append({"workload": "Model-C batch=4096, %s FC chain end to end, one index per bank, one replica per rank" % prec, "dtype": prec,
+                    cfg_all.append({"tag": "C4096_%s_per_bank" % prec, "workload": "Model-C batch=4096, %s FC chain end to end, one index per bank, one replica per rank" % prec, "dtype": prec,
                                     "value": r_[0], "unit": "inferences/s", "ranks_measured": r_[1], "how": "sum of the per-rank rates measured at the same time (>= 1 s each)"})
             if "c" in holder:
                 holder["c"][1].close()
@@ -1329,7 +1498,7 @@ def main():
 
             r_ = all_ranks(b_setup, lambda st: config_rate(st[1], st[0], 1024, "bf16"))
             if rank == 0 and r_ is not None:
-                cfg_all.append({"workload": "BASELINE configs[2]: Model-B batch=1024, bf16 FC, fused concat + FC chain, one replica per rank", "dtype": "bf16",
+                cfg_all.append({"tag": "B1024_bf16", "workload": "BASELINE configs[2]: Model-B batch=1024, bf16 FC, fused concat + FC chain, one replica per rank", "dtype": "bf16",
                                 "value": r_[0], "unit": "inferences/s", "ranks_measured": r_[1], "how": "sum of the per-rank rates measured at the same time (>= 1 s each)"})
             if "b" in holder:
                 holder["b"][1].close()
@@ -1352,39 +1521,20 @@ def main():
                          for t in [m5.tables()[si.src]]) for k in range(world))
         if not args.share_device and m5.min_shards() is not None and m5.min_shards() <= world and shard5 <= 0.85 * 288e9:
             cases.append(("configs[4]", dict(precision="fp8", row_scale=5.0)))
-        # These legs have data-path collectives INSIDE their step loop: a rank that fails there leaves its peers in a collective.  The headline
-        # must not be lost to that: every rank runs a leg under a watchdog; when a leg raises, or does not finish within its limit, rank 0
-        # prints the line as it stands (with `sharded_error`) and every rank leaves through os._exit(0) without another collective.
-        import threading
+        # These legs have data-path collectives INSIDE their step loop: every rank runs them under a LineGuard (above).
         keys = {"configs[3]": "sharded", "configs[4]": "sharded_inflated_fp8"}
-
-        def bail(why):
-            if rank == 0:
-                result["sharded_error"] = why
-                print(json.dumps(result), flush=True)
-            sys.stderr.write("rank %d: %s\n" % (rank, why))
-            sys.stderr.flush()
-            os._exit(0)
-
+        guard = LineGuard(rank, result)
         for name, kw in cases:
             sa = types.SimpleNamespace(batch=4096, steps=50, warmup=10, transport="lp", exchange="allgather", backend=args.backend, rows_cap=args.rows_cap,
                                        no_unsharded_check=False, **kw)
-            done = threading.Event()
-            limit = 300.0
-            dog = threading.Thread(target=lambda: None if done.wait(limit) else bail("%s leg (%s) did not finish within %.0f s" % (keys[name], name, limit)), daemon=True)
-            dog.start()
-            try:
-                res = run_sharded(fr, dist_mod, env, local_rank, sa, auto_steps_s=1.0)
-            except BaseException as ex:   # noqa: BLE001 -- whatever it was, the peers are waiting in a collective: report and leave
-                done.set()
-                bail("%s leg (%s) failed on rank %d: %r" % (keys[name], name, rank, ex))
-            done.set()
+            res = guard.run("%s leg (%s)" % (keys[name], name), 300.0, lambda: run_sharded(fr, dist_mod, env, local_rank, sa, auto_steps_s=1.0))
             res["baseline_config"] = name
             if rank == 0:
                 result[keys[name]] = res
+        guard.close()
 
     if rank == 0:
-        print(json.dumps(result))
+        emit(result)
     env.close()
 
 
@@ -1404,11 +1554,29 @@ def main_plumbing(args, graft):
     time.sleep(0.01 * (1 + env.rank))
     env.barrier()
     dt = env.max_over_ranks(time.perf_counter() - t0)
+    result = None
     if env.rank == 0:
-        print(json.dumps({"metric": "plumbing-only", "value": None, "unit": "inferences/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-                          "data": "none", "config": {"workload": "launcher / rendezvous / max-over-ranks check, no GPU work",
-                                                     "self_launched": os.environ.get("FR_BENCH_SELF_LAUNCHED") == "1"}}))
+        result = {"metric": "plumbing-only", "value": None, "unit": "inferences/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
+                  "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                  "data": "none", "config": {"workload": "launcher / rendezvous / max-over-ranks check, no GPU work",
+                                             "self_launched": os.environ.get("FR_BENCH_SELF_LAUNCHED") == "1"},
+                  # the objects of the real line, empty: the compact-line writer is the same code (tests/test_dist_gloo.py checks the shape)
+                  "roofline": {"bound": "none", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None},
+                  "cpu_baseline": {"value": None, "unit": "inferences/s", "cores": 0, "kind": "port", "sample": "none (plumbing only)"}}
+    if args.fail_sharded_rank >= 0:
+        # the collective-leg guard of the N > 1 line, on the CPU: rank --fail-sharded-rank raises inside the "leg", its peers sit in a barrier it
+        # never joins.  Expected: the line (with `sharded_error`) still appears on stdout, and the job's exit status is LineGuard.STATUS.
+        guard = LineGuard(env.rank, result)
+
+        def leg():
+            if env.rank == args.fail_sharded_rank:
+                time.sleep(0.5)   # let the peers get into their collective first
+                raise RuntimeError("injected failure inside the sharded leg")
+            env.barrier()
+        guard.run("sharded leg (injected failure)", 60.0, leg)
+        guard.close()
+    if env.rank == 0:
+        emit(result)
     env.close()
 
 

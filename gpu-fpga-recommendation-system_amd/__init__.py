@@ -25,7 +25,7 @@ LAYOUT_SEMANTIC, LAYOUT_BLOCKED = 0, 1
 INDEX_PER_TABLE, INDEX_PER_ITEM, INDEX_PER_BANK = 0, 1, 2
 SEG_TABLE, SEG_COPY, SEG_DENSE = 0, 1, 2
 GATHER_WORD_MAJOR, GATHER_ITEM_TILE, GATHER_ITEM_TILE_DEDUP, GATHER_ITEM_TILE_DEDUP_COUNT, GATHER_WORD_MAJOR_ONE_CHUNK = 0, 1, 2, 3, 4
-ABI_VERSION = 3   # include/fleetrec.h FR_ABI_VERSION this binding was written against
+ABI_VERSION = 4   # include/fleetrec.h FR_ABI_VERSION this binding was written against
 MEM_CLASS_NAMES = {0: "HBM", 1: "DDR", 2: "PLRAM"}
 
 
@@ -55,11 +55,11 @@ class FleetRecError(RuntimeError):
 
 _lib = None
 
-# every symbol include/fleetrec.h declares (the not-gpu test checks the .so exports all of them)
+# every symbol include/fleetrec.h, fleetrec_serving.h and fleetrec_diag.h declare (the not-gpu test checks the .so exports all of them)
 ABI_SYMBOLS = [
     "fr_abi_version", "fr_last_error", "fr_device_count", "fr_model_builtin", "fr_model_clone_scaled", "fr_model_free",
     "fr_model_table_bytes", "fr_model_index_cols", "fr_model_bank_map", "fr_ctx_set_gather_variant", "fr_ctx_gather_variant",
-    "fr_ctx_gather_merged_lookups", "fr_ctx_gather_groups", "fr_comm_unique_id", "fr_comm_init_rank", "fr_comm_init_all", "fr_comm_destroy",
+    "fr_ctx_gather_merged_lookups", "fr_ctx_gather_groups", "fr_comm_unique_id", "fr_comm_init_rank", "fr_comm_init_all", "fr_comm_destroy", "fr_comm_set_wait_ms",
     "fr_worker_submit_sharded", "fr_worker_calibrate_fp8_sharded", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
     "fr_ctx_fill_tables", "fr_ctx_upload_table", "fr_ctx_download_table", "fr_ctx_set_weights", "fr_ctx_fill_weights",
     "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_ctx_get_fp8_exponents", "fr_ctx_set_fp8_act_exponents",
@@ -122,7 +122,7 @@ def lib():
         "fr_ctx_stream_group": (i32, [vp]), "fr_ctx_set_stream_group": (i32, [vp, i32]),
         "fr_ctx_set_gather_variant": (i32, [vp, i32]), "fr_ctx_gather_variant": (i32, [vp]),
         "fr_comm_unique_id": (i32, [vp]), "fr_comm_init_rank": (i32, [vp, vp, ctypes.POINTER(vp)]),
-        "fr_comm_init_all": (i32, [ctypes.POINTER(vp), i32, ctypes.POINTER(vp)]), "fr_comm_destroy": (None, [vp]),
+        "fr_comm_init_all": (i32, [ctypes.POINTER(vp), i32, ctypes.POINTER(vp)]), "fr_comm_destroy": (None, [vp]), "fr_comm_set_wait_ms": (i32, [vp, i32]),
         "fr_worker_submit_sharded": (i32, [vp, vp, i32]), "fr_worker_calibrate_fp8_sharded": (i32, [vp, vp, i32]),
         "fr_ctx_gather_merged_lookups": (i32, [vp, ctypes.POINTER(ctypes.c_uint64), i32]),
         "fr_ctx_gather_groups": (i32, [vp, ctypes.POINTER(ctypes.c_int)]),
@@ -735,6 +735,10 @@ class Comm:
         out = (ctypes.c_void_p * n)()
         _check(lib().fr_comm_init_all(arr, n, out))
         return [cls(ctypes.c_void_p(out[i])) for i in range(n)]
+
+    def set_wait_ms(self, ms):
+        """Bound of fr_worker_sync's wait for a sharded step's collectives on this rank (default 60 s)."""
+        _check(lib().fr_comm_set_wait_ms(self._h, int(ms)))
 
     def close(self):
         if self._h:

@@ -407,6 +407,13 @@ extern "C" int fr_ctx_create_sharded(const fr_model_desc *m, int device, int sha
         ctx_free(c);
         return rc;
     }
+    {   // immutable after creation (read by every driver thread in fused_flush without synchronisation): the device's compute units and
+        // whether the persistent K-outer fused kernel applies to this context's descriptors and FC shape
+        int n_cu = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) n_cu = 0;
+        c->n_cu = n_cu > 0 ? n_cu : 256;
+        c->hk_ok = frk_fused_hk_ok(m->fc[0], m->fc[1], m->fc[2], m->fc[3], c->h_words.data(), c->n_words) ? 1 : 0;
+    }
     for (int l = 0; l < 4; l++) {
         size_t n = (size_t)m->fc[l] * m->fc[l + 1];
         e = hipMalloc((void **)&c->d_w[l], n * sizeof(float));
@@ -659,6 +666,7 @@ extern "C" void fr_worker_destroy(fr_worker *w) {
     if (w->h_dense) (void)hipHostFree(w->h_dense);
     if (w->h_score) (void)hipHostFree(w->h_score);
     if (w->h_err) (void)hipHostFree(w->h_err);
+    if (w->h_sh_status) (void)hipHostFree(w->h_sh_status);
     void *dev[] = {w->d_idx, w->d_dense, w->d_records, w->d_act[0], w->d_act[1], w->d_score, w->d_slice, w->d_gathered, w->d_score_part, w->d_score_all};
     for (void *p : dev)
         if (p) (void)hipFree(p);
@@ -1075,12 +1083,6 @@ static int fused_flush(fr_worker *w) {
         // (13-14 us, all workgroups at once), which only a second tile amortises.  Smaller launches (64 batches of 256 items = one tile per
         // compute unit, partial groups at fr_worker_sync) keep the chunked kernel.  Its batch list travels through device memory, so one
         // launch carries up to FR_FUSED_MAX_QUEUE batches (fr_ctx_set_stream_group above 64).
-        if (c->hk_ok < 0) {
-            int n_cu = 0;
-            FR_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
-            c->n_cu = n_cu > 0 ? n_cu : 256;
-            c->hk_ok = frk_fused_hk_ok(a.K, a.H1, a.H2, a.H3, c->h_words.data(), c->n_words) ? 1 : 0;
-        }
         int tiles = 0, max_tiles = 0;
         for (int i = 0; i < n_all; i++) {
             const int t_ = (w->pending[i].batch + 63) / 64;
@@ -1731,6 +1733,11 @@ extern "C" int fr_worker_sync(fr_worker *w) {
     if (frc) return frc;
     frc = pipeline_flush(w);  // drain the stage pipeline
     if (frc) return frc;
+    const int crc = fr_comm_wait(w);  // a table-sharded step in flight: bounded wait + the ranks' status words (fr_comm.cpp)
+    if (crc) {
+        w->in_flight = false;
+        return crc;
+    }
     FR_HIP(hipStreamSynchronize(w->stream));
     w->in_flight = false;
     if (__atomic_load_n(w->h_err, __ATOMIC_ACQUIRE)) {

@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <new>
 
@@ -25,6 +26,7 @@ struct Rccl {
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclCommAbort) CommAbort = nullptr;  // optional: a rank that cannot take part in a collective aborts the communicator
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;  // optional: polled by the bounded wait of fr_comm_wait
 };
 Rccl g_rccl;
 std::once_flag g_rccl_once;
@@ -53,6 +55,7 @@ int rccl_load() {
         FR_SYM(GetErrorString, "ncclGetErrorString")
 #undef FR_SYM
         g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(g_rccl.handle, "ncclCommAbort"));
+        g_rccl.CommGetAsyncError = reinterpret_cast<decltype(g_rccl.CommGetAsyncError)>(dlsym(g_rccl.handle, "ncclCommGetAsyncError"));
         g_rccl_ok = true;
     });
     if (!g_rccl_ok) FR_FAIL(FR_ERR_COMM, "librccl.so could not be loaded (dlopen / dlsym): %s", g_rccl_why);
@@ -71,12 +74,22 @@ struct fr_comm {
     int rank = 0, n_ranks = 1;
     fr_ctx *ctx = nullptr;
     bool broken = false;  // a collective step failed on this rank: the communicator was aborted, every later call returns FR_ERR_COMM
+    int wait_ms = 60000;  // bound of fr_comm_wait: how long fr_worker_sync lets a step's collectives take before it gives the peers up
 };
 
-// A collective step that fails on ONE rank must not leave the others inside the collective for ever (fr_worker_submit_sharded
-// used to return early between its two all-gathers; the peers then spun in ncclAllGather and ShardedEngine::run waited for them
-// indefinitely).  The failing rank ABORTS the communicator: the peers' pending and later collectives return an error (FR_ERR_COMM on
-// their side) instead of hanging.  The error text of the failure itself (already in fr_last_error) is kept.
+// Failure protocol of a collective step.  Three kinds of failure, three answers:
+//  (1) argument / state errors found BEFORE anything was enqueued (worker busy, batch too large, tables not filled ...): returned as they
+//      are, the communicator stays usable.  The ranks of a job are driven with the same arguments, so such an error is the same on every
+//      rank; a caller that lets ONE rank skip a step has broken the contract and its peers run into (3).
+//  (2) the local FC chain fails after the first collective: both collectives are still issued (the peers are on their way into them), the
+//      rank's score chunk is poisoned with NaN and its STATUS WORD -- one float all-gathered behind every score chunk -- carries the code:
+//      every rank's fr_worker_sync reads all G status words and returns FR_ERR_COMM naming the rank; nobody gets stale scores silently.
+//  (3) a real failure of the device / RCCL on this rank (a HIP error, a collective that cannot be enqueued), or peers that do not arrive:
+//      the rank ABORTS its communicator (comm_fail) and answers FR_ERR_COMM from then on; the peers' waits are BOUNDED (fr_comm_wait:
+//      the step's stream is polled together with ncclCommGetAsyncError for at most wait_ms, then the waiting rank aborts its own
+//      communicator and returns FR_ERR_COMM) -- a local ncclCommAbort does not by itself release a peer in another process.
+// Verified on hardware with one-rank communicators only (the test boxes have one GPU): the cross-rank behaviour of (2) and (3) follows
+// from the code, it has not run with G > 1.
 static int comm_fail(fr_comm *comm, int rc) {
     if (comm && !comm->broken) {
         comm->broken = true;
@@ -173,6 +186,12 @@ extern "C" int fr_comm_init_all(fr_ctx *const *ctxs, int n, fr_comm **out) {
     return FR_OK;
 }
 
+extern "C" int fr_comm_set_wait_ms(fr_comm *c, int wait_ms) {
+    if (!c || wait_ms < 1) FR_FAIL(FR_ERR_INVALID, "bad argument");
+    c->wait_ms = wait_ms;
+    return FR_OK;
+}
+
 extern "C" void fr_comm_destroy(fr_comm *c) {
     if (!c) return;
     if (c->comm && g_rccl_ok) {
@@ -187,7 +206,8 @@ static int shard_buffers(fr_worker *w, int G) {
     if (w->sh_ranks == G && w->d_slice) return FR_OK;
     fr_ctx *c = w->ctx;
     const size_t slice = (size_t)w->max_batch * (size_t)c->slice_padded * sizeof(float);
-    const size_t chunk = ((size_t)w->max_batch + G - 1) / G;
+    const size_t chunk = ((size_t)w->max_batch + G - 1) / G + 1;  // + the rank's status word (failure protocol, kind (2))
+    if (!w->h_sh_status) FR_HIP(hipHostMalloc((void **)&w->h_sh_status, sizeof(float) * 65, hipHostMallocDefault));  // [0] sent, [1 .. G] received
     void **bufs[] = {&w->d_slice, &w->d_gathered, (void **)&w->d_score_part, (void **)&w->d_score_all};
     for (void **b : bufs)
         if (*b) {
@@ -202,14 +222,21 @@ static int shard_buffers(fr_worker *w, int G) {
     return FR_OK;
 }
 
-static int sharded_prologue(fr_worker *w, fr_comm *comm, int batch) {
+// kind (1) of the failure protocol: nothing has been enqueued, the communicator is untouched
+static int sharded_check_args(fr_worker *w, fr_comm *comm, int batch) {
     if (!w || !comm) FR_FAIL(FR_ERR_INVALID, "NULL argument");
     fr_ctx *c = w->ctx;
     if (comm->ctx != c) FR_FAIL(FR_ERR_INVALID, "the communicator belongs to another context");
     if (batch <= 0 || batch > w->max_batch) FR_FAIL(FR_ERR_INVALID, "batch %d outside (0, max_batch=%d]", batch, w->max_batch);
     if (!c->tables_filled) FR_FAIL(FR_ERR_STATE, "tables have not been filled or uploaded");
     if (!c->weights_set) FR_FAIL(FR_ERR_STATE, "FC weights have not been set");
-    if (w->in_flight) FR_FAIL(FR_ERR_STATE, "a batch is already in flight on this worker: call fr_worker_sync first");
+    if (w->in_flight || w->sh_comm) FR_FAIL(FR_ERR_STATE, "a batch is already in flight on this worker: call fr_worker_sync first");
+    return FR_OK;
+}
+
+// buffers + H2D copies: a failure here is a device failure (kind (3))
+static int sharded_prologue(fr_worker *w, fr_comm *comm, int batch) {
+    fr_ctx *c = w->ctx;
     FR_HIP(hipSetDevice(c->device));
     int rc = shard_buffers(w, comm->n_ranks);
     if (rc) return rc;
@@ -222,10 +249,10 @@ static int sharded_prologue(fr_worker *w, fr_comm *comm, int batch) {
 
 extern "C" int fr_worker_submit_sharded(fr_worker *w, fr_comm *comm, int batch) {
     if (comm && comm->broken) FR_FAIL(FR_ERR_COMM, "the communicator was aborted by an earlier failure on this rank");
-    // every state and argument check (and the H2D copies) BEFORE the first collective; whatever fails from here on aborts the
-    // communicator, so that the peers get FR_ERR_COMM instead of waiting in a collective this rank will never join
-    int rc = sharded_prologue(w, comm, batch);
-    if (rc) return (w && comm && comm->ctx == w->ctx) ? comm_fail(comm, rc) : rc;
+    int rc = sharded_check_args(w, comm, batch);  // kind (1): returned as it is
+    if (rc) return rc;
+    rc = sharded_prologue(w, comm, batch);        // from here on: whatever fails aborts the communicator (kind (3))
+    if (rc) return comm_fail(comm, rc);
     fr_ctx *c = w->ctx;
     const int G = comm->n_ranks, r = comm->rank;
     const int transport = c->fc_precision;  // slices travel in the chain's own operand type: fp32, bf16 (half) or e4m3 (a quarter of the bytes)
@@ -239,15 +266,78 @@ extern "C" int fr_worker_submit_sharded(fr_worker *w, fr_comm *comm, int batch) 
     if (n_mine > 0) {
         w->in_flight = false;  // fr_worker_fc_from_slices_lp is a public entry point with its own state checks
         fc_rc = fr_worker_fc_from_slices_lp(w, batch, lo, n_mine, w->d_gathered, transport, w->d_score_part);
+        if (!fc_rc && FR_KNOB("SHARDED_INJECT_FC_FAIL", 0)) {  // experiments build only: the test of kind (2)
+            fr_set_error("injected FC failure (FR_SHARDED_INJECT_FC_FAIL)");
+            fc_rc = FR_ERR_STATE;
+        }
     }
-    // the second collective is issued whatever the local FC chain returned: the peers are already on their way into it
-    FR_NCCL_OR_ABORT(comm, g_rccl.AllGather(w->d_score_part, w->d_score_all, (size_t)chunk, ncclFloat, comm->comm, w->stream));
-    if (fc_rc) return fc_rc;  // (its text is the last error set before the all-gather succeeded)
-    for (int q = 0; q < G; q++) {  // every rank ends up with all B scores in its pinned score buffer
+    // kind (2): the second collective is issued whatever the local FC chain returned -- the peers are already on their way into it -- but a
+    // failed chain's chunk travels as NaN and its status word says so on every rank
+    char fc_text[200] = "";
+    if (fc_rc) {
+        snprintf(fc_text, sizeof(fc_text), "%s", fr_last_error());
+        if (hipMemsetAsync(w->d_score_part, 0xFF, (size_t)chunk * sizeof(float), w->stream) != hipSuccess) return comm_fail(comm, FR_ERR_HIP);
+    }
+    w->h_sh_status[0] = (float)fc_rc;
+    if (hipMemcpyAsync(w->d_score_part + chunk, w->h_sh_status, sizeof(float), hipMemcpyHostToDevice, w->stream) != hipSuccess) {
+        fr_set_error("status word H2D failed");
+        return comm_fail(comm, FR_ERR_HIP);
+    }
+    FR_NCCL_OR_ABORT(comm, g_rccl.AllGather(w->d_score_part, w->d_score_all, (size_t)chunk + 1, ncclFloat, comm->comm, w->stream));
+    hipError_t he = hipMemcpy2DAsync(w->h_sh_status + 1, sizeof(float), w->d_score_all + chunk, ((size_t)chunk + 1) * sizeof(float), sizeof(float), (size_t)G,
+                                     hipMemcpyDeviceToHost, w->stream);
+    for (int q = 0; q < G && he == hipSuccess; q++) {  // every rank ends up with all B scores in its pinned score buffer
         const int qlo = q * base + (q < rem ? q : rem), qn = base + (q < rem ? 1 : 0);
-        if (qn > 0) FR_HIP(hipMemcpyAsync(w->h_score + qlo, w->d_score_all + (size_t)q * chunk, (size_t)qn * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+        if (qn > 0) he = hipMemcpyAsync(w->h_score + qlo, w->d_score_all + (size_t)q * (chunk + 1), (size_t)qn * sizeof(float), hipMemcpyDeviceToHost, w->stream);
     }
+    if (he != hipSuccess) {
+        fr_set_error("score D2H failed: %s", hipGetErrorString(he));
+        return comm_fail(comm, FR_ERR_HIP);
+    }
+    w->sh_comm = comm;  // fr_worker_sync waits through fr_comm_wait and reads the G status words
     w->in_flight = true;
+    if (fc_rc) FR_FAIL(fc_rc, "FC chain failed on this rank (its peers learn it from the status word): %s", fc_text);
+    return FR_OK;
+}
+
+// fr_worker_sync of a worker with a sharded step in flight: a BOUNDED wait (failure protocol, kind (3)), then the status words (kind (2)).
+int fr_comm_wait(fr_worker *w) {
+    fr_comm *comm = w->sh_comm;
+    w->sh_comm = nullptr;
+    if (!comm) return FR_OK;
+    const int G = comm->n_ranks;
+    if (comm->broken) FR_FAIL(FR_ERR_COMM, "the communicator was aborted by an earlier failure on this rank");
+    // poll instead of hipStreamSynchronize: a peer that never arrives must not hold this rank for ever
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spin = 0;; spin++) {
+        hipError_t q = hipStreamQuery(w->stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) {
+            fr_set_error("sharded step: stream failed: %s", hipGetErrorString(q));
+            return comm_fail(comm, FR_ERR_HIP);
+        }
+        if ((spin & 63) == 63) {
+            ncclResult_t ar = ncclSuccess;
+            if (g_rccl.CommGetAsyncError && comm->comm && g_rccl.CommGetAsyncError(comm->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+                fr_set_error("sharded step: RCCL reported an asynchronous error: %s", g_rccl.GetErrorString(ar));
+                return comm_fail(comm, FR_ERR_COMM);
+            }
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            const double ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+            if (ms > comm->wait_ms) {
+                fr_set_error("sharded step: the collectives did not complete within %d ms (a peer rank is missing): communicator aborted", comm->wait_ms);
+                return comm_fail(comm, FR_ERR_COMM);
+            }
+            if (ms > 2.0) {  // long waits sleep between polls
+                struct timespec nap = {0, 50000};
+                nanosleep(&nap, nullptr);
+            }
+        }
+    }
+    for (int q = 0; q < G; q++)
+        if (w->h_sh_status[1 + q] != 0.0f)
+            FR_FAIL(FR_ERR_COMM, "shard rank %d reported a failed FC chain (status %d): the scores of its items are NaN", q, (int)w->h_sh_status[1 + q]);
     return FR_OK;
 }
 
@@ -255,8 +345,10 @@ extern "C" int fr_worker_submit_sharded(fr_worker *w, fr_comm *comm, int batch) 
 // (replicated) weights, so all ranks arrive at identical activation exponents without a further reduction.
 extern "C" int fr_worker_calibrate_fp8_sharded(fr_worker *w, fr_comm *comm, int batch) {
     if (comm && comm->broken) FR_FAIL(FR_ERR_COMM, "the communicator was aborted by an earlier failure on this rank");
-    int rc = sharded_prologue(w, comm, batch);
-    if (rc) return (w && comm && comm->ctx == w->ctx) ? comm_fail(comm, rc) : rc;
+    int rc = sharded_check_args(w, comm, batch);
+    if (rc) return rc;
+    rc = sharded_prologue(w, comm, batch);
+    if (rc) return comm_fail(comm, rc);
     fr_ctx *c = w->ctx;
     rc = fr_worker_gather_only(w, batch, w->d_idx, w->d_dense, reinterpret_cast<float *>(w->d_slice));
     if (rc) return comm_fail(comm, rc);

@@ -1,5 +1,5 @@
 // Internal declarations shared by the host-side C-ABI (fr_api.cpp, fr_registry.cpp) and the
-// gfx950 kernels (fr_fill / fr_gather / fr_pipeline / fr_gemm / fr_fused .hip).  Not installed; the public surface is include/fleetrec.h.
+// gfx950 kernels (fr_fill / fr_gather / fr_pipeline / fr_gemm / fr_fused .hip).  Not installed; the public surface is include/fleetrec.h (+ fleetrec_serving.h, fleetrec_diag.h).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -10,6 +10,8 @@
 #include <vector>
 
 #include "fleetrec.h"
+#include "fleetrec_diag.h"
+#include "fleetrec_serving.h"
 
 // ---- error plumbing ---------------------------------------------------------------------------
 void fr_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
@@ -217,8 +219,8 @@ struct fr_ctx {
     std::atomic<int> stream_group{FR_FUSED_DEFAULT_BATCHES};
     // host-fed blocks of at most this many batches take the stage pipeline instead of the fused kernel (fr_ctx_set_small_block; 0: never)
     std::atomic<int> small_block{0};
-    int n_cu = 0;                          // compute units of the device (grid of the persistent fused kernel)
-    int hk_ok = -1;                        // fr_fused_tile_hk_kernel applies to this context's descriptors (-1: not examined yet)
+    int n_cu = 0;                          // compute units of the device (grid of the persistent fused kernel); set at creation
+    int hk_ok = 0;                         // the persistent K-outer fused kernel applies to this context's descriptors; set at creation
 };
 
 struct fr_worker {
@@ -280,7 +282,9 @@ struct fr_worker {
     } hr;
     // table-sharded exchange (fr_worker_submit_sharded, fr_comm.cpp): this shard's slice, the all-gathered slices, score chunks
     void *d_slice = nullptr, *d_gathered = nullptr;
-    float *d_score_part = nullptr, *d_score_all = nullptr;
+    float *d_score_part = nullptr, *d_score_all = nullptr;  // [chunk + 1], [G][chunk + 1]: every rank's chunk ends with its status word
+    float *h_sh_status = nullptr;  // pinned: [0] this rank's status word as sent, [1 .. G] the status words of all ranks as received
+    struct fr_comm *sh_comm = nullptr;  // a sharded step is in flight through this communicator (fr_worker_sync -> fr_comm_wait)
     int sh_ranks = 0;
     int *h_err = nullptr;  // sticky index-range flag: pinned host word ...
     int *d_err = nullptr;  // ... and its device-side alias
@@ -288,6 +292,9 @@ struct fr_worker {
     char last_kernel[96] = "";  // fr_worker_last_kernel: the dominant kernel of the most recent launch this worker enqueued
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
+
+// ---- table-sharded exchange (fr_comm.cpp) ------------------------------------------------------------
+int fr_comm_wait(fr_worker *w);  // bounded wait for the sharded step in flight + the ranks' status words; FR_OK when none is in flight
 
 // ---- registry (fr_registry.cpp) -------------------------------------------------------------------
 int fr_model_validate(const fr_model_desc *m);

@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "fleetrec.h"
+#include "fleetrec_serving.h"
 
 struct Options {
     int model = FR_MODEL_A, batch = 256, threads = 4, port = 8080, device = 0;

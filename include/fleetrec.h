@@ -31,11 +31,13 @@ extern "C" {
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 #endif
 
-/* 2 (round 3): fr_ctx_set_stream_group is per context (1..64) and groups below 12 ride the stage pipeline; fr_worker_submit reads /
- * writes the worker's pinned buffers from the kernels; FR_INDEX_PER_BANK stores bank-interleaved tables; FR_GATHER_WORD_MAJOR_ONE_CHUNK;
- * the library reads no environment variable.  A binding must refuse a library whose fr_abi_version() differs from the header it was
- * written against (the Python binding does, also for a build loaded through FR_LIB). */
-#define FR_ABI_VERSION 3
+/* 4 (round 4): the surface is three headers -- this one (the three spans of thread_consume() that SURVEY section 8(b) cuts, the request
+ * driver core and the table-sharded mode), fleetrec_serving.h (host-fed streaming / serving extensions) and fleetrec_diag.h (measurement
+ * and parity hooks); fr_worker_submit_sharded all-gathers a status word behind every score chunk and fr_worker_sync bounds its wait for
+ * the collectives.  3 (round 3): fr_ctx_set_stream_group is per context (1..256), groups below 12 ride the stage pipeline;
+ * FR_INDEX_PER_BANK stores bank-interleaved tables; the library reads no environment variable.  A binding must refuse a library whose
+ * fr_abi_version() differs from the header it was written against (the Python binding does, also for a build loaded through FR_LIB). */
+#define FR_ABI_VERSION 4
 
 typedef enum fr_status {
     FR_OK = 0,
@@ -253,23 +255,11 @@ int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d_idx, const
  * R >= 2 * max(fr_ctx_stream_group(ctx), 5) buffer sets and calls fr_worker_sync once per trip round the ring (what
  * fr_driver_run_resident does with R = 512). */
 int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores);
-/* n consecutive fr_worker_push_device calls in one: batch[i], d_idx[i], d_dense[i] (the array or any entry may be NULL for a model
- * without dense features), d_scores[i] for i = 0 .. n-1, in that order, stopping at the first error (its status is returned; the
- * batches before it stay pushed).  For callers whose per-call cost is comparable to a batch's share of a launch -- a language
- * binding feeding 256 batches of a 0.5 us share each -- so that the stream, not the caller, sets the pace (bench.py's one-stream
- * roofline legs).  Same buffer-lifetime rule as fr_worker_push_device.  The reference's loop is the n = 1 case (cuda_server.c:406-497). */
-int fr_worker_push_device_list(fr_worker *w, int n, const int *batch, const int32_t *const *d_idx, const float *const *d_dense,
-                               float *const *d_scores);
 /* How many pushed batches one streaming launch carries on this context: 1 when fr_worker_push_device rides the stage pipeline
  * (models that do not fit the fused kernel), G (1..256, default 64) when
  * the model streams through the fused item-tile kernel -- the value fr_ctx_set_stream_group set, also when it is below 12 and the
  * pushes ride the stage pipeline. */
 int fr_ctx_stream_group(const fr_ctx *ctx);
-/* The kernel (instantiation included, as rocprofv3 prints it) of the most recent launch this worker enqueued through
- * fr_worker_push_device / fr_worker_sync (the fused item-tile kernel that carried the group), fr_worker_fc_layer_only (that layer's
- * kernel) or fr_worker_gather_only / fr_worker_gather_slices (the gather kernel).  "" before the first such launch.  The pointer
- * stays valid for the worker's lifetime; measurement code uses it so that a roofline figure names the kernel that actually ran. */
-const char *fr_worker_last_kernel(const fr_worker *w);
 /* Throughput/latency knob of the fused streaming path, PER CONTEXT: batches per launch, 1..256 (default 64).  Groups above 64 exist for
  * the bf16 chain: its persistent kernel (fr_fused_tile_hs_kernel: one workgroup per compute unit walks several 64-item tiles, the gather
  * of the next tile under the FC phases of the current one) takes a launch with at least two tiles per compute unit (records of 352 floats or fewer: 1.25) and up to 256 batches
@@ -286,38 +276,6 @@ const char *fr_worker_last_kernel(const fr_worker *w);
  * (atomic); a worker's queue that already holds >= the new size launches at its next push or sync, and a worker whose path changes
  * drains the other path first. */
 int fr_ctx_set_stream_group(fr_ctx *ctx, int batches_per_launch);
-/* Host-fed streaming: like fr_worker_push_device for a batch that sits in (any) host memory.  The rows are copied into the worker's
- * pinned staging before the call returns (h_idx / h_dense may be reused at once); batches travel in groups as one H2D copy + one
- * launch + one D2H copy; h_scores[0..batch) is valid after fr_worker_sync (earlier deliveries happen -- a block's scores are copied out
- * before its staging is reused, i.e. at the latest 4 blocks later -- but fr_worker_sync is the only completion point the API defines).
- * The streaming counterpart of the per-batch recv -> H2D -> GEMMs -> D2H sequence of cuda_server.c:425-495. */
-int fr_worker_push_host(fr_worker *w, int batch, const int32_t *h_idx, const float *h_dense, float *h_scores);
-/* The same without the copy into staging -- the reference's read() lands in pinned memory (cuda_server.c:136-160,437):
- * fr_worker_stage_acquire hands out where the NEXT pushed batch of this worker has to be written (*h_idx: batch x index_cols int32,
- * *h_dense: batch x dense_len floats or NULL; pinned, owned by the worker; it may first wait for the oldest block's scores and deliver
- * them, exactly as fr_worker_push_host does), the caller fills it (e.g. reads the socket into it), fr_worker_push_staged queues it
- * (batch <= the acquired size; h_scores as for fr_worker_push_host).  One slot at a time per worker; fr_worker_push_host between the
- * two calls is FR_ERR_STATE; fr_worker_sync drops a slot that was acquired and never pushed. */
-int fr_worker_stage_acquire(fr_worker *w, int batch, int32_t **h_idx, float **h_dense);
-int fr_worker_push_staged(fr_worker *w, int batch, float *h_scores);
-/* Serving with replies (fleetrec_server --stream --reply): fr_worker_flush launches what is queued on the worker right now -- a
- * partially filled host block, queued device pushes -- without waiting (the latency knob under light load: call it when the request
- * source runs dry); fr_worker_host_poll delivers the scores of the host-fed blocks that have FINISHED (oldest first, no waiting) and
- * reports how many host-fed batches have been delivered since the worker was created: batches are delivered in push order, so the
- * caller knows exactly which h_scores buffers are valid. */
-int fr_worker_flush(fr_worker *w);
-/* Latency of nearly empty host-fed blocks, PER CONTEXT: a block that leaves with at most max_batches batches (0..8; default 0 = never) rides
- * the stage pipeline of fr_worker_submit -- its n batches follow each other through the five stage launches, n + 4 launches of ~10 us,
- * the whole chip per layer -- instead of the fused item-tile kernel (133 us for any number of batches up to a chip-full).  Such batches
- * get fr_worker_submit's scores bit for bit (the fused kernel sums in another order: equal to ~1e-6, not bit for bit).
- * fleetrec_server --stream --reply sets 8 (4 requests in flight per connection: 18 M inferences/s at 185 us request -> reply, against
- * 14 M at 245 us with five launches per batch; profiles/r02_tcp_reply_small_blocks.txt). */
-int fr_ctx_set_small_block(fr_ctx *ctx, int max_batches);
-int fr_worker_host_poll(fr_worker *w, long long *delivered);
-/* Host-fed batches queued in the block being filled (not launched yet) / launched and not delivered yet, and the number of launched
- * blocks not delivered yet (at most 4) -- what an adaptive batcher needs: flush when the request source is dry AND at most one block is
- * still in flight; while more are running, let the next block fill (any output pointer may be NULL). */
-int fr_worker_host_pending(const fr_worker *w, int *queued, int *in_flight, int *blocks_in_flight);
 /* Launches whatever is still queued, drains the pipeline and waits for everything enqueued on the worker; returns
  * FR_ERR_INDEX_RANGE if any index was out of range. */
 int fr_worker_sync(fr_worker *w);
@@ -335,47 +293,6 @@ int fr_worker_calibrate_fp8_slices(fr_worker *w, int batch_total, int item0, int
 int fr_worker_gather_only(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense,
                           float *d_records);
 int fr_worker_fc_only(fr_worker *w, int batch, const float *d_records, float *d_scores);
-/* Roofline hook: launch ONE layer of the FC chain (0..2 = FC1..FC3, 3 = output layer) on the worker's resident
- * activations, exactly as submit() launches it. */
-int fr_worker_fc_layer_only(fr_worker *w, int batch, int layer);
-/* Which kernel serves the record-producing gather (fr_worker_gather_only; fp32 records, SEMANTIC layout or a shard slice) -- a tuning
- * knob with no counterpart in the reference (its gather is 28-47 independent HLS pipelines, embedding_47_krnl.cpp:645-740).
- *  WORD_MAJOR (default): one thread per 16-byte record word, lanes along the record (gather_pack_kernel): a wave never holds two
- *                        lookups of the same table, duplicate rows of a batch are merged by L1 / L2;
- *  ITEM_TILE           : 64 items x 64 record words per workgroup, lanes along (item, word-of-row), rows staged in LDS and written
- *                        out as whole 1 KiB record pieces (gather_tile_kernel<false>);
- *  ITEM_TILE_DEDUP     : the same with a wave-level merge of duplicate lookups (LDS hash + __shfl: only one lane per distinct
- *                        index loads the row) -- BASELINE.json north_star's "ballot/shuffle index dedup";
- *  ..._DEDUP_COUNT     : DEDUP + a __ballot count of the merged lookups (diagnostic; fr_ctx_gather_merged_lookups);
- *  WORD_MAJOR_ONE_CHUNK: the word-major mapping with one chunk of items per workgroup and no software pipeline
- *                        (gather_pack_xcd_kernel) -- what WORD_MAJOR itself falls back to when the records or the index buffer
- *                        of a launch reach 4000 MiB; selectable so that the fallback is parity-tested at ordinary sizes.
- * All variants produce bit-identical records.  DESIGN.md section 3.1 holds the measured A/B. */
-typedef enum fr_gather_variant {
-    FR_GATHER_WORD_MAJOR = 0, FR_GATHER_ITEM_TILE = 1, FR_GATHER_ITEM_TILE_DEDUP = 2, FR_GATHER_ITEM_TILE_DEDUP_COUNT = 3,
-    FR_GATHER_WORD_MAJOR_ONE_CHUNK = 4
-} fr_gather_variant;
-int fr_ctx_set_gather_variant(fr_ctx *ctx, int variant);
-int fr_ctx_gather_variant(const fr_ctx *ctx);
-/* Lookups (rows) the DEDUP_COUNT variant did NOT load because another lane of the wave loaded the same row, summed since the last
- * reset.  Synchronises the device. */
-int fr_ctx_gather_merged_lookups(fr_ctx *ctx, uint64_t *merged, int reset);
-/* Diagnostic: how the word-major gather deals the record's 16-byte words to the chip's 8 XCDs at large batches -- group g owns words
- * [starts[g], starts[g + 1]) of the record (the shard's slice).  The cuts sit on source-row boundaries (a table row; a whole bank row
- * of an FR_INDEX_PER_BANK context), so that no row is fetched through two L2s.  Returns FR_ERR_STATE when the context has no such plan
- * (short records: every group would be narrower than a wave). */
-int fr_ctx_gather_groups(const fr_ctx *ctx, int starts[9]);
-/* Device pointer of the worker's own record buffer ([max_batch][record_len] floats). */
-float *fr_worker_records_dptr(fr_worker *w);
-/* Debug/parity hook: device pointer of the worker's feature-major activation buffer written by the gather stage
- * of the LAST submitted/pushed batch, in the chain's q4 layout: feature k of item m at
- * xq[((k/4)*ld + m)*4 + k%4] with ld = round_up(batch, 32).  Lets tests check the pipeline's own gather bit-exactly. */
-float *fr_worker_features_dptr(fr_worker *w, int *ld_max);
-
-/* HIP-event timing on the worker's stream (the stream the kernels are launched on). */
-int fr_worker_timer_start(fr_worker *w);
-int fr_worker_timer_stop_ms(fr_worker *w, float *ms); /* records stop, synchronises, returns elapsed */
-
 /* ---- request-driver core: main() + the thread_consume() batch loop without sockets
  *      (cuda_server.c:23-25,406-497,554-560) ------------------------------------------------------- */
 typedef struct fr_driver fr_driver;
@@ -393,12 +310,6 @@ int fr_driver_run_resident(fr_driver *d, int batch, int64_t total_batches, const
  * transfers (cuda_server.c:425-495).  Returns wall time. */
 int fr_driver_run_host(fr_driver *d, int batch, int64_t total_batches, const int32_t *const *h_idx_pool,
                        const float *const *h_dense_pool, int n_pool, double *elapsed_s);
-/* Host-buffer STREAMING form: the same host-resident request stream handed to fr_worker_push_host (pinned staging blocks, one
- * H2D + one fused launch + one D2H per block, no per-batch synchronisation).  Only for models that stream through the fused
- * item-tile kernel.  Scores land in per-worker host rings (fr_driver_host_score_ring, same indexing as fr_driver_score_ring). */
-int fr_driver_run_host_streaming(fr_driver *d, int batch, int64_t total_batches, const int32_t *const *h_idx_pool,
-                                 const float *const *h_dense_pool, int n_pool, double *elapsed_s);
-const float *fr_driver_host_score_ring(fr_driver *d, int thread, int slot, int *ring_len);
 fr_worker *fr_driver_worker(fr_driver *d, int thread, int slot);
 /* Device pointer of the score ring fr_driver_run_resident writes for worker (thread, slot): *ring_len buffers of max_batch
  * floats; the k-th batch pushed to that worker lands in buffer k % *ring_len. */
@@ -443,10 +354,18 @@ int fr_comm_unique_id(void *id128);
 int fr_comm_init_rank(fr_ctx *ctx, const void *id128, fr_comm **out);
 int fr_comm_init_all(fr_ctx *const *ctxs, int n, fr_comm **out /* n handles */);
 void fr_comm_destroy(fr_comm *c);
+/* How long fr_worker_sync lets the collectives of a sharded step take on this rank before it gives the peers up (default 60000 ms): the
+ * stream is polled together with ncclCommGetAsyncError; past the bound the rank aborts its communicator and returns FR_ERR_COMM (from
+ * then on for every call).  The reference blocks in read() for ever when a sender dies (3-node cuda_server.c:513-591). */
+int fr_comm_set_wait_ms(fr_comm *c, int wait_ms);
 /* COLLECTIVE, asynchronous on the worker's stream: every rank holds the whole request batch in its worker's pinned idx / dense
  * buffers (as for fr_worker_submit).  Per rank: H2D -> gather of this shard's slice (in the chain's operand type: fp32, bf16 or e4m3)
  * -> ncclAllGather of the [batch x F] slices over xGMI -> FC chain on this rank's batch / G items -> ncclAllGather of the score
- * chunks -> D2H.  After fr_worker_sync() EVERY rank's fr_worker_score_ptr() holds all `batch` scores.  RCCL failures: FR_ERR_COMM. */
+ * chunks -> D2H.  After fr_worker_sync() EVERY rank's fr_worker_score_ptr() holds all `batch` scores.  RCCL failures: FR_ERR_COMM.
+ * Failure protocol: argument / state errors are returned before anything is enqueued and leave the communicator usable (the ranks of a job
+ * are driven with the same arguments); a rank whose FC chain fails still takes part in both collectives, its score chunk travels as NaN
+ * and its status word (one float all-gathered behind every chunk) makes EVERY rank's fr_worker_sync return FR_ERR_COMM naming it; a
+ * device / RCCL failure aborts the rank's communicator, and the peers' waits are bounded (fr_comm_set_wait_ms). */
 int fr_worker_submit_sharded(fr_worker *w, fr_comm *comm, int batch);
 /* COLLECTIVE, synchronous: fp8 activation exponents of a sharded context from this batch -- every rank calibrates on the same
  * all-gathered fp32 slices, so all ranks end with identical exponents (a slice encoded by one rank is decoded by the others). */

@@ -8,17 +8,22 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# fleetrec.h = the boundary proper (SURVEY 8(b)'s three spans, the driver core, the sharded mode); serving extensions and measurement hooks apart
+HEADERS = ("fleetrec.h", "fleetrec_serving.h", "fleetrec_diag.h")
 
 
 def declared_symbols():
-    hdr = open(os.path.join(ROOT, "include", "fleetrec.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(fr_[a-z0-9_]+)\s*\(", hdr)))
+    syms = set()
+    for name in HEADERS:
+        hdr = open(os.path.join(ROOT, "include", name)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        syms |= set(re.findall(r"\b(fr_[a-z0-9_]+)\s*\(", hdr))
+    return sorted(syms)
 
 
 def test_header_is_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "fleetrec.h"\nint main(void){ fr_model_desc d; (void)d; return FR_ABI_VERSION - 3; }\n')
+    src.write_text('#include "fleetrec.h"\n#include "fleetrec_serving.h"\n#include "fleetrec_diag.h"\nint main(void){ fr_model_desc d; (void)d; return FR_ABI_VERSION - 4; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
                            "-c", str(src), "-o", str(tmp_path / "t.o")])
 
@@ -29,7 +34,7 @@ def test_exports_every_declared_symbol(fr):
     L = ctypes.CDLL(fr.LIB_PATH)
     for s in syms:
         assert hasattr(L, s), "libfleetrec.so does not export %s" % s
-    assert fr.lib().fr_abi_version() == fr.ABI_VERSION == 3
+    assert fr.lib().fr_abi_version() == fr.ABI_VERSION == 4
     # nothing but the fr_* API is exported
     out = subprocess.check_output(["nm", "-D", "--defined-only", fr.LIB_PATH]).decode()
     exported = [l.split()[-1] for l in out.splitlines() if " T " in l]
@@ -81,3 +86,17 @@ def test_product_does_not_reference_oracle():
                         # comments that cite the oracle file for the shared hash spec are allowed
                         lines = [l for l in txt.splitlines() if needle in l and not l.strip().startswith(("//", "#", "*", "/*"))]
                         assert not lines, (f, lines)
+
+
+def test_core_header_is_the_three_spans_only():
+    """include/fleetrec.h carries the boundary SURVEY 8(b) cuts (context, worker, hot-loop body, the driver core, the
+    sharded mode); the serving extensions and the measurement hooks live in their own headers and stay out of it."""
+    core = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "fleetrec.h")).read(), flags=re.S)
+    core_syms = set(re.findall(r"\b(fr_[a-z0-9_]+)\s*\(", core))
+    for s in ("fr_worker_push_device_list", "fr_ctx_set_small_block", "fr_worker_host_pending", "fr_worker_flush", "fr_worker_host_poll", "fr_worker_push_host",
+              "fr_worker_stage_acquire", "fr_worker_push_staged", "fr_worker_last_kernel", "fr_ctx_set_gather_variant", "fr_worker_timer_start", "fr_worker_fc_layer_only"):
+        assert s not in core_syms, s
+    for s in ("fr_ctx_create", "fr_ctx_fill_tables", "fr_ctx_set_weights", "fr_worker_create", "fr_worker_idx_ptr", "fr_worker_submit", "fr_worker_sync",
+              "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_submit_sharded", "fr_driver_run_resident"):
+        assert s in core_syms, s
+    assert len(core_syms) <= 64, len(core_syms)

@@ -157,10 +157,53 @@ def test_single_rank_exchange_fills_the_callers_buffer(fr):
                 os.environ[k] = v
 
 
-def _run_bench(args, timeout=240):
+def _run_bench(args, timeout=240, detail=None):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    if detail:
+        env["FR_BENCH_DETAIL"] = detail   # where bench.py writes the full result (default: gpurun_out/bench_detail.json)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
     return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def _the_line(out):
+    """bench.py's stdout contract: the LAST line is ONE compact JSON object the driver can parse -- under 4 KB, with
+    the contract keys, `roofline` and `cpu_baseline`; nothing else on stdout starts with '{'."""
+    import json
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and out.rstrip().splitlines()[-1] == lines[0], out[-3000:]
+    assert len(lines[0]) < 4096, len(lines[0])
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in j, k
+    assert "workload" in j["config"]
+    return j
+
+
+def test_compact_line_of_a_full_result_stays_under_4k():
+    """The writer of the stdout line, fed the 21.7 KB result of round 3's driver command (the one the driver could not parse): the line it
+    makes of it is < 4 KB, carries `roofline` (bound / achieved / peak / unit / frac / traffic) and `cpu_baseline` (value / unit / cores /
+    kind / sample), and points at the detail file.  A result padded with 40 more configuration rows still fits (optional summaries drop)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_for_line_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_line_driver_cmd.json")))
+    assert len(json.dumps(full)) > 20000
+    for i, c in enumerate(full["configs"]):
+        c["tag"] = "row%d_%s" % (i, c["dtype"])
+    s = bench.compact_line(full)
+    j = json.loads(s)
+    assert len(s) < 4096 and "\n" not in s
+    assert all(k in j["roofline"] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_name", "avg_launch_ms"))
+    assert all(k in j["cpu_baseline"] for k in ("value", "unit", "cores", "kind", "sample"))
+    assert j["value"] == pytest.approx(full["value"], rel=1e-5) and j["gather_per_bank"]["frac"] == pytest.approx(full["gather_per_bank"]["frac"], rel=1e-5)
+    assert len(j["other_configs"]) == len(full["configs"]) and j["detail"].endswith("bench_detail.json")
+    full["configs"] = full["configs"] * 5
+    for i, c in enumerate(full["configs"]):
+        full["configs"][i] = dict(c, tag="a_rather_long_configuration_tag_%03d" % i)
+    s = bench.compact_line(full)
+    assert len(s) < 4096 and "roofline" in json.loads(s) and "cpu_baseline" in json.loads(s)
 
 
 def test_bench_self_launches_ranks_and_refuses_a_wrong_world():
@@ -170,9 +213,8 @@ def test_bench_self_launches_ranks_and_refuses_a_wrong_world():
     import json
     rc, out, err = _run_bench(["--gpus", "2", "--plumbing-only", "--steps", "7", "--warmup", "3"])
     assert rc == 0, err
-    lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out                      # ONE JSON line, from rank 0
-    j = json.loads(lines[0])
+    j = _the_line(out)                               # ONE compact JSON line, from rank 0
+    assert "roofline" in j and "cpu_baseline" in j   # (empty objects in this mode: the line writer is the real run's)
     assert j["n_gpus"] == 2 and j["steps"] == 7 and j["warmup"] == 3 and j["config"]["self_launched"] is True
     assert j["ms_per_step"] * 7 >= 20.0 - 1e-6       # max over ranks: rank 1 sleeps 20 ms
     env = dict(os.environ, WORLD_SIZE="2", RANK="0")
@@ -194,6 +236,41 @@ def test_bench_launcher_fails_fast_when_a_rank_dies():
     assert "rank 1 exited with status 3" in err and "{" not in out
 
 
+def test_bench_failed_collective_leg_keeps_the_line_and_exits_non_zero(tmp_path):
+    """VERDICT r03 item 6 / ADVICE r03: a sharded leg that fails on one rank after the headline was measured.  The line (with
+    `sharded_error`) must still be the last stdout line and the job's exit status must be non-zero -- whichever rank failed: the failing
+    rank leaves with status 4, the launcher stops its peers, and rank 0 -- possibly inside a collective's C code when the SIGTERM
+    arrives -- prints the line from its signal-watch thread before it leaves."""
+    import time
+    for bad in (1, 0):
+        t0 = time.time()
+        rc, out, err = _run_bench(["--gpus", "2", "--plumbing-only", "--fail-sharded-rank", str(bad)], timeout=120, detail=str(tmp_path / "d.json"))
+        assert rc == 4, (rc, err[-2000:])
+        assert time.time() - t0 < 60.0
+        j = _the_line(out)
+        assert j["n_gpus"] == 2 and "sharded_error" in j and "roofline" in j, j
+        assert "injected failure" in err
+
+
+@pytest.mark.gpu
+def test_bench_default_line_is_compact(gpu, tmp_path):
+    """`bench.py --gpus 1 --quick` (every leg of the driver's command, short timed regions): the stdout line parses, is < 4 KB and carries
+    roofline + cpu_baseline; the full result is in the detail file."""
+    import json
+    detail = str(tmp_path / "detail.json")
+    rc, out, err = _run_bench(["--gpus", "1", "--quick", "--steps", "20", "--warmup", "5"], timeout=1500, detail=detail)
+    assert rc == 0, err[-3000:]
+    j = _the_line(out)
+    rf, cb = j["roofline"], j["cpu_baseline"]
+    assert rf["bound"] == "mfma" and 0.3 < rf["frac"] <= 1.0 and rf["unit"] == "TFLOP/s" and rf["avg_launch_ms"] > 0 and "traffic" in rf, rf
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["sample"], cb
+    assert j["value"] > 0 and j["value_pcie_inclusive"] > 0 and j["config"]["batches_per_launch"] >= 1
+    assert 0.3 < j["gather_per_bank"]["frac"] <= 1.0
+    full = json.load(open(detail))
+    assert len(full["configs"]) >= 8 and all("roofline" in c or "error" in c for c in full["configs"])
+    assert len(j["other_configs"]) == sum(1 for c in full["configs"] if c.get("value"))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--mode", "sharded", "--rows-cap", "20000", "--steps", "3", "--warmup", "1"],
                                    ["--mode", "sharded", "--rows-cap", "20000", "--steps", "3", "--warmup", "1", "--precision", "fp8", "--exchange", "alltoall"],
@@ -205,12 +282,18 @@ def test_bench_two_ranks_on_one_gpu(gpu, extra):
     import json
     # the DEFAULT line (extra == []) keeps its roofline leg: at N > 1 rank 0 prices the dominant kernel on its own replica
     args = ["--gpus", "2", "--backend", "gloo", "--share-device", "--legs", "none" if extra else "roofline"] + (extra or ["--steps", "300", "--warmup", "100"])
-    rc, out, err = _run_bench(args, timeout=1200)
+    detail = None if extra else os.path.join(os.environ.get("TMPDIR", "/tmp"), "fr_bench_detail_%d.json" % os.getpid())
+    rc, out, err = _run_bench(args, timeout=1200, detail=detail)
     assert rc == 0, err[-3000:]
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0
+    if not extra:   # the default line is the compact one; the objects checked below live in the detail file
+        line = _the_line(out)
+        assert line["sharded"]["value"] > 0 and line["gather_per_bank_all_ranks"]["ranks_measured"] == 2 and len(line["configs_all_ranks"]) == 3, line
+        j = json.load(open(detail))
+        os.unlink(detail)
     if extra:
         c = j["config"]
         assert c["pipelined_equals_stepwise"] is True

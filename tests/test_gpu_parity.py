@@ -14,6 +14,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEED_TABLES, SEED_WEIGHTS = 0xF1EE7, 99
 NAMES = {0: "A", 1: "B", 2: "C"}
 
@@ -1532,13 +1533,67 @@ def test_submit_sharded_through_rccl_one_rank(fr, O, gpu, prec):
     ctx.close()
 
 
+def test_sharded_fc_failure_reaches_every_rank_through_the_status_word(fr, gpu):
+    """a rank whose FC chain fails inside fr_worker_submit_sharded used to return its error locally while the peers completed
+    the score all-gather with FR_OK and copied that rank's stale chunk.  Now the chunk travels as NaN and the rank's status word (one
+    float all-gathered behind every score chunk) makes every rank's fr_worker_sync return FR_ERR_COMM.  The failure is injected in the
+    EXPERIMENTS build (FR_SHARDED_INJECT_FC_FAIL=1; the product library has no such switch), in a child process, on a one-rank
+    communicator: the failing rank is then its own peer -- submit returns the FC error, sync reports the status word, scores are NaN,
+    and the communicator stays usable (nothing was aborted)."""
+    import subprocess
+    import sys
+    exp = os.path.join(os.path.dirname(fr.LIB_PATH), "libfleetrec_exp.so")
+    if not os.path.exists(exp):
+        pytest.skip("experiments library not built (make -C gpu-fpga-recommendation-system_amd/csrc exp)")
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+fr = g.load_package()
+m = fr.Model.builtin(fr.MODEL_C).clone(max_rows=30000)
+ctx = fr.Context(m, device=%d, shard_rank=0, n_shards=1)
+ctx.fill_tables(fr.FILL_HASH, 1); ctx.fill_weights(fr.WEIGHTS_UNIFORM, 2)
+comm = fr.Comm.init_rank(ctx, fr.Comm.unique_id())
+rng = np.random.default_rng(3)
+B = 200
+idx = (rng.random((B, m.n_tables)) * m.rows()[None, :]).astype(np.int32)
+dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+wk = fr.Worker(ctx, 256)
+good = wk.infer_sharded(comm, idx, dense)
+assert np.isfinite(good).all()
+os.environ["FR_SHARDED_INJECT_FC_FAIL"] = "1"
+wk.idx[:B] = idx; wk.dense[:B] = dense
+rc = fr.lib().fr_worker_submit_sharded(wk._h, comm._h, B)
+assert rc == fr.FR_ERR_STATE, rc
+assert b"injected FC failure" in fr.lib().fr_last_error()
+try:
+    wk.sync()
+    raise SystemExit("sync did not report the failed rank")
+except fr.FleetRecError as ex:
+    assert ex.status == fr.FR_ERR_COMM and "shard rank 0 reported a failed FC chain" in str(ex), ex
+assert np.isnan(wk.score[:B]).all()
+os.environ["FR_SHARDED_INJECT_FC_FAIL"] = "0"
+again = wk.infer_sharded(comm, idx, dense)       # nothing was aborted: the communicator still works
+assert np.array_equal(again, good)
+# an argument error is returned as it is and leaves the communicator usable too
+rc = fr.lib().fr_worker_submit_sharded(wk._h, comm._h, 100000)
+assert rc == fr.FR_ERR_INVALID, rc
+assert np.array_equal(wk.infer_sharded(comm, idx, dense), good)
+print("ok")
+""" % (ROOT, gpu)
+    env = dict(os.environ, FR_LIB=exp)
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0 and b"ok" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
 def test_submit_sharded_through_rccl_two_ranks(fr, O, gpu, prec):
     """The G > 1 path of fr_comm_* + fr_worker_submit_sharded, which the one-GPU test boxes cannot run: two table-ID shards
     on two devices, fr_comm_init_all, one thread per rank, an UNEVEN split (B = 301: ranks take 151 and 150 items), the score all-gather.
     Skipped where fewer than two GPUs are visible -- the G > 1 RCCL path stays unmeasured on such boxes and DESIGN.md says so.
-    Second half: a rank that cannot take part (bad batch size) aborts the communicator; its peer's collective returns FR_ERR_COMM
-    instead of hanging."""
+    Second half: a rank that does not take part (an argument error on that rank only: nothing is enqueued, its communicator stays usable)
+    leaves its peer in the collective -- the peer's wait is BOUNDED (fr_comm_set_wait_ms) and ends in FR_ERR_COMM instead of hanging."""
     import threading
     if fr.device_count() < 2:
         pytest.skip("needs two GPUs: the G > 1 RCCL path is unmeasured on one-GPU boxes")
@@ -1575,7 +1630,9 @@ def test_submit_sharded_through_rccl_two_ranks(fr, O, gpu, prec):
     rec = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES).view(np.float32)
     ref = om.fc_chain(rec, [ctxs_[0].get_weights(l) for l in range(4)], acc64=True)
     assert rel_err(got[0], ref) <= {"f32": 1e-3, "bf16": 3e-2}[prec]
-    # failure on one rank: rank 1 is handed a batch larger than its worker allows -> it aborts the communicator, rank 0 gets FR_ERR_COMM
+    # failure on one rank: rank 1 is handed a batch larger than its worker allows -> FR_ERR_INVALID there, nothing enqueued; rank 0's
+    # collective never completes -> its bounded wait (3 s here) aborts its communicator and returns FR_ERR_COMM
+    comms[0].set_wait_ms(3000)
     errs = [None] * G
     small = fr.Worker(ctxs_[1], 16)
     wks_bad = [wks[0], small]
