@@ -682,6 +682,12 @@ extern "C" void fr_worker_destroy(fr_worker *w) {
     if (w->d_blist) (void)hipFree(w->d_blist);
     for (hipEvent_t e : w->ev_blist)
         if (e) (void)hipEventDestroy(e);
+    if (w->aux) (void)hipStreamSynchronize(w->aux);
+    for (int p = 0; p < 2; p++) {
+        if (w->ev_x_ready[p]) (void)hipEventDestroy(w->ev_x_ready[p]);
+        if (w->ev_x_free[p]) (void)hipEventDestroy(w->ev_x_free[p]);
+    }
+    if (w->aux) (void)hipStreamDestroy(w->aux);
     if (w->ev_start) (void)hipEventDestroy(w->ev_start);
     if (w->ev_stop) (void)hipEventDestroy(w->ev_stop);
     if (w->stream) (void)hipStreamDestroy(w->stream);
@@ -856,6 +862,8 @@ static int pipeline_step(fr_worker *w) {
     a.err_flag = w->d_err;
     a.stamps = g_stamp_buffer;
     int blocks = 0, n_stages = 0, only = -1;
+    bool split0 = false;   // this step's gather (a large-batch transposing gather) leaves on the aux stream
+    int blocks0 = 0;
     for (int s = 0; s < FR_N_STAGES; s++) {
         FrStageArgs &st = a.st[s];
         st.block_begin = blocks;
@@ -895,6 +903,9 @@ static int pipeline_step(fr_worker *w) {
                     blocks += (trb + 7) / 8 * 8;
                     n_stages++;
                     only = s;
+                    // ... on the worker's second stream when the chain's layers are GEMM launches of their own (see below): beside FC1, not before it
+                    split0 = trv == 2 && !w->calibrating && FR_KNOB_ONCE("GATHER_AUX", 0) != 0 && frk_fc_lp_gemm_ok(prec, fc[0], fc[1], ldm);
+                    blocks0 = blocks;
                     continue;
                 }
                 if (fp8) {  // the q16 gather has its own grid shape
@@ -922,10 +933,31 @@ static int pipeline_step(fr_worker *w) {
                 st.in = rd.r3; st.in_part_stride = (int)rd.p3; st.out = sl.d_scores; st.w = wl[3];
                 break;
         }
+        if (s == 3 && st.nparts_in == 1 && st.nsplit == 1 && !w->calibrating && frk_fc_lp_gemm_ok(prec, st.K, st.N, ldm) && frk_fc_tail_ok(prec, st.K, st.N, ldm)) {
+            // large batch, bf16 / fp8: FC3 and the output layer of this batch in ONE launch (fc_tail_kernel); the batch leaves the pipeline here
+            int rc = frk_fc_tail(prec, st.w, st.in, wl[3], sl.d_scores, st.K, st.N, ldm, sl.batch, st.e_w, st.e_in, st.e_out, w->stream);
+            if (rc) return rc;
+            st.batch = 0;
+            sl.active = false;
+            w->n_active--;
+            continue;
+        }
         if (s >= 1 && s <= 3 && st.nparts_in == 1 && st.nsplit == 1 && frk_fc_lp_gemm_ok(prec, st.K, st.N, ldm)) {
             // a layer big enough to fill the chip alone runs as its own LDS-tiled GEMM launch (same stream, same step)
+            if (s == 1 && w->x_ready_set[par ^ 1]) {  // its X was gathered on the aux stream (previous step)
+                FR_HIP(hipStreamWaitEvent(w->stream, w->ev_x_ready[par ^ 1], 0));
+                w->x_ready_set[par ^ 1] = false;
+            }
+            if (s == 1 && w->aux && FR_KNOB_ONCE("GATHER_AUX", 0) == 2) {   // experiment: the gather of this step starts WITH this FC1, not before
+                FR_HIP(hipEventRecord(w->ev_x_free[par], w->stream));
+                w->x_free_set[par] = true;
+            }
             int rc = frk_fc_lp_gemm(prec, st.w, st.in, st.out, st.K, st.N, ldm, st.e_w, st.e_in, st.e_out, w->stream);
             if (rc) return rc;
+            if (s == 1 && w->aux && FR_KNOB_ONCE("GATHER_AUX", 0) != 2) {  // X[par ^ 1] may be overwritten by the gather of the NEXT step once this launch has finished
+                FR_HIP(hipEventRecord(w->ev_x_free[par ^ 1], w->stream));
+                w->x_free_set[par ^ 1] = true;
+            }
             st.batch = 0;  // inactive in the combined launch
             continue;
         }
@@ -940,6 +972,64 @@ static int pipeline_step(fr_worker *w) {
     a.n_blocks = blocks;
     w->launch_no = L + 1;
     if (n_stages == 0) return FR_OK;
+    if (split0) {
+        // The gather of batch L on the aux stream, enqueued AFTER this step's FC1 launch (batch L - 1, main stream): FC1's 256 workgroups
+        // (one per CU: 120 KiB of LDS) take their CUs first and one 56-register gather workgroup fits beside each of them, so the two
+        // kernels share every CU for the length of the gather instead of two gathers (or two FC1s) of different workers meeting each other
+        // (kernel trace of round 3's chain, profiles/r04_experiments.md section 1).
+        if (!w->aux) {
+            if (FR_KNOB_ONCE("GATHER_AUX_PRIO", 0)) {   // experiment: the gather's stream at the lowest priority
+                int lo = 0, hi = 0;
+                FR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                FR_HIP(hipStreamCreateWithPriority(&w->aux, hipStreamNonBlocking, lo));
+            } else
+            FR_HIP(hipStreamCreateWithFlags(&w->aux, hipStreamNonBlocking));
+            for (int p = 0; p < 2; p++) {
+                FR_HIP(hipEventCreateWithFlags(&w->ev_x_ready[p], hipEventDisableTiming));
+                FR_HIP(hipEventCreateWithFlags(&w->ev_x_free[p], hipEventDisableTiming));
+            }
+        }
+        if (w->x_free_set[par]) {  // the FC1 that read X[par] (previous step) must be through before X[par] is overwritten
+            FR_HIP(hipStreamWaitEvent(w->aux, w->ev_x_free[par], 0));
+            w->x_free_set[par] = false;
+        } else {  // no event yet (first steps, or a step whose FC1 was not a GEMM launch): order behind everything the main stream holds
+            FR_HIP(hipEventRecord(w->ev_x_free[par], w->stream));
+            FR_HIP(hipStreamWaitEvent(w->aux, w->ev_x_free[par], 0));
+        }
+        FrPipeArgs g = a;
+        for (int s = 1; s < FR_N_STAGES; s++) {
+            g.st[s].block_begin = blocks0;
+            g.st[s].batch = 0;
+        }
+        g.n_blocks = blocks0;
+        int rc = frk_pipeline_launch(g, -1, prec, w->aux);  // (the light gather | out kernel with an empty out stage)
+        if (rc) return rc;
+        FR_HIP(hipEventRecord(w->ev_x_ready[par], w->aux));
+        w->x_ready_set[par] = true;
+        for (int s = 1; s < FR_N_STAGES; s++) a.st[s].block_begin -= blocks0;
+        a.st[0].batch = 0;
+        a.n_blocks = blocks - blocks0;
+        n_stages--;
+        if (n_stages == 0) return FR_OK;
+        only = -1;
+        for (int s = 1; s < FR_N_STAGES; s++)
+            if (a.st[s].batch > 0 && (s == FR_N_STAGES - 1 ? a.n_blocks - a.st[s].block_begin : a.st[s + 1].block_begin - a.st[s].block_begin) > 0) only = s;
+        if (w->x_ready_set[par ^ 1] && a.st[1].batch > 0) {  // FC1 inside the combined launch reads an X the aux stream gathered
+            FR_HIP(hipStreamWaitEvent(w->stream, w->ev_x_ready[par ^ 1], 0));
+            w->x_ready_set[par ^ 1] = false;
+        }
+    } else if (w->aux) {
+        // a step that gathers on the main stream (or not at all) while aux-stream gathers may be outstanding: keep both orders
+        if (a.st[0].batch > 0 && blocks > 0) {
+            FR_HIP(hipEventRecord(w->ev_x_ready[par], w->aux));   // everything the aux stream holds ...
+            FR_HIP(hipStreamWaitEvent(w->stream, w->ev_x_ready[par], 0));  // ... before this step's launch writes X[par]
+            w->x_ready_set[par] = false;
+        }
+        if (w->x_ready_set[par ^ 1] && a.st[1].batch > 0) {
+            FR_HIP(hipStreamWaitEvent(w->stream, w->ev_x_ready[par ^ 1], 0));
+            w->x_ready_set[par ^ 1] = false;
+        }
+    }
     if (n_stages == 1) {  // a lone stage runs as its own, separately named kernel (rocprof attribution)
         const int begin = a.st[only].block_begin;
         for (int s = 0; s < FR_N_STAGES; s++) a.st[s].block_begin -= (s >= only) ? begin : 0;
@@ -1739,6 +1829,7 @@ extern "C" int fr_worker_sync(fr_worker *w) {
         return crc;
     }
     FR_HIP(hipStreamSynchronize(w->stream));
+    if (w->aux) FR_HIP(hipStreamSynchronize(w->aux));  // (its gathers were consumed by main-stream launches that have finished: returns at once)
     w->in_flight = false;
     if (__atomic_load_n(w->h_err, __ATOMIC_ACQUIRE)) {
         __atomic_store_n(w->h_err, 0, __ATOMIC_RELEASE);

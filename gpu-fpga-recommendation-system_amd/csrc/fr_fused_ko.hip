@@ -43,12 +43,20 @@ __device__ __forceinline__ FtWk ftk_w(const float4 *wq, int rows, int N, int hk,
     w.row2 = 2u * (unsigned)N * 16u;
     return w;
 }
+// the per-lane part again, from a freshly made lane number (the K-outer kernel re-derives it per phase instead of holding three of them)
+__device__ __forceinline__ void ftk_lane(FtWk &w, int hk, int lm) { w.voff = (unsigned)hk * (w.row2 >> 1) + (unsigned)lm * 16u; }
 // FR_HS_W_AUX (hand-built experiment variants only, tools/jobs/r03_waux.sh): cache-policy bits of the consumers' weight loads
 #ifndef FR_HS_W_AUX
 #define FR_HS_W_AUX 0
 #endif
 __device__ __forceinline__ uint4 ftk_load(const FtWk &w, unsigned soff, int imm) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.voff + imm, soff, FR_HS_W_AUX);
+    // The per-lane offset is made opaque at every load: seen through, hipcc knows its low bits (voff + 512 t == voff | 512 t), keeps one
+    // VGPR per n tile for the whole kernel, runs out of registers in FC1, spills exactly those to scratch and reloads each of them -- behind
+    // an s_waitcnt vmcnt(0) that drains the weight ring -- in front of the load that needs it.  Opaque, the tile offset rides the
+    // instruction's immediate field (buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen offset:512 t).
+    unsigned vo = w.voff;
+    asm volatile("" : "+v"(vo));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w.rs, vo + imm, soff, FR_HS_W_AUX);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
@@ -164,6 +172,13 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             if (st && lane == 0) st[k] = __builtin_amdgcn_s_memtime();
     };
     int tile_no = 0;
+    // The thread's lane number, re-made where it is needed (volatile: never hoisted, never kept): the thread id the kernel starts with is
+    // one more register held across every phase, and FC1 has none to spare -- kept, it was spilled to scratch and reloaded once per tile.
+    auto lane_now = [&]() {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
     // The workgroup barrier; the PRODUCERS' copy is stamped on both sides for the first two tiles (a release is common to all waves, and a
     // step the producers did not arrive last at waited for the consumers).  The consumers stamp only under FR_STAMP_CONSUMERS: their code is
     // then not the product's -- the stamp pointer and tile counter cost registers, hipcc spills, and the spills show up as slow steps.
@@ -273,7 +288,8 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
         {   // prologue: the first tile's slices 0, 1 into LDS, 2 .. D + 1 requested, the indices of D + 2 requested (every tile starts so).
             // (Issuing every index load first -- two dependent latencies instead of D + 2 -- measured no different: at launch start, with
             // every workgroup in its prologue, the chain takes 13-14 us either way, and the extra index registers spill.)
-            wl = tid & (LW - 1), it0 = ((tid - 512) / LW) * IPT;
+            const int t_ = 64 * (wave - 8) + lane_now();   // (not the kernel's thread id: held for this, it was live -- and spilled -- across the consumers' code)
+            wl = t_ & (LW - 1), it0 = (t_ / LW) * IPT;
 #pragma unroll
             for (int j = 0; j < D; j++) {
                 I_op(cur, j);
@@ -293,9 +309,8 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             HkTile nxt = cur;
             if (has_next) nxt = tile_at(t_nxt);
             else nxt.batch = 0;  // no next tile: the run-ahead gather reads row 0 of every table (index loads out of bounds return 0) into buffers nobody consumes
-            int tid_o = tid;     // lane geometry re-derived per tile from an opaque copy of the thread id: nothing of it is hoisted and kept live
-            asm volatile("" : "+v"(tid_o));
-            wl = tid_o & (LW - 1), it0 = (((tid_o - 512) & 255) / LW) * IPT;
+            const int tid_o = 64 * (wave - 8) + lane_now();   // lane geometry re-derived per tile: nothing of it is hoisted and kept live
+            wl = tid_o & (LW - 1), it0 = ((tid_o & 255) / LW) * IPT;
             auto tref = [&](int s) -> const HkTile & { return s >= NSL ? nxt : cur; };
 #pragma unroll
             for (int s = 0; s < NSL; s++) {
@@ -355,16 +370,18 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
         for (int i = 0; i < R1D; i++) ring1[i] = w1frag(i);
     };
     ring1_fill();
-    HkTile cur = tile_at(t_cur);
     if constexpr (kCStamps) stamp(1);
     while (true) {
-        const int t_nxt = next_tile(t_cur);
-        const bool has_next = t_nxt < n_tiles;
+        // (the tile's descriptor -- scores pointer, first item, batch size -- is read where the scores are stored, and the next tile is looked
+        // up at the bottom of the loop: held across the tile they cost registers the FC1 phase does not have and went to scratch)
         asm volatile("" : "+s"(n1), "+s"(n2), "+s"(n3));
-        int tid_o = tid;     // lane geometry re-derived per tile from an opaque copy of the thread id: nothing of it is hoisted out of the tile loop
-        asm volatile("" : "+v"(tid_o));
-        const int hk = (tid_o >> 5) & 1, lm = tid_o & 31;
+        int hk, lm;          // lane geometry, re-derived per phase (lane_now): nothing of it is held across FC1
+        {
+            const int l_ = lane_now();
+            hk = (l_ >> 5) & 1, lm = l_ & 31;
+        }
         const unsigned xlane = (unsigned)(2 * KG2 * HK_LD + hk * HK_LDX + lm);  // B-fragment lane base of FC1 (16-byte units): the X ring
+        ftk_lane(W1, hk, lm);
 
         // ---- FC1, K-outer: 128 outputs x 64 items per wave ----
         f32x16 acc1[4][2];
@@ -417,14 +434,32 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
 
         // ---- R1 -> LDS (bf16), FC2 K-outer over it: 64 outputs x 64 items per wave ----
         so2 = n2;
+        {
+            const int l_ = lane_now();
+            hk = (l_ >> 5) & 1, lm = l_ & 31;
+        }
+        ftk_lane(W2, hk, lm);
+        // FC2's first fragments are requested before the barrier that follows the R1 store -- but only as many as there are registers for:
+        // FC1's 128 accumulators are live until their tiles are stored, so half the ring goes out first and the other half once four of the
+        // eight tiles have been converted (all 16 at once needed 192 registers of the 168: that was the kernel's scratch)
 #pragma unroll
-        for (int i = 0; i < RB; i++) ringb[i] = w2load(i);  // FC2's first fragments: requested before the R1 store and the barrier
+        for (int i = 0; i < RB / 2; i++) ringb[i] = w2load(i);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) store_tile(R1, acc1[t][mt], 128 * wave + 32 * t, 32 * mt, hk, lm, os1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = RB / 2; i < RB; i++) ringb[i] = w2load(i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 2; t < 4; t++)
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) store_tile(R1, acc1[t][mt], 128 * wave + 32 * t, 32 * mt, hk, lm, os1);
         bar(NSL);         // R1 complete; the X ring is free (every consumer is past the last slice)
         const unsigned rlane = (unsigned)(hk * HK_LD + lm);  // B-fragment lane base of FC2 / FC3 (R1 / R2)
+        ftk_lane(W3, hk, lm);   // (FC2's tail requests W3's first fragments)
         f32x16 acc2[2][2];
 #pragma unroll
         for (int t = 0; t < 2; t++)
@@ -457,6 +492,10 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             }
         }
         bar(NSL + 1);     // every wave is done reading R1: R2 may overlay it
+        {
+            const int l_ = lane_now();
+            hk = (l_ >> 5) & 1, lm = l_ & 31;
+        }
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -483,12 +522,17 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
                 b0 = bn0, b1 = bn1;
             }
         }
+        {
+            const int l_ = lane_now();
+            hk = (l_ >> 5) & 1, lm = l_ & 31;
+        }
+        ftk_lane(W1, hk, lm);
         ring1_fill();  // the next tile's first k-group(s) of FC1: requested before the R3 store and the barriers
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) store_tile(R3, acc3[mt], 32 * wave, 32 * mt, hk, lm, os3);
         bar(NSL + 3);
         {   // score[m] = sum_n wout[n] * R3[n][m], fp32 sum: 64 items x 8 slices of the image's rows, fixed-order reduction
-            const int il = tid_o & 63, sl = (tid_o >> 6) & 7;
+            const int il = lane_now(), sl = wave;
             float sc = 0.0f;
             if constexpr (PREC == 1) {   // bf16 x bf16: 4 q8 rows per slice
                 const uint4 *wh = reinterpret_cast<const uint4 *>(a.wout);  // bf16 vector w[k], 8 per element
@@ -519,7 +563,8 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             }
             part[sl * 64 + il] = sc;
             bar(NSL + 4);
-            const int tl = tid_o & 1023;  // (the opaque copy: the score address is computed here, not at the top of the tile)
+            const int tl = 64 * wave + lane_now();  // (the score address is computed here, not at the top of the tile)
+            const HkTile cur = tile_at(t_cur);
             if (tl < 64 && cur.m0 + tl < cur.batch) {
                 float t = part[tl];
 #pragma unroll
@@ -529,9 +574,8 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             }
         }
         tile_no++;
-        if (!has_next) break;
-        cur = tile_at(t_nxt);
-        t_cur = t_nxt;
+        t_cur = next_tile(t_cur);
+        if (t_cur >= n_tiles) break;
     }
     if constexpr (kCStamps) stamp(126);
 }

@@ -19,7 +19,7 @@ constexpr int FR_GN = 128, FR_GR = 8, FR_GSTAGES = 2;
 // flight during the MFMAs of step s, and a 32 KiB stage-pipeline workgroup of another stream still fits beside the workgroup.
 // (Three steps, 144 KiB, were 10 % faster alone and slower overall: profiles/r01_experiments.md.)
 
-template <int PREC, int MU, int GN, int S>
+template <int PREC, int MU, int GN, int S, int GR = FR_GR>
 __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
                                                          int N, int ldm, int sc_a, int sc_b, float oscale) {
     extern __shared__ uint4 glds[];
@@ -56,8 +56,8 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict
         return rs;
     };
     const i32x4_t rsW = make_rs(W, (unsigned)KE * (unsigned)N * 16u), rsX = make_rs(X, (unsigned)KE * (unsigned)ldm * 16u);
-    auto As = [&](int st, int row) { return glds + ((size_t)st * FR_GR + row) * ROW; };          // GN elements
-    auto Bs = [&](int st, int row) { return glds + ((size_t)st * FR_GR + row) * ROW + GN; };  // GM elements
+    auto As = [&](int st, int row) { return glds + ((size_t)st * GR + row) * ROW; };          // GN elements
+    auto Bs = [&](int st, int row) { return glds + ((size_t)st * GR + row) * ROW + GN; };  // GM elements
     // global -> LDS without a VGPR round trip: lane i's 16 bytes land at M0 + 16 i.  Inline asm on purpose: through the builtin the
     // compiler treats every LDS read as a possible alias of the DMA write and waits for vmcnt(0) before each fragment read; the
     // s_waitcnt below is the only synchronisation these loads need.  M0 is written here without a clobber entry: hipcc rejects "m0" in a
@@ -72,16 +72,19 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict
     auto issue = [&](int step, int st) {
         if constexpr (GN == 128) {
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int row = (wave >> 1) + 4 * i;  // 8 waves x 2 = rows 0..7 x 2 halves
-                dma(rsW, As(st, row) + 64 * (wave & 1), vW, (unsigned)(step * FR_GR + row) * (unsigned)N * 16u);
+            for (int i = 0; i < GR / 4; i++) {
+                const int row = (wave >> 1) + 4 * i;  // 8 waves x (GR / 4) = rows 0..GR-1 x 2 halves
+                dma(rsW, As(st, row) + 64 * (wave & 1), vW, (unsigned)(step * GR + row) * (unsigned)N * 16u);
             }
-        } else {  // 64-wide n tile: one wave-instruction per row, wave w takes row w
-            dma(rsW, As(st, wave), vW, (unsigned)(step * FR_GR + wave) * (unsigned)N * 16u);
+        } else {  // 64-wide n tile: one wave-instruction per row, wave w takes rows w, w + 8, ...
+#pragma unroll
+            for (int rr = 0; rr < GR / 8; rr++) dma(rsW, As(st, wave + 8 * rr), vW, (unsigned)(step * GR + wave + 8 * rr) * (unsigned)N * 16u);
         }
 #pragma unroll
-        for (int i = 0; i < 2 * MU; i++)  // row = wave, GM / 64 parts
-            dma(rsX, Bs(st, wave) + 64 * i, vX + 64u * 16u * i, (unsigned)(step * FR_GR + wave) * (unsigned)ldm * 16u);
+        for (int rr = 0; rr < GR / 8; rr++)
+#pragma unroll
+            for (int i = 0; i < 2 * MU; i++)  // rows wave, wave + 8, ...; GM / 64 parts each
+                dma(rsX, Bs(st, wave + 8 * rr) + 64 * i, vX + 64u * 16u * i, (unsigned)(step * GR + wave + 8 * rr) * (unsigned)ldm * 16u);
     };
     f32x16 acc[TN][MU];
 #pragma unroll
@@ -90,11 +93,11 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict
         for (int u = 0; u < MU; u++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[t][u][i] = 0.0f;
-    const int nsteps = KE / FR_GR;
+    const int nsteps = KE / GR;
     // S stages in LDS: the loads of steps s + 1 .. s + S - 1 are in flight during the MFMAs of step s.  S = 2 is the round-1 form (one
     // step ahead, vmcnt(0)); the 64 x 128 tile of the narrow layers runs S = 4 with a counted wait -- its steps are only 128 MFMA
     // cycles per wave, far shorter than a load's round trip.
-    constexpr int LPS = (GN == 128 ? 2 : 1) + 2 * MU;      // DMA instructions per wave per step
+    constexpr int LPS = (GR / 8) * ((GN == 128 ? 2 : 1) + 2 * MU);      // DMA instructions per wave per step
     constexpr unsigned WAITN = (unsigned)LPS * (S - 2);    // may stay in flight when step s must have landed
     constexpr int IMM_WAIT = (int)((WAITN & 0xF) | ((WAITN >> 4) << 14) | 0x0F70u);
 #pragma unroll
@@ -110,7 +113,7 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict
         const int st = s % S;
         if constexpr (PREC == 0) {  // q4 fp32 elements: one element per lane feeds four v_mfma_f32_32x32x2_f32 (k = 8 kk + 4 h + c)
 #pragma unroll
-            for (int kk = 0; kk < FR_GR / 2; kk++) {
+            for (int kk = 0; kk < GR / 2; kk++) {
                 const uint4 *ar = As(st, 2 * kk + h) + wn * 32 * TN + r, *br = Bs(st, 2 * kk + h) + wm * 32 * MU + r;
                 uint4 a[TN], b[MU];
 #pragma unroll
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict
             }
         } else if constexpr (PREC == 1) {
 #pragma unroll
-            for (int kk = 0; kk < FR_GR / 2; kk++) {
+            for (int kk = 0; kk < GR / 2; kk++) {
                 const uint4 *ar = As(st, 2 * kk + h) + wn * 32 * TN + r, *br = Bs(st, 2 * kk + h) + wm * 32 * MU + r;
                 uint4 a[TN], b[MU];
 #pragma unroll
@@ -145,7 +148,7 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict
             }
         } else {
 #pragma unroll
-            for (int kk = 0; kk < FR_GR / 4; kk++) {
+            for (int kk = 0; kk < GR / 4; kk++) {
                 i32x8 a[TN], b[MU];
 #pragma unroll
                 for (int t = 0; t < TN; t++) {
@@ -600,6 +603,155 @@ __global__ void __launch_bounds__(256) fc_splitk_gemm_kernel(const uint4 *__rest
 }
 #endif  // FR_EXPERIMENTS
 
+// ===================================================================================================
+// fc_tail_kernel<PREC>: FC3 AND the output layer of a 32-item tile in one launch (bf16 / fp8 chains of a large batch: Model-C at batch
+// 4096 -> 128 workgroups).  The two layers used to be two launches of two different batches of the stage pipeline (FC3 as a 64 x 128-tile
+// GEMM on 128 of the 256 CUs, 5.5 us; the output layer as a 64-workgroup reduction, 3.8 us; a launch boundary between and after them):
+// 4.3 % of the chain's FLOPs at < 0.1 of the MFMA peak.  Here a workgroup owns 32 items for ALL outputs of FC3 (H3 <= 256: wave w takes
+// outputs [32 w, 32 w + 32)), streams the layer's whole weight matrix (256 KiB in bf16) and its 32-item slice of R2 straight from L2 into
+// registers in MFMA fragment layout (the q8 / q16 images are fragment-major: no LDS staging, no barrier in the K loop, a ring of PD
+// k-steps in flight per wave), rounds R3 once into an LDS image shaped like the output layer's operand, and runs the output layer on it.
+// Arithmetic = the separate kernels' bit for bit: the same MFMA (32x32x16 bf16 / scaled 32x32x64 e4m3) over k in ascending order with
+// fp32 accumulation, one rounding of R3, and the output layer's eight k slices of fmaf chains summed in slice order (fc_out_h_body /
+// fc_out_f_body of fr_pipeline.hip); R3 never reaches memory.  Reference shapes: 3-node cuda_server.c:610-621 (layers 3 and 4).
+// ===================================================================================================
+template <int PREC, int PD>
+__global__ void __launch_bounds__(512) fc_tail_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, const void *__restrict__ wout, float *__restrict__ scores,
+                                                      int KE /* element rows of FC3's K */, int N, int ldm, int batch, int sc_a, int sc_b, float oscale, float out_scale) {
+    static_assert(PREC == 1 || PREC == 2, "bf16 / fp8 chains only");
+    __shared__ uint4 r3s[32 * 32];   // the R3 tile as q8 / q16 elements: [element row][item]; 16 KiB
+    __shared__ float red[8 * 64];
+    constexpr int RPS = PREC == 2 ? 4 : 2;   // element rows per k-step (bf16: 2 halves x 8 k; e4m3: 2 halves x 2 rows x 16 k)
+    constexpr int FR = PREC == 2 ? 2 : 1;    // 16-byte loads per fragment
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * 32, n0 = wave * 32;
+    const int nk = KE / RPS;
+    if (n0 < N) {   // wave-uniform
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(W), 0, (unsigned)KE * (unsigned)N * 16u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(X), 0, (unsigned)KE * (unsigned)ldm * 16u, 0x00020000);
+        const unsigned hrow = PREC == 2 ? 2u * h : (unsigned)h;
+        const unsigned vW = (hrow * (unsigned)N + (unsigned)(n0 + r)) * 16u, vX = (hrow * (unsigned)ldm + (unsigned)(m0 + r)) * 16u;
+        const unsigned rowW = (unsigned)N * 16u, rowX = (unsigned)ldm * 16u;
+        uint4 ra[PD][FR], rb[PD][FR];
+        auto load_step = [&](int j, int slot) {
+#pragma unroll
+            for (int f = 0; f < FR; f++) {
+                ra[slot][f] = bload4u(rsW, vW, (unsigned)(RPS * j + f) * rowW);
+                rb[slot][f] = bload4u(rsX, vX, (unsigned)(RPS * j + f) * rowX);
+            }
+        };
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < PD; i++)
+            if (i < nk) load_step(i, i);
+        for (int jb = 0; jb < nk; jb += PD) {
+#pragma unroll
+            for (int i = 0; i < PD; i++) {
+                if (jb + i < nk) {
+                    if constexpr (PREC == 1) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[i][0]), __builtin_bit_cast(bf16x8, rb[i][0]), acc, 0, 0, 0);
+                    } else {
+                        i32x8 a8, b8;
+                        a8[0] = (int)ra[i][0].x; a8[1] = (int)ra[i][0].y; a8[2] = (int)ra[i][0].z; a8[3] = (int)ra[i][0].w;
+                        a8[4] = (int)ra[i][FR - 1].x; a8[5] = (int)ra[i][FR - 1].y; a8[6] = (int)ra[i][FR - 1].z; a8[7] = (int)ra[i][FR - 1].w;
+                        b8[0] = (int)rb[i][0].x; b8[1] = (int)rb[i][0].y; b8[2] = (int)rb[i][0].z; b8[3] = (int)rb[i][0].w;
+                        b8[4] = (int)rb[i][FR - 1].x; b8[5] = (int)rb[i][FR - 1].y; b8[6] = (int)rb[i][FR - 1].z; b8[7] = (int)rb[i][FR - 1].w;
+                        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc, 0, 0, 0, sc_a, 0, sc_b);
+                    }
+                    if (jb + i + PD < nk) load_step(jb + i + PD, i);
+                }
+            }
+        }
+        // R3 tile -> LDS, ONE rounding per value: registers 4 i .. 4 i + 3 are outputs n0 + 8 i + 4 h + (0..3) of item r
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int n = n0 + 8 * i + 4 * h;
+            if constexpr (PREC == 1) {
+                uint2 hv;
+                hv.x = pack_bf16x2(acc[4 * i + 0], acc[4 * i + 1]);
+                hv.y = pack_bf16x2(acc[4 * i + 2], acc[4 * i + 3]);
+                reinterpret_cast<uint2 *>(r3s)[((n >> 3) * 32 + r) * 2 + ((n & 7) >> 2)] = hv;
+            } else {
+                reinterpret_cast<uint32_t *>(r3s)[((n >> 4) * 32 + r) * 4 + ((n & 15) >> 2)] = pack_fp8x4(acc[4 * i + 0], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3], oscale);
+            }
+        }
+    }
+    __syncthreads();
+    // output layer: thread (q = wave, lane = item) sums its slice of FC3's outputs in ascending order, the eight slices are added in
+    // slice order -- fc_out_h_body / fc_out_f_body with the R3 elements read from LDS
+    {
+        const int q = wave;
+        const int HO = PREC == 1 ? N / 8 : N / 16;
+        const int per = (HO + 7) / 8;
+        const int h0 = q * per, h1 = (h0 + per) < HO ? (h0 + per) : HO;
+        float s = 0.0f;
+        if (lane < 32) {
+            for (int hh = h0; hh < h1; hh++) {
+                const uint4 rv = r3s[hh * 32 + lane];
+                if constexpr (PREC == 1) {
+                    const uint4 wv = reinterpret_cast<const uint4 *>(wout)[hh];
+                    const uint32_t rr[4] = {rv.x, rv.y, rv.z, rv.w}, ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        s = fmaf(__uint_as_float(ww[c] << 16), __uint_as_float(rr[c] << 16), s);
+                        s = fmaf(__uint_as_float(ww[c] & 0xFFFF0000u), __uint_as_float(rr[c] & 0xFFFF0000u), s);
+                    }
+                } else {
+                    const int rr[4] = {(int)rv.x, (int)rv.y, (int)rv.z, (int)rv.w};
+                    const float *wf = reinterpret_cast<const float *>(wout) + 16 * hh;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        s = fmaf(wf[4 * c + 0], __builtin_amdgcn_cvt_f32_fp8(rr[c], 0), s);
+                        s = fmaf(wf[4 * c + 1], __builtin_amdgcn_cvt_f32_fp8(rr[c], 1), s);
+                        s = fmaf(wf[4 * c + 2], __builtin_amdgcn_cvt_f32_fp8(rr[c], 2), s);
+                        s = fmaf(wf[4 * c + 3], __builtin_amdgcn_cvt_f32_fp8(rr[c], 3), s);
+                    }
+                }
+            }
+        }
+        red[q * 64 + lane] = s;
+        __syncthreads();
+        if (q == 0 && lane < 32 && m0 + lane < batch) {
+            float t = red[lane];
+#pragma unroll
+            for (int i = 1; i < 8; i++) t += red[i * 64 + lane];
+            scores[m0 + lane] = PREC == 2 ? t * out_scale : t;
+        }
+    }
+}
+
+// FC3 + output layer as one launch: for the layers the GEMM kernels would otherwise take one by one (large batches), in the bf16 / fp8 chains
+bool frk_fc_tail_ok(int precision, int K, int N, int ldm) {
+    if (precision != FR_FC_BF16 && precision != FR_FC_FP8) return false;
+    // EXPERIMENTS build only (FR_FC_TAIL=1): bit-identical to the two launches it replaces and 2.6-3 us shorter than their sum alone on the
+    // chip, but no faster inside the four-stream chain (bf16 38.3 -> 38.2 M inf/s) and slower in fp8 (63.0 -> 58.6 M): its 128 workgroups of
+    // 512 threads x 150-170 registers take whole CUs, the two small launches it replaces slip in beside the other streams' kernels
+    // (profiles/r04_experiments.md section 1.3)
+    if (FR_KNOB_ONCE("FC_TAIL", 0) == 0) return false;
+    if (N % 32 || N > 256 || ldm % 32 || ldm < 32 * 64) return false;         // eight waves x 32 outputs; enough 32-item tiles to be worth a launch of its own
+    if (precision == FR_FC_BF16) return K % 16 == 0 && K >= 16;
+    return K % 64 == 0 && N % 16 == 0;
+}
+
+int frk_fc_tail(int precision, const void *W3, const void *R2, const void *wout, float *scores, int K, int N, int ldm, int batch, int e_w, int e_in, int e_r3, hipStream_t s) {
+    if (!frk_fc_tail_ok(precision, K, N, ldm)) FR_FAIL(FR_ERR_INVALID, "internal: %d x %d x %d is not a fused-tail layer", K, N, ldm);
+    dim3 grid(ldm / 32);
+    if (precision == FR_FC_BF16) {
+        fc_tail_kernel<1, 16><<<grid, dim3(512), 0, s>>>(reinterpret_cast<const uint4 *>(W3), reinterpret_cast<const uint4 *>(R2), wout, scores, K / 8, N, ldm, batch, 0, 0, 1.0f, 1.0f);
+        KCHECK();
+        fr_note_kernel("fc_tail_kernel<1, 16>");
+    } else {
+        fc_tail_kernel<2, 8><<<grid, dim3(512), 0, s>>>(reinterpret_cast<const uint4 *>(W3), reinterpret_cast<const uint4 *>(R2), wout, scores, K / 16, N, ldm, batch, 127 - e_w, 127 - e_in,
+                                                        ldexpf(1.0f, e_r3), ldexpf(1.0f, -e_r3));
+        KCHECK();
+        fr_note_kernel("fc_tail_kernel<2, 8>");
+    }
+    return FR_OK;
+}
+
 // Pipeline shape (experiment knob FR_GEMM_PIPE = 10 * G + NS; 0 = fc_lp_gemm_kernel): G row groups of 4 element rows per sub-step, NS
 // sub-steps in LDS.  Default: see pipe_shape().
 static int pipe_shape() {
@@ -674,15 +826,16 @@ static int lp_gemm_mu(int precision, int K, int N, int ldm) {
 
 bool frk_fc_lp_gemm_ok(int precision, int K, int N, int ldm) { return lp_gemm_mu(precision, K, N, ldm) != 0; }
 
-template <int PREC, int MU, int GN, int S>
+template <int PREC, int MU, int GN, int S, int GR = FR_GR>
 static int lp_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
     static FrLdsAttrOnce lds_once;  // per instantiation, per device
-    const size_t lds = (size_t)S * FR_GR * (GN + 128 * MU) * 16;
-    if (int rc_ = fr_allow_full_lds(&fc_lp_gemm_kernel<PREC, MU, GN, S>, lds_once)) return rc_;
+    const size_t lds = (size_t)S * GR * (GN + 128 * MU) * 16;
+    if (int rc_ = fr_allow_full_lds(&fc_lp_gemm_kernel<PREC, MU, GN, S, GR>, lds_once)) return rc_;
     dim3 grid((N / GN) * (ldm / (128 * MU)));
-    fc_lp_gemm_kernel<PREC, MU, GN, S><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale);
+    fc_lp_gemm_kernel<PREC, MU, GN, S, GR><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale);
     KCHECK();
-    fr_note_kernel("fc_lp_gemm_kernel<%d, %d, %d, %d>", PREC, MU, GN, S);
+    if (GR == FR_GR) fr_note_kernel("fc_lp_gemm_kernel<%d, %d, %d, %d>", PREC, MU, GN, S);
+    else fr_note_kernel("fc_lp_gemm_kernel<%d, %d, %d, %d, %d>", PREC, MU, GN, S, GR);
     return FR_OK;
 }
 
@@ -713,6 +866,17 @@ static int lp_gemm_tile(int mu, const void *Wp, const void *Xp, void *Yp, int KE
         // 4 stages pay in bf16 only (Model-C FC2 19.8 -> 14.7 us, end to end +2.5 %); in fp8 / f32 the larger LDS footprint costs more
         // beside the other streams' kernels than the deeper prefetch gains (fp8 end to end 57.3 -> 52.8 M inf/s).  Knob: FR_LP_GEMM_STAGES
         const int deep = FR_KNOB_ONCE("LP_GEMM_STAGES", (PREC == 1 ? 4 : 2));
+#ifdef FR_EXPERIMENTS
+        const int rows = FR_KNOB_ONCE("LP_GEMM_ROWS", 8);   // element rows per K step of the narrow tile
+        if (rows == 16 && KE % 16 == 0 && KE / 16 >= 2) {
+            if (deep == 2) return lp_gemm_launch<PREC, 1, 64, 2, 16>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+            return lp_gemm_launch<PREC, 1, 64, 3, 16>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+        }
+        if (rows == 32 && KE % 32 == 0 && KE / 32 >= 2) return lp_gemm_launch<PREC, 1, 64, 2, 32>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+        if (deep == 3) return lp_gemm_launch<PREC, 1, 64, 3>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+        if (deep == 5) return lp_gemm_launch<PREC, 1, 64, 5>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+        if (deep == 6) return lp_gemm_launch<PREC, 1, 64, 6>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+#endif
         return deep == 2 ? lp_gemm_launch<PREC, 1, 64, 2>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s)
                          : lp_gemm_launch<PREC, 1, 64, 4>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
     }

@@ -249,6 +249,12 @@ struct fr_worker {
         const float *d_dense = nullptr;
         float *d_scores = nullptr;
     } ring[8];
+    // Large batches (transposing gather + GEMM-kernel FC layers: Model-C at batch 4096): the gather of batch L runs on a SECOND stream of the
+    // worker, beside the FC1 GEMM of batch L - 1 on the main one, ordered by events per activation-set parity: x_ready[p] = the gather into
+    // X[p] has finished (aux -> main), x_free[p] = the FC1 that read X[p] has finished (main -> aux).
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_x_ready[2] = {nullptr, nullptr}, ev_x_free[2] = {nullptr, nullptr};
+    bool x_ready_set[2] = {false, false}, x_free_set[2] = {false, false};
     uint64_t launch_no = 0;     // number of pipeline launches issued so far
     int n_active = 0;
     bool calibrating = false;   // fr_worker_calibrate_fp8: the pushed batch runs the fp32 stages without K-split partials
@@ -317,6 +323,8 @@ int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, int precision, hi
 int frk_pack_weights_q8_bf16(const float *W, uint16_t *Wh, int K, int H, hipStream_t s);
 bool frk_fc_lp_gemm_ok(int precision, int K, int N, int ldm);
 int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, hipStream_t s);
+bool frk_fc_tail_ok(int precision, int K, int N, int ldm);   // FC3 + output layer as one launch (fc_tail_kernel, fr_gemm.hip)
+int frk_fc_tail(int precision, const void *W3, const void *R2, const void *wout, float *scores, int K, int N, int ldm, int batch, int e_w, int e_in, int e_r3, hipStream_t s);
 int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, hipStream_t s);
 int frk_pack_weights_q16_fp8(const float *W, void *Wf, int K, int H, int e_w, hipStream_t s);
 int frk_pack_weights_q16h_fp8(const float *W, void *Wg, int K, int H, int e_w, hipStream_t s);  // the persistent fp8 kernel's operand layout
