@@ -1078,7 +1078,10 @@ static bool fused_eligible(const fr_ctx *c) {
     const int32_t *fc = c->model.fc;
     if (!enabled || c->n_shards != 1 || c->model.layout != FR_LAYOUT_SEMANTIC) return false;
     if (c->fc_precision == FR_FC_FP8) return frk_fused_f8_ok(fc[0], fc[1], fc[2], fc[3]);
-    return c->fc_precision == FR_FC_BF16 ? frk_fused_h_ok(fc[0], fc[1], fc[2], fc[3]) : frk_fused_ok(fc[0], fc[1], fc[2], fc[3]);
+    // bf16: the chunked kernel exists for the two reference records (352 / 880 floats); any other record the K-outer persistent kernel
+    // accepts (64 .. 880 floats in whole k-groups, frk_fused_hk_ok) streams through that kernel at every launch size
+    if (c->fc_precision == FR_FC_BF16) return frk_fused_h_ok(fc[0], fc[1], fc[2], fc[3]) || c->hk_ok == 1;
+    return frk_fused_ok(fc[0], fc[1], fc[2], fc[3]);
 }
 
 // Batches one streaming launch carries on this context: 1 for the stage pipeline, the fused kernel's group otherwise.
@@ -1185,7 +1188,8 @@ static int fused_flush(fr_worker *w) {
         // 460-463 M inf/s, at 1.5: 424 vs 452-455 M; with ONE tile per unit the chunked kernel leads 449 vs 409 M) --
         // profiles/r03_fused_hs_modelA_one_tile_ab.txt
         const int hs_from = a.K <= 352 ? c->n_cu + c->n_cu / 4 : 2 * c->n_cu;
-        if (c->hk_ok == 1 && hk != 0 && (hk == 1 || tiles >= hs_from)) {
+        const bool only_hs = bf16 && !frk_fused_h_ok(a.K, a.H1, a.H2, a.H3);   // a record the chunked kernel has no instantiation for
+        if (c->hk_ok == 1 && (only_hs || (hk != 0 && (hk == 1 || tiles >= hs_from)))) {
             if (!w->h_blist) {
                 FR_HIP(hipHostMalloc((void **)&w->h_blist, sizeof(FrFusedBatch) * FR_FUSED_MAX_QUEUE * FR_BLIST_RING, hipHostMallocDefault));
                 FR_HIP(hipMalloc((void **)&w->d_blist, sizeof(FrFusedBatch) * FR_FUSED_MAX_QUEUE * FR_BLIST_RING));

@@ -106,7 +106,12 @@ __device__ __forceinline__ void hk_mma(f32x16 &acc, const uint4 &a4, const uint4
 // exponents are folded into the scale of the next activation's quantisation, exactly).  KG = k-groups of the (zero-padded) record (16 k
 // each in bf16, 32 k in fp8); KGS = k-groups per slice; LW = producer lanes along the record words of a slice (16 or 32); D = row sets
 // a producer thread keeps in flight (NSL % D == 0: the set of a slice is a compile-time index); R1D = FC1 weight fragments in registers.
-template <int PREC, int KG, int KGS, int LW, int D, int R1D>
+// fp8 (round 4): the e4m3 R1 image is 64 KiB, so the LDS the bf16 form spends on R1 holds the WHOLE record image of a tile here (NSL
+// slice buffers instead of a ring of two), and the producers gather tile t + 1 while the consumers are anywhere in tile t: E2 of a tile's
+// NSL + D + 1 gather events run under FC2, E3 under FC3, the rest under FC1's first slices (one per slice barrier) -- with the bf16
+// schedule (every event under FC1) the fp8 consumers, whose operand stream is half as long, waited for the gather in every slice
+// (340 M inf/s against the chunked kernel's 398 M, profiles/r03_fused_hs_fp8_ab.txt).
+template <int PREC, int KG, int KGS, int LW, int D, int R1D, int E2 = 0, int E3 = 0>
 __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs a) {
     extern __shared__ uint4 lds[];
     constexpr int WPG = PREC == 2 ? 8 : 4;             // record words (4 floats each) per k-group
@@ -116,14 +121,19 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     constexpr int IPT = LW / 4;                        // items per producer thread (256 threads = LW words x 64 / IPT item slots)
     constexpr int XROWS = 2 * KGS;                     // operand rows of one X ring buffer
     constexpr int NBAR = NSL + 5;                      // barriers per tile (stamp slots)
-    static_assert(NSL % 2 == 0 && NSL % D == 0 && NSL >= D + 3, "two X buffers, D row sets, and the run-ahead stays inside the next tile");
+    constexpr bool FULLX = PREC == 2;                  // the X image of a whole tile in LDS (see above); bf16: a ring of two slices
+    constexpr int NXB = FULLX ? NSL : 2;               // X slice buffers
+    constexpr int NEV = NSL + D + 1;                   // FULLX: gather events per tile: event e = { W(e - 1 - D), R(e - 1), I(e) }
+    constexpr int NE1 = NEV - E2 - E3;                 // ... of which under FC1's slice barriers 0 .. NE1 - 1
+    static_assert(FULLX || (NSL % 2 == 0 && NSL % D == 0 && NSL >= D + 3), "two X buffers, D row sets, and the run-ahead stays inside the next tile");
+    static_assert(!FULLX || (NE1 >= 1 && NE1 <= NSL && E2 >= 0 && E3 >= 0), "FC1 carries at most one gather event per slice barrier");
     static_assert(WPG * KGS <= LW && (LW == 16 || LW == 32), "a slice's record words ride the lanes of one half / quarter wave");
     uint4 *R1 = lds;                                   // [2 KG2][64]: bf16 128 KiB, fp8 64 KiB
     uint4 *R2 = lds;                                   // [2 KG3][64], overlays R1 once FC2 has read it
     uint4 *R3 = lds + 2 * KG3 * HK_LD;                 // [2 KG4][64]
     float *part = reinterpret_cast<float *>(lds + (2 * KG3 + 2 * KG4) * HK_LD);  // 8 x 64 partial scores
-    uint4 *Xr = lds + 2 * KG2 * HK_LD;                 // [2][XROWS][65]
-    uint4 *Dsc = Xr + 2 * XROWS * HK_LDX;              // [n_words] packed descriptors
+    uint4 *Xr = lds + 2 * KG2 * HK_LD;                 // [NXB][XROWS][65]
+    uint4 *Dsc = Xr + NXB * XROWS * HK_LDX;            // [n_words] packed descriptors
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wave >= 8;                   // waves 8..11: one per SIMD beside two consumers (waves are dealt to SIMDs cyclically)
@@ -271,68 +281,117 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
                 for (int i = 0; i < IPT; i++) {
                     const uint32_t in = (0u - (uint32_t)(t.m0 + it0 + i < t.batch)) & real;  // all ones / zero: items past the batch are zero rows, branch-free
                     if constexpr (PREC == 1) {
-                        uint2 *xb = Xh2 + (size_t)(s & 1) * (XROWS * HK_LDX * 2);
+                        uint2 *xb = Xh2 + (size_t)(FULLX ? s : (s & 1)) * (XROWS * HK_LDX * 2);
                         uint2 hv;
                         hv.x = pack_bf16x2(__uint_as_float(r[i].x), __uint_as_float(r[i].y)) & in;
                         hv.y = pack_bf16x2(__uint_as_float(r[i].z), __uint_as_float(r[i].w)) & in;
                         xb[((size_t)(wl >> 1) * HK_LDX + it0 + i) * 2 + (wl & 1)] = hv;  // slice word wl = half (wl & 1) of q8 row wl / 2
                     } else {
                         // word wl = k 4 wl .. 4 wl + 3 of the slice: k-group wl / 8, step (wl % 8) / 4, lane half ((wl % 8) % 4) / 2, dword wl % 2
-                        uint32_t *xb = Xw + (size_t)(s & 1) * (XROWS * HK_LDX * 4);
+                        uint32_t *xb = Xw + (size_t)(FULLX ? s : (s & 1)) * (XROWS * HK_LDX * 4);
                         xb[((size_t)(2 * (wl >> 3) + ((wl >> 1) & 1)) * HK_LDX + it0 + i) * 4 + 2 * ((wl >> 2) & 1) + (wl & 1)] = pack_fp8_word(r[i], xscale) & in;
                     }
                 }
             }
         };
         HkTile cur = tile_at(t_cur);
-        {   // prologue: the first tile's slices 0, 1 into LDS, 2 .. D + 1 requested, the indices of D + 2 requested (every tile starts so).
-            // (Issuing every index load first -- two dependent latencies instead of D + 2 -- measured no different: at launch start, with
-            // every workgroup in its prologue, the chain takes 13-14 us either way, and the extra index registers spill.)
-            const int t_ = 64 * (wave - 8) + lane_now();   // (not the kernel's thread id: held for this, it was live -- and spilled -- across the consumers' code)
-            wl = t_ & (LW - 1), it0 = (t_ / LW) * IPT;
-#pragma unroll
-            for (int j = 0; j < D; j++) {
-                I_op(cur, j);
-                R_op(cur, j, rows[j]);
+        if constexpr (FULLX) {
+            // ---- whole-tile X image: the gather of tile t + 1 runs under every phase of tile t ----
+            // event e of a tile (0 <= e < NEV): convert slice e - 1 - D into its buffer (its rows were requested D events ago), request the
+            // rows of slice e - 1 (its indices were requested by the previous event), request the indices of slice e
+            auto event = [&](const HkTile &t, int e) {
+                if (e - 1 - D >= 0 && e - 1 - D < NSL) W_op(t, e - 1 - D, rows[(e - 1) % D]);
+                if (e >= 1 && e - 1 < NSL) R_op(t, e - 1, rows[(e - 1) % D]);
+                if (e < NSL) I_op(t, e);
+            };
+            {
+                const int t_ = 64 * (wave - 8) + lane_now();
+                wl = t_ & (LW - 1), it0 = (t_ / LW) * IPT;
             }
-            W_op(cur, 0, rows[0]);
-            I_op(cur, D);
-            R_op(cur, D, rows[0]);
-            W_op(cur, 1, rows[1]);
-            I_op(cur, D + 1);
-            R_op(cur, D + 1, rows[1]);
-            I_op(cur, D + 2);
-        }
-        while (true) {
-            const int t_nxt = next_tile(t_cur);
-            const bool has_next = t_nxt < n_tiles;
-            HkTile nxt = cur;
-            if (has_next) nxt = tile_at(t_nxt);
-            else nxt.batch = 0;  // no next tile: the run-ahead gather reads row 0 of every table (index loads out of bounds return 0) into buffers nobody consumes
-            const int tid_o = 64 * (wave - 8) + lane_now();   // lane geometry re-derived per tile: nothing of it is hoisted and kept live
-            wl = tid_o & (LW - 1), it0 = ((tid_o & 255) / LW) * IPT;
-            auto tref = [&](int s) -> const HkTile & { return s >= NSL ? nxt : cur; };
 #pragma unroll
-            for (int s = 0; s < NSL; s++) {
-                pbar(s);           // consumers start slice s; X[(s + 1) % 2] is free
-                if (s >= 1) {     // write slice s + 1, request the rows of s + 1 + D and the indices of s + 2 + D (slices >= NSL: the next tile's)
-                    W_op(tref(s + 1), (s + 1) % NSL, rows[(s + 1) % D]);
-                    R_op(tref(s + 1 + D), (s + 1 + D) % NSL, rows[(s + 1) % D]);
-                    I_op(tref(s + 2 + D), (s + 2 + D) % NSL);
+            for (int e = 0; e < NEV; e++) event(cur, e);   // the workgroup's first tile: everything before the consumers' first barrier
+            while (true) {
+                const int t_nxt = next_tile(t_cur);
+                const bool has_next = t_nxt < n_tiles;   // wave-uniform
+                HkTile nxt = cur;
+                if (has_next) nxt = tile_at(t_nxt);
+                {
+                    const int t_ = 64 * (wave - 8) + lane_now();
+                    wl = t_ & (LW - 1), it0 = (t_ / LW) * IPT;
                 }
+#pragma unroll
+                for (int s = 0; s < NSL; s++) {
+                    pbar(s);       // the consumers are done with slice s - 1 of this tile: buffer s - 1 may take the next tile's slice
+                    if (has_next && s < NE1) event(nxt, s);   // event s converts slice s - 1 - D at the latest
+                }
+                pbar(NSL);         // R1 stored; FC2 runs
+                if (has_next) {
+#pragma unroll
+                    for (int e = NE1; e < NE1 + E2; e++) event(nxt, e);
+                }
+                pbar(NSL + 1);     // FC2 done
+                pbar(NSL + 2);     // R2 stored; FC3 runs
+                if (has_next) {
+#pragma unroll
+                    for (int e = NE1 + E2; e < NEV; e++) event(nxt, e);
+                }
+                pbar(NSL + 3);     // R3 stored
+                pbar(NSL + 4);     // partial scores
+                tile_no++;
+                if (!has_next) break;
+                cur = nxt;
+                t_cur = t_nxt;
             }
-            pbar(NSL);             // R1 stored, every consumer is past the last slice: X[1] is free
-            W_op(nxt, 1, rows[1 % D]);
-            R_op(nxt, 1 + D, rows[1 % D]);
-            I_op(nxt, 2 + D);
-            pbar(NSL + 1);         // FC2 done
-            pbar(NSL + 2);         // R2 stored
-            pbar(NSL + 3);         // R3 stored
-            pbar(NSL + 4);         // partial scores
-            tile_no++;
-            if (!has_next) break;
-            cur = nxt;
-            t_cur = t_nxt;
+        } else {
+            {   // prologue: the first tile's slices 0, 1 into LDS, 2 .. D + 1 requested, the indices of D + 2 requested (every tile starts so).
+                // (Issuing every index load first -- two dependent latencies instead of D + 2 -- measured no different: at launch start, with
+                // every workgroup in its prologue, the chain takes 13-14 us either way, and the extra index registers spill.)
+                const int t_ = 64 * (wave - 8) + lane_now();   // (not the kernel's thread id: held for this, it was live -- and spilled -- across the consumers' code)
+                wl = t_ & (LW - 1), it0 = (t_ / LW) * IPT;
+    #pragma unroll
+                for (int j = 0; j < D; j++) {
+                    I_op(cur, j);
+                    R_op(cur, j, rows[j]);
+                }
+                W_op(cur, 0, rows[0]);
+                I_op(cur, D);
+                R_op(cur, D, rows[0]);
+                W_op(cur, 1, rows[1]);
+                I_op(cur, D + 1);
+                R_op(cur, D + 1, rows[1]);
+                I_op(cur, D + 2);
+            }
+            while (true) {
+                const int t_nxt = next_tile(t_cur);
+                const bool has_next = t_nxt < n_tiles;
+                HkTile nxt = cur;
+                if (has_next) nxt = tile_at(t_nxt);
+                else nxt.batch = 0;  // no next tile: the run-ahead gather reads row 0 of every table (index loads out of bounds return 0) into buffers nobody consumes
+                const int tid_o = 64 * (wave - 8) + lane_now();   // lane geometry re-derived per tile: nothing of it is hoisted and kept live
+                wl = tid_o & (LW - 1), it0 = ((tid_o & 255) / LW) * IPT;
+                auto tref = [&](int s) -> const HkTile & { return s >= NSL ? nxt : cur; };
+    #pragma unroll
+                for (int s = 0; s < NSL; s++) {
+                    pbar(s);           // consumers start slice s; X[(s + 1) % 2] is free
+                    if (s >= 1) {     // write slice s + 1, request the rows of s + 1 + D and the indices of s + 2 + D (slices >= NSL: the next tile's)
+                        W_op(tref(s + 1), (s + 1) % NSL, rows[(s + 1) % D]);
+                        R_op(tref(s + 1 + D), (s + 1 + D) % NSL, rows[(s + 1) % D]);
+                        I_op(tref(s + 2 + D), (s + 2 + D) % NSL);
+                    }
+                }
+                pbar(NSL);             // R1 stored, every consumer is past the last slice: X[1] is free
+                W_op(nxt, 1, rows[1 % D]);
+                R_op(nxt, 1 + D, rows[1 % D]);
+                I_op(nxt, 2 + D);
+                pbar(NSL + 1);         // FC2 done
+                pbar(NSL + 2);         // R2 stored
+                pbar(NSL + 3);         // R3 stored
+                pbar(NSL + 4);         // partial scores
+                tile_no++;
+                if (!has_next) break;
+                cur = nxt;
+                t_cur = t_nxt;
+            }
         }
         stamp(126);
         if (bad) atomicOr_system(a.err_flag, 1);
@@ -343,7 +402,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     // n1 / n2 / n3 and the lane offsets are re-declared opaque at the top of every tile: everything derived from them is tile-loop
     // invariant, and hoisted out of the loop the SGPR offsets of the weight stream alone spilled 200 scalars into vector registers
     unsigned n1 = (unsigned)(128 * wave) * 16u, n2 = (unsigned)(64 * wave) * 16u, n3 = (unsigned)(32 * wave) * 16u;
-    FtWk W1 = ftk_w(a.w1q, KG * 2, HK_H1, lane >> 5, lane & 31), W2 = ftk_w(a.w2q, KG2 * 2, HK_H2, lane >> 5, lane & 31), W3 = ftk_w(a.w3q, KG3 * 2, HK_H3, lane >> 5, lane & 31);
+    FtWk W1 = ftk_w(a.w1q, a.K / 8 /* the model's own q8 rows: an instantiation may be wider than the record, rows past it read 0 */, HK_H1, lane >> 5, lane & 31), W2 = ftk_w(a.w2q, KG2 * 2, HK_H2, lane >> 5, lane & 31), W3 = ftk_w(a.w3q, KG3 * 2, HK_H3, lane >> 5, lane & 31);
     // fp8: the accumulators hold sums of (w 2^e_w)(x 2^e_x); the next activation is quantised as e4m3(sat(value 2^e_next)), so the store
     // scales by 2^(e_next - e_w - e_x) -- powers of two, exact
     const float os1 = PREC == 2 ? __builtin_ldexpf(1.0f, a.e_act[1] - a.e_w[0] - a.e_act[0]) : 1.0f, os2 = PREC == 2 ? __builtin_ldexpf(1.0f, a.e_act[2] - a.e_w[1] - a.e_act[1]) : 1.0f,
@@ -398,7 +457,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
             if (kCStamps && s == 0 && tile_no == 0) cstamp(2);
             if (s == 0) so1 = n1;  // k-group 0; advanced once per k-group: inside k-group g it points at g + 1
             asm volatile("" : "+s"(so1));
-            const uint4 *xb = lds + xlane + (s & 1) * (XROWS * HK_LDX);
+            const uint4 *xb = lds + xlane + (FULLX ? s : (s & 1)) * (XROWS * HK_LDX);
             uint4 b0 = xb[0], b1 = xb[32];
 #pragma unroll
             for (int gl = 0; gl < kgs; gl++) {
@@ -580,23 +639,31 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
     if constexpr (kCStamps) stamp(126);
 }
 
-// Every word descriptor must fit the packed 16-byte form: 48-bit source address, 16-bit row stride.
+// Which models the K-outer kernel takes: the reference's FC widths (1024 / 512 / 256, constant.h:24-27 -- the LDS plan is built on them) and
+// ANY record of 64 .. 880 floats in whole k-groups of 16 (the generated constants.hpp of a user kernel, embedding_47_krnl/src/hls/
+// constants.hpp:28,505, may hold any table set): the record rides the narrowest of four instantiations (22 / 33 / 44 / 55 k-groups = 352 /
+// 528 / 704 / 880 floats) that holds it, the k-groups past the record are zeros on both sides (weight rows past the matrix read 0 through
+// the buffer resource's bounds, the producers store zero words).  Every word descriptor must fit the packed 16-byte form: 48-bit source
+// address, 16-bit row stride.
 bool frk_fused_hk_ok(int K, int H1, int H2, int H3, const FrWordDesc *h_words, int n_words) {
-    if ((K != 880 && K != 352) || H1 != HK_H1 || H2 != HK_H2 || H3 != HK_H3 || n_words != K / 4) return false;
+    if (K % 16 || K < 64 || K > 880 || H1 != HK_H1 || H2 != HK_H2 || H3 != HK_H3 || n_words != K / 4) return false;
     for (int w = 0; w < n_words; w++)
         if (h_words[w].stride >= 65536u || (h_words[w].src >> 48) != 0 || (h_words[w].idx_col & ~FR_DESC_DENSE) >= (1u << 28)) return false;
     return true;
 }
 
-template <int PREC, int KG, int KGS, int LW, int D, int R1D>
+template <int PREC, int KG, int KGS, int LW, int D, int R1D, int E2 = 0, int E3 = 0>
 static int fused_hk_launch_inst(const FrFusedArgs &a, int n_cu, hipStream_t s) {
     static FrLdsAttrOnce lds_once;  // per instantiation, per device
-    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, D, R1D>, lds_once)) return rc_;
+    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, D, R1D, E2, E3>, lds_once)) return rc_;
     const size_t r1_rows = 2 * (HK_H1 / (PREC == 2 ? 32 : 16));
-    const size_t lds = (r1_rows * HK_LD + (size_t)2 * 2 * KGS * HK_LDX + (size_t)a.n_words) * 16;
+    const size_t x_bufs = PREC == 2 ? (KG + KGS - 1) / KGS : 2;   // fp8: the X image of a whole tile; bf16: a ring of two slices
+    const size_t lds = (r1_rows * HK_LD + x_bufs * 2 * KGS * HK_LDX + (size_t)a.n_words) * 16;
+    if (lds > 160 * 1024) FR_FAIL(FR_ERR_INVALID, "internal: the K-outer fused kernel needs %zu bytes of LDS", lds);
     const int tiles = a.n_batches * a.tiles_per_batch;
-    fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, D, R1D><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(768), lds, s>>>(a);
-    fr_note_kernel("fr_fused_tile_hs_kernel<%d, %d, %d, %d, %d, %d>", PREC, KG, KGS, LW, D, R1D);
+    fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, D, R1D, E2, E3><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(768), lds, s>>>(a);
+    if (PREC == 2) fr_note_kernel("fr_fused_tile_hs_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", PREC, KG, KGS, LW, D, R1D, E2, E3);
+    else fr_note_kernel("fr_fused_tile_hs_kernel<%d, %d, %d, %d, %d, %d>", PREC, KG, KGS, LW, D, R1D);
     KCHECK();
     return FR_OK;
 }
@@ -611,15 +678,26 @@ int frk_fused_hk_launch(const FrFusedArgs &a, int n_cu, int precision, hipStream
         // 398-400 M inf/s, profiles/r03_fused_hs_fp8_ab.txt) -- with the consumers twice as fast as in bf16, the gather, which only runs
         // under FC1, is what a tile waits for.
 #ifdef FR_EXPERIMENTS
-        if (a.K == 880) return fused_hk_launch_inst<2, 28, 2, 16, 2, 4>(a, n_cu, s);   // Model-B: K 880 -> 896 = 28 k-groups of 32, 14 slices of 2
-        if (a.K == 352) return fused_hk_launch_inst<2, 11, 2, 16, 3, 4>(a, n_cu, s);   // Model-A: K 352 = 11 k-groups of 32, 6 slices of 2 (1)
+        if (a.K == 880) {   // Model-B: K 880 -> 896 = 28 k-groups of 32, 14 slices of 2; 4 row sets in flight; 19 gather events per tile
+            switch (FR_KNOB_ONCE("FUSED_F8_SCHED", 63)) {   // 10 E2 + E3: gather events under FC2 / FC3 (the rest under FC1)
+                case 50: return fused_hk_launch_inst<2, 28, 2, 16, 4, 4, 5, 0>(a, n_cu, s);
+                case 42: return fused_hk_launch_inst<2, 28, 2, 16, 4, 4, 4, 2>(a, n_cu, s);
+                case 84: return fused_hk_launch_inst<2, 28, 2, 16, 4, 4, 8, 4>(a, n_cu, s);
+                default: return fused_hk_launch_inst<2, 28, 2, 16, 4, 4, 6, 3>(a, n_cu, s);
+            }
+        }
+        if (a.K == 352) return fused_hk_launch_inst<2, 11, 2, 16, 3, 4, 3, 1>(a, n_cu, s);   // Model-A: K 352 = 11 k-groups of 32, 6 slices of 2 (1); 10 events
 #endif
         FR_FAIL(FR_ERR_INVALID, "no K-outer fp8 fused instantiation for K=%d in this build", a.K);
     }
 #ifdef FR_EXPERIMENTS
     if (a.K == 880 && FR_KNOB_ONCE("FUSED_R1D", 6) == 4) return fused_hk_launch_inst<1, 55, 7, 32, 2, 4>(a, n_cu, s);
 #endif
-    if (a.K == 880) return fused_hk_launch_inst<1, 55, 7, 32, 2, 6>(a, n_cu, s);   // Model-B: 8 slices of 7 (6) k-groups, 2 row sets in flight, 6 FC1 fragments
-    if (a.K == 352) return fused_hk_launch_inst<1, 22, 4, 16, 3, 4>(a, n_cu, s);   // Model-A: 6 slices of 4 (2) k-groups, 3 row sets in flight, 4 FC1 fragments
+    if (a.K % 16 == 0 && a.K >= 64) {
+        if (a.K <= 352) return fused_hk_launch_inst<1, 22, 4, 16, 3, 4>(a, n_cu, s);   // Model-A: 6 slices of 4 (2) k-groups, 3 row sets in flight, 4 FC1 fragments
+        if (a.K <= 528) return fused_hk_launch_inst<1, 33, 6, 32, 3, 4>(a, n_cu, s);   // 6 slices of 6 (3) k-groups, 3 row sets
+        if (a.K <= 704) return fused_hk_launch_inst<1, 44, 6, 32, 2, 6>(a, n_cu, s);   // 8 slices of 6 (2) k-groups, 2 row sets
+        if (a.K <= 880) return fused_hk_launch_inst<1, 55, 7, 32, 2, 6>(a, n_cu, s);   // Model-B: 8 slices of 7 (6) k-groups, 2 row sets in flight, 6 FC1 fragments
+    }
     FR_FAIL(FR_ERR_INVALID, "no K-outer bf16 fused instantiation for K=%d", a.K);
 }

@@ -100,3 +100,26 @@ def test_core_header_is_the_three_spans_only():
               "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_submit_sharded", "fr_driver_run_resident"):
         assert s in core_syms, s
     assert len(core_syms) <= 64, len(core_syms)
+
+
+def test_persistent_kernels_use_no_scratch(fr):
+    """the product instantiations of the persistent K-outer bf16 kernel (fr_fused_tile_hs_kernel: BASELINE configs[2]'s
+    kernel and its three other record widths) compile without a single spilled vector register and without a private (scratch) segment
+    -- round 3's build spilled 11-14 registers per instantiation and reloaded them, behind an s_waitcnt vmcnt(0), in front of FC1's weight
+    loads.  Read from the code object's metadata notes inside libfleetrec.so (tools/kernel_resources.py: the offload bundle is unpacked by
+    hand, llvm-readelf --notes prints the per-kernel records)."""
+    import importlib.util
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not available")
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    recs = [r for r in kr.kernel_records(fr.LIB_PATH) if "fr_fused_tile_hs_kernel" in r["name"]]
+    assert len(recs) >= 4, [r["name"] for r in recs]
+    for r in recs:
+        assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, r
+        assert r["vgpr_count"] <= 168, r      # 12 waves per workgroup = 3 per SIMD
+    # ... and no kernel of the library needs more than a few dwords of scratch (a regression guard for the others)
+    worst = max(kr.kernel_records(fr.LIB_PATH), key=lambda r: r["private_segment_fixed_size"])
+    assert worst["private_segment_fixed_size"] <= 64, worst

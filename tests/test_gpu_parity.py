@@ -2019,6 +2019,79 @@ def test_random_custom_models(fr, O, gpu, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("spec_k", [496, 688, 64, 880])
+def test_custom_model_rides_the_persistent_bf16_kernel(fr, O, gpu, spec_k):
+    """the persistent bf16 kernel (fr_fused_tile_hs_kernel) is not reserved for the two reference records (352 / 880
+    floats): a Model.from_spec model with the reference's FC widths (1024 / 512 / 256) and ANY record of 64 .. 880 floats in whole
+    k-groups of 16 takes the narrowest instantiation that holds it (22 / 33 / 44 / 55 k-groups; the k-groups past the record are zeros),
+    and fr_worker_last_kernel says which.  Records of 496 (-> 33 k-groups), 688 (-> 44), 64 (-> 22) and 880 floats (-> 55) with a dense
+    block and a COPY pad; a launch of 40 batches of 1024 items (640 tiles: what selects the kernel); every batch against the host
+    restatement of the bf16 arithmetic (5e-3) and, bit for bit, against a small launch of the same rows (the chunked kernel for the 880-float
+    record, the persistent kernel with one tile per workgroup for the others)."""
+    rng = np.random.default_rng(4000 + spec_k)
+    dims = []
+    left = spec_k - 16 - 4          # a 16-float dense block and one 4-float COPY pad
+    while left > 0:
+        d = int(rng.choice([d_ for d_ in (4, 8, 16, 32) if d_ <= left]))
+        dims.append(d)
+        left -= d
+    spec = {"name": "custom_%d" % spec_k, "tables": [{"dim": d, "rows": int(rng.integers(50, 5000)), "class": "HBM"} for d in dims],
+            "dense_len": 16, "dense_at": len(dims) // 2, "pad": [{"after_table": 0, "copy_of": 0, "col": 0}], "fc": [1024, 512, 256]}
+    m = fr.Model.from_spec(spec)
+    assert m.record_len == spec_k
+    ctx = fr.Context(m, device=gpu)
+    tabs = m.tables()
+    host = [rng.standard_normal((t.rows, t.dim)).astype(np.float32) for t in tabs]
+    for t, a_ in enumerate(host):
+        ctx.upload_table(t, a_)
+    fcw = list(m.fc)
+    ws = [(rng.uniform(-1, 1, fcw[i] * fcw[i + 1]) / np.sqrt(fcw[i])).astype(np.float32) for i in range(4)]
+    for l in range(4):
+        ctx.set_weights(l, ws[l])
+    ctx.set_fc_precision(fr.FC_BF16)
+    B = 1024
+    pool = []
+    for _ in range(3):
+        idx = uniform_idx(rng, m.rows(), B)
+        dense = rng.uniform(-1, 1, (B, 16)).astype(np.float32)
+        want = np.empty((B, spec_k), np.float32)
+        for sg in m.segments():
+            if sg.kind == fr.SEG_DENSE:
+                want[:, sg.rec_offset:sg.rec_offset + sg.len] = dense[:, sg.src_col:sg.src_col + sg.len]
+            else:
+                want[:, sg.rec_offset:sg.rec_offset + sg.len] = host[sg.src][idx[:, sg.src], sg.src_col:sg.src_col + sg.len]
+        pool.append((fr.DeviceBuffer.from_numpy(ctx, idx), fr.DeviceBuffer.from_numpy(ctx, dense), chain_bf16_reference(want, ws, fcw)))
+    wk = fr.Worker(ctx, B)
+    small = [fr.DeviceBuffer(ctx, B * 4) for _ in range(3)]
+    for j in range(3):
+        wk.push_device(B, pool[j][0], pool[j][1], small[j])
+    wk.sync()
+    # a small launch: the two reference records have a chunked kernel for it; every other record rides the persistent kernel at any size
+    assert wk.last_kernel().startswith("fr_fused_tile_h_kernel<" if spec_k == 880 else "fr_fused_tile_hs_kernel<1, "), wk.last_kernel()
+    chunked = [b_.download(np.float32, B) for b_ in small]
+    sizes = [1024, 1000, 1024, 65, 1024]
+    outs = []
+    for rep in range(40):
+        j, b = rep % 3, sizes[rep % len(sizes)]
+        buf = fr.DeviceBuffer(ctx, B * 4)
+        buf.upload(np.full(B, np.nan, np.float32))
+        wk.push_device(b, pool[j][0], pool[j][1], buf)
+        outs.append((buf, j, b))
+    wk.sync()
+    kg = {496: 33, 688: 44, 64: 22, 880: 55}[spec_k]
+    assert wk.last_kernel().startswith("fr_fused_tile_hs_kernel<1, %d," % kg), wk.last_kernel()
+    for buf, j, b in outs:
+        got = buf.download(np.float32, B)
+        assert np.isnan(got[b:]).all(), (j, b)
+        refh = pool[j][2]
+        assert np.abs(got[:b] - refh[:b]).max() <= 5e-3 * np.abs(refh).max(), (j, b, np.abs(got[:b] - refh[:b]).max() / np.abs(refh).max())
+        assert np.array_equal(got[:b], chunked[j][:b]), (j, b)
+        buf.free()
+    wk.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("which", [1, 0, "B-per-bank"])
 def test_bf16_persistent_fused_kernel_many_tiles(fr, O, ctxs, gpu, which):
     """fr_fused_tile_hs_kernel (fr_fused_ko.hip), BASELINE configs[2]'s kernel: 8 MFMA waves + 4 gather waves per workgroup, one persistent
