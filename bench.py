@@ -1321,7 +1321,7 @@ def main():
             dib = [fr.DeviceBuffer.from_numpy(cb, a) for a in ihb]
             cb.set_stream_group(bf16_launch_group(1024))
             cfgs.append(leg_config(fr, cb, mbb, 1024, "bf16", dib, None, ihb[0], None, args.threads, args.depth,
-                                   "BASELINE configs[2] under the kernel's index contract: Model-B batch=1024, bf16 FC, ONE index per bank (FR_INDEX_PER_BANK, 49 banks), %d batches per launch" % bf16_launch_group(1024), tag="B1024_bf16_per_bank"))
+                                   "BASELINE configs[2] under the kernel's index contract: Model-B batch=1024, bf16 FC, ONE index per bank (FR_INDEX_PER_BANK, 49 banks), %d batches per launch" % bf16_launch_group(1024), tag="B1024_bf16_per_bank", profile_csv=find_profile("B1024_bf16_per_bank_kernel_stats.csv")))
             cb.close()
         except Exception as ex:
             cfgs.append({"workload": "Model-B", "error": repr(ex)})
@@ -1340,7 +1340,7 @@ def main():
                 ga = bf16_launch_group(B) if prec == "bf16" else 64
                 ca.set_stream_group(ga)
                 cfgs.append(leg_config(fr, ca, ma, B, prec, dia, None, iha[0], None, args.threads, args.depth,
-                                       "Model-A batch=%d (the headline workload), %s FC chain through the fused item-tile kernel, %d batches per launch (fr_ctx_set_stream_group)" % (B, prec, ga), tag="A%d_%s" % (B, prec)))
+                                       "Model-A batch=%d (the headline workload), %s FC chain through the fused item-tile kernel, %d batches per launch (fr_ctx_set_stream_group)" % (B, prec, ga), tag="A%d_%s" % (B, prec), profile_csv=find_profile("A%d_%s_kernel_stats.csv" % (B, prec))))
             ca.close()
         except Exception as ex:
             cfgs.append({"workload": "Model-A low precision", "error": repr(ex)})

@@ -662,8 +662,7 @@ static int fused_hk_launch_inst(const FrFusedArgs &a, int n_cu, hipStream_t s) {
     if (lds > 160 * 1024) FR_FAIL(FR_ERR_INVALID, "internal: the K-outer fused kernel needs %zu bytes of LDS", lds);
     const int tiles = a.n_batches * a.tiles_per_batch;
     fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, D, R1D, E2, E3><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(768), lds, s>>>(a);
-    if (PREC == 2) fr_note_kernel("fr_fused_tile_hs_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", PREC, KG, KGS, LW, D, R1D, E2, E3);
-    else fr_note_kernel("fr_fused_tile_hs_kernel<%d, %d, %d, %d, %d, %d>", PREC, KG, KGS, LW, D, R1D);
+    fr_note_kernel("fr_fused_tile_hs_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", PREC, KG, KGS, LW, D, R1D, E2, E3);   // as rocprofv3 prints it
     KCHECK();
     return FR_OK;
 }

@@ -834,8 +834,7 @@ static int lp_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int 
     dim3 grid((N / GN) * (ldm / (128 * MU)));
     fc_lp_gemm_kernel<PREC, MU, GN, S, GR><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale);
     KCHECK();
-    if (GR == FR_GR) fr_note_kernel("fc_lp_gemm_kernel<%d, %d, %d, %d>", PREC, MU, GN, S);
-    else fr_note_kernel("fc_lp_gemm_kernel<%d, %d, %d, %d, %d>", PREC, MU, GN, S, GR);
+    fr_note_kernel("fc_lp_gemm_kernel<%d, %d, %d, %d, %d>", PREC, MU, GN, S, GR);   // as rocprofv3 prints it
     return FR_OK;
 }
 

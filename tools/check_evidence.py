@@ -5,15 +5,17 @@ kernel in the CSV the object names, and the two fractions.  The CSVs come from s
 line's HIP-event time and the CSV average differ by the run-to-run spread of power-bound kernels (up to ~7 % on the bf16 GEMM); the SAME-RUN
 pairs -- the HIP-event figure each profiled run printed itself against that run's CSV -- are in profiles/r03_roofline_pairs.json and agree
 within 3.5 %.  Exit status 1 when a cross-run pair differs by more than 8 %, a same-run pair by more than 3.5 %, or a CSV lacks the kernel.
-usage: python tools/check_evidence.py [profiles/r03_bench_line_driver_cmd.json]"""
+usage: python tools/check_evidence.py [profiles/r04_bench_detail_driver_cmd.json]"""
 import csv
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-line = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_bench_line_driver_cmd.json")
-d = json.loads(open(line).read().strip().splitlines()[-1])
+# round 4: the stdout line is a compact summary; the roofline objects of every leg are in the DETAIL file written beside it
+line = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_bench_detail_driver_cmd.json")
+txt = open(line).read().strip()
+d = json.loads(txt) if txt.startswith("{\n") or "\n" in txt[:3] else json.loads(txt.splitlines()[-1])
 
 
 def prof(csv_path, kernel):
@@ -46,7 +48,7 @@ for name, rf, csvp in rows:
     print("%-50s %-48s live %8.1f us  profiled %s (%d calls)  frac %.3f -> %s  %s" % (
         name, rf["kernel_name"], live, "%8.1f us" % p if p else "   absent", calls, frac_live, "%.3f" % (frac_live * live / p) if p else "-", "ok" if ok else "MISMATCH"))
 pairs = os.path.join(ROOT, "profiles", "r03_roofline_pairs.json")
-if os.path.exists(pairs):
+if os.path.exists(pairs) and "r03" in os.path.basename(line):
     print("same-run pairs (profiles/r03_roofline_pairs.json):")
     for leg, e in json.load(open(pairs)).items():
         ok = abs(e["rocprofv3_avg_us"] - e["hip_events_us_same_run"]) <= 0.035 * e["hip_events_us_same_run"]

@@ -8,7 +8,7 @@
 #   gather_C4096_per_bank_uniform    bench.py --legs bank                          gather_pack_xcd_kernel
 #   fused_h_B1024_bf16               bench.py --roofline-only --model B --batch 1024 --precision bf16    fr_fused_tile_hs_kernel (round 3; fr_fused_tile_h_kernel before)
 #   gemm_C4096_{f32,bf16,fp8}        bench.py --roofline-only --model C --batch 4096 --precision P       the FC1 GEMM kernel of that precision
-# Run on the GPU box from the repo root:  bash tools/pmc_passes.sh [key ...]   -> gpurun_out/pmc/<key>/<pass>/ + gpurun_out/pmc/r03_pmc.json
+# Run on the GPU box from the repo root:  bash tools/pmc_passes.sh [key ...]   -> gpurun_out/pmc/<key>/<pass>/ + gpurun_out/pmc/<PMC_NAME: r04_pmc.json>
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc
@@ -32,6 +32,6 @@ for key in $KEYS; do
     tag=$(echo $pass | tr ' ' '_')
     timeout -k 10 240 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/$key/$tag -- python3 $ROOT/bench.py --quick --no-gather-ab $ARGS > $OUT/$key/$tag.log 2>&1 || echo "pass $key/$tag failed"
   done
-  python3 $ROOT/tools/pmc_summarize.py $OUT/$key $key "$KERNEL" $OUT/r03_pmc.json
+  python3 $ROOT/tools/pmc_summarize.py $OUT/$key $key "$KERNEL" $OUT/${PMC_NAME:-r04_pmc.json}
 done
-cat $OUT/r03_pmc.json
+cat $OUT/${PMC_NAME:-r04_pmc.json}
