@@ -864,6 +864,18 @@ static int pipeline_step(fr_worker *w) {
     int blocks = 0, n_stages = 0, only = -1;
     bool split0 = false;   // this step's gather (a large-batch transposing gather) leaves on the aux stream
     int blocks0 = 0;
+    // Large batches in the bf16 / fp8 chains: this step's gather (batch L) rides INSIDE the FC1 launch of batch L - 1 (fc_gemm_gather_kernel:
+    // producer waves beside the GEMM's consumer waves) whenever both stages are present and FC1 takes the 128 x 256 tile.
+    bool fuse01 = false;
+    {
+        const fr_worker::Slot &s1 = w->ring[(L - 1) % 8], &s0 = w->ring[L % 8];
+        const bool has1 = L >= 1 && s1.active && s1.launch0 == L - 1 && s1.first_stage <= 1;
+        const bool has0 = s0.active && s0.launch0 == L && s0.first_stage == 0;
+        if (has0 && has1 && !w->calibrating && frk_fc_gemm_gather_ok(prec, fc[0], fc[1], s1.ldm)) {
+            const int trv = frk_gather_tr_variant(s0.batch, (int)idx_cols(c));
+            fuse01 = trv == 2 && frk_gather_tr_blocks(c->n_words, s0.ldm, trv) > 0 && (c->n_words & 1) == 0;
+        }
+    }
     for (int s = 0; s < FR_N_STAGES; s++) {
         FrStageArgs &st = a.st[s];
         st.block_begin = blocks;
@@ -896,6 +908,10 @@ static int pipeline_step(fr_worker *w) {
                 st.out = wr.x;
                 st.K = fc[0];
                 w->last_x_parity = par;
+                if (fuse01) {   // gathered by the producer waves of this step's FC1 launch (below)
+                    st.batch = 0;
+                    continue;
+                }
                 const int trv = frk_gather_tr_variant(sl.batch, a.idx_stride);
                 const int trb = frk_gather_tr_blocks(c->n_words, ldm, trv);
                 if (trb > 0) {  // large batch: LDS-transposing gather
@@ -940,6 +956,15 @@ static int pipeline_step(fr_worker *w) {
             st.batch = 0;
             sl.active = false;
             w->n_active--;
+            continue;
+        }
+        if (s == 1 && fuse01) {
+            const fr_worker::Slot &g0 = w->ring[L % 8];   // the batch pushed in this step: its operand image goes to this step's WRITE set
+            int rc = frk_fc_gemm_gather(prec, st.w, st.in, st.out, st.K, st.N, ldm, st.e_w, st.e_in, st.e_out, c->d_words, c->n_words, (int)idx_cols(c), g0.d_idx, g0.d_dense,
+                                        g0.batch, g0.ldm, fc[0], wr.x, prec == FR_FC_FP8 ? c->f8_e_act[0] : 0, w->d_err, w->stream);
+            if (rc) return rc;
+            w->last_x_parity = par;
+            st.batch = 0;
             continue;
         }
         if (s >= 1 && s <= 3 && st.nparts_in == 1 && st.nsplit == 1 && frk_fc_lp_gemm_ok(prec, st.K, st.N, ldm)) {

@@ -19,10 +19,9 @@ constexpr int FR_GN = 128, FR_GR = 8, FR_GSTAGES = 2;
 // flight during the MFMAs of step s, and a 32 KiB stage-pipeline workgroup of another stream still fits beside the workgroup.
 // (Three steps, 144 KiB, were 10 % faster alone and slower overall: profiles/r01_experiments.md.)
 
-template <int PREC, int MU, int GN, int S, int GR = FR_GR>
-__global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
-                                                         int N, int ldm, int sc_a, int sc_b, float oscale) {
-    extern __shared__ uint4 glds[];
+template <int PREC, int MU, int GN, int S, int GR>
+__device__ __forceinline__ void lp_gemm_body(uint4 *glds, const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
+                                             int N, int ldm, int sc_a, int sc_b, float oscale) {
     typedef __attribute__((address_space(3))) void *lds_ptr;
     constexpr int GM = 128 * MU, ROW = GN + GM, TN = GN / 64;  // elements per staged row: GN of W, GM of X; TN n tiles of 32 per wave
     const int tid = threadIdx.x, lane = tid & 63;
@@ -192,6 +191,177 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict
                 }
             }
         }
+}
+
+template <int PREC, int MU, int GN, int S, int GR = FR_GR>
+__global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
+                                                         int N, int ldm, int sc_a, int sc_b, float oscale) {
+    extern __shared__ uint4 glds[];
+    lp_gemm_body<PREC, MU, GN, S, GR>(glds, W, X, Y, KE, N, ldm, sc_a, sc_b, oscale);
+}
+
+// ===================================================================================================
+// fc_gemm_gather_kernel<PREC>: north_star's "fused concat + first FC" for the model whose record does not fit a CU (Model-C, batch 4096,
+// bf16 / fp8): the FC1 GEMM of batch L - 1 (fc_lp_gemm_kernel's 128 x 256 tile body, 8 consumer waves) and the GATHER of batch L (4
+// producer waves, one per SIMD) in ONE workgroup, so the two share every CU for the length of the kernel by construction -- the
+// separately launched gather met another stream's gather, not a GEMM (profiles/r04_experiments.md section 1).  A 128 x 256 tile cannot
+// gather its own operand (16 n tiles share an item tile: 16 x the row fetches), hence the stage pipeline's shift by one batch: the
+// producers write the q8 / q16 operand image of the NEXT launch's FC1 to HBM.
+//   producers: the batch is cut into half-tiles of 16 items x 64 record words; producer wave p of workgroup b owns half-tiles
+//   4 b + p, + 4 grid, ...; lanes run along the record words (a table row is read by adjacent lanes), 16 index loads and 16 row loads
+//   per lane and half-tile stay in flight in registers; a half-tile is converted (fp32 -> bf16 / e4m3) into a wave-private LDS patch
+//   laid out as operand elements and written out with lanes along items (256 contiguous bytes per 16 lanes).  No cross-wave hand-off:
+//   the only synchronisation is the wave's own instruction order.
+//   coupling: s_barrier counts every wave of the workgroup, so the producers pass one RAW s_barrier (no vmcnt / lgkmcnt wait) per K step
+//   of the consumers; their n_ht + 2 events (event e = { convert half-tile e - 2, request the rows of e - 1, request the indices of e })
+//   are spread evenly over the K steps, so an event's loads have ~ n_steps / n_events steps (several us) to land.
+// ===================================================================================================
+struct FrGatherJob {
+    const FrWordDesc *words;
+    const int32_t *idx;
+    const float *dense;
+    void *out;        // q8 (bf16) / q16 (e4m3) operand image of the batch, leading dimension ldm
+    int *err_flag;
+    int n_words, idx_stride, batch, ldm, K;
+    float scale;      // fp8: 2^e_x
+};
+constexpr int FR_GG_LD = 17;                          // patch row stride in 16-byte elements (16 items + 1: conflict-free both ways)
+constexpr int FR_GG_PATCH = 32 * FR_GG_LD;            // 16-byte elements of a wave's patch (32 q8 rows; fp8 uses 16 q16 rows of it)
+
+template <int PREC>
+__device__ __forceinline__ void gg_producer(const FrGatherJob &g, uint4 *patch, int pw, int nsteps) {
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    const int n_wb = (g.n_words + 63) >> 6, n_mi = g.ldm >> 4;
+    const int total = n_wb * n_mi, stride = (int)gridDim.x * 4, first = (int)blockIdx.x * 4 + pw;
+    const int n_ht = (g.words && first < total) ? (total - first + stride - 1) / stride : 0;
+    const int n_ev = n_ht ? n_ht + 2 : 0;
+    const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(g.idx), 0, (unsigned)g.batch * (unsigned)g.idx_stride * 4u, 0x00020000);
+    uint32_t idxr[16];
+    uint4 rows[16];
+    // Word descriptors: fetched ONE EVENT AHEAD (raw, q0 / q1) and decoded when the half-tile's index event runs -- fetched inside the
+    // event, the dependent chain descriptor -> index address put an s_waitcnt vmcnt(0) behind the 16 row loads the same event had just
+    // issued (a wave's loads return in order), and every such wait held all 12 waves at the next s_barrier: the fused kernel took as
+    // long as the GEMM and the gather one after the other (profiles/r04_experiments.md section 1.6).
+    uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0;
+    uint64_t d_base = 0;   // decoded descriptor of the half-tile whose rows are requested next
+    uint32_t d_stride = 0, d_rows = 0;
+    bool d_dense = false;
+    unsigned bad = 0u;
+    auto ht_of = [&](int h) { return first + h * stride; };
+    auto D_ld = [&](int h) {   // raw descriptor of half-tile h's word of this lane
+        const int ht = ht_of(h), wb = ht / n_mi;
+        int w = (wb << 6) + lane;
+        w = w < g.n_words ? w : g.n_words - 1;   // a lane past the record repeats the last word (never stored)
+        q0 = reinterpret_cast<const uint4 *>(g.words)[2 * w];
+        q1 = reinterpret_cast<const uint4 *>(g.words)[2 * w + 1];
+    };
+    // the fetched descriptor, pinned into registers at the START of an event: the wait for it (everything older has long landed) must not sink
+    // below the row loads the event issues
+    uint32_t n_lo = 0, n_hi = 0, n_stride = 0, n_col = 0, n_rows = 0;
+    auto D_pin = [&]() {
+        n_lo = q0.x, n_hi = q0.y, n_stride = q0.z, n_col = q0.w, n_rows = q1.x;
+        asm volatile("" : "+v"(n_lo), "+v"(n_hi), "+v"(n_stride), "+v"(n_col), "+v"(n_rows));
+    };
+    auto I_ev = [&](int h) {
+        const int ht = ht_of(h), wb = ht / n_mi, m0 = (ht - wb * n_mi) << 4;
+        d_dense = (n_col & FR_DESC_DENSE) != 0;
+        d_base = (d_dense ? (uint64_t)reinterpret_cast<uintptr_t>(g.dense) : 0ull) + (((uint64_t)n_hi << 32) | n_lo);
+        d_stride = n_stride, d_rows = n_rows;
+        const unsigned icol = d_dense ? 0u : n_col * 4u;
+#pragma unroll
+        for (int i = 0; i < 16; i++)   // items past the batch: out of the resource's bounds, 0 comes back
+            idxr[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_idx, (unsigned)(m0 + i) * (unsigned)g.idx_stride * 4u + icol, 0, 0);
+    };
+    auto R_ev = [&](int h) {
+        const int ht = ht_of(h), wb = ht / n_mi, m0 = (ht - wb * n_mi) << 4;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const unsigned m = (unsigned)(m0 + i);
+            uint32_t r = idxr[i];
+            const bool oob = !d_dense & (r >= d_rows);   // reference: silent out-of-bounds read (embedding_47_krnl.cpp:927-933); here reported
+            bad |= oob ? 1u : 0u;
+            r = oob ? 0u : r;
+            r = d_dense ? (m < (unsigned)g.batch ? m : 0u) : r;
+            typedef const u32x4_t __attribute__((address_space(1))) * gptr_t;
+            const u32x4_t q = *(gptr_t)(d_base + (uint64_t)r * d_stride);
+            rows[i] = make_uint4(q.x, q.y, q.z, q.w);
+        }
+    };
+    auto W_ev = [&](int h) {
+        const int ht = ht_of(h), wb = ht / n_mi, m0 = (ht - wb * n_mi) << 4, w0 = wb << 6;
+        const uint32_t real = 0u - (uint32_t)(w0 + lane < g.n_words);   // words past the record are zeros (the fp8 image's pad up to 64 k)
+        if constexpr (PREC == 1) {
+            uint2 *p2 = reinterpret_cast<uint2 *>(patch);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t in = (0u - (uint32_t)(m0 + i < g.batch)) & real;
+                uint2 hv;
+                hv.x = pack_bf16x2(__uint_as_float(rows[i].x), __uint_as_float(rows[i].y)) & in;
+                hv.y = pack_bf16x2(__uint_as_float(rows[i].z), __uint_as_float(rows[i].w)) & in;
+                p2[((lane >> 1) * FR_GG_LD + i) * 2 + (lane & 1)] = hv;   // word = half (lane & 1) of q8 row lane / 2
+            }
+        } else {
+            uint32_t *p1 = reinterpret_cast<uint32_t *>(patch);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t in = (0u - (uint32_t)(m0 + i < g.batch)) & real;
+                p1[((lane >> 2) * FR_GG_LD + i) * 4 + (lane & 3)] = pack_fp8_word(rows[i], g.scale) & in;   // word = dword (lane & 3) of q16 row lane / 4
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own stores have reached LDS (in-order per wave): read the patch back along items
+        constexpr int NR = PREC == 1 ? 8 : 4;              // read passes: 4 element rows x 16 items per wave-instruction
+        const int row0 = PREC == 1 ? (w0 >> 1) : (w0 >> 2), n_rows = PREC == 1 ? (g.n_words >> 1) : ((g.K + 63) / 64 * 4);
+        uint4 *img = reinterpret_cast<uint4 *>(g.out);
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int j = (lane >> 4) + 4 * r, it = lane & 15;
+            const uint4 v = patch[j * FR_GG_LD + it];
+            if (row0 + j < n_rows) img[(size_t)(row0 + j) * g.ldm + m0 + it] = v;
+        }
+        asm volatile("" ::: "memory");
+    };
+    int e = 0;
+    if (n_ht) D_ld(0);
+    for (int s = 0; s < nsteps; s++) {
+        while (e < n_ev && (long)e * nsteps <= (long)s * n_ev) {   // event e at step floor(e nsteps / n_ev)
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) HERE, where every outstanding operation is an event old: left to hipcc, counted waits land between the row loads
+            asm volatile("" ::: "memory");
+            if (e < n_ht) D_pin();
+            if (e >= 2) W_ev(e - 2);
+            if (e >= 1 && e - 1 < n_ht) R_ev(e - 1);
+            if (e < n_ht) I_ev(e);
+            if (e + 1 < n_ht) D_ld(e + 1);
+            e++;
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // raw: no vmcnt / lgkmcnt wait -- the loads of the last events stay in flight across it
+        asm volatile("" ::: "memory");
+    }
+    while (e < n_ev) {   // (fewer K steps than events: finish behind the loop)
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) HERE, where every outstanding operation is an event old: left to hipcc, counted waits land between the row loads
+            asm volatile("" ::: "memory");
+            if (e < n_ht) D_pin();
+        if (e >= 2) W_ev(e - 2);
+        if (e >= 1 && e - 1 < n_ht) R_ev(e - 1);
+        if (e < n_ht) I_ev(e);
+        if (e + 1 < n_ht) D_ld(e + 1);
+        e++;
+    }
+    if (bad) atomicOr_system(g.err_flag, 1);
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(768) fc_gemm_gather_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE, int N, int ldm, int sc_a,
+                                                              int sc_b, float oscale, const FrGatherJob g) {
+    extern __shared__ uint4 glds[];
+    constexpr int GEMM_LDS = FR_GSTAGES * FR_GR * (FR_GN + 256);   // 16-byte elements of the consumers' two K steps
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave >= 8) {
+        gg_producer<PREC>(g, glds + GEMM_LDS + (wave - 8) * FR_GG_PATCH, wave - 8, KE / FR_GR);
+        return;
+    }
+    lp_gemm_body<PREC, 2, FR_GN, FR_GSTAGES, FR_GR>(glds, W, X, Y, KE, N, ldm, sc_a, sc_b, oscale);
 }
 
 // ===================================================================================================
@@ -880,6 +1050,45 @@ static int lp_gemm_tile(int mu, const void *Wp, const void *Xp, void *Yp, int KE
                          : lp_gemm_launch<PREC, 1, 64, 4>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
     }
     return lp_gemm_launch<PREC, 1, 128, FR_GSTAGES>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+}
+
+// FC1 of one batch + the gather of the next in one launch (fc_gemm_gather_kernel): for layers the 128 x 256 tile takes, bf16 / fp8
+bool frk_fc_gemm_gather_ok(int precision, int K, int N, int ldm) {
+    if (precision != FR_FC_BF16 && precision != FR_FC_FP8) return false;
+    // EXPERIMENTS build only (FR_GEMM_GATHER=1).  Correct (tests/test_gpu_parity.py::test_model_c_streaming_gather_inside_fc1: operand image and
+    // fp8 scores bit for bit) and SLOWER: alone on one stream the fused launch takes as long as the GEMM and the gather one after the other
+    // (bf16 102.7 us against 63.1 + 37.7; fp8 66.3 against 32.8 + 35.8), in the four-stream chain bf16 38.1 -> 33.7 M inf/s, fp8 60.6 -> 50.1 M.
+    // The two do not overlap inside a CU: the GEMM's operand DMA and the gather's row fetches go through the same vector-memory path, and a
+    // wave-private producer still gates all 12 waves at every s_barrier (profiles/r04_experiments.md section 1.2).
+    if (FR_KNOB_ONCE("GEMM_GATHER", 0) == 0) return false;
+    return lp_gemm_mu(precision, K, N, ldm) == 2;
+}
+
+int frk_fc_gemm_gather(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, const FrWordDesc *words, int n_words,
+                       int idx_stride, const int32_t *idx, const float *dense, int g_batch, int g_ldm, int g_K, void *g_out, int g_e_x, int *err_flag, hipStream_t s) {
+    if (!frk_fc_gemm_gather_ok(precision, K, N, ldm)) FR_FAIL(FR_ERR_INVALID, "internal: %d x %d x %d is not a gather + GEMM layer", K, N, ldm);
+    const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : K / 8;
+    FrGatherJob g{};
+    g.words = words, g.idx = idx, g.dense = dense, g.out = g_out, g.err_flag = err_flag;
+    g.n_words = n_words, g.idx_stride = idx_stride, g.batch = g_batch, g.ldm = g_ldm, g.K = g_K;
+    g.scale = ldexpf(1.0f, g_e_x);
+    const size_t lds = ((size_t)FR_GSTAGES * FR_GR * (FR_GN + 256) + 4 * (size_t)FR_GG_PATCH) * 16;
+    dim3 grid((N / FR_GN) * (ldm / 256));
+    if (precision == FR_FC_BF16) {
+        static FrLdsAttrOnce once1;
+        if (int rc_ = fr_allow_full_lds(&fc_gemm_gather_kernel<1>, once1)) return rc_;
+        fc_gemm_gather_kernel<1><<<grid, dim3(768), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, 0, 0, 1.0f, g);
+        KCHECK();
+        fr_note_kernel("fc_gemm_gather_kernel<1>");
+    } else {
+        static FrLdsAttrOnce once2;
+        if (int rc_ = fr_allow_full_lds(&fc_gemm_gather_kernel<2>, once2)) return rc_;
+        fc_gemm_gather_kernel<2><<<grid, dim3(768), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, 127 - e_w, 127 - e_in,
+                                                              ldexpf(1.0f, e_out), g);
+        KCHECK();
+        fr_note_kernel("fc_gemm_gather_kernel<2>");
+    }
+    return FR_OK;
 }
 
 int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, hipStream_t s) {

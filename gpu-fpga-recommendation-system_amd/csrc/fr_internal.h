@@ -323,6 +323,9 @@ int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, int precision, hi
 int frk_pack_weights_q8_bf16(const float *W, uint16_t *Wh, int K, int H, hipStream_t s);
 bool frk_fc_lp_gemm_ok(int precision, int K, int N, int ldm);
 int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, hipStream_t s);
+bool frk_fc_gemm_gather_ok(int precision, int K, int N, int ldm);   // FC1 of batch L - 1 + the gather of batch L in one launch (fc_gemm_gather_kernel)
+int frk_fc_gemm_gather(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, const FrWordDesc *words, int n_words,
+                       int idx_stride, const int32_t *idx, const float *dense, int g_batch, int g_ldm, int g_K, void *g_out, int g_e_x, int *err_flag, hipStream_t s);
 bool frk_fc_tail_ok(int precision, int K, int N, int ldm);   // FC3 + output layer as one launch (fc_tail_kernel, fr_gemm.hip)
 int frk_fc_tail(int precision, const void *W3, const void *R2, const void *wout, float *scores, int K, int N, int ldm, int batch, int e_w, int e_in, int e_r3, hipStream_t s);
 int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, hipStream_t s);

@@ -1888,6 +1888,90 @@ def test_tiled_gemm_model_c_batch_4096(fr, O, ctxs, prec):
         ctx.set_fc_precision(fr.FC_FP32)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp8"])
+@pytest.mark.parametrize("per_bank", [False, True])
+def test_model_c_streaming_gather_inside_fc1(fr, O, ctxs, gpu, prec, per_bank):
+    """fc_gemm_gather_kernel: in the streaming path of a large batch (Model-C 4096, bf16 / fp8) the gather of batch L runs in the producer
+    waves of the FC1 launch of batch L - 1 ("fused concat + first FC" for the model whose record does not fit a CU).  Six pushed batches of
+    different index rows (ragged last ones), every batch against the same rows through fr_worker_submit (one batch at a time: the
+    separately launched gather; bf16: FC1 there is the 16x16x32 software-pipelined kernel, so equal up to flipped bf16 roundings; fp8: the
+    same GEMM body, bit for bit), the operand image the producers wrote against the submit path's (bit for bit), one batch against the
+    fp64-accumulating oracle on every item, an out-of-range index reported, and the result stable run to run.  Per-table and per-bank
+    (bank-interleaved tables, 82 index columns) contexts.  The kernel is built into the EXPERIMENTS library only (it is slower than the separate
+    launches: profiles/r04_experiments.md section 1.2): run with FR_LIB=.../libfleetrec_exp.so FR_GEMM_GATHER=1."""
+    if os.path.basename(fr.LIB_PATH) != "libfleetrec_exp.so" or os.environ.get("FR_GEMM_GATHER") != "1":
+        pytest.skip("fc_gemm_gather_kernel is reachable in the experiments library only: run with FR_LIB=.../libfleetrec_exp.so FR_GEMM_GATHER=1")
+    own = None
+    if per_bank:
+        m = fr.Model.builtin(fr.MODEL_C).clone(index_mode=fr.INDEX_PER_BANK)
+        own = ctx = fr.Context(m, device=gpu)
+        ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+        ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    else:
+        m, ctx = ctxs(2)
+    om = O.OracleModel(NAMES[2])
+    B = 4096
+    rng = np.random.default_rng(4096 + per_bank)
+    sizes = [4096, 4096, 4096, 4000, 4096, 3333]
+    pool = [(uniform_idx(rng, m.index_ranges(), B), rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)) for _ in sizes]
+    ctx.set_fc_precision({"bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[prec])
+    try:
+        ref_wk = fr.Worker(ctx, B)
+        if prec == "fp8":
+            ref_wk.calibrate_fp8(pool[0][0], pool[0][1])
+        refs = [ref_wk.infer(i_[:b], d_[:b]) for (i_, d_), b in zip(pool, sizes)]
+        feat_ref = ref_wk.features(sizes[-1], fp8=(prec == "fp8"), bf16=(prec == "bf16"))   # the operand image the submit path's gather kernel wrote
+        wk = fr.Worker(ctx, B)
+        d_i = [fr.DeviceBuffer.from_numpy(ctx, i_) for i_, _ in pool]
+        d_d = [fr.DeviceBuffer.from_numpy(ctx, d_) for _, d_ in pool]
+        for rep in range(2):
+            outs = []
+            for j, b in enumerate(sizes):
+                buf = fr.DeviceBuffer(ctx, B * 4)
+                buf.upload(np.full(B, np.nan, np.float32))
+                wk.push_device(b, d_i[j], d_d[j], buf)
+                outs.append(buf)
+            wk.sync()
+            got = [o_.download(np.float32, B) for o_ in outs]
+            for o_ in outs:
+                o_.free()
+            for j, b in enumerate(sizes):
+                assert np.isnan(got[j][b:]).all(), (j, b)
+                if prec == "fp8":
+                    assert np.array_equal(got[j][:b], refs[j]), (j, rel_err(got[j][:b], refs[j]))
+                else:
+                    assert rel_err(got[j][:b], refs[j]) <= 1e-2, (j, rel_err(got[j][:b], refs[j]))
+            if rep == 0:
+                first = got
+            else:
+                assert all(np.array_equal(a_[:b], b_[:b]) for a_, b_, b in zip(first, got, sizes))   # run to run
+        if feat_ref is not None:   # the operand image of the LAST pushed batch, as the producer waves wrote it
+            feat = wk.features(sizes[-1], fp8=True) if prec == "fp8" else wk.features(sizes[-1], bf16=True)
+            assert np.array_equal(feat, feat_ref)
+        rec = om.gather(pool[1][0], dense=pool[1][1], content_mode=O.FILL_HASH, seed=SEED_TABLES, per_bank=per_bank).view(np.float32)
+        ref32 = om.fc_chain(rec, [ctx.get_weights(l) for l in range(4)], acc64=True)
+        assert rel_err(first[1], ref32) <= {"bf16": 3e-2, "fp8": 0.15}[prec]
+        # an out-of-range index in a batch gathered by producer waves
+        bad = pool[2][0].copy()
+        bad[4095, 5] = m.index_ranges()[5]
+        d_bad = fr.DeviceBuffer.from_numpy(ctx, bad)
+        sc = [fr.DeviceBuffer(ctx, B * 4) for _ in range(3)]
+        wk.push_device(B, d_i[0], d_d[0], sc[0])
+        wk.push_device(B, d_bad, d_d[2], sc[1])
+        wk.push_device(B, d_i[1], d_d[1], sc[2])
+        with pytest.raises(fr.FleetRecError) as e:
+            wk.sync()
+        assert e.value.status == fr.FR_ERR_INDEX_RANGE
+        for b_ in sc + [d_bad] + d_i + d_d:
+            b_.free()
+        wk.close()
+        ref_wk.close()
+    finally:
+        ctx.set_fc_precision(fr.FC_FP32)
+        if own is not None:
+            own.close()
+
+
 def _random_model(fr, rng, width_mult=32):
     """A random user-defined model: random table dims/rows, an optional dense block in the middle of the record, an
     optional COPY pad, random FC widths.  Exercises the descriptor machinery beyond the three reference models."""
