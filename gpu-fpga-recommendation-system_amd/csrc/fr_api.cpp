@@ -1208,11 +1208,10 @@ static int fused_flush(fr_worker *w) {
             if (t_ > max_tiles) max_tiles = t_;
         }
         const int hk = FR_KNOB_ONCE("FUSED_HK", -1);  // experiments build: 0 = never, 1 = whenever it applies
-        // The persistent kernel pays once a workgroup walks more than one tile; where exactly depends on the record: K = 880 (Model-B) from
-        // two tiles per compute unit (at 1.25 / 1.5 the chunked kernel is level / 3 % ahead), K = 352 (Model-A) from 1.25 (371-377 vs
-        // 460-463 M inf/s, at 1.5: 424 vs 452-455 M; with ONE tile per unit the chunked kernel leads 449 vs 409 M) --
-        // profiles/r03_fused_hs_modelA_one_tile_ab.txt
-        const int hs_from = a.K <= 352 ? c->n_cu + c->n_cu / 4 : 2 * c->n_cu;
+        // Where the persistent kernel starts to pay (re-measured in round 4, after its scratch was removed: profiles/r04_fused_hs_threshold.txt):
+        // K <= 352 (Model-A) level with the chunked kernel at ONE tile per compute unit (451 vs 452 M inf/s, the kernel alone 46.4 vs 49.0 us)
+        // and 10-30 % ahead from 1.25 on; K = 880 (Model-B) 5 % behind at one tile (305 vs 320 M), 5 % ahead at 1.25, level at 1.5, 6 % ahead at 2.
+        const int hs_from = a.K <= 352 ? c->n_cu : c->n_cu + c->n_cu / 4;
         const bool only_hs = bf16 && !frk_fused_h_ok(a.K, a.H1, a.H2, a.H3);   // a record the chunked kernel has no instantiation for
         if (c->hk_ok == 1 && (only_hs || (hk != 0 && (hk == 1 || tiles >= hs_from)))) {
             if (!w->h_blist) {

@@ -262,7 +262,7 @@ int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_idx, const f
 int fr_ctx_stream_group(const fr_ctx *ctx);
 /* Throughput/latency knob of the fused streaming path, PER CONTEXT: batches per launch, 1..256 (default 64).  Groups above 64 exist for
  * the bf16 chain: its persistent kernel (fr_fused_tile_hs_kernel: one workgroup per compute unit walks several 64-item tiles, the gather
- * of the next tile under the FC phases of the current one) takes a launch with at least two tiles per compute unit (records of 352 floats or fewer: 1.25) and up to 256 batches
+ * of the next tile under the FC phases of the current one) takes a launch with at least 1.25 tiles per compute unit (records of 352 floats or fewer: one) and up to 256 batches
  * (Model-A's batches of 256 items need a group of 128+ for that; batches of 1024 reach it at the default); every other kernel carries at
  * most 64 batches per launch and a larger group is launched in slices of 64.  64 batches of 256 items = one 64-item
  * workgroup per CU (fp32: fr_fused_tile_m2_kernel, used only for a group of 64 AND a launch of more than 128 such tiles); smaller groups
