@@ -1507,6 +1507,9 @@ def test_submit_sharded_through_rccl_one_rank(fr, O, gpu, prec):
     ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
     ctx.set_fc_precision(P)
     comm = fr.Comm.init_rank(ctx, fr.Comm.unique_id())
+    comm.set_wait_ms(20000)                            # the bound of fr_worker_sync's wait for the step's collectives (default 60 s)
+    with pytest.raises(fr.FleetRecError):
+        comm.set_wait_ms(0)
     rng = np.random.default_rng(31)
     B = 300
     idx = uniform_idx(rng, m.rows(), B)
