@@ -67,9 +67,15 @@ __device__ __forceinline__ void lp_gemm_body(uint4 *glds, const uint4 *__restric
         asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
     };
     // staging: wave-instructions of 64 elements; every wave issues 2 of W's 16 and 2 MU of X's 16 MU per step
-    const unsigned vW = (unsigned)(n0 + (GN == 128 ? 64 * (wave & 1) : 0) + lane) * 16u, vX = (unsigned)(m0 + lane) * 16u;
+    const unsigned vW = (unsigned)(n0 + (GN == 256 ? 64 * (wave & 3) : GN == 128 ? 64 * (wave & 1) : 0) + lane) * 16u, vX = (unsigned)(m0 + lane) * 16u;
     auto issue = [&](int step, int st) {
-        if constexpr (GN == 128) {
+        if constexpr (GN == 256) {   // 256-wide n tile: four wave-instructions per row, wave w takes quarter w % 4 of rows w / 4, w / 4 + 2, ...
+#pragma unroll
+            for (int i = 0; i < GR / 2; i++) {
+                const int row = (wave >> 2) + 2 * i;
+                dma(rsW, As(st, row) + 64 * (wave & 3), vW, (unsigned)(step * GR + row) * (unsigned)N * 16u);
+            }
+        } else if constexpr (GN == 128) {
 #pragma unroll
             for (int i = 0; i < GR / 4; i++) {
                 const int row = (wave >> 1) + 4 * i;  // 8 waves x (GR / 4) = rows 0..GR-1 x 2 halves
@@ -96,7 +102,7 @@ __device__ __forceinline__ void lp_gemm_body(uint4 *glds, const uint4 *__restric
     // S stages in LDS: the loads of steps s + 1 .. s + S - 1 are in flight during the MFMAs of step s.  S = 2 is the round-1 form (one
     // step ahead, vmcnt(0)); the 64 x 128 tile of the narrow layers runs S = 4 with a counted wait -- its steps are only 128 MFMA
     // cycles per wave, far shorter than a load's round trip.
-    constexpr int LPS = (GR / 8) * ((GN == 128 ? 2 : 1) + 2 * MU);      // DMA instructions per wave per step
+    constexpr int LPS = (GR / 8) * ((GN == 256 ? 4 : GN == 128 ? 2 : 1) + 2 * MU);      // DMA instructions per wave per step
     constexpr unsigned WAITN = (unsigned)LPS * (S - 2);    // may stay in flight when step s must have landed
     constexpr int IMM_WAIT = (int)((WAITN & 0xF) | ((WAITN >> 4) << 14) | 0x0F70u);
 #pragma unroll
@@ -987,6 +993,11 @@ static int lp_gemm_mu(int precision, int K, int N, int ldm) {
         if (s128 >= 192 && s128 <= 512) return 4;
         if (s64 >= 128 && s64 <= 512) return 5;
     }
+    // 256 (n) x 256 (m) tiles when THEY cover the chip (batch 8192 of Model-C's FC1: 8 x 32): a third fewer operand bytes per output through
+    // the CU's vector-memory return path, which is what the 128 x 256 kernel keeps busy (texture data return busy 0.73, MFMA busy 0.50:
+    // profiles/r04_pmc_gemm_bf16.json); bf16 / fp8 only (the fp32 kernel is MFMA-bound)
+    const long t256sq = (N % 256 || ldm % 256) ? 0 : (long)(N / 256) * (ldm / 256);
+    if (precision != FR_FC_FP32 && t256sq >= 192 && FR_KNOB_ONCE("LP_GEMM_256", 1)) return 6;
     if (t256 >= 192) return 2;
     if (t128 >= 192) return 1;
     if (t64 >= 128 && small_tile == 3) return 3;
@@ -1024,6 +1035,9 @@ static int splitk_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, 
 
 template <int PREC>
 static int lp_gemm_tile(int mu, const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
+    if constexpr (PREC != 0) {
+        if (mu == 6) return lp_gemm_launch<PREC, 2, 256, FR_GSTAGES>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+    }
     if (mu == 2) return lp_gemm_launch<PREC, 2, 128, FR_GSTAGES>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
 #ifdef FR_EXPERIMENTS
     if constexpr (PREC != 0) {   // ring depth: 4 k-steps of 16 k (bf16) / 2 of 64 k (fp8) = 24 / 48 KiB in flight per wave at 128 x 64

@@ -1975,6 +1975,40 @@ def test_model_c_streaming_gather_inside_fc1(fr, O, ctxs, gpu, prec, per_bank):
             own.close()
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp8"])
+def test_gemm_256_tile_batch_8192(fr, O, ctxs, prec):
+    """From batch 8192 on Model-C's FC1 (3968 x 2048 x 8192) has enough 256 (n) x 256 (m) tiles to cover the chip (8 x 32) and takes
+    fc_lp_gemm_kernel<P, 2, 256, 2>: a third fewer operand bytes per output through the CU's vector-memory path than the 128 x 256 tile
+    (FC1 137 -> 117 us in bf16, 69 -> 59 us in fp8; profiles/r04_experiments.md section 1.6).  The 8192 items against the same rows as two
+    batches of 4096 (the 128 x 256 kernels: same sums over k in the same order per output up to the MFMA's own grouping) and 1024 of them
+    against the fp64-accumulating oracle; the layer's kernel as the library names it."""
+    m, ctx = ctxs(2)
+    om = O.OracleModel(NAMES[2])
+    B = 8192
+    rng = np.random.default_rng(8192)
+    idx = uniform_idx(rng, m.rows(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+    ctx.set_fc_precision({"bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[prec])
+    try:
+        wk = fr.Worker(ctx, B)
+        if prec == "fp8":
+            wk.calibrate_fp8(idx[:4096], dense[:4096])
+        big = wk.infer(idx, dense)
+        wk.fc_layer_only(B, 0)
+        assert wk.last_kernel().startswith("fc_lp_gemm_kernel<%d, 2, 256, 2" % (1 if prec == "bf16" else 2)), wk.last_kernel()
+        wk.sync()
+        halves = np.concatenate([wk.infer(idx[:4096], dense[:4096]), wk.infer(idx[4096:], dense[4096:])])
+        assert rel_err(big, halves) <= {"bf16": 1e-2, "fp8": 4e-2}[prec], rel_err(big, halves)
+        sub = slice(3584, 4608)   # 1024 items across the middle of the batch
+        rec = om.gather(idx[sub], dense=dense[sub], content_mode=O.FILL_HASH, seed=SEED_TABLES).view(np.float32)
+        ref32 = om.fc_chain(rec, [ctx.get_weights(l) for l in range(4)], acc64=True)
+        assert np.abs(big[sub] - ref32).max() <= {"bf16": 3e-2, "fp8": 0.15}[prec] * np.abs(ref32).max()
+        assert np.array_equal(wk.infer(idx, dense), big)
+        wk.close()
+    finally:
+        ctx.set_fc_precision(fr.FC_FP32)
+
+
 def _random_model(fr, rng, width_mult=32):
     """A random user-defined model: random table dims/rows, an optional dense block in the middle of the record, an
     optional COPY pad, random FC widths.  Exercises the descriptor machinery beyond the three reference models."""
