@@ -1305,11 +1305,11 @@ def main():
             rngb = np.random.default_rng(SEED_IDX)
             ih = [uniform_idx(rngb, mb.rows(), 1024) for _ in range(32)]
             di = [fr.DeviceBuffer.from_numpy(cb, a) for a in ih]
-            for prec in ("bf16", "f32"):
-                cb.set_stream_group(bf16_launch_group(1024) if prec == "bf16" else 64)
+            for prec in ("bf16", "f32", "fp8"):
+                cb.set_stream_group(bf16_launch_group(1024) if prec != "f32" else 64)   # (fp8: the chunked kernel, whose launches carry 16 batches of 1024 each: the group only deepens the queue)
                 cfgs.append(leg_config(fr, cb, mb, 1024, prec, di, None, ih[0], None, args.threads, args.depth,
                                        "BASELINE configs[2]: Model-B (embedding_98_krnl, 15.1 GB) batch=1024, %s FC, fused concat + FC chain, per-table indices, %d batches per launch (fr_ctx_set_stream_group)" % (prec, bf16_launch_group(1024))
-                                       if prec == "bf16" else "Model-B batch=1024, f32 FC (the reference's own precision), per-table indices",
+                                       if prec == "bf16" else "Model-B batch=1024, %s FC%s, per-table indices" % (prec, " (the reference's own precision)" if prec == "f32" else " through the chunked fused kernel, launch group %d" % bf16_launch_group(1024)),
                                        pmc_key="fused_h_B1024_bf16" if prec == "bf16" else None, profile_csv=find_profile("B1024_%s_kernel_stats.csv" % prec), tag="B1024_" + prec))
             cb.close()
             # the same configuration under the reference kernel's index contract: one index per bank (49 banks of 2 tables), bank rows in HBM
