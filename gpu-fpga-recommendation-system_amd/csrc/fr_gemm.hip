@@ -914,6 +914,9 @@ bool frk_fc_tail_ok(int precision, int K, int N, int ldm) {
 
 int frk_fc_tail(int precision, const void *W3, const void *R2, const void *wout, float *scores, int K, int N, int ldm, int batch, int e_w, int e_in, int e_r3, hipStream_t s) {
     if (!frk_fc_tail_ok(precision, K, N, ldm)) FR_FAIL(FR_ERR_INVALID, "internal: %d x %d x %d is not a fused-tail layer", K, N, ldm);
+#ifndef FR_EXPERIMENTS
+    FR_FAIL(FR_ERR_INVALID, "internal: fc_tail_kernel is built into the experiments library only");
+#else
     dim3 grid(ldm / 32);
     if (precision == FR_FC_BF16) {
         fc_tail_kernel<1, 16><<<grid, dim3(512), 0, s>>>(reinterpret_cast<const uint4 *>(W3), reinterpret_cast<const uint4 *>(R2), wout, scores, K / 8, N, ldm, batch, 0, 0, 1.0f, 1.0f);
@@ -926,6 +929,7 @@ int frk_fc_tail(int precision, const void *W3, const void *R2, const void *wout,
         fr_note_kernel("fc_tail_kernel<2, 8>");
     }
     return FR_OK;
+#endif
 }
 
 // Pipeline shape (experiment knob FR_GEMM_PIPE = 10 * G + NS; 0 = fc_lp_gemm_kernel): G row groups of 4 element rows per sub-step, NS
@@ -1081,6 +1085,9 @@ bool frk_fc_gemm_gather_ok(int precision, int K, int N, int ldm) {
 int frk_fc_gemm_gather(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, const FrWordDesc *words, int n_words,
                        int idx_stride, const int32_t *idx, const float *dense, int g_batch, int g_ldm, int g_K, void *g_out, int g_e_x, int *err_flag, hipStream_t s) {
     if (!frk_fc_gemm_gather_ok(precision, K, N, ldm)) FR_FAIL(FR_ERR_INVALID, "internal: %d x %d x %d is not a gather + GEMM layer", K, N, ldm);
+#ifndef FR_EXPERIMENTS
+    FR_FAIL(FR_ERR_INVALID, "internal: fc_gemm_gather_kernel is built into the experiments library only");
+#else
     const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : K / 8;
     FrGatherJob g{};
     g.words = words, g.idx = idx, g.dense = dense, g.out = g_out, g.err_flag = err_flag;
@@ -1103,6 +1110,7 @@ int frk_fc_gemm_gather(int precision, const void *Wp, const void *Xp, void *Yp, 
         fr_note_kernel("fc_gemm_gather_kernel<2>");
     }
     return FR_OK;
+#endif
 }
 
 int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, hipStream_t s) {
