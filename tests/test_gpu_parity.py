@@ -2140,13 +2140,13 @@ def test_random_custom_models(fr, O, gpu, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("spec_k", [496, 688, 64, 880])
+@pytest.mark.parametrize("spec_k", [496, 688, 64, 880, 352, 368, 528, 544, 704, 720, 864])
 def test_custom_model_rides_the_persistent_bf16_kernel(fr, O, gpu, spec_k):
     """the persistent bf16 kernel (fr_fused_tile_hs_kernel) is not reserved for the two reference records (352 / 880
     floats): a Model.from_spec model with the reference's FC widths (1024 / 512 / 256) and ANY record of 64 .. 880 floats in whole
     k-groups of 16 takes the narrowest instantiation that holds it (22 / 33 / 44 / 55 k-groups; the k-groups past the record are zeros),
-    and fr_worker_last_kernel says which.  Records of 496 (-> 33 k-groups), 688 (-> 44), 64 (-> 22) and 880 floats (-> 55) with a dense
-    block and a COPY pad; a launch of 40 batches of 1024 items (640 tiles: what selects the kernel); every batch against the host
+    and fr_worker_last_kernel says which.  Records of 64 ... 880 floats on both sides of every instantiation's edge (352 | 368, 528 | 544,
+    704 | 720), with a dense block and a COPY pad; a launch of 40 batches of 1024 items (640 tiles: what selects the kernel); every batch against the host
     restatement of the bf16 arithmetic (5e-3) and, bit for bit, against a small launch of the same rows (the chunked kernel for the 880-float
     record, the persistent kernel with one tile per workgroup for the others)."""
     rng = np.random.default_rng(4000 + spec_k)
@@ -2188,7 +2188,7 @@ def test_custom_model_rides_the_persistent_bf16_kernel(fr, O, gpu, spec_k):
         wk.push_device(B, pool[j][0], pool[j][1], small[j])
     wk.sync()
     # a small launch: the two reference records have a chunked kernel for it; every other record rides the persistent kernel at any size
-    assert wk.last_kernel().startswith("fr_fused_tile_h_kernel<" if spec_k == 880 else "fr_fused_tile_hs_kernel<1, "), wk.last_kernel()
+    assert wk.last_kernel().startswith("fr_fused_tile_h_kernel<" if spec_k in (880, 352) else "fr_fused_tile_hs_kernel<1, "), wk.last_kernel()
     chunked = [b_.download(np.float32, B) for b_ in small]
     sizes = [1024, 1000, 1024, 65, 1024]
     outs = []
@@ -2199,7 +2199,7 @@ def test_custom_model_rides_the_persistent_bf16_kernel(fr, O, gpu, spec_k):
         wk.push_device(b, pool[j][0], pool[j][1], buf)
         outs.append((buf, j, b))
     wk.sync()
-    kg = {496: 33, 688: 44, 64: 22, 880: 55}[spec_k]
+    kg = 22 if spec_k <= 352 else 33 if spec_k <= 528 else 44 if spec_k <= 704 else 55   # the narrowest instantiation that holds the record (both sides of every edge are cases)
     assert wk.last_kernel().startswith("fr_fused_tile_hs_kernel<1, %d," % kg), wk.last_kernel()
     for buf, j, b in outs:
         got = buf.download(np.float32, B)
