@@ -755,7 +755,7 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
     pm = (pmc(pmc_key) or {}) if pmc_key else {}
     res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TF[precision], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TF[precision],
                        "traffic": pm.get("traffic_bytes_per_launch"), "kernel": what, "kernel_name": kname, "avg_launch_ms": ms, "algorithmic_flops_per_launch": flops}
-    if profile_csv:   # the committed rocprofv3 --kernel-trace --stats summary of this leg's own command: must agree with avg_launch_ms
+    if profile_csv and os.path.exists(os.path.join(ROOT, "profiles", profile_csv)):   # the committed rocprofv3 --kernel-trace --stats summary of this leg's own command: must agree with avg_launch_ms
         res["roofline"]["profiled_avg_launch_us"] = profiled_avg_us(profile_csv, kname)
         res["roofline"]["profile"] = "profiles/" + profile_csv
     if pm:

@@ -20,6 +20,8 @@ d = json.loads(txt) if txt.startswith("{\n") or "\n" in txt[:3] else json.loads(
 
 def prof(csv_path, kernel):
     key = kernel.split("(")[0].strip()
+    if not os.path.exists(os.path.join(ROOT, csv_path)):
+        return None, 0
     for r in csv.DictReader(open(os.path.join(ROOT, csv_path))):
         if key in r["Name"]:
             return float(r["AverageNs"]) / 1e3, int(r["Calls"])
