@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
-"""Builds profiles/r03_roofline_pairs.json from one evidence job (tools/jobs/r03_evidence.sh): for every profiled leg, the HIP-event launch
+"""Builds profiles/r04_roofline_pairs.json from one evidence job (tools/jobs/r04_evidence.sh): for every profiled leg, the HIP-event launch
 time the profiled run printed on its own JSON line (stats_<leg>.log) beside the rocprofv3 average of the same kernel in that run's
 kernel-stats CSV (<leg>_kernel_stats.csv) -- the same-run pairs tools/check_evidence.py checks to 3.5 %.
-usage: python tools/make_roofline_pairs.py [gpurun_out/r03_evidence] [profiles/r03_roofline_pairs.json]"""
+usage: python tools/make_roofline_pairs.py [gpurun_out/r04_evidence] [profiles/r04_roofline_pairs.json]"""
 import csv
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r03_evidence")
-dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r03_roofline_pairs.json")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r04_evidence")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r04_roofline_pairs.json")
 
 
 def line_of(leg):
@@ -24,7 +24,7 @@ def roof_of(leg, d):
     if leg == "roofline":
         return d["roofline"]
     if leg.startswith("gather_per_table_zipf"):
-        return d["gather"]["zipf_1.05"]
+        return d["gather"].get("zipf_1.05") or d["gather"]   # (the compact line of a --gather-law zipf run carries the zipf leg as `gather`)
     if leg.startswith("gather_per_table"):
         return d["gather"]
     if leg.startswith("gather_per_bank"):
@@ -33,11 +33,12 @@ def roof_of(leg, d):
 
 
 out = {}
-for leg in ("roofline", "gather_per_table_uniform", "gather_per_table_zipf", "gather_per_bank_uniform", "C4096_f32", "C4096_bf16", "C4096_fp8", "B1024_bf16", "B1024_f32"):
+for leg in ("roofline", "gather_per_table_uniform", "gather_per_bank_uniform", "C4096_f32", "C4096_bf16", "C4096_fp8", "B1024_bf16", "B1024_bf16_per_bank", "B1024_f32",
+            "A256_bf16", "A256_fp8"):
     if not os.path.exists(os.path.join(src, "stats_%s.log" % leg)):
         continue
     rf = roof_of(leg, line_of(leg))
-    key = rf["kernel_name"].split("(")[0].strip()
+    key = rf["kernel_name"].split("(")[0].strip().rstrip(">")   # (a name noted with fewer template arguments than rocprofv3 prints still matches its prefix)
     hit = [r for r in csv.DictReader(open(os.path.join(src, "%s_kernel_stats.csv" % leg))) if key in r["Name"]]
     if not hit:
         raise SystemExit("%s: kernel %s not in the CSV" % (leg, key))
