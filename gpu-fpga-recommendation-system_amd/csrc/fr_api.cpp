@@ -662,6 +662,7 @@ extern "C" void fr_worker_destroy(fr_worker *w) {
     if (!w) return;
     if (w->ctx) (void)hipSetDevice(w->ctx->device);
     if (w->stream) (void)hipStreamSynchronize(w->stream);
+    if (w->counted) w->ctx->n_workers.fetch_sub(1, std::memory_order_relaxed);
     if (w->h_idx) (void)hipHostFree(w->h_idx);
     if (w->h_dense) (void)hipHostFree(w->h_dense);
     if (w->h_score) (void)hipHostFree(w->h_score);
@@ -726,7 +727,19 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
     w->max_batch = max_batch;
     const fr_model_desc &m = ctx->model;
     const size_t B = (size_t)max_batch;
-    W_HIP(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
+    {
+        // A model that runs the stage pipeline (several launches per step: Model-C, sharded contexts) spreads its workers over the stream
+        // priorities: the HIP runtime keeps one pool of hardware queues per priority, and four equal-priority streams share two queues
+        // (profiles/r04_C4096_chain_trace_bf16.txt), where a small launch of one worker waits behind the other's FC1.  Model-C 4096, four
+        // workers: bf16 41.9 -> 43.1 M inf/s, fp8 65.5 -> 68.9 M = what GPU_MAX_HW_QUEUES=8 buys (profiles/r04_stream_priorities_ab.txt).
+        // Fused-kernel models (one launch per group) gain nothing from it and keep one priority.
+        const bool chain = !(ctx->n_shards == 1 && m.layout == FR_LAYOUT_SEMANTIC && frk_fused_ok(m.fc[0], m.fc[1], m.fc[2], m.fc[3]));
+        const int spread = FR_KNOB_ONCE("STREAM_PRIO", -1);   // experiment knob: 0 = never, 1 = always
+        int lo = 0, hi = 0;   // numerically lower = higher priority
+        if (spread < 0 ? chain : spread != 0) W_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        if (lo > hi) W_HIP(hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, hi + ctx->n_workers.load(std::memory_order_relaxed) % (lo - hi + 1)));
+        else W_HIP(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
+    }
     W_HIP(hipHostMalloc((void **)&w->h_idx, B * idx_cols(ctx) * sizeof(int32_t), hipHostMallocDefault));
     if (m.dense_len) W_HIP(hipHostMalloc((void **)&w->h_dense, B * m.dense_len * sizeof(float), hipHostMallocDefault));
     W_HIP(hipHostMalloc((void **)&w->h_score, B * sizeof(float), hipHostMallocDefault));
@@ -748,6 +761,8 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
     W_HIP(hipMalloc((void **)&w->d_score, B * sizeof(float)));
     W_HIP(hipEventCreate(&w->ev_start));
     W_HIP(hipEventCreate(&w->ev_stop));
+    w->counted = true;
+    ctx->n_workers.fetch_add(1, std::memory_order_relaxed);
     *out = w;
     return FR_OK;
 }
@@ -977,7 +992,7 @@ static int pipeline_step(fr_worker *w) {
                 FR_HIP(hipEventRecord(w->ev_x_free[par], w->stream));
                 w->x_free_set[par] = true;
             }
-            int rc = frk_fc_lp_gemm(prec, st.w, st.in, st.out, st.K, st.N, ldm, st.e_w, st.e_in, st.e_out, w->stream);
+            int rc = frk_fc_lp_gemm(prec, st.w, st.in, st.out, st.K, st.N, ldm, st.e_w, st.e_in, st.e_out, c->n_workers.load(std::memory_order_relaxed), w->stream);
             if (rc) return rc;
             if (s == 1 && w->aux && FR_KNOB_ONCE("GATHER_AUX", 0) != 2) {  // X[par ^ 1] may be overwritten by the gather of the NEXT step once this launch has finished
                 FR_HIP(hipEventRecord(w->ev_x_free[par ^ 1], w->stream));

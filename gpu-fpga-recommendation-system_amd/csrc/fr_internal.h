@@ -221,6 +221,7 @@ struct fr_ctx {
     std::atomic<int> small_block{0};
     int n_cu = 0;                          // compute units of the device (grid of the persistent fused kernel); set at creation
     int hk_ok = 0;                         // the persistent K-outer fused kernel applies to this context's descriptors; set at creation
+    std::atomic<int> n_workers{0};         // live workers of the context: W of them -> GEMM layers take tiles that cover 1 / min(W, 4) of the chip (lp_gemm_mu)
 };
 
 struct fr_worker {
@@ -257,6 +258,7 @@ struct fr_worker {
     bool x_ready_set[2] = {false, false}, x_free_set[2] = {false, false};
     uint64_t launch_no = 0;     // number of pipeline launches issued so far
     int n_active = 0;
+    bool counted = false;       // in fr_ctx::n_workers
     bool calibrating = false;   // fr_worker_calibrate_fp8: the pushed batch runs the fp32 stages without K-split partials
     int last_x_parity = 0;      // which activation set holds Xt of the most recently pushed batch (debug hook)
     // fused item-tile path: batches queued by fr_worker_push_device until a launch group is full
@@ -322,7 +324,8 @@ int frk_transpose_slices_lp(int precision, const void *gathered, int n_shards, i
 int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, int precision, hipStream_t s);
 int frk_pack_weights_q8_bf16(const float *W, uint16_t *Wh, int K, int H, hipStream_t s);
 bool frk_fc_lp_gemm_ok(int precision, int K, int N, int ldm);
-int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, hipStream_t s);
+// workers: live workers of the context -> the larger tile already when it covers 1 / min(workers, 4) of the chip (lp_gemm_mu)
+int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, int workers, hipStream_t s);
 bool frk_fc_gemm_gather_ok(int precision, int K, int N, int ldm);   // FC1 of batch L - 1 + the gather of batch L in one launch (fc_gemm_gather_kernel)
 int frk_fc_gemm_gather(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, const FrWordDesc *words, int n_words,
                        int idx_stride, const int32_t *idx, const float *dense, int g_batch, int g_ldm, int g_K, void *g_out, int g_e_x, int *err_flag, hipStream_t s);

@@ -2009,6 +2009,58 @@ def test_gemm_256_tile_batch_8192(fr, O, ctxs, prec):
         ctx.set_fc_precision(fr.FC_FP32)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp8"])
+def test_half_chip_tiles_once_a_second_worker_exists(fr, O, ctxs, prec):
+    """A context with two or more workers gives its GEMM layers the larger tile as soon as it covers HALF the chip (Model-C batch 4096: FC1
+    8 x 16 tiles of 256 x 256 instead of 256 of 128 x 256, FC2 4 x 32 of 128 x 128 instead of 256 of 64 x 128): the workers' streams run
+    their chains in step on two hardware queues, so two half-chip launches of the cheaper tile run side by side (bf16 38.4 -> 41.9 M inf/s,
+    fp8 62.6 -> 66.4 M; profiles/r04_C4096_half_chip_tiles_ab.txt).  The rule follows the LIVE worker count; scores agree with the full-chip
+    kernels' (fp8 bit for bit) and with the fp64-accumulating oracle."""
+    m, ctx = ctxs(2)
+    om = O.OracleModel(NAMES[2])
+    B = 4096
+    P = 1 if prec == "bf16" else 2
+    rng = np.random.default_rng(4096 + P)
+    idx = uniform_idx(rng, m.rows(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+    ctx.set_fc_precision({"bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[prec])
+    try:
+        wk = fr.Worker(ctx, B)
+        if prec == "fp8":
+            wk.calibrate_fp8(idx, dense)
+
+        def layer_kernels():
+            names = []
+            for layer in (0, 1):
+                wk.fc_layer_only(B, layer)
+                names.append(wk.last_kernel())
+                wk.sync()
+            return names
+
+        alone = wk.infer(idx, dense)
+        k_alone = layer_kernels()
+        assert "256, 2" not in k_alone[0] and k_alone[1].startswith("fc_lp_gemm_kernel<%d, 1, 64" % P), k_alone
+        other = fr.Worker(ctx, B)
+        paired = wk.infer(idx, dense)
+        k_paired = layer_kernels()
+        assert k_paired[0].startswith("fc_lp_gemm_kernel<%d, 2, 256, 2" % P) and k_paired[1].startswith("fc_lp_gemm_kernel<%d, 1, 128" % P), k_paired
+        assert np.array_equal(other.infer(idx, dense), paired)
+        if prec == "fp8":
+            assert np.array_equal(paired, alone)
+        else:
+            assert rel_err(paired, alone) <= 1e-2, rel_err(paired, alone)
+        sub = slice(1536, 2560)
+        rec = om.gather(idx[sub], dense=dense[sub], content_mode=O.FILL_HASH, seed=SEED_TABLES).view(np.float32)
+        ref32 = om.fc_chain(rec, [ctx.get_weights(l) for l in range(4)], acc64=True)
+        assert np.abs(paired[sub] - ref32).max() <= {"bf16": 3e-2, "fp8": 0.15}[prec] * np.abs(ref32).max()
+        other.close()
+        assert layer_kernels() == k_alone
+        assert np.array_equal(wk.infer(idx, dense), alone)
+        wk.close()
+    finally:
+        ctx.set_fc_precision(fr.FC_FP32)
+
+
 def _random_model(fr, rng, width_mult=32):
     """A random user-defined model: random table dims/rows, an optional dense block in the middle of the record, an
     optional COPY pad, random FC widths.  Exercises the descriptor machinery beyond the three reference models."""
