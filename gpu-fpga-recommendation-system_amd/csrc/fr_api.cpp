@@ -728,16 +728,21 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
     const fr_model_desc &m = ctx->model;
     const size_t B = (size_t)max_batch;
     {
-        // A model that runs the stage pipeline (several launches per step: Model-C, sharded contexts) spreads its workers over the stream
-        // priorities: the HIP runtime keeps one pool of hardware queues per priority, and four equal-priority streams share two queues
-        // (profiles/r04_C4096_chain_trace_bf16.txt), where a small launch of one worker waits behind the other's FC1.  Model-C 4096, four
-        // workers: bf16 41.9 -> 43.1 M inf/s, fp8 65.5 -> 68.9 M = what GPU_MAX_HW_QUEUES=8 buys (profiles/r04_stream_priorities_ab.txt).
-        // Fused-kernel models (one launch per group) gain nothing from it and keep one priority.
+        // A model that runs the stage pipeline (several launches per step: Model-C, sharded contexts) gives its workers hardware queues of
+        // their own: the HIP runtime keeps one pool of hardware queues per stream priority, four equal-priority streams share two queues
+        // (profiles/r04_C4096_chain_trace_bf16.txt), and there a small launch of one worker waits behind the other's FC1.  The workers
+        // alternate between the HIGHEST and the LOWEST priority, never the default one: those two pools are this library's alone, so the
+        // first four workers get four consecutively created queues = one per compute pipe of the command processor (queue id mod 4;
+        // two workers whose queues share a pipe run 10 % behind the others: profiles/r04_stream_queues_after_other_contexts.txt -- with
+        // the default priority in the rotation, a context served earlier in the process had that effect).  Model-C 4096, four workers:
+        // bf16 41.9 -> 43.1 M inf/s, fp8 65.5 -> 68.9 M = what GPU_MAX_HW_QUEUES=8 buys (profiles/r04_stream_priorities_ab.txt).
+        // Fused-kernel models (one launch per group) gain nothing from it and keep the default streams.
         const bool chain = !(ctx->n_shards == 1 && m.layout == FR_LAYOUT_SEMANTIC && frk_fused_ok(m.fc[0], m.fc[1], m.fc[2], m.fc[3]));
-        const int spread = FR_KNOB_ONCE("STREAM_PRIO", -1);   // experiment knob: 0 = never, 1 = always
+        const int spread = FR_KNOB_ONCE("STREAM_PRIO", -1);   // experiment knob: 0 = never, 1 = always, 2 = rotate over every level (default included)
         int lo = 0, hi = 0;   // numerically lower = higher priority
         if (spread < 0 ? chain : spread != 0) W_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        if (lo > hi) W_HIP(hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, hi + ctx->n_workers.load(std::memory_order_relaxed) % (lo - hi + 1)));
+        const int k = ctx->n_workers.load(std::memory_order_relaxed);
+        if (lo > hi) W_HIP(hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, spread == 2 ? hi + k % (lo - hi + 1) : (k % 2 ? lo : hi)));
         else W_HIP(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
     }
     W_HIP(hipHostMalloc((void **)&w->h_idx, B * idx_cols(ctx) * sizeof(int32_t), hipHostMallocDefault));

@@ -85,6 +85,9 @@ extern "C" int fr_driver_run_resident(fr_driver *d, int batch, int64_t total_bat
             float **rings = &d->score_rings[(size_t)t * d->depth];
             int64_t local = 0;
             int rc = FR_OK;
+#ifdef FR_EXPERIMENTS
+            double t_push = 0.0, t_sync = 0.0, t_push_max = 0.0;
+#endif
             while (rc == FR_OK) {
                 int64_t id;
                 {
@@ -97,12 +100,28 @@ extern "C" int fr_driver_run_resident(fr_driver *d, int batch, int64_t total_bat
                 float *scores = rings[slot] + (size_t)((local / d->depth) % FR_SCORE_RING) * d->max_batch;
                 local++;
                 const int p = (int)(id % n_pool);
+#ifdef FR_EXPERIMENTS
+                const auto tp0 = std::chrono::steady_clock::now();
+#endif
                 rc = fr_worker_push_device(wk[slot], batch, d_idx_pool[p], d_dense_pool ? d_dense_pool[p] : nullptr, scores);
+#ifdef FR_EXPERIMENTS
+                const auto tp1 = std::chrono::steady_clock::now();
+                t_push += std::chrono::duration<double>(tp1 - tp0).count();
+                const double dt = std::chrono::duration<double>(tp1 - tp0).count();
+                if (dt > t_push_max) t_push_max = dt;
+#endif
                 // bound the host's run-ahead (and keep score buffers unique): a worker is synchronised once per trip round its
                 // ring, the workers of a thread at staggered points so that one of them always has launches queued
                 const int64_t mine = (local - 1) / d->depth + 1;  // pushes this worker has received
                 if (rc == FR_OK && (mine + (int64_t)slot * (FR_SCORE_RING / d->depth)) % FR_SCORE_RING == 0) rc = fr_worker_sync(wk[slot]);
+#ifdef FR_EXPERIMENTS
+                t_sync += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp1).count();
+#endif
             }
+#ifdef FR_EXPERIMENTS
+            if (FR_KNOB_ONCE("DRIVER_TIMING", 0))
+                fprintf(stderr, "driver thread %d: %lld pushes, in push %.3f s (max %.1f us), in sync %.3f s\n", t, (long long)local, t_push, 1e6 * t_push_max, t_sync);
+#endif
             for (int s = 0; s < d->depth; s++) {
                 int r2 = fr_worker_sync(wk[s]);
                 if (rc == FR_OK) rc = r2;

@@ -7,7 +7,9 @@
 #   gather_C4096_per_table_zipf      bench.py --legs gather --gather-law zipf      gather_pack_xcd_kernel
 #   gather_C4096_per_bank_uniform    bench.py --legs bank                          gather_pack_xcd_kernel
 #   fused_h_B1024_bf16               bench.py --roofline-only --model B --batch 1024 --precision bf16    fr_fused_tile_hs_kernel (round 3; fr_fused_tile_h_kernel before)
-#   gemm_C4096_{f32,bf16,fp8}        bench.py --roofline-only --model C --batch 4096 --precision P       the FC1 GEMM kernel of that precision
+#   gemm_C4096_{f32,bf16,fp8}        bench.py --roofline-only --model C --batch 4096 --precision P       the FC1 GEMM kernel of that precision (bf16 / fp8: the
+#                                    256 x 256-tile kernel the four workers run side by side; counter passes serialise the launches, so
+#                                    bytes per launch are the figure to read -- busy fractions are of a launch alone on half the chip)
 # Run on the GPU box from the repo root:  bash tools/pmc_passes.sh [key ...]   -> gpurun_out/pmc/<key>/<pass>/ + gpurun_out/pmc/<PMC_NAME: r04_pmc.json>
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -23,8 +25,8 @@ for key in $KEYS; do
     gather_C4096_per_bank_uniform) ARGS="--legs bank"; KERNEL="gather_pack"; EXTRA=();;
     fused_h_B1024_bf16) ARGS="--roofline-only --model B --batch 1024 --precision bf16"; KERNEL="fr_fused_tile_h"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
     gemm_C4096_f32) ARGS="--roofline-only --model C --batch 4096 --precision f32"; KERNEL="fc_lp_gemm_kernel<0, 2"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
-    gemm_C4096_bf16) ARGS="--roofline-only --model C --batch 4096 --precision bf16"; KERNEL="fc_gemm_pipe_kernel"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
-    gemm_C4096_fp8) ARGS="--roofline-only --model C --batch 4096 --precision fp8"; KERNEL="fc_lp_gemm_kernel<2, 2"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
+    gemm_C4096_bf16) ARGS="--roofline-only --model C --batch 4096 --precision bf16"; KERNEL="fc_lp_gemm_kernel<1, 2, 256"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
+    gemm_C4096_fp8) ARGS="--roofline-only --model C --batch 4096 --precision fp8"; KERNEL="fc_lp_gemm_kernel<2, 2, 256"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
     *) echo "unknown key $key"; exit 1;;
   esac
   mkdir -p $OUT/$key
