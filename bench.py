@@ -25,6 +25,7 @@ import ctypes
 import glob
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -685,6 +686,18 @@ def leg_group_table(fr, ctx, model, B, d_idx, threads, depth):
     return out
 
 
+def gemm_workgroups(kname, N, ldm):
+    """Workgroups of one launch of a GEMM-layer kernel, from the name the library reports (fr_worker_last_kernel): fc_lp_gemm_kernel<P, MU, GN, ...>
+    has GN (n) x 128 MU (m) tiles, fc_gemm_pipe_kernel 128 x 256; None for any other kernel (stage bodies: one launch fills the chip)."""
+    m_ = re.match(r"fc_lp_gemm_kernel<\d+, (\d+), (\d+)", kname or "")
+    if m_:
+        mu, gn = int(m_.group(1)), int(m_.group(2))
+        return max(1, (N // gn) * (ldm // (128 * mu)))
+    if (kname or "").startswith("fc_gemm_pipe_kernel"):
+        return max(1, (N // 128) * (ldm // 256))
+    return None
+
+
 def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_host0, threads, depth, label, min_s=1.0, pmc_key=None, env=None, profile_csv=None, tag=None):
     """One non-headline BASELINE configuration: steady-state throughput (>= 1 s) + an in-run roofline object for its dominant
     kernel from HIP events on one worker's stream."""
@@ -730,9 +743,10 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
         for b_ in ring:
             b_.free()
     else:           # stage pipeline: FC1 runs as its own LDS-tiled GEMM launch (fc_lp_gemm_kernel) -- the dominant kernel
-        # measured the way the timed region runs it: threads x depth workers launch the layer side by side, each on its own stream.  (With
-        # W workers on the context the bf16 / fp8 layers take tiles that cover 1 / min(W, 4) of the chip; a launch's duration is what HIP
-        # events on ITS stream see, and the chip's rate is W launches' FLOPs over that duration.)
+        # measured with the context in the timed region's state -- threads x depth live workers: with W of them the bf16 / fp8 layers take tiles
+        # that cover 1 / min(W, 4) of the chip -- and as many of those workers launching the layer side by side as FIT on the chip together
+        # (256 compute units / workgroups per launch): every launch then runs from the moment it is dequeued, so the HIP-event time per
+        # launch on its stream is the kernel duration rocprofv3 averages, and the chip's rate is `fit` launches' FLOPs over it.
         d_sc = fr.DeviceBuffer(ctx, B * 4)
         wk.submit_device(B, d_idx[0], d_dense[0] if d_dense else None, d_sc)
         wk.sync()
@@ -743,19 +757,23 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
         layer_ms, layer_kernels, layer_conc, layer_spread = [], [], [], []
         reps = 60
         for layer in range(4):
-            for _ in range(10):
-                for v in side:
-                    v.fc_layer_only(B, layer)
+            wk.fc_layer_only(B, layer)
             layer_kernels.append(wk.last_kernel())
-            for v in side:
+            wk.sync()
+            wgs = gemm_workgroups(layer_kernels[-1], fc[layer + 1] if layer < 3 else 1, B)
+            act = side[:max(1, min(len(side), 256 // wgs))] if wgs else side[:1]
+            for _ in range(10):
+                for v in act:
+                    v.fc_layer_only(B, layer)
+            for v in act:
                 v.sync()
-            for v in side:
+            for v in act:
                 v.timer_start()
             for _ in range(reps):
-                for v in side:
+                for v in act:
                     v.fc_layer_only(B, layer)
-            stops = [None] * len(side)   # every stream's stop event is recorded NOW (a thread per worker: the call records, then waits)
-            th = [threading.Thread(target=lambda i=i, v=v: stops.__setitem__(i, v.timer_stop_ms())) for i, v in enumerate(side)]
+            stops = [None] * len(act)   # every stream's stop event is recorded NOW (a thread per worker: the call records, then waits)
+            th = [threading.Thread(target=lambda i=i, v=v: stops.__setitem__(i, v.timer_stop_ms())) for i, v in enumerate(act)]
             for t_ in th:
                 t_.start()
             for t_ in th:
@@ -768,9 +786,9 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
         ms = layer_ms[0]
         flops = 2 * fc[0] * fc[1] * B
         kname = layer_kernels[0]
-        what = ("%s (FC1: %d x %d x %d), %d workers' launches side by side as in the timed region: avg_launch_ms = mean duration of a launch on its "
-                "stream, concurrent_launches = the streams' busy time over the wall time, achieved = concurrent_launches x FLOPs per launch / "
-                "avg_launch_ms = all FLOPs over the wall time" % (kname, fc[0], fc[1], B, len(side)))
+        what = ("%s (FC1: %d x %d x %d): the tile %d live workers give it, as many launches side by side as fit on the chip; avg_launch_ms = mean "
+                "launch duration on its stream, concurrent_launches = the streams' busy time over the wall time, achieved = concurrent_launches x "
+                "FLOPs per launch / avg_launch_ms = all FLOPs over the wall time" % (kname, fc[0], fc[1], B, len(side)))
         res["layer_launch_ms"] = layer_ms
         res["layer_kernels"] = layer_kernels
         res["concurrent_launches"] = layer_conc[0]

@@ -218,6 +218,11 @@ int fr_ctx_get_fp8_exponents(const fr_ctx *ctx, int act_exp[4], int w_exp[3]);
 int fr_ctx_set_fp8_act_exponents(fr_ctx *ctx, const int act_exp[4]);
 
 /* ---- worker: replaces thread_consume()'s set-up (cuda_server.c:110-354) --------------------- */
+/* One worker = one stream + its buffers (the reference's per-thread cudaStream_t, pinned and device buffers).  Workers of one context
+ * share the chip: a model that runs as a chain of launches per batch (Model-C; any sharded context) gets each worker a hardware queue of
+ * its own (streams created alternately on the highest and the lowest stream priority), and with W live workers its bf16 / fp8 GEMM layers
+ * use tiles that cover 1 / min(W, 4) of the chip, so create the workers a context will use BEFORE timing anything on it.  Scores do not
+ * depend on W beyond the precision's tolerance (fp8: bit-identical; bf16: <= 1e-2 relative between tile shapes). */
 int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out);
 void fr_worker_destroy(fr_worker *w);
 /* Pinned host staging buffers the driver's socket read() lands in directly (cuda_server.c:437 reads

@@ -9,7 +9,7 @@ for prec in bf16 fp8 f32; do
 import json,csv
 d=[json.loads(l) for l in open("$O/$prec.log") if l.startswith('{"metric"')][-1]
 rf=d["roofline"]; print("$prec", rf["kernel_name"], "events %.1f us" % (1e3*rf["avg_launch_ms"]), "conc", rf.get("concurrent_launches"), "frac %.3f" % rf["frac"])
-det=json.load(open("$R/gpurun_out/bench_detail.json")); print("  layers", det.get("layer_kernels"), [round(1e3*x,1) for x in det.get("layer_launch_ms",[])])
+print("  layers", d.get("layer_kernels"), [round(1e3*x,1) for x in d.get("layer_launch_ms",[])], [round(x,2) for x in d.get("layer_concurrency",[])])
 for r in csv.DictReader(open("$O/${prec}_kernel_stats.csv")):
     if "gemm" in r["Name"]: print("  prof %-50s calls %5s avg %.1f us" % (r["Name"][:50], r["Calls"], float(r["AverageNs"])/1e3))
 PY
