@@ -19,7 +19,9 @@ constexpr int FR_GN = 128, FR_GR = 8, FR_GSTAGES = 2;
 // flight during the MFMAs of step s, and a 32 KiB stage-pipeline workgroup of another stream still fits beside the workgroup.
 // (Three steps, 144 KiB, were 10 % faster alone and slower overall: profiles/r01_experiments.md.)
 
-template <int PREC, int MU, int GN, int S, int GR>
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int PREC, int MU, int GN, int S, int GR, int MF = 32>
 __device__ __forceinline__ void lp_gemm_body(uint4 *glds, const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
                                              int N, int ldm, int sc_a, int sc_b, float oscale) {
     typedef __attribute__((address_space(3))) void *lds_ptr;
@@ -91,13 +93,24 @@ __device__ __forceinline__ void lp_gemm_body(uint4 *glds, const uint4 *__restric
             for (int i = 0; i < 2 * MU; i++)  // rows wave, wave + 8, ...; GM / 64 parts each
                 dma(rsX, Bs(st, wave + 8 * rr) + 64 * i, vX + 64u * 16u * i, (unsigned)(step * GR + wave + 8 * rr) * (unsigned)ldm * 16u);
     };
+    // MF = 16 (bf16 only): v_mfma_f32_16x16x32_bf16 on 16 x 16 output tiles -- same LDS bytes and MFMA cycles per FLOP as the 32x32x16 form, but
+    // the chip holds a higher clock on it under load (see fc_gemm_pipe_kernel); the accumulators are the same registers seen as 4 x 4 tiles
+    static_assert(MF == 32 || (MF == 16 && PREC == 1 && GR % 4 == 0), "16 x 16 MFMA tiles: bf16 only");
     f32x16 acc[TN][MU];
+    f32x4_t acc16[MF == 16 ? 2 * TN : 1][MF == 16 ? 2 * MU : 1];
+    if constexpr (MF == 16) {
 #pragma unroll
-    for (int t = 0; t < TN; t++)
+        for (int t = 0; t < 2 * TN; t++)
 #pragma unroll
-        for (int u = 0; u < MU; u++)
+            for (int u = 0; u < 2 * MU; u++) acc16[t][u] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    } else {
 #pragma unroll
-            for (int i = 0; i < 16; i++) acc[t][u][i] = 0.0f;
+        for (int t = 0; t < TN; t++)
+#pragma unroll
+            for (int u = 0; u < MU; u++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[t][u][i] = 0.0f;
+    }
     const int nsteps = KE / GR;
     // S stages in LDS: the loads of steps s + 1 .. s + S - 1 are in flight during the MFMAs of step s.  S = 2 is the round-1 form (one
     // step ahead, vmcnt(0)); the 64 x 128 tile of the narrow layers runs S = 4 with a counted wait -- its steps are only 128 MFMA
@@ -135,6 +148,21 @@ __device__ __forceinline__ void lp_gemm_body(uint4 *glds, const uint4 *__restric
                             const uint32_t bv = c == 0 ? b[u].x : c == 1 ? b[u].y : c == 2 ? b[u].z : b[u].w;
                             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av), __uint_as_float(bv), acc[t][u], 0, 0, 0);
                         }
+            }
+        } else if constexpr (PREC == 1 && MF == 16) {
+#pragma unroll
+            for (int kk = 0; kk < GR / 4; kk++) {   // 32 k: lane (g, j) = k group g = lane / 16 of the four, row j = lane % 16 of its tile
+                const uint4 *ar = As(st, 4 * kk + (lane >> 4)) + wn * 32 * TN + (lane & 15), *br = Bs(st, 4 * kk + (lane >> 4)) + wm * 32 * MU + (lane & 15);
+                uint4 a[2 * TN], b[2 * MU];
+#pragma unroll
+                for (int t = 0; t < 2 * TN; t++) a[t] = ar[16 * t];
+#pragma unroll
+                for (int u = 0; u < 2 * MU; u++) b[u] = br[16 * u];
+#pragma unroll
+                for (int u = 0; u < 2 * MU; u++)
+#pragma unroll
+                    for (int t = 0; t < 2 * TN; t++)
+                        acc16[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[t]), __builtin_bit_cast(bf16x8, b[u]), acc16[t][u], 0, 0, 0);
             }
         } else if constexpr (PREC == 1) {
 #pragma unroll
@@ -175,6 +203,21 @@ __device__ __forceinline__ void lp_gemm_body(uint4 *glds, const uint4 *__restric
         }
     }
     // epilogue: ONE rounding per output; registers 4i..4i+3 of a tile are 4 consecutive n
+    if constexpr (MF == 16) {   // 16 x 16 tiles: lane holds m = lane % 16 and n = 4 (lane / 16) + c
+#pragma unroll
+        for (int t = 0; t < 2 * TN; t++)
+#pragma unroll
+            for (int u = 0; u < 2 * MU; u++) {
+                const f32x4_t &c = acc16[t][u];
+                const int m = m0 + wm * 32 * MU + 16 * u + (lane & 15);
+                const int n = n0 + wn * 32 * TN + 16 * t + 4 * (lane >> 4);
+                uint2 hv;
+                hv.x = pack_bf16x2(c[0], c[1]);
+                hv.y = pack_bf16x2(c[2], c[3]);
+                reinterpret_cast<uint2 *>(Y)[((size_t)(n >> 3) * ldm + m) * 2 + ((n & 7) >> 2)] = hv;
+            }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TN; t++)
 #pragma unroll
@@ -199,11 +242,11 @@ __device__ __forceinline__ void lp_gemm_body(uint4 *glds, const uint4 *__restric
         }
 }
 
-template <int PREC, int MU, int GN, int S, int GR = FR_GR>
+template <int PREC, int MU, int GN, int S, int GR = FR_GR, int MF = 32>
 __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
                                                          int N, int ldm, int sc_a, int sc_b, float oscale) {
     extern __shared__ uint4 glds[];
-    lp_gemm_body<PREC, MU, GN, S, GR>(glds, W, X, Y, KE, N, ldm, sc_a, sc_b, oscale);
+    lp_gemm_body<PREC, MU, GN, S, GR, MF>(glds, W, X, Y, KE, N, ldm, sc_a, sc_b, oscale);
 }
 
 // ===================================================================================================
@@ -388,7 +431,6 @@ __global__ void __launch_bounds__(768) fc_gemm_gather_kernel(const uint4 *__rest
 // summation inside one instruction (16x16x32 vs 32x32x16 group k differently) -- same tolerance class, tested against the oracle.
 // ===================================================================================================
 constexpr int FR_PR = 4;  // element rows per row group; a sub-step is G groups
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <int PREC>
 struct FrPipeFrag {  // one row group's operands of one wave: bf16: 4 + 4 fragments of 16 rows x 32 k; fp8: 2 + 2 fragments of 32 rows x 64 k (two elements each)
@@ -1020,15 +1062,15 @@ static int lp_gemm_mu(int precision, int K, int N, int ldm, int workers = 1) {
 
 bool frk_fc_lp_gemm_ok(int precision, int K, int N, int ldm) { return lp_gemm_mu(precision, K, N, ldm) != 0; }
 
-template <int PREC, int MU, int GN, int S, int GR = FR_GR>
+template <int PREC, int MU, int GN, int S, int GR = FR_GR, int MF = 32>
 static int lp_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
     static FrLdsAttrOnce lds_once;  // per instantiation, per device
     const size_t lds = (size_t)S * GR * (GN + 128 * MU) * 16;
-    if (int rc_ = fr_allow_full_lds(&fc_lp_gemm_kernel<PREC, MU, GN, S, GR>, lds_once)) return rc_;
+    if (int rc_ = fr_allow_full_lds(&fc_lp_gemm_kernel<PREC, MU, GN, S, GR, MF>, lds_once)) return rc_;
     dim3 grid((N / GN) * (ldm / (128 * MU)));
-    fc_lp_gemm_kernel<PREC, MU, GN, S, GR><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale);
+    fc_lp_gemm_kernel<PREC, MU, GN, S, GR, MF><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale);
     KCHECK();
-    fr_note_kernel("fc_lp_gemm_kernel<%d, %d, %d, %d, %d>", PREC, MU, GN, S, GR);   // as rocprofv3 prints it
+    fr_note_kernel("fc_lp_gemm_kernel<%d, %d, %d, %d, %d, %d>", PREC, MU, GN, S, GR, MF);   // as rocprofv3 prints it
     return FR_OK;
 }
 
@@ -1049,6 +1091,9 @@ static int splitk_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, 
 template <int PREC>
 static int lp_gemm_tile(int mu, const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
     if constexpr (PREC != 0) {
+        if constexpr (PREC == 1) {
+            if (mu == 6 && FR_KNOB_ONCE("LP_GEMM_MF16", 1)) return lp_gemm_launch<1, 2, 256, FR_GSTAGES, FR_GR, 16>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+        }
         if (mu == 6) return lp_gemm_launch<PREC, 2, 256, FR_GSTAGES>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
     }
     if (mu == 2) return lp_gemm_launch<PREC, 2, 128, FR_GSTAGES>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
