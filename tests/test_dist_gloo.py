@@ -179,6 +179,20 @@ def _the_line(out):
     return j
 
 
+def test_gemm_workgroups_from_the_kernel_name():
+    """bench.py sizes the side-by-side roofline measurement of a stage-pipeline row from the kernel name the library reports: workgroups per
+    launch -> how many launches fit on the chip's 256 compute units together."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_wg_test", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.gemm_workgroups("fc_lp_gemm_kernel<1, 2, 256, 2, 8, 16>", 2048, 4096) == 128      # Model-C FC1, 256 x 256 tiles: two launches fit
+    assert b.gemm_workgroups("fc_lp_gemm_kernel<0, 2, 128, 2, 8, 32>", 2048, 4096) == 256      # fp32, 128 x 256 tiles: the chip
+    assert b.gemm_workgroups("fc_gemm_pipe_kernel<1, 5, 1>", 512, 4096) == 64                   # FC2 on 128 x 256 tiles
+    assert b.gemm_workgroups("fc_lp_gemm_kernel<2, 1, 128, 2, 8, 32>", 256, 4096) == 64         # FC3 on 128 x 128 tiles
+    assert b.gemm_workgroups("fr_pipeline_kernel<4, 1>", 1, 4096) is None and b.gemm_workgroups(None, 1, 1) is None
+
+
 def test_compact_line_of_a_full_result_stays_under_4k():
     """The writer of the stdout line, fed the 21.7 KB result of round 3's driver command (the one the driver could not parse): the line it
     makes of it is < 4 KB, carries `roofline` (bound / achieved / peak / unit / frac / traffic) and `cpu_baseline` (value / unit / cores /
