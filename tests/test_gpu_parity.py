@@ -2061,6 +2061,50 @@ def test_half_chip_tiles_once_a_second_worker_exists(fr, O, ctxs, prec):
         ctx.set_fc_precision(fr.FC_FP32)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp8"])
+def test_scores_do_not_depend_on_how_many_workers_live(fr, ctxs, prec):
+    """The GEMM layers' tile follows the LIVE worker count of the context (1 / min(W, 4) of the chip), so a batch may meet another kernel
+    whenever a worker has been created or closed since the last one.  Workers come and go at random (1 .. 5 alive), batches of every size
+    class (ragged, 1024, 2048, 4096) go to a random one: fp8 scores are bit-identical to a lone worker's, bf16 within 1e-2 of them."""
+    m, ctx = ctxs(2)
+    rng = np.random.default_rng(77)
+    sizes = [4096, 2048, 1024, 1000, 4032, 256]
+    data = {}
+    ctx.set_fc_precision({"bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[prec])
+    try:
+        lone = fr.Worker(ctx, 4096)
+        if prec == "fp8":
+            lone.calibrate_fp8(uniform_idx(rng, m.rows(), 4096), rng.uniform(-1, 1, (4096, m.dense_len)).astype(np.float32))
+        for b in sizes:
+            idx = uniform_idx(rng, m.rows(), b)
+            dense = rng.uniform(-1, 1, (b, m.dense_len)).astype(np.float32)
+            data[b] = (idx, dense, lone.infer(idx, dense))
+        live = [lone]
+        seen = set()
+        for step in range(40):
+            want = int(rng.integers(1, 6))
+            while len(live) < want:
+                live.append(fr.Worker(ctx, 4096))
+            while len(live) > want:
+                live.pop(int(rng.integers(0, len(live)))).close()
+            wk = live[int(rng.integers(0, len(live)))]
+            b = sizes[int(rng.integers(0, len(sizes)))]
+            idx, dense, ref = data[b]
+            got = wk.infer(idx, dense)
+            wk.fc_layer_only(b, 0)
+            seen.add((min(len(live), 4), b, wk.last_kernel()))
+            wk.sync()
+            if prec == "fp8":
+                assert np.array_equal(got, ref), (step, len(live), b, wk.last_kernel())
+            else:
+                assert rel_err(got, ref) <= 1e-2, (step, len(live), b, rel_err(got, ref), wk.last_kernel())
+        assert len({k for _, b, k in seen if b == 4096}) >= 2, seen   # batch 4096 met at least two FC1 kernels
+        for w in live:
+            w.close()
+    finally:
+        ctx.set_fc_precision(fr.FC_FP32)
+
+
 def _random_model(fr, rng, width_mult=32):
     """A random user-defined model: random table dims/rows, an optional dense block in the middle of the record, an
     optional COPY pad, random FC widths.  Exercises the descriptor machinery beyond the three reference models."""
