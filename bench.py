@@ -331,25 +331,33 @@ def time_launches(wk, push, per_launch, launches, warm_launches=4, push_launch=N
     one launch).  -> average launch duration in ms.  With push_launch (launch_pusher below) a launch's batches are pushed by ONE
     native call: a Python push costs ~0.7 us, which is a batch's whole share of a launch for the small-batch low-precision rows
     (Model-A fp8: 64 pushes per 35 us kernel) -- the stream, not the interpreter, must set the pace of a roofline figure."""
+    # the launches are timed in blocks and the MEDIAN block counts: one disturbed stretch (another process's burst on the host, a clock
+    # step) must not set a roofline figure (seen once: 440 us for a 375 us kernel whose throughput leg in the same run was normal)
+    blocks = 5 if launches >= 50 else 1
+    per_block = launches // blocks
     if push_launch is not None:
         for l in range(warm_launches):
             push_launch(l)
         wk.sync()
-        wk.timer_start()
-        for l in range(launches):
-            push_launch(l)
-        ms = wk.timer_stop_ms() / launches
+        ms = []
+        for b_ in range(blocks):
+            wk.timer_start()
+            for l in range(per_block):
+                push_launch(b_ * per_block + l)
+            ms.append(wk.timer_stop_ms() / per_block)
         wk.sync()
-        return ms
+        return float(np.median(ms))
     for i in range(warm_launches * per_launch):
         push(i)
     wk.sync()
-    wk.timer_start()
-    for i in range(launches * per_launch):
-        push(i)
-    ms = wk.timer_stop_ms() / launches
+    ms = []
+    for b_ in range(blocks):
+        wk.timer_start()
+        for i in range(per_block * per_launch):
+            push(b_ * per_block * per_launch + i)
+        ms.append(wk.timer_stop_ms() / per_block)
     wk.sync()
-    return ms
+    return float(np.median(ms))
 
 
 def launch_pusher(wk, B, d_idx, d_dense, ring, per_launch, n_lists=8):
@@ -827,10 +835,13 @@ def leg_gather(fr, ctx, model, B, law, reps=200, nbuf=32, seed=SEED_IDX, variant
     for i in range(20):
         wk.gather_only(B, idxs[i % nbuf], dns[i % nbuf] if dns else None, rec)
     wk.sync()
-    wk.timer_start()
-    for i in range(reps):
-        wk.gather_only(B, idxs[i % nbuf], dns[i % nbuf] if dns else None, rec)
-    ms = wk.timer_stop_ms() / reps
+    blk = []   # five blocks, the median counts (see time_launches)
+    for b_ in range(5):
+        wk.timer_start()
+        for i in range(reps // 5):
+            wk.gather_only(B, idxs[(b_ * (reps // 5) + i) % nbuf], dns[(b_ * (reps // 5) + i) % nbuf] if dns else None, rec)
+        blk.append(wk.timer_stop_ms() / (reps // 5))
+    ms = float(np.median(blk))
     wk.sync()
     kernel_name = wk.last_kernel()   # what fr_worker_gather_only launched (fr_worker_last_kernel)
     ab = None
