@@ -1450,12 +1450,12 @@ def test_table_sharded_mode_single_device_emulation(fr, O, gpu, which, G):
 
 
 def test_table_sharded_full_size_g8(fr, O, gpu):
-    """BASELINE configs[3] at FULL table size: Model-C's eight table-ID shards (63.2 GB together) side by side on one GPU, batch
-    1024, uniform indices over every table's whole row range.  Every shard's slice bit-exact against the oracle; every item's
+    """BASELINE configs[3] at FULL table size AND full batch: Model-C's eight table-ID shards (63.2 GB together) side by side on one GPU,
+    batch 4096 (the configuration's own batch), uniform indices over every table's whole row range.  Every shard's slice bit-exact against the oracle; every item's
     score (each computed by the shard that owns it, from the all-gathered layout) within 1e-3 of the fp64-accumulating oracle."""
     import importlib
     dist_mod = importlib.import_module("fleetrec_amd.dist")
-    G, B = 8, 1024
+    G, B = 8, 4096
     m = fr.Model.builtin(fr.MODEL_C)
     om = O.OracleModel("C")
     offs, lens, F = m.shard_plan(G)
@@ -1690,6 +1690,104 @@ def test_config5_inflated_shard_gather(fr, O, gpu, rank):
     assert e.value.status == fr.FR_ERR_INDEX_RANGE
     wk.close()
     c.close()
+
+
+
+def test_config5_all_shards_fp8_chain(fr, O, gpu):
+    """BASELINE configs[4] completely, on the one GPU a test box has: Model-C with every table 5 x its rows (316 GB: past one GPU's
+    288 GB), 8-way table-ID shards, batch 4096, fp8 FC.  All EIGHT inflated shards (30-60 GB each) take their turn on the device:
+    create, fill, gather the shard's slice, keep it on the host, destroy -- twice: once in fp32 (the calibration pass every rank of
+    the real job makes through fr_worker_calibrate_fp8_sharded) and once in e4m3 TRANSPORT with the calibrated X exponent, which is
+    what travels through the all-gather.  Then the all-gathered layout [G][B][F] goes through fr_worker_fc_from_slices_lp for EVERY
+    rank's B/G items, exactly as rank r of the 8-GPU job would run it.
+    Checks: every fp32 slice bit-exact vs the oracle; every e4m3 slice = the documented encoding of the fp32 slice; fp8 scores from
+    e4m3 transport == fp8 scores from fp32 slices bit for bit; vs the fp64-accumulating oracle <= 0.15 (fp8) and <= 3e-2 (the bf16
+    chain on the same slices); fp8 vs bf16 chain <= 0.15."""
+    import importlib
+    dist_mod = importlib.import_module("fleetrec_amd.dist")
+    G, B = 8, 4096
+    m = fr.Model.builtin(fr.MODEL_C).clone(row_scale=5.0)
+    assert m.table_bytes() > 288e9 and m.min_shards() > 1
+    om = O.OracleModel("C")
+    offs, lens, F = m.shard_plan(G)
+    rng = np.random.default_rng(5005)
+    rows = m.rows()
+    idx = uniform_idx(rng, rows, B)
+    idx[0], idx[1] = 0, rows - 1                      # first and last row of every (inflated) table
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+    full = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES)
+
+    def shard_pass(r, fn):
+        c = fr.Context(m, device=gpu, shard_rank=r, n_shards=G)
+        c.fill_tables(fr.FILL_HASH, SEED_TABLES)
+        wk = fr.Worker(c, B)
+        try:
+            return fn(c, wk)
+        finally:
+            wk.close()
+            c.close()
+
+    # pass 1: fp32 slices (bit-exact vs the oracle) -> the calibration input
+    slices = []
+    for r in range(G):
+        sl = shard_pass(r, lambda c, wk: wk.gather_records(idx, dense).reshape(B, F))
+        assert np.array_equal(sl[:, :lens[r]], full[:, offs[r]:offs[r] + lens[r]]), r
+        slices.append(sl)
+    gathered32 = np.stack(slices)                     # [G][B][F] uint32 = what the fp32 all-gather delivers
+    # the FC side: any shard's context serves (FC weights are replicated; its tables are never read by fc_from_slices) -- shard 0, unfilled
+    cf = fr.Context(m, device=gpu, shard_rank=0, n_shards=G)
+    cf.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    ws = [cf.get_weights(l) for l in range(4)]
+    ref = om.fc_chain(full.view(np.float32), ws, acc64=True)
+    wf = fr.Worker(cf, B)
+    d_g32 = fr.DeviceBuffer.from_numpy(cf, gathered32)
+    cf.set_fc_precision(fr.FC_FP8)
+    wf.calibrate_fp8_slices(B, 0, B, d_g32)
+    act_exp, w_exp = cf.fp8_exponents()
+
+    def fc_all_ranks(d_gathered, transport):
+        out = np.empty(B, np.float32)
+        for r in range(G):                            # rank r's share of the batch, from the all-gathered layout
+            lo, hi = dist_mod.item_range(r, G, B)
+            d_s = fr.DeviceBuffer(cf, (hi - lo) * 4)
+            wf.fc_from_slices_lp(B, lo, hi - lo, d_gathered, transport, d_s)
+            wf.sync()
+            out[lo:hi] = d_s.download(np.float32, hi - lo)
+            d_s.free()
+        return out
+
+    fp8_from_f32 = fc_all_ranks(d_g32, fr.FC_FP32)
+    # pass 2: every shard again, now emitting e4m3 slices with the calibrated X exponent (a quarter of the all-gather bytes)
+    lp_slices = []
+    for r in range(G):
+        def emit(c, wk):
+            c.set_fc_precision(fr.FC_FP8)
+            c.set_fp8_act_exponents(act_exp)
+            d_i = fr.DeviceBuffer.from_numpy(c, idx)
+            d_d = fr.DeviceBuffer.from_numpy(c, dense)
+            d_sl = fr.DeviceBuffer(c, B * F)
+            wk.gather_slices(B, d_i, d_d, d_sl, fr.FC_FP8)
+            wk.sync()
+            return d_sl.download(np.uint8, B * F).reshape(B, F)
+        s8 = shard_pass(r, emit)
+        want8 = e4m3_encode(np.clip(slices[r][:, :lens[r]].view(np.float32).astype(np.float64) * 2.0 ** act_exp[0], -448, 448))
+        assert np.array_equal(s8[:, :lens[r]], want8), r
+        lp_slices.append(s8)
+    d_g8 = fr.DeviceBuffer.from_numpy(cf, np.stack(lp_slices))
+    fp8_scores = fc_all_ranks(d_g8, fr.FC_FP8)
+    assert np.array_equal(fp8_scores, fp8_from_f32)   # the transport changes the bytes on the wire, not a bit of a score
+    assert rel_err(fp8_scores, ref) <= 0.15, rel_err(fp8_scores, ref)
+    # the bf16 chain on the same slices (bf16 wire format = RNE of the fp32 slice: test_table_sharded_mode_single_device_emulation pins that)
+    cf.set_fc_precision(fr.FC_BF16)
+    g16 = (bf16_round(gathered32.view(np.float32)).view(np.uint32) >> 16).astype(np.uint16)
+    d_g16 = fr.DeviceBuffer.from_numpy(cf, g16)
+    bf16_scores = fc_all_ranks(d_g16, fr.FC_BF16)
+    assert rel_err(bf16_scores, ref) <= 3e-2, rel_err(bf16_scores, ref)
+    assert rel_err(fp8_scores, bf16_scores) <= 0.15
+    for b_ in (d_g32, d_g8, d_g16):
+        b_.free()
+    wf.close()
+    cf.close()
 
 
 def bf16_round(x):
