@@ -2,8 +2,9 @@
 
 A thin ctypes mirror of include/fleetrec.h (the C-ABI in libfleetrec.so).  It exists for the test
 harness and bench.py; the production host is the C++ driver (the counterpart of the reference's
-GPU/final_network_cublasLt_1_node_no_FIFO_scatter/cuda_server.c).  There is no CPU fallback: if the
-HIP library is missing or no gfx950 device is visible, calls raise FleetRecError.
+GPU/final_network_cublasLt_1_node_no_FIFO_scatter/cuda_server.c).  There is no silent CPU fallback: if the
+HIP library is missing, or a context is asked for on a device that is not a visible gfx950, calls raise
+FleetRecError; Context(model, device=DEVICE_CPU) asks for the library's own CPU back-end explicitly.
 
 Vocabulary follows the reference: tables, banks, rounds, records (the per-item concatenated
 feature vector the FPGA sends), workers (thread_consume), batches.
@@ -25,7 +26,7 @@ LAYOUT_SEMANTIC, LAYOUT_BLOCKED = 0, 1
 INDEX_PER_TABLE, INDEX_PER_ITEM, INDEX_PER_BANK = 0, 1, 2
 SEG_TABLE, SEG_COPY, SEG_DENSE = 0, 1, 2
 GATHER_WORD_MAJOR, GATHER_ITEM_TILE, GATHER_ITEM_TILE_DEDUP, GATHER_ITEM_TILE_DEDUP_COUNT, GATHER_WORD_MAJOR_ONE_CHUNK = 0, 1, 2, 3, 4
-ABI_VERSION = 4   # include/fleetrec.h FR_ABI_VERSION this binding was written against
+ABI_VERSION = 5   # include/fleetrec.h FR_ABI_VERSION this binding was written against
 MEM_CLASS_NAMES = {0: "HBM", 1: "DDR", 2: "PLRAM"}
 
 
@@ -57,7 +58,7 @@ _lib = None
 
 # every symbol include/fleetrec.h, fleetrec_serving.h and fleetrec_diag.h declare (the not-gpu test checks the .so exports all of them)
 ABI_SYMBOLS = [
-    "fr_abi_version", "fr_last_error", "fr_device_count", "fr_model_builtin", "fr_model_clone_scaled", "fr_model_free",
+    "fr_abi_version", "fr_last_error", "fr_device_count", "fr_cpu_set_threads", "fr_model_builtin", "fr_model_clone_scaled", "fr_model_free",
     "fr_model_table_bytes", "fr_model_index_cols", "fr_model_bank_map", "fr_ctx_set_gather_variant", "fr_ctx_gather_variant",
     "fr_ctx_gather_merged_lookups", "fr_ctx_gather_groups", "fr_comm_unique_id", "fr_comm_init_rank", "fr_comm_init_all", "fr_comm_destroy", "fr_comm_set_wait_ms",
     "fr_worker_submit_sharded", "fr_worker_calibrate_fp8_sharded", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
@@ -84,7 +85,7 @@ def lib():
     vp, i32, i64, u32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint32, ctypes.c_size_t
     pf, pi = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)
     sig = {
-        "fr_abi_version": (i32, []), "fr_last_error": (ctypes.c_char_p, []), "fr_device_count": (i32, []),
+        "fr_abi_version": (i32, []), "fr_last_error": (ctypes.c_char_p, []), "fr_device_count": (i32, []), "fr_cpu_set_threads": (i32, [i32]),
         "fr_model_builtin": (ctypes.POINTER(ModelDesc), [i32]),
         "fr_model_clone_scaled": (i32, [ctypes.POINTER(ModelDesc), ctypes.c_double, i64, i64, ctypes.POINTER(ctypes.POINTER(ModelDesc))]),
         "fr_model_free": (None, [ctypes.POINTER(ModelDesc)]),
@@ -150,6 +151,17 @@ def _check(status):
 
 def device_count():
     return lib().fr_device_count()
+
+
+DEVICE_CPU = -1   # Context(model, device=DEVICE_CPU): the library's CPU back-end (fp32 only; include/fleetrec.h fr_ctx_create)
+
+
+def cpu_set_threads(n=0):
+    """Host threads of the CPU back-end (0 = every usable core) -> the number in use."""
+    r = lib().fr_cpu_set_threads(n)
+    if r < 0:
+        _check(r)
+    return r
 
 
 class Model:

@@ -2,6 +2,7 @@
 // worker = stream + staging buffers, submit/sync = the hot-loop body of the reference's
 // thread_consume() (GPU/final_network_cublasLt_1_node_no_FIFO_scatter/cuda_server.c:101-503) with
 // the FPGA embedding stage (FPGA/kernel/user_krnl/embedding_*_krnl) pulled in front of the FC chain.
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -51,9 +52,14 @@ extern "C" int fr_device_count(void) {
     return n;
 }
 
+extern "C" int fr_cpu_set_threads(int n) {
+    if (n < 0) FR_FAIL(FR_ERR_INVALID, "fr_cpu_set_threads(%d): n >= 1, or 0 for every usable core", n);
+    return frc_set_threads(n);
+}
+
 static int select_device(int device) {
     int n = fr_device_count();
-    if (n <= 0) FR_FAIL(FR_ERR_NO_DEVICE, "no HIP device visible: the FleetRec hot path has no CPU back-end");
+    if (n <= 0) FR_FAIL(FR_ERR_NO_DEVICE, "no HIP device visible (device >= 0 never falls back to the CPU; device = -1 asks for the CPU back-end)");
     if (device < 0 || device >= n) FR_FAIL(FR_ERR_NO_DEVICE, "device %d not available (%d visible)", device, n);
     hipDeviceProp_t prop;
     FR_HIP(hipGetDeviceProperties(&prop, device));
@@ -62,6 +68,12 @@ static int select_device(int device) {
     FR_HIP(hipSetDevice(device));
     return FR_OK;
 }
+
+// every entry point selects its context's device first; a CPU context (device = -1, fr_cpu.cpp) has none
+#define FR_SET_DEVICE(ctx_)                                    \
+    do {                                                       \
+        if (!(ctx_)->cpu) FR_HIP(hipSetDevice((ctx_)->device)); \
+    } while (0)
 
 static unsigned long long *g_stamp_buffer = nullptr;  // diagnostics (tools/experiments): see fr_debug_set_stamp_buffer
 extern "C" __attribute__((visibility("default"))) void fr_debug_set_stamp_buffer(void *dptr) { g_stamp_buffer = (unsigned long long *)dptr; }
@@ -73,6 +85,12 @@ static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 // ---- context --------------------------------------------------------------------------------------
 static void ctx_free(fr_ctx *c) {
     if (!c) return;
+    if (c->cpu) {   // the CPU back-end: host memory only
+        frc_arena_free(c->table_arena, c->table_arena_bytes);
+        for (int i = 0; i < 4; i++) free(c->d_w[i]);
+        delete c;
+        return;
+    }
     if (c->device >= 0) (void)hipSetDevice(c->device);
     if (c->table_arena) (void)hipFree(c->table_arena);
     if (c->d_words) (void)hipFree(c->d_words);
@@ -273,7 +291,12 @@ static int build_words(fr_ctx *c) {
         off = align_up(off + (size_t)m.tables[t].rows * m.tables[t].dim * 4, 256);
     }
     c->table_arena_bytes = off;
-    if (off) FR_HIP(hipMalloc((void **)&c->table_arena, off));
+    if (off && c->cpu) {
+        c->table_arena = (char *)frc_arena_alloc(off);
+        if (!c->table_arena) return FR_ERR_OOM;
+    } else if (off) {
+        FR_HIP(hipMalloc((void **)&c->table_arena, off));
+    }
 
     // source runs (for the BLOCKED layout)
     int src_start[3] = {0, 0, 0}, src_len[3] = {0, 0, 0};
@@ -318,6 +341,7 @@ static int build_words(fr_ctx *c) {
         }
     }
     c->n_words = (int)c->h_words.size();
+    if (c->cpu) return FR_OK;   // the CPU back-end walks h_words
     plan_gather_groups(c);
     FR_HIP(hipMalloc((void **)&c->d_words, sizeof(FrWordDesc) * c->n_words));
     FR_HIP(hipMemcpy(c->d_words, c->h_words.data(), sizeof(FrWordDesc) * c->n_words, hipMemcpyHostToDevice));
@@ -382,11 +406,15 @@ extern "C" int fr_ctx_create_sharded(const fr_model_desc *m, int device, int sha
     if (n_shards < 1 || shard_rank < 0 || shard_rank >= n_shards) FR_FAIL(FR_ERR_INVALID, "bad shard %d of %d", shard_rank, n_shards);
     if (n_shards > m->n_segments) FR_FAIL(FR_ERR_INVALID, "more shards (%d) than record segments (%d)", n_shards, m->n_segments);
     if (n_shards > 1 && m->layout != FR_LAYOUT_SEMANTIC) FR_FAIL(FR_ERR_INVALID, "table sharding requires the SEMANTIC layout");
-    rc = select_device(device);
-    if (rc) return rc;
+    const bool cpu = device == -1;   // the CPU back-end (fr_cpu.cpp): no device is selected, no HIP call is made
+    if (!cpu) {
+        rc = select_device(device);
+        if (rc) return rc;
+    }
     fr_ctx *c = new (std::nothrow) fr_ctx();
     if (!c) FR_FAIL(FR_ERR_OOM, "out of host memory");
     c->device = device;
+    c->cpu = cpu;
     c->tables.assign(m->tables, m->tables + m->n_tables);
     c->segments.assign(m->segments, m->segments + m->n_segments);
     c->model = *m;
@@ -396,7 +424,7 @@ extern "C" int fr_ctx_create_sharded(const fr_model_desc *m, int device, int sha
     c->shard_rank = shard_rank;
     c->n_shards = n_shards;
     c->stream_group.store(fused_group_initial(), std::memory_order_relaxed);
-    hipError_t e = hipStreamCreateWithFlags(&c->setup_stream, hipStreamNonBlocking);
+    hipError_t e = cpu ? hipSuccess : hipStreamCreateWithFlags(&c->setup_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         fr_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
         ctx_free(c);
@@ -406,6 +434,17 @@ extern "C" int fr_ctx_create_sharded(const fr_model_desc *m, int device, int sha
     if (rc) {
         ctx_free(c);
         return rc;
+    }
+    if (cpu) {   // fp32 master weights in the reference's column-major H x K layout: all the CPU chain reads
+        for (int l = 0; l < 4; l++) {
+            c->d_w[l] = (float *)malloc((size_t)m->fc[l] * m->fc[l + 1] * sizeof(float));
+            if (!c->d_w[l]) {
+                ctx_free(c);
+                FR_FAIL(FR_ERR_OOM, "out of host memory (weights layer %d)", l);
+            }
+        }
+        *out = c;
+        return FR_OK;
     }
     {   // immutable after creation (read by every driver thread in fused_flush without synchronisation): the device's compute units and
         // whether the persistent K-outer fused kernel applies to this context's descriptors and FC shape
@@ -467,12 +506,17 @@ extern "C" int fr_ctx_shard_info(const fr_ctx *ctx, int *shard_rank, int *n_shar
 extern "C" int fr_ctx_fill_tables(fr_ctx *ctx, int mode, uint32_t seed) {
     if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
     if (mode < FR_FILL_EVEN_ODD || mode > FR_FILL_TAGGED) FR_FAIL(FR_ERR_INVALID, "bad fill mode %d", mode);
-    FR_HIP(hipSetDevice(ctx->device));
+    if (!ctx->cpu) FR_SET_DEVICE(ctx);
     for (int t = 0; t < ctx->model.n_tables; t++) {
         if (!ctx->table_mem[t].resident) continue;
         const fr_table_desc &d = ctx->tables[t];
         const FrTableMem &tm = ctx->table_mem[t];
         const int64_t head = tm.il_rows ? (int64_t)tm.il_rows : d.rows;  // rows at byte_offset (all of them unless interleaved)
+        if (ctx->cpu) {
+            frc_fill_table((float *)(ctx->table_arena + tm.byte_offset), 0, head, d.dim, (int64_t)tm.row_stride, mode, seed, fr_table_uid(d));
+            if (head < d.rows) frc_fill_table((float *)(ctx->table_arena + tm.tail_offset), head, d.rows - head, d.dim, (int64_t)d.dim * 4, mode, seed, fr_table_uid(d));
+            continue;
+        }
         int rc = frk_fill_table((float *)(ctx->table_arena + tm.byte_offset), 0, head, d.dim, (int64_t)tm.row_stride, mode, seed, fr_table_uid(d), ctx->setup_stream);
         if (rc) return rc;
         if (head < d.rows) {
@@ -480,7 +524,7 @@ extern "C" int fr_ctx_fill_tables(fr_ctx *ctx, int mode, uint32_t seed) {
             if (rc) return rc;
         }
     }
-    FR_HIP(hipStreamSynchronize(ctx->setup_stream));
+    if (!ctx->cpu) FR_HIP(hipStreamSynchronize(ctx->setup_stream));
     ctx->tables_filled = true;
     return FR_OK;
 }
@@ -494,11 +538,21 @@ static int table_copy(fr_ctx *ctx, int table, int64_t row0, int64_t nrows, float
     const fr_table_desc &d = ctx->tables[table];
     if (row0 < 0 || nrows < 0 || row0 + nrows > d.rows) FR_FAIL(FR_ERR_INVALID, "rows [%lld,+%lld) outside table %d", (long long)row0, (long long)nrows, table);
     if (!host_rows && nrows) FR_FAIL(FR_ERR_INVALID, "host_rows is NULL");
-    FR_HIP(hipSetDevice(ctx->device));
+    if (!ctx->cpu) FR_SET_DEVICE(ctx);
     const FrTableMem &tm = ctx->table_mem[table];
     const size_t row_bytes = (size_t)d.dim * 4;
     const int64_t head_rows = tm.il_rows ? (int64_t)tm.il_rows : d.rows;
     const int64_t n_head = row0 < head_rows ? (row0 + nrows < head_rows ? nrows : head_rows - row0) : 0;  // rows of the request below head_rows
+    if (ctx->cpu) {   // host arena: plain copies, row by row where the table is one column block of a bank row
+        for (int64_t r = 0; r < nrows; r++) {
+            char *a = r < n_head ? ctx->table_arena + tm.byte_offset + (size_t)(row0 + r) * tm.row_stride
+                                 : ctx->table_arena + tm.tail_offset + (size_t)(row0 + r - head_rows) * row_bytes;
+            float *h = host_rows + (size_t)r * d.dim;
+            if (to_device) memcpy(a, h, row_bytes);
+            else memcpy(h, a, row_bytes);
+        }
+        return FR_OK;
+    }
     if (n_head > 0) {
         char *dev = ctx->table_arena + tm.byte_offset + (size_t)row0 * tm.row_stride;
         if (tm.row_stride == row_bytes) {
@@ -598,7 +652,12 @@ extern "C" int fr_ctx_set_weights(fr_ctx *ctx, int layer, const float *w, size_t
     if (layer < 0 || layer > 3) FR_FAIL(FR_ERR_INVALID, "layer %d out of range", layer);
     size_t n = (size_t)ctx->model.fc[layer] * ctx->model.fc[layer + 1];
     if (count != n) FR_FAIL(FR_ERR_INVALID, "layer %d expects %zu weights (H=%d x K=%d), got %zu", layer, n, ctx->model.fc[layer + 1], ctx->model.fc[layer], count);
-    FR_HIP(hipSetDevice(ctx->device));
+    if (ctx->cpu) {
+        memcpy(ctx->d_w[layer], w, n * sizeof(float));
+        ctx->weights_set = true;
+        return FR_OK;
+    }
+    FR_SET_DEVICE(ctx);
     FR_HIP(hipMemcpy(ctx->d_w[layer], w, n * sizeof(float), hipMemcpyHostToDevice));
     int rc = refresh_bf16(ctx, layer);
     if (rc) return rc;
@@ -610,7 +669,13 @@ extern "C" int fr_ctx_set_weights(fr_ctx *ctx, int layer, const float *w, size_t
 extern "C" int fr_ctx_fill_weights(fr_ctx *ctx, int mode, uint32_t seed) {
     if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
     if (mode != FR_WEIGHTS_ONES && mode != FR_WEIGHTS_UNIFORM) FR_FAIL(FR_ERR_INVALID, "bad weight mode %d", mode);
-    FR_HIP(hipSetDevice(ctx->device));
+    if (ctx->cpu) {
+        for (int l = 0; l < 4; l++)
+            frc_fill_weights(ctx->d_w[l], (size_t)ctx->model.fc[l] * ctx->model.fc[l + 1], mode, seed, (uint32_t)l, 1.0f / std::sqrt((float)ctx->model.fc[l]));
+        ctx->weights_set = true;
+        return FR_OK;
+    }
+    FR_SET_DEVICE(ctx);
     for (int l = 0; l < 4; l++) {
         size_t n = (size_t)ctx->model.fc[l] * ctx->model.fc[l + 1];
         float scale = 1.0f / std::sqrt((float)ctx->model.fc[l]);
@@ -629,7 +694,11 @@ extern "C" int fr_ctx_get_weights(fr_ctx *ctx, int layer, float *w, size_t count
     if (layer < 0 || layer > 3) FR_FAIL(FR_ERR_INVALID, "layer %d out of range", layer);
     size_t n = (size_t)ctx->model.fc[layer] * ctx->model.fc[layer + 1];
     if (count != n) FR_FAIL(FR_ERR_INVALID, "layer %d holds %zu weights, got %zu", layer, n, count);
-    FR_HIP(hipSetDevice(ctx->device));
+    if (ctx->cpu) {
+        memcpy(w, ctx->d_w[layer], n * sizeof(float));
+        return FR_OK;
+    }
+    FR_SET_DEVICE(ctx);
     FR_HIP(hipMemcpy(w, ctx->d_w[layer], n * sizeof(float), hipMemcpyDeviceToHost));
     return FR_OK;
 }
@@ -637,7 +706,11 @@ extern "C" int fr_ctx_get_weights(fr_ctx *ctx, int layer, float *w, size_t count
 extern "C" int fr_ctx_set_fc_precision(fr_ctx *ctx, int precision) {
     if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
     if (precision != FR_FC_FP32 && precision != FR_FC_BF16 && precision != FR_FC_FP8) FR_FAIL(FR_ERR_INVALID, "bad precision %d", precision);
-    FR_HIP(hipSetDevice(ctx->device));
+    if (ctx->cpu) {
+        if (precision != FR_FC_FP32) FR_FAIL(FR_ERR_INVALID, "the CPU back-end computes the FC chain in fp32 only (the reference's own precision, cuda_server.c:211)");
+        return FR_OK;
+    }
+    FR_SET_DEVICE(ctx);
     if (precision == FR_FC_BF16) {
         for (int l = 0; l < 4; l++)
             if (ctx->model.fc[l] % 16) FR_FAIL(FR_ERR_INVALID, "bf16 chain needs fc[%d]=%d to be a multiple of 16", l, ctx->model.fc[l]);
@@ -660,8 +733,16 @@ extern "C" int fr_ctx_set_fc_precision(fr_ctx *ctx, int precision) {
 // ---- worker -----------------------------------------------------------------------------------------
 extern "C" void fr_worker_destroy(fr_worker *w) {
     if (!w) return;
+    if (w->ctx && w->ctx->cpu) {
+        if (w->counted) w->ctx->n_workers.fetch_sub(1, std::memory_order_relaxed);
+        void *host[] = {w->h_idx, w->h_dense, w->h_score, w->d_records, w->c_scratch, w->c_x};
+        for (void *p : host) free(p);
+        delete w;
+        return;
+    }
     if (w->ctx) (void)hipSetDevice(w->ctx->device);
     if (w->stream) (void)hipStreamSynchronize(w->stream);
+    fr_comm_forget(w);   // a sharded step that was never synchronised lets go of its communicator
     if (w->counted) w->ctx->n_workers.fetch_sub(1, std::memory_order_relaxed);
     if (w->h_idx) (void)hipHostFree(w->h_idx);
     if (w->h_dense) (void)hipHostFree(w->h_dense);
@@ -720,13 +801,31 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
         if ((uint64_t)widest * (uint64_t)round_up(max_batch, 64) * 4ull >= (1ull << 32))
             FR_FAIL(FR_ERR_INVALID, "max_batch %d: an activation tensor of %d x batch floats would reach 4 GiB (32-bit buffer offsets)", max_batch, widest);
     }
-    FR_HIP(hipSetDevice(ctx->device));
+    FR_SET_DEVICE(ctx);
     fr_worker *w = new (std::nothrow) fr_worker();
     if (!w) FR_FAIL(FR_ERR_OOM, "out of host memory");
     w->ctx = ctx;
     w->max_batch = max_batch;
     const fr_model_desc &m = ctx->model;
     const size_t B = (size_t)max_batch;
+    if (ctx->cpu) {   // the CPU back-end: plain host buffers behind the same accessors (fr_worker_idx_ptr / dense_ptr / score_ptr)
+        auto host = [](size_t bytes) { return aligned_alloc(64, align_up(bytes ? bytes : 64, 64)); };
+        w->h_idx = (int32_t *)host(B * idx_cols(ctx) * sizeof(int32_t));
+        if (m.dense_len) w->h_dense = (float *)host(B * m.dense_len * sizeof(float));
+        w->h_score = (float *)host(B * sizeof(float));
+        w->d_records = (float *)host(B * (size_t)ctx->slice_padded * sizeof(float));
+        w->c_scratch = (float *)host(B * ((size_t)m.fc[1] + m.fc[2] + m.fc[3]) * sizeof(float));
+        if (ctx->n_shards > 1) w->c_x = (float *)host(B * (size_t)m.fc[0] * sizeof(float));
+        if (!w->h_idx || (m.dense_len && !w->h_dense) || !w->h_score || !w->d_records || !w->c_scratch || (ctx->n_shards > 1 && !w->c_x)) {
+            fr_worker_destroy(w);
+            FR_FAIL(FR_ERR_OOM, "out of host memory (worker buffers for batch %d)", max_batch);
+        }
+        w->h_err = w->d_err = &w->c_err;
+        w->counted = true;
+        ctx->n_workers.fetch_add(1, std::memory_order_relaxed);
+        *out = w;
+        return FR_OK;
+    }
     {
         // A model that runs the stage pipeline (several launches per step: Model-C, sharded contexts) gives its workers hardware queues of
         // their own: the HIP runtime keeps one pool of hardware queues per stream priority, four equal-priority streams share two queues
@@ -799,6 +898,10 @@ static int launch_gather(fr_worker *w, int batch, const int32_t *d_idx, const fl
         for (const FrWordDesc &wd : c->h_words) needs |= (wd.idx_col & FR_DESC_DENSE) != 0;
         if (needs) FR_FAIL(FR_ERR_INVALID, "model has dense features but d_dense is NULL");
     }
+    if (c->cpu) {
+        if (transport != FR_FC_FP32) FR_FAIL(FR_ERR_STATE, "the CPU back-end gathers fp32 records only");
+        return frc_gather(c->h_words.data(), c->n_words, d_idx, (int)idx_cols(c), d_dense, reinterpret_cast<float *>(d_records), batch, &w->c_err);
+    }
     const int variant = c->gather_variant.load(std::memory_order_relaxed);
     const bool one_chunk = variant == FR_GATHER_WORD_MAJOR_ONE_CHUNK;
     if (variant != FR_GATHER_WORD_MAJOR && !one_chunk && transport == FR_FC_FP32 && c->n_chunks > 0)
@@ -829,7 +932,7 @@ extern "C" int fr_ctx_gather_merged_lookups(fr_ctx *ctx, uint64_t *merged, int r
     if (!ctx || !merged) FR_FAIL(FR_ERR_INVALID, "NULL argument");
     *merged = 0;
     if (!ctx->d_merged) return FR_OK;
-    FR_HIP(hipSetDevice(ctx->device));
+    FR_SET_DEVICE(ctx);
     FR_HIP(hipDeviceSynchronize());
     unsigned long long v = 0;
     FR_HIP(hipMemcpy(&v, ctx->d_merged, sizeof(v), hipMemcpyDeviceToHost));
@@ -1278,6 +1381,10 @@ static int check_gather_args(fr_worker *w, const int32_t *d_idx, const float *d_
 static int launch_fc(fr_worker *w, int batch, const float *d_records, float *d_scores) {
     fr_ctx *c = w->ctx;
     if (c->n_shards > 1) FR_FAIL(FR_ERR_STATE, "fc on a sharded ctx needs the all-gathered records (use the sharded driver)");
+    if (c->cpu) {
+        frc_fc_chain(c->model.fc, c->d_w, d_records, batch, w->c_scratch, d_scores);
+        return FR_OK;
+    }
     if (w->n_active) FR_FAIL(FR_ERR_STATE, "pipeline busy: call fr_worker_sync first");
     if (w->launch_no == 0) w->launch_no = 1;  // stage 1 of the next launch reads the set the (virtual) previous launch wrote
     const int ldm = round_up(batch, 32);
@@ -1302,7 +1409,13 @@ static int fc_from_slices_impl(fr_worker *w, int batch_total, int item0, int n_i
     if (!d_gathered || !d_scores) FR_FAIL(FR_ERR_INVALID, "NULL device pointer");
     if (batch_total < 1 || item0 < 0 || item0 + n_items > batch_total) FR_FAIL(FR_ERR_INVALID, "items [%d,+%d) outside batch %d", item0, n_items, batch_total);
     if (w->n_active || w->n_pending) FR_FAIL(FR_ERR_STATE, "pipeline busy: call fr_worker_sync first");
-    FR_HIP(hipSetDevice(c->device));
+    if (c->cpu) {
+        if (c->n_shards < 2) FR_FAIL(FR_ERR_STATE, "fc_from_slices needs a sharded context");
+        frc_slices_to_records(d_gathered, c->n_shards, batch_total, c->slice_padded, c->shard_offset.data(), c->shard_len.data(), item0, n_items, w->c_x, c->model.fc[0]);
+        frc_fc_chain(c->model.fc, c->d_w, w->c_x, n_items, w->c_scratch, d_scores);
+        return FR_OK;
+    }
+    FR_SET_DEVICE(c);
     if (w->launch_no == 0) w->launch_no = 1;
     const int ldm = round_up(n_items, 32);
     const int par_prev = (int)((w->launch_no - 1) & 1);
@@ -1338,6 +1451,11 @@ extern "C" int fr_worker_fc_from_slices(fr_worker *w, int batch_total, int item0
 static int launch_pipeline(fr_worker *w, int batch, const int32_t *d_idx, const float *d_dense, float *d_scores) {
     fr_ctx *c = w->ctx;
     if (c->n_shards > 1) FR_FAIL(FR_ERR_STATE, "submit on a sharded ctx: use the sharded driver (gather_only + all-gather + fc_only)");
+    if (c->cpu) {   // the record in the model's layout (SEMANTIC, or the 3-node buffer read as B x K item-major), then the chain
+        int rc = launch_gather(w, batch, d_idx, d_dense, w->d_records);
+        if (rc) return rc;
+        return launch_fc(w, batch, w->d_records, d_scores);
+    }
     if (c->model.layout != FR_LAYOUT_SEMANTIC) {
         // literal 3-node buffer arithmetic (F8): materialise the blocked records, then read them as B x K item-major
         int rc = launch_gather(w, batch, d_idx, d_dense, w->d_records);
@@ -1355,7 +1473,7 @@ extern "C" int fr_worker_gather_only(fr_worker *w, int batch, const int32_t *d_i
     int rc = check_ready(w, batch, true, false);
     if (rc) return rc;
     if (!d_records) FR_FAIL(FR_ERR_INVALID, "d_records is NULL");
-    FR_HIP(hipSetDevice(w->ctx->device));
+    FR_SET_DEVICE(w->ctx);
     rc = launch_gather(w, batch, d_idx, d_dense, d_records);
     keep_kernel(w);
     if (rc) return rc;
@@ -1371,7 +1489,7 @@ extern "C" int fr_worker_gather_slices(fr_worker *w, int batch, const int32_t *d
     if (!d_slice) FR_FAIL(FR_ERR_INVALID, "d_slice is NULL");
     if (transport != FR_FC_FP32 && transport != FR_FC_BF16 && transport != FR_FC_FP8) FR_FAIL(FR_ERR_INVALID, "bad transport %d", transport);
     if (transport != FR_FC_FP32 && w->ctx->model.layout != FR_LAYOUT_SEMANTIC) FR_FAIL(FR_ERR_STATE, "low-precision transport: SEMANTIC layout only");
-    FR_HIP(hipSetDevice(w->ctx->device));
+    FR_SET_DEVICE(w->ctx);
     rc = launch_gather(w, batch, d_idx, d_dense, d_slice, transport);
     keep_kernel(w);
     if (rc) return rc;
@@ -1391,7 +1509,7 @@ extern "C" int fr_worker_fc_from_slices_lp(fr_worker *w, int batch_total, int it
     if (!d_gathered || !d_scores) FR_FAIL(FR_ERR_INVALID, "NULL device pointer");
     if (batch_total < 1 || item0 < 0 || item0 + n_items > batch_total) FR_FAIL(FR_ERR_INVALID, "items [%d,+%d) outside batch %d", item0, n_items, batch_total);
     if (w->n_active || w->n_pending) FR_FAIL(FR_ERR_STATE, "pipeline busy: call fr_worker_sync first");
-    FR_HIP(hipSetDevice(c->device));
+    FR_SET_DEVICE(c);
     if (w->launch_no == 0) w->launch_no = 1;
     const int ldm = round_up(n_items, 32);
     const int par_prev = (int)((w->launch_no - 1) & 1);
@@ -1410,7 +1528,7 @@ extern "C" int fr_worker_fc_only(fr_worker *w, int batch, const float *d_records
     int rc = check_ready(w, batch, false, true);
     if (rc) return rc;
     if (!d_records || !d_scores) FR_FAIL(FR_ERR_INVALID, "NULL device pointer");
-    FR_HIP(hipSetDevice(w->ctx->device));
+    FR_SET_DEVICE(w->ctx);
     rc = launch_fc(w, batch, d_records, d_scores);
     if (rc) return rc;
     w->in_flight = true;
@@ -1423,9 +1541,10 @@ extern "C" int fr_worker_fc_layer_only(fr_worker *w, int batch, int layer) {
     int rc = check_ready(w, batch, false, true);
     if (rc) return rc;
     if (layer < 0 || layer > 3) FR_FAIL(FR_ERR_INVALID, "layer %d out of range", layer);
+    FR_NOT_ON_CPU(w->ctx, "fr_worker_fc_layer_only");
     if (w->n_active) FR_FAIL(FR_ERR_STATE, "pipeline busy: call fr_worker_sync first");
     fr_ctx *c = w->ctx;
-    FR_HIP(hipSetDevice(c->device));
+    FR_SET_DEVICE(c);
     // place a virtual batch so that the next launch runs exactly stage layer+1 of it, then drop it again
     const int stage = layer + 1;
     if (w->launch_no < (uint64_t)stage) w->launch_no = stage;
@@ -1465,7 +1584,13 @@ extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_i
         FR_FAIL(FR_ERR_STATE, "push_device needs an unsharded SEMANTIC-layout context");
     rc = check_gather_args(w, d_idx, d_dense);
     if (rc) return rc;
-    FR_HIP(hipSetDevice(c->device));
+    if (c->cpu) {   // the CPU back-end has nothing to queue behind: the batch is computed before the call returns
+        rc = launch_pipeline(w, batch, d_idx, d_dense, d_scores);
+        if (rc) return rc;
+        w->in_flight = true;
+        return FR_OK;
+    }
+    FR_SET_DEVICE(c);
     // Launch groups below FR_FUSED_MIN_GROUP ride the stage pipeline even on a fused-eligible context: a fused launch of g batches takes
     // one item tile's time (~130 us for Model-A) whatever g is, so small groups give 7 M (g = 1) .. 35 M inferences/s (g = 8) at 145 us,
     // where the pipelined stage launches give 43 M at 36 us (profiles/r02_launch_group_paths.txt).
@@ -1521,7 +1646,7 @@ extern "C" int fr_worker_submit_device(fr_worker *w, int batch, const int32_t *d
     int rc = check_ready(w, batch, true, true);
     if (rc) return rc;
     if (!d_scores) FR_FAIL(FR_ERR_INVALID, "d_scores is NULL");
-    FR_HIP(hipSetDevice(w->ctx->device));
+    FR_SET_DEVICE(w->ctx);
     if (w->n_active || w->n_pending) FR_FAIL(FR_ERR_STATE, "pipeline busy (push_device in flight): call fr_worker_sync first");
     rc = launch_pipeline(w, batch, d_idx, d_dense, d_scores);
     if (rc) return rc;
@@ -1534,7 +1659,13 @@ extern "C" int fr_worker_submit(fr_worker *w, int batch) {
     if (rc) return rc;
     if (w->in_flight) FR_FAIL(FR_ERR_STATE, "a batch is already in flight on this worker: call fr_worker_sync first");
     fr_ctx *c = w->ctx;
-    FR_HIP(hipSetDevice(c->device));
+    if (c->cpu) {
+        rc = launch_pipeline(w, batch, w->h_idx, c->model.dense_len ? w->h_dense : nullptr, w->h_score);
+        if (rc) return rc;
+        w->in_flight = true;
+        return FR_OK;
+    }
+    FR_SET_DEVICE(c);
     // Default: no copy commands on the stream -- the gather stage reads the index rows (and dense features) straight from the worker's
     // pinned host buffers over PCIe and the output layer writes the scores straight into the pinned score buffer.  Against the
     // reference's H2D / D2H commands (cuda_server.c:460-461,494-495; FR_SUBMIT_ZEROCOPY=0 keeps them) that takes 4-8 us off a submit +
@@ -1655,8 +1786,9 @@ static int host_slot_prepare(fr_worker *w, int batch, int32_t **idx_slot, float 
     int rc = check_ready(w, batch, true, true);
     if (rc) return rc;
     fr_ctx *c = w->ctx;
+    FR_NOT_ON_CPU(c, "host-fed streaming (fr_worker_push_host / fr_worker_stage_acquire)");
     if (!fused_eligible(c)) FR_FAIL(FR_ERR_STATE, "host-fed streaming needs a model that streams through the fused item-tile kernel (use fr_worker_submit)");
-    FR_HIP(hipSetDevice(c->device));
+    FR_SET_DEVICE(c);
     rc = host_ring_init(w);
     if (rc) return rc;
     fr_worker::HostRing &r = w->hr;
@@ -1780,9 +1912,10 @@ extern "C" int fr_worker_calibrate_fp8(fr_worker *w, int batch) {
     int rc = check_ready(w, batch, true, true);
     if (rc) return rc;
     fr_ctx *c = w->ctx;
+    FR_NOT_ON_CPU(c, "fr_worker_calibrate_fp8");
     if (c->n_shards > 1 || c->model.layout != FR_LAYOUT_SEMANTIC) FR_FAIL(FR_ERR_STATE, "fp8 calibration from index rows: unsharded SEMANTIC contexts only (sharded: fr_worker_calibrate_fp8_slices)");
     if (w->in_flight || w->n_active || w->n_pending) FR_FAIL(FR_ERR_STATE, "worker busy: call fr_worker_sync first");
-    FR_HIP(hipSetDevice(c->device));
+    FR_SET_DEVICE(c);
     if (!c->d_stats) FR_HIP(hipMalloc((void **)&c->d_stats, 64));
     FR_HIP(hipMemcpyAsync(w->d_idx, w->h_idx, (size_t)batch * idx_cols(c) * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
     if (c->model.dense_len)
@@ -1802,8 +1935,9 @@ extern "C" int fr_worker_calibrate_fp8(fr_worker *w, int batch) {
 extern "C" int fr_worker_calibrate_fp8_slices(fr_worker *w, int batch_total, int item0, int n_items, const float *d_gathered) {
     if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
     fr_ctx *c = w->ctx;
+    FR_NOT_ON_CPU(c, "fr_worker_calibrate_fp8_slices");
     if (w->in_flight) FR_FAIL(FR_ERR_STATE, "worker busy: call fr_worker_sync first");
-    FR_HIP(hipSetDevice(c->device));
+    FR_SET_DEVICE(c);
     if (!c->d_stats) FR_HIP(hipMalloc((void **)&c->d_stats, 64));
     uint64_t L1 = 0;
     w->calibrating = true;
@@ -1817,7 +1951,7 @@ extern "C" int fr_worker_calibrate_fp8_slices(fr_worker *w, int batch_total, int
 extern "C" int fr_worker_flush(fr_worker *w) {
     if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
     if (w->hr.staged) FR_FAIL(FR_ERR_STATE, "a staging slot is acquired: push it with fr_worker_push_staged first");
-    FR_HIP(hipSetDevice(w->ctx->device));
+    FR_SET_DEVICE(w->ctx);
     if (w->hr.g) {
         int rc = host_block_launch(w);
         if (rc) return rc;
@@ -1831,7 +1965,7 @@ extern "C" int fr_worker_host_poll(fr_worker *w, long long *delivered) {
     if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
     fr_worker::HostRing &r = w->hr;
     if (r.g) {
-        FR_HIP(hipSetDevice(w->ctx->device));
+        FR_SET_DEVICE(w->ctx);
         for (int k = 0; k < FR_HOST_BLOCKS; k++) {
             const int b = (r.cur + k) % FR_HOST_BLOCKS;  // oldest first
             if (!r.inflight[b]) continue;
@@ -1864,13 +1998,19 @@ extern "C" int fr_worker_host_pending(const fr_worker *w, int *queued, int *in_f
 
 extern "C" int fr_worker_sync(fr_worker *w) {
     if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
-    FR_HIP(hipSetDevice(w->ctx->device));
+    if (w->ctx->cpu) {   // everything was computed inside the calls; only a sticky index-range error is left to report
+        w->in_flight = false;
+        if (__atomic_exchange_n(&w->c_err, 0, __ATOMIC_ACQ_REL)) FR_FAIL(FR_ERR_INDEX_RANGE, "a lookup index was outside its table (row 0 was read instead)");
+        return FR_OK;
+    }
+    FR_SET_DEVICE(w->ctx);
     int frc = host_ring_drain(w);  // host-fed blocks: launch the partial one, deliver every block's scores
-    if (frc) return frc;
-    frc = fused_flush(w);  // launch batches still queued by fr_worker_push_device
-    if (frc) return frc;
-    frc = pipeline_flush(w);  // drain the stage pipeline
-    if (frc) return frc;
+    if (!frc) frc = fused_flush(w);  // launch batches still queued by fr_worker_push_device
+    if (!frc) frc = pipeline_flush(w);  // drain the stage pipeline
+    if (frc) {
+        fr_comm_forget(w);   // a sharded step in flight keeps no hold on its communicator past a failed sync
+        return frc;
+    }
     const int crc = fr_comm_wait(w);  // a table-sharded step in flight: bounded wait + the ranks' status words (fr_comm.cpp)
     if (crc) {
         w->in_flight = false;
@@ -1888,14 +2028,22 @@ extern "C" int fr_worker_sync(fr_worker *w) {
 
 extern "C" int fr_worker_timer_start(fr_worker *w) {
     if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
-    FR_HIP(hipSetDevice(w->ctx->device));
+    if (w->ctx->cpu) {
+        w->c_t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        return FR_OK;
+    }
+    FR_SET_DEVICE(w->ctx);
     FR_HIP(hipEventRecord(w->ev_start, w->stream));
     return FR_OK;
 }
 
 extern "C" int fr_worker_timer_stop_ms(fr_worker *w, float *ms) {
     if (!w || !ms) FR_FAIL(FR_ERR_INVALID, "NULL argument");
-    FR_HIP(hipSetDevice(w->ctx->device));
+    if (w->ctx->cpu) {
+        *ms = (float)(1e3 * (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - w->c_t0));
+        return FR_OK;
+    }
+    FR_SET_DEVICE(w->ctx);
     FR_HIP(hipEventRecord(w->ev_stop, w->stream));
     FR_HIP(hipEventSynchronize(w->ev_stop));
     FR_HIP(hipEventElapsedTime(ms, w->ev_start, w->ev_stop));
@@ -1905,31 +2053,49 @@ extern "C" int fr_worker_timer_stop_ms(fr_worker *w, float *ms) {
 // ---- device memory helpers ------------------------------------------------------------------------------
 extern "C" int fr_device_malloc(fr_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) FR_FAIL(FR_ERR_INVALID, "NULL argument");
-    FR_HIP(hipSetDevice(ctx->device));
+    if (ctx->cpu) {   // "device memory" of the CPU back-end is host memory: the same calling code runs against either
+        *dptr = aligned_alloc(64, align_up(bytes ? bytes : 64, 64));
+        if (!*dptr) FR_FAIL(FR_ERR_OOM, "out of host memory (%zu bytes)", bytes);
+        return FR_OK;
+    }
+    FR_SET_DEVICE(ctx);
     FR_HIP(hipMalloc(dptr, bytes ? bytes : 1));
     return FR_OK;
 }
 extern "C" int fr_device_free(fr_ctx *ctx, void *dptr) {
     if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
-    FR_HIP(hipSetDevice(ctx->device));
+    if (ctx->cpu) {
+        free(dptr);
+        return FR_OK;
+    }
+    FR_SET_DEVICE(ctx);
     if (dptr) FR_HIP(hipFree(dptr));
     return FR_OK;
 }
 extern "C" int fr_memcpy_h2d(fr_ctx *ctx, void *dptr, const void *host, size_t bytes) {
     if (!ctx || (bytes && (!dptr || !host))) FR_FAIL(FR_ERR_INVALID, "NULL argument");
-    FR_HIP(hipSetDevice(ctx->device));
+    if (ctx->cpu) {
+        if (bytes) memcpy(dptr, host, bytes);
+        return FR_OK;
+    }
+    FR_SET_DEVICE(ctx);
     if (bytes) FR_HIP(hipMemcpy(dptr, host, bytes, hipMemcpyHostToDevice));
     return FR_OK;
 }
 extern "C" int fr_memcpy_d2h(fr_ctx *ctx, void *host, const void *dptr, size_t bytes) {
     if (!ctx || (bytes && (!dptr || !host))) FR_FAIL(FR_ERR_INVALID, "NULL argument");
-    FR_HIP(hipSetDevice(ctx->device));
+    if (ctx->cpu) {
+        if (bytes) memcpy(host, dptr, bytes);
+        return FR_OK;
+    }
+    FR_SET_DEVICE(ctx);
     if (bytes) FR_HIP(hipMemcpy(host, dptr, bytes, hipMemcpyDeviceToHost));
     return FR_OK;
 }
 extern "C" int fr_device_synchronize(fr_ctx *ctx) {
     if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
-    FR_HIP(hipSetDevice(ctx->device));
+    if (ctx->cpu) return FR_OK;
+    FR_SET_DEVICE(ctx);
     FR_HIP(hipDeviceSynchronize());
     return FR_OK;
 }

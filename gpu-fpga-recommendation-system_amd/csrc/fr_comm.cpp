@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: the functions are resolved through dlsym
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
@@ -75,7 +76,12 @@ struct fr_comm {
     fr_ctx *ctx = nullptr;
     bool broken = false;  // a collective step failed on this rank: the communicator was aborted, every later call returns FR_ERR_COMM
     int wait_ms = 60000;  // bound of fr_comm_wait: how long fr_worker_sync lets a step's collectives take before it gives the peers up
+    // one reference for the handle fr_comm_init_* gave out + one per worker with a sharded step in flight through this communicator
+    // (fr_worker::sh_comm): fr_comm_destroy between a submit and its sync only drops the handle's reference, the communicator itself goes
+    // when the last worker has synchronised (fr_comm_wait used to dereference a freed object in that sequence)
+    std::atomic<int> refs{1};
 };
+constexpr int FR_COMM_MAX_RANKS = 64;   // fr_worker::h_sh_status holds 1 + FR_COMM_MAX_RANKS status words
 
 // Failure protocol of a collective step.  Three kinds of failure, three answers:
 //  (1) argument / state errors found BEFORE anything was enqueued (worker busy, batch too large, tables not filled ...): returned as they
@@ -123,6 +129,8 @@ extern "C" int fr_comm_unique_id(void *id128) {
 
 static int comm_check_ctx(const fr_ctx *ctx) {
     if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
+    FR_NOT_ON_CPU(ctx, "the RCCL exchange (fr_comm_*)");
+    if (ctx->n_shards > FR_COMM_MAX_RANKS) FR_FAIL(FR_ERR_INVALID, "%d shards: the RCCL exchange serves at most %d ranks", ctx->n_shards, FR_COMM_MAX_RANKS);
     if (ctx->model.layout != FR_LAYOUT_SEMANTIC) FR_FAIL(FR_ERR_STATE, "the sharded exchange needs the SEMANTIC layout");
     return FR_OK;
 }
@@ -152,7 +160,7 @@ extern "C" int fr_comm_init_rank(fr_ctx *ctx, const void *id128, fr_comm **out) 
 }
 
 extern "C" int fr_comm_init_all(fr_ctx *const *ctxs, int n, fr_comm **out) {
-    if (!ctxs || !out || n < 1 || n > 64) FR_FAIL(FR_ERR_INVALID, "bad argument");
+    if (!ctxs || !out || n < 1 || n > FR_COMM_MAX_RANKS) FR_FAIL(FR_ERR_INVALID, "bad argument");
     for (int r = 0; r < n; r++) out[r] = nullptr;
     int rc = rccl_load();
     if (rc) return rc;
@@ -192,13 +200,24 @@ extern "C" int fr_comm_set_wait_ms(fr_comm *c, int wait_ms) {
     return FR_OK;
 }
 
-extern "C" void fr_comm_destroy(fr_comm *c) {
-    if (!c) return;
+static void comm_release(fr_comm *c) {
+    if (c->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
     if (c->comm && g_rccl_ok) {
         if (c->ctx) (void)hipSetDevice(c->ctx->device);
         (void)g_rccl.CommDestroy(c->comm);
     }
     delete c;
+}
+
+extern "C" void fr_comm_destroy(fr_comm *c) {
+    if (c) comm_release(c);
+}
+
+// fr_worker_sync leaves early (another path of the worker failed first): the step's reference goes without a wait
+void fr_comm_forget(fr_worker *w) {
+    fr_comm *comm = w->sh_comm;
+    w->sh_comm = nullptr;
+    if (comm) comm_release(comm);
 }
 
 // exchange buffers of a worker: slice [max_batch][F] and gathered [G][max_batch][F] sized for fp32 elements, score chunks
@@ -207,7 +226,8 @@ static int shard_buffers(fr_worker *w, int G) {
     fr_ctx *c = w->ctx;
     const size_t slice = (size_t)w->max_batch * (size_t)c->slice_padded * sizeof(float);
     const size_t chunk = ((size_t)w->max_batch + G - 1) / G + 1;  // + the rank's status word (failure protocol, kind (2))
-    if (!w->h_sh_status) FR_HIP(hipHostMalloc((void **)&w->h_sh_status, sizeof(float) * 65, hipHostMallocDefault));  // [0] sent, [1 .. G] received
+    if (G > FR_COMM_MAX_RANKS) FR_FAIL(FR_ERR_INVALID, "%d ranks: the status words of a sharded step hold %d", G, FR_COMM_MAX_RANKS);
+    if (!w->h_sh_status) FR_HIP(hipHostMalloc((void **)&w->h_sh_status, sizeof(float) * (1 + FR_COMM_MAX_RANKS), hipHostMallocDefault));  // [0] sent, [1 .. G] received
     void **bufs[] = {&w->d_slice, &w->d_gathered, (void **)&w->d_score_part, (void **)&w->d_score_all};
     for (void **b : bufs)
         if (*b) {
@@ -295,16 +315,24 @@ extern "C" int fr_worker_submit_sharded(fr_worker *w, fr_comm *comm, int batch) 
         return comm_fail(comm, FR_ERR_HIP);
     }
     w->sh_comm = comm;  // fr_worker_sync waits through fr_comm_wait and reads the G status words
+    comm->refs.fetch_add(1, std::memory_order_relaxed);
     w->in_flight = true;
     if (fc_rc) FR_FAIL(fc_rc, "FC chain failed on this rank (its peers learn it from the status word): %s", fc_text);
     return FR_OK;
 }
 
 // fr_worker_sync of a worker with a sharded step in flight: a BOUNDED wait (failure protocol, kind (3)), then the status words (kind (2)).
+static int comm_wait_step(fr_worker *w, fr_comm *comm);
 int fr_comm_wait(fr_worker *w) {
     fr_comm *comm = w->sh_comm;
     w->sh_comm = nullptr;
     if (!comm) return FR_OK;
+    const int rc = comm_wait_step(w, comm);
+    comm_release(comm);   // the step's reference; the last one destroys a communicator that fr_comm_destroy has already let go
+    return rc;
+}
+
+static int comm_wait_step(fr_worker *w, fr_comm *comm) {
     const int G = comm->n_ranks;
     if (comm->broken) FR_FAIL(FR_ERR_COMM, "the communicator was aborted by an earlier failure on this rank");
     // poll instead of hipStreamSynchronize: a peer that never arrives must not hold this rank for ever

@@ -17,6 +17,15 @@
 
 #include "fr_internal.h"
 
+// the device drained on both sides of a timed run (nothing to drain on a CPU context: its calls compute before they return)
+#define FR_DRAIN_DEVICE(ctx_)                          \
+    do {                                               \
+        if (!(ctx_)->cpu) {                            \
+            FR_HIP(hipSetDevice((ctx_)->device));      \
+            FR_HIP(hipDeviceSynchronize());            \
+        }                                              \
+    } while (0)
+
 constexpr int FR_SCORE_RING = 512;  // eight launches of 64 batches (two of 256: the largest group) per worker between two syncs
 
 struct fr_driver {
@@ -31,9 +40,11 @@ struct fr_driver {
 extern "C" void fr_driver_destroy(fr_driver *d) {
     if (!d) return;
     for (fr_worker *w : d->workers) fr_worker_destroy(w);
-    if (d->ctx) (void)hipSetDevice(d->ctx->device);
-    for (float *p : d->score_rings)
-        if (p) (void)hipFree(p);
+    if (d->ctx && !d->ctx->cpu) (void)hipSetDevice(d->ctx->device);
+    for (float *p : d->score_rings) {
+        if (p && d->ctx->cpu) free(p);
+        else if (p) (void)hipFree(p);
+    }
     delete d;
 }
 
@@ -56,6 +67,15 @@ extern "C" int fr_driver_create(fr_ctx *ctx, int n_threads, int depth, int max_b
         }
         d->workers.push_back(w);
         float *ring = nullptr;
+        if (ctx->cpu) {   // the CPU back-end's "device" buffers are host memory
+            ring = (float *)calloc((size_t)FR_SCORE_RING * max_batch, sizeof(float));
+            if (!ring) {
+                fr_driver_destroy(d);
+                FR_FAIL(FR_ERR_OOM, "out of host memory (score ring)");
+            }
+            d->score_rings.push_back(ring);
+            continue;
+        }
         if (hipMalloc((void **)&ring, (size_t)FR_SCORE_RING * max_batch * sizeof(float)) != hipSuccess) {
             fr_driver_destroy(d);
             FR_FAIL(FR_ERR_OOM, "hipMalloc(score ring) failed");
@@ -76,8 +96,7 @@ extern "C" int fr_driver_run_resident(fr_driver *d, int batch, int64_t total_bat
     std::vector<int> status(d->n_threads, FR_OK);
     std::vector<std::string> messages(d->n_threads);
     std::vector<std::thread> threads;
-    FR_HIP(hipSetDevice(d->ctx->device));
-    FR_HIP(hipDeviceSynchronize());
+    FR_DRAIN_DEVICE(d->ctx);
     const auto t0 = std::chrono::steady_clock::now();
     for (int t = 0; t < d->n_threads; t++) {
         threads.emplace_back([&, t]() {
@@ -131,7 +150,7 @@ extern "C" int fr_driver_run_resident(fr_driver *d, int batch, int64_t total_bat
         });
     }
     for (auto &th : threads) th.join();
-    FR_HIP(hipDeviceSynchronize());
+    FR_DRAIN_DEVICE(d->ctx);
     *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (int t = 0; t < d->n_threads; t++)
         if (status[t]) FR_FAIL(status[t], "driver thread %d: %s", t, messages[t].c_str());
@@ -154,8 +173,7 @@ extern "C" int fr_driver_run_host(fr_driver *d, int batch, int64_t total_batches
     std::vector<int> status(d->n_threads, FR_OK);
     std::vector<std::string> messages(d->n_threads);
     std::vector<std::thread> threads;
-    FR_HIP(hipSetDevice(d->ctx->device));
-    FR_HIP(hipDeviceSynchronize());
+    FR_DRAIN_DEVICE(d->ctx);
     const auto t0 = std::chrono::steady_clock::now();
     for (int t = 0; t < d->n_threads; t++) {
         threads.emplace_back([&, t]() {
@@ -192,7 +210,7 @@ extern "C" int fr_driver_run_host(fr_driver *d, int batch, int64_t total_batches
         });
     }
     for (auto &th : threads) th.join();
-    FR_HIP(hipDeviceSynchronize());
+    FR_DRAIN_DEVICE(d->ctx);
     *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (int t = 0; t < d->n_threads; t++)
         if (status[t]) FR_FAIL(status[t], "driver thread %d: %s", t, messages[t].c_str());
@@ -207,6 +225,7 @@ extern "C" int fr_driver_run_host_streaming(fr_driver *d, int batch, int64_t tot
     if (!d || !h_idx_pool || n_pool < 1 || !elapsed_s) FR_FAIL(FR_ERR_INVALID, "bad argument");
     if (batch < 1 || batch > d->max_batch || total_batches < 0) FR_FAIL(FR_ERR_INVALID, "batch %d / total %lld out of range", batch, (long long)total_batches);
     if (d->ctx->model.dense_len && !h_dense_pool) FR_FAIL(FR_ERR_INVALID, "model has dense features but h_dense_pool is NULL");
+    FR_NOT_ON_CPU(d->ctx, "fr_driver_run_host_streaming");
     if (d->host_rings.empty()) {
         d->host_rings.resize(d->workers.size());
         for (auto &r : d->host_rings) r.assign((size_t)FR_SCORE_RING * d->max_batch, 0.0f);
@@ -216,8 +235,7 @@ extern "C" int fr_driver_run_host_streaming(fr_driver *d, int batch, int64_t tot
     std::vector<int> status(d->n_threads, FR_OK);
     std::vector<std::string> messages(d->n_threads);
     std::vector<std::thread> threads;
-    FR_HIP(hipSetDevice(d->ctx->device));
-    FR_HIP(hipDeviceSynchronize());
+    FR_DRAIN_DEVICE(d->ctx);
     const auto t0 = std::chrono::steady_clock::now();
     for (int t = 0; t < d->n_threads; t++) {
         threads.emplace_back([&, t]() {
@@ -248,7 +266,7 @@ extern "C" int fr_driver_run_host_streaming(fr_driver *d, int batch, int64_t tot
         });
     }
     for (auto &th : threads) th.join();
-    FR_HIP(hipDeviceSynchronize());
+    FR_DRAIN_DEVICE(d->ctx);
     *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (int t = 0; t < d->n_threads; t++)
         if (status[t]) FR_FAIL(status[t], "driver thread %d: %s", t, messages[t].c_str());

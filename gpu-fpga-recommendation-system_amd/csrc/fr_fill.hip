@@ -1,47 +1,25 @@
 // Table / weight fills, operand re-packs and reductions: one-off or diagnostic kernels around the hot path.
 #include <type_traits>
 
+#include "fr_content.h"
 #include "fr_device.h"
 
-// ---------------------------------------------------------------------------------------------------
-// Procedural contents.  Bit-for-bit the same functions as oracle/fleetrec_oracle.c content_bits().
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
-    h ^= h >> 16;
-    h *= 0x85EBCA6Bu;
-    h ^= h >> 13;
-    h *= 0xC2B2AE35u;
-    h ^= h >> 16;
-    return h;
-}
-
-__device__ __forceinline__ uint32_t content_bits(int mode, uint32_t h_seed_uid, uint32_t uid, uint64_t row, uint32_t col) {
-    if (mode == FR_FILL_EVEN_ODD) return (row & 1) ? 0u : 0x3F800000u;
-    if (mode == FR_FILL_TAGGED) {
-        uint32_t source = uid >> 10, cls = (uid >> 8) & 3, tid = uid & 255;
-        return (source << 31) | (cls << 29) | (tid << 21) | ((uint32_t)(row & 0xFFFF) << 5) | (col & 31);
-    }
-    uint32_t h = fmix32(h_seed_uid ^ (uint32_t)row);
-    h = fmix32(h ^ (uint32_t)(row >> 32) ^ (col * 0x27D4EB2Fu));
-    float v = (float)(int32_t)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
-    return __float_as_uint(v);
-}
-
+// Procedural contents: fr_content.h (shared with the CPU back-end; oracle/fleetrec_oracle.c content_bits() restates the same functions).
 // one thread per 16-byte word, grid-stride; stores are 16 B/lane fully coalesced.  Row r of the table (r = row0 + local row) lives at
 // base + local_row * row_stride_words: row_stride_words == words_per_row for a table stored on its own, larger for a table that is one
 // column block of a bank-interleaved region (FR_INDEX_PER_BANK, fr_api.cpp build_words).
 __global__ void __launch_bounds__(256) fill_table_kernel(uint4 *base, uint64_t n_words, uint32_t words_per_row, uint64_t row_stride_words, uint64_t row0,
                                                           int mode, uint32_t seed, uint32_t uid) {
-    const uint32_t h0 = fmix32(seed ^ (uid * 0x9E3779B1u));
+    const uint32_t h0 = fr_table_hash_seed(seed, uid);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
         const uint64_t lrow = w / words_per_row, row = row0 + lrow;
         const uint32_t wc = (uint32_t)(w - lrow * words_per_row), c0 = wc * 4;
         uint4 v;
-        v.x = content_bits(mode, h0, uid, row, c0 + 0);
-        v.y = content_bits(mode, h0, uid, row, c0 + 1);
-        v.z = content_bits(mode, h0, uid, row, c0 + 2);
-        v.w = content_bits(mode, h0, uid, row, c0 + 3);
+        v.x = fr_content_bits(mode, h0, uid, row, c0 + 0);
+        v.y = fr_content_bits(mode, h0, uid, row, c0 + 1);
+        v.z = fr_content_bits(mode, h0, uid, row, c0 + 2);
+        v.w = fr_content_bits(mode, h0, uid, row, c0 + 3);
         base[lrow * row_stride_words + wc] = v;
     }
 }
@@ -58,17 +36,9 @@ int frk_fill_table(float *base, int64_t row0, int64_t rows, int dim, int64_t row
 }
 
 __global__ void __launch_bounds__(256) fill_weights_kernel(float *w, uint64_t n, int mode, uint32_t seed, uint32_t layer, float scale) {
-    const uint32_t h0 = fmix32(seed ^ ((layer + 1u) * 0x9E3779B1u));
+    const uint32_t h0 = fr_weight_hash_seed(seed, layer);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        float v = 1.0f;
-        if (mode == FR_WEIGHTS_UNIFORM) {
-            uint32_t h = fmix32(h0 ^ (uint32_t)i);
-            h = fmix32(h ^ (uint32_t)(i >> 32));
-            v = ((float)(int32_t)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale;
-        }
-        w[i] = v;
-    }
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) w[i] = fr_weight_value(mode, h0, i, scale);
 }
 
 int frk_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t layer, float scale, hipStream_t s) {

@@ -174,6 +174,7 @@ struct FrTableMem {
 
 struct fr_ctx {
     int device = -1;
+    bool cpu = false;                      // the CPU back-end (fr_ctx_create with device = -1, fr_cpu.cpp): every pointer below is host memory, no HIP call is made
     fr_model_desc model{};                 // deep copy (tables/segments point into the vectors below)
     std::vector<fr_table_desc> tables;
     std::vector<fr_segment> segments;
@@ -227,6 +228,11 @@ struct fr_ctx {
 struct fr_worker {
     fr_ctx *ctx = nullptr;
     int max_batch = 0;
+    // CPU back-end: a call computes before it returns; an index-range error stays in c_err until fr_worker_sync reports it
+    float *c_scratch = nullptr;  // [max_batch][H1 + H2 + H3]
+    float *c_x = nullptr;        // records of the sharded FC entry points, [max_batch][K]
+    int c_err = 0;
+    double c_t0 = 0.0;           // fr_worker_timer_start (steady clock, seconds)
     hipStream_t stream = nullptr;
     // pinned host staging (cudaMallocHost in the reference, cuda_server.c:136-160)
     int32_t *h_idx = nullptr;
@@ -303,6 +309,22 @@ struct fr_worker {
 
 // ---- table-sharded exchange (fr_comm.cpp) ------------------------------------------------------------
 int fr_comm_wait(fr_worker *w);  // bounded wait for the sharded step in flight + the ranks' status words; FR_OK when none is in flight
+void fr_comm_forget(fr_worker *w);  // drop the step's hold on its communicator without waiting (fr_worker_sync leaving early)
+
+// ---- CPU back-end (fr_cpu.cpp): device = -1 -----------------------------------------------------------
+int frc_set_threads(int n);   // 0: all usable cores; -> the pool's size
+int frc_threads();
+void *frc_arena_alloc(size_t bytes);   // nullptr (+ fr_last_error) when the host cannot hold it
+void frc_arena_free(void *p, size_t bytes);
+int frc_fill_table(float *base, int64_t row0, int64_t rows, int dim, int64_t row_stride_bytes, int mode, uint32_t seed, uint32_t uid);
+int frc_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t layer, float scale);
+int frc_gather(const FrWordDesc *words, int n_words, const int32_t *idx, int idx_stride, const float *dense, float *out, int batch, int *err_flag);
+void frc_fc_chain(const int32_t fc[5], const float *const w[4], const float *X, int batch, float *scratch, float *scores);
+void frc_slices_to_records(const float *gathered, int n_shards, int batch_total, int slice_padded, const int *offs, const int *lens, int item0, int n_items, float *X, int K);
+#define FR_NOT_ON_CPU(ctx_, what)                                                                                                  \
+    do {                                                                                                                           \
+        if ((ctx_)->cpu) FR_FAIL(FR_ERR_STATE, "%s is not available on the CPU back-end (device = -1): fp32 submit / sync / gather_only / fc_only only", what); \
+    } while (0)
 
 // ---- registry (fr_registry.cpp) -------------------------------------------------------------------
 int fr_model_validate(const fr_model_desc *m);

@@ -15,8 +15,10 @@
  * FR_OK (0) or a negative fr_status; fr_last_error() gives a thread-local message.  Nothing here
  * ever exit()s or prints-and-continues (contrast checkCudaStatus, cuda_server.c:27-32).
  *
- * There is NO CPU fallback: every compute entry point needs a gfx950 device and fails with
- * FR_ERR_NO_DEVICE otherwise.
+ * There is no SILENT CPU fallback: a context created on device >= 0 needs a gfx950 device and fails with FR_ERR_NO_DEVICE otherwise.
+ * device = -1 asks for the CPU back-end explicitly (BASELINE configs[0], the reference's `make check
+ * TARGET=sw_emu` plumbing run, FPGA/Makefile:154-158): the same symbols, fp32 only, the library's own host code (csrc/fr_cpu.cpp) --
+ * see fr_ctx_create.
  */
 #ifndef FLEETREC_H
 #define FLEETREC_H
@@ -31,18 +33,20 @@ extern "C" {
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 #endif
 
-/* 4 (round 4): the surface is three headers -- this one (the three spans of thread_consume() that SURVEY section 8(b) cuts, the request
+/* 5 (round 5): fr_ctx_create(device = -1) = the CPU back-end, fr_cpu_set_threads; fr_ctx_set_chain_width / fr_ctx_chain_width (the GEMM tile
+ * shape of a chain model no longer follows the number of live workers).
+ * 4 (round 4): the surface is three headers -- this one (the three spans of thread_consume() that SURVEY section 8(b) cuts, the request
  * driver core and the table-sharded mode), fleetrec_serving.h (host-fed streaming / serving extensions) and fleetrec_diag.h (measurement
  * and parity hooks); fr_worker_submit_sharded all-gathers a status word behind every score chunk and fr_worker_sync bounds its wait for
  * the collectives.  3 (round 3): fr_ctx_set_stream_group is per context (1..256), groups below 12 ride the stage pipeline;
  * FR_INDEX_PER_BANK stores bank-interleaved tables; the library reads no environment variable.  A binding must refuse a library whose
  * fr_abi_version() differs from the header it was written against (the Python binding does, also for a build loaded through FR_LIB). */
-#define FR_ABI_VERSION 4
+#define FR_ABI_VERSION 5
 
 typedef enum fr_status {
     FR_OK = 0,
     FR_ERR_INVALID = -1,     /* bad argument / malformed model description */
-    FR_ERR_NO_DEVICE = -2,   /* no usable gfx950 device (there is no CPU back-end) */
+    FR_ERR_NO_DEVICE = -2,   /* no usable gfx950 device (device >= 0 never falls back to the CPU; device = -1 asks for it) */
     FR_ERR_OOM = -3,         /* device or pinned-host allocation failed */
     FR_ERR_HIP = -4,         /* HIP runtime error; see fr_last_error() */
     FR_ERR_INDEX_RANGE = -5, /* a lookup index was >= the table's row count (reference: silent OOB,
@@ -167,6 +171,9 @@ int fr_abi_version(void);
 const char *fr_last_error(void); /* thread-local, never NULL */
 /* Number of visible HIP devices (0 when none; never fails).  cuda_server.c:508-522 device probe. */
 int fr_device_count(void);
+/* Host threads the CPU back-end (device = -1) spreads a call over: n >= 1 sets it, n = 0 = every usable core (the default); returns the
+ * number in use.  Process-wide; the back-end runs one parallel region at a time.  (No environment variable: the library reads none.) */
+int fr_cpu_set_threads(int n);
 
 /* ---- model descriptions ---------------------------------------------------------------------- */
 /* Built-in reference models; returned pointer is static, never freed. */
@@ -191,7 +198,15 @@ int fr_model_bank_map(const fr_model_desc *m, int32_t *bank_of_table, int64_t *b
  *      plus the FPGA host's table set-up (host.cpp:264-423,691-731) ----------------------------- */
 /* Validates `m`, selects `device`, allocates every table and the FC weights in HBM.
  * Shard [shard_rank, n_shards): n_shards == 1 keeps all tables; n_shards > 1 keeps only the tables of
- * segments assigned to this shard (table-ID sharding); see fr_ctx_shard_info. */
+ * segments assigned to this shard (table-ID sharding); see fr_ctx_shard_info.
+ * device = -1: the CPU back-end.  Tables and weights live in host memory (refused with FR_ERR_OOM when they cannot fit the host's RAM),
+ * the gather walks the same record-word descriptors the gfx950 kernels walk, the FC chain is a k-ordered fp32 multiply-add chain over
+ * the column-major weights (CUBLAS_COMPUTE_32F, cuda_server.c:211).  Available on such a context: everything in the "context" and
+ * "worker" sections, fr_worker_submit / submit_device / push_device (each computes before it returns) / sync, fr_worker_gather_only,
+ * fr_worker_fc_only, the fp32 forms of fr_worker_gather_slices / fr_worker_fc_from_slices(_lp), the fr_driver_* loops except the
+ * host-fed streaming one, the fr_device_* helpers ("device memory" is host memory there, so the same calling code runs against either
+ * back-end).  Not available (FR_ERR_STATE / FR_ERR_INVALID): bf16 / fp8 chains, host-fed streaming, RCCL, the diagnostics of
+ * fleetrec_diag.h that name kernels.  Records are bit-identical to the device's; fp32 scores agree to ~1e-6 (another summation order). */
 int fr_ctx_create(const fr_model_desc *m, int device, fr_ctx **out);
 int fr_ctx_create_sharded(const fr_model_desc *m, int device, int shard_rank, int n_shards, fr_ctx **out);
 void fr_ctx_destroy(fr_ctx *ctx);

@@ -1,5 +1,6 @@
-"""The C-ABI boundary: libfleetrec.so loads, exports every symbol include/fleetrec.h declares, and
-refuses to compute without a gfx950 device (no CPU fallback)."""
+"""The C-ABI boundary: libfleetrec.so loads, exports every symbol include/fleetrec.h declares, and a context asked for on a
+device >= 0 refuses to compute without a gfx950 device (no silent CPU fallback; device = -1 asks for the CPU back-end:
+tests/test_cpu_backend.py)."""
 import ctypes
 import os
 import re
@@ -23,7 +24,7 @@ def declared_symbols():
 
 def test_header_is_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "fleetrec.h"\n#include "fleetrec_serving.h"\n#include "fleetrec_diag.h"\nint main(void){ fr_model_desc d; (void)d; return FR_ABI_VERSION - 4; }\n')
+    src.write_text('#include "fleetrec.h"\n#include "fleetrec_serving.h"\n#include "fleetrec_diag.h"\nint main(void){ fr_model_desc d; (void)d; return FR_ABI_VERSION - 5; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
                            "-c", str(src), "-o", str(tmp_path / "t.o")])
 
@@ -34,7 +35,7 @@ def test_exports_every_declared_symbol(fr):
     L = ctypes.CDLL(fr.LIB_PATH)
     for s in syms:
         assert hasattr(L, s), "libfleetrec.so does not export %s" % s
-    assert fr.lib().fr_abi_version() == fr.ABI_VERSION == 4
+    assert fr.lib().fr_abi_version() == fr.ABI_VERSION == 5
     # nothing but the fr_* API is exported
     out = subprocess.check_output(["nm", "-D", "--defined-only", fr.LIB_PATH]).decode()
     exported = [l.split()[-1] for l in out.splitlines() if " T " in l]
@@ -63,13 +64,18 @@ def test_struct_layout_matches_header(fr, tmp_path):
     assert sizes == [ctypes.sizeof(fr.TableDesc), ctypes.sizeof(fr.Segment), ctypes.sizeof(fr.ModelDesc)]
 
 
-def test_no_cpu_fallback(fr):
-    """Without a device the product refuses loudly (this test only asserts on GPU-less machines)."""
+def test_no_silent_cpu_fallback(fr):
+    """Without a device a context on device >= 0 is refused loudly: the CPU back-end exists, but only when asked for by name (device = -1).
+    (This test only asserts on GPU-less machines.)"""
     if fr.device_count() > 0:
         pytest.skip("a HIP device is visible")
+    for dev in (0, 3):
+        with pytest.raises(fr.FleetRecError) as e:
+            fr.Context(fr.Model.builtin(fr.MODEL_A), device=dev)
+        assert e.value.status == fr.FR_ERR_NO_DEVICE and "never falls back to the CPU" in str(e.value)
     with pytest.raises(fr.FleetRecError) as e:
-        fr.Context(fr.Model.builtin(fr.MODEL_A), device=0)
-    assert e.value.status == fr.FR_ERR_NO_DEVICE and "no CPU back-end" in str(e.value)
+        fr.Context(fr.Model.builtin(fr.MODEL_A), device=-2)
+    assert e.value.status == fr.FR_ERR_NO_DEVICE
 
 
 def test_product_does_not_reference_oracle():

@@ -1,0 +1,324 @@
+"""The CPU back-end behind the same symbols (fr_ctx_create(..., device = -1); SURVEY section 8(b), BASELINE configs[0]): the library's
+own host code (csrc/fr_cpu.cpp) against the oracle.  Runs without a GPU.  Bar: records bit-exact; fp32 scores within 2e-6 of the
+fp64-accumulating oracle (max-abs over max|ref|, as in tests/test_gpu_parity.py: a k-ordered fp32 chain over K = 3968 terms carries ~1e-6
+of rounding by itself -- the oracle's own fp32 chain sits at 0.8e-6 from its fp64 one); the reference's known answers exact."""
+import ctypes
+import os
+import re
+import subprocess
+import time
+
+import numpy as np
+import pytest
+from conftest import free_port_block
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "gpu-fpga-recommendation-system_amd", "host")
+SEED_TABLES, SEED_WEIGHTS = 0xF1EE7, 99
+NAMES = {0: "A", 1: "B", 2: "C"}
+CPU = -1
+
+
+def rel_err(got, ref):
+    return float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def uniform_idx(rng, rows, B):
+    return (rng.random((B, len(rows))) * rows[None, :]).astype(np.int32)
+
+
+@pytest.mark.parametrize("which", [0, 1, 2])
+def test_records_bit_exact_and_scores_vs_oracle(fr, O, which):
+    """Models A / B / C (rows capped at 20 000 so that the tables fit any host), hashed tables, random weights, uniform per-table indices:
+    gather_only bit-exact, submit + sync and fc_only within 2e-6 of the fp64-accumulating oracle, the two bit-identical to each other,
+    ragged batches bit-identical to the same items inside a larger batch (the CPU chain has one summation order whatever the batch)."""
+    m = fr.Model.builtin(which).clone(max_rows=20000)
+    om = O.OracleModel(NAMES[which])
+    ctx = fr.Context(m, device=CPU)
+    ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    rng = np.random.default_rng(11 + which)
+    B = 300
+    idx = uniform_idx(rng, m.rows(), B)
+    idx[0], idx[1] = 0, m.rows() - 1
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32) if m.dense_len else None
+    wk = fr.Worker(ctx, 512)
+    rec = wk.gather_records(idx, dense).reshape(B, m.record_len)
+    want = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES)
+    assert np.array_equal(rec, want)
+    scores = wk.infer(idx, dense)
+    ws = [ctx.get_weights(l) for l in range(4)]
+    ref = om.fc_chain(want.view(np.float32), ws, acc64=True)
+    assert rel_err(scores, ref) <= 2e-6, rel_err(scores, ref)
+    assert np.array_equal(wk.fc_scores(want.view(np.float32)), scores)
+    for b in (1, 2, 3, 5, 63):
+        assert np.array_equal(wk.infer(idx[:b], None if dense is None else dense[:b]), scores[:b]), b
+    # the resident-buffer entry points (what fr_driver_run_resident calls): "device" memory of a CPU context is host memory
+    d_i = fr.DeviceBuffer.from_numpy(ctx, idx)
+    d_d = fr.DeviceBuffer.from_numpy(ctx, dense) if dense is not None else None
+    d_s = fr.DeviceBuffer(ctx, B * 4)
+    wk.submit_device(B, d_i, d_d, d_s)
+    wk.sync()
+    assert np.array_equal(d_s.download(np.float32, B), scores)
+    wk.push_device(B, d_i, d_d, d_s)
+    wk.sync()
+    assert np.array_equal(d_s.download(np.float32, B), scores)
+    # the fills are the device's fills (csrc/fr_content.h is one definition for both back-ends) = the oracle's content function
+    t = m.n_tables // 2
+    assert np.array_equal(ctx.download_table(t, 7, 5), rec_rows(O, om, m, t, 7, 5))
+    wk.close()
+    ctx.close()
+
+
+def rec_rows(O, om, m, t, row0, n):
+    """Rows [row0, row0 + n) of table t as the oracle's content function fills them (through a one-column gather)."""
+    idx = np.zeros((n, m.n_tables), np.int32)
+    idx[:, t] = np.arange(row0, row0 + n)
+    dense = np.zeros((n, m.dense_len), np.float32) if m.dense_len else None
+    full = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES)
+    seg = [s for s in m.segments() if s.kind == 0 and s.src == t][0]
+    return full[:, seg.rec_offset:seg.rec_offset + seg.len]
+
+
+@pytest.mark.parametrize("which", [0, 1, 2])
+def test_reference_literal_mode_known_answer(fr, O, which):
+    """The reference's own run on the CPU back-end: even/odd tables (host.cpp:66-88), ONE index per item broadcast to every table, the 32
+    fixed indices (embedding_47_krnl.cpp:899-914), all-ones weights (cuda_server.c:152-160) -> K * H1 * H2 * H3 or 0, exactly."""
+    m = fr.Model.builtin(which).clone(max_rows=200, index_mode=fr.INDEX_PER_ITEM)
+    om = O.OracleModel(NAMES[which])
+    ctx = fr.Context(m, device=CPU)
+    ctx.fill_tables(fr.FILL_EVEN_ODD, 0)
+    ctx.fill_weights(fr.WEIGHTS_ONES, 0)
+    idx = np.tile(om.halves[0].idx_random, 3)
+    B = len(idx)
+    dense = np.tile(np.where(idx % 2 == 0, 1.0, 0.0).astype(np.float32)[:, None], (1, m.dense_len)) if m.dense_len else None
+    wk = fr.Worker(ctx, B)
+    rec = wk.gather_records(idx[:, None], dense).reshape(B, m.record_len)
+    assert np.array_equal(rec, om.gather(idx, dense=dense, content_mode=O.FILL_EVEN_ODD))
+    assert all((rec[j] == (0x3F800000 if idx[j] % 2 == 0 else 0)).all() for j in range(B))
+    fc = m.fc
+    val = np.float32(float(fc[0]) * fc[1] * fc[2] * fc[3])
+    assert np.array_equal(wk.infer(idx[:, None], dense), np.where(idx % 2 == 0, val, np.float32(0)))
+    wk.close()
+    ctx.close()
+
+
+def test_readme_known_answers(fr):
+    """GPU/final_network_cublasLt_1_node_no_FIFO_scatter/README.md:7-11: K = 512 -> 2^36, K = 1024 -> 2^37 (batch 128, constant.h:32)."""
+    for K, want in ((512, 2.0 ** 36), (1024, 2.0 ** 37)):
+        T = fr.TableDesc(mem_class=0, table_id=0, source=0, dim=K, rows=4, bank=0, round=0, addr_axi=0)
+        S = fr.Segment(kind=fr.SEG_TABLE, src=0, src_col=0, rec_offset=0, len=K, source=0)
+        d = fr.ModelDesc()
+        d.name = b"readme"
+        d.n_tables, d.n_segments = 1, 1
+        d.tables = ctypes.pointer(T)
+        d.segments = ctypes.pointer(S)
+        d.record_len, d.dense_len = K, 0
+        for i, v in enumerate((K, 1024, 512, 256, 1)):
+            d.fc[i] = v
+        m = fr.Model(ctypes.pointer(d), keepalive=(T, S, d))
+        ctx = fr.Context(m, device=CPU)
+        ctx.upload_table(0, np.ones((4, K), np.float32))
+        ctx.fill_weights(fr.WEIGHTS_ONES, 0)
+        wk = fr.Worker(ctx, 128)
+        assert (wk.infer(np.zeros((128, 1), np.int32)) == np.float32(want)).all()
+        wk.close()
+        ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["bank", "blocked"])
+def test_bank_contract_and_3node_buffer(fr, O, mode):
+    """FR_INDEX_PER_BANK (one index per memory bank, bank-interleaved rows: the kernel's contract, embedding_377_krnl.cpp:1261-1290) and
+    FR_LAYOUT_BLOCKED (the 3-node server's receive buffer, 3-node cuda_server.c:515,541,566) on the CPU back-end, Model-C."""
+    base = fr.Model.builtin(fr.MODEL_C)
+    om = O.OracleModel("C")
+    rng = np.random.default_rng(5)
+    B = 96
+    if mode == "bank":
+        m = base.clone(max_rows=5000, index_mode=fr.INDEX_PER_BANK)
+        idx = uniform_idx(rng, m.index_ranges(), B)
+    else:
+        m = base.clone(max_rows=5000, layout=fr.LAYOUT_BLOCKED)
+        idx = uniform_idx(rng, m.rows(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+    ctx = fr.Context(m, device=CPU)
+    ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    wk = fr.Worker(ctx, B)
+    rec = wk.gather_records(idx, dense)
+    want = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES, per_bank=(mode == "bank"))
+    ws = [ctx.get_weights(l) for l in range(4)]
+    if mode == "bank":
+        assert np.array_equal(rec.reshape(B, -1), want)
+        x = want.view(np.float32)
+    else:   # [CPU: B x 64][FPGA0: B x 1952][FPGA1: B x 1952], then read by the GEMM as B x 3968 item-major
+        blocked = np.concatenate([want[:, 0:64].ravel(), want[:, 64:2016].ravel(), want[:, 2016:3968].ravel()])
+        assert np.array_equal(rec, blocked)
+        x = blocked.view(np.float32).reshape(B, m.record_len)
+    ref = om.fc_chain(x, ws, acc64=True)
+    assert rel_err(wk.infer(idx, dense), ref) <= 2e-6
+    wk.close()
+    ctx.close()
+
+
+def test_errors_and_what_the_cpu_back_end_refuses(fr):
+    m = fr.Model.builtin(fr.MODEL_A).clone(max_rows=1000)
+    ctx = fr.Context(m, device=CPU)
+    wk = fr.Worker(ctx, 64)
+    idx = np.zeros((8, m.n_tables), np.int32)
+    with pytest.raises(fr.FleetRecError) as e:          # tables not filled
+        wk.infer(idx)
+    assert e.value.status == fr.FR_ERR_STATE
+    ctx.fill_tables(fr.FILL_HASH, 1)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, 2)
+    good = wk.infer(idx)
+    bad = idx.copy()
+    bad[3, 5] = m.rows()[5]                             # one past the end of table 5 (reference: silent OOB, embedding_47_krnl.cpp:927-933)
+    with pytest.raises(fr.FleetRecError) as e:
+        wk.infer(bad)
+    assert e.value.status == fr.FR_ERR_INDEX_RANGE
+    assert np.array_equal(wk.infer(idx), good)          # the flag does not stick
+    wk.idx[:8] = idx
+    wk.submit(8)
+    with pytest.raises(fr.FleetRecError) as e:          # one batch in flight per worker, as on the device
+        wk.submit(8)
+    assert e.value.status == fr.FR_ERR_STATE
+    wk.sync()
+    for prec in (fr.FC_BF16, fr.FC_FP8):                # fp32 only
+        with pytest.raises(fr.FleetRecError) as e:
+            ctx.set_fc_precision(prec)
+        assert e.value.status == fr.FR_ERR_INVALID and "fp32 only" in str(e.value)
+    ctx.set_fc_precision(fr.FC_FP32)
+    sc = np.empty(8, np.float32)
+    with pytest.raises(fr.FleetRecError) as e:          # host-fed streaming is a device path
+        wk.push_host(idx, None, sc)
+    assert e.value.status == fr.FR_ERR_STATE and "CPU back-end" in str(e.value)
+    with pytest.raises(fr.FleetRecError):
+        wk.fc_layer_only(8, 0)
+    with pytest.raises(fr.FleetRecError):
+        wk.calibrate_fp8(idx)
+    with pytest.raises(fr.FleetRecError):
+        fr.Comm.init_rank(ctx, b"\0" * 128)
+    assert fr.cpu_set_threads(2) == 2 and np.array_equal(wk.infer(idx), good)   # the thread count changes no bit
+    assert fr.cpu_set_threads(0) >= 1
+    with pytest.raises(fr.FleetRecError):
+        fr.cpu_set_threads(-3)
+    wk.close()
+    ctx.close()
+    # a device >= 0 never falls back to the CPU
+    if fr.device_count() == 0:
+        with pytest.raises(fr.FleetRecError) as e:
+            fr.Context(m, device=0)
+        assert e.value.status == fr.FR_ERR_NO_DEVICE
+    # tables that cannot fit the host are refused up front instead of being killed half-way through the fill
+    huge = fr.Model.builtin(fr.MODEL_C).clone(row_scale=40.0)
+    with pytest.raises(fr.FleetRecError) as e:
+        fr.Context(huge, device=CPU)
+    assert e.value.status == fr.FR_ERR_OOM
+
+
+def test_table_sharded_contexts_on_the_cpu(fr, O):
+    """BASELINE configs[3]'s data flow through the CPU back-end: Model-C's eight table-ID shards as eight CPU contexts, every shard's slice
+    bit-exact, and fr_worker_fc_from_slices on the all-gathered layout for every rank's B/G items = the unsharded context's scores, bit
+    for bit (the chain's summation order does not depend on how the record was assembled)."""
+    import importlib
+    dist_mod = importlib.import_module("fleetrec_amd.dist")
+    G, B = 8, 100
+    m = fr.Model.builtin(fr.MODEL_C).clone(max_rows=3000)
+    om = O.OracleModel("C")
+    offs, lens, F = m.shard_plan(G)
+    rng = np.random.default_rng(8)
+    idx = uniform_idx(rng, m.rows(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+    full = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES)
+    shards, slices = [], []
+    for r in range(G):
+        c = fr.Context(m, device=CPU, shard_rank=r, n_shards=G)
+        c.fill_tables(fr.FILL_HASH, SEED_TABLES)
+        c.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+        wk = fr.Worker(c, B)
+        sl = wk.gather_records(idx, dense).reshape(B, F)
+        assert np.array_equal(sl[:, :lens[r]], full[:, offs[r]:offs[r] + lens[r]]), r
+        with pytest.raises(fr.FleetRecError):
+            wk.infer(idx, dense)                         # submit on a sharded context: as on the device, use the sharded entry points
+        shards.append((c, wk))
+        slices.append(sl)
+    gathered = np.stack(slices)
+    whole = fr.Context(m, device=CPU)
+    whole.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    whole.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    w0 = fr.Worker(whole, B)
+    ref = w0.infer(idx, dense)
+    scores = np.empty(B, np.float32)
+    for r, (c, wk) in enumerate(shards):
+        lo, hi = dist_mod.item_range(r, G, B)
+        d_g = fr.DeviceBuffer.from_numpy(c, gathered)
+        d_s = fr.DeviceBuffer(c, max(hi - lo, 1) * 4)
+        wk.fc_from_slices_lp(B, lo, hi - lo, d_g, fr.FC_FP32, d_s)
+        wk.sync()
+        scores[lo:hi] = d_s.download(np.float32, hi - lo)
+        with pytest.raises(fr.FleetRecError):
+            wk.fc_from_slices_lp(B, lo, hi - lo, d_g, fr.FC_BF16, d_s)   # low-precision transports are device paths
+    assert np.array_equal(scores, ref)
+    for c, wk in shards:
+        wk.close()
+        c.close()
+    w0.close()
+    whole.close()
+
+
+def test_driver_loops_on_the_cpu(fr, O):
+    """main() + the thread_consume() batch loop (cuda_server.c:23-25,406-497,554-560) over a CPU context: THREAD_NUM threads drawing batch
+    ids from the mutex-guarded counter, resident and host-buffer forms; the scores in the rings are the worker's own."""
+    m = fr.Model.builtin(fr.MODEL_A).clone(max_rows=5000)
+    ctx = fr.Context(m, device=CPU)
+    ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    rng = np.random.default_rng(3)
+    B = 32
+    host = [uniform_idx(rng, m.rows(), B) for _ in range(4)]
+    pool = [fr.DeviceBuffer.from_numpy(ctx, a) for a in host]
+    wk = fr.Worker(ctx, B)
+    want = [wk.infer(a) for a in host]
+    dv = fr.Driver(ctx, 2, 2, B)
+    assert dv.run_resident(B, 24, pool) > 0
+    ring = dv.score_ring(0, 0, B)
+    assert any(any(np.array_equal(ring[k], w_) for w_ in want) for k in range(4))
+    assert dv.run_host(B, 24, host) > 0
+    with pytest.raises(fr.FleetRecError):
+        dv.run_host(B, 8, host, streaming=True)
+    dv.close()
+    wk.close()
+    ctx.close()
+
+
+def test_server_answers_the_sender_on_the_cpu_back_end(fr):
+    """BASELINE configs[0] end to end -- "Model-A batch = 1 ... on host CPU (plumbing, no accelerator)": fleetrec_server --device -1 takes
+    batches of ONE item from fleetrec_sender over TCP, with the reference's data (even/odd tables, the 32 fixed indices, all-ones weights):
+    every thread's last score is K * H1 * H2 * H3 or 0 (cuda_server.c:499-502 prints the first five of the last batch; a batch of one has one)."""
+    if not os.path.exists(os.path.join(HOST, "fleetrec_server")):
+        subprocess.check_call(["make", "-s", "-C", HOST])
+    for batch, total in ((1, 64), (128, 16)):
+        threads = 2
+        port = free_port_block(threads)
+        srv = subprocess.Popen([os.path.join(HOST, "fleetrec_server"), "--model", "A", "--batch", str(batch), "--threads", str(threads), "--port", str(port),
+                                "--total", str(total), "--tables", "evenodd", "--weights", "ones", "--device", "-1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        time.sleep(0.5)
+        snd = subprocess.Popen([os.path.join(HOST, "fleetrec_sender"), "--model", "A", "--batch", str(batch), "--threads", str(threads), "--port", str(port),
+                                "--indices", "reference"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        try:
+            out, _ = srv.communicate(timeout=120)
+            snd.communicate(timeout=60)
+        finally:
+            for p in (srv, snd):
+                if p.poll() is None:
+                    p.kill()
+        out = out.decode()
+        assert srv.returncode == 0, out
+        assert "processed %d batches" % total in out, out
+        rows = re.findall(r"thread \d+ scores:((?: [-0-9.e+]+)+)", out)
+        assert rows, out
+        val = 352.0 * 2 ** 27
+        for r in rows:
+            v = [float(x) for x in r.split()]
+            assert v == ([0.0, 0.0, val, val, 0.0] if batch >= 5 else v) and all(x in (0.0, val) for x in v), (v, out)
