@@ -58,7 +58,7 @@ _lib = None
 
 # every symbol include/fleetrec.h, fleetrec_serving.h and fleetrec_diag.h declare (the not-gpu test checks the .so exports all of them)
 ABI_SYMBOLS = [
-    "fr_abi_version", "fr_last_error", "fr_device_count", "fr_cpu_set_threads", "fr_model_builtin", "fr_model_clone_scaled", "fr_model_free",
+    "fr_abi_version", "fr_last_error", "fr_device_count", "fr_cpu_set_threads", "fr_ctx_set_chain_width", "fr_ctx_chain_width", "fr_model_builtin", "fr_model_clone_scaled", "fr_model_free",
     "fr_model_table_bytes", "fr_model_index_cols", "fr_model_bank_map", "fr_ctx_set_gather_variant", "fr_ctx_gather_variant",
     "fr_ctx_gather_merged_lookups", "fr_ctx_gather_groups", "fr_comm_unique_id", "fr_comm_init_rank", "fr_comm_init_all", "fr_comm_destroy", "fr_comm_set_wait_ms",
     "fr_worker_submit_sharded", "fr_worker_calibrate_fp8_sharded", "fr_ctx_create", "fr_ctx_create_sharded", "fr_ctx_destroy", "fr_ctx_model",
@@ -85,7 +85,7 @@ def lib():
     vp, i32, i64, u32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint32, ctypes.c_size_t
     pf, pi = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)
     sig = {
-        "fr_abi_version": (i32, []), "fr_last_error": (ctypes.c_char_p, []), "fr_device_count": (i32, []), "fr_cpu_set_threads": (i32, [i32]),
+        "fr_abi_version": (i32, []), "fr_last_error": (ctypes.c_char_p, []), "fr_device_count": (i32, []), "fr_cpu_set_threads": (i32, [i32]), "fr_ctx_set_chain_width": (i32, [vp, i32]), "fr_ctx_chain_width": (i32, [vp]),
         "fr_model_builtin": (ctypes.POINTER(ModelDesc), [i32]),
         "fr_model_clone_scaled": (i32, [ctypes.POINTER(ModelDesc), ctypes.c_double, i64, i64, ctypes.POINTER(ctypes.POINTER(ModelDesc))]),
         "fr_model_free": (None, [ctypes.POINTER(ModelDesc)]),
@@ -474,6 +474,14 @@ class Context:
 
     def set_stream_group(self, batches_per_launch):
         _check(lib().fr_ctx_set_stream_group(self._h, batches_per_launch))
+
+    def set_chain_width(self, width):
+        """Chain width W (1..4): a chain model's bf16 / fp8 GEMM layers take tiles covering 1 / W of the chip (fr_ctx_set_chain_width)."""
+        _check(lib().fr_ctx_set_chain_width(self._h, width))
+
+    def chain_width(self):
+        """The context's chain width; 0 while undecided (the first low-precision GEMM-layer launch freezes it)."""
+        return lib().fr_ctx_chain_width(self._h)
 
     def set_small_block(self, max_batches):
         """Host-fed blocks of at most max_batches batches take fr_worker_submit's stage launches instead of the fused kernel (latency)."""

@@ -760,6 +760,12 @@ extern "C" void fr_worker_destroy(fr_worker *w) {
         if (p) (void)hipFree(p);
     for (hipEvent_t e : w->hr.ev)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : w->hr.ev_in)
+        if (e) (void)hipEventDestroy(e);
+    if (w->hr.copy) {
+        (void)hipStreamSynchronize(w->hr.copy);
+        (void)hipStreamDestroy(w->hr.copy);
+    }
     if (w->h_blist) (void)hipHostFree(w->h_blist);
     if (w->d_blist) (void)hipFree(w->d_blist);
     for (hipEvent_t e : w->ev_blist)
@@ -836,11 +842,16 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
         // the default priority in the rotation, a context served earlier in the process had that effect).  Model-C 4096, four workers:
         // bf16 41.9 -> 43.1 M inf/s, fp8 65.5 -> 68.9 M = what GPU_MAX_HW_QUEUES=8 buys (profiles/r04_stream_priorities_ab.txt).
         // Fused-kernel models (one launch per group) gain nothing from it and keep the default streams.
-        const bool chain = !(ctx->n_shards == 1 && m.layout == FR_LAYOUT_SEMANTIC && frk_fused_ok(m.fc[0], m.fc[1], m.fc[2], m.fc[3]));
+        // (a model no fused kernel of any precision serves -- the decision must not depend on the precision the context happens to have now)
+        const bool any_fused = frk_fused_ok(m.fc[0], m.fc[1], m.fc[2], m.fc[3]) || frk_fused_h_ok(m.fc[0], m.fc[1], m.fc[2], m.fc[3]) ||
+                               frk_fused_f8_ok(m.fc[0], m.fc[1], m.fc[2], m.fc[3]) || ctx->hk_ok == 1;
+        const bool chain = !(ctx->n_shards == 1 && m.layout == FR_LAYOUT_SEMANTIC && any_fused);
         const int spread = FR_KNOB_ONCE("STREAM_PRIO", -1);   // experiment knob: 0 = never, 1 = always, 2 = rotate over every level (default included)
         int lo = 0, hi = 0;   // numerically lower = higher priority
         if (spread < 0 ? chain : spread != 0) W_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        const int k = ctx->n_workers.load(std::memory_order_relaxed);
+        // k = how many workers the context has EVER created (one fetch_add: two threads creating workers at once cannot draw the same k, and a
+        // destroy + create keeps alternating -- ADVICE r04: the live count did neither)
+        const int k = ctx->worker_seq.fetch_add(1, std::memory_order_relaxed);
         if (lo > hi) W_HIP(hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, spread == 2 ? hi + k % (lo - hi + 1) : (k % 2 ? lo : hi)));
         else W_HIP(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
     }
@@ -968,6 +979,26 @@ static ActSet act_set(const fr_worker *w, int parity) {
     a.p3 = (size_t)fc[3] * ld;
     return a;
 }
+
+// The context's chain width: frozen by the first low-precision GEMM-layer launch at min(live workers, 4) unless fr_ctx_set_chain_width
+// decided it before; from then on only that call changes it.
+static int chain_width(fr_ctx *c) {
+    int w = c->chain_width.load(std::memory_order_relaxed);
+    if (w) return w;
+    const int live = c->n_workers.load(std::memory_order_relaxed);
+    const int want = live < 1 ? 1 : (live > 4 ? 4 : live);
+    int expected = 0;
+    return c->chain_width.compare_exchange_strong(expected, want, std::memory_order_relaxed) ? want : expected;
+}
+
+extern "C" int fr_ctx_set_chain_width(fr_ctx *ctx, int width) {
+    if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
+    if (width < 1 || width > 4) FR_FAIL(FR_ERR_INVALID, "chain width %d outside [1, 4]", width);
+    ctx->chain_width.store(width, std::memory_order_relaxed);
+    return FR_OK;
+}
+
+extern "C" int fr_ctx_chain_width(const fr_ctx *ctx) { return ctx ? ctx->chain_width.load(std::memory_order_relaxed) : FR_ERR_INVALID; }
 
 // Issue ONE pipeline launch: every in-flight batch advances by one stage; `fresh` (may be NULL) enters at stage 0.
 // only_stage >= 0: debugging/roofline -- run just that stage of the (single) in-flight batch as its own kernel.
@@ -1100,7 +1131,7 @@ static int pipeline_step(fr_worker *w) {
                 FR_HIP(hipEventRecord(w->ev_x_free[par], w->stream));
                 w->x_free_set[par] = true;
             }
-            int rc = frk_fc_lp_gemm(prec, st.w, st.in, st.out, st.K, st.N, ldm, st.e_w, st.e_in, st.e_out, c->n_workers.load(std::memory_order_relaxed), w->stream);
+            int rc = frk_fc_lp_gemm(prec, st.w, st.in, st.out, st.K, st.N, ldm, st.e_w, st.e_in, st.e_out, prec == FR_FC_FP32 ? 1 : chain_width(c), w->stream);
             if (rc) return rc;
             if (s == 1 && w->aux && FR_KNOB_ONCE("GATHER_AUX", 0) != 2) {  // X[par ^ 1] may be overwritten by the gather of the NEXT step once this launch has finished
                 FR_HIP(hipEventRecord(w->ev_x_free[par ^ 1], w->stream));
@@ -1716,6 +1747,8 @@ static int host_ring_init(fr_worker *w) {
     FR_HIP(hipHostMalloc((void **)&r.h_sc, slots * r.score_slot * sizeof(float), hipHostMallocDefault));
     FR_HIP(hipMalloc((void **)&r.d_sc, slots * r.score_slot * sizeof(float)));
     for (int b = 0; b < FR_HOST_BLOCKS; b++) FR_HIP(hipEventCreateWithFlags(&r.ev[b], hipEventDisableTiming));
+    FR_HIP(hipStreamCreateWithFlags(&r.copy, hipStreamNonBlocking));
+    for (int b = 0; b < FR_HOST_BLOCKS; b++) FR_HIP(hipEventCreateWithFlags(&r.ev_in[b], hipEventDisableTiming));
     r.g = g;
     return FR_OK;
 }
@@ -1762,19 +1795,35 @@ static int host_block_launch(fr_worker *w) {
         r.cur = (b + 1) % FR_HOST_BLOCKS;
         return FR_OK;
     }
-    FR_HIP(hipMemcpyAsync(r.d_idx + s0 * r.idx_slot, r.h_idx + s0 * r.idx_slot, (size_t)n * r.idx_slot * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
-    if (r.dense_slot)
-        FR_HIP(hipMemcpyAsync(r.d_dense + s0 * r.dense_slot, r.h_dense + s0 * r.dense_slot, (size_t)n * r.dense_slot * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    // The two PCIe hops of the reference's loop (cuda_server.c:460-461,494-495), arranged so that the worker's stream carries NOTHING but its
+    // kernels: the block's index rows travel as one H2D copy on the worker's COPY stream -- issued now, while the previous block's kernel
+    // still runs, and joined by an event the launch waits for (long satisfied when the launch reaches the head of its hardware queue) --
+    // and the output layer writes the scores straight into the pinned staging (no D2H command).  With both copies as commands of the one
+    // stream (round 4) a block's H2D could not start before the previous block's D2H, its 130 us sat between two launches of the stream,
+    // and the barrier packet in front of the launch held back every other stream that shares the hardware queue: 95-96 % of the
+    // HBM-resident rate with 8 streams on 4 queues; this form: 98-99 % (profiles/r05_host_fed_timeline.txt).
+    // Experiments build: FR_HOST_ZEROCOPY 0 = round 4's commands, 1 = no H2D either (the kernel reads the rows over PCIe: slower), 2 = H2D on the worker's stream.
+    const int zc = FR_KNOB_ONCE("HOST_ZEROCOPY", 3);
+    hipStream_t cs = zc == 3 ? r.copy : w->stream;
+    if (zc != 1) {
+        FR_HIP(hipMemcpyAsync(r.d_idx + s0 * r.idx_slot, r.h_idx + s0 * r.idx_slot, (size_t)n * r.idx_slot * sizeof(int32_t), hipMemcpyHostToDevice, cs));
+        if (r.dense_slot)
+            FR_HIP(hipMemcpyAsync(r.d_dense + s0 * r.dense_slot, r.h_dense + s0 * r.dense_slot, (size_t)n * r.dense_slot * sizeof(float), hipMemcpyHostToDevice, cs));
+        if (zc == 3) {   // (the device block is free: host_slot_prepare delivered its previous use -- its kernel has finished -- before refilling the staging)
+            FR_HIP(hipEventRecord(r.ev_in[b], r.copy));
+            FR_HIP(hipStreamWaitEvent(w->stream, r.ev_in[b], 0));
+        }
+    }
     for (int i = 0; i < n; i++) {
         FrFusedBatch &fb = w->pending[w->n_pending++];
-        fb.idx = r.d_idx + (s0 + i) * r.idx_slot;
-        fb.dense = r.dense_slot ? r.d_dense + (s0 + i) * r.dense_slot : nullptr;
-        fb.scores = r.d_sc + (s0 + i) * r.score_slot;
+        fb.idx = (zc == 1 ? r.h_idx : r.d_idx) + (s0 + i) * r.idx_slot;
+        fb.dense = r.dense_slot ? (zc == 1 ? r.h_dense : r.d_dense) + (s0 + i) * r.dense_slot : nullptr;
+        fb.scores = (zc ? r.h_sc : r.d_sc) + (s0 + i) * r.score_slot;
         fb.batch = r.bsz[b][i];
     }
     rc = fused_flush(w);
     if (rc) return rc;
-    FR_HIP(hipMemcpyAsync(r.h_sc + s0 * r.score_slot, r.d_sc + s0 * r.score_slot, (size_t)n * r.score_slot * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+    if (!zc) FR_HIP(hipMemcpyAsync(r.h_sc + s0 * r.score_slot, r.d_sc + s0 * r.score_slot, (size_t)n * r.score_slot * sizeof(float), hipMemcpyDeviceToHost, w->stream));
     FR_HIP(hipEventRecord(r.ev[b], w->stream));
     r.inflight[b] = true;
     r.cur = (b + 1) % FR_HOST_BLOCKS;

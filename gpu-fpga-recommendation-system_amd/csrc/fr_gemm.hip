@@ -1014,7 +1014,7 @@ static int pipe_gemm_dispatch(int shape, const void *Wp, const void *Xp, void *Y
 // Which block tile serves the layer: 2 = 128 (n) x 256 (m) when those tiles cover most of the chip, 1 = 128 x 128, 3 = 64 x 128 for layers
 // with few outputs (Model-C FC2 / FC3 at batch 4096: 512 / 256 outputs -> 256 / 128 tiles instead of 128 / 64), 0 = not worth a GEMM
 // launch (the stage pipeline's per-tile body takes it).
-static int lp_gemm_mu(int precision, int K, int N, int ldm, int workers = 1) {
+static int lp_gemm_mu(int precision, int K, int N, int ldm, int width = 1) {
     const int forced = FR_KNOB_ONCE("LP_GEMM", -1);  // experiment knob: 0 = never, 1 / 2 / 3 = only that tile
     const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : (precision == FR_FC_BF16 ? K / 8 : K / 4);
     if ((precision == FR_FC_BF16 && K % 8) || (precision == FR_FC_FP32 && K % 4) || KE % FR_GR || KE / FR_GR < 2 || N % 64 || ldm % 128) return 0;
@@ -1043,14 +1043,15 @@ static int lp_gemm_mu(int precision, int K, int N, int ldm, int workers = 1) {
     // the CU's vector-memory return path, which is what the 128 x 256 kernel keeps busy (texture data return busy 0.73, MFMA busy 0.50:
     // profiles/r04_pmc_gemm_bf16.json); bf16 / fp8 only (the fp32 kernel is MFMA-bound)
     const long t256sq = (N % 256 || ldm % 256) ? 0 : (long)(N / 256) * (ldm / 256);
-    // `workers` = live workers of the context (fr_ctx::n_workers).  With W of them the larger tile is taken as soon as it covers 1 / min(W, 4)
+    // `width` = the context's chain width W (fr_ctx_set_chain_width; frozen at min(live workers, 4) by the context's first low-precision
+    // GEMM-layer launch otherwise).  The larger tile is taken as soon as it covers 1 / W
     // of the chip: a chain model's workers sit on their own hardware queues (fr_worker_create) and run their chains side by side, so W
     // part-chip launches of the cheaper tile (fewer operand bytes per output through the CU's vector-memory path) share the chip where W
     // full-chip launches time-share every CU.  Model-C batch 4096, four workers: FC1 8 x 16 tiles of 256 x 256 (for 256 of 128 x 256), FC2
     // 4 x 16 of 128 x 256 (for 256 of 64 x 128), FC3 2 x 32 of 128 x 128: bf16 38.4 -> 44.5 M inf/s, fp8 62.6 -> 69.0 M; a lone worker on
     // half-chip tiles would lose 15-18 % (profiles/r04_C4096_half_chip_tiles_ab.txt).  bf16 / fp8 only (the fp32 kernel is MFMA-bound).
     const int part_knob = FR_KNOB_ONCE("LP_GEMM_PART", -1);   // experiment knob: the divisor (1 = full-chip tiles only, 2, 4), whatever the worker count
-    const int part = precision == FR_FC_FP32 ? 1 : (part_knob > 0 ? part_knob : (workers < 1 ? 1 : (workers > 4 ? 4 : workers)));
+    const int part = precision == FR_FC_FP32 ? 1 : (part_knob > 0 ? part_knob : (width < 1 ? 1 : (width > 4 ? 4 : width)));
     const long full = 192 / part;
     if (precision != FR_FC_FP32 && t256sq >= full && FR_KNOB_ONCE("LP_GEMM_256", 1)) return 6;
     if (t256 >= full) return 2;
@@ -1167,8 +1168,8 @@ int frk_fc_gemm_gather(int precision, const void *Wp, const void *Xp, void *Yp, 
 #endif
 }
 
-int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, int workers, hipStream_t s) {
-    const int mu = lp_gemm_mu(precision, K, N, ldm, workers);
+int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, int width, hipStream_t s) {
+    const int mu = lp_gemm_mu(precision, K, N, ldm, width);
     if (mu == 0) FR_FAIL(FR_ERR_INVALID, "internal: layer %d x %d x %d is not a GEMM-kernel layer", K, N, ldm);
     const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : (precision == FR_FC_BF16 ? K / 8 : K / 4);
     if (precision == FR_FC_FP32) return lp_gemm_tile<0>(mu, Wp, Xp, Yp, KE, N, ldm, 0, 0, 1.0f, s);

@@ -222,7 +222,12 @@ struct fr_ctx {
     std::atomic<int> small_block{0};
     int n_cu = 0;                          // compute units of the device (grid of the persistent fused kernel); set at creation
     int hk_ok = 0;                         // the persistent K-outer fused kernel applies to this context's descriptors; set at creation
-    std::atomic<int> n_workers{0};         // live workers of the context: W of them -> GEMM layers take tiles that cover 1 / min(W, 4) of the chip (lp_gemm_mu)
+    std::atomic<int> n_workers{0};         // live workers of the context
+    std::atomic<int> worker_seq{0};        // workers ever created on the context: a chain model's k-th worker takes the highest (k even) / lowest (k odd) stream priority
+    // chain width W (fr_ctx_set_chain_width): the bf16 / fp8 GEMM layers of a chain model take tiles that cover 1 / W of the chip (lp_gemm_mu).
+    // 0 = not decided yet: the first low-precision GEMM-layer launch on the context freezes it at min(live workers, 4); from then on only an
+    // explicit fr_ctx_set_chain_width changes it -- never a worker coming or going
+    std::atomic<int> chain_width{0};
 };
 
 struct fr_worker {
@@ -286,6 +291,8 @@ struct fr_worker {
         int32_t *h_idx = nullptr, *d_idx = nullptr;
         float *h_dense = nullptr, *d_dense = nullptr, *h_sc = nullptr, *d_sc = nullptr;
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        hipStream_t copy = nullptr;   // the blocks' H2D copies run here, ahead of the launches on the worker's stream (ev_in: block b's rows have landed)
+        hipEvent_t ev_in[4] = {nullptr, nullptr, nullptr, nullptr};
         bool inflight[4] = {false, false, false, false};
         int count[4] = {0, 0, 0, 0};          // batches in the block
         float *dst[4][FR_FUSED_MAX_BATCHES];  // where each batch's scores go
@@ -346,8 +353,8 @@ int frk_transpose_slices_lp(int precision, const void *gathered, int n_shards, i
 int frk_pipeline_launch(const FrPipeArgs &a, int single_stage, int precision, hipStream_t s);
 int frk_pack_weights_q8_bf16(const float *W, uint16_t *Wh, int K, int H, hipStream_t s);
 bool frk_fc_lp_gemm_ok(int precision, int K, int N, int ldm);
-// workers: live workers of the context -> the larger tile already when it covers 1 / min(workers, 4) of the chip (lp_gemm_mu)
-int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, int workers, hipStream_t s);
+// width: the context's chain width (fr_ctx::chain_width) -> the larger tile already when it covers 1 / width of the chip (lp_gemm_mu)
+int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, int width, hipStream_t s);
 bool frk_fc_gemm_gather_ok(int precision, int K, int N, int ldm);   // FC1 of batch L - 1 + the gather of batch L in one launch (fc_gemm_gather_kernel)
 int frk_fc_gemm_gather(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, const FrWordDesc *words, int n_words,
                        int idx_stride, const int32_t *idx, const float *dense, int g_batch, int g_ldm, int g_K, void *g_out, int g_e_x, int *err_flag, hipStream_t s);

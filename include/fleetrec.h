@@ -235,10 +235,22 @@ int fr_ctx_set_fp8_act_exponents(fr_ctx *ctx, const int act_exp[4]);
 /* ---- worker: replaces thread_consume()'s set-up (cuda_server.c:110-354) --------------------- */
 /* One worker = one stream + its buffers (the reference's per-thread cudaStream_t, pinned and device buffers).  Workers of one context
  * share the chip: a model that runs as a chain of launches per batch (Model-C; any sharded context) gets each worker a hardware queue of
- * its own (streams created alternately on the highest and the lowest stream priority), and with W live workers its bf16 / fp8 GEMM layers
- * use tiles that cover 1 / min(W, 4) of the chip, so create the workers a context will use BEFORE timing anything on it.  Scores do not
- * depend on W beyond the precision's tolerance (fp8: bit-identical; bf16: <= 1e-2 relative between tile shapes). */
+ * its own -- the k-th worker EVER created on the context takes the highest (k even) or the lowest (k odd) stream priority, never the
+ * default one.  Side effect across contexts of one process: a lowest-priority worker can be held back by default-priority streams of
+ * other contexts or of a host framework, a highest-priority one runs ahead of them (measured on this chip: the priority only selects the
+ * queue pool, profiles/r04_experiments.md section 6.7); fused-kernel models (A, B) keep default-priority streams. */
 int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out);
+/* Chain width W (1..4) of a chain model: its bf16 / fp8 GEMM layers use tiles that cover 1 / W of the chip, so that W workers' chains run
+ * side by side on part-chip tiles (fewer operand bytes per output) instead of time-sharing every compute unit: Model-C batch 4096, W = 4:
+ * bf16 +16 %, fp8 +10 %; a lone busy worker at W = 4 loses 15-18 % (profiles/r04_C4096_half_chip_tiles_ab.txt).  CONTRACT: the width is
+ * decided ONCE per context -- by this call, or else by the context's first low-precision GEMM-layer launch, which freezes it at
+ * min(workers alive at that moment, 4) -- and never follows workers coming or going afterwards: scores of a stream in flight cannot
+ * change because an unrelated worker was created or destroyed.  Call it again only on purpose: it takes effect from the next launch on,
+ * and in bf16 the tile shape fixes the summation order (<= 1e-2 relative between widths; fp8 and fp32 scores are bit-identical for every
+ * width).  fr_ctx_chain_width: the current value, 0 while undecided.  Set W = 1 if a runtime update should ever stop giving the
+ * workers hardware queues of their own (tests/test_gpu_parity.py::test_chain_workers_run_their_layers_side_by_side guards that). */
+int fr_ctx_set_chain_width(fr_ctx *ctx, int width);
+int fr_ctx_chain_width(const fr_ctx *ctx);
 void fr_worker_destroy(fr_worker *w);
 /* Pinned host staging buffers the driver's socket read() lands in directly (cuda_server.c:437 reads
  * into pinned input_feature): int32 idx[max_batch][fr_model_index_cols(model)],
