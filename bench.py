@@ -42,8 +42,8 @@ MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0}   # dense MFMA peak
 SEED_TABLES, SEED_IDX, SEED_WEIGHTS = 0xF1EE7, 1234, 99
 N_IDX_BUFFERS = 64           # distinct index buffers rotated through (>= 32), so caches are not re-hit artificially
 STEADY_S = 2.2               # minimum wall clock of the timed region behind `value`
-PROFILE_ROUND = "r04"       # prefix of the committed rocprofv3 summaries the roofline objects quote (profiles/<round>_*_kernel_stats.csv)
-PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json")]   # newest first, entry by entry (see pmc())
+PROFILE_ROUND = "r05"       # prefix of the committed rocprofv3 summaries the roofline objects quote (profiles/<round>_*_kernel_stats.csv)
+PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json")]   # newest first, entry by entry (see pmc())
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -126,12 +126,12 @@ def compact_line(result):
     line = {k: result.get(k) for k in keys}
     cfg = dict(result.get("config") or {})
     line["config"] = cfg
-    for k in ("timed_batches", "timed_s", "value_pcie_inclusive", "sharded_error"):
+    for k in ("timed_batches", "timed_s", "value_pcie_inclusive", "value_hbm_resident", "sharded_error", "leg_seconds_total"):
         if result.get(k) is not None:
             line[k] = result[k]
     rf = result.get("roofline")
     if rf:
-        line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_name", "avg_launch_ms", "batches_per_launch",
+        line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_name", "avg_launch_ms", "batches_per_launch", "achieved_is",
                                       "concurrent_launches", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch", "profiled_avg_launch_us", "profile", "pmc_mfma_busy_fraction"))
         line["roofline"].setdefault("traffic", None)
     cb = result.get("cpu_baseline")
@@ -171,6 +171,15 @@ def compact_line(result):
             s = json.dumps(line, separators=(",", ":"))
             if len(s) < LINE_LIMIT:
                 break
+    if len(s) >= LINE_LIMIT:   # the mandatory keys alone are too long: shorten the free-text fields, the workload string last
+        for holder, key, keep in ((line.get("cpu_baseline") or {}, "sample", 60), (line.get("cpu_baseline") or {}, "blas", 24), (line.get("roofline") or {}, "kernel_name", 48),
+                                  (line["config"], "workload", 200), (line["config"], "workload", 60)):
+            if isinstance(holder.get(key), str) and len(holder[key]) > keep:
+                holder[key] = holder[key][:keep - 3] + "..."
+            s = json.dumps(line, separators=(",", ":"))
+            if len(s) < LINE_LIMIT:
+                break
+    assert len(s) < LINE_LIMIT, "bench.py: the stdout line is %d bytes (limit %d)" % (len(s), LINE_LIMIT)
     return s
 
 
@@ -275,7 +284,7 @@ def pmc(key, field=None):
 
 def find_profile(suffix):
     """Newest committed rocprofv3 summary profiles/rNN_<suffix> (this round's, else an earlier round's for legs whose kernel did not change)."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         if os.path.exists(os.path.join(ROOT, "profiles", "%s_%s" % (rnd, suffix))):
             return "%s_%s" % (rnd, suffix)
     return "%s_%s" % (PROFILE_ROUND, suffix)
@@ -503,10 +512,20 @@ def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=
     if blas is not None:
         try:
             import torch
-            budget_main, budget_s = budget_s, min(budget_s, 1.5)
-            t_rate, t_reps = timed(lambda i: cpu_fc_chain(None, X, ws, fc, bufs))
+            budget_main, budget_s = budget_s, min(budget_s, 1.0)
+            # torch.mm at its own default thread count AND at every usable core (the baseline must not idle three quarters
+            # of the host because one BLAS build caps at 64 threads); the faster setting stays and is what `cores` reports
+            t_default = torch.get_num_threads()
+            tries = {}
+            for nt in sorted({t_default, usable}):
+                torch.set_num_threads(nt)
+                tries[nt] = timed(lambda i: cpu_fc_chain(None, X, ws, fc, bufs))
+            t_threads = max(tries, key=lambda k: tries[k][0])
+            torch.set_num_threads(t_threads)
+            t_rate, t_reps = tries[t_threads]
             budget_s = budget_main
-            alt = {"engine": "torch.mm", "fc_only": t_rate, "fc_GFLOPs": t_rate * fc_flops_per_inference(fc) / 1e9, "threads": torch.get_num_threads(),
+            alt = {"engine": "torch.mm", "fc_only": t_rate, "fc_GFLOPs": t_rate * fc_flops_per_inference(fc) / 1e9, "threads": t_threads,
+                   "fc_only_by_threads": {str(k): v[0] for k, v in tries.items()},
                    "build": ", ".join(tok.strip() for ln in torch.__config__.show().split("\n") for tok in ln.split(",") if "BLAS_INFO" in tok or "USE_MKL=" in tok),
                    "calls": t_reps}
             if t_rate > f_rate:
@@ -524,30 +543,12 @@ def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=
     cpu_scores = bufs[3].ravel()[:B].copy()
     err = float(np.abs(cpu_scores - gpu_scores_first).max() / max(np.abs(cpu_scores).max(), 1e-30)) if gpu_scores_first is not None else None
     gbytes = 1408 + 188 + 1408
-    # BASELINE configs[0] -- "Model-A batch 1 on the host CPU, no accelerator" (the reference's sw_emu plumbing case): one item through the
-    # memory-resident gather and the oracle's own fp32 chain (scalar loops, one thread), median of 200
-    b1 = None
-    try:
-        O.lib().oracle_set_num_threads(1)
-        one = np.ascontiguousarray(hidx[:1])
-        ts = []
-        for _ in range(200):
-            t1 = time.perf_counter()
-            r1 = h.gather_direct(one, True, imgs)
-            om.fc_chain(r1.view(np.float32), ws, acc64=False)
-            ts.append(time.perf_counter() - t1)
-        ts.sort()
-        b1 = {"us_p50": 1e6 * ts[len(ts) // 2], "us_p90": 1e6 * ts[9 * len(ts) // 10], "what": "BASELINE configs[0]: Model-A batch 1 on one host core through the checker "
-              "(memory-resident gather + scalar fp32 chain), ctypes call overhead included"}
-        O.lib().oracle_set_num_threads(threads)
-    except Exception as ex:
-        b1 = {"error": repr(ex)[:200]}
     fc_threads = (alt or {}).get("threads") if blas_used is None else blas["threads"]
     # `cores` = the most host threads any phase of the end-to-end figure ran on: the gather's OpenMP team (`gather_threads`, the fastest of the
     # probe above -- all cores is not the fastest: hyper-threads / cgroup quotas) and the FC engine's pool (`fc_threads`: OpenBLAS builds cap
     # at 64, torch.mm takes its own default) run one after the other, never at the same time
     return {"value": e_rate, "unit": "inferences/s", "cores": max(threads, fc_threads or 0), "gather_threads": threads, "fc_threads": fc_threads,
-            "kind": "port", "batch_1": b1,
+            "kind": "port",
             "gather_only": g_rate, "fc_only": f_rate, "end_to_end": e_rate,
             "gather_GBps_algorithmic": g_rate * gbytes / 1e9, "fc_GFLOPs": f_rate * fc_flops_per_inference(fc) / 1e9,
             "blas": blas["name"] if blas else "torch.mm (" + __import__("torch").__config__.parallel_info().split("\n")[0] + ")",
@@ -558,6 +559,50 @@ def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=
             "sample": "Model-A, %d items per call (64 batches of 256 = one fused GPU launch), gather-only %d calls, FC-only %d, end-to-end %d (>= %.1f s each); "
                       "same seeded tables / weights / index law, 8 index groups rotated (the first = the GPU run's buffers); gather = OpenMP over items reading "
                       "bank images in host RAM (oracle_gather_banks_direct), FC = 4 chained column-major sgemm calls" % (n, g_reps, f_reps, e_reps, budget_s)}
+
+
+def leg_cpu_backend(fr, idx_host, B, gpu_scores_first):
+    """BASELINE configs[0] -- "Model-A (smallest user_krnl config), batch=1 ... on host CPU (plumbing, no accelerator)" -- through the PRODUCT:
+    the library's own CPU back-end (fr_ctx_create(model, device = -1): csrc/fr_cpu.cpp, the same C-ABI, no checker code involved).
+    Full-size Model-A in host memory; one request of one item through fr_worker_submit + fr_worker_sync (median of 300), and the 16384-item
+    sample of the cpu_baseline leg through the same entry points on every usable core."""
+    m = fr.Model.builtin(fr.MODEL_A)
+    t0 = time.perf_counter()
+    threads = fr.cpu_set_threads(0)
+    ctx = fr.Context(m, device=fr.DEVICE_CPU)
+    ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    t_setup = time.perf_counter() - t0
+    w1 = fr.Worker(ctx, 1)
+    one = idx_host[0][:1]
+    for _ in range(30):
+        w1.infer(one)
+    ts = []
+    for _ in range(300):
+        t1 = time.perf_counter()
+        s1 = w1.infer(one)
+        ts.append(time.perf_counter() - t1)
+    ts.sort()
+    w1.close()
+    big = np.concatenate(idx_host[:64], axis=0)
+    wk = fr.Worker(ctx, big.shape[0])
+    sc = wk.infer(big)
+    reps, t_begin = 0, time.perf_counter()
+    while reps < 2 or time.perf_counter() - t_begin < 1.5:
+        wk.infer(big)
+        reps += 1
+    rate = big.shape[0] * reps / (time.perf_counter() - t_begin)
+    wk.close()
+    ctx.close()
+    err = float(np.abs(sc[:B] - gpu_scores_first).max() / max(np.abs(gpu_scores_first).max(), 1e-30)) if gpu_scores_first is not None else None
+    return {"batch_1": {"us_p50": 1e6 * ts[len(ts) // 2], "us_p90": 1e6 * ts[9 * len(ts) // 10], "inferences_per_s": 1.0 / ts[len(ts) // 2],
+                        "score_equals_batch_of_16384": bool(s1[0] == sc[0]),
+                        "what": "BASELINE configs[0]: Model-A batch 1 on the host CPU through the library's CPU back-end (fr_ctx_create device = -1; fr_worker_submit + "
+                                "fr_worker_sync, the ctypes call included): a request of one item runs on one core"},
+            "end_to_end": rate, "unit": "inferences/s", "threads": threads, "sample_items": int(big.shape[0]), "calls": reps, "setup_s": t_setup,
+            "cpu_vs_gpu_max_rel_err_first_batch": err,
+            "what": "the cpu_baseline leg's 16384-item sample (64 batches of 256) through the same back-end: gather over the record-word descriptors + "
+                    "k-ordered fp32 multiply-add chain (own code, no BLAS), %d threads" % threads}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -717,6 +762,9 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
         cal.close()
     fc = model.fc
     flops_inf = fc_flops_per_inference(fc)
+    # a chain model's GEMM tiles follow the context's chain width (fr_ctx_set_chain_width): decided HERE, on purpose, as a host that drives
+    # threads x depth streams would -- not by whichever worker happens to launch first (--roofline-only has no driver)
+    ctx.set_chain_width(min(4, threads * depth))
     if min_s > 0:
         dv = fr.Driver(ctx, threads, depth, B)
         dv.run_resident(B, 256, d_idx, d_dense)
@@ -751,8 +799,8 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
         for b_ in ring:
             b_.free()
     else:           # stage pipeline: FC1 runs as its own LDS-tiled GEMM launch (fc_lp_gemm_kernel) -- the dominant kernel
-        # measured with the context in the timed region's state -- threads x depth live workers: with W of them the bf16 / fp8 layers take tiles
-        # that cover 1 / min(W, 4) of the chip -- and as many of those workers launching the layer side by side as FIT on the chip together
+        # measured with the context in the timed region's state -- chain width W = min(threads x depth, 4): the bf16 / fp8 layers take tiles
+        # that cover 1 / W of the chip -- and as many workers launching the layer side by side as FIT on the chip together
         # (256 compute units / workgroups per launch): every launch then runs from the moment it is dequeued, so the HIP-event time per
         # launch on its stream is the kernel duration rocprofv3 averages, and the chip's rate is `fit` launches' FLOPs over it.
         d_sc = fr.DeviceBuffer(ctx, B * 4)
@@ -794,9 +842,10 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
         ms = layer_ms[0]
         flops = 2 * fc[0] * fc[1] * B
         kname = layer_kernels[0]
-        what = ("%s (FC1: %d x %d x %d): the tile %d live workers give it, as many launches side by side as fit on the chip; avg_launch_ms = mean "
+        what = ("%s (FC1: %d x %d x %d): the tile chain width %d gives it, as many launches side by side as fit on the chip; avg_launch_ms = mean "
                 "launch duration on its stream, concurrent_launches = the streams' busy time over the wall time, achieved = concurrent_launches x "
-                "FLOPs per launch / avg_launch_ms = all FLOPs over the wall time" % (kname, fc[0], fc[1], B, len(side)))
+                "FLOPs per launch / avg_launch_ms = all FLOPs over the wall time" % (kname, fc[0], fc[1], B, ctx.chain_width()))
+        res["chain_width"] = ctx.chain_width()
         res["layer_launch_ms"] = layer_ms
         res["layer_kernels"] = layer_kernels
         res["concurrent_launches"] = layer_conc[0]
@@ -889,8 +938,14 @@ def main_sharded(args, graft):
     dist_mod = importlib.import_module("fleetrec_amd.dist")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     env = dist_mod.DistEnv(args.backend if world > 1 else None)
-    n_dev = max(fr.device_count(), 1)
-    dev_id = env.local_rank % n_dev if args.share_device else env.local_rank
+    if args.device == -1:
+        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        fr.cpu_set_threads(max(1, usable // world))
+        dev_id = fr.DEVICE_CPU
+        args.precision = "f32"
+    else:
+        n_dev = max(fr.device_count(), 1)
+        dev_id = env.local_rank % n_dev if args.share_device else env.local_rank
     if args.batch == 256:
         args.batch = 4096
     res = run_sharded(fr, dist_mod, env, dev_id, args)
@@ -908,6 +963,8 @@ def run_sharded(fr, dist_mod, env, dev_id, args, auto_steps_s=0.0):
     sizes the timed region to that many seconds from the warm-up steps (the same count on every rank: MAX over ranks).
     Every rank calls this with the same arguments; the contexts are created and closed inside.  -> the result dict (every rank)."""
     import torch
+    if dev_id == fr.DEVICE_CPU:
+        return run_sharded_cpu(fr, dist_mod, env, args)
     world = env.world
     G, r = env.world, env.rank
     B = args.batch
@@ -1082,6 +1139,81 @@ def run_sharded(fr, dist_mod, env, dev_id, args, auto_steps_s=0.0):
     return res
 
 
+def run_sharded_cpu(fr, dist_mod, env, args):
+    """run_sharded on the library's CPU back-end (--device -1: a REHEARSAL of the table-sharded step's control flow and plan arithmetic with
+    any number of ranks and no GPU): per step every rank gathers its [B x F] fp32 slice (fr_worker_gather_slices on a CPU context), ONE
+    all-gather (or all-to-all) through the process group delivers the slices, rank r runs the fp32 chain on its B / G items
+    (fr_worker_fc_from_slices_lp).  Steps run one after the other (nothing to overlap on a host).  Same result keys as run_sharded; the
+    figures are not measurements of anything."""
+    import torch
+    G, r = env.world, env.rank
+    B = args.batch
+    steps, warmup = max(args.steps, 1), args.warmup
+    if args.precision != "f32":
+        raise SystemExit("--device -1: the CPU back-end computes in fp32")
+    model = fr.Model.builtin(fr.MODEL_C)
+    if args.rows_cap or args.row_scale != 1.0:
+        model = model.clone(row_scale=args.row_scale, max_rows=args.rows_cap)
+    ctx = fr.Context(model, device=fr.DEVICE_CPU, shard_rank=r, n_shards=G)
+    ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    offs, lens, F = model.shard_plan(G)
+    rng = np.random.default_rng(SEED_IDX)
+    rows = model.rows()
+    nbuf = 2
+    idx_host = [uniform_idx(rng, rows, B) for _ in range(nbuf)]
+    dense_host = [rng.uniform(-1, 1, (B, model.dense_len)).astype(np.float32) for _ in range(nbuf)]
+    a2a = args.exchange == "alltoall"
+    if a2a and B % G:
+        raise SystemExit("--exchange alltoall needs the batch divisible by the number of ranks")
+    wk = fr.Worker(ctx, B)
+    lo, hi = dist_mod.item_range(r, G, B)
+    local = np.zeros((B, F), np.float32)
+    scores = np.zeros(max(hi - lo, 1), np.float32)
+
+    def step(i):
+        wk.gather_slices(B, idx_host[i % nbuf].ctypes.data, dense_host[i % nbuf].ctypes.data, local.ctypes.data, fr.FC_FP32)
+        wk.sync()
+        g = (env.all_to_all_slices if a2a else env.all_gather_slices)(torch.from_numpy(local)).contiguous().numpy()
+        if a2a:
+            wk.fc_from_slices_lp(B // G, 0, hi - lo, g.ctypes.data, fr.FC_FP32, scores.ctypes.data)
+        else:
+            wk.fc_from_slices_lp(B, lo, hi - lo, g.ctypes.data, fr.FC_FP32, scores.ctypes.data)
+        wk.sync()
+
+    for i in range(warmup):
+        step(i)
+    env.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    env.barrier()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    vs_unsharded = None
+    if r == 0 and not args.no_unsharded_check and args.row_scale == 1.0:   # this rank's items through an unsharded CPU context of the same model
+        last = steps - 1
+        full = fr.Context(model, device=fr.DEVICE_CPU)
+        full.fill_tables(fr.FILL_HASH, SEED_TABLES)
+        full.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+        fw = fr.Worker(full, max(hi - lo, 1))
+        ref = fw.infer(idx_host[last % nbuf][lo:hi], dense_host[last % nbuf][lo:hi])
+        vs_unsharded = {"max_rel_err": float(np.abs(scores[:hi - lo] - ref).max() / max(np.abs(ref).max(), 1e-30)), "bit_identical": bool(np.array_equal(scores[:hi - lo], ref))}
+        fw.close()
+        full.close()
+    res = {"metric": "inferences/sec, Model-C batch %d, tables sharded by table-ID" % B, "value": B * steps / dt, "unit": "inferences/s", "n_gpus": G, "steps": steps,
+           "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic (REHEARSAL on the CPU back-end)",
+           "config": {"workload": "REHEARSAL on the CPU back-end: Model-C%s batch=%d, %d-way table-ID shards (slice F=%d floats), 1 %s of [B x F] per step, FC on B/G items per rank"
+                                  % (" (rows x %g)" % args.row_scale if args.row_scale != 1.0 else "", B, G, F, "all-to-all" if a2a else "all-gather"),
+                      "parallelism": "table-sharded x%d" % G, "shard_table_bytes_this_rank": int(sum(model.shard_table_bytes(G)[r:r + 1])), "min_shards_for_288GB": model.min_shards(),
+                      "exchange": args.exchange, "backend": args.backend if G > 1 else None, "slice_transport": "f32", "pipelined_equals_stepwise": True,
+                      "sharded_vs_unsharded_context": vs_unsharded, "exchange_bytes_in_per_rank_per_step": int(G * (B // G if a2a else B) * F * 4),
+                      "slice_offsets": offs, "slice_lens": lens, "items_this_rank": [lo, hi]}}
+    wk.close()
+    ctx.close()
+    return res
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -1106,6 +1238,10 @@ def main():
                     help="sharded mode: all-gather every slice to every rank (BASELINE configs[3]) or all-to-all only each rank's items")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true", help="plumbing test: ranks share the visible GPU(s) (use with --backend gloo)")
+    ap.add_argument("--device", type=int, default=None,
+                    help="-1: REHEARSAL on the library's CPU back-end (fr_ctx_create device = -1), no GPU touched -- the whole control flow of the line (every "
+                         "leg's collectives, votes, plan arithmetic, LineGuard) with fp32 CPU contexts, row-capped tables and token step counts; use with "
+                         "--backend gloo --rows-cap N.  The numbers of such a line are not measurements of anything")
     ap.add_argument("--rows-cap", type=int, default=0, help="plumbing tests: cap every table's row count (sharded mode)")
     ap.add_argument("--row-scale", type=float, default=1.0,
                     help="sharded mode: multiply every table's row count (BASELINE configs[4]: 5 inflates Model-C to 316 GB, past one GPU's 288 GB)")
@@ -1144,11 +1280,27 @@ def main():
     dist_mod = importlib.import_module("fleetrec_amd.dist")
     env = dist_mod.DistEnv(args.backend if world_env > 1 else None)
     rank, world = env.rank, env.world
-    if fr.device_count() < 1:
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    n_dev = fr.device_count()
-    local_rank = env.local_rank % n_dev if args.share_device else env.local_rank  # --share-device: plumbing test on one GPU
+    cpu = args.device == -1   # rehearsal on the CPU back-end: see --device
+    if cpu:
+        if args.model != "A" or args.precision != "f32":
+            raise SystemExit("--device -1 rehearses the default line (the CPU back-end computes in fp32)")
+        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        fr.cpu_set_threads(max(1, usable // world))
+        local_rank = fr.DEVICE_CPU
+        if args.legs == "all":
+            args.legs = "none"
+    else:
+        if fr.device_count() < 1:
+            raise SystemExit("bench.py needs an MI355X: a context on device >= 0 never falls back to the CPU (--device -1 rehearses the line on the CPU back-end)")
+        n_dev = fr.device_count()
+        local_rank = env.local_rank % n_dev if args.share_device else env.local_rank  # --share-device: plumbing test on one GPU
     legs = set() if args.legs == "none" else set(args.legs.split(","))
+    leg_s, t_leg = {}, [time.perf_counter()]   # wall time per leg (rank 0's clock): the budget the driver's timeout is held against
+
+    def leg_done(name):
+        now = time.perf_counter()
+        leg_s[name] = round(leg_s.get(name, 0.0) + now - t_leg[0], 2)
+        t_leg[0] = now
     # N > 1: the line carries the `roofline` object as well -- rank 0's HIP-event leg of the dominant kernel on its own replica while the
     # other ranks wait at the next barrier (one rank's launches on one stream: the same measurement as at N = 1); the other rank-0 legs are N = 1 only
     want = lambda name: rank == 0 and ("all" in legs or name in legs) and (world == 1 or name == "roofline")
@@ -1156,6 +1308,8 @@ def main():
     B = args.batch
     which = {"A": fr.MODEL_A, "B": fr.MODEL_B, "C": fr.MODEL_C}[args.model]
     model = fr.Model.builtin(which)
+    if cpu and args.rows_cap:
+        model = model.clone(max_rows=args.rows_cap)
     if args.per_bank:   # the reference kernel's index contract: one index per memory bank per item, bank-interleaved tables
         if args.model == "A" and args.precision == "f32":
             raise SystemExit("--per-bank: with --model B/C or a --precision other than f32 (the headline's 47 tables are 47 banks)")
@@ -1210,7 +1364,7 @@ def main():
     barrier()
     burst_dt = env.max_over_ranks(time.perf_counter() - t0)
     # (the calibration run inside steady_run includes the ramp and overestimates the time per batch by ~8 %: size for 1.12 x the target)
-    n_timed = args.steps if args.roofline_only else max(steady_run(lambda k: driver.run_resident(B, k, d_idx), 0.3 if args.quick else 1.12 * STEADY_S, n_first=8192, env=env),
+    n_timed = args.steps if (args.roofline_only or cpu) else max(steady_run(lambda k: driver.run_resident(B, k, d_idx), 0.3 if args.quick else 1.12 * STEADY_S, n_first=8192, env=env),
                                                         args.steps)
     barrier()
     t0 = time.perf_counter()
@@ -1218,6 +1372,7 @@ def main():
     barrier()
     dt = env.max_over_ranks(time.perf_counter() - t0)
 
+    leg_done("headline")
     result = None
     if rank == 0:
         result = {
@@ -1226,11 +1381,12 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Model-A (embedding_47_krnl: 47 tables, 1.415 GB) batch=%d, fp32 FC 352-1024-512-256-1, all tables resident in "
                                    "one GPU's HBM; hash-filled tables, uniform per-table indices; index rows resident in HBM when the timed region "
-                                   "starts (%d rotating buffers), scores left in HBM (bench contract); value_pcie_inclusive = the same stream fed "
-                                   "from host memory with scores delivered to host memory" % (B, n_bufs),
+                                   "starts (%d rotating buffers), scores left in HBM (the bench contract's definition of `value`); value_pcie_inclusive "
+                                   "= the reference's own loop (cuda_server.c:460-461,494-495): the same stream fed from host memory with scores "
+                                   "delivered to host memory" % (B, n_bufs),
                        "batch": B, "driver_threads": args.threads, "workers_per_thread": args.depth,
                        "batches_per_launch": ctx.stream_group(), "parallelism": "replicas x%d" % world},
-            "timed_batches": n_timed, "timed_s": dt,
+            "timed_batches": n_timed, "timed_s": dt, "leg_seconds": leg_s,
             "value_is": "steady state: %d back-to-back batches per rank over %.2f s (sized for >= %.1f s from a calibration run, whatever --steps says)" % (n_timed, dt, STEADY_S),
             "burst": {"steps": args.steps, "warmup": args.warmup, "value": world * args.steps * B / burst_dt, "unit": "inferences/s",
                       "ms_per_step": 1e3 * burst_dt / max(args.steps, 1),
@@ -1238,8 +1394,13 @@ def main():
                               "latency (a fused launch carries %d batches), not throughput" % ctx.stream_group()},
         }
 
+    if rank == 0 and cpu:
+        result["data"] = "synthetic (REHEARSAL on the CPU back-end: control flow only, no figure of this line is a measurement)"
+        result["config"]["rehearsal"] = "fr_ctx_create(device = -1) on every rank, fp32, rows capped at %d, token step counts" % args.rows_cap
+        result["roofline"] = {"bound": "none", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None}
+        result["cpu_baseline"] = {"value": None, "unit": "inferences/s", "cores": 0, "kind": "port", "sample": "none (rehearsal)"}
     gpu_scores_first = None
-    if want("roofline"):
+    if want("roofline") and not cpu:
         # ---- roofline of the dominant kernel: measured live with HIP events on the worker's stream ----
         # Model-A streams through the fused item-tile kernel: ONE launch = the whole hot path (gather + 4 GEMMs) of `group` queued
         # batches, 64 items per workgroup at the default group of 64.
@@ -1282,6 +1443,7 @@ def main():
         for b_ in ring:
             b_.free()
 
+    leg_done("roofline")
     if want("groups"):
         result["launch_group_table"] = {"workload": "Model-A batch 256 fp32, %d threads x %d workers; group = fr_ctx_set_stream_group: below 12 every push is one "
                                                     "stage-pipeline launch, from 12 up a group is one fused launch; launch_ms_one_stream = time per group of pushes"
@@ -1291,6 +1453,7 @@ def main():
             if row["group"] == result["config"]["batches_per_launch"]:
                 result["config"]["push_to_scores_us_p50"] = 1e3 * row["push_to_scores_ms_p50"]
 
+    leg_done("groups")
     if want("pcie"):
         # ---- PCIe-inclusive rates (index rows start in HOST memory, scores end in HOST memory; reported, never `value`) ----
         # host threads of these legs = the reference's THREAD_NUM = 4 (constant.h:42): every pushed batch is first copied into pinned
@@ -1305,17 +1468,24 @@ def main():
         result["pcie_inclusive"] = {"value": n * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / n, "timed_batches": n, "timed_s": el,
                                     "what": "per batch: memcpy to pinned -> fr_worker_submit (5 stage launches; index rows read from and scores written to the pinned "
                                             "buffers over PCIe) -> sync (the reference's own per-batch sequence, cuda_server.c:425-495), %d threads x 4 workers" % ht}
-        hs = fr.Driver(ctx, ht, args.depth, B)
+        # the reference's loop with its two PCIe hops inside (cuda_server.c:460-461,494-495), streamed: 4 host threads (the reference's THREAD_NUM)
+        # x ONE worker each = one stream per hardware queue -- a block's H2D runs on the worker's copy stream ahead of its launch, the scores
+        # are written straight to pinned memory, the worker's stream carries nothing but kernels (profiles/r05_host_fed_timeline.txt:
+        # 99.6-100 % of the HBM-resident rate; round 4's three commands per block on 4 x 2 streams: 94-96 %)
+        hs = fr.Driver(ctx, ht, 1, B)
         hs.run_host(B, 2048, idx_host, streaming=True)
         n = steady_run(lambda k: hs.run_host(B, k, idx_host, streaming=True), STEADY_S, n_first=8192)
         el = hs.run_host(B, n, idx_host, streaming=True)
         hs.close()
         result["value_pcie_inclusive"] = n * B / el   # the same metric with the reference loop's H2D / D2H inside (never `value`: bench contract)
+        result["value_hbm_resident"] = result["value"]
         result["pcie_inclusive_streaming"] = {"value": n * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / n, "timed_batches": n, "timed_s": el,
+                                              "fraction_of_value": n * B / el / result["value"],
                                               "what": "host-resident request stream, scores delivered to host memory: blocks of 64 batches staged in pinned "
-                                                      "memory, one H2D + one fused launch + one D2H per block (fr_worker_push_host), %d threads x %d workers"
-                                                      % (ht, args.depth)}
+                                                      "memory, one H2D (copy stream) + one fused launch per block, scores written to pinned memory by the kernel "
+                                                      "(fr_worker_push_host), %d threads x 1 worker" % ht}
 
+    leg_done("pcie")
     if want("tcp"):
         try:
             result["tcp_streaming"] = leg_tcp(B, local_rank)
@@ -1326,11 +1496,18 @@ def main():
         except Exception as ex:
             result["tcp_serving_with_replies"] = {"error": repr(ex)[:300]}
 
+    leg_done("tcp")
     if want("cpu"):
         try:
             result["cpu_baseline"] = leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first)
         except Exception as ex:
             result["cpu_baseline"] = {"error": repr(ex)}
+        try:   # BASELINE configs[0] and the same sample through the library's own CPU back-end (device = -1): product code, not the checker
+            result["cpu_backend"] = leg_cpu_backend(fr, idx_host, B, gpu_scores_first)
+            if isinstance(result.get("cpu_baseline"), dict):
+                result["cpu_baseline"]["batch_1"] = result["cpu_backend"]["batch_1"]
+        except Exception as ex:
+            result["cpu_backend"] = {"error": repr(ex)[:300]}
         try:   # the same single request on the GPU path: fr_worker_submit + sync of a batch of 1 (index row H2D, 5 stage launches, score D2H)
             w1 = fr.Worker(ctx, 1)
             one = idx_host[0][:1]
@@ -1348,6 +1525,7 @@ def main():
         except Exception as ex:
             result["batch_1_gpu"] = {"error": repr(ex)[:200]}
 
+    leg_done("cpu")
     driver.close()
     for b in d_idx:
         b.free()
@@ -1404,6 +1582,7 @@ def main():
         except Exception as ex:
             cfgs.append({"workload": "Model-A low precision", "error": repr(ex)})
         result["configs"] = cfgs
+    leg_done("configs_A_B")
 
     if want("gather") or want("configs") or want("bank"):
         try:
@@ -1474,6 +1653,7 @@ def main():
         except Exception as ex:  # the main metric must still be reported
             result.setdefault("gather", {})["error"] = repr(ex)
 
+    leg_done("gather_and_configs_C")
     if world > 1 and not args.no_multi_gather:
         # N > 1: the other half of BASELINE.json's metric ("embedding-gather HBM GB/s vs peak, 1 -> 8 MI355X") and BASELINE.md section 3's
         # other models -- every rank runs the legs below on its own replicas at the same time, rank 0 reports the SUM of the per-rank rates.
@@ -1500,7 +1680,8 @@ def main():
         holder = {}
 
         def gather_setup():
-            mcb = fr.Model.builtin(fr.MODEL_C).clone(index_mode=fr.INDEX_PER_BANK)
+            # (--rows-cap: plumbing runs with several ranks on one device, or on the CPU back-end, cannot hold a full replica per rank)
+            mcb = fr.Model.builtin(fr.MODEL_C).clone(index_mode=fr.INDEX_PER_BANK, max_rows=args.rows_cap)
             cbk = fr.Context(mcb, device=local_rank)
             cbk.fill_tables(fr.FILL_HASH, SEED_TABLES)
             cbk.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
@@ -1508,7 +1689,8 @@ def main():
             holder["c"] = (mcb, cbk)
             return mcb, cbk
 
-        r_ = all_ranks(gather_setup, lambda st: leg_gather(fr, st[1], st[0], 4096, "uniform", reps=200, nbuf=32, seed=dist_mod.replica_seed(SEED_IDX, rank))["achieved"])
+        r_ = all_ranks(gather_setup, lambda st: leg_gather(fr, st[1], st[0], 4096, "uniform", reps=10 if cpu else 200, nbuf=2 if cpu else 32, seed=dist_mod.replica_seed(SEED_IDX, rank))["achieved"])
+        leg_done("gather_per_bank_all_ranks")
         if rank == 0 and r_ is not None:
             result["gather_per_bank_all_ranks"] = {"achieved": r_[0], "unit": "GB/s", "peak": HBM_PEAK_GBS * world, "frac": r_[0] / (HBM_PEAK_GBS * world),
                                                    "ranks_measured": r_[1], "bound": "hbm",
@@ -1516,6 +1698,17 @@ def main():
                                                            "every rank on its own replica at the same time (HIP events on each rank's stream)"}
 
         def config_rate(ctx_, model_, Bc, prec):
+            if cpu:   # rehearsal: the CPU back-end computes in fp32; a token batch and step count
+                Bc = 128
+                rngc = np.random.default_rng(dist_mod.replica_seed(SEED_IDX + 5, rank))
+                ih = [uniform_idx(rngc, model_.index_ranges(), Bc) for _ in range(2)]
+                dh = [rngc.uniform(-1, 1, (Bc, model_.dense_len)).astype(np.float32) for _ in range(2)] if model_.dense_len else None
+                di = [fr.DeviceBuffer.from_numpy(ctx_, a_) for a_ in ih]
+                dd = [fr.DeviceBuffer.from_numpy(ctx_, a_) for a_ in dh] if dh else None
+                dv = fr.Driver(ctx_, args.threads, args.depth, Bc)
+                el_ = dv.run_resident(Bc, 4, di, dd)
+                dv.close()
+                return 4 * Bc / el_
             rngc = np.random.default_rng(dist_mod.replica_seed(SEED_IDX + 5, rank))
             ih = [uniform_idx(rngc, model_.index_ranges(), Bc) for _ in range(8)]
             dh = [rngc.uniform(-1, 1, (Bc, model_.dense_len)).astype(np.float32) for _ in range(8)] if model_.dense_len else None
@@ -1547,7 +1740,7 @@ def main():
                 del holder["c"]
 
             def b_setup():
-                mbb = fr.Model.builtin(fr.MODEL_B)
+                mbb = fr.Model.builtin(fr.MODEL_B).clone(max_rows=args.rows_cap)
                 cbb = fr.Context(mbb, device=local_rank)
                 cbb.fill_tables(fr.FILL_HASH, SEED_TABLES)
                 cbb.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
@@ -1565,6 +1758,7 @@ def main():
                 result["configs_all_ranks"] = cfg_all
         elif "c" in holder:
             holder["c"][1].close()
+        leg_done("configs_all_ranks")
 
     if world > 1 and not args.no_multi_sharded:
         # N > 1: the table-sharded split north_star names (BASELINE configs[3] / [4]) on the DEFAULT line -- Model-C batch 4096, tables
@@ -1578,21 +1772,26 @@ def main():
         offs5, lens5, _ = m5.shard_plan(world)
         shard5 = max(sum(t.rows * t.dim * 4 for si in m5.segments() if si.kind == fr.SEG_TABLE and offs5[k] <= si.rec_offset < offs5[k] + lens5[k]
                          for t in [m5.tables()[si.src]]) for k in range(world))
-        if not args.share_device and m5.min_shards() is not None and m5.min_shards() <= world and shard5 <= 0.85 * 288e9:
+        if cpu:   # rehearsal: both configurations' plans (configs[4] with the 5 x inflated row counts under the cap), fp32 chains
+            cases = [("configs[3]", dict(precision="f32", row_scale=1.0)), ("configs[4]", dict(precision="f32", row_scale=5.0))]
+        elif not args.share_device and m5.min_shards() is not None and m5.min_shards() <= world and shard5 <= 0.85 * 288e9:
             cases.append(("configs[4]", dict(precision="fp8", row_scale=5.0)))
         # These legs have data-path collectives INSIDE their step loop: every rank runs them under a LineGuard (above).
         keys = {"configs[3]": "sharded", "configs[4]": "sharded_inflated_fp8"}
         guard = LineGuard(rank, result)
         for name, kw in cases:
-            sa = types.SimpleNamespace(batch=4096, steps=50, warmup=10, transport="lp", exchange="allgather", backend=args.backend, rows_cap=args.rows_cap,
-                                       no_unsharded_check=False, **kw)
-            res = guard.run("%s leg (%s)" % (keys[name], name), 300.0, lambda: run_sharded(fr, dist_mod, env, local_rank, sa, auto_steps_s=1.0))
+            sa = types.SimpleNamespace(batch=4096, steps=2 if cpu else 50, warmup=1 if cpu else 10, transport="lp", exchange="allgather", backend=args.backend,
+                                       rows_cap=args.rows_cap, no_unsharded_check=False, **kw)
+            res = guard.run("%s leg (%s)" % (keys[name], name), 300.0, lambda: run_sharded(fr, dist_mod, env, local_rank, sa, auto_steps_s=0.0 if cpu else 1.0))
             res["baseline_config"] = name
             if rank == 0:
                 result[keys[name]] = res
+            leg_done(keys[name])
         guard.close()
 
     if rank == 0:
+        result["leg_seconds_total"] = round(sum(leg_s.values()), 1)
+        sys.stderr.write("bench.py: wall time per leg (s): %s; total %.1f s\n" % (", ".join("%s %.1f" % kv for kv in leg_s.items() if kv[1] >= 0.05), result["leg_seconds_total"]))
         emit(result)
     env.close()
 

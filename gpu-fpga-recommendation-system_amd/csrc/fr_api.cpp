@@ -993,7 +993,7 @@ static int chain_width(fr_ctx *c) {
 
 extern "C" int fr_ctx_set_chain_width(fr_ctx *ctx, int width) {
     if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
-    if (width < 1 || width > 4) FR_FAIL(FR_ERR_INVALID, "chain width %d outside [1, 4]", width);
+    if (width < 0 || width > 4) FR_FAIL(FR_ERR_INVALID, "chain width %d outside [0, 4] (0 = undecided again: the next low-precision GEMM-layer launch freezes it)", width);
     ctx->chain_width.store(width, std::memory_order_relaxed);
     return FR_OK;
 }

@@ -83,6 +83,12 @@ extern "C" int fr_driver_create(fr_ctx *ctx, int n_threads, int depth, int max_b
         (void)hipMemset(ring, 0, (size_t)FR_SCORE_RING * max_batch * sizeof(float));
         d->score_rings.push_back(ring);
     }
+    // a driver knows how many chains it will run side by side: an undecided context takes its chain width from it (fr_ctx_set_chain_width)
+    {
+        int expected = 0;
+        const int w = n_threads * depth > 4 ? 4 : n_threads * depth;
+        (void)ctx->chain_width.compare_exchange_strong(expected, w, std::memory_order_relaxed);
+    }
     *out = d;
     return FR_OK;
 }

@@ -247,7 +247,7 @@ int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out);
  * min(workers alive at that moment, 4) -- and never follows workers coming or going afterwards: scores of a stream in flight cannot
  * change because an unrelated worker was created or destroyed.  Call it again only on purpose: it takes effect from the next launch on,
  * and in bf16 the tile shape fixes the summation order (<= 1e-2 relative between widths; fp8 and fp32 scores are bit-identical for every
- * width).  fr_ctx_chain_width: the current value, 0 while undecided.  Set W = 1 if a runtime update should ever stop giving the
+ * width; width = 0 makes the context undecided again).  fr_ctx_chain_width: the current value, 0 while undecided.  Set W = 1 if a runtime update should ever stop giving the
  * workers hardware queues of their own (tests/test_gpu_parity.py::test_chain_workers_run_their_layers_side_by_side guards that). */
 int fr_ctx_set_chain_width(fr_ctx *ctx, int width);
 int fr_ctx_chain_width(const fr_ctx *ctx);
@@ -328,7 +328,8 @@ int fr_worker_fc_only(fr_worker *w, int batch, const float *d_records, float *d_
 /* ---- request-driver core: main() + the thread_consume() batch loop without sockets
  *      (cuda_server.c:23-25,406-497,554-560) ------------------------------------------------------- */
 typedef struct fr_driver fr_driver;
-/* n_threads host threads (THREAD_NUM, constant.h:42), each owning `depth` workers/streams. */
+/* n_threads host threads (THREAD_NUM, constant.h:42), each owning `depth` workers/streams.  A context whose chain width is still undecided
+ * takes min(n_threads * depth, 4) from its first driver (fr_ctx_set_chain_width). */
 int fr_driver_create(fr_ctx *ctx, int n_threads, int depth, int max_batch, fr_driver **out);
 void fr_driver_destroy(fr_driver *d);
 /* Processes `total_batches` batches of `batch` items: threads draw batch ids from a mutex-guarded global

@@ -129,3 +129,44 @@ def test_persistent_kernels_use_no_scratch(fr):
     # ... and no kernel of the library needs more than a few dwords of scratch (a regression guard for the others)
     worst = max(kr.kernel_records(fr.LIB_PATH), key=lambda r: r["private_segment_fixed_size"])
     assert worst["private_segment_fixed_size"] <= 64, worst
+
+
+def test_lds_dma_kernels_touch_m0_only_through_the_asm(fr, tmp_path):
+    """VERDICT r04 item 6(b).  The GEMM kernels move their operands global -> LDS with `buffer_load_dwordx4 ... lds` from inline asm that
+    writes M0 (the LDS base of the wave-instruction) WITHOUT a clobber entry -- hipcc rejects "m0" in a clobber list -- on the argument
+    that those kernels contain no other M0 user whose set-up the compiler could move across the asm (fr_gemm.hip, `dma`).  This test is
+    that argument, checked by a machine at every build: every gfx950 kernel of libfleetrec.so that contains an LDS-DMA load is
+    disassembled, and (1) every instruction that mentions m0 must be the asm's own `s_mov_b32 m0, s<N>`; (2) every LDS-DMA load must be
+    IMMEDIATELY preceded by such a write (the asm's two lines were not separated)."""
+    import importlib.util
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    n_kernels = n_loads = 0
+    for i, co in enumerate(kr.code_objects(fr.LIB_PATH)):
+        f = tmp_path / ("co%d.o" % i)
+        f.write_bytes(co)
+        asm = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(f)], capture_output=True, text=True).stdout
+        cur, body = None, {}
+        for line in asm.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                cur = m.group(1)
+                body[cur] = []
+            elif cur is not None and line.strip() and not line.lstrip().startswith("//"):
+                body[cur].append(re.sub(r"\s*//.*$", "", line).strip())
+        for name, ins in body.items():
+            dma = [k for k, t in enumerate(ins) if re.match(r"buffer_load_dword(x[234])? .*\blds\b", t)]
+            if not dma:
+                continue
+            n_kernels += 1
+            n_loads += len(dma)
+            for k, t in enumerate(ins):
+                if re.search(r"\bm0\b", t):
+                    assert re.match(r"s_mov_b32 m0, s\d+$", t), "%s: unexpected M0 user `%s`" % (name, t)
+            for k in dma:
+                assert k > 0 and re.match(r"s_mov_b32 m0, s\d+$", ins[k - 1]), "%s: LDS-DMA load not directly behind its M0 write: `%s` / `%s`" % (name, ins[k - 1], ins[k])
+    assert n_kernels >= 6 and n_loads >= 100, (n_kernels, n_loads)   # the fc_lp_gemm / fc_gemm_pipe instantiations of three precisions

@@ -2,6 +2,7 @@
 ONE exchange step (all-gather of [B x F] slices) + item partition.  The oracle stands in for the per-rank kernels here;
 the same orchestration runs on RCCL in bench.py --mode sharded."""
 import os
+import re
 import subprocess
 import sys
 import textwrap
@@ -266,6 +267,53 @@ def test_bench_failed_collective_leg_keeps_the_line_and_exits_non_zero(tmp_path)
         assert "injected failure" in err
 
 
+def test_bench_eight_ranks_rehearsal_on_the_cpu_back_end(tmp_path):
+    """the default `bench.py --gpus 8` line with EIGHT ranks before an 8-GPU node ever sees it.  The test boxes have one
+    GPU and their process guard allows at most six processes on it, so the eight ranks run on the library's CPU back-end (--device -1:
+    fr_ctx_create(device = -1) on every rank, gloo, row-capped tables, token step counts): the same control flow -- self-launch, rendezvous,
+    barriers and max-over-ranks timing of the headline, the voted per-rank legs (gather_per_bank_all_ranks, configs_all_ranks), the two
+    table-sharded legs under their LineGuard with Model-C batch 4096 cut EIGHT ways (slice plan 496 / 496 / 504 / 488 / 496 ..., F = 504,
+    512 items per rank, one all-gather of [4096 x 504] slices per step) and configs[4]'s inflated row counts -- so that the first real
+    8-GPU run cannot die on plan arithmetic, a missing key or a hung collective.  Asserts every leg's keys, rank 0's scores of its 512 items
+    bit-identical to an unsharded CPU context, and the printed wall-time budget."""
+    import json
+    import time
+    detail = str(tmp_path / "detail.json")
+    t0 = time.time()
+    rc, out, err = _run_bench(["--gpus", "8", "--device", "-1", "--backend", "gloo", "--rows-cap", "2000", "--steps", "4", "--warmup", "2"], timeout=600, detail=detail)
+    wall = time.time() - t0
+    assert rc == 0, err[-3000:]
+    line = _the_line(out)
+    assert line["n_gpus"] == 8 and line["value"] > 0 and line["scaling"] == "weak" and "REHEARSAL" in line["data"]
+    assert line["gather_per_bank_all_ranks"]["ranks_measured"] == 8 and len(line["configs_all_ranks"]) == 3
+    assert all(c["ranks"] == 8 and c["inf_per_s"] > 0 for c in line["configs_all_ranks"].values())
+    for k in ("sharded", "sharded_inflated_fp8"):
+        assert line[k]["n_gpus"] == 8 and line[k]["value"] > 0 and line[k]["ok"] is True and line[k]["scaling"] == "strong" and line[k]["exchange"] == "allgather", line[k]
+    assert "sharded_error" not in line and "roofline" in line and "cpu_baseline" in line
+    j = json.load(open(detail))
+    for k in ("headline", "gather_per_bank_all_ranks", "configs_all_ranks", "sharded", "sharded_inflated_fp8"):
+        assert j["leg_seconds"][k] > 0, j["leg_seconds"]
+    assert abs(sum(j["leg_seconds"].values()) - j["leg_seconds_total"]) < 0.2 and j["leg_seconds_total"] <= wall
+    m_ = re.search(r"bench.py: wall time per leg \(s\): .*; total ([0-9.]+) s", err)
+    assert m_ and float(m_.group(1)) < 300.0, err[-1500:]
+    c3, c4 = j["sharded"]["config"], j["sharded_inflated_fp8"]["config"]
+    assert c3["slice_lens"] == [496, 496, 504, 488, 496, 496, 496, 496] and sum(c3["slice_lens"]) == 3968 and c3["items_this_rank"] == [0, 512]
+    assert c3["exchange_bytes_in_per_rank_per_step"] == 8 * 4096 * 504 * 4 and c3["sharded_vs_unsharded_context"]["bit_identical"] is True
+    assert j["sharded"]["baseline_config"] == "configs[3]" and j["sharded_inflated_fp8"]["baseline_config"] == "configs[4]" and "rows x 5" in c4["workload"]
+
+
+def test_bench_eight_rank_sharded_alltoall_rehearsal():
+    """`bench.py --mode sharded --exchange alltoall` with eight ranks on the CPU back-end: each rank receives only ITS 512 items' slices."""
+    import json
+    rc, out, err = _run_bench(["--gpus", "8", "--device", "-1", "--backend", "gloo", "--mode", "sharded", "--exchange", "alltoall", "--rows-cap", "2000",
+                               "--steps", "2", "--warmup", "1"], timeout=600)
+    assert rc == 0, err[-3000:]
+    j = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    c = j["config"]
+    assert j["n_gpus"] == 8 and c["exchange"] == "alltoall" and c["exchange_bytes_in_per_rank_per_step"] == 8 * 512 * 504 * 4
+    assert c["sharded_vs_unsharded_context"]["bit_identical"] is True
+
+
 @pytest.mark.gpu
 def test_bench_default_line_is_compact(gpu, tmp_path):
     """`bench.py --gpus 1 --quick` (every leg of the driver's command, short timed regions): the stdout line parses, is < 4 KB and carries
@@ -335,6 +383,27 @@ def test_bench_two_ranks_on_one_gpu(gpu, extra):
         assert "sharded_inflated_fp8" not in j      # 316 GB do not fit the one GPU both ranks share here
         rf = j["roofline"]                          # the N > 1 line carries the roofline object too
         assert rf["bound"] == "mfma" and 0.3 < rf["frac"] <= 1.0 and rf["avg_launch_ms"] > 0, rf
+
+
+@pytest.mark.gpu
+def test_bench_four_ranks_on_one_gpu(gpu, tmp_path):
+    """The default N > 1 line with as many ranks as a one-GPU box allows on its card (the pool's process guard: six processes, one of them
+    this test runner): four self-launched ranks on device 0 (--share-device, gloo), row-capped replicas so that four of them fit, every leg of
+    the line -- replicas headline, rank 0's roofline leg, the per-rank gather and configuration legs, the 4-way table-sharded step (bf16
+    transport) against an unsharded context -- and the printed wall-time budget.  (Eight ranks: the CPU-back-end rehearsal above.)"""
+    import json
+    detail = str(tmp_path / "detail.json")
+    rc, out, err = _run_bench(["--gpus", "4", "--backend", "gloo", "--share-device", "--rows-cap", "20000", "--legs", "roofline", "--steps", "300", "--warmup", "100", "--quick"],
+                              timeout=1200, detail=detail)
+    assert rc == 0, err[-3000:]
+    line = _the_line(out)
+    assert line["n_gpus"] == 4 and line["value"] > 0 and line["roofline"]["bound"] == "mfma" and 0.3 < line["roofline"]["frac"] <= 1.0
+    assert line["gather_per_bank_all_ranks"]["ranks_measured"] == 4 and len(line["configs_all_ranks"]) == 3
+    assert line["sharded"]["n_gpus"] == 4 and line["sharded"]["ok"] is True and line["sharded"]["dtype"] == "bf16"
+    j = json.load(open(detail))
+    assert j["sharded"]["config"]["sharded_vs_unsharded_context"]["max_rel_err"] <= 5e-3
+    m_ = re.search(r"bench.py: wall time per leg \(s\): .*; total ([0-9.]+) s", err)
+    assert m_ and float(m_.group(1)) < 600.0, err[-1500:]
 
 
 @pytest.mark.gpu
