@@ -21,9 +21,20 @@ constexpr int FR_GN = 128, FR_GR = 8, FR_GSTAGES = 2;
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-template <int PREC, int MU, int GN, int S, int GR, int MF = 32>
+// EPI = 1: the OUTPUT LAYER folded into the epilogue (SURVEY.md "FC-out (N = 1) folded into FC3 epilogue"; the reference runs it as a fourth
+// GEMM with one output, cuda_server.c:486-491): a 256 (n) x 128 (m) tile holds ALL of FC3's outputs of its 128 items, so the tile rounds
+// R3 once to the chain's type in registers, multiplies by wout and writes the items' scores -- R3 never reaches memory and the batch
+// leaves the stage pipeline one launch earlier.
+struct FrTailArgs {
+    const void *wout;   // bf16 chain: bf16 w[n]; fp8 chain: fp32 w[n] (its output layer runs in fp32 on the de-quantised R3)
+    float *scores;
+    int batch;          // items past it (the padding up to ldm) are not stored
+    float out_scale;    // fp8: 2^-e of R3's quantisation
+};
+
+template <int PREC, int MU, int GN, int S, int GR, int MF = 32, int EPI = 0>
 __device__ __forceinline__ void lp_gemm_body(uint4 *glds, const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
-                                             int N, int ldm, int sc_a, int sc_b, float oscale) {
+                                             int N, int ldm, int sc_a, int sc_b, float oscale, const FrTailArgs tail = FrTailArgs{}) {
     typedef __attribute__((address_space(3))) void *lds_ptr;
     constexpr int GM = 128 * MU, ROW = GN + GM, TN = GN / 64;  // elements per staged row: GN of W, GM of X; TN n tiles of 32 per wave
     const int tid = threadIdx.x, lane = tid & 63;
@@ -202,6 +213,68 @@ __device__ __forceinline__ void lp_gemm_body(uint4 *glds, const uint4 *__restric
             }
         }
     }
+    if constexpr (EPI == 1) {
+        // The output layer, bit for bit as the stage pipeline's own out stage computes it (fc_out_h_body / fc_out_f_body, fr_pipeline.hip): the
+        // N = 256 outputs of an item in eight slices of 32 n, each slice one fmaf chain over ASCENDING n from 0, the eight slice sums added
+        // in slice order.  A slice is exactly one 32 x 32 MFMA tile of the accumulators, but a tile's 32 n of an item sit in TWO lanes (lane r:
+        // n = 8 i + c, lane r + 32: n = 8 i + 4 + c): v_permlane32_swap on the accumulators of a PAIR of tiles hands lane r all 32 n of the
+        // even tile and lane r + 32 all 32 n of the odd one, so every lane runs one whole chain and no partial sum crosses lanes.
+        static_assert(PREC != 0 && MU == 1 && GN == 256 && MF == 32 && TN == 4, "the fused output layer: 256 x 128 tiles of the bf16 / fp8 chains");
+        float *red = reinterpret_cast<float *>(glds);   // [8 slices][128 items]; the operand stages are dead after the K loop
+        __syncthreads();                                // ... once every wave has read its last fragments
+#pragma unroll
+        for (int p = 0; p < TN / 2; p++) {
+            f32x16 &E = acc[2 * p][0], &O = acc[2 * p + 1][0];
+            float a_[16], b_[16];   // after the swap: a_ = the lane's tile, registers of the h = 0 half (n = 8 i + c), b_ = the h = 1 half (n = 8 i + 4 + c)
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(E[j]), __float_as_uint(O[j]), false, false);
+                a_[j] = __uint_as_float(sw[0]);
+                b_[j] = __uint_as_float(sw[1]);
+            }
+            const int slice = 4 * wn + 2 * p + h;       // = (n / 32) of the lane's tile: n0 == 0, the wave's tiles start at 128 wn
+            float sacc = 0.0f;
+            if constexpr (PREC == 1) {
+                const uint4 *wv = reinterpret_cast<const uint4 *>(tail.wout) + 4 * slice;   // 8 bf16 per element
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint4 w4 = wv[i];
+                    const uint32_t ww[4] = {w4.x, w4.y, w4.z, w4.w};
+                    const uint32_t rr[4] = {pack_bf16x2(a_[4 * i + 0], a_[4 * i + 1]), pack_bf16x2(a_[4 * i + 2], a_[4 * i + 3]),
+                                            pack_bf16x2(b_[4 * i + 0], b_[4 * i + 1]), pack_bf16x2(b_[4 * i + 2], b_[4 * i + 3])};
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        sacc = fmaf(__uint_as_float(ww[c] << 16), __uint_as_float(rr[c] << 16), sacc);
+                        sacc = fmaf(__uint_as_float(ww[c] & 0xFFFF0000u), __uint_as_float(rr[c] & 0xFFFF0000u), sacc);
+                    }
+                }
+            } else {
+                const float4 *wf = reinterpret_cast<const float4 *>(tail.wout) + 8 * slice;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int q_[2] = {(int)pack_fp8x4(a_[4 * i + 0], a_[4 * i + 1], a_[4 * i + 2], a_[4 * i + 3], oscale),
+                                       (int)pack_fp8x4(b_[4 * i + 0], b_[4 * i + 1], b_[4 * i + 2], b_[4 * i + 3], oscale)};
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        const float4 w4 = wf[2 * i + c];
+                        sacc = fmaf(w4.x, __builtin_amdgcn_cvt_f32_fp8(q_[c], 0), sacc);
+                        sacc = fmaf(w4.y, __builtin_amdgcn_cvt_f32_fp8(q_[c], 1), sacc);
+                        sacc = fmaf(w4.z, __builtin_amdgcn_cvt_f32_fp8(q_[c], 2), sacc);
+                        sacc = fmaf(w4.w, __builtin_amdgcn_cvt_f32_fp8(q_[c], 3), sacc);
+                    }
+                }
+            }
+            red[slice * 128 + wm * 32 + r] = sacc;
+        }
+        __syncthreads();
+        if (tid < 128 && m0 + tid < tail.batch) {
+            float t = red[tid];
+#pragma unroll
+            for (int q = 1; q < 8; q++) t += red[q * 128 + tid];
+            tail.scores[m0 + tid] = PREC == 2 ? t * tail.out_scale : t;
+        }
+        return;
+    }
     // epilogue: ONE rounding per output; registers 4i..4i+3 of a tile are 4 consecutive n
     if constexpr (MF == 16) {   // 16 x 16 tiles: lane holds m = lane % 16 and n = 4 (lane / 16) + c
 #pragma unroll
@@ -247,6 +320,14 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_kernel(const uint4 *__restrict
                                                          int N, int ldm, int sc_a, int sc_b, float oscale) {
     extern __shared__ uint4 glds[];
     lp_gemm_body<PREC, MU, GN, S, GR, MF>(glds, W, X, Y, KE, N, ldm, sc_a, sc_b, oscale);
+}
+
+// FC3 + the output layer: 256 (n) x 128 (m) tiles, EPI = 1 (see FrTailArgs)
+template <int PREC, int S>
+__global__ void __launch_bounds__(512) fc_lp_gemm_out_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, int KE, int N, int ldm, int sc_a, int sc_b, float oscale,
+                                                             const FrTailArgs tail) {
+    extern __shared__ uint4 glds[];
+    lp_gemm_body<PREC, 1, 256, S, FR_GR, 32, 1>(glds, W, X, nullptr, KE, N, ldm, sc_a, sc_b, oscale, tail);
 }
 
 // ===================================================================================================
@@ -821,157 +902,42 @@ __global__ void __launch_bounds__(256) fc_splitk_gemm_kernel(const uint4 *__rest
 }
 #endif  // FR_EXPERIMENTS
 
-// ===================================================================================================
-// fc_tail_kernel<PREC>: FC3 AND the output layer of a 32-item tile in one launch (bf16 / fp8 chains of a large batch: Model-C at batch
-// 4096 -> 128 workgroups).  The two layers used to be two launches of two different batches of the stage pipeline (FC3 as a 64 x 128-tile
-// GEMM on 128 of the 256 CUs, 5.5 us; the output layer as a 64-workgroup reduction, 3.8 us; a launch boundary between and after them):
-// 4.3 % of the chain's FLOPs at < 0.1 of the MFMA peak.  Here a workgroup owns 32 items for ALL outputs of FC3 (H3 <= 256: wave w takes
-// outputs [32 w, 32 w + 32)), streams the layer's whole weight matrix (256 KiB in bf16) and its 32-item slice of R2 straight from L2 into
-// registers in MFMA fragment layout (the q8 / q16 images are fragment-major: no LDS staging, no barrier in the K loop, a ring of PD
-// k-steps in flight per wave), rounds R3 once into an LDS image shaped like the output layer's operand, and runs the output layer on it.
-// Arithmetic = the separate kernels' bit for bit: the same MFMA (32x32x16 bf16 / scaled 32x32x64 e4m3) over k in ascending order with
-// fp32 accumulation, one rounding of R3, and the output layer's eight k slices of fmaf chains summed in slice order (fc_out_h_body /
-// fc_out_f_body of fr_pipeline.hip); R3 never reaches memory.  Reference shapes: 3-node cuda_server.c:610-621 (layers 3 and 4).
-// ===================================================================================================
-template <int PREC, int PD>
-__global__ void __launch_bounds__(512) fc_tail_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, const void *__restrict__ wout, float *__restrict__ scores,
-                                                      int KE /* element rows of FC3's K */, int N, int ldm, int batch, int sc_a, int sc_b, float oscale, float out_scale) {
-    static_assert(PREC == 1 || PREC == 2, "bf16 / fp8 chains only");
-    __shared__ uint4 r3s[32 * 32];   // the R3 tile as q8 / q16 elements: [element row][item]; 16 KiB
-    __shared__ float red[8 * 64];
-    constexpr int RPS = PREC == 2 ? 4 : 2;   // element rows per k-step (bf16: 2 halves x 8 k; e4m3: 2 halves x 2 rows x 16 k)
-    constexpr int FR = PREC == 2 ? 2 : 1;    // 16-byte loads per fragment
-    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * 32, n0 = wave * 32;
-    const int nk = KE / RPS;
-    if (n0 < N) {   // wave-uniform
-        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(W), 0, (unsigned)KE * (unsigned)N * 16u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(X), 0, (unsigned)KE * (unsigned)ldm * 16u, 0x00020000);
-        const unsigned hrow = PREC == 2 ? 2u * h : (unsigned)h;
-        const unsigned vW = (hrow * (unsigned)N + (unsigned)(n0 + r)) * 16u, vX = (hrow * (unsigned)ldm + (unsigned)(m0 + r)) * 16u;
-        const unsigned rowW = (unsigned)N * 16u, rowX = (unsigned)ldm * 16u;
-        uint4 ra[PD][FR], rb[PD][FR];
-        auto load_step = [&](int j, int slot) {
-#pragma unroll
-            for (int f = 0; f < FR; f++) {
-                ra[slot][f] = bload4u(rsW, vW, (unsigned)(RPS * j + f) * rowW);
-                rb[slot][f] = bload4u(rsX, vX, (unsigned)(RPS * j + f) * rowX);
-            }
-        };
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < PD; i++)
-            if (i < nk) load_step(i, i);
-        for (int jb = 0; jb < nk; jb += PD) {
-#pragma unroll
-            for (int i = 0; i < PD; i++) {
-                if (jb + i < nk) {
-                    if constexpr (PREC == 1) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[i][0]), __builtin_bit_cast(bf16x8, rb[i][0]), acc, 0, 0, 0);
-                    } else {
-                        i32x8 a8, b8;
-                        a8[0] = (int)ra[i][0].x; a8[1] = (int)ra[i][0].y; a8[2] = (int)ra[i][0].z; a8[3] = (int)ra[i][0].w;
-                        a8[4] = (int)ra[i][FR - 1].x; a8[5] = (int)ra[i][FR - 1].y; a8[6] = (int)ra[i][FR - 1].z; a8[7] = (int)ra[i][FR - 1].w;
-                        b8[0] = (int)rb[i][0].x; b8[1] = (int)rb[i][0].y; b8[2] = (int)rb[i][0].z; b8[3] = (int)rb[i][0].w;
-                        b8[4] = (int)rb[i][FR - 1].x; b8[5] = (int)rb[i][FR - 1].y; b8[6] = (int)rb[i][FR - 1].z; b8[7] = (int)rb[i][FR - 1].w;
-                        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc, 0, 0, 0, sc_a, 0, sc_b);
-                    }
-                    if (jb + i + PD < nk) load_step(jb + i + PD, i);
-                }
-            }
-        }
-        // R3 tile -> LDS, ONE rounding per value: registers 4 i .. 4 i + 3 are outputs n0 + 8 i + 4 h + (0..3) of item r
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int n = n0 + 8 * i + 4 * h;
-            if constexpr (PREC == 1) {
-                uint2 hv;
-                hv.x = pack_bf16x2(acc[4 * i + 0], acc[4 * i + 1]);
-                hv.y = pack_bf16x2(acc[4 * i + 2], acc[4 * i + 3]);
-                reinterpret_cast<uint2 *>(r3s)[((n >> 3) * 32 + r) * 2 + ((n & 7) >> 2)] = hv;
-            } else {
-                reinterpret_cast<uint32_t *>(r3s)[((n >> 4) * 32 + r) * 4 + ((n & 15) >> 2)] = pack_fp8x4(acc[4 * i + 0], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3], oscale);
-            }
-        }
-    }
-    __syncthreads();
-    // output layer: thread (q = wave, lane = item) sums its slice of FC3's outputs in ascending order, the eight slices are added in
-    // slice order -- fc_out_h_body / fc_out_f_body with the R3 elements read from LDS
-    {
-        const int q = wave;
-        const int HO = PREC == 1 ? N / 8 : N / 16;
-        const int per = (HO + 7) / 8;
-        const int h0 = q * per, h1 = (h0 + per) < HO ? (h0 + per) : HO;
-        float s = 0.0f;
-        if (lane < 32) {
-            for (int hh = h0; hh < h1; hh++) {
-                const uint4 rv = r3s[hh * 32 + lane];
-                if constexpr (PREC == 1) {
-                    const uint4 wv = reinterpret_cast<const uint4 *>(wout)[hh];
-                    const uint32_t rr[4] = {rv.x, rv.y, rv.z, rv.w}, ww[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        s = fmaf(__uint_as_float(ww[c] << 16), __uint_as_float(rr[c] << 16), s);
-                        s = fmaf(__uint_as_float(ww[c] & 0xFFFF0000u), __uint_as_float(rr[c] & 0xFFFF0000u), s);
-                    }
-                } else {
-                    const int rr[4] = {(int)rv.x, (int)rv.y, (int)rv.z, (int)rv.w};
-                    const float *wf = reinterpret_cast<const float *>(wout) + 16 * hh;
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        s = fmaf(wf[4 * c + 0], __builtin_amdgcn_cvt_f32_fp8(rr[c], 0), s);
-                        s = fmaf(wf[4 * c + 1], __builtin_amdgcn_cvt_f32_fp8(rr[c], 1), s);
-                        s = fmaf(wf[4 * c + 2], __builtin_amdgcn_cvt_f32_fp8(rr[c], 2), s);
-                        s = fmaf(wf[4 * c + 3], __builtin_amdgcn_cvt_f32_fp8(rr[c], 3), s);
-                    }
-                }
-            }
-        }
-        red[q * 64 + lane] = s;
-        __syncthreads();
-        if (q == 0 && lane < 32 && m0 + lane < batch) {
-            float t = red[lane];
-#pragma unroll
-            for (int i = 1; i < 8; i++) t += red[i * 64 + lane];
-            scores[m0 + lane] = PREC == 2 ? t * out_scale : t;
-        }
-    }
-}
-
-// FC3 + output layer as one launch: for the layers the GEMM kernels would otherwise take one by one (large batches), in the bf16 / fp8 chains
+// FC3 + the output layer as ONE launch (fc_lp_gemm_out_kernel): wherever FC3 would run as a GEMM launch of its own (large batches) in the
+// bf16 / fp8 chains and ONE 256-wide n tile holds all of its outputs (the reference's 256, constant.h:26).  Scores are bit-identical to FC3's
+// GEMM launch + the stage pipeline's out stage (the epilogue keeps that stage's summation order), so nothing else in the library can tell the
+// difference -- except the clock: Model-C batch 4096 saves the output launch (6.7 us of chip time per batch at < 0.01 of the MFMA peak), the
+// R3 image's round trip through memory, and one launch of pipeline depth (profiles/r05_fc3_out_epilogue_ab.txt).
+// (Round 4's fc_tail_kernel -- whole-CU workgroups of 32 items streaming W3 from L2 into registers, no LDS staging -- was a different design
+// and no faster inside the four-stream chain; it is gone.)
 bool frk_fc_tail_ok(int precision, int K, int N, int ldm) {
     if (precision != FR_FC_BF16 && precision != FR_FC_FP8) return false;
-    // EXPERIMENTS build only (FR_FC_TAIL=1): bit-identical to the two launches it replaces and 2.6-3 us shorter than their sum alone on the
-    // chip, but no faster inside the four-stream chain (bf16 38.3 -> 38.2 M inf/s) and slower in fp8 (63.0 -> 58.6 M): its 128 workgroups of
-    // 512 threads x 150-170 registers take whole CUs, the two small launches it replaces slip in beside the other streams' kernels
-    // (profiles/r04_experiments.md section 1.3)
-    if (FR_KNOB_ONCE("FC_TAIL", 0) == 0) return false;
-    if (N % 32 || N > 256 || ldm % 32 || ldm < 32 * 64) return false;         // eight waves x 32 outputs; enough 32-item tiles to be worth a launch of its own
-    if (precision == FR_FC_BF16) return K % 16 == 0 && K >= 16;
-    return K % 64 == 0 && N % 16 == 0;
+    if (FR_KNOB_ONCE("FC_TAIL", 1) == 0) return false;   // experiments build: FR_FC_TAIL=0 = the two launches (A/B)
+    const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : K / 8;
+    if (N != 256 || ldm % 128 || (precision == FR_FC_BF16 && K % 8) || KE % FR_GR || KE / FR_GR < 2) return false;
+    return true;
 }
 
 int frk_fc_tail(int precision, const void *W3, const void *R2, const void *wout, float *scores, int K, int N, int ldm, int batch, int e_w, int e_in, int e_r3, hipStream_t s) {
     if (!frk_fc_tail_ok(precision, K, N, ldm)) FR_FAIL(FR_ERR_INVALID, "internal: %d x %d x %d is not a fused-tail layer", K, N, ldm);
-#ifndef FR_EXPERIMENTS
-    FR_FAIL(FR_ERR_INVALID, "internal: fc_tail_kernel is built into the experiments library only");
-#else
-    dim3 grid(ldm / 32);
+    const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : K / 8;
+    const size_t lds = (size_t)FR_GSTAGES * FR_GR * (256 + 128) * 16;
+    dim3 grid(ldm / 128);
+    FrTailArgs t{wout, scores, batch, precision == FR_FC_FP8 ? ldexpf(1.0f, -e_r3) : 1.0f};
     if (precision == FR_FC_BF16) {
-        fc_tail_kernel<1, 16><<<grid, dim3(512), 0, s>>>(reinterpret_cast<const uint4 *>(W3), reinterpret_cast<const uint4 *>(R2), wout, scores, K / 8, N, ldm, batch, 0, 0, 1.0f, 1.0f);
+        static FrLdsAttrOnce once1;
+        if (int rc_ = fr_allow_full_lds(&fc_lp_gemm_out_kernel<1, FR_GSTAGES>, once1)) return rc_;
+        fc_lp_gemm_out_kernel<1, FR_GSTAGES><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(W3), reinterpret_cast<const uint4 *>(R2), KE, N, ldm, 0, 0, 1.0f, t);
         KCHECK();
-        fr_note_kernel("fc_tail_kernel<1, 16>");
+        fr_note_kernel("fc_lp_gemm_out_kernel<1, %d>", FR_GSTAGES);
     } else {
-        fc_tail_kernel<2, 8><<<grid, dim3(512), 0, s>>>(reinterpret_cast<const uint4 *>(W3), reinterpret_cast<const uint4 *>(R2), wout, scores, K / 16, N, ldm, batch, 127 - e_w, 127 - e_in,
-                                                        ldexpf(1.0f, e_r3), ldexpf(1.0f, -e_r3));
+        static FrLdsAttrOnce once2;
+        if (int rc_ = fr_allow_full_lds(&fc_lp_gemm_out_kernel<2, FR_GSTAGES>, once2)) return rc_;
+        fc_lp_gemm_out_kernel<2, FR_GSTAGES><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(W3), reinterpret_cast<const uint4 *>(R2), KE, N, ldm, 127 - e_w, 127 - e_in,
+                                                                         ldexpf(1.0f, e_r3), t);
         KCHECK();
-        fr_note_kernel("fc_tail_kernel<2, 8>");
+        fr_note_kernel("fc_lp_gemm_out_kernel<2, %d>", FR_GSTAGES);
     }
     return FR_OK;
-#endif
 }
 
 // Pipeline shape (experiment knob FR_GEMM_PIPE = 10 * G + NS; 0 = fc_lp_gemm_kernel): G row groups of 4 element rows per sub-step, NS
