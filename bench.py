@@ -857,11 +857,20 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
     pm = (pmc(pmc_key) or {}) if pmc_key else {}
     res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TF[precision], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TF[precision],
                        "traffic": pm.get("traffic_bytes_per_launch"), "kernel": what, "kernel_name": kname, "avg_launch_ms": ms, "algorithmic_flops_per_launch": flops}
+    # what `achieved` is (stage-pipeline rows changed their definition in round 4; the marker makes rows comparable across rounds)
+    res["roofline"]["achieved_is"] = "one_launch_alone_on_one_stream"
     if res.get("concurrent_launches"):
         res["roofline"]["concurrent_launches"] = res["concurrent_launches"]   # achieved = concurrent_launches x algorithmic_flops_per_launch / avg_launch_ms
+        res["roofline"]["achieved_is"] = "concurrent_launches_side_by_side_x_flops_per_launch_over_avg_launch_ms"
     if profile_csv and os.path.exists(os.path.join(ROOT, "profiles", profile_csv)):   # the committed rocprofv3 --kernel-trace --stats summary of this leg's own command: must agree with avg_launch_ms
         res["roofline"]["profiled_avg_launch_us"] = profiled_avg_us(profile_csv, kname)
         res["roofline"]["profile"] = "profiles/" + profile_csv
+        # the same kernel under the row's own MULTI-stream throughput run (as the headline carries it): launches of several streams share the chip,
+        # so a launch is longer but more of them are in flight -- which is why a row's end-to-end rate can exceed its one-stream kernel fraction
+        ms_csv = profile_csv.replace("_kernel_stats.csv", "_4streams_kernel_stats.csv")
+        if os.path.exists(os.path.join(ROOT, "profiles", ms_csv)):
+            res["roofline"]["profiled_avg_launch_us_4streams"] = profiled_avg_us(ms_csv, kname)
+            res["roofline"]["profile_4streams"] = "profiles/" + ms_csv
     if pm:
         res["roofline"]["pmc_mfma_busy_fraction"] = pm.get("mfma_busy_fraction")
         res["roofline"]["traffic_source"] = "%s[%s]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE x2 gfx950 correction), bytes per launch" % (pm.get("pmc_file"), pmc_key)
@@ -1394,6 +1403,39 @@ def main():
                               "latency (a fused launch carries %d batches), not throughput" % ctx.stream_group()},
         }
 
+    # (the host-fed twin of `value` is measured right behind it, before the other legs have created and destroyed their streams)
+    if want("pcie"):
+        # ---- PCIe-inclusive rates (index rows start in HOST memory, scores end in HOST memory; reported, never `value`) ----
+        # host threads of these legs = the reference's THREAD_NUM = 4 (constant.h:42): every pushed batch is first copied into pinned
+        # staging by its driver thread (the counterpart of the reference's read() into pinned memory), and two threads cannot stage
+        # 13 GB/s of index rows (measured: 2 x 2 workers 60.7 M inf/s, 4 x 2 workers 67.1 M, profiles/r02_experiments.md section 5)
+        ht = max(args.threads, 4)
+        hd = fr.Driver(ctx, ht, 4, B)
+        hd.run_host(B, 200, idx_host)
+        n = steady_run(lambda k: hd.run_host(B, k, idx_host), 1.0, n_first=1000, quantum=64)
+        el = hd.run_host(B, n, idx_host)
+        hd.close()
+        result["pcie_inclusive"] = {"value": n * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / n, "timed_batches": n, "timed_s": el,
+                                    "what": "per batch: memcpy to pinned -> fr_worker_submit (5 stage launches; index rows read from and scores written to the pinned "
+                                            "buffers over PCIe) -> sync (the reference's own per-batch sequence, cuda_server.c:425-495), %d threads x 4 workers" % ht}
+        # the reference's loop with its two PCIe hops inside (cuda_server.c:460-461,494-495), streamed: 4 host threads (the reference's THREAD_NUM)
+        # x ONE worker each = one stream per hardware queue -- a block's H2D runs on the worker's copy stream ahead of its launch, the scores
+        # are written straight to pinned memory, the worker's stream carries nothing but kernels (profiles/r05_host_fed_timeline.txt:
+        # 99.6-100 % of the HBM-resident rate; round 4's three commands per block on 4 x 2 streams: 94-96 %)
+        hs = fr.Driver(ctx, ht, 1, B)
+        hs.run_host(B, 2048, idx_host, streaming=True)
+        n = steady_run(lambda k: hs.run_host(B, k, idx_host, streaming=True), STEADY_S, n_first=8192)
+        el = hs.run_host(B, n, idx_host, streaming=True)
+        hs.close()
+        result["value_pcie_inclusive"] = n * B / el   # the same metric with the reference loop's H2D / D2H inside (never `value`: bench contract)
+        result["value_hbm_resident"] = result["value"]
+        result["pcie_inclusive_streaming"] = {"value": n * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / n, "timed_batches": n, "timed_s": el,
+                                              "fraction_of_value": n * B / el / result["value"],
+                                              "what": "host-resident request stream, scores delivered to host memory: blocks of 64 batches staged in pinned "
+                                                      "memory, one H2D (copy stream) + one fused launch per block, scores written to pinned memory by the kernel "
+                                                      "(fr_worker_push_host), %d threads x 1 worker" % ht}
+
+    leg_done("pcie")
     if rank == 0 and cpu:
         result["data"] = "synthetic (REHEARSAL on the CPU back-end: control flow only, no figure of this line is a measurement)"
         result["config"]["rehearsal"] = "fr_ctx_create(device = -1) on every rank, fp32, rows capped at %d, token step counts" % args.rows_cap
@@ -1429,7 +1471,7 @@ def main():
                               "profile_what": "rocprofv3 --kernel-trace --stats of `bench.py --roofline-only`; *_value_4streams_kernel_stats.csv is the same kernel "
                                               "under the DEFAULT four-stream `value` run",
                               "profiled_avg_launch_us_4streams": profiled_avg_us(find_profile("value_4streams_kernel_stats.csv"), kname),
-                              "batches_per_launch": group, "avg_launch_ms": pipe_ms, "algorithmic_flops_per_launch": flops,
+                              "batches_per_launch": group, "avg_launch_ms": pipe_ms, "algorithmic_flops_per_launch": flops, "achieved_is": "one_launch_alone_on_one_stream",
                               "pmc_mfma_busy_fraction": pm.get("mfma_busy_fraction"), "pmc_mfma_f32_flops_per_launch": pm.get("mfma_f32_flops_per_launch"),
                               "note": "`value` above runs %d such streams concurrently" % (args.threads * args.depth)}
         wk.sync()
@@ -1454,38 +1496,6 @@ def main():
                 result["config"]["push_to_scores_us_p50"] = 1e3 * row["push_to_scores_ms_p50"]
 
     leg_done("groups")
-    if want("pcie"):
-        # ---- PCIe-inclusive rates (index rows start in HOST memory, scores end in HOST memory; reported, never `value`) ----
-        # host threads of these legs = the reference's THREAD_NUM = 4 (constant.h:42): every pushed batch is first copied into pinned
-        # staging by its driver thread (the counterpart of the reference's read() into pinned memory), and two threads cannot stage
-        # 13 GB/s of index rows (measured: 2 x 2 workers 60.7 M inf/s, 4 x 2 workers 67.1 M, profiles/r02_experiments.md section 5)
-        ht = max(args.threads, 4)
-        hd = fr.Driver(ctx, ht, 4, B)
-        hd.run_host(B, 200, idx_host)
-        n = steady_run(lambda k: hd.run_host(B, k, idx_host), 1.0, n_first=1000, quantum=64)
-        el = hd.run_host(B, n, idx_host)
-        hd.close()
-        result["pcie_inclusive"] = {"value": n * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / n, "timed_batches": n, "timed_s": el,
-                                    "what": "per batch: memcpy to pinned -> fr_worker_submit (5 stage launches; index rows read from and scores written to the pinned "
-                                            "buffers over PCIe) -> sync (the reference's own per-batch sequence, cuda_server.c:425-495), %d threads x 4 workers" % ht}
-        # the reference's loop with its two PCIe hops inside (cuda_server.c:460-461,494-495), streamed: 4 host threads (the reference's THREAD_NUM)
-        # x ONE worker each = one stream per hardware queue -- a block's H2D runs on the worker's copy stream ahead of its launch, the scores
-        # are written straight to pinned memory, the worker's stream carries nothing but kernels (profiles/r05_host_fed_timeline.txt:
-        # 99.6-100 % of the HBM-resident rate; round 4's three commands per block on 4 x 2 streams: 94-96 %)
-        hs = fr.Driver(ctx, ht, 1, B)
-        hs.run_host(B, 2048, idx_host, streaming=True)
-        n = steady_run(lambda k: hs.run_host(B, k, idx_host, streaming=True), STEADY_S, n_first=8192)
-        el = hs.run_host(B, n, idx_host, streaming=True)
-        hs.close()
-        result["value_pcie_inclusive"] = n * B / el   # the same metric with the reference loop's H2D / D2H inside (never `value`: bench contract)
-        result["value_hbm_resident"] = result["value"]
-        result["pcie_inclusive_streaming"] = {"value": n * B / el, "unit": "inferences/s", "ms_per_step": 1e3 * el / n, "timed_batches": n, "timed_s": el,
-                                              "fraction_of_value": n * B / el / result["value"],
-                                              "what": "host-resident request stream, scores delivered to host memory: blocks of 64 batches staged in pinned "
-                                                      "memory, one H2D (copy stream) + one fused launch per block, scores written to pinned memory by the kernel "
-                                                      "(fr_worker_push_host), %d threads x 1 worker" % ht}
-
-    leg_done("pcie")
     if want("tcp"):
         try:
             result["tcp_streaming"] = leg_tcp(B, local_rank)

@@ -100,6 +100,10 @@ template <int NT, int R, int CNT>
 __device__ __forceinline__ void ft_gemm_ct(f32x16 (&acc)[NT], float4 (&ring)[R][NT], const FtW &w, int n0, const uint4 *Bq, int gb0, int g0, int hk,
                                            int lm) {
     const unsigned s0 = (unsigned)g0 * w.row2 + (unsigned)n0 * 16u;
+    // The refill's SGPR offset is a RUNNING value (one s_add per group), re-declared opaque every group: written as s0 + (g + R) * row2 in
+    // fully unrolled code, hipcc computes dozens of them ahead of their loads and runs out of scalar registers -- Model-B's 110-group FC1
+    // spilled 92 SGPRs into vector-register lanes and read them back inside the MFMA stream.
+    unsigned so = s0 + (unsigned)R * w.row2;
     const uint4 *bl = Bq + (size_t)(2 * gb0 + hk) * FR_FT_LD + lm;
     f32x16 alt;
 #pragma unroll
@@ -127,7 +131,9 @@ __device__ __forceinline__ void ft_gemm_ct(f32x16 (&acc)[NT], float4 (&ring)[R][
         }
         if (g + R < CNT) {  // compile-time after unrolling: refill the slot just consumed
 #pragma unroll
-            for (int t = 0; t < NT; t++) ring[g % R][t] = ft_wload(w, s0 + (unsigned)(g + R) * w.row2, 512 * t);
+            for (int t = 0; t < NT; t++) ring[g % R][t] = ft_wload(w, so, 512 * t);
+            so += w.row2;
+            asm volatile("" : "+s"(so));
         }
         __builtin_amdgcn_sched_barrier(0);  // keep this interleave: the scheduler would otherwise sink the refills
         bcur = bnext;

@@ -469,6 +469,10 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
                 // the slot of fragment q = 4 g + t takes fragment q + R1D: k-group g + (t + R1D) / 4 (so1 + ((t + R1D) / 4 - 1) row2), n tile (t + R1D) % 4
                 auto refill = [&](int t) {
                     const int q2 = 4 * g + t + R1D;
+#ifdef FR_HS_W1_SKIP   // TIMING ABLATION (wrong scores; `make w1skip` only): every FR_HS_W1_SKIP-th FC1 weight fragment is not loaded, its slot keeps the old one --
+                       // an upper bound on what a design that streams fewer W1 bytes per item (a two-CU supertile) could gain (profiles/r05_experiments.md section 3)
+                    if (q2 % FR_HS_W1_SKIP == 0) return;
+#endif
                     if (q2 < 4 * KG) ring1[(4 * g + t) % R1D] = ftk_load(W1, so1 + (unsigned)((t + R1D) / 4 - 1) * W1.row2, 512 * (q2 & 3));
                 };
                 const bool more_b = gl + 1 < kgs;

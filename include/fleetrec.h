@@ -398,7 +398,10 @@ int fr_comm_set_wait_ms(fr_comm *c, int wait_ms);
  * Failure protocol: argument / state errors are returned before anything is enqueued and leave the communicator usable (the ranks of a job
  * are driven with the same arguments); a rank whose FC chain fails still takes part in both collectives, its score chunk travels as NaN
  * and its status word (one float all-gathered behind every chunk) makes EVERY rank's fr_worker_sync return FR_ERR_COMM naming it; a
- * device / RCCL failure aborts the rank's communicator, and the peers' waits are bounded (fr_comm_set_wait_ms). */
+ * device / RCCL failure aborts the rank's communicator, and the peers' waits are bounded (fr_comm_set_wait_ms).
+ * A call that returns an error AFTER its first collective (the local FC chain failed) has still enqueued the step: the caller must call
+ * fr_worker_sync(w) before the worker's next submit (it returns FR_ERR_COMM naming the rank).  fr_comm_destroy between a submit and its
+ * fr_worker_sync is safe: the worker keeps the communicator alive until it has synchronised. */
 int fr_worker_submit_sharded(fr_worker *w, fr_comm *comm, int batch);
 /* COLLECTIVE, synchronous: fp8 activation exponents of a sharded context from this batch -- every rank calibrates on the same
  * all-gathered fp32 slices, so all ranks end with identical exponents (a slice encoded by one rank is decoded by the others). */

@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
-"""Builds profiles/r04_roofline_pairs.json from one evidence job (tools/jobs/r04_evidence.sh): for every profiled leg, the HIP-event launch
-time the profiled run printed on its own JSON line (stats_<leg>.log) beside the rocprofv3 average of the same kernel in that run's
-kernel-stats CSV (<leg>_kernel_stats.csv) -- the same-run pairs tools/check_evidence.py checks to 3.5 %.
-usage: python tools/make_roofline_pairs.py [gpurun_out/r04_evidence] [profiles/r04_roofline_pairs.json]"""
+"""Builds profiles/rNN_roofline_pairs.json from one evidence job (tools/jobs/r05_evidence.sh): for every profiled leg, the HIP-event launch
+time the profiled run printed on its own JSON line (stats_<leg>.log) beside the rocprofv3 figures of the same kernel in that run: the
+kernel-stats CSV's average (<leg>_kernel_stats.csv) and, from the same run's kernel trace (<leg>_kernel_durations.json, made by
+tools/trace_kernel_median.py), the MEDIAN duration and the span per launch of the back-to-back run -- the profiler's own equivalent of the
+HIP-event figure.  tools/check_evidence.py checks the same-run pairs.
+usage: python tools/make_roofline_pairs.py [gpurun_out/r05_evidence] [profiles/r05_roofline_pairs.json]"""
 import csv
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r04_evidence")
-dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r04_roofline_pairs.json")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r05_evidence")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r05_roofline_pairs.json")
 
 
 def line_of(leg):
@@ -44,6 +46,14 @@ for leg in ("roofline", "gather_per_table_uniform", "gather_per_bank_uniform", "
         raise SystemExit("%s: kernel %s not in the CSV" % (leg, key))
     live = 1e3 * rf["avg_launch_ms"]
     out[leg] = {"kernel": rf["kernel_name"], "hip_events_us_same_run": live, "rocprofv3_avg_us": float(hit[0]["AverageNs"]) / 1e3,
-                "rocprofv3_calls": int(hit[0]["Calls"]), "frac_same_run": rf["frac"]}
+                "rocprofv3_calls": int(hit[0]["Calls"]), "rocprofv3_max_us": float(hit[0]["MaxNs"]) / 1e3, "frac_same_run": rf["frac"]}
+    dj = os.path.join(src, "%s_kernel_durations.json" % leg)
+    if os.path.exists(dj):
+        for name, rec in json.load(open(dj)).items():
+            if key in name:
+                out[leg].update({"rocprofv3_median_us": rec["median_us"], "rocprofv3_p10_us": rec["p10_us"], "rocprofv3_p90_us": rec["p90_us"],
+                                 "rocprofv3_span_per_launch_us": rec.get("span_per_launch_us"), "rocprofv3_avg_in_back_to_back_run_us": rec.get("avg_in_that_run_us"),
+                                 "back_to_back_launches": rec.get("back_to_back_launches")})
+                break
 json.dump(out, open(dst, "w"), indent=1)
 print("wrote %s (%d legs)" % (dst, len(out)))

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Per-kernel duration statistics of a rocprofv3 --kernel-trace CSV that `--stats` does not print: the MEDIAN (the stats file's AverageNs
+includes the cold launches at the head of a run -- its MaxNs gives them away), p10 / p90, and, per stream, the SPAN per launch of the
+kernel's longest uninterrupted run of back-to-back launches (first start -> last end, over the launches in it): what HIP events around
+those launches measure.  avg > span means consecutive launches overlap (a kernel whose last workgroups trail lets its successor start).
+usage: trace_kernel_median.py <kernel_trace.csv> [out.json]"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+by = defaultdict(list)
+for r in rows:
+    by[r["Kernel_Name"].split("(")[0].replace("void ", "").strip()].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Stream_Id", "0")))
+out = {}
+for name, ev in by.items():
+    d = sorted(e[1] - e[0] for e in ev)
+    n = len(d)
+    rec = {"calls": n, "avg_us": sum(d) / n / 1e3, "median_us": d[n // 2] / 1e3, "p10_us": d[n // 10] / 1e3, "p90_us": d[min(n - 1, 9 * n // 10)] / 1e3, "max_us": d[-1] / 1e3}
+    # longest back-to-back run on one stream: consecutive launches of THIS kernel whose gap is below half a duration
+    best = None
+    streams = defaultdict(list)
+    for e in sorted(ev):
+        streams[e[2]].append(e)
+    for L in streams.values():
+        run = [L[0]]
+        for a, b in zip(L, L[1:]):
+            if b[0] - a[1] < 0.5 * d[n // 2]:
+                run.append(b)
+            else:
+                if best is None or len(run) > len(best):
+                    best = run
+                run = [b]
+        if best is None or len(run) > len(best):
+            best = run
+    if best and len(best) >= 8:
+        core = best[len(best) // 4:]   # the run's last three quarters: clocks settled
+        rec["back_to_back_launches"] = len(core)
+        rec["span_per_launch_us"] = (max(e[1] for e in core) - core[0][0]) / len(core) / 1e3
+        rec["avg_in_that_run_us"] = sum(e[1] - e[0] for e in core) / len(core) / 1e3
+    out[name] = rec
+if len(sys.argv) > 2:
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
+for name, rec in sorted(out.items(), key=lambda kv: -kv[1]["calls"] * kv[1]["avg_us"])[:12]:
+    print("%-70s n=%5d avg %8.2f median %8.2f p10 %8.2f p90 %8.2f max %8.2f  span/launch %s" % (name[:70], rec["calls"], rec["avg_us"], rec["median_us"], rec["p10_us"], rec["p90_us"], rec["max_us"],
+          "%8.2f (%d back to back, avg there %8.2f)" % (rec["span_per_launch_us"], rec["back_to_back_launches"], rec["avg_in_that_run_us"]) if "span_per_launch_us" in rec else "-"))
