@@ -751,7 +751,7 @@ def gemm_workgroups(kname, N, ldm):
     return None
 
 
-def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_host0, threads, depth, label, min_s=1.0, pmc_key=None, env=None, profile_csv=None, tag=None):
+def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_host0, threads, depth, label, min_s=1.0, pmc_key=None, env=None, profile_csv=None, tag=None, roofline=True):
     """One non-headline BASELINE configuration: steady-state throughput (>= 1 s) + an in-run roofline object for its dominant
     kernel from HIP events on one worker's stream."""
     prec_enum = {"f32": fr.FC_FP32, "bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[precision]
@@ -786,6 +786,8 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
     else:   # --roofline-only: no multi-stream loop
         res = {"tag": tag, "workload": label, "dtype": precision, "value": None, "unit": "inferences/s", "timed_batches": 0, "timed_s": 0.0, "ms_per_step": None,
                "fc_tflops_end_to_end": None, "frac_of_mfma_peak_end_to_end": None}
+    if not roofline:   # --throughput-only: a profiled run of the multi-stream loop alone (profiles/*_4streams_kernel_stats.csv)
+        return res
     wk = fr.Worker(ctx, B)
     group = ctx.stream_group()
     if group > 1:   # fused item-tile kernel: one launch = the whole hot path of min(group, items per launch / B) queued batches
@@ -1261,6 +1263,7 @@ def main():
                     help="rocprofv3 --kernel-trace --stats runs: nothing but the single-stream roofline launches touches the kernels being priced (the "
                          "multi-stream throughput loops, whose concurrent launches stretch each other, are skipped), so the profiler's average agrees with "
                          "the HIP-event figure on the bench line")
+    ap.add_argument("--throughput-only", action="store_true", help="single-configuration runs: the multi-stream throughput loop alone, no one-stream roofline leg (profiled: *_4streams_kernel_stats.csv)")
     ap.add_argument("--quick", action="store_true", help="profiling runs: 0.3 s instead of >= 2 s behind `value` (the legs are what is being profiled)")
     ap.add_argument("--per-bank", action="store_true", help="single-configuration runs (--model / --precision): FR_INDEX_PER_BANK context and indices")
     ap.add_argument("--no-multi-gather", action="store_true", help="N > 1: skip the per-rank legs (gather_per_bank_all_ranks, configs_all_ranks)")
@@ -1346,12 +1349,12 @@ def main():
         # one non-headline configuration on its own: throughput + its roofline leg
         res = leg_config(fr, ctx, model, B, args.precision, d_idx, d_dense, idx_host[0], dense_host[0] if dense_host else None, args.threads, args.depth,
                          "Model-%s batch=%d %s FC chain, %s, index rows resident in HBM, %d batches per launch" % (args.model, B, args.precision, "one index per bank" if args.per_bank else "per-table indices", ctx.stream_group()),
-                         min_s=0.0 if args.roofline_only else (0.05 if args.quick else 1.0), env=env)
+                         min_s=0.0 if args.roofline_only else (0.05 if args.quick else 1.0), env=env, roofline=not args.throughput_only)
         if rank == 0:
             print(json.dumps({"metric": "inferences/sec", "value": res["value"], "unit": "inferences/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                               "dtype": args.precision, "data": "synthetic", "config": {"workload": res["workload"]}, "timed_batches": res["timed_batches"],
-                              "timed_s": res["timed_s"], "roofline": res["roofline"], "fc_tflops_end_to_end": res["fc_tflops_end_to_end"],
+                              "timed_s": res["timed_s"], "roofline": res.get("roofline"), "fc_tflops_end_to_end": res["fc_tflops_end_to_end"],
                               "layer_launch_ms": res.get("layer_launch_ms"), "layer_kernels": res.get("layer_kernels"), "layer_concurrency": res.get("layer_concurrency"),
                               "layer_stream_busy_ms": res.get("layer_stream_busy_ms")}))
         ctx.close()

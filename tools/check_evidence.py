@@ -2,10 +2,16 @@
 """Recomputes every roofline fraction of a committed bench line from the committed rocprofv3 kernel-stats CSVs (what the judge does by
 hand): prints, per roofline object, the kernel the library reported, the HIP-event time on the line, the profiler's average for that
 kernel in the CSV the object names, and the two fractions.  The CSVs come from separate (profiled) runs of the same job, so the driver
-line's HIP-event time and the CSV average differ by the run-to-run spread of power-bound kernels (up to ~7 % on the bf16 GEMM); the SAME-RUN
-pairs -- the HIP-event figure each profiled run printed itself against that run's CSV -- are in profiles/r03_roofline_pairs.json and agree
-within 3.5 %.  Exit status 1 when a cross-run pair differs by more than 8 %, a same-run pair by more than 6 %, or a CSV lacks the kernel.
-usage: python tools/check_evidence.py [profiles/r04_bench_detail_driver_cmd.json]"""
+line's HIP-event time and the CSV average differ by the run-to-run spread of power-bound kernels (up to ~7 % on the bf16 GEMM): a
+cross-run pair may differ by 8 %.
+The SAME-RUN pairs (profiles/rNN_roofline_pairs.json, tools/make_roofline_pairs.py) put the HIP-event figure each profiled run printed
+itself beside that run's own kernel trace, three ways: the stats file's AVERAGE over every call (cold head of the run included -- its
+MaxNs gives that away), the MEDIAN duration, and the SPAN per launch of the back-to-back run (first start -> last end over the launches):
+the span is what HIP events around those launches measure, so THAT pair must agree within 3.5 % (the round-3 tolerance; round 4 had
+widened the average's tolerance to 6 % to pass two legs -- ADVICE r04).  Median vs HIP events may differ by more where consecutive
+launches overlap (a kernel whose last workgroups trail lets its successor start: span < duration) or where several launches run side by
+side (the Model-C GEMM rows): reported, and checked at 8 %.  Exit status 1 on any violation or when a CSV lacks the kernel.
+usage: python tools/check_evidence.py [profiles/r05_bench_detail_driver_cmd.json]"""
 import csv
 import json
 import os
@@ -13,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # round 4: the stdout line is a compact summary; the roofline objects of every leg are in the DETAIL file written beside it
-line = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_bench_detail_driver_cmd.json")
+line = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_bench_detail_driver_cmd.json")
 txt = open(line).read().strip()
 d = json.loads(txt) if txt.startswith("{\n") or "\n" in txt[:3] else json.loads(txt.splitlines()[-1])
 
@@ -49,17 +55,22 @@ for name, rf, csvp in rows:
     bad += 0 if ok else 1
     print("%-50s %-48s live %8.1f us  profiled %s (%d calls)  frac %.3f -> %s  %s" % (
         name, rf["kernel_name"], live, "%8.1f us" % p if p else "   absent", calls, frac_live, "%.3f" % (frac_live * live / p) if p else "-", "ok" if ok else "MISMATCH"))
-rnd = "r03" if "r03" in os.path.basename(line) else "r04"
+import re
+m_ = re.search(r"(r\d\d)_", os.path.basename(line))
+rnd = m_.group(1) if m_ else "r05"
 pairs = os.path.join(ROOT, "profiles", rnd + "_roofline_pairs.json")
 if os.path.exists(pairs):
-    print("same-run pairs (profiles/%s_roofline_pairs.json): the HIP-event figure each PROFILED run printed itself against that run's CSV" % rnd)
+    print("same-run pairs (profiles/%s_roofline_pairs.json): the HIP-event figure each PROFILED run printed itself against that run's own kernel trace" % rnd)
     for leg, e in json.load(open(pairs)).items():
-        # 6 %: two known systematic differences sit inside it -- a kernel whose workgroups end unevenly (Model-B fp32: two rounds of workgroups per CU)
-        # overlaps its successor's start, so the profiler's per-kernel durations sum to more than the stream's wall time (+ 3 %); a launch fed by
-        # 256 host pushes (Model-A bf16 at 256 batches per launch) shows the host's share in the HIP-event figure (- 5 %)
-        ok = abs(e["rocprofv3_avg_us"] - e["hip_events_us_same_run"]) <= 0.06 * e["hip_events_us_same_run"]
+        ev = e["hip_events_us_same_run"]
+        span, med, avg = e.get("rocprofv3_span_per_launch_us"), e.get("rocprofv3_median_us"), e["rocprofv3_avg_us"]
+        if span is not None:        # like for like: what the events bracket
+            ok = abs(span - ev) <= 0.035 * ev and (med is None or abs(med - ev) <= 0.08 * ev)
+        else:                       # (a pairs file of an earlier round: the stats average only, at that round's 6 %)
+            ok = abs(avg - ev) <= 0.06 * ev
         bad += 0 if ok else 1
-        print("  %-26s %-48s HIP events %8.1f us  rocprofv3 %8.1f us (%d calls)  %+.1f %%  %s" % (
-            leg, e["kernel"], e["hip_events_us_same_run"], e["rocprofv3_avg_us"], e["rocprofv3_calls"],
-            100 * (e["rocprofv3_avg_us"] / e["hip_events_us_same_run"] - 1), "ok" if ok else "MISMATCH"))
+        print("  %-26s %-44s HIP events %8.1f us | span/launch %s  median %s  avg %8.1f (max %s, %d calls)  %s" % (
+            leg, e["kernel"][:44], ev, "%8.1f (%+.1f %%)" % (span, 100 * (span / ev - 1)) if span is not None else "       -",
+            "%8.1f (%+.1f %%)" % (med, 100 * (med / ev - 1)) if med is not None else "       -", avg,
+            "%.0f" % e["rocprofv3_max_us"] if e.get("rocprofv3_max_us") else "-", e["rocprofv3_calls"], "ok" if ok else "MISMATCH"))
 sys.exit(1 if bad else 0)
