@@ -12,13 +12,14 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 by = defaultdict(list)
 for r in rows:
-    by[r["Kernel_Name"].split("(")[0].replace("void ", "").strip()].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Stream_Id", "0")))
+    by[r["Kernel_Name"].split("(")[0].replace("void ", "").strip()].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "0") + "/" + r.get("Stream_Id", "0")))
 out = {}
 for name, ev in by.items():
     d = sorted(e[1] - e[0] for e in ev)
     n = len(d)
     rec = {"calls": n, "avg_us": sum(d) / n / 1e3, "median_us": d[n // 2] / 1e3, "p10_us": d[n // 10] / 1e3, "p90_us": d[min(n - 1, 9 * n // 10)] / 1e3, "max_us": d[-1] / 1e3}
-    # longest back-to-back run on one stream: consecutive launches of THIS kernel whose gap is below half a duration
+    # longest back-to-back run on one stream (hardware queue / stream id): consecutive launches of THIS kernel with at most a tenth of a duration
+    # (>= 4 us) between them -- a host that cannot push fast enough leaves such gaps and HIP events see them too; a host synchronisation leaves more
     best = None
     streams = defaultdict(list)
     for e in sorted(ev):
@@ -26,7 +27,7 @@ for name, ev in by.items():
     for L in streams.values():
         run = [L[0]]
         for a, b in zip(L, L[1:]):
-            if b[0] - a[1] < 0.5 * d[n // 2]:
+            if b[0] - a[1] < max(0.1 * d[n // 2], 4000.0):
                 run.append(b)
             else:
                 if best is None or len(run) > len(best):
