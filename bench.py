@@ -815,6 +815,9 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
         layer_ms, layer_kernels, layer_conc, layer_spread = [], [], [], []
         reps = 60
         for layer in range(4):
+            if layer == 3 and layer_kernels[2].startswith("fc_lp_gemm_out_kernel"):   # the output layer rides in FC3's epilogue: no launch of its own in the chain
+                res["output_layer"] = "folded into FC3's epilogue (%s): no launch of its own" % layer_kernels[2]
+                break
             wk.fc_layer_only(B, layer)
             layer_kernels.append(wk.last_kernel())
             wk.sync()
