@@ -53,7 +53,8 @@ for leg in ("roofline", "gather_per_table_uniform", "gather_per_bank_uniform", "
             if key in name:
                 out[leg].update({"rocprofv3_median_us": rec["median_us"], "rocprofv3_p10_us": rec["p10_us"], "rocprofv3_p90_us": rec["p90_us"],
                                  "rocprofv3_span_per_launch_us": rec.get("span_per_launch_us"), "rocprofv3_avg_in_back_to_back_run_us": rec.get("avg_in_that_run_us"),
-                                 "back_to_back_launches": rec.get("back_to_back_launches")})
+                                 "back_to_back_launches": rec.get("back_to_back_launches"), "back_to_back_runs": rec.get("back_to_back_runs"),
+                                 "rocprofv3_span_per_launch_min_us": rec.get("span_per_launch_min_us"), "rocprofv3_span_per_launch_max_us": rec.get("span_per_launch_max_us")})
                 break
 json.dump(out, open(dst, "w"), indent=1)
 print("wrote %s (%d legs)" % (dst, len(out)))

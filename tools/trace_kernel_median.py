@@ -18,9 +18,11 @@ for name, ev in by.items():
     d = sorted(e[1] - e[0] for e in ev)
     n = len(d)
     rec = {"calls": n, "avg_us": sum(d) / n / 1e3, "median_us": d[n // 2] / 1e3, "p10_us": d[n // 10] / 1e3, "p90_us": d[min(n - 1, 9 * n // 10)] / 1e3, "max_us": d[-1] / 1e3}
-    # longest back-to-back run on one stream (hardware queue / stream id): consecutive launches of THIS kernel with at most a tenth of a duration
-    # (>= 4 us) between them -- a host that cannot push fast enough leaves such gaps and HIP events see them too; a host synchronisation leaves more
-    best = None
+    # back-to-back runs on one stream (hardware queue / stream id): consecutive launches of THIS kernel with at most a tenth of a duration
+    # (>= 4 us) between them -- a host that cannot push fast enough leaves such gaps and HIP events see them too; a host synchronisation
+    # leaves more and ends the run.  bench.py times its launches in blocks and reports the MEDIAN block: so does this -- span per launch of
+    # every run of >= 8 launches (first start -> last end over its launches), the median over the runs.
+    runs = []
     streams = defaultdict(list)
     for e in sorted(ev):
         streams[e[2]].append(e)
@@ -30,19 +32,20 @@ for name, ev in by.items():
             if b[0] - a[1] < max(0.1 * d[n // 2], 4000.0):
                 run.append(b)
             else:
-                if best is None or len(run) > len(best):
-                    best = run
+                runs.append(run)
                 run = [b]
-        if best is None or len(run) > len(best):
-            best = run
-    if best and len(best) >= 8:
-        core = best[len(best) // 4:]   # the run's last three quarters: clocks settled
-        rec["back_to_back_launches"] = len(core)
-        rec["span_per_launch_us"] = (max(e[1] for e in core) - core[0][0]) / len(core) / 1e3
-        rec["avg_in_that_run_us"] = sum(e[1] - e[0] for e in core) / len(core) / 1e3
+        runs.append(run)
+    runs = [r_ for r_ in runs if len(r_) >= 8]
+    if runs:
+        spans = sorted((max(e[1] for e in r_) - r_[0][0]) / len(r_) / 1e3 for r_ in runs)
+        rec["back_to_back_runs"] = len(runs)
+        rec["back_to_back_launches"] = sum(len(r_) for r_ in runs)
+        rec["span_per_launch_us"] = spans[len(spans) // 2]
+        rec["span_per_launch_min_us"], rec["span_per_launch_max_us"] = spans[0], spans[-1]
+        rec["avg_in_that_run_us"] = sum(e[1] - e[0] for r_ in runs for e in r_) / rec["back_to_back_launches"] / 1e3
     out[name] = rec
 if len(sys.argv) > 2:
     json.dump(out, open(sys.argv[2], "w"), indent=1)
 for name, rec in sorted(out.items(), key=lambda kv: -kv[1]["calls"] * kv[1]["avg_us"])[:12]:
     print("%-70s n=%5d avg %8.2f median %8.2f p10 %8.2f p90 %8.2f max %8.2f  span/launch %s" % (name[:70], rec["calls"], rec["avg_us"], rec["median_us"], rec["p10_us"], rec["p90_us"], rec["max_us"],
-          "%8.2f (%d back to back, avg there %8.2f)" % (rec["span_per_launch_us"], rec["back_to_back_launches"], rec["avg_in_that_run_us"]) if "span_per_launch_us" in rec else "-"))
+          "%8.2f (median of %d runs, %d launches, avg there %8.2f)" % (rec["span_per_launch_us"], rec["back_to_back_runs"], rec["back_to_back_launches"], rec["avg_in_that_run_us"]) if "span_per_launch_us" in rec else "-"))
