@@ -951,7 +951,9 @@ def main_sharded(args, graft):
     fr = graft.load_package()
     dist_mod = importlib.import_module("fleetrec_amd.dist")
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    env = dist_mod.DistEnv(args.backend if world > 1 else None)
+    if args.force_process_group:
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+    env = dist_mod.DistEnv(args.backend if (world > 1 or args.force_process_group) else None, force_group=args.force_process_group)
     if args.device == -1:
         usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         fr.cpu_set_threads(max(1, usable // world))
@@ -1016,7 +1018,7 @@ def run_sharded(fr, dist_mod, env, dev_id, args, auto_steps_s=0.0):
     gathered = [torch.empty((G, B // G if a2a else B, F * esz), dtype=torch.uint8, device=dev) for _ in range(2)]
     lo, hi = dist_mod.item_range(r, G, B)
     scores = torch.empty((max(hi - lo, 1),), dtype=torch.float32, device=dev)
-    gloo = world > 1 and args.backend == "gloo"   # plumbing test: gloo moves host tensors
+    gloo = env.dist is not None and args.backend == "gloo"   # plumbing test: gloo moves host tensors
 
     def xchg(fn, src, dst):
         if gloo:
@@ -1139,7 +1141,7 @@ def run_sharded(fr, dist_mod, env, dev_id, args, auto_steps_s=0.0):
                    "shard_table_bytes_this_rank": int(sum(t.rows * t.dim * 4 for si in model.segments() if si.kind == fr.SEG_TABLE and offs[r] <= si.rec_offset < offs[r] + lens[r]
                                                         for t in [model.tables()[si.src]])),
                    "min_shards_for_288GB": model.min_shards(),   # north_star: shard ONLY when the tables outgrow one GPU (1 = replicas would do)
-                   "exchange": args.exchange, "backend": args.backend if world > 1 else None,
+                   "exchange": args.exchange, "backend": args.backend if env.dist is not None else None,
                    "slice_transport": args.precision if lp else "f32", "pipelined_equals_stepwise": verified,
                    "sharded_vs_unsharded_context": vs_unsharded,
                    "exchange_bytes_in_per_rank_per_step": int(G * (B // G if a2a else B) * F * esz)}}
@@ -1252,6 +1254,9 @@ def main():
                     help="sharded mode: all-gather every slice to every rank (BASELINE configs[3]) or all-to-all only each rank's items")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true", help="plumbing test: ranks share the visible GPU(s) (use with --backend gloo)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="--gpus 1: build the torch.distributed process group (--backend nccl = RCCL) for the ONE rank and run the N > 1 legs through it -- "
+                         "a one-GPU rehearsal of the RCCL code path (device tensors, all_gather_into_tensor on RCCL's stream, the external-stream hand-over)")
     ap.add_argument("--device", type=int, default=None,
                     help="-1: REHEARSAL on the library's CPU back-end (fr_ctx_create device = -1), no GPU touched -- the whole control flow of the line (every "
                          "leg's collectives, votes, plan arithmetic, LineGuard) with fp32 CPU contexts, row-capped tables and token step counts; use with "
@@ -1293,8 +1298,11 @@ def main():
         return main_sharded(args, graft)
     fr = graft.load_package()
     dist_mod = importlib.import_module("fleetrec_amd.dist")
-    env = dist_mod.DistEnv(args.backend if world_env > 1 else None)
+    if args.force_process_group:
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+    env = dist_mod.DistEnv(args.backend if (world_env > 1 or args.force_process_group) else None, force_group=args.force_process_group)
     rank, world = env.rank, env.world
+    multi = world > 1 or args.force_process_group   # the N > 1 legs (one rank with --force-process-group: the RCCL code path rehearsed on one GPU)
     cpu = args.device == -1   # rehearsal on the CPU back-end: see --device
     if cpu:
         if args.model != "A" or args.precision != "f32":
@@ -1318,7 +1326,7 @@ def main():
         t_leg[0] = now
     # N > 1: the line carries the `roofline` object as well -- rank 0's HIP-event leg of the dominant kernel on its own replica while the
     # other ranks wait at the next barrier (one rank's launches on one stream: the same measurement as at N = 1); the other rank-0 legs are N = 1 only
-    want = lambda name: rank == 0 and ("all" in legs or name in legs) and (world == 1 or name == "roofline")
+    want = lambda name: rank == 0 and ("all" in legs or name in legs) and (not multi or name == "roofline")
 
     B = args.batch
     which = {"A": fr.MODEL_A, "B": fr.MODEL_B, "C": fr.MODEL_C}[args.model]
@@ -1670,7 +1678,7 @@ def main():
             result.setdefault("gather", {})["error"] = repr(ex)
 
     leg_done("gather_and_configs_C")
-    if world > 1 and not args.no_multi_gather:
+    if multi and not args.no_multi_gather:
         # N > 1: the other half of BASELINE.json's metric ("embedding-gather HBM GB/s vs peak, 1 -> 8 MI355X") and BASELINE.md section 3's
         # other models -- every rank runs the legs below on its own replicas at the same time, rank 0 reports the SUM of the per-rank rates.
         # Collectives sit OUTSIDE the try blocks and every rank reaches every one of them whatever happens to its own leg: a rank that
@@ -1776,7 +1784,7 @@ def main():
             holder["c"][1].close()
         leg_done("configs_all_ranks")
 
-    if world > 1 and not args.no_multi_sharded:
+    if multi and not args.no_multi_sharded:
         # N > 1: the table-sharded split north_star names (BASELINE configs[3] / [4]) on the DEFAULT line -- Model-C batch 4096, tables
         # sharded by table-ID over the N ranks, one all-gather of the looked-up slices per step (bf16 transport), FC on B / N items per rank;
         # and, when the node holds it, configs[4]: every table 5 x its rows (316 GB: past one GPU's 288 GB), fp8 FC.  Fresh contexts (the

@@ -15,25 +15,42 @@ import numpy as np
 
 
 class DistEnv:
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, force_group=False):
+        """force_group: build the process group even for ONE rank (a one-GPU rehearsal of the RCCL code path: every collective of the
+        N > 1 line really goes through torch.distributed / RCCL on device tensors, degenerate as it is)."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.backend = backend
         self.dist = None
         self.torch = None
-        if self.world > 1:
+        if self.world > 1 or (force_group and backend):
             import torch
             import torch.distributed as dist
             self.torch, self.dist = torch, dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", str(self.rank))            # (a forced one-rank group: the env:// rendezvous still wants them)
+            os.environ.setdefault("WORLD_SIZE", str(self.world))
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             self.backend = backend
             if backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
-                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+                # librccl prints a version banner ("RCCL version : ...", five lines) to STDOUT when its first communicator comes up; rank 0's
+                # stdout is the bench contract's ONE JSON line.  The communicator is brought up here, with fd 1 pointed at stderr meanwhile.
+                import sys
+                sys.stdout.flush()
+                saved = os.dup(1)
+                os.dup2(2, 1)
+                try:
+                    torch.cuda.set_device(self.local_rank)
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                finally:
+                    sys.stdout.flush()
+                    os.dup2(saved, 1)
+                    os.close(saved)
             else:
                 dist.init_process_group(backend)
 

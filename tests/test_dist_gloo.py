@@ -407,6 +407,34 @@ def test_bench_four_ranks_on_one_gpu(gpu, tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_rccl_code_path_on_one_rank(gpu, tmp_path):
+    """The one-GPU boxes cannot run two RCCL ranks (RCCL refuses two ranks on one device), so the N > 1 line's RCCL code path had never executed
+    anywhere.  `--force-process-group --backend nccl` builds a ONE-rank torch.distributed process group on RCCL and sends every collective of
+    the line through it: max / sum over ranks on device tensors, the voted per-rank legs, the sharded leg's all-gather on RCCL's stream with
+    the external-stream hand-over between the gather worker, the exchange and the FC worker.  Also guards the bench contract's stdout: librccl
+    prints a five-line version banner to STDOUT when its first communicator comes up (DistEnv points fd 1 at stderr meanwhile) -- the line
+    must be the ONLY thing on stdout."""
+    import json
+    detail = str(tmp_path / "detail.json")
+    rc, out, err = _run_bench(["--gpus", "1", "--backend", "nccl", "--force-process-group", "--legs", "none", "--quick", "--rows-cap", "200000"], timeout=900, detail=detail)
+    assert rc == 0, err[-3000:]
+    assert len(out.strip().splitlines()) == 1, out[:2000]          # no RCCL banner in front of the line
+    line = _the_line(out)
+    assert line["n_gpus"] == 1 and line["gather_per_bank_all_ranks"]["ranks_measured"] == 1 and len(line["configs_all_ranks"]) == 3
+    assert line["sharded"]["ok"] is True and line["sharded"]["dtype"] == "bf16"
+    j = json.load(open(detail))
+    assert j["sharded"]["config"]["sharded_vs_unsharded_context"]["bit_identical"] is True     # one shard = the whole record: the same kernels
+    for prec, ex in (("fp8", "alltoall"), ("bf16", "allgather")):
+        rc, out, err = _run_bench(["--gpus", "1", "--backend", "nccl", "--force-process-group", "--mode", "sharded", "--precision", prec, "--exchange", ex,
+                                   "--rows-cap", "200000", "--steps", "10", "--warmup", "3"], timeout=600)
+        assert rc == 0, err[-3000:]
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        assert len(lines) == 1 and len(out.strip().splitlines()) == 1, out[:1000]
+        c = json.loads(lines[0])["config"]
+        assert c["pipelined_equals_stepwise"] is True and c["sharded_vs_unsharded_context"]["bit_identical"] is True and c["exchange"] == ex, c
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_other_configuration(gpu):
     """`bench.py --gpus 2 --model B --batch 1024 --precision bf16`: the non-headline configurations aggregate over the ranks too (same number
     of batches on every rank, barriers on both sides, slowest rank's time)."""
