@@ -322,3 +322,40 @@ def test_server_answers_the_sender_on_the_cpu_back_end(fr):
         for r in rows:
             v = [float(x) for x in r.split()]
             assert v == ([0.0, 0.0, val, val, 0.0] if batch >= 5 else v) and all(x in (0.0, val) for x in v), (v, out)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_custom_models(fr, seed):
+    """User-defined models (the run-time counterpart of the reference's generated constants.hpp) on the CPU back-end: random tables,
+    an optional dense block, COPY pads, random FC widths; tables and weights uploaded from the host.  The record against its semantic
+    definition (concatenate the segments), bit for bit; the scores against an fp64 chain of the same weights."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_parity_helpers", os.path.join(ROOT, "tests", "test_gpu_parity.py"))
+    helpers = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(helpers)
+    rng = np.random.default_rng(1000 + seed)
+    m, segs, fcw = helpers._random_model(fr, rng, 64 if seed % 2 == 0 else 32)
+    ctx = fr.Context(m, device=CPU)
+    host = [rng.standard_normal((t.rows, t.dim)).astype(np.float32) for t in m.tables()]
+    for t, a in enumerate(host):
+        ctx.upload_table(t, a)
+        assert np.array_equal(ctx.download_table(t, 0, a.shape[0], dtype=np.float32), a)
+    ws = [(rng.uniform(-1, 1, fcw[i] * fcw[i + 1]) / np.sqrt(fcw[i])).astype(np.float32) for i in range(4)]
+    for l in range(4):
+        ctx.set_weights(l, ws[l])
+        assert np.array_equal(ctx.get_weights(l), ws[l])
+    B = int(rng.integers(1, 300))
+    idx = uniform_idx(rng, m.rows(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32) if m.dense_len else None
+    want = np.empty((B, m.record_len), np.float32)
+    for (k, src, c0, off, ln, _) in segs:
+        want[:, off:off + ln] = dense[:, c0:c0 + ln] if k == fr.SEG_DENSE else host[src][idx[:, src], c0:c0 + ln]
+    wk = fr.Worker(ctx, B)
+    assert np.array_equal(wk.gather_records(idx, dense).reshape(B, m.record_len), want.view(np.uint32))
+    x = want.astype(np.float64)
+    for l in range(4):   # column-major H x K: element (h, k) at w[h + k * H]  ->  [k][h]
+        x = (x @ ws[l].astype(np.float64).reshape(fcw[l], fcw[l + 1])).astype(np.float32).astype(np.float64)
+    got = wk.infer(idx, dense)
+    assert rel_err(got, x[:, 0].astype(np.float32)) <= 2e-6 or B < 8      # (a handful of items: max|ref| is noise)
+    wk.close()
+    ctx.close()
