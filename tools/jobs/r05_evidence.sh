@@ -12,6 +12,11 @@ st() { # name, bench args...
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$n -- python3 $R/bench.py "$@" > $O/stats_$n.log 2>&1 || echo "stats $n failed"
   f=$(ls $O/stats_$n/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/${n}_kernel_stats.csv
   t=$(ls $O/stats_$n/*/*kernel_trace.csv 2>/dev/null | head -1); [ -n "$t" ] && python3 $R/tools/trace_kernel_median.py $t $O/${n}_kernel_durations.json > $O/${n}_kernel_durations.txt 2>&1
+  [ -n "$t" ] && python3 -c "
+import csv,sys
+w=csv.writer(open(sys.argv[2],'w'))
+w.writerow(['Queue_Id','Stream_Id','Kernel_Name','Start_Timestamp','End_Timestamp'])
+for r in csv.DictReader(open(sys.argv[1])): w.writerow([r['Queue_Id'],r['Stream_Id'],r['Kernel_Name'].split('(')[0],r['Start_Timestamp'],r['End_Timestamp']])" $t $O/${n}_kernel_trace_min.csv   # kept in gpurun_out (scratch) so that the reduction can be re-run here
   rm -rf $O/stats_$n
   echo "stats $n done"
 }
