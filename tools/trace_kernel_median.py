@@ -18,9 +18,10 @@ for name, ev in by.items():
     d = sorted(e[1] - e[0] for e in ev)
     n = len(d)
     rec = {"calls": n, "avg_us": sum(d) / n / 1e3, "median_us": d[n // 2] / 1e3, "p10_us": d[n // 10] / 1e3, "p90_us": d[min(n - 1, 9 * n // 10)] / 1e3, "max_us": d[-1] / 1e3}
-    # back-to-back runs on one stream (hardware queue / stream id): consecutive launches of THIS kernel with at most a tenth of a duration
-    # (but at least min(half a duration, 15 us)) between them -- a host that cannot push fast enough leaves such gaps and HIP events see
-    # them too; a host synchronisation (>= 20 us before the next launch starts) leaves more and ends the run.  bench.py times its launches in blocks and reports the MEDIAN block: so does this -- span per launch of
+    # back-to-back runs on one stream (hardware queue / stream id): consecutive launches of THIS kernel with less than 20 us between them --
+    # queued launches follow each other within 0-1 us, a launch that waits for a small copy or for the host's pushes within ~10 us (HIP
+    # events see those gaps too), a host synchronisation leaves 30-70 us before the next launch starts and ends the run (gap listings:
+    # profiles/r05_experiments.md section 7).  bench.py times its launches in blocks and reports the MEDIAN block: so does this -- span per launch of
     # every run of >= 8 launches (first start -> last end over its launches), the median over the runs.
     runs = []
     streams = defaultdict(list)
@@ -29,7 +30,7 @@ for name, ev in by.items():
     for L in streams.values():
         run = [L[0]]
         for a, b in zip(L, L[1:]):
-            if b[0] - a[1] < max(0.1 * d[n // 2], min(0.5 * d[n // 2], 15000.0)):
+            if b[0] - a[1] < 20000.0:
                 run.append(b)
             else:
                 runs.append(run)
