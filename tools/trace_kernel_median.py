@@ -38,10 +38,16 @@ for name, ev in by.items():
         runs.append(run)
     runs = [r_ for r_ in runs if len(r_) >= 8]
     if runs:
-        spans = sorted((max(e[1] for e in r_) - r_[0][0]) / len(r_) / 1e3 for r_ in runs)
+        sw = sorted(((max(e[1] for e in r_) - r_[0][0]) / len(r_) / 1e3, len(r_)) for r_ in runs)   # (span per launch, launches) per run
+        spans = [x[0] for x in sw]
         rec["back_to_back_runs"] = len(runs)
         rec["back_to_back_launches"] = sum(len(r_) for r_ in runs)
-        rec["span_per_launch_us"] = spans[len(spans) // 2]
+        half, acc_ = rec["back_to_back_launches"] / 2.0, 0   # the median over the runs, every run weighted by its launches (a 10-launch warm-up
+        for sp_, n_ in sw:                                   # run must not outvote a 60-launch timed one)
+            acc_ += n_
+            if acc_ >= half:
+                rec["span_per_launch_us"] = sp_
+                break
         rec["span_per_launch_min_us"], rec["span_per_launch_max_us"] = spans[0], spans[-1]
         rec["avg_in_that_run_us"] = sum(e[1] - e[0] for r_ in runs for e in r_) / rec["back_to_back_launches"] / 1e3
     out[name] = rec
