@@ -794,7 +794,9 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
         per_launch = max(1, min(group, (262144 if precision == "bf16" else 16384) // B))   # bf16: the persistent kernel's launches carry as many items as the group allows
         ring = [fr.DeviceBuffer(ctx, B * 4) for _ in range(2 * per_launch)]
         push = lambda i: wk.push_device(B, d_idx[i % len(d_idx)], d_dense[i % len(d_dense)] if d_dense else None, ring[i % len(ring)])
-        ms = time_launches(wk, push, per_launch, 100, warm_launches=30, push_launch=launch_pusher(wk, B, d_idx, d_dense, ring, per_launch))
+        # (--roofline-only = a PROFILED run: 500 timed launches, so that the 30 cold ones at the head of the process are 6 % of the calls the
+        # stats file averages instead of 23 % -- its AverageNs then sits within ~1 % of the steady launch time)
+        ms = time_launches(wk, push, per_launch, 500 if min_s == 0 else 100, warm_launches=30, push_launch=launch_pusher(wk, B, d_idx, d_dense, ring, per_launch))
         flops = flops_inf * B * per_launch
         kname = wk.last_kernel()   # the kernel that carried these launches, as the library reports it (fr_worker_last_kernel)
         what = "%s: one launch = gather + 4-GEMM chain of %d queued batches of %d, back-to-back on ONE stream" % (kname, per_launch, B)
