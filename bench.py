@@ -830,13 +830,16 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
                     v.fc_layer_only(B, layer)
             for v in act:
                 v.sync()
-            for v in act:
+            # one host thread per worker (as a server has): start event, `reps` launches from ONE native call (ctypes drops the GIL: the threads
+            # really issue side by side, and no Python-level call sits between two launches -- under rocprofv3 such a call costs more than a
+            # 57 us kernel takes, and the HIP-event figure of a profiled run read 13-17 % above its own trace), stop event, wait
+            stops = [None] * len(act)
+
+            def run_one(i, v):
                 v.timer_start()
-            for _ in range(reps):
-                for v in act:
-                    v.fc_layer_only(B, layer)
-            stops = [None] * len(act)   # every stream's stop event is recorded NOW (a thread per worker: the call records, then waits)
-            th = [threading.Thread(target=lambda i=i, v=v: stops.__setitem__(i, v.timer_stop_ms())) for i, v in enumerate(act)]
+                v.fc_layer_repeat(B, layer, reps)
+                stops[i] = v.timer_stop_ms()
+            th = [threading.Thread(target=run_one, args=(i, v)) for i, v in enumerate(act)]
             for t_ in th:
                 t_.start()
             for t_ in th:
@@ -874,6 +877,14 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
         res["roofline"]["profile"] = "profiles/" + profile_csv
         # the same kernel under the row's own MULTI-stream throughput run (as the headline carries it): launches of several streams share the chip,
         # so a launch is longer but more of them are in flight -- which is why a row's end-to-end rate can exceed its one-stream kernel fraction
+        try:   # ... and the same run's launch period from its own trace (profiles/rNN_roofline_pairs.json): what the HIP-event figure above measures
+            rnd_, leg_ = profile_csv.split("_", 1)[0], profile_csv.split("_", 1)[1].replace("_kernel_stats.csv", "")
+            pe = json.load(open(os.path.join(ROOT, "profiles", rnd_ + "_roofline_pairs.json"))).get(leg_) or {}
+            if pe.get("rocprofv3_span_per_launch_us"):
+                res["roofline"]["profiled_span_per_launch_us"] = pe["rocprofv3_span_per_launch_us"]
+                res["roofline"]["profiled_median_us"] = pe.get("rocprofv3_median_us")
+        except Exception:
+            pass
         ms_csv = profile_csv.replace("_kernel_stats.csv", "_4streams_kernel_stats.csv")
         if os.path.exists(os.path.join(ROOT, "profiles", ms_csv)):
             res["roofline"]["profiled_avg_launch_us_4streams"] = profiled_avg_us(ms_csv, kname)

@@ -66,7 +66,7 @@ ABI_SYMBOLS = [
     "fr_ctx_get_weights", "fr_ctx_set_fc_precision", "fr_ctx_get_fp8_exponents", "fr_ctx_set_fp8_act_exponents",
     "fr_worker_calibrate_fp8", "fr_worker_calibrate_fp8_slices", "fr_worker_push_host", "fr_worker_stage_acquire", "fr_worker_push_staged", "fr_worker_flush", "fr_worker_host_poll", "fr_worker_host_pending", "fr_ctx_set_small_block", "fr_worker_stream", "fr_worker_gather_slices", "fr_worker_fc_from_slices_lp", "fr_worker_create", "fr_worker_destroy", "fr_worker_idx_ptr",
     "fr_worker_dense_ptr", "fr_worker_score_ptr", "fr_worker_submit", "fr_worker_submit_device", "fr_worker_push_device", "fr_worker_push_device_list", "fr_worker_sync",
-    "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
+    "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_fc_layer_repeat", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
     "fr_device_synchronize", "fr_ctx_shard_info", "fr_driver_create", "fr_driver_destroy", "fr_driver_run_resident",
     "fr_driver_worker", "fr_driver_score_ring", "fr_driver_run_host", "fr_driver_run_host_streaming", "fr_driver_host_score_ring", "fr_ctx_stream_group", "fr_ctx_set_stream_group", "fr_model_shard_plan", "fr_worker_fc_from_slices", "fr_worker_last_kernel",
@@ -110,7 +110,7 @@ def lib():
         "fr_worker_idx_ptr": (pi, [vp]), "fr_worker_dense_ptr": (pf, [vp]), "fr_worker_score_ptr": (pf, [vp]),
         "fr_worker_submit": (i32, [vp, i32]), "fr_worker_submit_device": (i32, [vp, i32, vp, vp, vp]), "fr_worker_push_device": (i32, [vp, i32, vp, vp, vp]), "fr_worker_push_device_list": (i32, [vp, i32, vp, vp, vp, vp]),
         "fr_worker_sync": (i32, [vp]), "fr_worker_gather_only": (i32, [vp, i32, vp, vp, vp]),
-        "fr_worker_fc_only": (i32, [vp, i32, vp, vp]), "fr_worker_fc_layer_only": (i32, [vp, i32, i32]), "fr_worker_records_dptr": (vp, [vp]),
+        "fr_worker_fc_only": (i32, [vp, i32, vp, vp]), "fr_worker_fc_layer_only": (i32, [vp, i32, i32]), "fr_worker_fc_layer_repeat": (i32, [vp, i32, i32, i32]), "fr_worker_records_dptr": (vp, [vp]),
         "fr_worker_features_dptr": (vp, [vp, ctypes.POINTER(ctypes.c_int)]),
         "fr_worker_timer_start": (i32, [vp]), "fr_worker_timer_stop_ms": (i32, [vp, pf]),
         "fr_device_malloc": (i32, [vp, sz, ctypes.POINTER(vp)]), "fr_device_free": (i32, [vp, vp]),
@@ -652,6 +652,10 @@ class Worker:
 
     def fc_layer_only(self, batch, layer):
         _check(lib().fr_worker_fc_layer_only(self._h, batch, layer))
+
+    def fc_layer_repeat(self, batch, layer, n):
+        """n launches of one layer back to back from one native call (fr_worker_fc_layer_repeat)."""
+        _check(lib().fr_worker_fc_layer_repeat(self._h, batch, layer, n))
 
     def last_kernel(self):
         """The kernel (instantiation included) of this worker's most recent fused / layer / gather launch (fr_worker_last_kernel)."""

@@ -1601,6 +1601,15 @@ extern "C" int fr_worker_fc_layer_only(fr_worker *w, int batch, int layer) {
     return FR_OK;
 }
 
+extern "C" int fr_worker_fc_layer_repeat(fr_worker *w, int batch, int layer, int n) {
+    if (n < 0) FR_FAIL(FR_ERR_INVALID, "n = %d", n);
+    for (int i = 0; i < n; i++) {
+        const int rc = fr_worker_fc_layer_only(w, batch, layer);
+        if (rc) return rc;
+    }
+    return FR_OK;
+}
+
 // Streaming form of the hot loop body: enqueue batch after batch without synchronising (cuda_server.c:406-497 does
 // exactly that).  Each call issues ONE launch in which this batch is gathered while the previous four batches of
 // this worker advance through FC1, FC2, FC3 and the output layer.  d_scores of a pushed batch are complete after

@@ -26,6 +26,9 @@ const char *fr_worker_last_kernel(const fr_worker *w);
 /* Roofline hook: launch ONE layer of the FC chain (0..2 = FC1..FC3, 3 = output layer) on the worker's resident
  * activations, exactly as submit() launches it. */
 int fr_worker_fc_layer_only(fr_worker *w, int batch, int layer);
+/* The same launch n times back to back from ONE native call: a roofline leg that prices a 57 us kernel on two streams side by side must not
+ * be paced by its host loop (under rocprofv3 a Python-issued launch costs more than that kernel takes). */
+int fr_worker_fc_layer_repeat(fr_worker *w, int batch, int layer, int n);
 /* Which kernel serves the record-producing gather (fr_worker_gather_only; fp32 records, SEMANTIC layout or a shard slice) -- a tuning
  * knob with no counterpart in the reference (its gather is 28-47 independent HLS pipelines, embedding_47_krnl.cpp:645-740).
  *  WORD_MAJOR (default): one thread per 16-byte record word, lanes along the record (gather_pack_kernel): a wave never holds two
