@@ -55,13 +55,16 @@ class Pool {
             job_ = &fn;
             units_ = units;
             next_.store(0, std::memory_order_relaxed);
-            pending_ = (int)helpers_.size();
-            generation_++;
+            pending_.store((int)helpers_.size(), std::memory_order_relaxed);
+            generation_.fetch_add(1, std::memory_order_release);
         }
         cv_work_.notify_all();
         work();
-        std::unique_lock<std::mutex> lk(m_);
-        cv_done_.wait(lk, [&] { return pending_ == 0; });
+        for (int spin = 0; spin < kSpin && pending_.load(std::memory_order_acquire) != 0; spin++) cpu_relax();
+        if (pending_.load(std::memory_order_acquire) != 0) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_done_.wait(lk, [&] { return pending_.load(std::memory_order_acquire) == 0; });
+        }
         job_ = nullptr;
     }
 
@@ -84,27 +87,32 @@ class Pool {
         }
     }
     void start_helpers() {
-        stop_ = false;
+        stop_.store(false, std::memory_order_relaxed);
         for (int i = 1; i < n_; i++)
             helpers_.emplace_back([this] {
                 uint64_t seen = 0;
                 for (;;) {
-                    {
+                    // a request is several parallel regions a few hundred microseconds apart (gather, four layers): a helper that went to sleep
+                    // between them costs a futex wake-up per region (measured here: 11 ms instead of 2.4 ms for a batch of 256) -- spin briefly first
+                    for (int spin = 0; spin < kSpin && generation_.load(std::memory_order_acquire) == seen && !stop_.load(std::memory_order_relaxed); spin++) cpu_relax();
+                    if (generation_.load(std::memory_order_acquire) == seen) {
                         std::unique_lock<std::mutex> lk(m_);
-                        cv_work_.wait(lk, [&] { return stop_ || generation_ != seen; });
-                        if (stop_) return;
-                        seen = generation_;
+                        cv_work_.wait(lk, [&] { return stop_.load(std::memory_order_relaxed) || generation_.load(std::memory_order_acquire) != seen; });
                     }
+                    if (stop_.load(std::memory_order_relaxed)) return;
+                    seen = generation_.load(std::memory_order_acquire);
                     work();
-                    std::lock_guard<std::mutex> lk(m_);
-                    if (--pending_ == 0) cv_done_.notify_one();
+                    if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                        std::lock_guard<std::mutex> lk(m_);
+                        cv_done_.notify_one();
+                    }
                 }
             });
     }
     void stop_helpers() {
         {
             std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
+            stop_.store(true, std::memory_order_relaxed);
         }
         cv_work_.notify_all();
         for (auto &t : helpers_) t.join();
@@ -114,10 +122,12 @@ class Pool {
     std::condition_variable cv_work_, cv_done_;
     std::vector<std::thread> helpers_;
     const std::function<void(int)> *job_ = nullptr;
-    std::atomic<int> next_{0};
-    int units_ = 0, pending_ = 0, n_ = 1;
-    uint64_t generation_ = 0;
-    bool stop_ = false;
+    static constexpr int kSpin = 40000;   // ~100-200 us of pause instructions before a thread blocks
+    static void cpu_relax() { __builtin_ia32_pause(); }
+    std::atomic<int> next_{0}, pending_{0};
+    int units_ = 0, n_ = 1;
+    std::atomic<uint64_t> generation_{0};
+    std::atomic<bool> stop_{false};
 };
 }  // namespace
 
@@ -281,12 +291,18 @@ void fc_layer(const float *W, int H, int K, const float *X, int ldx, float *Y, i
         return;
     }
     const int nb = (batch + FC_MB - 1) / FC_MB, nh = H / FC_HT;
-    auto body = [&](int u) { unit(W, H, K, X, ldx, Y, ldy, batch, (u / nh) * FC_MB, (u % nh) * FC_HT); };
     if ((double)batch * H * K < 4e6) {   // a request of a few items: a parallel region's hand-over would cost more than the work
-        for (int u = 0; u < nb * nh; u++) body(u);
+        for (int u = 0; u < nb * nh; u++) unit(W, H, K, X, ldx, Y, ldy, batch, (u / nh) * FC_MB, (u % nh) * FC_HT);
         return;
     }
-    Pool::get().run(nb * nh, body);
+    // a work unit = ONE 32-output slice of W (K x 128 bytes: it stays in the core's L1 / L2) against a run of FC_IB item blocks: the weights are
+    // streamed once per run instead of once per item block (batch 16384, Model-A FC1: 0.7 GB of X re-reads instead of 5.9 GB of W re-reads)
+    constexpr int FC_IB = 16;
+    const int nr = (nb + FC_IB - 1) / FC_IB;
+    Pool::get().run(nr * nh, [&](int u) {
+        const int h0 = (u % nh) * FC_HT, ib0 = (u / nh) * FC_IB, ib1 = ib0 + FC_IB < nb ? ib0 + FC_IB : nb;
+        for (int ib = ib0; ib < ib1; ib++) unit(W, H, K, X, ldx, Y, ldy, batch, ib * FC_MB, h0);
+    });
 }
 }  // namespace
 
