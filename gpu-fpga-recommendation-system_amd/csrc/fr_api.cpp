@@ -1756,7 +1756,16 @@ static int host_ring_init(fr_worker *w) {
     FR_HIP(hipHostMalloc((void **)&r.h_sc, slots * r.score_slot * sizeof(float), hipHostMallocDefault));
     FR_HIP(hipMalloc((void **)&r.d_sc, slots * r.score_slot * sizeof(float)));
     for (int b = 0; b < FR_HOST_BLOCKS; b++) FR_HIP(hipEventCreateWithFlags(&r.ev[b], hipEventDisableTiming));
-    FR_HIP(hipStreamCreateWithFlags(&r.copy, hipStreamNonBlocking));
+    {   // The copy stream lives in the LOWEST stream priority's pool of hardware queues: the HIP runtime pools queues per priority, and in the
+        // default pool the marker packet behind a block's copy (its event) would sit in a hardware queue that some worker's launches share --
+        // that worker's next launch then waits out another worker's 65 us copy (seen as a bimodal 97 % / 99 % of the HBM-resident rate,
+        // by which queue the runtime happened to hand out: profiles/r05_experiments.md section 1).  Fused-kernel models keep their worker
+        // streams on the default priority, so the low pool is the copy streams' alone.
+        int lo = 0, hi = 0;
+        FR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        if (lo > hi) FR_HIP(hipStreamCreateWithPriority(&r.copy, hipStreamNonBlocking, lo));
+        else FR_HIP(hipStreamCreateWithFlags(&r.copy, hipStreamNonBlocking));
+    }
     for (int b = 0; b < FR_HOST_BLOCKS; b++) FR_HIP(hipEventCreateWithFlags(&r.ev_in[b], hipEventDisableTiming));
     r.g = g;
     return FR_OK;
