@@ -1536,6 +1536,40 @@ def test_submit_sharded_through_rccl_one_rank(fr, O, gpu, prec):
     ctx.close()
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp8"])
+def test_submit_sharded_through_rccl_full_size_batch_4096(fr, O, ctxs, prec):
+    """The RCCL hot-loop body (fr_worker_submit_sharded: H2D -> slice gather in the chain's operand type -> ncclAllGather -> FC chain ->
+    ncclAllGather of the scores and status words -> D2H) at the configuration's own size: FULL-size Model-C (63.2 GB), batch 4096 -- on the
+    one-rank communicator a one-GPU box allows (VERDICT r04 missing 1: it had only run on row-capped tables at batch 300).  One shard = the
+    whole record, so the scores must equal the unsharded submit of the same context bit for bit; 1024 of them against the oracle."""
+    m, ctx = ctxs(2)
+    om = O.OracleModel("C")
+    P = {"bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[prec]
+    B = 4096
+    rng = np.random.default_rng(409 + P)
+    idx = uniform_idx(rng, m.rows(), B)
+    idx[0], idx[1] = 0, m.rows() - 1
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+    ctx.set_fc_precision(P)
+    try:
+        comm = fr.Comm.init_rank(ctx, fr.Comm.unique_id())
+        wk = fr.Worker(ctx, B)
+        if prec == "fp8":
+            wk.calibrate_fp8_sharded(comm, idx, dense)
+        got = wk.infer_sharded(comm, idx, dense)
+        assert np.array_equal(got, wk.infer(idx, dense))
+        assert np.array_equal(wk.infer_sharded(comm, idx, dense), got)         # the step is repeatable on the same communicator
+        sub = slice(1024, 2048)
+        rec = om.gather(idx[sub], dense=dense[sub], content_mode=O.FILL_HASH, seed=SEED_TABLES).view(np.float32)
+        ref = om.fc_chain(rec, [ctx.get_weights(l) for l in range(4)], acc64=True)
+        assert np.abs(got[sub] - ref).max() <= {"bf16": 3e-2, "fp8": 0.15}[prec] * np.abs(ref).max()
+        wk.close()
+        comm.close()
+    finally:
+        ctx.set_chain_width(0)
+        ctx.set_fc_precision(fr.FC_FP32)
+
+
 def test_sharded_fc_failure_reaches_every_rank_through_the_status_word(fr, gpu):
     """a rank whose FC chain fails inside fr_worker_submit_sharded used to return its error locally while the peers completed
     the score all-gather with FR_OK and copied that rank's stale chunk.  Now the chunk travels as NaN and the rank's status word (one
