@@ -28,10 +28,14 @@ extern "C" {
 int fr_worker_push_device_list(fr_worker *w, int n, const int *batch, const int32_t *const *d_idx, const float *const *d_dense,
                                float *const *d_scores);
 /* Host-fed streaming: like fr_worker_push_device for a batch that sits in (any) host memory.  The rows are copied into the worker's
- * pinned staging before the call returns (h_idx / h_dense may be reused at once); batches travel in groups as one H2D copy + one
- * launch + one D2H copy; h_scores[0..batch) is valid after fr_worker_sync (earlier deliveries happen -- a block's scores are copied out
- * before its staging is reused, i.e. at the latest 4 blocks later -- but fr_worker_sync is the only completion point the API defines).
- * The streaming counterpart of the per-batch recv -> H2D -> GEMMs -> D2H sequence of cuda_server.c:425-495. */
+ * pinned staging before the call returns (h_idx / h_dense may be reused at once); batches travel in blocks: ONE H2D copy on the worker's
+ * copy stream (issued when the block is full, while the previous block's kernel still runs) + ONE launch whose output layer writes the
+ * scores straight into pinned memory -- the worker's own stream carries nothing but kernels (round 5; rounds 2-4 issued H2D, launch and
+ * D2H as three commands of that stream and lost 5 % to it: profiles/r05_host_fed_timeline.txt).  h_scores[0..batch) is valid after
+ * fr_worker_sync (earlier deliveries happen -- a block's scores are copied out before its staging is reused, i.e. at the latest 4 blocks
+ * later -- but fr_worker_sync is the only completion point the API defines).  Feed it from at most four streaming workers per context
+ * (one worker stream per hardware queue).  The streaming counterpart of the per-batch recv -> H2D -> GEMMs -> D2H sequence of
+ * cuda_server.c:425-495. */
 int fr_worker_push_host(fr_worker *w, int batch, const int32_t *h_idx, const float *h_dense, float *h_scores);
 /* The same without the copy into staging -- the reference's read() lands in pinned memory (cuda_server.c:136-160,437):
  * fr_worker_stage_acquire hands out where the NEXT pushed batch of this worker has to be written (*h_idx: batch x index_cols int32,
@@ -60,7 +64,7 @@ int fr_worker_host_poll(fr_worker *w, long long *delivered);
  * still in flight; while more are running, let the next block fill (any output pointer may be NULL). */
 int fr_worker_host_pending(const fr_worker *w, int *queued, int *in_flight, int *blocks_in_flight);
 /* Host-buffer STREAMING form: the same host-resident request stream handed to fr_worker_push_host (pinned staging blocks, one
- * H2D + one fused launch + one D2H per block, no per-batch synchronisation).  Only for models that stream through the fused
+ * H2D + one fused launch per block, scores written to pinned memory by the kernel, no per-batch synchronisation).  Only for models that stream through the fused
  * item-tile kernel.  Scores land in per-worker host rings (fr_driver_host_score_ring, same indexing as fr_driver_score_ring). */
 int fr_driver_run_host_streaming(fr_driver *d, int batch, int64_t total_batches, const int32_t *const *h_idx_pool,
                                  const float *const *h_dense_pool, int n_pool, double *elapsed_s);
