@@ -1531,8 +1531,15 @@ def test_submit_sharded_through_rccl_one_rank(fr, O, gpu, prec):
         w2.infer_sharded(comm, idx[:8], dense[:8])
     w2.close()
     other.close()
-    wk.close()
+    # fr_comm_destroy between a submit and its sync used to leave the worker with a dangling communicator; now the step in flight
+    # keeps it alive and the sync completes normally
+    wk.idx[:B] = idx
+    wk.dense[:B] = dense
+    fr._check(fr.lib().fr_worker_submit_sharded(wk._h, comm._h, B))
     comm.close()
+    wk.sync()
+    assert np.array_equal(wk.score[:B], got)
+    wk.close()
     ctx.close()
 
 
