@@ -2279,8 +2279,8 @@ def test_chain_workers_run_their_layers_side_by_side(fr, ctxs):
     workers alternate between the highest and the lowest priority (fr_worker_create), and the command processor serves queue q on compute
     pipe q mod 4.  A ROCm update that re-pools the queues must turn this suite red, not the throughput grey: Model-C batch 4096 bf16,
     chain width 4, 2 x 2 workers; FC1 (128 workgroups of 256 x 256 per launch: two launches fit on the chip) is launched back to back on
-    two workers' streams at once and the streams' busy times must overlap -- launches in flight on average >= 1.8 (the figure bench.py's
-    stage-pipeline rows report as `layer_concurrency`; measured 1.97-2.00).  If this fails: fr_ctx_set_chain_width(ctx, 1) is the fallback
+    two workers' streams at once and must take about as long per launch as one worker's alone (measured ratio 1.15-1.19: 87 us alone, 102-105 us
+    beside a neighbour; taking turns on a shared queue: 2.0; asserted <= 1.4; tools/experiments/chain_concurrency_margin.py prints both figures).  If this fails: fr_ctx_set_chain_width(ctx, 1) is the fallback
     (full-chip tiles, which do not need the overlap) until the queue assignment is repaired."""
     m, ctx = ctxs(2)
     B = 4096
@@ -2296,40 +2296,49 @@ def test_chain_workers_run_their_layers_side_by_side(fr, ctxs):
         wks[0].fc_layer_only(B, 0)
         assert wks[0].last_kernel().startswith("fc_lp_gemm_kernel<1, 2, 256,"), wks[0].last_kernel()
         wks[0].sync()
-        act, reps = wks[:2], 60
-        best = 0.0
-        for attempt in range(3):                         # the best of three: another tenant's burst must not fail the suite
-            for _ in range(10):
-                for w in act:
-                    w.fc_layer_only(B, 0)
+        reps = 60
+
+        def per_launch_ms(act):
+            """`reps` FC1 launches per worker of `act`, issued natively and side by side (a host thread per worker) -> mean stream time per launch."""
+            for w in act:
+                w.fc_layer_repeat(B, 0, 10)
             for w in act:
                 w.sync()
-            for w in act:
-                w.timer_start()
-            for _ in range(reps):
-                for w in act:
-                    w.fc_layer_only(B, 0)
             stops = [None] * len(act)
-            th = [threading.Thread(target=lambda i=i, w=w: stops.__setitem__(i, w.timer_stop_ms())) for i, w in enumerate(act)]
+
+            def run_one(i, w):
+                w.timer_start()
+                w.fc_layer_repeat(B, 0, reps)
+                stops[i] = w.timer_stop_ms()
+            th = [threading.Thread(target=run_one, args=(i, w)) for i, w in enumerate(act)]
             [t.start() for t in th]
             [t.join() for t in th]
-            best = max(best, float(np.sum(stops) / np.max(stops)))
-        assert best >= 1.8, "FC1 launches of two workers did not overlap (launches in flight %.2f): the workers no longer have hardware queues of their own" % best
-        # ... and all four workers' chains together: the busy times of the four streams overlap as well (>= 3 chains in flight on average)
+            return float(np.mean(stops)) / reps
+        # side by side = a launch takes about as long with a neighbour's launch on the other half of the chip as alone (105-110 us either way);
+        # two launches taking turns on one hardware queue would take TWICE as long per stream.  (Streams that merely finish together say
+        # nothing: interleaved launches do that too.)  Best of three: another tenant's burst must not fail the suite.
+        ratio = min(per_launch_ms(wks[:2]) / per_launch_ms(wks[:1]) for _ in range(3))
+        assert ratio <= 1.4, "an FC1 launch takes %.2f x as long beside a second worker's as alone: the workers no longer run side by side (hardware queues shared?)" % ratio
+        # ... and the whole chains: four workers streaming side by side finish their batches at >= 1.2 x the rate of one worker alone on the same
+        # part-chip tiles (measured 1.64-1.78 x: 41-44 M against 25 M inf/s); chains taking turns would gain nothing
+        import time
         d_i, d_d = fr.DeviceBuffer.from_numpy(ctx, idx), fr.DeviceBuffer.from_numpy(ctx, dense)
         d_s = [fr.DeviceBuffer(ctx, B * 4) for _ in wks]
-        for w in wks:
-            w.timer_start()
-        for _ in range(24):
-            for w, sc in zip(wks, d_s):
-                w.push_device(B, d_i, d_d, sc)
-        stops = [None] * len(wks)
-        th = [threading.Thread(target=lambda i=i, w=w: stops.__setitem__(i, w.timer_stop_ms())) for i, w in enumerate(wks)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        for w in wks:
-            w.sync()
-        assert float(np.sum(stops) / np.max(stops)) >= 3.0, stops
+
+        def rate(act, n=24):
+            for w in act:
+                w.sync()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                for w, sc in zip(act, d_s):
+                    w.push_device(B, d_i, d_d, sc)
+            for w in act:
+                w.sync()
+            return len(act) * n * B / (time.perf_counter() - t0)
+        rate(wks)
+        gain = max(rate(wks) / rate(wks[:1]) for _ in range(3))
+        assert gain >= 1.2, "four chains side by side run at %.2f x the rate of one alone" % gain
         for w in wks:
             w.close()
     finally:
