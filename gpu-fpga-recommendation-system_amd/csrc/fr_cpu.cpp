@@ -5,9 +5,12 @@
 // (CUBLAS_COMPUTE_32F, cuda_server.c:211) over the fp32 master weights in the reference's column-major H x K layout (cuda_server.c:215).
 // Scope (fleetrec.h): context set-up, fr_worker_submit / submit_device / push_device / sync, gather_only, fc_only, the fp32 forms of the
 // table-sharded entry points, the request-driver core.  fp32 only; everything else returns FR_ERR_STATE on a CPU context.
+#include <pthread.h>
 #include <sys/mman.h>
 #include <sched.h>
 #include <unistd.h>
+
+#include <cstdio>
 
 #include <atomic>
 #include <condition_variable>
@@ -25,7 +28,15 @@ namespace {
 class Pool {
   public:
     static Pool &get() {
-        static Pool *p = new Pool();  // never destroyed: helper threads may outlive static destructors
+        // Never destroyed: helper threads may outlive static destructors.  A fork()ed child (Python's multiprocessing) inherits the object but
+        // none of its threads -- and possibly its mutexes in a locked state: the child's atfork handler drops the pointer, the child's first
+        // call builds a pool of its own (the parent's object is leaked there).
+        Pool *p = inst_.load(std::memory_order_acquire);
+        if (p) return *p;
+        Pool *n = new Pool();
+        if (inst_.compare_exchange_strong(p, n, std::memory_order_acq_rel)) return *n;
+        n->stop_helpers();   // another thread was first
+        delete n;
         return *p;
     }
     int size() {
@@ -69,7 +80,12 @@ class Pool {
     }
 
   private:
-    Pool() : n_(usable_cpus()) { start_helpers(); }
+    Pool() : n_(usable_cpus()) {
+        static const int once = pthread_atfork(nullptr, nullptr, [] { inst_.store(nullptr, std::memory_order_release); });
+        (void)once;
+        start_helpers();
+    }
+    static std::atomic<Pool *> inst_;
     static int usable_cpus() {
         int n = (int)std::thread::hardware_concurrency();
         cpu_set_t set;
@@ -129,6 +145,7 @@ class Pool {
     std::atomic<uint64_t> generation_{0};
     std::atomic<bool> stop_{false};
 };
+std::atomic<Pool *> Pool::inst_{nullptr};
 }  // namespace
 
 int frc_set_threads(int n) { return Pool::get().resize(n); }
@@ -140,8 +157,16 @@ int frc_threads() { return Pool::get().size(); }
 void *frc_arena_alloc(size_t bytes) {
     if (bytes == 0) bytes = 4096;
     const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
-    if (pages > 0 && psz > 0 && (double)bytes > 0.85 * (double)pages * (double)psz) {
-        fr_set_error("CPU back-end: %.1f GB of tables do not fit this host's %.1f GB of memory", bytes / 1e9, (double)pages * psz / 1e9);
+    double limit = pages > 0 && psz > 0 ? (double)pages * (double)psz : 0.0;
+    for (const char *path : {"/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"}) {   // a container's own limit, where one is set
+        if (FILE *f = fopen(path, "r")) {
+            double v = 0.0;
+            if (fscanf(f, "%lf", &v) == 1 && v > 0.0 && (limit == 0.0 || v < limit)) limit = v;
+            fclose(f);
+        }
+    }
+    if (limit > 0.0 && (double)bytes > 0.85 * limit) {
+        fr_set_error("CPU back-end: %.1f GB of tables do not fit this host's %.1f GB of memory", bytes / 1e9, limit / 1e9);
         return nullptr;
     }
     void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);

@@ -359,3 +359,38 @@ def test_random_custom_models(fr, seed):
     assert rel_err(got, x[:, 0].astype(np.float32)) <= 2e-6 or B < 8      # (a handful of items: max|ref| is noise)
     wk.close()
     ctx.close()
+
+
+def test_a_forked_child_gets_a_thread_pool_of_its_own(fr):
+    """fork() (Python's multiprocessing) copies the CPU back-end's pool object but none of its helper threads: a parallel region in the child would
+    wait for helpers that do not exist.  The child's atfork handler drops the inherited pool; its first call builds its own."""
+    m = fr.Model.builtin(fr.MODEL_A).clone(max_rows=5000)
+    ctx = fr.Context(m, device=CPU)
+    ctx.fill_tables(fr.FILL_HASH, 1)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, 2)
+    wk = fr.Worker(ctx, 512)
+    idx = uniform_idx(np.random.default_rng(0), m.rows(), 512)
+    fr.cpu_set_threads(4)
+    ref = wk.infer(idx)                       # the parent's pool is up and has run
+    pid = os.fork()
+    if pid == 0:
+        try:
+            ok = np.array_equal(wk.infer(idx), ref)
+        except BaseException:                  # noqa: BLE001
+            ok = False
+        os._exit(0 if ok else 3)
+    deadline = time.time() + 60
+    while time.time() < deadline:
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done:
+            break
+        time.sleep(0.05)
+    else:
+        os.kill(pid, 9)
+        os.waitpid(pid, 0)
+        pytest.fail("the forked child hung in a parallel region")
+    assert os.WEXITSTATUS(status) == 0
+    assert np.array_equal(wk.infer(idx), ref)
+    fr.cpu_set_threads(0)
+    wk.close()
+    ctx.close()
