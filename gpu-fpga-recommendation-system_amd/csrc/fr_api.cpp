@@ -1279,7 +1279,7 @@ extern "C" int fr_ctx_set_small_block(fr_ctx *ctx, int max_batches) {
     return FR_OK;
 }
 
-extern "C" int fr_ctx_stream_group(const fr_ctx *ctx) { return (ctx && fused_eligible(ctx)) ? fused_group(ctx) : 1; }
+extern "C" int fr_ctx_stream_group(const fr_ctx *ctx) { return (ctx && !ctx->cpu && fused_eligible(ctx)) ? fused_group(ctx) : 1; }   // (a CPU context computes every push at once)
 
 // One launch of the kernarg-fed fused kernels: batches [first, first + n) of the worker's queue (n <= FR_FUSED_MAX_BATCHES).
 static int fused_launch_slice(fr_worker *w, FrFusedArgs &a, int first, int n) {
