@@ -295,7 +295,8 @@ def test_bench_eight_ranks_rehearsal_on_the_cpu_back_end(tmp_path):
         assert j["leg_seconds"][k] > 0, j["leg_seconds"]
     assert abs(sum(j["leg_seconds"].values()) - j["leg_seconds_total"]) < 0.2 and j["leg_seconds_total"] <= wall
     m_ = re.search(r"bench.py: wall time per leg \(s\): .*; total ([0-9.]+) s", err)
-    assert m_ and float(m_.group(1)) < 300.0, err[-1500:]
+    slow_build = "san.so" in os.path.basename(os.environ.get("FR_LIB", ""))   # tools/run_sanitizers.sh: instrumented host code, no time bound
+    assert m_ and (float(m_.group(1)) < 300.0 or slow_build), err[-1500:]
     c3, c4 = j["sharded"]["config"], j["sharded_inflated_fp8"]["config"]
     assert c3["slice_lens"] == [496, 496, 504, 488, 496, 496, 496, 496] and sum(c3["slice_lens"]) == 3968 and c3["items_this_rank"] == [0, 512]
     assert c3["exchange_bytes_in_per_rank_per_step"] == 8 * 4096 * 504 * 4 and c3["sharded_vs_unsharded_context"]["bit_identical"] is True
