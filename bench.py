@@ -741,13 +741,15 @@ def leg_group_table(fr, ctx, model, B, d_idx, threads, depth):
 
 def gemm_workgroups(kname, N, ldm):
     """Workgroups of one launch of a GEMM-layer kernel, from the name the library reports (fr_worker_last_kernel): fc_lp_gemm_kernel<P, MU, GN, ...>
-    has GN (n) x 128 MU (m) tiles, fc_gemm_pipe_kernel 128 x 256; None for any other kernel (stage bodies: one launch fills the chip)."""
+    has GN (n) x 128 MU (m) tiles, fc_gemm_pipe_kernel 128 x 256, fc_pp_gemm_kernel 256 x 256; None for any other kernel (stage bodies: one launch fills the chip)."""
     m_ = re.match(r"fc_lp_gemm_kernel<\d+, (\d+), (\d+)", kname or "")
     if m_:
         mu, gn = int(m_.group(1)), int(m_.group(2))
         return max(1, (N // gn) * (ldm // (128 * mu)))
     if (kname or "").startswith("fc_gemm_pipe_kernel"):
         return max(1, (N // 128) * (ldm // 256))
+    if (kname or "").startswith("fc_pp_gemm_kernel"):      # 256 x 256 tiles
+        return max(1, (N // 256) * (ldm // 256))
     return None
 
 

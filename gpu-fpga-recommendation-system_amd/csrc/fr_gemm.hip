@@ -331,6 +331,207 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_out_kernel(const uint4 *__rest
 }
 
 // ===================================================================================================
+// fc_pp_gemm_kernel<PREC, D>: the 256 (n) x 256 (m) tile of the bf16 / fp8 GEMM layers with the two waves of every SIMD in OPPOSITE phases.
+// Same operand images, same 2 x 4 wave grid with 128 x 64 wave tiles, same MFMA instructions on the same k groups in the same order as
+// fc_lp_gemm_kernel<PREC, 2, 256, ...> (scores are bit-identical), but where that kernel's eight waves all issue their DMAs, all read
+// their fragments and only then all want the matrix pipe, here a K sub-step of 4 element rows (32 k in bf16, 64 k in fp8: 512 MFMA
+// cycles per wave) is split into a MEMORY phase (the wave reads the sub-step's 12 fragments into registers and issues its 4 DMAs of
+// sub-step s + D) and a MATRIX phase (its 32 / 8 MFMAs, from registers, at raised priority), the phases are fenced by s_barrier, and waves
+// 4-7 run one phase behind waves 0-3: at any moment one wave of each SIMD multiplies while the other one fetches.  D + 1 sub-steps in
+// LDS (D = 3: 128 KiB).  Hazards, with M(s) / C(s) the phases of sub-step s: group 0 runs M(s) in global phase 2 s, group 1 in 2 s + 1;
+//   * landed before read: a wave waits (counted vmcnt: the D - 1 younger sub-steps stay in flight) for its own DMAs of sub-step s + 1 at
+//     the end of M(s), i.e. before the barrier that ends phase 2 s + 1 at the latest; the first read of sub-step s + 1 is in phase 2 s + 2;
+//   * read before overwritten: the DMAs of sub-step s + D, issued in M(s) (phase 2 s or later), overwrite the stage of sub-step s - 1,
+//     whose last reads (group 1's M(s - 1), phase 2 s - 1) were retired by lgkmcnt(0) before that phase's closing barrier.
+// ===================================================================================================
+template <int PREC, int D>
+__global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
+                                                         int N, int ldm, int sc_a, int sc_b, float oscale, int ablate) {
+    static_assert(PREC == 1 || PREC == 2, "bf16 / fp8");
+#ifndef FR_EXPERIMENTS
+    ablate = 0;   // timing ablations (wrong results: 1 = no DMA inside the loop, 2 = no fragment reads, 4 = no MFMAs) exist in the experiments build only
+#endif
+    extern __shared__ uint4 glds[];
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    constexpr int GN = 256, GM = 256, ROW = GN + GM, PR = 4, S = D + 1, STAGE = PR * ROW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1, grp = wave >> 2;
+    const int tn = N / GN, tm = ldm / GM;
+    int n_tile, m_tile;  // XCD-aware 2 (n) x 4 (m) tile map, as in fc_lp_gemm_kernel
+    if (tn % 2 == 0 && tm % 4 == 0) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int tnx = tn / 2;
+        n_tile = (x & 1) * tnx + j % tnx;
+        m_tile = (x >> 1) * (tm / 4) + j / tnx;
+    } else {
+        n_tile = blockIdx.x % tn;
+        m_tile = blockIdx.x / tn;
+    }
+    const int n0 = n_tile * GN, m0 = m_tile * GM;
+    auto make_rs = [](const void *p, unsigned bytes) {
+        const unsigned long long a = (unsigned long long)p;
+        i32x4_t rs;
+        rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        rs[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+        rs[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+        rs[3] = 0x00020000;
+        return rs;
+    };
+    // a sub-step is 4 rows x (256 + 256) elements = 32 wave-instructions of 64 elements, 4 per wave: waves 0-3 stage W's row w, waves 4-7
+    // X's row w - 4, the four quarters of the row each.  (M0 without a clobber: see fc_lp_gemm_kernel.)
+    const int drow = wave & 3;
+    const i32x4_t rs = grp == 0 ? make_rs(W, (unsigned)KE * (unsigned)N * 16u) : make_rs(X, (unsigned)KE * (unsigned)ldm * 16u);
+    const unsigned voff = (unsigned)((grp == 0 ? n0 : m0) + lane) * 16u;
+    const unsigned row_bytes = __builtin_amdgcn_readfirstlane((unsigned)(grp == 0 ? N : ldm) * 16u);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_ptr)glds);
+    unsigned iss_lds = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(drow * ROW + (grp == 0 ? 0 : GN)) * 16u);
+    unsigned iss_src = __builtin_amdgcn_readfirstlane((unsigned)drow * row_bytes);
+    int iss_stage = 0;
+    auto issue_next = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned la = iss_lds + 1024u * q, so = iss_src + 1024u * q;
+            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(la), "v"(voff), "s"(rs), "s"(so) : "memory");
+        }
+        iss_src += PR * row_bytes;
+        iss_stage++;
+        iss_lds += (unsigned)STAGE * 16u;
+        if (iss_stage == S) {
+            iss_stage = 0;
+            iss_lds -= (unsigned)(S * STAGE) * 16u;
+        }
+    };
+    constexpr int NA = PREC == 1 ? 8 : 8, NB = 4;   // fragment registers (uint4): bf16 8 n tiles + 4 m tiles of 16; fp8 4 n tiles + 2 m tiles of 32, two elements each
+    f32x4_t acc16[PREC == 1 ? 32 : 1];
+    f32x16 acc32[PREC == 1 ? 1 : 8];
+    if constexpr (PREC == 1) {
+#pragma unroll
+        for (int i = 0; i < 32; i++) acc16[i] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc32[i][e] = 0.0f;
+    }
+    uint4 fa[NA], fb[NB];
+    const uint4 *rd_ptr = glds;
+    int rd_stage = 0;
+    auto read_frags = [&]() {
+        if constexpr (PREC == 1) {   // lane (g, j): k group g = lane / 16 of the sub-step's four rows, row j = lane % 16 of its tile
+            const uint4 *p = rd_ptr + (size_t)(lane >> 4) * ROW + (lane & 15);
+#pragma unroll
+            for (int t = 0; t < 8; t++) fa[t] = p[wn * 128 + 16 * t];
+#pragma unroll
+            for (int u = 0; u < 4; u++) fb[u] = p[GN + wm * 64 + 16 * u];
+        } else {                     // k = 32 h + j: element rows 2 h, 2 h + 1
+            const uint4 *p = rd_ptr + (size_t)(2 * (lane >> 5)) * ROW + (lane & 31);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                fa[2 * t] = p[wn * 128 + 32 * t];
+                fa[2 * t + 1] = p[ROW + wn * 128 + 32 * t];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                fb[2 * u] = p[GN + wm * 64 + 32 * u];
+                fb[2 * u + 1] = p[ROW + GN + wm * 64 + 32 * u];
+            }
+        }
+        rd_stage++;
+        rd_ptr += STAGE;
+        if (rd_stage == S) {
+            rd_stage = 0;
+            rd_ptr = glds;
+        }
+    };
+    auto mfmas = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (PREC == 1) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                    acc16[4 * t + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[t]), __builtin_bit_cast(bf16x8, fb[u]), acc16[4 * t + u], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint4 &a0 = fa[2 * t], &a1 = fa[2 * t + 1], &b0 = fb[2 * u], &b1 = fb[2 * u + 1];
+                    i32x8 av, bv;
+                    av[0] = (int)a0.x; av[1] = (int)a0.y; av[2] = (int)a0.z; av[3] = (int)a0.w;
+                    av[4] = (int)a1.x; av[5] = (int)a1.y; av[6] = (int)a1.z; av[7] = (int)a1.w;
+                    bv[0] = (int)b0.x; bv[1] = (int)b0.y; bv[2] = (int)b0.z; bv[3] = (int)b0.w;
+                    bv[4] = (int)b1.x; bv[5] = (int)b1.y; bv[6] = (int)b1.z; bv[7] = (int)b1.w;
+                    acc32[2 * t + u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc32[2 * t + u], 0, 0, 0, sc_a, 0, sc_b);
+                }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto fence_barrier = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    const int nsub = KE / PR;   // >= D + 1 (checked by the launcher)
+    constexpr unsigned INFL = 4u * (D - 1);   // DMAs of the D - 1 younger sub-steps may stay in flight
+    constexpr int IMM_STEADY = (int)((INFL & 0xF) | ((INFL >> 4) << 14) | 0x0070u);   // ... and lgkmcnt(0): the fragment reads are done
+    constexpr int IMM_FIRST = (int)((INFL & 0xF) | ((INFL >> 4) << 14) | 0x0F70u);
+#pragma unroll
+    for (int i = 0; i < D; i++) issue_next();
+    __builtin_amdgcn_s_waitcnt(IMM_FIRST);   // sub-step 0 has landed
+    fence_barrier();
+    const int main_end = nsub - D;           // s < main_end: M(s) issues sub-step s + D
+    auto memory_phase = [&](int s) {
+        if (!(ablate & 2) || s == 0) read_frags();
+        if (s < main_end) {
+            if (!(ablate & 1)) issue_next();
+            __builtin_amdgcn_s_waitcnt(IMM_STEADY);
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0070);   // the pipeline's tail: vmcnt(0), lgkmcnt(0)
+        }
+    };
+    if (grp == 1) fence_barrier();           // waves 4-7: one phase behind
+    for (int s = 0; s < nsub; s++) {
+        memory_phase(s);
+        fence_barrier();
+        if (!(ablate & 4)) mfmas();
+        fence_barrier();
+    }
+    if (grp == 0) fence_barrier();
+    // epilogue: ONE rounding per output (as fc_lp_gemm_kernel)
+    if constexpr (PREC == 1) {   // 16 x 16 tiles: lane holds m = lane % 16 and n = 4 (lane / 16) + c
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const f32x4_t &c = acc16[4 * t + u];
+                const int m = m0 + wm * 64 + 16 * u + (lane & 15);
+                const int n = n0 + wn * 128 + 16 * t + 4 * (lane >> 4);
+                uint2 hv;
+                hv.x = pack_bf16x2(c[0], c[1]);
+                hv.y = pack_bf16x2(c[2], c[3]);
+                reinterpret_cast<uint2 *>(Y)[((size_t)(n >> 3) * ldm + m) * 2 + ((n & 7) >> 2)] = hv;
+            }
+    } else {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const f32x16 &c = acc32[2 * t + u];
+                const int m = m0 + wm * 64 + 32 * u + r;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int n = n0 + wn * 128 + 32 * t + 8 * i + 4 * h;
+                    reinterpret_cast<uint32_t *>(Y)[((size_t)(n >> 4) * ldm + m) * 4 + ((n & 15) >> 2)] =
+                        pack_fp8x4(c[4 * i + 0], c[4 * i + 1], c[4 * i + 2], c[4 * i + 3], oscale);
+                }
+            }
+    }
+}
+
+// ===================================================================================================
 // fc_gemm_gather_kernel<PREC>: north_star's "fused concat + first FC" for the model whose record does not fit a CU (Model-C, batch 4096,
 // bf16 / fp8): the FC1 GEMM of batch L - 1 (fc_lp_gemm_kernel's 128 x 256 tile body, 8 consumer waves) and the GATHER of batch L (4
 // producer waves, one per SIMD) in ONE workgroup, so the two share every CU for the length of the kernel by construction -- the
@@ -1041,6 +1242,19 @@ static int lp_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int 
     return FR_OK;
 }
 
+template <int PREC, int D>
+static int pp_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
+    static FrLdsAttrOnce lds_once;
+    const size_t lds = (size_t)(D + 1) * 4 * 512 * 16;
+    if (int rc_ = fr_allow_full_lds(&fc_pp_gemm_kernel<PREC, D>, lds_once)) return rc_;
+    dim3 grid((N / 256) * (ldm / 256));
+    fc_pp_gemm_kernel<PREC, D><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale,
+                                                            FR_KNOB_ONCE("PP_ABLATE", 0));
+    KCHECK();
+    fr_note_kernel("fc_pp_gemm_kernel<%d, %d>", PREC, D);
+    return FR_OK;
+}
+
 #ifdef FR_EXPERIMENTS
 template <int PREC, int NT, int MT, int PD>
 static int splitk_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
@@ -1058,6 +1272,12 @@ static int splitk_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, 
 template <int PREC>
 static int lp_gemm_tile(int mu, const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
     if constexpr (PREC != 0) {
+        if (mu == 6 && KE % 4 == 0 && KE / 4 >= 4) {   // the 256 x 256 tile with the SIMD's two waves in opposite phases (fc_pp_gemm_kernel)
+            // sub-steps ahead: 3 in bf16, 2 in fp8 (profiles/r05_experiments.md section 13); experiment knob: 0 = fc_lp_gemm_kernel's plain loop
+            const int pp = FR_KNOB_ONCE("LP_GEMM_PP", (PREC == 1 ? 3 : 2));
+            if (pp == 3) return pp_gemm_launch<PREC, 3>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+            if (pp == 2) return pp_gemm_launch<PREC, 2>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+        }
         if constexpr (PREC == 1) {
             if (mu == 6 && FR_KNOB_ONCE("LP_GEMM_MF16", 1)) return lp_gemm_launch<1, 2, 256, FR_GSTAGES, FR_GR, 16>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
         }

@@ -187,7 +187,8 @@ def test_gemm_workgroups_from_the_kernel_name():
     spec = importlib.util.spec_from_file_location("bench_for_wg_test", os.path.join(ROOT, "bench.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    assert b.gemm_workgroups("fc_lp_gemm_kernel<1, 2, 256, 2, 8, 16>", 2048, 4096) == 128      # Model-C FC1, 256 x 256 tiles: two launches fit
+    assert b.gemm_workgroups("fc_pp_gemm_kernel<1, 3>", 2048, 4096) == 128                      # Model-C FC1, 256 x 256 tiles: two launches fit
+    assert b.gemm_workgroups("fc_lp_gemm_kernel<1, 2, 256, 2, 8, 16>", 2048, 4096) == 128      # ... the same tile's plain loop
     assert b.gemm_workgroups("fc_lp_gemm_kernel<0, 2, 128, 2, 8, 32>", 2048, 4096) == 256      # fp32, 128 x 256 tiles: the chip
     assert b.gemm_workgroups("fc_gemm_pipe_kernel<1, 5, 1>", 512, 4096) == 64                   # FC2 on 128 x 256 tiles
     assert b.gemm_workgroups("fc_lp_gemm_kernel<2, 1, 128, 2, 8, 32>", 256, 4096) == 64         # FC3 on 128 x 128 tiles

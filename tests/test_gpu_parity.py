@@ -2114,10 +2114,38 @@ def test_model_c_streaming_gather_inside_fc1(fr, O, ctxs, gpu, prec, per_bank):
             own.close()
 
 
+def test_gemm_256_tile_phased_waves_bit_identical_to_plain_loop(fr, gpu, tmp_path):
+    """fc_pp_gemm_kernel (the 256 x 256 GEMM tile with the two waves of every SIMD in opposite phases: one fetches while the other multiplies)
+    issues the same MFMA instructions on the same k groups in the same order as fc_lp_gemm_kernel<P, 2, 256, ...>'s plain loop: Model-C's
+    scores at batch 4096 (chain width 4) and 8192, bf16 and fp8, must agree BIT FOR BIT, and 20 repeats of every batch with themselves (a
+    DMA / barrier race would show as a flipped score).  The plain loop is reachable in the experiments build only (FR_LP_GEMM_PP=0, read
+    once per process): one child process per variant (tools/experiments/gemm_pp_check.py)."""
+    import subprocess
+    import sys
+    exp = os.path.join(os.path.dirname(fr.LIB_PATH), "libfleetrec_exp.so")
+    if not os.path.exists(exp):
+        pytest.skip("experiments library not built (make -C gpu-fpga-recommendation-system_amd/csrc exp)")
+    tool = os.path.join(ROOT, "tools", "experiments", "gemm_pp_check.py")
+    outs = {}
+    for pp in ("0", "default"):
+        env = dict(os.environ, FR_LIB=exp)
+        env.pop("FR_LP_GEMM_PP", None)
+        if pp != "default":
+            env["FR_LP_GEMM_PP"] = pp
+        outs[pp] = str(tmp_path / ("pp_%s.npz" % pp))
+        p_ = subprocess.run([sys.executable, tool, outs[pp]], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p_.returncode == 0, (p_.stdout[-2000:], p_.stderr[-3000:])
+    a, b = np.load(outs["0"]), np.load(outs["default"])
+    for k in ("bf16_4096", "fp8_4096", "bf16_8192", "fp8_8192"):
+        assert str(a["kernel_" + k]).startswith("fc_lp_gemm_kernel<%d, 2, 256," % (1 if k.startswith("bf16") else 2)), str(a["kernel_" + k])
+        assert str(b["kernel_" + k]).startswith("fc_pp_gemm_kernel<%d, " % (1 if k.startswith("bf16") else 2)), str(b["kernel_" + k])
+        assert np.array_equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("prec", ["bf16", "fp8"])
 def test_gemm_256_tile_batch_8192(fr, O, ctxs, prec):
     """From batch 8192 on Model-C's FC1 (3968 x 2048 x 8192) has enough 256 (n) x 256 (m) tiles to cover the chip (8 x 32) and takes
-    fc_lp_gemm_kernel<P, 2, 256, 2>: a third fewer operand bytes per output through the CU's vector-memory path than the 128 x 256 tile
+    fc_pp_gemm_kernel<P, D> (the 256 x 256 tile): a third fewer operand bytes per output through the CU's vector-memory path than the 128 x 256 tile
     (FC1 137 -> 117 us in bf16, 69 -> 59 us in fp8; profiles/r04_experiments.md section 1.6).  The 8192 items against the same rows as two
     batches of 4096 (the 128 x 256 kernels: same sums over k in the same order per output up to the MFMA's own grouping) and 1024 of them
     against the fp64-accumulating oracle; the layer's kernel as the library names it."""
@@ -2134,7 +2162,7 @@ def test_gemm_256_tile_batch_8192(fr, O, ctxs, prec):
             wk.calibrate_fp8(idx[:4096], dense[:4096])
         big = wk.infer(idx, dense)
         wk.fc_layer_only(B, 0)
-        assert wk.last_kernel().startswith("fc_lp_gemm_kernel<%d, 2, 256," % (1 if prec == "bf16" else 2)), wk.last_kernel()
+        assert wk.last_kernel().startswith("fc_pp_gemm_kernel<%d, " % (1 if prec == "bf16" else 2)), wk.last_kernel()
         wk.sync()
         halves = np.concatenate([wk.infer(idx[:4096], dense[:4096]), wk.infer(idx[4096:], dense[4096:])])
         assert rel_err(big, halves) <= {"bf16": 1e-2, "fp8": 4e-2}[prec], rel_err(big, halves)
@@ -2182,14 +2210,14 @@ def test_part_chip_tiles_follow_the_chain_width_not_the_worker_count(fr, O, ctxs
         alone = wk.infer(idx, dense)                     # the first low-precision launch: one live worker -> W = 1, frozen
         assert ctx.chain_width() == 1
         k_alone = layer_kernels()
-        assert ", 2, 256," not in k_alone[0] and k_alone[1].startswith("fc_lp_gemm_kernel<%d, 1, 64" % P), k_alone
+        assert ", 2, 256," not in k_alone[0] and "fc_pp_gemm" not in k_alone[0] and k_alone[1].startswith("fc_lp_gemm_kernel<%d, 1, 64" % P), k_alone
         other = fr.Worker(ctx, B)                        # a second worker appears: NOTHING changes for the first one
         assert ctx.chain_width() == 1 and layer_kernels() == k_alone
         assert np.array_equal(wk.infer(idx, dense), alone) and np.array_equal(other.infer(idx, dense), alone)
         ctx.set_chain_width(2)                           # the caller's decision, on purpose
         paired = wk.infer(idx, dense)
         k_paired = layer_kernels()
-        assert k_paired[0].startswith("fc_lp_gemm_kernel<%d, 2, 256," % P) and k_paired[1].startswith("fc_lp_gemm_kernel<%d, 1, 128" % P), k_paired
+        assert k_paired[0].startswith("fc_pp_gemm_kernel<%d, " % P) and k_paired[1].startswith("fc_lp_gemm_kernel<%d, 1, 128" % P), k_paired
         assert np.array_equal(other.infer(idx, dense), paired)
         if prec == "fp8":
             assert np.array_equal(paired, alone)         # fp8: one summation order whatever the tile
@@ -2294,7 +2322,7 @@ def test_chain_workers_run_their_layers_side_by_side(fr, ctxs):
         for w in wks:                                    # every worker's activation image is written once (the layer launches read it)
             w.infer(idx, dense)
         wks[0].fc_layer_only(B, 0)
-        assert wks[0].last_kernel().startswith("fc_lp_gemm_kernel<1, 2, 256,"), wks[0].last_kernel()
+        assert wks[0].last_kernel().startswith("fc_pp_gemm_kernel<1, "), wks[0].last_kernel()
         wks[0].sync()
         reps = 60
 
