@@ -349,7 +349,8 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
                                                          int N, int ldm, int sc_a, int sc_b, float oscale, int ablate) {
     static_assert(PREC == 1 || PREC == 2, "bf16 / fp8");
 #ifndef FR_EXPERIMENTS
-    ablate = 0;   // timing ablations (wrong results: 1 = no DMA inside the loop, 2 = no fragment reads, 4 = no MFMAs) exist in the experiments build only
+    ablate = 0;   // timing ablations (wrong results: 1 = no DMA inside the loop, 2 = no fragment reads, 4 = no MFMAs, 8 = every sub-step re-reads the first
+                  // one's rows) and schedule variants (16 = the other s_setprio choice, 32 = DMAs before the fragment reads) exist in the experiments build only
 #endif
     extern __shared__ uint4 glds[];
     typedef __attribute__((address_space(3))) void *lds_ptr;
@@ -394,7 +395,7 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
             const unsigned la = iss_lds + 1024u * q, so = iss_src + 1024u * q;
             asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(la), "v"(voff), "s"(rs), "s"(so) : "memory");
         }
-        iss_src += PR * row_bytes;
+        if (!(ablate & 8)) iss_src += PR * row_bytes;
         iss_stage++;
         iss_lds += (unsigned)STAGE * 16u;
         if (iss_stage == S) {
@@ -445,7 +446,10 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
         }
     };
     auto mfmas = [&]() {
-        __builtin_amdgcn_s_setprio(1);
+        // raised priority for the multiplying wave pays in fp8 only (bf16 FC1, two launches side by side: 102.2 -> 99.7 us without it)
+        constexpr int PRIO_BIT = PREC == 1 ? 16 : 0;   // experiments build, FR_PP_ABLATE=16: the other choice
+        const bool prio = ((ablate & 16) != 0) == (PRIO_BIT != 0);
+        if (prio) __builtin_amdgcn_s_setprio(1);
         if constexpr (PREC == 1) {
 #pragma unroll
             for (int u = 0; u < 4; u++)
@@ -466,7 +470,7 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
                     acc32[2 * t + u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc32[2 * t + u], 0, 0, 0, sc_a, 0, sc_b);
                 }
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (prio) __builtin_amdgcn_s_setprio(0);
     };
     auto fence_barrier = [&]() {
         asm volatile("" ::: "memory");
@@ -483,9 +487,10 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
     fence_barrier();
     const int main_end = nsub - D;           // s < main_end: M(s) issues sub-step s + D
     auto memory_phase = [&](int s) {
+        if ((ablate & 32) && s < main_end) issue_next();
         if (!(ablate & 2) || s == 0) read_frags();
         if (s < main_end) {
-            if (!(ablate & 1)) issue_next();
+            if (!(ablate & 33)) issue_next();
             __builtin_amdgcn_s_waitcnt(IMM_STEADY);
         } else {
             __builtin_amdgcn_s_waitcnt(0x0070);   // the pipeline's tail: vmcnt(0), lgkmcnt(0)
