@@ -472,9 +472,13 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
         }
         if (prio) __builtin_amdgcn_s_setprio(0);
     };
+    // sched_barrier(0): NOTHING is scheduled across -- MFMAs are register-only instructions, and without it hipcc moves most of a phase's
+    // MFMAs behind the next barrier, into the other group's phase (the phases are the point of this kernel; measured: bf16 FC1 117 for 102 us)
     auto fence_barrier = [&]() {
         asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
     };
     const int nsub = KE / PR;   // >= D + 1 (checked by the launcher)
@@ -1225,7 +1229,11 @@ static int lp_gemm_mu(int precision, int K, int N, int ldm, int width = 1) {
     const int part_knob = FR_KNOB_ONCE("LP_GEMM_PART", -1);   // experiment knob: the divisor (1 = full-chip tiles only, 2, 4), whatever the worker count
     const int part = precision == FR_FC_FP32 ? 1 : (part_knob > 0 ? part_knob : (width < 1 ? 1 : (width > 4 ? 4 : width)));
     const long full = 192 / part;
-    if (precision != FR_FC_FP32 && t256sq >= full && FR_KNOB_ONCE("LP_GEMM_256", 1)) return 6;
+    // at W = 4 a layer takes 256 x 256 tiles from 24 of them on (Model-C FC2 at batch 4096: 32 tiles on 32 CUs for 64 of 128 x 256 on 64): a launch
+    // takes longer (45 for 35 us) on half the CUs, and the four chains share the chip -- bf16 47.2 -> 48.2 M inf/s, fp8 69.6 -> 72.4 M
+    // (profiles/r05_experiments.md section 13)
+    const long full256 = part >= 4 ? 24 : full;
+    if (precision != FR_FC_FP32 && t256sq >= full256 && FR_KNOB_ONCE("LP_GEMM_256", 1)) return 6;
     if (t256 >= full) return 2;
     if (t128 >= full) return 1;
     if (t64 >= 128 && small_tile == 3) return 3;
