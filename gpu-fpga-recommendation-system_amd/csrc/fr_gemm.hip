@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_out_kernel(const uint4 *__rest
 //   * read before overwritten: the DMAs of sub-step s + D, issued in M(s) (phase 2 s or later), overwrite the stage of sub-step s - 1,
 //     whose last reads (group 1's M(s - 1), phase 2 s - 1) were retired by lgkmcnt(0) before that phase's closing barrier.
 // ===================================================================================================
-template <int PREC, int D>
+template <int PREC, int D, int NT>
 __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
                                                          int N, int ldm, int sc_a, int sc_b, float oscale, int ablate) {
     static_assert(PREC == 1 || PREC == 2, "bf16 / fp8");
@@ -358,7 +358,8 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wm = wave >> 1, grp = wave >> 2;
-    const int tn = N / GN, tm = ldm / GM;
+    const int tn = NT ? NT : N / GN, tm = ldm / GM;   // NT: the layer's n tiles at compile time (8: Model-C FC1, 2: its FC2; 0 = any) -- the tile map's
+                                                      // divisions fold, and the chain's layers carry distinct kernel names in a profile
     int n_tile, m_tile;  // XCD-aware 2 (n) x 4 (m) tile map, as in fc_lp_gemm_kernel
     if (tn % 2 == 0 && tm % 4 == 0) {
         const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -1255,17 +1256,24 @@ static int lp_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int 
     return FR_OK;
 }
 
-template <int PREC, int D>
-static int pp_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
+template <int PREC, int D, int NT>
+static int pp_gemm_launch_nt(const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
     static FrLdsAttrOnce lds_once;
     const size_t lds = (size_t)(D + 1) * 4 * 512 * 16;
-    if (int rc_ = fr_allow_full_lds(&fc_pp_gemm_kernel<PREC, D>, lds_once)) return rc_;
+    if (int rc_ = fr_allow_full_lds(&fc_pp_gemm_kernel<PREC, D, NT>, lds_once)) return rc_;
     dim3 grid((N / 256) * (ldm / 256));
-    fc_pp_gemm_kernel<PREC, D><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale,
-                                                            FR_KNOB_ONCE("PP_ABLATE", 0));
+    fc_pp_gemm_kernel<PREC, D, NT><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale,
+                                                                FR_KNOB_ONCE("PP_ABLATE", 0));
     KCHECK();
-    fr_note_kernel("fc_pp_gemm_kernel<%d, %d>", PREC, D);
+    fr_note_kernel("fc_pp_gemm_kernel<%d, %d, %d>", PREC, D, NT);
     return FR_OK;
+}
+
+template <int PREC, int D>
+static int pp_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
+    if (N == 2048) return pp_gemm_launch_nt<PREC, D, 8>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+    if (N == 512) return pp_gemm_launch_nt<PREC, D, 2>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+    return pp_gemm_launch_nt<PREC, D, 0>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
 }
 
 #ifdef FR_EXPERIMENTS
@@ -1285,16 +1293,20 @@ static int splitk_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, 
 template <int PREC>
 static int lp_gemm_tile(int mu, const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
     if constexpr (PREC != 0) {
-        if (mu == 6 && KE % 4 == 0 && KE / 4 >= 4) {   // the 256 x 256 tile with the SIMD's two waves in opposite phases (fc_pp_gemm_kernel)
-            // sub-steps ahead: 3 in bf16, 2 in fp8 (profiles/r05_experiments.md section 13); experiment knob: 0 = fc_lp_gemm_kernel's plain loop
-            const int pp = FR_KNOB_ONCE("LP_GEMM_PP", (PREC == 1 ? 3 : 2));
+        if (mu == 6) {   // the 256 x 256 tile: fc_pp_gemm_kernel, the SIMD's two waves in opposite phases; 3 sub-steps ahead in bf16, 2 in fp8
+                         // (profiles/r05_experiments.md section 13).  lp_gemm_mu guarantees KE % 8 == 0 and KE >= 16: whole sub-steps, a full pipeline.
+#ifdef FR_EXPERIMENTS
+            const int pp = FR_KNOB_ONCE("LP_GEMM_PP", (PREC == 1 ? 3 : 2));   // 0 = fc_lp_gemm_kernel's plain loop on the same tile (the A/B partner: same bits)
             if (pp == 3) return pp_gemm_launch<PREC, 3>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
             if (pp == 2) return pp_gemm_launch<PREC, 2>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+            if constexpr (PREC == 1) {
+                if (FR_KNOB_ONCE("LP_GEMM_MF16", 1)) return lp_gemm_launch<1, 2, 256, FR_GSTAGES, FR_GR, 16>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+            }
+            return lp_gemm_launch<PREC, 2, 256, FR_GSTAGES>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+#else
+            return pp_gemm_launch<PREC, (PREC == 1 ? 3 : 2)>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
+#endif
         }
-        if constexpr (PREC == 1) {
-            if (mu == 6 && FR_KNOB_ONCE("LP_GEMM_MF16", 1)) return lp_gemm_launch<1, 2, 256, FR_GSTAGES, FR_GR, 16>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
-        }
-        if (mu == 6) return lp_gemm_launch<PREC, 2, 256, FR_GSTAGES>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
     }
     if (mu == 2) return lp_gemm_launch<PREC, 2, 128, FR_GSTAGES>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
 #ifdef FR_EXPERIMENTS
