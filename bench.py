@@ -817,7 +817,7 @@ def leg_config(fr, ctx, model, B, precision, d_idx, d_dense, idx_host0, dense_ho
             v.submit_device(B, d_idx[0], d_dense[0] if d_dense else None, d_sc)
             v.sync()
         layer_ms, layer_kernels, layer_conc, layer_spread = [], [], [], []
-        reps = 60
+        reps = 200   # per stream; the block's fixed cost (first dispatch, stop event: ~0.1 ms under rocprofv3) stays below 1 % of a 47 us launch
         for layer in range(4):
             if layer == 3 and layer_kernels[2].startswith("fc_lp_gemm_out_kernel"):   # the output layer rides in FC3's epilogue: no launch of its own in the chain
                 res["output_layer"] = "folded into FC3's epilogue (%s): no launch of its own" % layer_kernels[2]

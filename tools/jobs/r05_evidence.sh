@@ -7,8 +7,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05_evidence
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-st() { # name, bench args...
+st() { # name, bench args...   (ONLY=<prefix> in the environment: just the legs whose name starts with it)
   n=$1; shift
+  case "$n" in ${ONLY:-}*) ;; *) return 0;; esac
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$n -- python3 $R/bench.py "$@" > $O/stats_$n.log 2>&1 || echo "stats $n failed"
   f=$(ls $O/stats_$n/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/${n}_kernel_stats.csv
   t=$(ls $O/stats_$n/*/*kernel_trace.csv 2>/dev/null | head -1); [ -n "$t" ] && python3 $R/tools/trace_kernel_median.py $t $O/${n}_kernel_durations.json > $O/${n}_kernel_durations.txt 2>&1

@@ -25,8 +25,8 @@ for key in $KEYS; do
     gather_C4096_per_bank_uniform) ARGS="--legs bank"; KERNEL="gather_pack"; EXTRA=();;
     fused_h_B1024_bf16) ARGS="--roofline-only --model B --batch 1024 --precision bf16"; KERNEL="fr_fused_tile_h"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
     gemm_C4096_f32) ARGS="--roofline-only --model C --batch 4096 --precision f32"; KERNEL="fc_lp_gemm_kernel<0, 2"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
-    gemm_C4096_bf16) ARGS="--roofline-only --model C --batch 4096 --precision bf16"; KERNEL="fc_lp_gemm_kernel<1, 2, 256"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
-    gemm_C4096_fp8) ARGS="--roofline-only --model C --batch 4096 --precision fp8"; KERNEL="fc_lp_gemm_kernel<2, 2, 256"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
+    gemm_C4096_bf16) ARGS="--roofline-only --model C --batch 4096 --precision bf16"; KERNEL="fc_pp_gemm_kernel<1, 3, 8"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
+    gemm_C4096_fp8) ARGS="--roofline-only --model C --batch 4096 --precision fp8"; KERNEL="fc_pp_gemm_kernel<2, 2, 8"; EXTRA=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE");;
     *) echo "unknown key $key"; exit 1;;
   esac
   mkdir -p $OUT/$key
