@@ -2143,6 +2143,56 @@ def test_gemm_256_tile_phased_waves_bit_identical_to_plain_loop(fr, gpu, tmp_pat
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp8"])
+def test_gemm_256_tile_phased_waves_on_a_user_model(fr, O, gpu, prec):
+    """fc_pp_gemm_kernel<P, D, 0> -- the instantiation whose n-tile count is a run-time value -- on layer shapes none of the built-in models has:
+    a user model K = 512 -> 1024 -> 768 -> 256 -> 1 at batch 4096 and chain width 4: FC1 has 4 x 16 tiles of 256 x 256 (XCD-aware 2 x 4 tile
+    map), FC2 3 x 16 (an odd n-tile count: the linear tile map), FC3 + the output layer ride fc_lp_gemm_out_kernel.  Every item against the
+    fp64-accumulating oracle chain on the records the library gathered (the gather is pinned bit-exact elsewhere), against the same items at
+    chain width 1 (other tiles, other kernels: same arithmetic up to summation order / single rounding flips), the kernels as the library
+    names them, and 10 repeats bit for bit."""
+    rng = np.random.default_rng(77)
+    dims = [4, 8, 16, 32, 64, 4, 8, 16, 32, 64, 8, 8, 16, 16, 32, 32, 64, 24, 40, 24]
+    assert sum(dims) == 512
+    m = fr.Model.from_spec({"name": "wide_hidden", "fc": [1024, 768, 256], "tables": [{"dim": d_, "rows": int(rng.integers(50, 20000))} for d_ in dims]})
+    P = {"bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[prec]
+    B = 4096
+    idx = uniform_idx(rng, m.rows(), B)
+    res = {}
+    for W in (1, 4):
+        ctx = fr.Context(m, device=gpu)
+        ctx.fill_tables(fr.FILL_HASH, 11)
+        ctx.fill_weights(fr.WEIGHTS_UNIFORM, 12)
+        ctx.set_fc_precision(P)
+        ctx.set_chain_width(W)
+        wk = fr.Worker(ctx, B)
+        if prec == "fp8":
+            wk.calibrate_fp8(idx)
+        got = wk.infer(idx)
+        names = []
+        for layer in range(3):
+            wk.fc_layer_only(B, layer)
+            names.append(wk.last_kernel())
+            wk.sync()
+        if W == 4:
+            pn = 1 if prec == "bf16" else 2
+            assert names[0].startswith("fc_pp_gemm_kernel<%d, " % pn) and names[0].endswith(", 0>"), names
+            assert names[1].startswith("fc_pp_gemm_kernel<%d, " % pn) and names[1].endswith(", 0>"), names
+            assert names[2].startswith("fc_lp_gemm_out_kernel<%d" % pn), names
+            for _ in range(10):
+                assert np.array_equal(wk.infer(idx), got)
+            rec = wk.gather_records(idx).view(np.float32).reshape(B, -1)[:, :512]
+            ws = [ctx.get_weights(l) for l in range(4)]
+            ref = O.OracleModel("A").fc_chain(np.ascontiguousarray(rec), ws, acc64=True, dims=[512, 1024, 768, 256, 1])
+            assert rel_err(got, ref) <= {"bf16": 3e-2, "fp8": 0.15}[prec], rel_err(got, ref)
+        else:
+            assert not any(n.startswith("fc_pp_gemm_kernel") for n in names), names
+        res[W] = got
+        wk.close()
+        ctx.close()
+    assert rel_err(res[4], res[1]) <= {"bf16": 1e-2, "fp8": 4e-2}[prec], rel_err(res[4], res[1])
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp8"])
 def test_gemm_256_tile_batch_8192(fr, O, ctxs, prec):
     """From batch 8192 on Model-C's FC1 (3968 x 2048 x 8192) has enough 256 (n) x 256 (m) tiles to cover the chip (8 x 32) and takes
     fc_pp_gemm_kernel<P, D> (the 256 x 256 tile): a third fewer operand bytes per output through the CU's vector-memory path than the 128 x 256 tile
