@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
     static_assert(PREC == 1 || PREC == 2, "bf16 / fp8");
 #ifndef FR_EXPERIMENTS
     ablate = 0;   // timing ablations (wrong results: 1 = no DMA inside the loop, 2 = no fragment reads, 4 = no MFMAs, 8 = every sub-step re-reads the first
-                  // one's rows) and schedule variants (16 = the other s_setprio choice, 32 = DMAs before the fragment reads) exist in the experiments build only
+                  // one's rows) and schedule variants (16 = the other s_setprio choice, 32 = DMAs before the fragment reads, 64 = the fetching wave at raised priority) exist in the experiments build only
 #endif
     extern __shared__ uint4 glds[];
     typedef __attribute__((address_space(3))) void *lds_ptr;
@@ -492,6 +492,7 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
     fence_barrier();
     const int main_end = nsub - D;           // s < main_end: M(s) issues sub-step s + D
     auto memory_phase = [&](int s) {
+        if (ablate & 64) __builtin_amdgcn_s_setprio(2);   // experiment: the FETCHING wave above the multiplying one
         if ((ablate & 32) && s < main_end) issue_next();
         if (!(ablate & 2) || s == 0) read_frags();
         if (s < main_end) {
@@ -500,6 +501,7 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
         } else {
             __builtin_amdgcn_s_waitcnt(0x0070);   // the pipeline's tail: vmcnt(0), lgkmcnt(0)
         }
+        if (ablate & 64) __builtin_amdgcn_s_setprio(0);
     };
     if (grp == 1) fence_barrier();           // waves 4-7: one phase behind
     for (int s = 0; s < nsub; s++) {
