@@ -1009,6 +1009,7 @@ def run_sharded(fr, dist_mod, env, dev_id, args, auto_steps_s=0.0):
     ctx = fr.Context(model, device=dev_id, shard_rank=r, n_shards=G)
     ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
     ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    ctx.set_chain_width(1)   # ONE worker runs FC chains on this rank (the other one gathers): its GEMM launches have the chip to themselves
     offs, lens, F = model.shard_plan(G)
     dev = torch.device("cuda", dev_id)
     torch.cuda.set_device(dev)

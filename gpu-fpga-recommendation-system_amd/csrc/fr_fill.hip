@@ -95,11 +95,30 @@ int frk_transpose_records(const float *X, float *Xq, int batch, int K, int ldm, 
 }
 
 // Sharded mode: all-gathered padded slices [G][B][F] (item-major per shard) -> Xq[K/4][ldm][4] for items [item0, item0+n).
-// One launch per shard (slice offsets/lengths are host data); a transpose of 16-byte elements like the one above.
-__global__ void __launch_bounds__(256) transpose_slice_kernel(const float4 *__restrict__ S /* [B][F/4] of this shard */, int FQ, int item0,
-                                                              int n_items, int q_off, int q_len, float4 *__restrict__ Xq, int ldm) {
+// ONE launch for all shards (blockIdx.z = shard; the slice offsets / lengths travel as a kernel argument): a rank of an 8-way job used
+// to issue eight small launches one behind the other in front of every FC chain.  A transpose of 16-byte elements like the one above.
+constexpr int FR_SLICE_TABLE = 64;   // shards per launch (more: one launch per 64)
+struct FrSliceTable {
+    int q_off[FR_SLICE_TABLE], q_len[FR_SLICE_TABLE];   // record words (16 bytes of fp32) per shard
+};
+
+// shards [g0, g0 + n) -> the table; -> the longest slice among them
+static int slice_table(FrSliceTable &t, int g0, int n, const int *h_offsets, const int *h_lens) {
+    int max_q = 0;
+    for (int g = 0; g < n; g++) {
+        t.q_off[g] = h_offsets[g0 + g] / 4, t.q_len[g] = h_lens[g0 + g] / 4;
+        if (t.q_len[g] > max_q) max_q = t.q_len[g];
+    }
+    return max_q;
+}
+
+__global__ void __launch_bounds__(256) transpose_slices_kernel(const float4 *__restrict__ S /* [G][B][F/4] */, size_t shard_stride, int FQ, int item0, int n_items,
+                                                               const FrSliceTable t, float4 *__restrict__ Xq, int ldm) {
     __shared__ float4 tile[16][17];
+    const int g = blockIdx.z, q_len = t.q_len[g], q_off = t.q_off[g];
     const int q0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    if (q0 >= q_len) return;
+    S += (size_t)g * shard_stride;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     {
         const int m = m0 + ty, q = q0 + tx;
@@ -116,30 +135,37 @@ int frk_transpose_slices(const float *gathered, int n_shards, int batch_total, i
                          int item0, int n_items, float *Xq, int ldm, hipStream_t s) {
     if (slice_padded % 4) FR_FAIL(FR_ERR_INVALID, "slice_padded %d must be a multiple of 4", slice_padded);
     const int FQ = slice_padded / 4;
-    for (int g = 0; g < n_shards; g++) {
-        const int q_len = h_lens[g] / 4;
-        if (q_len == 0) continue;
-        dim3 grid((q_len + 15) / 16, (ldm + 15) / 16);
-        transpose_slice_kernel<<<grid, dim3(256), 0, s>>>(reinterpret_cast<const float4 *>(gathered) + (size_t)g * batch_total * FQ, FQ, item0,
-                                                         n_items, h_offsets[g] / 4, q_len, reinterpret_cast<float4 *>(Xq), ldm);
+    for (int g0 = 0; g0 < n_shards; g0 += FR_SLICE_TABLE) {
+        const int n = n_shards - g0 < FR_SLICE_TABLE ? n_shards - g0 : FR_SLICE_TABLE;
+        FrSliceTable t;
+        const int max_q = slice_table(t, g0, n, h_offsets, h_lens);
+        if (max_q == 0) continue;
+        dim3 grid((max_q + 15) / 16, (ldm + 15) / 16, n);
+        transpose_slices_kernel<<<grid, dim3(256), 0, s>>>(reinterpret_cast<const float4 *>(gathered) + (size_t)g0 * batch_total * FQ, (size_t)batch_total * FQ, FQ, item0,
+                                                          n_items, t, reinterpret_cast<float4 *>(Xq), ldm);
     }
     KCHECK();
     return FR_OK;
 }
 
 // Sharded mode with low-precision transport: all-gathered slices [G][B][F] of bf16 (PREC 1: 8 bytes per record word) or e4m3
-// (PREC 2: 4 bytes per word) -> the q8 / q16 operand image for items [item0, item0+n).  The image is zeroed first (fp8 pad rows).
+// (PREC 2: 4 bytes per word) -> the q8 / q16 operand image for items [item0, item0+n).  One launch for all shards, as above.  The slices cover
+// every record word and the kernel writes zeros for the items past n_items, so nothing is cleared beforehand except the fp8 image's rows past
+// K / 16 (its k is padded to a multiple of 64) -- the whole image used to be zeroed in front of every FC chain (32 MB at batch 4096).
 template <int PREC>
-__global__ void __launch_bounds__(256) transpose_slice_lp_kernel(const void *__restrict__ S /* [B][F/4] words of this shard */, int FQ, int item0, int n_items,
-                                                                  int q_off, int q_len, void *__restrict__ X, int ldm) {
+__global__ void __launch_bounds__(256) transpose_slices_lp_kernel(const char *__restrict__ S /* [G][B][F/4] words */, size_t shard_stride_bytes, int FQ, int item0,
+                                                                   int n_items, const FrSliceTable t, void *__restrict__ X, int ldm) {
     typedef typename std::conditional<PREC == 1, uint2, uint32_t>::type word_t;
     __shared__ word_t tile[16][17];
+    const int g = blockIdx.z, q_len = t.q_len[g], q_off = t.q_off[g];
     const int q0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    if (q0 >= q_len) return;
+    const word_t *Sg = reinterpret_cast<const word_t *>(S + (size_t)g * shard_stride_bytes);
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     {
         const int m = m0 + ty, q = q0 + tx;
         word_t z{};
-        tile[ty][tx] = (m < n_items && q < q_len) ? reinterpret_cast<const word_t *>(S)[(size_t)(item0 + m) * FQ + q] : z;
+        tile[ty][tx] = (m < n_items && q < q_len) ? Sg[(size_t)(item0 + m) * FQ + q] : z;
     }
     __syncthreads();
     {
@@ -158,16 +184,19 @@ int frk_transpose_slices_lp(int precision, const void *gathered, int n_shards, i
     const int FQ = slice_padded / 4;
     const size_t esz = precision == FR_FC_BF16 ? 8 : 4;  // bytes per record word on the wire
     const size_t rows = precision == FR_FC_FP8 ? (size_t)(K + 63) / 64 * 4 : (size_t)K / 8;
-    if (hipMemsetAsync(X, 0, rows * ldm * 16, s) != hipSuccess) FR_FAIL(FR_ERR_HIP, "hipMemsetAsync failed");
-    for (int g = 0; g < n_shards; g++) {
-        const int q_len = h_lens[g] / 4;
-        if (q_len == 0) continue;
-        dim3 grid((q_len + 15) / 16, (ldm + 15) / 16);
-        const char *src = reinterpret_cast<const char *>(gathered) + (size_t)g * batch_total * FQ * esz;
-        if (precision == FR_FC_BF16)
-            transpose_slice_lp_kernel<1><<<grid, dim3(256), 0, s>>>(src, FQ, item0, n_items, h_offsets[g] / 4, q_len, X, ldm);
-        else
-            transpose_slice_lp_kernel<2><<<grid, dim3(256), 0, s>>>(src, FQ, item0, n_items, h_offsets[g] / 4, q_len, X, ldm);
+    const size_t covered = precision == FR_FC_FP8 ? (size_t)K / 16 : (size_t)K / 8;   // element rows whose every word a slice writes
+    if (covered < rows && hipMemsetAsync(reinterpret_cast<char *>(X) + covered * ldm * 16, 0, (rows - covered) * ldm * 16, s) != hipSuccess)
+        FR_FAIL(FR_ERR_HIP, "hipMemsetAsync failed");
+    const size_t stride = (size_t)batch_total * FQ * esz;
+    for (int g0 = 0; g0 < n_shards; g0 += FR_SLICE_TABLE) {
+        const int n = n_shards - g0 < FR_SLICE_TABLE ? n_shards - g0 : FR_SLICE_TABLE;
+        FrSliceTable t;
+        const int max_q = slice_table(t, g0, n, h_offsets, h_lens);
+        if (max_q == 0) continue;
+        dim3 grid((max_q + 15) / 16, (ldm + 15) / 16, n);
+        const char *src = reinterpret_cast<const char *>(gathered) + (size_t)g0 * stride;
+        if (precision == FR_FC_BF16) transpose_slices_lp_kernel<1><<<grid, dim3(256), 0, s>>>(src, stride, FQ, item0, n_items, t, X, ldm);
+        else transpose_slices_lp_kernel<2><<<grid, dim3(256), 0, s>>>(src, stride, FQ, item0, n_items, t, X, ldm);
     }
     KCHECK();
     return FR_OK;
