@@ -1334,7 +1334,7 @@ def test_random_stage_pipeline_sequences(fr, gpu, prec):
     ctx.close()
 
 
-@pytest.mark.parametrize("which,G", [(0, 2), (1, 4), (2, 8)])
+@pytest.mark.parametrize("which,G", [(0, 2), (1, 4), (2, 8), (2, 70)])   # 70 shards: the slice transposes take 64 shards per launch
 def test_table_sharded_mode_single_device_emulation(fr, O, gpu, which, G):
     """BASELINE config 4 on one GPU: G table-sharded contexts (each holds only its tables), every shard gathers its
     [B x F] slice, the all-gather is emulated by concatenating the slices in shard order, then 'rank' r runs the FC chain on
