@@ -331,14 +331,14 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_out_kernel(const uint4 *__rest
 }
 
 // ===================================================================================================
-// fc_pp_gemm_kernel<PREC, D>: the 256 (n) x 256 (m) tile of the bf16 / fp8 GEMM layers with the two waves of every SIMD in OPPOSITE phases.
+// fc_pp_gemm_kernel<PREC, D, NT>: the 256 (n) x 256 (m) tile of the bf16 / fp8 GEMM layers with the two waves of every SIMD in OPPOSITE phases.
 // Same operand images, same 2 x 4 wave grid with 128 x 64 wave tiles, same MFMA instructions on the same k groups in the same order as
 // fc_lp_gemm_kernel<PREC, 2, 256, ...> (scores are bit-identical), but where that kernel's eight waves all issue their DMAs, all read
 // their fragments and only then all want the matrix pipe, here a K sub-step of 4 element rows (32 k in bf16, 64 k in fp8: 512 MFMA
 // cycles per wave) is split into a MEMORY phase (the wave reads the sub-step's 12 fragments into registers and issues its 4 DMAs of
-// sub-step s + D) and a MATRIX phase (its 32 / 8 MFMAs, from registers, at raised priority), the phases are fenced by s_barrier, and waves
+// sub-step s + D) and a MATRIX phase (its 32 / 8 MFMAs, from registers; fp8: at raised priority), the phases are fenced by s_barrier, and waves
 // 4-7 run one phase behind waves 0-3: at any moment one wave of each SIMD multiplies while the other one fetches.  D + 1 sub-steps in
-// LDS (D = 3: 128 KiB).  Hazards, with M(s) / C(s) the phases of sub-step s: group 0 runs M(s) in global phase 2 s, group 1 in 2 s + 1;
+// LDS (bf16 D = 3: 128 KiB; fp8 D = 2: 96 KiB).  Hazards, with M(s) / C(s) the phases of sub-step s: group 0 runs M(s) in global phase 2 s, group 1 in 2 s + 1;
 //   * landed before read: a wave waits (counted vmcnt: the D - 1 younger sub-steps stay in flight) for its own DMAs of sub-step s + 1 at
 //     the end of M(s), i.e. before the barrier that ends phase 2 s + 1 at the latest; the first read of sub-step s + 1 is in phase 2 s + 2;
 //   * read before overwritten: the DMAs of sub-step s + D, issued in M(s) (phase 2 s or later), overwrite the stage of sub-step s - 1,
