@@ -750,6 +750,8 @@ def gemm_workgroups(kname, N, ldm):
         return max(1, (N // 128) * (ldm // 256))
     if (kname or "").startswith("fc_pp_gemm_kernel"):      # 256 x 256 tiles
         return max(1, (N // 256) * (ldm // 256))
+    if (kname or "").startswith("fc_pp_gemm_n128_kernel"):  # 128 x 256 tiles
+        return max(1, (N // 128) * (ldm // 256))
     return None
 
 

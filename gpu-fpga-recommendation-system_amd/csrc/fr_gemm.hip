@@ -344,17 +344,18 @@ __global__ void __launch_bounds__(512) fc_lp_gemm_out_kernel(const uint4 *__rest
 //   * read before overwritten: the DMAs of sub-step s + D, issued in M(s) (phase 2 s or later), overwrite the stage of sub-step s - 1,
 //     whose last reads (group 1's M(s - 1), phase 2 s - 1) were retired by lgkmcnt(0) before that phase's closing barrier.
 // ===================================================================================================
-template <int PREC, int D, int NT>
-__global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
-                                                         int N, int ldm, int sc_a, int sc_b, float oscale, int ablate) {
+template <int PREC, int D, int NT, int GN, int PR>
+__device__ __forceinline__ void pp_gemm_body(uint4 *glds, const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
+                                             int N, int ldm, int sc_a, int sc_b, float oscale, int ablate) {
     static_assert(PREC == 1 || PREC == 2, "bf16 / fp8");
+    static_assert((GN == 256 && PR == 4) || (GN == 128 && PR == 8), "256 x 256 tiles in sub-steps of 4 element rows, 128 x 256 tiles in sub-steps of 8");
 #ifndef FR_EXPERIMENTS
     ablate = 0;   // timing ablations (wrong results: 1 = no DMA inside the loop, 2 = no fragment reads, 4 = no MFMAs, 8 = every sub-step re-reads the first
                   // one's rows) and schedule variants (16 = the other s_setprio choice, 32 = DMAs before the fragment reads, 64 = the fetching wave at raised priority) exist in the experiments build only
 #endif
-    extern __shared__ uint4 glds[];
     typedef __attribute__((address_space(3))) void *lds_ptr;
-    constexpr int GN = 256, GM = 256, ROW = GN + GM, PR = 4, S = D + 1, STAGE = PR * ROW;
+    constexpr int GM = 256, ROW = GN + GM, S = D + 1, STAGE = PR * ROW;
+    constexpr int WN = GN / 2, KGS = PR / 4;   // n per wave (2 x 4 waves: WN x 64 wave tiles); k groups of 4 element rows per sub-step
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wm = wave >> 1, grp = wave >> 2;
@@ -380,23 +381,36 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
         rs[3] = 0x00020000;
         return rs;
     };
-    // a sub-step is 4 rows x (256 + 256) elements = 32 wave-instructions of 64 elements, 4 per wave: waves 0-3 stage W's row w, waves 4-7
-    // X's row w - 4, the four quarters of the row each.  (M0 without a clobber: see fc_lp_gemm_kernel.)
-    const int drow = wave & 3;
-    const i32x4_t rs = grp == 0 ? make_rs(W, (unsigned)KE * (unsigned)N * 16u) : make_rs(X, (unsigned)KE * (unsigned)ldm * 16u);
-    const unsigned voff = (unsigned)((grp == 0 ? n0 : m0) + lane) * 16u;
-    const unsigned row_bytes = __builtin_amdgcn_readfirstlane((unsigned)(grp == 0 ? N : ldm) * 16u);
+    // staging.  256 x 256, 4 rows: 32 wave-instructions of 64 elements per sub-step, 4 per wave -- waves 0-3 stage W's row w, waves 4-7 X's row
+    // w - 4, the four quarters of the row each.  128 x 256, 8 rows: 48 per sub-step, 6 per wave -- wave w stages row w: W's two halves and X's four
+    // quarters.  (M0 without a clobber: see fc_lp_gemm_kernel.)
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_ptr)glds);
-    unsigned iss_lds = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(drow * ROW + (grp == 0 ? 0 : GN)) * 16u);
-    unsigned iss_src = __builtin_amdgcn_readfirstlane((unsigned)drow * row_bytes);
+    // 256 x 256: a wave stages ONE operand (rsA = W for waves 0-3, X for waves 4-7); 128 x 256: both (rsA = W, rsB = X)
+    const bool first_w = GN == 128 || grp == 0;
+    const i32x4_t rsA = first_w ? make_rs(W, (unsigned)KE * (unsigned)N * 16u) : make_rs(X, (unsigned)KE * (unsigned)ldm * 16u);
+    const unsigned voffA = (unsigned)((first_w ? n0 : m0) + lane) * 16u;
+    const unsigned rowA = __builtin_amdgcn_readfirstlane((unsigned)(first_w ? N : ldm) * 16u);
+    const int drow = GN == 256 ? (wave & 3) : wave;
+    unsigned iss_lds = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(drow * ROW + (first_w ? 0 : GN)) * 16u);   // this wave's row (and operand) of the stage being filled
+    unsigned iss_a = __builtin_amdgcn_readfirstlane((unsigned)drow * rowA);
+    // (the second operand's state exists in the 128 x 256 form only)
+    const i32x4_t rsB = GN == 128 ? make_rs(X, (unsigned)KE * (unsigned)ldm * 16u) : rsA;
+    const unsigned voffB = (unsigned)(m0 + lane) * 16u;
+    const unsigned rowB = __builtin_amdgcn_readfirstlane((unsigned)ldm * 16u);
+    unsigned iss_b = __builtin_amdgcn_readfirstlane((unsigned)drow * rowB);
     int iss_stage = 0;
+    auto dma = [&](const i32x4_t &rs, unsigned la, unsigned voff, unsigned so) {
+        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(la), "v"(voff), "s"(rs), "s"(so) : "memory");
+    };
     auto issue_next = [&]() {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const unsigned la = iss_lds + 1024u * q, so = iss_src + 1024u * q;
-            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(la), "v"(voff), "s"(rs), "s"(so) : "memory");
+        for (int q = 0; q < (GN == 256 ? 4 : GN / 64); q++) dma(rsA, iss_lds + 1024u * q, voffA, iss_a + 1024u * q);
+        if (!(ablate & 8)) iss_a += PR * rowA;
+        if constexpr (GN == 128) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) dma(rsB, iss_lds + (unsigned)GN * 16u + 1024u * q, voffB, iss_b + 1024u * q);
+            if (!(ablate & 8)) iss_b += PR * rowB;
         }
-        if (!(ablate & 8)) iss_src += PR * row_bytes;
         iss_stage++;
         iss_lds += (unsigned)STAGE * 16u;
         if (iss_stage == S) {
@@ -404,39 +418,43 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
             iss_lds -= (unsigned)(S * STAGE) * 16u;
         }
     };
-    constexpr int NA = PREC == 1 ? 8 : 8, NB = 4;   // fragment registers (uint4): bf16 8 n tiles + 4 m tiles of 16; fp8 4 n tiles + 2 m tiles of 32, two elements each
-    f32x4_t acc16[PREC == 1 ? 32 : 1];
-    f32x16 acc32[PREC == 1 ? 1 : 8];
+    constexpr int NT16 = WN / 16, NT32 = WN / 32;   // the wave's n tiles: of 16 (bf16, v_mfma_f32_16x16x32_bf16), of 32 (fp8, v_mfma_scale_f32_32x32x64_f8f6f4)
+    constexpr int NA = PREC == 1 ? NT16 : 2 * NT32, NB = 4;   // fragment registers (uint4) per k group: bf16 NT16 + 4 tiles of 16; fp8 NT32 + 2 tiles of 32, two elements each
+    f32x4_t acc16[PREC == 1 ? 4 * NT16 : 1];
+    f32x16 acc32[PREC == 1 ? 1 : 2 * NT32];
     if constexpr (PREC == 1) {
 #pragma unroll
-        for (int i = 0; i < 32; i++) acc16[i] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < 4 * NT16; i++) acc16[i] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < 2 * NT32; i++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc32[i][e] = 0.0f;
     }
-    uint4 fa[NA], fb[NB];
+    uint4 fa[KGS][NA], fb[KGS][NB];
     const uint4 *rd_ptr = glds;
     int rd_stage = 0;
     auto read_frags = [&]() {
-        if constexpr (PREC == 1) {   // lane (g, j): k group g = lane / 16 of the sub-step's four rows, row j = lane % 16 of its tile
-            const uint4 *p = rd_ptr + (size_t)(lane >> 4) * ROW + (lane & 15);
 #pragma unroll
-            for (int t = 0; t < 8; t++) fa[t] = p[wn * 128 + 16 * t];
+        for (int kg = 0; kg < KGS; kg++) {
+            if constexpr (PREC == 1) {   // lane (g, j): k group g = lane / 16 of the four rows, row j = lane % 16 of its tile
+                const uint4 *p = rd_ptr + (size_t)(4 * kg + (lane >> 4)) * ROW + (lane & 15);
 #pragma unroll
-            for (int u = 0; u < 4; u++) fb[u] = p[GN + wm * 64 + 16 * u];
-        } else {                     // k = 32 h + j: element rows 2 h, 2 h + 1
-            const uint4 *p = rd_ptr + (size_t)(2 * (lane >> 5)) * ROW + (lane & 31);
+                for (int t = 0; t < NT16; t++) fa[kg][t] = p[wn * WN + 16 * t];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                fa[2 * t] = p[wn * 128 + 32 * t];
-                fa[2 * t + 1] = p[ROW + wn * 128 + 32 * t];
-            }
+                for (int u = 0; u < 4; u++) fb[kg][u] = p[GN + wm * 64 + 16 * u];
+            } else {                     // k = 32 h + j: element rows 2 h, 2 h + 1
+                const uint4 *p = rd_ptr + (size_t)(4 * kg + 2 * (lane >> 5)) * ROW + (lane & 31);
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                fb[2 * u] = p[GN + wm * 64 + 32 * u];
-                fb[2 * u + 1] = p[ROW + GN + wm * 64 + 32 * u];
+                for (int t = 0; t < NT32; t++) {
+                    fa[kg][2 * t] = p[wn * WN + 32 * t];
+                    fa[kg][2 * t + 1] = p[ROW + wn * WN + 32 * t];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    fb[kg][2 * u] = p[GN + wm * 64 + 32 * u];
+                    fb[kg][2 * u + 1] = p[ROW + GN + wm * 64 + 32 * u];
+                }
             }
         }
         rd_stage++;
@@ -451,25 +469,28 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
         constexpr int PRIO_BIT = PREC == 1 ? 16 : 0;   // experiments build, FR_PP_ABLATE=16: the other choice
         const bool prio = ((ablate & 16) != 0) == (PRIO_BIT != 0);
         if (prio) __builtin_amdgcn_s_setprio(1);
-        if constexpr (PREC == 1) {
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+        for (int kg = 0; kg < KGS; kg++) {
+            if constexpr (PREC == 1) {
 #pragma unroll
-                for (int t = 0; t < 8; t++)
-                    acc16[4 * t + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[t]), __builtin_bit_cast(bf16x8, fb[u]), acc16[4 * t + u], 0, 0, 0);
-        } else {
+                for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int u = 0; u < 2; u++)
+                    for (int t = 0; t < NT16; t++)
+                        acc16[4 * t + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[kg][t]), __builtin_bit_cast(bf16x8, fb[kg][u]), acc16[4 * t + u], 0, 0, 0);
+            } else {
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const uint4 &a0 = fa[2 * t], &a1 = fa[2 * t + 1], &b0 = fb[2 * u], &b1 = fb[2 * u + 1];
-                    i32x8 av, bv;
-                    av[0] = (int)a0.x; av[1] = (int)a0.y; av[2] = (int)a0.z; av[3] = (int)a0.w;
-                    av[4] = (int)a1.x; av[5] = (int)a1.y; av[6] = (int)a1.z; av[7] = (int)a1.w;
-                    bv[0] = (int)b0.x; bv[1] = (int)b0.y; bv[2] = (int)b0.z; bv[3] = (int)b0.w;
-                    bv[4] = (int)b1.x; bv[5] = (int)b1.y; bv[6] = (int)b1.z; bv[7] = (int)b1.w;
-                    acc32[2 * t + u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc32[2 * t + u], 0, 0, 0, sc_a, 0, sc_b);
-                }
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int t = 0; t < NT32; t++) {
+                        const uint4 &a0 = fa[kg][2 * t], &a1 = fa[kg][2 * t + 1], &b0 = fb[kg][2 * u], &b1 = fb[kg][2 * u + 1];
+                        i32x8 av, bv;
+                        av[0] = (int)a0.x; av[1] = (int)a0.y; av[2] = (int)a0.z; av[3] = (int)a0.w;
+                        av[4] = (int)a1.x; av[5] = (int)a1.y; av[6] = (int)a1.z; av[7] = (int)a1.w;
+                        bv[0] = (int)b0.x; bv[1] = (int)b0.y; bv[2] = (int)b0.z; bv[3] = (int)b0.w;
+                        bv[4] = (int)b1.x; bv[5] = (int)b1.y; bv[6] = (int)b1.z; bv[7] = (int)b1.w;
+                        acc32[2 * t + u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc32[2 * t + u], 0, 0, 0, sc_a, 0, sc_b);
+                    }
+            }
         }
         if (prio) __builtin_amdgcn_s_setprio(0);
     };
@@ -483,7 +504,8 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
         asm volatile("" ::: "memory");
     };
     const int nsub = KE / PR;   // >= D + 1 (checked by the launcher)
-    constexpr unsigned INFL = 4u * (D - 1);   // DMAs of the D - 1 younger sub-steps may stay in flight
+    constexpr unsigned LPS = GN == 256 ? 4u : (unsigned)(GN / 64 + 4);   // DMAs per wave per sub-step
+    constexpr unsigned INFL = LPS * (D - 1);   // DMAs of the D - 1 younger sub-steps may stay in flight
     constexpr int IMM_STEADY = (int)((INFL & 0xF) | ((INFL >> 4) << 14) | 0x0070u);   // ... and lgkmcnt(0): the fragment reads are done
     constexpr int IMM_FIRST = (int)((INFL & 0xF) | ((INFL >> 4) << 14) | 0x0F70u);
 #pragma unroll
@@ -514,12 +536,12 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
     // epilogue: ONE rounding per output (as fc_lp_gemm_kernel)
     if constexpr (PREC == 1) {   // 16 x 16 tiles: lane holds m = lane % 16 and n = 4 (lane / 16) + c
 #pragma unroll
-        for (int t = 0; t < 8; t++)
+        for (int t = 0; t < NT16; t++)
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const f32x4_t &c = acc16[4 * t + u];
                 const int m = m0 + wm * 64 + 16 * u + (lane & 15);
-                const int n = n0 + wn * 128 + 16 * t + 4 * (lane >> 4);
+                const int n = n0 + wn * WN + 16 * t + 4 * (lane >> 4);
                 uint2 hv;
                 hv.x = pack_bf16x2(c[0], c[1]);
                 hv.y = pack_bf16x2(c[2], c[3]);
@@ -528,19 +550,35 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict
     } else {
         const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+        for (int t = 0; t < NT32; t++)
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const f32x16 &c = acc32[2 * t + u];
                 const int m = m0 + wm * 64 + 32 * u + r;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const int n = n0 + wn * 128 + 32 * t + 8 * i + 4 * h;
+                    const int n = n0 + wn * WN + 32 * t + 8 * i + 4 * h;
                     reinterpret_cast<uint32_t *>(Y)[((size_t)(n >> 4) * ldm + m) * 4 + ((n & 15) >> 2)] =
                         pack_fp8x4(c[4 * i + 0], c[4 * i + 1], c[4 * i + 2], c[4 * i + 3], oscale);
                 }
             }
     }
+}
+
+template <int PREC, int D, int NT>
+__global__ void __launch_bounds__(512) fc_pp_gemm_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
+                                                         int N, int ldm, int sc_a, int sc_b, float oscale, int ablate) {
+    extern __shared__ uint4 glds[];
+    pp_gemm_body<PREC, D, NT, 256, 4>(glds, W, X, Y, KE, N, ldm, sc_a, sc_b, oscale, ablate);
+}
+
+// the same on 128 (n) x 256 (m) tiles (64 x 64 wave tiles) in sub-steps of 8 element rows (two k groups per phase: 32 / 8 MFMAs per wave again;
+// D = 2: 144 KiB): layers whose 256 x 256 tiles would not cover their share of the chip -- Model-C FC1 for a lone worker
+template <int PREC, int D>
+__global__ void __launch_bounds__(512) fc_pp_gemm_n128_kernel(const uint4 *__restrict__ W, const uint4 *__restrict__ X, void *__restrict__ Y, int KE /* element rows */,
+                                                              int N, int ldm, int sc_a, int sc_b, float oscale, int ablate) {
+    extern __shared__ uint4 glds[];
+    pp_gemm_body<PREC, D, 0, 128, 8>(glds, W, X, Y, KE, N, ldm, sc_a, sc_b, oscale, ablate);
 }
 
 // ===================================================================================================
@@ -1272,6 +1310,19 @@ static int pp_gemm_launch_nt(const void *Wp, const void *Xp, void *Yp, int KE, i
 }
 
 template <int PREC, int D>
+static int pp_gemm_n128_launch(const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
+    static FrLdsAttrOnce lds_once;
+    const size_t lds = (size_t)(D + 1) * 8 * (128 + 256) * 16;
+    if (int rc_ = fr_allow_full_lds(&fc_pp_gemm_n128_kernel<PREC, D>, lds_once)) return rc_;
+    dim3 grid((N / 128) * (ldm / 256));
+    fc_pp_gemm_n128_kernel<PREC, D><<<grid, dim3(512), lds, s>>>(reinterpret_cast<const uint4 *>(Wp), reinterpret_cast<const uint4 *>(Xp), Yp, KE, N, ldm, sc_a, sc_b, oscale,
+                                                                 FR_KNOB_ONCE("PP_ABLATE", 0));
+    KCHECK();
+    fr_note_kernel("fc_pp_gemm_n128_kernel<%d, %d>", PREC, D);
+    return FR_OK;
+}
+
+template <int PREC, int D>
 static int pp_gemm_launch(const void *Wp, const void *Xp, void *Yp, int KE, int N, int ldm, int sc_a, int sc_b, float oscale, hipStream_t s) {
     if (N == 2048) return pp_gemm_launch_nt<PREC, D, 8>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
     if (N == 512) return pp_gemm_launch_nt<PREC, D, 2>(Wp, Xp, Yp, KE, N, ldm, sc_a, sc_b, oscale, s);
@@ -1388,6 +1439,13 @@ int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int 
     if (precision == FR_FC_FP32) return lp_gemm_tile<0>(mu, Wp, Xp, Yp, KE, N, ldm, 0, 0, 1.0f, s);
     // bf16 128 x 256 layers run the software-pipelined kernel; fp8 stays on fc_lp_gemm_kernel, which measured faster there (29.4 vs
     // 32.9 us on Model-C FC1: its 8-row steps halve the barriers per 64-cycle MFMA) unless FR_GEMM_PIPE_FP8=1 asks for the experiment
+    // 128 x 256 layers (a lone worker's Model-C FC1: chain width 1) on the phased-waves body in 8-row sub-steps (lp_gemm_mu guarantees KE % 8 == 0;
+    // KE >= 24: a full pipeline): bit-identical to the kernels below, FC1 bf16 65.5 -> 59.6 us, fp8 32.5 -> 31.4 us (profiles/r05_experiments.md
+    // section 13).  Experiment knob FR_LP_GEMM_PP128=0: the kernels below.
+    if (mu == 2 && precision != FR_FC_FP32 && FR_KNOB_ONCE("LP_GEMM_PP128", 1) && KE / 8 >= 3) {
+        if (precision == FR_FC_FP8) return pp_gemm_n128_launch<2, 2>(Wp, Xp, Yp, KE, N, ldm, 127 - e_w, 127 - e_in, ldexpf(1.0f, e_out), s);
+        return pp_gemm_n128_launch<1, 2>(Wp, Xp, Yp, KE, N, ldm, 0, 0, 1.0f, s);
+    }
     const bool pipe_fp8 = FR_KNOB_ONCE("GEMM_PIPE_FP8", 0) != 0;
     if (mu == 2 && (precision == FR_FC_BF16 || (precision == FR_FC_FP8 && pipe_fp8)) && pipe_shape_ok(pipe_shape(), KE)) {
         if (precision == FR_FC_FP8) return pipe_gemm_dispatch<2>(pipe_shape(), Wp, Xp, Yp, KE, N, ldm, 127 - e_w, 127 - e_in, ldexpf(1.0f, e_out), s);

@@ -191,6 +191,7 @@ def test_gemm_workgroups_from_the_kernel_name():
     assert b.gemm_workgroups("fc_lp_gemm_kernel<1, 2, 256, 2, 8, 16>", 2048, 4096) == 128      # ... the same tile's plain loop
     assert b.gemm_workgroups("fc_lp_gemm_kernel<0, 2, 128, 2, 8, 32>", 2048, 4096) == 256      # fp32, 128 x 256 tiles: the chip
     assert b.gemm_workgroups("fc_gemm_pipe_kernel<1, 5, 1>", 512, 4096) == 64                   # FC2 on 128 x 256 tiles
+    assert b.gemm_workgroups("fc_pp_gemm_n128_kernel<1, 2>", 2048, 4096) == 256                 # a lone worker's FC1: 128 x 256 tiles cover the chip
     assert b.gemm_workgroups("fc_lp_gemm_kernel<2, 1, 128, 2, 8, 32>", 256, 4096) == 64         # FC3 on 128 x 128 tiles
     assert b.gemm_workgroups("fr_pipeline_kernel<4, 1>", 1, 4096) is None and b.gemm_workgroups(None, 1, 1) is None
 

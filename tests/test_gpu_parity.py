@@ -2185,7 +2185,7 @@ def test_gemm_256_tile_phased_waves_on_a_user_model(fr, O, gpu, prec):
             ref = O.OracleModel("A").fc_chain(np.ascontiguousarray(rec), ws, acc64=True, dims=[512, 1024, 768, 256, 1])
             assert rel_err(got, ref) <= {"bf16": 3e-2, "fp8": 0.15}[prec], rel_err(got, ref)
         else:
-            assert not any(n.startswith("fc_pp_gemm_kernel") for n in names), names
+            assert not any(n.startswith("fc_pp_gemm_kernel<") for n in names), names   # chain width 1: no part-chip 256 x 256 tiles
         res[W] = got
         wk.close()
         ctx.close()
@@ -2260,7 +2260,7 @@ def test_part_chip_tiles_follow_the_chain_width_not_the_worker_count(fr, O, ctxs
         alone = wk.infer(idx, dense)                     # the first low-precision launch: one live worker -> W = 1, frozen
         assert ctx.chain_width() == 1
         k_alone = layer_kernels()
-        assert ", 2, 256," not in k_alone[0] and "fc_pp_gemm" not in k_alone[0] and k_alone[1].startswith("fc_lp_gemm_kernel<%d, 1, 64" % P), k_alone
+        assert k_alone[0].startswith("fc_pp_gemm_n128_kernel<%d, " % P) and k_alone[1].startswith("fc_lp_gemm_kernel<%d, 1, 64" % P), k_alone   # full-chip 128 x 256 tiles
         other = fr.Worker(ctx, B)                        # a second worker appears: NOTHING changes for the first one
         assert ctx.chain_width() == 1 and layer_kernels() == k_alone
         assert np.array_equal(wk.infer(idx, dense), alone) and np.array_equal(other.infer(idx, dense), alone)

@@ -18,7 +18,7 @@ import __graft_entry__ as g
 fr = g.load_package()
 m = fr.Model.builtin(fr.MODEL_C)
 ctx = fr.Context(m, device=0); ctx.fill_tables(fr.FILL_HASH, 1); ctx.fill_weights(fr.WEIGHTS_UNIFORM, 2)
-ctx.set_chain_width(4)
+ctx.set_chain_width(int(os.environ.get("FR_CHECK_WIDTH", "4")))   # 1: the full-chip 128 x 256 tiles (FR_LP_GEMM_PP128: fc_pp_gemm_n128_kernel)
 rng = np.random.default_rng(5)
 out = {}
 for B in (4096, 8192):
