@@ -2114,31 +2114,40 @@ def test_model_c_streaming_gather_inside_fc1(fr, O, ctxs, gpu, prec, per_bank):
             own.close()
 
 
-def test_gemm_256_tile_phased_waves_bit_identical_to_plain_loop(fr, gpu, tmp_path):
+@pytest.mark.parametrize("width", [4, 1])
+def test_gemm_tiles_phased_waves_bit_identical_to_plain_loops(fr, gpu, tmp_path, width):
     """fc_pp_gemm_kernel (the 256 x 256 GEMM tile with the two waves of every SIMD in opposite phases: one fetches while the other multiplies)
     issues the same MFMA instructions on the same k groups in the same order as fc_lp_gemm_kernel<P, 2, 256, ...>'s plain loop: Model-C's
     scores at batch 4096 (chain width 4) and 8192, bf16 and fp8, must agree BIT FOR BIT, and 20 repeats of every batch with themselves (a
-    DMA / barrier race would show as a flipped score).  The plain loop is reachable in the experiments build only (FR_LP_GEMM_PP=0, read
-    once per process): one child process per variant (tools/experiments/gemm_pp_check.py)."""
+    DMA / barrier race would show as a flipped score).  Chain width 1: the same for fc_pp_gemm_n128_kernel (128 x 256 tiles, a lone worker's
+    FC1 at batch 4096) against fc_gemm_pipe_kernel (bf16) and fc_lp_gemm_kernel<2, 2, 128, ...> (fp8).  The plain loops are reachable in the
+    experiments build only (FR_LP_GEMM_PP=0 / FR_LP_GEMM_PP128=0, read once per process): one child process per variant
+    (tools/experiments/gemm_pp_check.py)."""
     import subprocess
     import sys
     exp = os.path.join(os.path.dirname(fr.LIB_PATH), "libfleetrec_exp.so")
     if not os.path.exists(exp):
         pytest.skip("experiments library not built (make -C gpu-fpga-recommendation-system_amd/csrc exp)")
     tool = os.path.join(ROOT, "tools", "experiments", "gemm_pp_check.py")
+    knob = "FR_LP_GEMM_PP" if width == 4 else "FR_LP_GEMM_PP128"
     outs = {}
     for pp in ("0", "default"):
-        env = dict(os.environ, FR_LIB=exp)
+        env = dict(os.environ, FR_LIB=exp, FR_CHECK_WIDTH=str(width))
         env.pop("FR_LP_GEMM_PP", None)
+        env.pop("FR_LP_GEMM_PP128", None)
         if pp != "default":
-            env["FR_LP_GEMM_PP"] = pp
+            env[knob] = pp
         outs[pp] = str(tmp_path / ("pp_%s.npz" % pp))
         p_ = subprocess.run([sys.executable, tool, outs[pp]], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert p_.returncode == 0, (p_.stdout[-2000:], p_.stderr[-3000:])
     a, b = np.load(outs["0"]), np.load(outs["default"])
     for k in ("bf16_4096", "fp8_4096", "bf16_8192", "fp8_8192"):
-        assert str(a["kernel_" + k]).startswith("fc_lp_gemm_kernel<%d, 2, 256," % (1 if k.startswith("bf16") else 2)), str(a["kernel_" + k])
-        assert str(b["kernel_" + k]).startswith("fc_pp_gemm_kernel<%d, " % (1 if k.startswith("bf16") else 2)), str(b["kernel_" + k])
+        P = 1 if k.startswith("bf16") else 2
+        ka, kb = str(a["kernel_" + k]), str(b["kernel_" + k])
+        if width == 4:
+            assert ka.startswith("fc_lp_gemm_kernel<%d, 2, 256," % P) and kb.startswith("fc_pp_gemm_kernel<%d, " % P), (ka, kb)
+        elif k.endswith("4096"):
+            assert ka.startswith("fc_gemm_pipe_kernel<1," if P == 1 else "fc_lp_gemm_kernel<2, 2, 128,") and kb.startswith("fc_pp_gemm_n128_kernel<%d, " % P), (ka, kb)
         assert np.array_equal(a[k], b[k]), k
 
 
