@@ -2,7 +2,8 @@
 """Race screen of the GEMM-layer chain (Model-C batch 4096, chain width 4: fc_pp_gemm_kernel on FC1 / FC2, fc_lp_gemm_out_kernel, the gather) under
 its real neighbours: four workers on four host threads push device-resident batches for `seconds`; every delivered score vector is compared BIT FOR
 BIT with the one a lone worker computed for the same rows before the soak.  A DMA that lands late, a stage overwritten early or a barrier that
-does not cover a read shows as a flipped score (such races come and go with what else runs on the CU).  Usage: soak_chain.py [seconds] [bf16|fp8]"""
+does not cover a read shows as a flipped score (such races come and go with what else runs on the CU).  workers = 1: chain width 1, the lone worker's
+full-chip tiles (fc_pp_gemm_n128_kernel).  Usage: soak_chain.py [seconds] [bf16|fp8] [workers: 4]"""
 import os
 import sys
 import threading
@@ -17,12 +18,13 @@ import __graft_entry__ as g   # noqa: E402
 fr = g.load_package()
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+n_workers = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 m = fr.Model.builtin(fr.MODEL_C)
 ctx = fr.Context(m, device=0)
 ctx.fill_tables(fr.FILL_HASH, 0xF1EE7)
 ctx.fill_weights(fr.WEIGHTS_UNIFORM, 99)
 ctx.set_fc_precision({"bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[prec])
-ctx.set_chain_width(4)
+ctx.set_chain_width(min(4, n_workers))
 B = 4096
 rng0 = np.random.default_rng(1)
 NP = 6
@@ -40,7 +42,7 @@ k0 = ref_wk.last_kernel()
 ref_wk.sync()
 ref_wk.close()
 stop = time.time() + secs
-errors, counts = [], [0, 0, 0, 0]
+errors, counts = [], [0] * n_workers
 
 
 def run(t):
@@ -64,12 +66,12 @@ def run(t):
     wk.close()
 
 
-th = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+th = [threading.Thread(target=run, args=(t,)) for t in range(n_workers)]
 for t_ in th:
     t_.start()
 for t_ in th:
     t_.join()
-print("soak_chain %s: FC1 = %s, %d batches of %d in %.0f s on 4 workers, %d mismatches" % (prec, k0, sum(counts), B, secs, len(errors)))
+print("soak_chain %s: FC1 = %s, %d batches of %d in %.0f s on %d worker(s), %d mismatches" % (prec, k0, sum(counts), B, secs, n_workers, len(errors)))
 for e in errors[:5]:
     print("  ", e)
 sys.exit(1 if errors else 0)
