@@ -1131,7 +1131,11 @@ static int pipeline_step(fr_worker *w) {
                 FR_HIP(hipEventRecord(w->ev_x_free[par], w->stream));
                 w->x_free_set[par] = true;
             }
-            int rc = frk_fc_lp_gemm(prec, st.w, st.in, st.out, st.K, st.N, ldm, st.e_w, st.e_in, st.e_out, prec == FR_FC_FP32 ? 1 : chain_width(c), w->stream);
+            // a MINOR layer (at most half the work of the chain's heaviest) may sit on fewer CUs than its share: see lp_gemm_mu
+            long heaviest = 0;
+            for (int l = 0; l < 3; l++) heaviest = std::max(heaviest, (long)fc[l] * fc[l + 1]);
+            const bool minor = 2 * (long)st.K * st.N <= heaviest;
+            int rc = frk_fc_lp_gemm(prec, st.w, st.in, st.out, st.K, st.N, ldm, st.e_w, st.e_in, st.e_out, prec == FR_FC_FP32 ? 1 : chain_width(c), minor, w->stream);
             if (rc) return rc;
             if (s == 1 && w->aux && FR_KNOB_ONCE("GATHER_AUX", 0) != 2) {  // X[par ^ 1] may be overwritten by the gather of the NEXT step once this launch has finished
                 FR_HIP(hipEventRecord(w->ev_x_free[par ^ 1], w->stream));

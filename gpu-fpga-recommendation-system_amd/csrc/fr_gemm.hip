@@ -1231,7 +1231,7 @@ static int pipe_gemm_dispatch(int shape, const void *Wp, const void *Xp, void *Y
 // Which block tile serves the layer: 2 = 128 (n) x 256 (m) when those tiles cover most of the chip, 1 = 128 x 128, 3 = 64 x 128 for layers
 // with few outputs (Model-C FC2 / FC3 at batch 4096: 512 / 256 outputs -> 256 / 128 tiles instead of 128 / 64), 0 = not worth a GEMM
 // launch (the stage pipeline's per-tile body takes it).
-static int lp_gemm_mu(int precision, int K, int N, int ldm, int width = 1) {
+static int lp_gemm_mu(int precision, int K, int N, int ldm, int width = 1, bool minor = false) {
     const int forced = FR_KNOB_ONCE("LP_GEMM", -1);  // experiment knob: 0 = never, 1 / 2 / 3 = only that tile
     const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : (precision == FR_FC_BF16 ? K / 8 : K / 4);
     if ((precision == FR_FC_BF16 && K % 8) || (precision == FR_FC_FP32 && K % 4) || KE % FR_GR || KE / FR_GR < 2 || N % 64 || ldm % 128) return 0;
@@ -1270,10 +1270,11 @@ static int lp_gemm_mu(int precision, int K, int N, int ldm, int width = 1) {
     const int part_knob = FR_KNOB_ONCE("LP_GEMM_PART", -1);   // experiment knob: the divisor (1 = full-chip tiles only, 2, 4), whatever the worker count
     const int part = precision == FR_FC_FP32 ? 1 : (part_knob > 0 ? part_knob : (width < 1 ? 1 : (width > 4 ? 4 : width)));
     const long full = 192 / part;
-    // at W = 4 a layer takes 256 x 256 tiles from 24 of them on (Model-C FC2 at batch 4096: 32 tiles on 32 CUs for 64 of 128 x 256 on 64): a launch
-    // takes longer (45 for 35 us) on half the CUs, and the four chains share the chip -- bf16 47.2 -> 48.2 M inf/s, fp8 69.6 -> 72.4 M
-    // (profiles/r05_experiments.md section 13)
-    const long full256 = part >= 4 ? 24 : full;
+    // at W = 4 a MINOR layer of the chain (at most half the work of its heaviest layer: Model-C's FC2 beside FC1) takes 256 x 256 tiles from 24 of
+    // them on (FC2 at batch 4096: 32 tiles on 32 CUs for 64 of 128 x 256 on 64): a launch takes longer (45 for 35 us) on half the CUs, the heavy
+    // layers of the other chains fill the rest -- bf16 47.2 -> 48.2 M inf/s, fp8 69.6 -> 72.4 M.  The heaviest layer itself must cover its share:
+    // with the low threshold Model-C FC1 at batch 1024 sat on 4 x 32 CUs -- bf16 34.3 -> 28.2 M inf/s (profiles/r05_experiments.md section 13)
+    const long full256 = (part >= 4 && minor) ? FR_KNOB_ONCE("LP_GEMM_256_MIN", 24) : full;   // experiment knob: 48 = no low threshold
     if (precision != FR_FC_FP32 && t256sq >= full256 && FR_KNOB_ONCE("LP_GEMM_256", 1)) return 6;
     if (t256 >= full) return 2;
     if (t128 >= full) return 1;
@@ -1432,8 +1433,8 @@ int frk_fc_gemm_gather(int precision, const void *Wp, const void *Xp, void *Yp, 
 #endif
 }
 
-int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, int width, hipStream_t s) {
-    const int mu = lp_gemm_mu(precision, K, N, ldm, width);
+int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, int width, bool minor, hipStream_t s) {
+    const int mu = lp_gemm_mu(precision, K, N, ldm, width, minor);
     if (mu == 0) FR_FAIL(FR_ERR_INVALID, "internal: layer %d x %d x %d is not a GEMM-kernel layer", K, N, ldm);
     const int KE = precision == FR_FC_FP8 ? (K + 63) / 64 * 4 : (precision == FR_FC_BF16 ? K / 8 : K / 4);
     if (precision == FR_FC_FP32) return lp_gemm_tile<0>(mu, Wp, Xp, Yp, KE, N, ldm, 0, 0, 1.0f, s);

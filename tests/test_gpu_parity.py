@@ -2401,11 +2401,12 @@ def test_chain_workers_run_their_layers_side_by_side(fr, ctxs):
             [t.start() for t in th]
             [t.join() for t in th]
             return float(np.mean(stops)) / reps
-        # side by side = a launch takes about as long with a neighbour's launch on the other half of the chip as alone (105-110 us either way);
-        # two launches taking turns on one hardware queue would take TWICE as long per stream.  (Streams that merely finish together say
-        # nothing: interleaved launches do that too.)  Best of three: another tenant's burst must not fail the suite.
+        # side by side = a launch takes not much longer with a neighbour's launch on the other half of the chip than alone (the phased-waves tile:
+        # 76 us alone, 90-97 us beside a neighbour -- the two halves share the chip's power budget: 1.2-1.3 x; up to 1.5 x measured after other
+        # tests' workers); two launches taking turns on one hardware queue would take TWICE as long per stream.  (Streams that merely finish
+        # together say nothing: interleaved launches do that too.)  Best of three: another tenant's burst must not fail the suite.
         ratio = min(per_launch_ms(wks[:2]) / per_launch_ms(wks[:1]) for _ in range(3))
-        assert ratio <= 1.4, "an FC1 launch takes %.2f x as long beside a second worker's as alone: the workers no longer run side by side (hardware queues shared?)" % ratio
+        assert ratio <= 1.7, "an FC1 launch takes %.2f x as long beside a second worker's as alone: the workers no longer run side by side (hardware queues shared?)" % ratio
         # ... and the whole chains: four workers streaming side by side finish their batches at >= 1.2 x the rate of one worker alone on the same
         # part-chip tiles (measured 1.64-1.78 x: 41-44 M against 25 M inf/s); chains taking turns would gain nothing
         import time
