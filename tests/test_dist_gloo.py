@@ -282,7 +282,8 @@ def test_bench_eight_ranks_rehearsal_on_the_cpu_back_end(tmp_path):
     import time
     detail = str(tmp_path / "detail.json")
     t0 = time.time()
-    rc, out, err = _run_bench(["--gpus", "8", "--device", "-1", "--backend", "gloo", "--rows-cap", "2000", "--steps", "4", "--warmup", "2"], timeout=600, detail=detail)
+    slow_build = "san.so" in os.path.basename(os.environ.get("FR_LIB", ""))   # tools/run_sanitizers.sh: instrumented host code, eight ranks of it on eight cores
+    rc, out, err = _run_bench(["--gpus", "8", "--device", "-1", "--backend", "gloo", "--rows-cap", "2000", "--steps", "4", "--warmup", "2"], timeout=1800 if slow_build else 600, detail=detail)
     wall = time.time() - t0
     assert rc == 0, err[-3000:]
     line = _the_line(out)
@@ -297,7 +298,6 @@ def test_bench_eight_ranks_rehearsal_on_the_cpu_back_end(tmp_path):
         assert j["leg_seconds"][k] > 0, j["leg_seconds"]
     assert abs(sum(j["leg_seconds"].values()) - j["leg_seconds_total"]) < 0.2 and j["leg_seconds_total"] <= wall
     m_ = re.search(r"bench.py: wall time per leg \(s\): .*; total ([0-9.]+) s", err)
-    slow_build = "san.so" in os.path.basename(os.environ.get("FR_LIB", ""))   # tools/run_sanitizers.sh: instrumented host code, no time bound
     assert m_ and (float(m_.group(1)) < 300.0 or slow_build), err[-1500:]
     c3, c4 = j["sharded"]["config"], j["sharded_inflated_fp8"]["config"]
     assert c3["slice_lens"] == [496, 496, 504, 488, 496, 496, 496, 496] and sum(c3["slice_lens"]) == 3968 and c3["items_this_rank"] == [0, 512]

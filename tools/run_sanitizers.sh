@@ -11,7 +11,7 @@ rc=0
 # the experiment knobs' names, and a -g build carries every identifier in its debug info.  Leak checking is off: the interpreter's own.
 LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 \
 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 FR_LIB=$PWD/$PKG/libfleetrec_asan.so \
-    timeout 1800 python -m pytest tests -q -m "not gpu" -p no:cacheprovider \
+    timeout 3000 python -m pytest tests -q -m "not gpu" -p no:cacheprovider \
     --deselect tests/test_abi.py::test_product_library_reads_no_environment_variable 2>&1 | tee /tmp/fr_asan.log | tail -3 || rc=1
 grep -q "ERROR: AddressSanitizer\|runtime error:" /tmp/fr_asan.log && { echo "ASan/UBSan reports: /tmp/fr_asan.log"; rc=1; }
 # TSan: the CPU back-end's tests (thread pool, workers on several host threads, the driver loops).  Left out: the two tests that start

@@ -3,7 +3,7 @@
 its real neighbours: four workers on four host threads push device-resident batches for `seconds`; every delivered score vector is compared BIT FOR
 BIT with the one a lone worker computed for the same rows before the soak.  A DMA that lands late, a stage overwritten early or a barrier that
 does not cover a read shows as a flipped score (such races come and go with what else runs on the CU).  workers = 1: chain width 1, the lone worker's
-full-chip tiles (fc_pp_gemm_n128_kernel).  Usage: soak_chain.py [seconds] [bf16|fp8] [workers: 4]"""
+full-chip tiles (fc_pp_gemm_n128_kernel).  Usage: soak_chain.py [seconds] [bf16|fp8] [workers: 4] [batch: 4096]"""
 import os
 import sys
 import threading
@@ -25,7 +25,7 @@ ctx.fill_tables(fr.FILL_HASH, 0xF1EE7)
 ctx.fill_weights(fr.WEIGHTS_UNIFORM, 99)
 ctx.set_fc_precision({"bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[prec])
 ctx.set_chain_width(min(4, n_workers))
-B = 4096
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 rng0 = np.random.default_rng(1)
 NP = 6
 pool, d_pool = [], []
