@@ -170,3 +170,51 @@ def test_lds_dma_kernels_touch_m0_only_through_the_asm(fr, tmp_path):
             for k in dma:
                 assert k > 0 and re.match(r"s_mov_b32 m0, s\d+$", ins[k - 1]), "%s: LDS-DMA load not directly behind its M0 write: `%s` / `%s`" % (name, ins[k - 1], ins[k])
     assert n_kernels >= 6 and n_loads >= 100, (n_kernels, n_loads)   # the fc_lp_gemm / fc_gemm_pipe instantiations of three precisions
+
+def test_phased_waves_kernels_keep_their_mfmas_between_the_barriers(fr, tmp_path):
+    """fc_pp_gemm_kernel / fc_pp_gemm_n128_kernel split a K sub-step into a fetching and a multiplying phase fenced by s_barrier, with the two
+    waves of a SIMD in opposite phases.  MFMAs are register-only instructions: without the sched_barrier(0) on both sides of every barrier
+    hipcc moved 29 of a phase's 32 MFMAs behind the next barrier (the product build of round 5's first version: bf16 FC1 117 us for 97, scores
+    unchanged -- no parity test can see it).  This test is the guard: in every instantiation of the shipped library the MFMAs sit in whole
+    phases -- between two consecutive barriers there are either none or exactly one phase's worth (32 of 16x16x32 in bf16, 8 of 32x32x64 in
+    fp8), and never a memory instruction among them."""
+    import importlib.util
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    seen = 0
+    for i, co in enumerate(kr.code_objects(fr.LIB_PATH)):
+        f = tmp_path / ("pp%d.o" % i)
+        f.write_bytes(co)
+        asm = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(f)], capture_output=True, text=True).stdout
+        cur, body = None, {}
+        for line in asm.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                cur = m.group(1)
+                body[cur] = []
+            elif cur is not None and line.strip() and not line.lstrip().startswith("//"):
+                body[cur].append(re.sub(r"\s*//.*$", "", line).strip())
+        for name, ins in body.items():
+            if "fc_pp_gemm" not in name or name.endswith(".kd"):
+                continue
+            seen += 1
+            segs, cur_seg = [], []
+            for t in ins:
+                if t.startswith("s_barrier"):
+                    segs.append(cur_seg)
+                    cur_seg = []
+                else:
+                    cur_seg.append(t)
+            segs.append(cur_seg)
+            counts = [sum(1 for t in sg if t.startswith("v_mfma")) for sg in segs]
+            bf16 = any("v_mfma_f32_16x16x32_bf16" in t for t in ins)
+            want = 32 if bf16 else 8
+            assert set(counts) <= {0, want} and want in counts, "%s: MFMAs per barrier-to-barrier segment %s (a phase is %d)" % (name, counts, want)
+            for sg, c in zip(segs, counts):
+                if c:
+                    assert not any(re.match(r"(buffer_load|ds_read|ds_write|global_load|buffer_store|global_store)", t) for t in sg), "%s: memory instructions in the multiplying phase" % name
+    assert seen >= 7, seen   # <1, 3, {0, 2, 8}>, <2, 2, {0, 2, 8}>, the two 128 x 256 forms
