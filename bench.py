@@ -1062,6 +1062,7 @@ def run_sharded(fr, dist_mod, env, dev_id, args, auto_steps_s=0.0):
     s_fc = torch.cuda.ExternalStream(wk_fc.stream_ptr(), device=dev)
     s_x = torch.cuda.Stream(device=dev)            # the exchange (RCCL) stream
     state = {"pending": None, "fc_done": [None, None]}   # pending: buffer set gathered + exchanged, waiting for its FC chain
+    fc_events = [torch.cuda.Event(), torch.cuda.Event()]   # one per buffer set, re-recorded every other step (the host loop is what bounds small steps)
 
     def step(i):
         k = i & 1
@@ -1072,12 +1073,10 @@ def run_sharded(fr, dist_mod, env, dev_id, args, auto_steps_s=0.0):
             p = state["pending"]
             s_fc.wait_stream(s_x)                      # its exchange has landed
             fc(p)                                      # async on the FC worker's stream: overlaps this step's gather + exchange
-            ev = torch.cuda.Event()
-            ev.record(s_fc)
-            state["fc_done"][p] = ev
+            fc_events[p].record(s_fc)
+            state["fc_done"][p] = fc_events[p]
         s_x.wait_stream(s_gather)                      # the slice must be complete before RCCL reads it
-        with torch.cuda.stream(s_x):
-            exchange(k)
+        exchange(k)                                    # on s_x: torch's CURRENT stream for the whole loop (set below; the workers' launches name their own streams)
         state["pending"] = k
 
     def drain():
@@ -1108,6 +1107,8 @@ def run_sharded(fr, dist_mod, env, dev_id, args, auto_steps_s=0.0):
             act, _ = ctx.fp8_exponents()
             ctx.set_fp8_act_exponents(env.min_over_ranks_int(act))
             del cal_l, cal_g
+    prev_stream = torch.cuda.current_stream(dev)
+    torch.cuda.set_stream(s_x)   # the exchange stream is torch's current stream from here to the verification below (no per-step context manager)
     tw = time.perf_counter()
     for i in range(warmup):
         step(i)
@@ -1134,6 +1135,7 @@ def run_sharded(fr, dist_mod, env, dev_id, args, auto_steps_s=0.0):
     wk_fc.sync()
     torch.cuda.synchronize()
     verified = bool(torch.equal(piped, scores))
+    torch.cuda.set_stream(prev_stream)
     vs_unsharded = None
     if r == 0 and not args.no_unsharded_check:
         full = fr.Context(model, device=dev_id)
