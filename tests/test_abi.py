@@ -218,3 +218,20 @@ def test_phased_waves_kernels_keep_their_mfmas_between_the_barriers(fr, tmp_path
                 if c:
                     assert not any(re.match(r"(buffer_load|ds_read|ds_write|global_load|buffer_store|global_store)", t) for t in sg), "%s: memory instructions in the multiplying phase" % name
     assert seen >= 7, seen   # <1, 3, {0, 2, 8}>, <2, 2, {0, 2, 8}>, the two 128 x 256 forms
+
+
+def test_repo_root_holds_only_the_allow_listed_files():
+    """nine `hipcc -save-temps` leftovers sat tracked at the repo root for a round (4.7 MB on every GPU box).  What is
+    tracked at the root is an allow-list; anything else (a compiler temp, a scratch script) fails here before it is committed twice."""
+    if not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("not a git checkout (a gpurun snapshot travels without .git)")
+    try:
+        out = subprocess.check_output(["git", "-C", ROOT, "ls-files"], stderr=subprocess.DEVNULL).decode()
+    except (OSError, subprocess.CalledProcessError):
+        pytest.skip("git not usable here")
+    roots = sorted({p.split("/")[0] for p in out.splitlines() if p})
+    allowed = re.compile(r"^(\.gitignore|\.gpurunignore|ADVICE\.md|BASELINE\.(json|md)|(BENCH|GPUTEST|MULTICHIP|SCALE)_r\d+\.json|DESIGN\.md|INTEGRATION\.md|"
+                         r"PAPERS\.md|README\.md|SNIPPETS\.md|SURVEY\.md|VERDICT\.md|__graft_entry__\.py|bench\.py|pytest\.ini|"
+                         r"gpu-fpga-recommendation-system_amd|include|oracle|profiles|tests|tools)$")
+    stray = [r for r in roots if not allowed.match(r)]
+    assert not stray, "tracked at the repo root but not on the allow-list: %s" % stray
