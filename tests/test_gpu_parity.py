@@ -1,10 +1,12 @@
 """GPU parity tests proper: the HIP path (called through the C-ABI) vs the CPU oracle on the same
 seeded inputs.  Bar: gather records bit-exact; fp32 scores within 1e-3 relative (BASELINE.json).
 
-Tolerance definition for scores (written here as the north star requires):
-    max_b |gpu[b] - ref[b]|  <=  1e-3 * max_b |ref[b]|
-where ref = the oracle's chain with fp64 accumulation and fp32 intermediates.  (Per-element relative
-error is meaningless for scores that cancel to ~0; cuBLASLt's own summation order is unknowable.)
+Two tolerance definitions for fp32 scores, both asserted (north_star: "within 1e-3 relative on fp32 scores"):
+  (1) max-norm   : max_b |gpu[b] - ref[b]|  <=  1e-3 * max_b |ref[b]|                              -- rel_err()
+  (2) per element: |gpu[b] - ref[b]| <= 1e-3 * |ref[b]|  for EVERY item with |ref[b]| >= 1e-3 * max_b |ref[b]|  -- rel_err_each()
+where ref = the oracle's chain with fp64 accumulation and fp32 intermediates.  (2) leaves out only the scores that
+cancel to ~0 against the batch's scale, where a relative error says nothing; cuBLASLt's own summation order is
+unknowable, hence a tolerance at all.  Measured: (1) 3e-7 .. 2e-5, (2) <= 2e-4.  bf16 / fp8 chains carry (1) only.
 """
 import os
 import threading
@@ -21,6 +23,14 @@ NAMES = {0: "A", 1: "B", 2: "C"}
 
 def rel_err(got, ref):
     return float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def rel_err_each(got, ref, floor=1e-3):
+    """Definition (2) above: the largest per-item relative error over the items whose reference score is not a cancellation."""
+    g, r = np.asarray(got, np.float64).ravel(), np.asarray(ref, np.float64).ravel()
+    keep = np.abs(r) >= floor * max(np.abs(r).max(), 1e-30)
+    assert keep.any()
+    return float((np.abs(g[keep] - r[keep]) / np.abs(r[keep])).max())
 
 
 def uniform_idx(rng, rows, B):
@@ -523,6 +533,7 @@ def test_scores_within_tolerance(fr, O, ctxs, which, B):
     e = rel_err(scores, ref)
     assert e <= 1e-3, e
     assert e <= 2e-5, "fp32 MFMA path should be far inside the tolerance (got %g)" % e
+    assert rel_err_each(scores, ref) <= 1e-3, rel_err_each(scores, ref)     # north_star's wording, item by item
     # the pipeline's own feature-major gather (gather_t) is bit-exact too: Xt[k][m] == record[m][k]
     assert np.array_equal(wk.features(B), rec.T)
     # fc_only on oracle records gives the same scores as the fused pipeline (bitwise: same FC kernels)
@@ -2024,6 +2035,8 @@ def test_tiled_gemm_model_c_batch_4096(fr, O, ctxs, prec):
         tol_pair, tol32 = {"f32": (1e-5, 1e-3), "bf16": (1e-2, 3e-2), "fp8": (4e-2, 0.15)}[prec]
         assert rel_err(big[:S], small) <= tol_pair, rel_err(big[:S], small)
         assert rel_err(big, ref32) <= tol32, rel_err(big, ref32)
+        if prec == "f32":
+            assert rel_err_each(big, ref32) <= 1e-3, rel_err_each(big, ref32)    # definition (2): every item of the 4096
         assert np.array_equal(wk.infer(idx, dense), big)   # deterministic
         wk.close()
     finally:
@@ -2749,8 +2762,11 @@ def test_committed_fc_fixtures_on_device(fr, O, ctxs, which):
             assert np.abs(got - ref).max() <= tol * scale, (prec, "submit", np.abs(got - ref).max() / scale)
             if prec == "f32":
                 assert np.abs(got - ref).max() <= 2e-5 * scale      # what the exact-f32 MFMA chain actually reaches
+                assert rel_err_each(got, ref) <= 1e-3, rel_err_each(got, ref)      # definition (2), against the committed float64 numbers
             got = wk.fc_scores(rec.view(np.float32))
             assert np.abs(got - ref).max() <= tol * scale, (prec, "fc_only", np.abs(got - ref).max() / scale)
+            if prec == "f32":
+                assert rel_err_each(got, ref) <= 1e-3
             outs = [fr.DeviceBuffer(ctx, n * 4) for _ in range(3)]
             for o in outs:
                 wk.push_device(n, d_i, d_d, o)
@@ -2758,6 +2774,8 @@ def test_committed_fc_fixtures_on_device(fr, O, ctxs, which):
             for o in outs:
                 got = o.download(np.float32, n)
                 assert np.abs(got - ref).max() <= tol * scale, (prec, "push", np.abs(got - ref).max() / scale)
+                if prec == "f32":
+                    assert rel_err_each(got, ref) <= 1e-3
                 o.free()
             wk.close()
     finally:
