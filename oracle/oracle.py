@@ -4,8 +4,13 @@ TEST INFRASTRUCTURE, NOT PRODUCT: importable only from tests/, __graft_entry__.s
 bench.py's cpu_baseline leg.  The product package never imports this module.
 
 The model structure comes straight from tests/golden/registry_{47,98,377}.json (extracted from the
-reference text by oracle/tools/extract_registry.py) -- deliberately NOT from the product's
-csrc/registry_data.inc, so the product registry is checked against an independent derivation.
+reference's KERNEL text by oracle/tools/extract_registry.py).  The product's csrc/registry_data.inc is
+generated from the SAME JSON (tools/gen_registry.py), so oracle-vs-product agreement checks the two
+formulations (bank memories here, word descriptors there), NOT the extraction.  What checks the
+extraction: SURVEY's prose rules (tests/test_registry.py::test_wire_order_matches_survey_rules) and, for
+the table -> bank map, a second witness taken from the FPGA host programs and the linker's sp= map
+(oracle/tools/extract_host_witness.py -> tests/golden/host_witness_*.json,
+tests/test_registry.py::test_host_side_witness_agrees_with_the_kernel_walk).
 """
 import ctypes
 import json

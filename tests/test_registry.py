@@ -125,6 +125,86 @@ def test_extraction_is_reproducible(tmp_path):
     assert ex.extract_gpu() == json.load(open(os.path.join(GOLD, "registry_gpu.json")))
 
 
+def host_witness_disagreements(reg, wit):
+    """Every way the kernel-text walk (registry_*.json) and the host-side witness (host_witness_*.json) can contradict each other,
+    as a list of strings (empty = they agree)."""
+    bad = []
+    # the three statements of a host buffer's memory bank agree with each other: Ext.flags (0..31 HBM, 32 + d DDR), sp=, the port's name
+    for b in wit["banks"]:
+        cls, k = b["vector_class"], b["vector"]
+        flag_mem = ["HBM", b["flag_index"]] if b["flag_index"] < 32 else ["DDR", b["flag_index"] - 32]
+        if not (flag_mem == b["sp_memory"] == [cls, k] and b["port"] == "table_%s%d" % (cls, k)):
+            bad.append("host buffer %s%d: flags %s, sp %s, port %s" % (cls, k, flag_mem, b["sp_memory"], b["port"]))
+    wbank = {(b["vector_class"], b["vector"]): b for b in wit["banks"]}
+    wtab = {(t["class"], t["id"]): t for t in wit["tables"]}
+    seen = set()
+    for b in reg["banks"]:
+        if b["class"] == "PLRAM":
+            continue                      # on-chip arrays: the host never sees them
+        hb = wbank.get((b["class"], b["bank"]))
+        if hb is None:
+            bad.append("bank %s: no host buffer" % b["name"])
+        elif hb["size_axi_words"] != b["bank_axi_words"]:
+            bad.append("bank %s: %d words in the kernel's constants, %d in the host's" % (b["name"], b["bank_axi_words"], hb["size_axi_words"]))
+        for t in b["tables"]:
+            key = (t["class"], t["id"])
+            seen.add(key)
+            wt = wtab.get(key)
+            if wt is None:
+                bad.append("table %s: the host initialises no such table" % t["name"])
+                continue
+            if (wt["vector_class"], wt["vector"]) != (b["class"], b["bank"]):
+                bad.append("table %s: bank %s by the kernel walk, %s%d by the host" % (t["name"], b["name"], wt["vector_class"], wt["vector"]))
+            for f in ("rows", "axi_words", "addr_axi"):
+                if wt[f] != t[f]:
+                    bad.append("table %s: %s %d by the kernel walk, %d by the host" % (t["name"], f, t[f], wt[f]))
+    for key in sorted(set(wtab) - seen):
+        bad.append("table %s_%d: initialised by the host, absent from the kernel walk" % key)
+    return bad
+
+
+def test_host_side_witness_agrees_with_the_kernel_walk():
+    """a SECOND statement of the table -> bank map, from files the kernel-text walk never opens -- the FPGA host's
+    init_vectors calls, its buffer -> bank flags and setArg order (FPGA/host/embedding_N_krnl/host.cpp:392-760), the host's own
+    constants.hpp, and the linker's sp= map (config_sp_embedding_N_krnl.txt:5-34) -- extracted by oracle/tools/extract_host_witness.py
+    into tests/golden/host_witness_*.json.  Every HBM / DDR table's (class, bank, rows, words per row, start address) and every such
+    bank's size must agree with registry_*.json; and the comparison has teeth: moving one table to another bank, or changing one row
+    count, in a copy of the registry is reported."""
+    import copy
+    for n, covered in ((47, 30), (98, 60), (377, 144)):
+        reg = load(n)
+        wit = json.load(open(os.path.join(GOLD, "host_witness_%d.json" % n)))
+        assert len(wit["tables"]) == covered and len(wit["banks"]) == 30
+        assert host_witness_disagreements(reg, wit) == []
+        # teeth 1: one table's bank edited in the JSON
+        hbm = [i for i, b in enumerate(reg["banks"]) if b["class"] == "HBM"]
+        mut = copy.deepcopy(reg)
+        moved = mut["banks"][hbm[3]]["tables"].pop(0)
+        mut["banks"][hbm[5]]["tables"].append(moved)
+        bad = host_witness_disagreements(mut, wit)
+        assert any(moved["name"] in s and "bank" in s for s in bad), bad
+        # teeth 2: one row count, one start address
+        mut = copy.deepcopy(reg)
+        mut["banks"][hbm[7]]["tables"][0]["rows"] += 1
+        mut["banks"][hbm[9]]["tables"][-1]["addr_axi"] += 2
+        bad = host_witness_disagreements(mut, wit)
+        assert len(bad) == 2 and "rows" in bad[0] and "addr_axi" in bad[1], bad
+    # the reference host's own quirk is kept as data, not papered over: DDR round 1 is initialised with round 0's row count
+    # (embedding_98_krnl/host.cpp:457-458, embedding_377_krnl/host.cpp:547-548)
+    for n in (98, 377):
+        wit = json.load(open(os.path.join(GOLD, "host_witness_%d.json" % n)))
+        assert sorted((t["class"], t["id"]) for t in wit["tables"] if "rows_initialised_with" in t) == [("DDR", 2), ("DDR", 3)]
+
+
+def test_host_witness_extraction_is_reproducible():
+    if not os.path.isdir("/root/reference/FPGA/host"):
+        pytest.skip("the reference tree is not present (GPU box)")
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "tools"))
+    import extract_host_witness as ex
+    for n in (47, 98, 377):
+        assert ex.extract(n) == json.load(open(os.path.join(GOLD, "host_witness_%d.json" % n)))
+
+
 def test_product_registry_matches_extraction(fr, O):
     """Built-in models read through the C-ABI == the oracle-side view derived from the JSON."""
     for which, name in ((fr.MODEL_A, "A"), (fr.MODEL_B, "B"), (fr.MODEL_C, "C")):
