@@ -877,7 +877,13 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
     W_HIP(hipEventCreate(&w->ev_start));
     W_HIP(hipEventCreate(&w->ev_stop));
     w->counted = true;
-    ctx->n_workers.fetch_add(1, std::memory_order_relaxed);
+    const int live = ctx->n_workers.fetch_add(1, std::memory_order_relaxed) + 1;
+    // A width frozen by an early launch is kept (scores in flight must not change), but the caller is told once per worker that outnumbers
+    // it: the call succeeds and fr_last_error() carries the note.
+    const int cw = ctx->chain_width.load(std::memory_order_relaxed);
+    if (cw && cw < 4 && live > cw && ctx->chain_width_auto.load(std::memory_order_relaxed))
+        fr_set_error("note: the context's chain width was frozen at %d by a launch made while %d worker(s) existed; %d workers are live now and share tiles sized for %d "
+                     "side-by-side chains -- call fr_ctx_set_chain_width(ctx, %d) before streaming if that is not intended", cw, cw, live, cw, live > 4 ? 4 : live);
     *out = w;
     return FR_OK;
 }
@@ -980,21 +986,27 @@ static ActSet act_set(const fr_worker *w, int parity) {
     return a;
 }
 
-// The context's chain width: frozen by the first low-precision GEMM-layer launch at min(live workers, 4) unless fr_ctx_set_chain_width
-// decided it before; from then on only that call changes it.
-static int chain_width(fr_ctx *c) {
+// The context's chain width: frozen by the first low-precision GEMM-layer launch of a submit / push path at min(live workers, 4) unless
+// fr_ctx_set_chain_width (or a driver) decided it before; from then on only that call changes it.  Diagnostic single-layer launches
+// (freeze = false) and calibration batches (fp32 stages: they never get here) read the width they would run at and freeze nothing
+// ("create one worker, calibrate or warm up, then create the other three" must not pin W = 1 by accident).
+static int chain_width(fr_ctx *c, bool freeze = true) {
     int w = c->chain_width.load(std::memory_order_relaxed);
     if (w) return w;
     const int live = c->n_workers.load(std::memory_order_relaxed);
     const int want = live < 1 ? 1 : (live > 4 ? 4 : live);
+    if (!freeze) return want;
     int expected = 0;
-    return c->chain_width.compare_exchange_strong(expected, want, std::memory_order_relaxed) ? want : expected;
+    if (!c->chain_width.compare_exchange_strong(expected, want, std::memory_order_relaxed)) return expected;
+    c->chain_width_auto.store(true, std::memory_order_relaxed);
+    return want;
 }
 
 extern "C" int fr_ctx_set_chain_width(fr_ctx *ctx, int width) {
     if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
     if (width < 0 || width > 4) FR_FAIL(FR_ERR_INVALID, "chain width %d outside [0, 4] (0 = undecided again: the next low-precision GEMM-layer launch freezes it)", width);
     ctx->chain_width.store(width, std::memory_order_relaxed);
+    ctx->chain_width_auto.store(false, std::memory_order_relaxed);
     return FR_OK;
 }
 
@@ -1135,7 +1147,7 @@ static int pipeline_step(fr_worker *w) {
             long heaviest = 0;
             for (int l = 0; l < 3; l++) heaviest = std::max(heaviest, (long)fc[l] * fc[l + 1]);
             const bool minor = 2 * (long)st.K * st.N <= heaviest;
-            int rc = frk_fc_lp_gemm(prec, st.w, st.in, st.out, st.K, st.N, ldm, st.e_w, st.e_in, st.e_out, prec == FR_FC_FP32 ? 1 : chain_width(c), minor, w->stream);
+            int rc = frk_fc_lp_gemm(prec, st.w, st.in, st.out, st.K, st.N, ldm, st.e_w, st.e_in, st.e_out, prec == FR_FC_FP32 ? 1 : chain_width(c, !w->diag_launch), minor, w->stream);
             if (rc) return rc;
             if (s == 1 && w->aux && FR_KNOB_ONCE("GATHER_AUX", 0) != 2) {  // X[par ^ 1] may be overwritten by the gather of the NEXT step once this launch has finished
                 FR_HIP(hipEventRecord(w->ev_x_free[par ^ 1], w->stream));
@@ -1594,7 +1606,9 @@ extern "C" int fr_worker_fc_layer_only(fr_worker *w, int batch, int layer) {
     sl.d_dense = nullptr;
     sl.d_scores = w->d_score;
     w->n_active++;
+    w->diag_launch = true;   // a diagnostic launch never freezes the context's chain width
     rc = pipeline_step(w);
+    w->diag_launch = false;
     keep_kernel(w);  // the layer's kernel, as launched (fr_worker_last_kernel)
     if (sl.active) {  // stages 1..3 leave the batch in flight: retire it by hand
         sl.active = false;
@@ -1827,26 +1841,40 @@ static int host_block_launch(fr_worker *w) {
     // Experiments build: FR_HOST_ZEROCOPY 0 = round 4's commands, 1 = no H2D either (the kernel reads the rows over PCIe: slower), 2 = H2D on the worker's stream.
     const int zc = FR_KNOB_ONCE("HOST_ZEROCOPY", 3);
     hipStream_t cs = zc == 3 ? r.copy : w->stream;
-    if (zc != 1) {
-        FR_HIP(hipMemcpyAsync(r.d_idx + s0 * r.idx_slot, r.h_idx + s0 * r.idx_slot, (size_t)n * r.idx_slot * sizeof(int32_t), hipMemcpyHostToDevice, cs));
-        if (r.dense_slot)
-            FR_HIP(hipMemcpyAsync(r.d_dense + s0 * r.dense_slot, r.h_dense + s0 * r.dense_slot, (size_t)n * r.dense_slot * sizeof(float), hipMemcpyHostToDevice, cs));
-        if (zc == 3) {   // (the device block is free: host_slot_prepare delivered its previous use -- its kernel has finished -- before refilling the staging)
-            FR_HIP(hipEventRecord(r.ev_in[b], r.copy));
-            FR_HIP(hipStreamWaitEvent(w->stream, r.ev_in[b], 0));
+    const int pending0 = w->n_pending;
+    auto issue = [&]() -> int {
+        if (zc != 1) {
+            FR_HIP(hipMemcpyAsync(r.d_idx + s0 * r.idx_slot, r.h_idx + s0 * r.idx_slot, (size_t)n * r.idx_slot * sizeof(int32_t), hipMemcpyHostToDevice, cs));
+            if (r.dense_slot)
+                FR_HIP(hipMemcpyAsync(r.d_dense + s0 * r.dense_slot, r.h_dense + s0 * r.dense_slot, (size_t)n * r.dense_slot * sizeof(float), hipMemcpyHostToDevice, cs));
+            if (zc == 3) {   // (the device block is free: host_slot_prepare delivered its previous use -- its kernel has finished -- before refilling the staging)
+                FR_HIP(hipEventRecord(r.ev_in[b], r.copy));
+                FR_HIP(hipStreamWaitEvent(w->stream, r.ev_in[b], 0));
+            }
         }
+        for (int i = 0; i < n; i++) {
+            FrFusedBatch &fb = w->pending[w->n_pending++];
+            fb.idx = (zc == 1 ? r.h_idx : r.d_idx) + (s0 + i) * r.idx_slot;
+            fb.dense = r.dense_slot ? (zc == 1 ? r.h_dense : r.d_dense) + (s0 + i) * r.dense_slot : nullptr;
+            fb.scores = (zc ? r.h_sc : r.d_sc) + (s0 + i) * r.score_slot;
+            fb.batch = r.bsz[b][i];
+        }
+        int rc2 = fused_flush(w);
+        if (rc2) return rc2;
+        if (!zc) FR_HIP(hipMemcpyAsync(r.h_sc + s0 * r.score_slot, r.d_sc + s0 * r.score_slot, (size_t)n * r.score_slot * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+        FR_HIP(hipEventRecord(r.ev[b], w->stream));
+        return FR_OK;
+    };
+    rc = issue();
+    if (rc) {
+        // the block's H2D copy may already be queued while the block is NOT marked in flight -- the caller could refill the
+        // pinned staging of block b under the pending copy.  Drain both streams before handing the error back (the message of the failing
+        // call stays in fr_last_error), and forget the batches that were queued for the launch that did not happen.
+        (void)hipStreamSynchronize(cs);
+        (void)hipStreamSynchronize(w->stream);
+        if (w->n_pending > pending0) w->n_pending = pending0;
+        return rc;
     }
-    for (int i = 0; i < n; i++) {
-        FrFusedBatch &fb = w->pending[w->n_pending++];
-        fb.idx = (zc == 1 ? r.h_idx : r.d_idx) + (s0 + i) * r.idx_slot;
-        fb.dense = r.dense_slot ? (zc == 1 ? r.h_dense : r.d_dense) + (s0 + i) * r.dense_slot : nullptr;
-        fb.scores = (zc ? r.h_sc : r.d_sc) + (s0 + i) * r.score_slot;
-        fb.batch = r.bsz[b][i];
-    }
-    rc = fused_flush(w);
-    if (rc) return rc;
-    if (!zc) FR_HIP(hipMemcpyAsync(r.h_sc + s0 * r.score_slot, r.d_sc + s0 * r.score_slot, (size_t)n * r.score_slot * sizeof(float), hipMemcpyDeviceToHost, w->stream));
-    FR_HIP(hipEventRecord(r.ev[b], w->stream));
     r.inflight[b] = true;
     r.cur = (b + 1) % FR_HOST_BLOCKS;
     return FR_OK;

@@ -33,12 +33,16 @@ class Pool {
         // call builds a pool of its own (the parent's object is leaked there).
         Pool *p = inst_.load(std::memory_order_acquire);
         if (p) return *p;
-        Pool *n = new Pool();
+        Pool *n = new Pool(first_size_.load(std::memory_order_relaxed));
         if (inst_.compare_exchange_strong(p, n, std::memory_order_acq_rel)) return *n;
         n->stop_helpers();   // another thread was first
         delete n;
         return *p;
     }
+    // fr_cpu_set_threads(n) BEFORE the first parallel region: the pool is built with n threads straight away (it used to
+    // start one helper per usable core first and shrink afterwards)
+    static bool exists() { return inst_.load(std::memory_order_acquire) != nullptr; }
+    static void set_first_size(int n) { first_size_.store(n, std::memory_order_relaxed); }
     int size() {
         std::lock_guard<std::mutex> g(run_m_);
         return n_;
@@ -80,12 +84,13 @@ class Pool {
     }
 
   private:
-    Pool() : n_(usable_cpus()) {
+    explicit Pool(int n) : n_(n > 0 ? (n > 1024 ? 1024 : n) : usable_cpus()) {
         static const int once = pthread_atfork(nullptr, nullptr, [] { inst_.store(nullptr, std::memory_order_release); });
         (void)once;
         start_helpers();
     }
     static std::atomic<Pool *> inst_;
+    static std::atomic<int> first_size_;
     static int usable_cpus() {
         int n = (int)std::thread::hardware_concurrency();
         cpu_set_t set;
@@ -139,16 +144,24 @@ class Pool {
     std::vector<std::thread> helpers_;
     const std::function<void(int)> *job_ = nullptr;
     static constexpr int kSpin = 40000;   // ~100-200 us of pause instructions before a thread blocks
+#if defined(__x86_64__)
     static void cpu_relax() { __builtin_ia32_pause(); }
+#else
+    static void cpu_relax() { std::atomic_signal_fence(std::memory_order_seq_cst); }   // portable: a compiler barrier, no pause hint
+#endif
     std::atomic<int> next_{0}, pending_{0};
     int units_ = 0, n_ = 1;
     std::atomic<uint64_t> generation_{0};
     std::atomic<bool> stop_{false};
 };
 std::atomic<Pool *> Pool::inst_{nullptr};
+std::atomic<int> Pool::first_size_{0};
 }  // namespace
 
-int frc_set_threads(int n) { return Pool::get().resize(n); }
+int frc_set_threads(int n) {
+    if (!Pool::exists()) Pool::set_first_size(n);
+    return Pool::get().resize(n);
+}
 int frc_threads() { return Pool::get().size(); }
 
 // ---- memory ------------------------------------------------------------------------------------------------------------------------
@@ -285,21 +298,28 @@ static inline __attribute__((always_inline)) void fc_unit_any(const float *W, in
     }
     for (int b = b0; b < batch; b++) fc_unit<1, FC_HT>(W, H, K, X, ldx, Y, ldy, batch, b, h0);
 }
-__attribute__((target("arch=x86-64-v4"))) void fc_unit_v4(const float *W, int H, int K, const float *X, int ldx, float *Y, int ldy, int batch, int b0, int h0) {
+#if defined(__x86_64__)
+// Per-function ISA clones, each naming EXACTLY the features pick_fc_unit() checks (target("arch=x86-64-v3") also licenses
+// BMI / LZCNT / MOVBE / F16C, which a VM may mask while it shows AVX2 + FMA).
+__attribute__((target("avx512f,avx512vl,avx512bw,avx512dq,avx2,fma"))) void fc_unit_v4(const float *W, int H, int K, const float *X, int ldx, float *Y, int ldy, int batch, int b0, int h0) {
     fc_unit_any<FC_MB>(W, H, K, X, ldx, Y, ldy, batch, b0, h0);
 }
-__attribute__((target("arch=x86-64-v3"))) void fc_unit_v3(const float *W, int H, int K, const float *X, int ldx, float *Y, int ldy, int batch, int b0, int h0) {
+__attribute__((target("avx2,fma"))) void fc_unit_v3(const float *W, int H, int K, const float *X, int ldx, float *Y, int ldy, int batch, int b0, int h0) {
     fc_unit_any<FC_MB>(W, H, K, X, ldx, Y, ldy, batch, b0, h0);
 }
+#endif
 void fc_unit_base(const float *W, int H, int K, const float *X, int ldx, float *Y, int ldy, int batch, int b0, int h0) {   // no FMA unit: fmaf() in software, still one rounding per step
     fc_unit_any<FC_MB>(W, H, K, X, ldx, Y, ldy, batch, b0, h0);
 }
 using FcUnitFn = void (*)(const float *, int, int, const float *, int, float *, int, int, int, int);
 FcUnitFn pick_fc_unit() {
+#if defined(__x86_64__)
     __builtin_cpu_init();
-    if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq")) return fc_unit_v4;
-    if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) return fc_unit_v3;
-    return fc_unit_base;
+    const bool v3 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+    if (v3 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq")) return fc_unit_v4;
+    if (v3) return fc_unit_v3;
+#endif
+    return fc_unit_base;   // any other host: the compiler's baseline (fmaf() keeps one rounding per step everywhere)
 }
 
 void fc_layer(const float *W, int H, int K, const float *X, int ldx, float *Y, int ldy, int batch) {

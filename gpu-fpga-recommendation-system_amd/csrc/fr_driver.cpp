@@ -87,7 +87,7 @@ extern "C" int fr_driver_create(fr_ctx *ctx, int n_threads, int depth, int max_b
     {
         int expected = 0;
         const int w = n_threads * depth > 4 ? 4 : n_threads * depth;
-        (void)ctx->chain_width.compare_exchange_strong(expected, w, std::memory_order_relaxed);
+        if (ctx->chain_width.compare_exchange_strong(expected, w, std::memory_order_relaxed)) ctx->chain_width_auto.store(false, std::memory_order_relaxed);
     }
     *out = d;
     return FR_OK;

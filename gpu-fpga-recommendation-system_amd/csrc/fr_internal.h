@@ -228,6 +228,7 @@ struct fr_ctx {
     // 0 = not decided yet: the first low-precision GEMM-layer launch on the context freezes it at min(live workers, 4); from then on only an
     // explicit fr_ctx_set_chain_width changes it -- never a worker coming or going
     std::atomic<int> chain_width{0};
+    std::atomic<bool> chain_width_auto{false};   // the width was frozen by a launch (not by fr_ctx_set_chain_width / a driver): fr_worker_create leaves a note when workers outnumber it
 };
 
 struct fr_worker {
@@ -270,6 +271,7 @@ struct fr_worker {
     uint64_t launch_no = 0;     // number of pipeline launches issued so far
     int n_active = 0;
     bool counted = false;       // in fr_ctx::n_workers
+    bool diag_launch = false;   // fr_worker_fc_layer_only: a single-layer diagnostic launch reads the chain width it WOULD run at and freezes nothing
     bool calibrating = false;   // fr_worker_calibrate_fp8: the pushed batch runs the fp32 stages without K-split partials
     int last_x_parity = 0;      // which activation set holds Xt of the most recently pushed batch (debug hook)
     // fused item-tile path: batches queued by fr_worker_push_device until a launch group is full

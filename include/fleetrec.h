@@ -243,8 +243,10 @@ int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out);
 /* Chain width W (1..4) of a chain model: its bf16 / fp8 GEMM layers use tiles that cover 1 / W of the chip, so that W workers' chains run
  * side by side on part-chip tiles (fewer operand bytes per output) instead of time-sharing every compute unit: Model-C batch 4096, W = 4:
  * bf16 +16 %, fp8 +10 %; a lone busy worker at W = 4 loses 15-18 % (profiles/r04_C4096_half_chip_tiles_ab.txt).  CONTRACT: the width is
- * decided ONCE per context -- by this call, or else by the context's first low-precision GEMM-layer launch, which freezes it at
- * min(workers alive at that moment, 4) -- and never follows workers coming or going afterwards: scores of a stream in flight cannot
+ * decided ONCE per context -- by this call, or else by the context's first low-precision GEMM-layer launch of a submit / push path, which
+ * freezes it at min(workers alive at that moment, 4) (calibration batches and fleetrec_diag.h's single-layer launches freeze nothing; a
+ * fr_worker_create that makes the workers outnumber a width frozen that way succeeds and leaves a note in fr_last_error()) -- and never
+ * follows workers coming or going afterwards: scores of a stream in flight cannot
  * change because an unrelated worker was created or destroyed.  Call it again only on purpose: it takes effect from the next launch on,
  * and in bf16 the tile shape fixes the summation order (<= 1e-2 relative between widths; fp8 and fp32 scores are bit-identical for every
  * width; width = 0 makes the context undecided again).  fr_ctx_chain_width: the current value, 0 while undecided.  Set W = 1 if a runtime update should ever stop giving the

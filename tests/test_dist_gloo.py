@@ -291,7 +291,10 @@ def test_bench_eight_ranks_rehearsal_on_the_cpu_back_end(tmp_path):
     assert line["gather_per_bank_all_ranks"]["ranks_measured"] == 8 and len(line["configs_all_ranks"]) == 3
     assert all(c["ranks"] == 8 and c["inf_per_s"] > 0 for c in line["configs_all_ranks"].values())
     for k in ("sharded", "sharded_inflated_fp8"):
-        assert line[k]["n_gpus"] == 8 and line[k]["value"] > 0 and line[k]["ok"] is True and line[k]["scaling"] == "strong" and line[k]["exchange"] == "allgather", line[k]
+        assert line[k]["n_gpus"] == 8 and line[k]["value"] > 0 and line[k]["scaling"] == "strong" and line[k]["exchange"] == "allgather", line[k]
+    # "ok" = the leg's own verification.  The rehearsal has no pipelined form: the sharded leg compares rank 0's scores with an unsharded
+    # CPU context's bit for bit (True); the row-inflated leg compares nothing and says so (None, not a constant True: ADVICE r05)
+    assert line["sharded"]["ok"] is True and line["sharded_inflated_fp8"].get("ok") is None, (line["sharded"], line["sharded_inflated_fp8"])
     assert "sharded_error" not in line and "roofline" in line and "cpu_baseline" in line
     j = json.load(open(detail))
     for k in ("headline", "gather_per_bank_all_ranks", "configs_all_ranks", "sharded", "sharded_inflated_fp8"):

@@ -2317,6 +2317,41 @@ def test_part_chip_tiles_follow_the_chain_width_not_the_worker_count(fr, O, ctxs
         ctx.set_fc_precision(fr.FC_FP32)
 
 
+def test_diagnostic_and_calibration_launches_do_not_freeze_the_chain_width(fr, ctxs):
+    """"create one worker, calibrate / probe, then create the other three" must not pin W = 1 by accident.  Calibration batches
+    (fp32 stages) and fleetrec_diag.h's single-layer launches leave the context undecided; the first submit freezes it at the workers alive
+    THEN; and a worker created later that outnumbers a width frozen that way is created all the same, with a note in fr_last_error()."""
+    m, ctx = ctxs(2)
+    rng = np.random.default_rng(5)
+    B = 4096
+    idx, dense = uniform_idx(rng, m.rows(), B), rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+    ctx.set_fc_precision(fr.FC_FP8)
+    ws = []
+    try:
+        ctx.set_chain_width(0)
+        ws.append(fr.Worker(ctx, B))
+        ws[0].calibrate_fp8(idx, dense)
+        assert ctx.chain_width() == 0, "a calibration batch froze the chain width"
+        ws[0].fc_layer_only(B, 0)
+        ws[0].sync()
+        assert ctx.chain_width() == 0, "a diagnostic single-layer launch froze the chain width"
+        ws += [fr.Worker(ctx, B) for _ in range(2)]
+        ws[0].infer(idx, dense)                                  # the first real launch: three workers alive
+        assert ctx.chain_width() == 3
+        ws.append(fr.Worker(ctx, B))                             # outnumbers the launch-frozen width: created, with a note
+        note = fr.lib().fr_last_error().decode()
+        assert note.startswith("note:") and "frozen at 3" in note and "fr_ctx_set_chain_width(ctx, 4)" in note, note
+        assert ctx.chain_width() == 3                            # ... and the width stays what the stream in flight was promised
+        ctx.set_chain_width(4)                                   # decided on purpose: no note any more
+        ws.append(fr.Worker(ctx, B))
+        assert ctx.chain_width() == 4
+    finally:
+        for w in ws:
+            w.close()
+        ctx.set_chain_width(0)
+        ctx.set_fc_precision(fr.FC_FP32)
+
+
 @pytest.mark.parametrize("prec", ["bf16", "fp8"])
 def test_scores_do_not_depend_on_workers_coming_and_going(fr, ctxs, prec):
     """workers are created and destroyed at random (1 .. 6 alive) WHILE another worker streams batches of every size
