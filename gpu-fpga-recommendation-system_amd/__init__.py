@@ -69,7 +69,7 @@ ABI_SYMBOLS = [
     "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_fc_layer_repeat", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
     "fr_device_synchronize", "fr_ctx_shard_info", "fr_driver_create", "fr_driver_destroy", "fr_driver_run_resident",
-    "fr_driver_worker", "fr_driver_score_ring", "fr_driver_run_host", "fr_driver_run_host_streaming", "fr_driver_host_score_ring", "fr_ctx_stream_group", "fr_ctx_set_stream_group", "fr_model_shard_plan", "fr_worker_fc_from_slices", "fr_worker_last_kernel",
+    "fr_driver_worker", "fr_driver_score_ring", "fr_driver_run_host", "fr_driver_run_host_streaming", "fr_driver_host_score_ring", "fr_ctx_stream_group", "fr_ctx_set_stream_group", "fr_model_shard_plan", "fr_worker_fc_from_slices", "fr_worker_last_kernel", "fr_worker_inject_fc_failure",
 ]
 
 
@@ -132,7 +132,7 @@ def lib():
         "fr_driver_host_score_ring": (vp, [vp, i32, i32, ctypes.POINTER(ctypes.c_int)]),
         "fr_model_shard_plan": (i32, [ctypes.POINTER(ModelDesc), i32, pi, pi, ctypes.POINTER(ctypes.c_int)]),
         "fr_worker_fc_from_slices": (i32, [vp, i32, i32, i32, vp, vp]),
-        "fr_worker_last_kernel": (ctypes.c_char_p, [vp]),
+        "fr_worker_last_kernel": (ctypes.c_char_p, [vp]), "fr_worker_inject_fc_failure": (i32, [vp, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -577,6 +577,14 @@ class Worker:
         self.sync()
         return self.score[:B].copy()
 
+    def submit_sharded(self, comm, batch):
+        """fr_worker_submit_sharded on the rows already in self.idx / self.dense (asynchronous; follow with sync())."""
+        _check(lib().fr_worker_submit_sharded(self._h, comm._h, int(batch)))
+
+    def inject_fc_failure(self, steps):
+        """fleetrec_diag.h test hook: this worker's next `steps` sharded steps report a failed FC chain (failure protocol, kind (2))."""
+        _check(lib().fr_worker_inject_fc_failure(self._h, int(steps)))
+
     def calibrate_fp8_sharded(self, comm, idx, dense=None):
         idx = np.asarray(idx, dtype=np.int32).reshape(len(idx), -1)
         B = idx.shape[0]
@@ -735,7 +743,8 @@ class Worker:
 
 
 class Comm:
-    """One rank's RCCL communicator over the shards of a table-sharded model (fr_comm_*)."""
+    """One rank's communicator over the shards of a table-sharded model (fr_comm_*): RCCL for GPU contexts, the in-process host
+    exchange for CPU contexts (init_all only)."""
 
     def __init__(self, handle):
         self._h = handle

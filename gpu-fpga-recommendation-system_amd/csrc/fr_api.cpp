@@ -734,8 +734,9 @@ extern "C" int fr_ctx_set_fc_precision(fr_ctx *ctx, int precision) {
 extern "C" void fr_worker_destroy(fr_worker *w) {
     if (!w) return;
     if (w->ctx && w->ctx->cpu) {
+        fr_comm_worker_release(w);   // a sharded step still on the worker's host stream: waited for (bounded), its communicator let go
         if (w->counted) w->ctx->n_workers.fetch_sub(1, std::memory_order_relaxed);
-        void *host[] = {w->h_idx, w->h_dense, w->h_score, w->d_records, w->c_scratch, w->c_x};
+        void *host[] = {w->h_idx, w->h_dense, w->h_score, w->d_records, w->c_scratch, w->c_x, w->d_slice, w->d_gathered, w->d_score_part, w->d_score_all, w->h_sh_status};
         for (void *p : host) free(p);
         delete w;
         return;
@@ -2097,8 +2098,10 @@ extern "C" int fr_worker_host_pending(const fr_worker *w, int *queued, int *in_f
 
 extern "C" int fr_worker_sync(fr_worker *w) {
     if (!w) FR_FAIL(FR_ERR_INVALID, "worker is NULL");
-    if (w->ctx->cpu) {   // everything was computed inside the calls; only a sticky index-range error is left to report
+    if (w->ctx->cpu) {   // everything was computed inside the calls -- but for a table-sharded step, which runs on the worker's host stream
+        const int crc = fr_comm_wait(w);   // (bounded wait + the ranks' status words, fr_comm.cpp; FR_OK at once when no such step is in flight)
         w->in_flight = false;
+        if (crc) return crc;
         if (__atomic_exchange_n(&w->c_err, 0, __ATOMIC_ACQ_REL)) FR_FAIL(FR_ERR_INDEX_RANGE, "a lookup index was outside its table (row 0 was read instead)");
         return FR_OK;
     }

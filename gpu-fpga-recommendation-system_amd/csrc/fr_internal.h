@@ -309,6 +309,8 @@ struct fr_worker {
     float *h_sh_status = nullptr;  // pinned: [0] this rank's status word as sent, [1 .. G] the status words of all ranks as received
     struct fr_comm *sh_comm = nullptr;  // a sharded step is in flight through this communicator (fr_worker_sync -> fr_comm_wait)
     int sh_ranks = 0;
+    std::atomic<int> sh_inject_fc_fail{0};   // fr_worker_inject_fc_failure (fleetrec_diag.h): sharded steps left whose FC chain is reported as failed
+    void *sh_host_stream = nullptr;  // CPU workers: the host stream their sharded steps run on (fr_comm.cpp HostStream), made on first use
     int *h_err = nullptr;  // sticky index-range flag: pinned host word ...
     int *d_err = nullptr;  // ... and its device-side alias
     bool in_flight = false;
@@ -318,6 +320,7 @@ struct fr_worker {
 
 // ---- table-sharded exchange (fr_comm.cpp) ------------------------------------------------------------
 int fr_comm_wait(fr_worker *w);  // bounded wait for the sharded step in flight + the ranks' status words; FR_OK when none is in flight
+void fr_comm_worker_release(fr_worker *w);  // fr_worker_destroy of a CPU worker: stop its host stream (bounded), then fr_comm_forget
 void fr_comm_forget(fr_worker *w);  // drop the step's hold on its communicator without waiting (fr_worker_sync leaving early)
 
 // ---- CPU back-end (fr_cpu.cpp): device = -1 -----------------------------------------------------------

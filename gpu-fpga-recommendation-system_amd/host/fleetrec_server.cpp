@@ -14,7 +14,8 @@
 //        [--stream [--reply [--flush-us 50] [--flush-min 32]]]: streaming with score replies and adaptive batching -- see thread_consume
 //                        [--tables evenodd|hash] [--weights ones|uniform] [--per-item | --per-bank] [--reply] [--row-cap N]
 //                        [--shards G [--precision f32|bf16|fp8]]
-// --shards G: BASELINE configs[3]/[4] -- the tables are sharded by table-ID over GPUs device .. device + G - 1 of this node (one
+// --shards G: BASELINE configs[3]/[4] -- the tables are sharded by table-ID over GPUs device .. device + G - 1 of this node, or with
+// --device -1 over G CPU shard contexts of this process exchanging through the library's in-process host exchange (one
 // context and one worker per shard, fr_comm_init_all); every batch goes through fr_worker_submit_sharded on all shards (slices
 // all-gathered over RCCL, FC on batch / G items per GPU, scores all-gathered).  The counterpart of the 3-node server, whose batch
 // arrives in three parts from three senders (3-node cuda_server.c:513-591).
@@ -429,7 +430,8 @@ int main(int argc, char **argv) {
         engine.comms.assign(o.shards, nullptr);
         engine.workers.assign(o.shards, nullptr);
         for (int r = 0; r < o.shards; r++) {
-            if (fr_ctx_create_sharded(model, o.device + r, r, o.shards, &engine.ctxs[r]) != FR_OK || fr_ctx_fill_tables(engine.ctxs[r], o.tables, 0xF1EE7) != FR_OK ||
+            // GPUs device .. device + G - 1, or (--device -1) G CPU shard contexts exchanging in process (fr_comm_init_all picks the transport)
+            if (fr_ctx_create_sharded(model, o.device < 0 ? -1 : o.device + r, r, o.shards, &engine.ctxs[r]) != FR_OK || fr_ctx_fill_tables(engine.ctxs[r], o.tables, 0xF1EE7) != FR_OK ||
                 fr_ctx_fill_weights(engine.ctxs[r], o.weights, 99) != FR_OK || fr_ctx_set_fc_precision(engine.ctxs[r], o.precision) != FR_OK ||
                 fr_worker_create(engine.ctxs[r], o.batch, &engine.workers[r]) != FR_OK) {
                 fprintf(stderr, "shard %d set-up failed: %s\n", r, fr_last_error());
@@ -437,7 +439,7 @@ int main(int argc, char **argv) {
             }
         }
         if (fr_comm_init_all(engine.ctxs.data(), o.shards, engine.comms.data()) != FR_OK) {
-            fprintf(stderr, "RCCL set-up failed: %s\n", fr_last_error());
+            fprintf(stderr, "exchange set-up failed: %s\n", fr_last_error());
             return 1;
         }
         engine.idx_bytes = (size_t)o.batch * (size_t)fr_model_index_cols(model) * sizeof(int32_t);
@@ -445,7 +447,8 @@ int main(int argc, char **argv) {
         for (int r = 0; r < o.shards; r++) engine.threads.emplace_back(&ShardedEngine::shard_loop, &engine, r);
         g_engine = &engine;
         ctx = engine.ctxs[0];
-        printf("table-sharded over %d GPUs (RCCL all-gather of the looked-up slices)\n", o.shards);
+        if (o.device < 0) printf("table-sharded over %d CPU shard contexts (in-process host exchange of the looked-up slices)\n", o.shards);
+        else printf("table-sharded over %d GPUs (RCCL all-gather of the looked-up slices)\n", o.shards);
     } else if (fr_ctx_create(model, o.device, &ctx) != FR_OK || fr_ctx_fill_tables(ctx, o.tables, 0xF1EE7) != FR_OK ||
                fr_ctx_fill_weights(ctx, o.weights, 99) != FR_OK || fr_ctx_set_fc_precision(ctx, o.precision) != FR_OK) {
         fprintf(stderr, "set-up failed: %s\n", fr_last_error());

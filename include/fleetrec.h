@@ -52,7 +52,7 @@ typedef enum fr_status {
     FR_ERR_INDEX_RANGE = -5, /* a lookup index was >= the table's row count (reference: silent OOB,
                                 embedding_47_krnl.cpp:927-933) */
     FR_ERR_STATE = -6,       /* call sequence error (e.g. sync without submit, tables not filled) */
-    FR_ERR_COMM = -7         /* RCCL error in the table-sharded mode (fr_comm_*, fr_worker_submit_sharded) */
+    FR_ERR_COMM = -7         /* exchange (RCCL / in-process host exchange) error in the table-sharded mode (fr_comm_*, fr_worker_submit_sharded) */
 } fr_status;
 
 /* Memory class a table lived in on the FPGA card.  Purely descriptive on MI355X (everything is in
@@ -383,7 +383,12 @@ int fr_worker_fc_from_slices_lp(fr_worker *w, int batch_total, int item0, int n_
  * One process per GPU: rank 0 calls fr_comm_unique_id, the host ships the 128 bytes to the other ranks (socket, file, launcher),
  * every rank calls fr_comm_init_rank with its sharded context (rank = shard_rank, size = n_shards; collective).
  * One process driving G GPUs: fr_comm_init_all(ctxs, G, comms) with ctxs[r] = shard r on its own device (ncclCommInitAll); the
- * collective calls below must then come from G different threads. */
+ * collective calls below must then come from G different threads.
+ * CPU contexts (device = -1; round 6): fr_comm_init_all over the G CPU shard contexts of one process sets up the IN-PROCESS HOST EXCHANGE
+ * instead -- the same step, status words, reference counts and bounded wait above another transport (a rendezvous of the ranks' host
+ * streams; librccl.so is not touched).  A CPU worker's step runs on a host stream of its own behind fr_worker_submit_sharded, so one thread
+ * may submit on all G workers and then synchronise them, or G threads may drive one rank each.  fp32 only; fr_comm_init_rank /
+ * fr_comm_unique_id (ranks in different processes) remain RCCL-only. */
 typedef struct fr_comm fr_comm;
 int fr_comm_unique_id(void *id128);
 int fr_comm_init_rank(fr_ctx *ctx, const void *id128, fr_comm **out);
@@ -400,7 +405,9 @@ int fr_comm_set_wait_ms(fr_comm *c, int wait_ms);
  * Failure protocol: argument / state errors are returned before anything is enqueued and leave the communicator usable (the ranks of a job
  * are driven with the same arguments); a rank whose FC chain fails still takes part in both collectives, its score chunk travels as NaN
  * and its status word (one float all-gathered behind every chunk) makes EVERY rank's fr_worker_sync return FR_ERR_COMM naming it; a
- * device / RCCL failure aborts the rank's communicator, and the peers' waits are bounded (fr_comm_set_wait_ms).
+ * device / RCCL failure aborts the rank's communicator, and the peers' waits are bounded (fr_comm_set_wait_ms).  (Host exchange: the step
+ * runs behind the call, so a rank whose FC chain fails learns it from its own fr_worker_sync like its peers; an abort releases every rank
+ * of the in-process group at once.)
  * A call that returns an error AFTER its first collective (the local FC chain failed) has still enqueued the step: the caller must call
  * fr_worker_sync(w) before the worker's next submit (it returns FR_ERR_COMM naming the rank).  fr_comm_destroy between a submit and its
  * fr_worker_sync is safe: the worker keeps the communicator alive until it has synchronised. */

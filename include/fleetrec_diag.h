@@ -63,6 +63,13 @@ float *fr_worker_records_dptr(fr_worker *w);
  * xq[((k/4)*ld + m)*4 + k%4] with ld = round_up(batch, 32).  Lets tests check the pipeline's own gather bit-exactly. */
 float *fr_worker_features_dptr(fr_worker *w, int *ld_max);
 
+/* Failure-injection hook for the table-sharded step's failure protocol (fleetrec.h, kind (2)): the FC chains of this worker's next `steps`
+ * fr_worker_submit_sharded calls are reported as failed (FR_ERR_STATE) AFTER they ran -- the rank still joins both collectives, its score
+ * chunk travels as NaN and its status word makes every rank's fr_worker_sync return FR_ERR_COMM naming it.  steps = 0 disarms.  A test hook:
+ * it lets the cross-rank protocol be exercised on one rank of G, in process, in the product build (tests/test_cpu_backend.py, also under
+ * ThreadSanitizer); nothing else reads the counter. */
+int fr_worker_inject_fc_failure(fr_worker *w, int steps);
+
 /* HIP-event timing on the worker's stream (the stream the kernels are launched on). */
 int fr_worker_timer_start(fr_worker *w);
 int fr_worker_timer_stop_ms(fr_worker *w, float *ms); /* records stop, synchronises, returns elapsed */

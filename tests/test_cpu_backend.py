@@ -394,3 +394,213 @@ def test_a_forked_child_gets_a_thread_pool_of_its_own(fr):
     fr.cpu_set_threads(0)
     wk.close()
     ctx.close()
+
+
+# ---- the table-sharded step behind the C-ABI with G > 1 ranks: fr_comm_init_all over G CPU shard contexts = the in-process host exchange
+#      (csrc/fr_comm.cpp: the SAME step / status words / reference counts / bounded wait as over RCCL, another transport below them).
+#      Counterpart of the 3-node server taking every batch from three senders (3-node cuda_server.c:513-591). ---------------------------------
+def _sharded_job(fr, G, max_batch, max_rows=2000):
+    m = fr.Model.builtin(fr.MODEL_C).clone(max_rows=max_rows)
+    ctxs, wks = [], []
+    for r in range(G):
+        c = fr.Context(m, device=CPU, shard_rank=r, n_shards=G)
+        c.fill_tables(fr.FILL_HASH, SEED_TABLES)
+        c.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+        ctxs.append(c)
+        wks.append(fr.Worker(c, max_batch))
+    whole = fr.Context(m, device=CPU)
+    whole.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    whole.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    return m, ctxs, wks, fr.Comm.init_all(ctxs), whole, fr.Worker(whole, max_batch)
+
+
+def _close_job(ctxs, wks, comms, whole, w0):
+    for w in wks:
+        w.close()
+    for cm in comms:
+        cm.close()
+    for c in ctxs:
+        c.close()
+    w0.close()
+    whole.close()
+
+
+def _load_request(wks, idx, dense):
+    for w in wks:                       # every rank holds the whole request batch (as for fr_worker_submit)
+        w.idx[:len(idx)] = idx
+        w.dense[:len(idx)] = dense
+
+
+def _sync_status(fr, w):
+    try:
+        w.sync()
+        return fr.FR_OK, ""
+    except fr.FleetRecError as e:
+        return e.status, str(e)
+
+
+@pytest.mark.parametrize("G,batches", [(2, (301, 64, 1)), (3, (301, 2, 300)), (8, (301, 5, 512))])
+def test_sharded_step_with_several_ranks_through_the_host_exchange(fr, G, batches):
+    """VERDICT r05 item 1.  G = 2, 3 (uneven: B = 301), 8 ranks on row-capped Model-C: after fr_worker_sync EVERY rank's score buffer holds
+    all B scores, bit-identical to an unsharded CPU context's -- for batches that do not divide by G, for batches smaller than G (ranks with
+    no items of their own still join both collectives), driven by G host threads (the server's shape) and by ONE thread that submits on
+    all ranks and then synchronises them (a CPU worker's step runs on its own host stream behind the call)."""
+    import threading
+    B_max = max(batches)
+    m, ctxs, wks, comms, whole, w0 = _sharded_job(fr, G, B_max)
+    rng = np.random.default_rng(100 + G)
+    try:
+        for step, B in enumerate(batches):
+            idx = uniform_idx(rng, m.rows(), B)
+            dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+            ref = w0.infer(idx, dense)
+            _load_request(wks, idx, dense)
+            got = [None] * G
+            if step % 2 == 0:           # G threads, one per rank: submit + sync each
+                def rank(r):
+                    wks[r].submit_sharded(comms[r], B)
+                    wks[r].sync()
+                    got[r] = wks[r].score[:B].copy()
+                ts = [threading.Thread(target=rank, args=(r,)) for r in range(G)]
+                for t in ts:
+                    t.start()
+                for t in ts:
+                    t.join(120)
+                assert not any(t.is_alive() for t in ts)
+            else:                       # one thread: all submits, then all syncs (in reverse rank order for good measure)
+                for r in range(G):
+                    wks[r].submit_sharded(comms[r], B)
+                for r in reversed(range(G)):
+                    wks[r].sync()
+                    got[r] = wks[r].score[:B].copy()
+            for r in range(G):
+                assert got[r] is not None and np.array_equal(got[r], ref), (G, B, r)
+    finally:
+        _close_job(ctxs, wks, comms, whole, w0)
+
+
+def test_sharded_step_failure_protocol_across_ranks(fr):
+    """The three kinds of failure of a collective step (csrc/fr_comm.cpp), each with more than one rank for the first time:
+    (1) an argument error is returned before anything is enqueued and leaves the communicator usable;
+    (2) a failed FC chain on rank q (fleetrec_diag.h's injection hook) -> EVERY rank's fr_worker_sync returns FR_ERR_COMM naming q, q's
+        items are NaN on every rank, the others' scores are right, and the next step works again;
+    (3) a rank that never arrives trips the bounded wait of the ranks that did (fr_comm_set_wait_ms), the communicator is aborted, every
+        later call on any rank of the group answers FR_ERR_COMM."""
+    import importlib
+    dist_mod = importlib.import_module("fleetrec_amd.dist")
+    G, B, q = 3, 301, 1
+    m, ctxs, wks, comms, whole, w0 = _sharded_job(fr, G, 400)
+    rng = np.random.default_rng(9)
+    idx = uniform_idx(rng, m.rows(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+    ref = w0.infer(idx, dense)
+    try:
+        _load_request(wks, idx, dense)
+        # (1)
+        with pytest.raises(fr.FleetRecError) as e:
+            wks[0].submit_sharded(comms[0], 401)
+        assert e.value.status == fr.FR_ERR_INVALID
+        with pytest.raises(fr.FleetRecError) as e:
+            wks[0].submit_sharded(comms[1], B)                  # another rank's communicator
+        assert e.value.status == fr.FR_ERR_INVALID
+        # (2)
+        wks[q].inject_fc_failure(1)
+        for r in range(G):
+            wks[r].submit_sharded(comms[r], B)
+        lo, hi = dist_mod.item_range(q, G, B)
+        for r in range(G):
+            st, text = _sync_status(fr, wks[r])
+            assert st == fr.FR_ERR_COMM and "shard rank %d reported a failed FC chain" % q in text, (r, st, text)
+            sc = wks[r].score[:B]
+            assert np.isnan(sc[lo:hi]).all() and np.array_equal(sc[:lo], ref[:lo]) and np.array_equal(sc[hi:], ref[hi:]), r
+        for r in range(G):                                      # the communicator survived: the same request again, nobody fails
+            wks[r].submit_sharded(comms[r], B)
+        for r in range(G):
+            wks[r].sync()
+            assert np.array_equal(wks[r].score[:B], ref), r
+        # (3): rank 2 never submits
+        for cm in comms:
+            cm.set_wait_ms(300)
+        t0 = time.time()
+        for r in (0, 1):
+            wks[r].submit_sharded(comms[r], B)
+        for r in (0, 1):
+            st, text = _sync_status(fr, wks[r])
+            assert st == fr.FR_ERR_COMM and ("did not complete within 300 ms" in text or "aborted" in text), (r, st, text)
+        assert time.time() - t0 < 20
+        for r in range(G):                                      # aborted for good, on every rank of the in-process group
+            with pytest.raises(fr.FleetRecError) as e:
+                wks[r].submit_sharded(comms[r], B)
+            assert e.value.status == fr.FR_ERR_COMM
+        st, _ = _sync_status(fr, wks[2])                        # nothing in flight there
+        assert st == fr.FR_OK
+    finally:
+        _close_job(ctxs, wks, comms, whole, w0)
+
+
+def test_sharded_step_outlives_its_communicator_handle_and_its_worker(fr):
+    """Reference counts of a communicator: fr_comm_destroy between the submits and the syncs only drops the handles -- the
+    step in flight keeps the communicator (and the group all G handles share) alive until its worker has synchronised, and the scores are
+    right.  And a worker destroyed with a step still parked in a rendezvous (its peer never came) does not hang: the destroy waits for the
+    communicator's bound, aborts the exchange and joins the host stream."""
+    G, B = 2, 77
+    m, ctxs, wks, comms, whole, w0 = _sharded_job(fr, G, 128)
+    rng = np.random.default_rng(4)
+    idx = uniform_idx(rng, m.rows(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+    ref = w0.infer(idx, dense)
+    try:
+        _load_request(wks, idx, dense)
+        for r in range(G):
+            wks[r].submit_sharded(comms[r], B)
+        for cm in comms:
+            cm.close()                                          # destroy in flight
+        for r in range(G):
+            wks[r].sync()
+            assert np.array_equal(wks[r].score[:B], ref), r
+        # a second job on the same contexts: rank 1 never arrives, rank 0's worker is destroyed with its step in flight
+        comms2 = fr.Comm.init_all(ctxs)
+        comms2[0].set_wait_ms(200)
+        wks[0].submit_sharded(comms2[0], B)
+        t0 = time.time()
+        wks[0].close()
+        assert time.time() - t0 < 20
+        with pytest.raises(fr.FleetRecError) as e:              # the group was aborted by that destroy
+            wks[1].submit_sharded(comms2[1], B)
+        assert e.value.status == fr.FR_ERR_COMM
+        for cm in comms2:
+            cm.close()
+    finally:
+        _close_job(ctxs, wks, comms, whole, w0)
+
+
+def test_server_shards_model_c_over_cpu_shard_contexts(fr):
+    """The end-to-end form of the G > 1 step: `fleetrec_server --shards 3 --device -1` -- the 3-node server's shape
+    (three parts per batch, 3-node cuda_server.c:513-591) with three CPU shard contexts exchanging in process -- fed by fleetrec_sender over
+    TCP with the reference's data (even/odd tables, the 32 fixed indices, all-ones weights): the first five scores of every thread's last
+    batch are 0 0 K*H1*H2*H3 K*H1*H2*H3 0."""
+    if not os.path.exists(os.path.join(HOST, "fleetrec_server")):
+        subprocess.check_call(["make", "-s", "-C", HOST])
+    threads, total, batch = 2, 12, 100            # 100 items over 3 ranks: 34 + 33 + 33
+    port = free_port_block(threads)
+    srv = subprocess.Popen([os.path.join(HOST, "fleetrec_server"), "--model", "C", "--batch", str(batch), "--threads", str(threads), "--port", str(port),
+                            "--total", str(total), "--tables", "evenodd", "--weights", "ones", "--row-cap", "200", "--shards", "3", "--device", "-1"],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    time.sleep(0.5)
+    snd = subprocess.Popen([os.path.join(HOST, "fleetrec_sender"), "--model", "C", "--batch", str(batch), "--threads", str(threads), "--port", str(port),
+                            "--indices", "reference", "--row-cap", "200"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    try:
+        out, _ = srv.communicate(timeout=300)
+        snd.communicate(timeout=60)
+    finally:
+        for p in (srv, snd):
+            if p.poll() is None:
+                p.kill()
+    out = out.decode()
+    assert srv.returncode == 0, out
+    assert "table-sharded over 3 CPU shard contexts" in out and "processed %d batches" % total in out, out
+    rows = re.findall(r"thread \d+ scores:((?: [-0-9.e+]+)+)", out)
+    assert rows, out
+    val = 3968.0 * 2 ** 28
+    for r in rows:
+        assert [float(x) for x in r.split()] == [0.0, 0.0, val, val, 0.0], (r, out)
