@@ -69,7 +69,7 @@ ABI_SYMBOLS = [
     "fr_worker_gather_only", "fr_worker_fc_only", "fr_worker_fc_layer_only", "fr_worker_fc_layer_repeat", "fr_worker_records_dptr", "fr_worker_features_dptr", "fr_worker_timer_start",
     "fr_worker_timer_stop_ms", "fr_device_malloc", "fr_device_free", "fr_memcpy_h2d", "fr_memcpy_d2h",
     "fr_device_synchronize", "fr_ctx_shard_info", "fr_driver_create", "fr_driver_destroy", "fr_driver_run_resident",
-    "fr_driver_worker", "fr_driver_score_ring", "fr_driver_run_host", "fr_driver_run_host_streaming", "fr_driver_host_score_ring", "fr_ctx_stream_group", "fr_ctx_set_stream_group", "fr_model_shard_plan", "fr_worker_fc_from_slices", "fr_worker_last_kernel", "fr_worker_inject_fc_failure",
+    "fr_driver_worker", "fr_driver_score_ring", "fr_driver_run_host", "fr_driver_run_host_streaming", "fr_driver_host_score_ring", "fr_ctx_stream_group", "fr_ctx_set_stream_group", "fr_model_shard_plan", "fr_worker_fc_from_slices", "fr_worker_last_kernel", "fr_worker_inject_fc_failure", "fr_ctx_set_lp_bank_image", "fr_ctx_lp_bank_image_bytes",
 ]
 
 
@@ -133,6 +133,7 @@ def lib():
         "fr_model_shard_plan": (i32, [ctypes.POINTER(ModelDesc), i32, pi, pi, ctypes.POINTER(ctypes.c_int)]),
         "fr_worker_fc_from_slices": (i32, [vp, i32, i32, i32, vp, vp]),
         "fr_worker_last_kernel": (ctypes.c_char_p, [vp]), "fr_worker_inject_fc_failure": (i32, [vp, i32]),
+        "fr_ctx_set_lp_bank_image": (i32, [vp, i32]), "fr_ctx_lp_bank_image_bytes": (ctypes.c_size_t, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -474,6 +475,13 @@ class Context:
 
     def set_stream_group(self, batches_per_launch):
         _check(lib().fr_ctx_set_stream_group(self._h, batches_per_launch))
+
+    def set_lp_bank_image(self, on):
+        """fleetrec_diag.h: 0 = the in-chain gather of a per-bank bf16 / fp8 context reads the fp32 rows (A/B and parity hook)."""
+        _check(lib().fr_ctx_set_lp_bank_image(self._h, int(bool(on))))
+
+    def lp_bank_image_bytes(self):
+        return int(lib().fr_ctx_lp_bank_image_bytes(self._h))
 
     def set_chain_width(self, width):
         """Chain width W (1..4): a chain model's bf16 / fp8 GEMM layers take tiles covering 1 / W of the chip (fr_ctx_set_chain_width)."""

@@ -93,6 +93,8 @@ static void ctx_free(fr_ctx *c) {
     }
     if (c->device >= 0) (void)hipSetDevice(c->device);
     if (c->table_arena) (void)hipFree(c->table_arena);
+    if (c->lp_arena) (void)hipFree(c->lp_arena);
+    if (c->d_words_lp) (void)hipFree(c->d_words_lp);
     if (c->d_words) (void)hipFree(c->d_words);
     if (c->d_passes) (void)hipFree(c->d_passes);
     if (c->d_chunks) (void)hipFree(c->d_chunks);
@@ -306,10 +308,14 @@ static int build_words(fr_ctx *c) {
         src_len[g.source] += g.len;
     }
     c->h_words.clear();
+    c->h_word_table.clear();
+    c->h_word_col.clear();
     for (int s = s0; s < s1; s++) {
         const fr_segment &g = m.segments[s];
         for (int j = 0; j < g.len / 4; j++) {
             FrWordDesc w{};
+            c->h_word_table.push_back(g.kind == FR_SEG_DENSE ? -1 : g.src);
+            c->h_word_col.push_back(g.src_col + 4 * j);
             if (g.kind == FR_SEG_DENSE) {
                 w.src = (uint64_t)(g.src_col + 4 * j) * 4;
                 w.stride = (uint32_t)m.dense_len * 4;
@@ -526,6 +532,7 @@ extern "C" int fr_ctx_fill_tables(fr_ctx *ctx, int mode, uint32_t seed) {
     }
     if (!ctx->cpu) FR_HIP(hipStreamSynchronize(ctx->setup_stream));
     ctx->tables_filled = true;
+    ctx->tables_gen++;   // an operand-type bank image made from older contents is stale (lp_ensure_image)
     return FR_OK;
 }
 
@@ -578,6 +585,7 @@ extern "C" int fr_ctx_upload_table(fr_ctx *ctx, int table, int64_t row0, int64_t
     int rc = table_copy(ctx, table, row0, nrows, const_cast<float *>(host_rows), true);
     if (rc) return rc;
     ctx->tables_filled = true;
+    ctx->tables_gen++;   // an operand-type bank image made from older contents is stale (lp_ensure_image)
     return FR_OK;
 }
 
@@ -1013,6 +1021,98 @@ extern "C" int fr_ctx_set_chain_width(fr_ctx *ctx, int width) {
 
 extern "C" int fr_ctx_chain_width(const fr_ctx *ctx) { return ctx ? ctx->chain_width.load(std::memory_order_relaxed) : FR_ERR_INVALID; }
 
+// ---- operand-type bank image (fr_internal.h, fr_ctx::lp_arena) ------------------------------------------------------------------------
+// Which contexts have one: FR_INDEX_PER_BANK, unsharded or sharded, SEMANTIC layout, bf16 / fp8 chain.  (Per-table contexts gain nothing: a
+// row is one 128-byte line whatever its element type -- the gather is bound by the fabric's REQUEST rate)
+static bool lp_image_applies(const fr_ctx *c, int prec) {
+    return !c->cpu && c->model.index_mode == FR_INDEX_PER_BANK && (prec == FR_FC_BF16 || prec == FR_FC_FP8) && c->n_words > 0 &&
+           c->lp_image_on.load(std::memory_order_relaxed) != 0;
+}
+
+extern "C" int fr_ctx_set_lp_bank_image(fr_ctx *ctx, int on) {
+    if (!ctx) FR_FAIL(FR_ERR_INVALID, "ctx is NULL");
+    ctx->lp_image_on.store(on ? 1 : 0, std::memory_order_relaxed);
+    return FR_OK;
+}
+extern "C" size_t fr_ctx_lp_bank_image_bytes(const fr_ctx *ctx) { return (ctx && ctx->lp_prec) ? ctx->lp_arena_bytes : 0; }
+
+// Make the image current for (prec, X exponent, table contents).  Called by the launch path right before a gather that reads it; the
+// rebuild runs on the context's set-up stream and is waited for (tens of milliseconds for Model-C, once per change of precision /
+// calibration / table contents -- set-up calls, which by contract do not run beside a stream in flight).
+static int lp_ensure_image(fr_ctx *c, int prec) {
+    const int e_x = prec == FR_FC_FP8 ? c->f8_e_act[0] : 0;
+    std::lock_guard<std::mutex> lk(c->lp_mutex);
+    if (c->lp_prec == prec && c->lp_e_x == e_x && c->lp_tables_gen == c->tables_gen && c->d_words_lp) return FR_OK;
+    const fr_model_desc &m = c->model;
+    const size_t esz = prec == FR_FC_BF16 ? 2 : 1;
+    struct Bank { std::vector<int> members; size_t payload_floats = 0, lp_off = 0, lp_stride = 0; uint64_t rows = 0; };
+    std::vector<Bank> banks(c->n_banks);
+    for (int t = 0; t < m.n_tables; t++)
+        if (c->table_mem[t].resident) {
+            Bank &b = banks[c->bank_of_table[t]];
+            b.members.push_back(t);
+            b.payload_floats += (size_t)m.tables[t].dim;
+        }
+    auto lines_x128 = [](size_t stride, size_t bytes) {  // expected 128-byte lines per row, x128 (exact over one period) -- as for the fp32 bank rows
+        size_t acc = 0;
+        for (size_t r = 0; r < 128; r++) acc += ((r * stride) % 128 + bytes + 127) / 128;
+        return acc;
+    };
+    size_t off = 0;
+    for (int bi = 0; bi < c->n_banks; bi++) {
+        Bank &b = banks[bi];
+        if (b.members.empty()) continue;
+        const size_t payload = b.payload_floats * esz;
+        size_t best = align_up(payload, 8);
+        for (size_t cand : {align_up(payload, 16), align_up(payload, 32), align_up(payload, 64), align_up(payload, 128)})
+            if (lines_x128(cand, payload) < lines_x128(best, payload)) best = cand;
+        b.lp_stride = best;
+        b.rows = (uint64_t)c->bank_rows[bi];
+        b.lp_off = align_up(off, 256);
+        off = b.lp_off + (size_t)b.rows * best;
+    }
+    off = align_up(off, 256);
+    FR_SET_DEVICE(c);
+    if (off != c->lp_arena_bytes) {
+        if (c->lp_arena) (void)hipFree(c->lp_arena);
+        c->lp_arena = nullptr;
+        c->lp_arena_bytes = 0;
+        c->lp_prec = 0;
+        if (hipMalloc((void **)&c->lp_arena, off) != hipSuccess) {
+            (void)hipGetLastError();
+            FR_FAIL(FR_ERR_OOM, "operand-type bank image: hipMalloc(%zu bytes) failed", off);
+        }
+        c->lp_arena_bytes = off;
+    }
+    std::vector<size_t> lp_base(m.n_tables, 0);   // offset of (row 0, column 0) of every resident table inside lp_arena
+    for (Bank &b : banks) {
+        size_t col = 0;
+        for (int t : b.members) {
+            const FrTableMem &tm = c->table_mem[t];
+            lp_base[t] = b.lp_off + col * esz;
+            // a table's reachable rows: the bank-interleaved region (il_rows = the bank's rows), or a lone table's own rows
+            int rc = frk_convert_rows_lp(prec, c->table_arena + tm.byte_offset, (size_t)tm.row_stride, c->lp_arena + lp_base[t], b.lp_stride, (int64_t)b.rows, m.tables[t].dim, e_x,
+                                         c->setup_stream);
+            if (rc) return rc;
+            col += (size_t)m.tables[t].dim;
+        }
+    }
+    std::vector<FrWordDesc> lw(c->h_words);
+    for (int i = 0; i < c->n_words; i++) {
+        const int t = c->h_word_table[i];
+        if (t < 0) continue;   // dense words come from the request, in fp32
+        lw[i].src = (uint64_t)(uintptr_t)(c->lp_arena + lp_base[t]) + (uint64_t)c->h_word_col[i] * esz;
+        lw[i].stride = (uint32_t)banks[c->bank_of_table[t]].lp_stride;
+    }
+    if (!c->d_words_lp) FR_HIP(hipMalloc((void **)&c->d_words_lp, sizeof(FrWordDesc) * c->n_words));
+    FR_HIP(hipMemcpyAsync(c->d_words_lp, lw.data(), sizeof(FrWordDesc) * c->n_words, hipMemcpyHostToDevice, c->setup_stream));
+    FR_HIP(hipStreamSynchronize(c->setup_stream));
+    c->lp_prec = prec;
+    c->lp_e_x = e_x;
+    c->lp_tables_gen = c->tables_gen;
+    return FR_OK;
+}
+
 // Issue ONE pipeline launch: every in-flight batch advances by one stage; `fresh` (may be NULL) enters at stage 0.
 // only_stage >= 0: debugging/roofline -- run just that stage of the (single) in-flight batch as its own kernel.
 static int pipeline_step(fr_worker *w) {
@@ -1083,6 +1183,12 @@ static int pipeline_step(fr_worker *w) {
                 const int trb = frk_gather_tr_blocks(c->n_words, ldm, trv);
                 if (trb > 0) {  // large batch: LDS-transposing gather
                     st.variant = trv;
+                    if (trv == 2 && lp_image_applies(c, prec)) {   // ... of bank rows that are already in the chain's operand type
+                        const int irc = lp_ensure_image(c, prec);
+                        if (irc) return irc;
+                        a.words = c->d_words_lp;
+                        a.src_lp = 1;
+                    }
                     blocks += (trb + 7) / 8 * 8;
                     n_stages++;
                     only = s;

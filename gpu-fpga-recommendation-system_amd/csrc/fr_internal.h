@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -119,6 +120,7 @@ struct FrPipeArgs {
     int n_blocks;
     // gather stage
     const struct FrWordDesc *words;
+    int src_lp;   // 1: `words` address the operand-type bank image (rows already bf16 / e4m3: 8 / 4 bytes per record word); dense words stay fp32
     int n_words;
     int idx_stride;
     const int32_t *idx;
@@ -147,6 +149,7 @@ struct FrFusedArgs {
     int n_batches;
     int tiles_per_batch;  // max over the batches of ceil(batch / 32)
     const struct FrWordDesc *words;
+    int src_lp;   // 1: `words` address the operand-type bank image (rows already bf16 / e4m3: 8 / 4 bytes per record word); dense words stay fp32
     int n_words;
     int idx_stride;
     int *err_flag;
@@ -194,6 +197,20 @@ struct fr_ctx {
     FrPassDesc *d_passes = nullptr;
     FrChunkDesc *d_chunks = nullptr;
     int n_chunks = 0;
+    // Operand-type bank image (round 6; FR_INDEX_PER_BANK contexts, bf16 / fp8 chains): the reachable rows [0, bank_rows[b]) of every bank
+    // once more, already in the chain's operand type -- bf16, or e4m3 at the X exponent -- so that the in-chain gather of a large batch
+    // fetches 82 lines per Model-C item instead of 142 and converts nothing.  Made from the fp32 arena by the SAME rounding functions the
+    // gather applies (RNE at fill = RNE at gather: bit-identical scores); rebuilt lazily (lp_ensure_image) when the precision, the X exponent
+    // or the table contents have changed.  The fp32 arena stays the master (gather_only, fp32 chain, calibration, upload / download).
+    std::vector<int> h_word_table, h_word_col;   // per h_words entry: source table (-1: dense) and the float column inside its row
+    char *lp_arena = nullptr;
+    size_t lp_arena_bytes = 0;
+    FrWordDesc *d_words_lp = nullptr;      // h_words with src / stride pointing into lp_arena (dense words unchanged)
+    int lp_prec = 0, lp_e_x = 0;           // what the image holds (FR_FC_BF16 / FR_FC_FP8 and, for fp8, the X exponent); 0 = nothing
+    uint64_t lp_tables_gen = 0;            // tables_gen the image was made from
+    uint64_t tables_gen = 1;               // bumped by every fill / upload
+    std::mutex lp_mutex;
+    std::atomic<int> lp_image_on{1};       // fr_ctx_set_lp_bank_image (fleetrec_diag.h): 0 = the in-chain gather reads the fp32 rows and converts them itself
     unsigned long long *d_merged = nullptr;  // lookups merged by the dedup gather (FR_GATHER_ITEM_TILE_DEDUP_COUNT)
     std::atomic<int> gather_variant{0};    // fr_gather_variant (fr_ctx_set_gather_variant)
     // FC weights: fp32 master copies in the reference's column-major H x K layout
@@ -348,6 +365,9 @@ static inline uint32_t fr_table_uid(const fr_table_desc &t) {
 }
 int frk_fill_table(float *base, int64_t row0, int64_t rows, int dim, int64_t row_stride_bytes, int mode, uint32_t seed, uint32_t uid, hipStream_t s);
 int frk_fill_weights(float *w, size_t count, int mode, uint32_t seed, uint32_t layer, float scale, hipStream_t s);
+// rows [0, rows) of an fp32 region (row r at src + r * src_stride, `floats` floats wide) -> the same rows in the operand type of `precision`
+// (bf16: RNE; fp8: x 2^e_x, saturated, e4m3) at dst + r * dst_stride: the rounding of the gather kernels themselves (fr_device.h)
+int frk_convert_rows_lp(int precision, const void *src, size_t src_stride, void *dst, size_t dst_stride, int64_t rows, int floats, int e_x, hipStream_t s);
 int frk_gather(const FrWordDesc *words, int n_words, const FrGatherGroups &groups, const int32_t *idx, int idx_stride, const float *dense, void *out, int batch, int *err_flag,
                int transport, int e_x, hipStream_t s, int out_words, bool one_chunk = false);
 int frk_gather_tile(const FrPassDesc *passes, const FrChunkDesc *chunks, int n_chunks, const int32_t *idx, int idx_stride, const float *dense, void *out,

@@ -278,6 +278,114 @@ __device__ __forceinline__ void gather_tr_stream_body(const FrPipeArgs &a, const
     if (bad) atomicOr_system(a.err_flag, 1);
 }
 
+// The same gather over the OPERAND-TYPE BANK IMAGE (a.src_lp; round 6): the table words a.words address are already in the chain's operand
+// type -- 8 bytes (4 bf16) or 4 bytes (4 e4m3) per record word -- so a Model-C item costs 82 lines of the fabric instead of 142, the LDS
+// tile is a half / a quarter of the size and phase 2 converts nothing: one ds_read_b128 IS one image element.  Dense words (the request's
+// fp32 features) are converted by the lane that loads them, with the rounding the image was made with (pack_bf16x2 / pack_fp8_word), so the
+// image written here is bit-identical to gather_tr_stream_body's.  Tile element = one record word (uint2 / uint32); element (item, word)
+// sits at item * 64 + (((word / EW) ^ (item & SW)) * EW + word % EW), EW = words per image element (2 / 4): the words of an image element
+// stay adjacent (phase 2 reads them in one piece), 16 consecutive words of an item (phase 1) and one element of 32 consecutive items
+// (phase 2) spread over all banks.
+template <int PREC, int NT, int AUX>
+__device__ __forceinline__ void gather_tr_stream_lp_body(const FrPipeArgs &a, const FrStageArgs &st, int local, uint4 *tile_raw) {
+    static_assert(PREC == 1 || PREC == 2, "operand-type rows exist for the bf16 and fp8 chains");
+    constexpr int EW = PREC == 1 ? 2 : 4;          // record words per 16-byte image element
+    constexpr int SW = 64 / EW - 1;                // swizzle mask over the element index
+    using word_t = typename std::conditional<PREC == 1, uint2, uint32_t>::type;
+    word_t *tile = reinterpret_cast<word_t *>(tile_raw);
+    auto at = [](int item, int word) { return item * FR_GT_WORDS + ((((word / EW) ^ (item & SW)) * EW) | (word % EW)); };
+    const int m_tiles = st.ldm / FR_GT_ITEMS, m_groups = (m_tiles + NT - 1) / NT;
+    const int mg = local % m_groups, wb = local / m_groups;
+    const int w0 = wb * FR_GT_WORDS;
+    if (w0 >= a.n_words) return;  // padding workgroup
+    const int wl = threadIdx.x & 63, ig = threadIdx.x >> 6;
+    const bool w_live = w0 + wl < a.n_words;     // a lane past the record writes zeros (fp8: the image's zero pad up to 64 k)
+    const int w = w_live ? w0 + wl : a.n_words - 1;
+    const uint4 d0 = reinterpret_cast<const uint4 *>(a.words)[2 * w];
+    const uint4 d1 = reinterpret_cast<const uint4 *>(a.words)[2 * w + 1];
+    const uint32_t stride = d0.z, idx_col = d0.w, rows = d1.x;
+    const bool is_dense = (idx_col & FR_DESC_DENSE) != 0;
+    const uint64_t base = (is_dense ? (uint64_t)reinterpret_cast<uintptr_t>(a.dense) : 0ull) + (((uint64_t)d0.y << 32) | d0.x);
+    const unsigned icol = is_dense ? 0u : idx_col * 4u;
+    const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.idx), 0, (unsigned)st.batch * (unsigned)a.idx_stride * 4u, 0x00020000);
+    const float scale = PREC == 2 ? __builtin_ldexpf(1.0f, st.e_out) : 1.0f;
+    uint32_t id[NT][4];
+    word_t v[NT][4];
+    bool bad = false;
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const unsigned m = (unsigned)((mg * NT + t) * FR_GT_ITEMS + 4 * ig + i);
+            id[t][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_idx, m * (unsigned)a.idx_stride * 4u + icol, 0, 0);
+        }
+    if (is_dense) {   // wave-divergent only in the word block that holds the request's dense features
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const unsigned m = (unsigned)((mg * NT + t) * FR_GT_ITEMS + 4 * ig + i);
+                const unsigned r = m < (unsigned)st.batch ? m : 0u;
+                typedef const u32x4_t __attribute__((address_space(1))) * gptr_t;
+                const u32x4_t q = *(gptr_t)(base + (uint64_t)r * stride);
+                if constexpr (PREC == 1) v[t][i] = make_uint2(pack_bf16x2(__uint_as_float(q.x), __uint_as_float(q.y)), pack_bf16x2(__uint_as_float(q.z), __uint_as_float(q.w)));
+                else v[t][i] = pack_fp8_word(make_uint4(q.x, q.y, q.z, q.w), scale);
+            }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t r = id[t][i];
+                const bool oob = r >= rows;  // reference: silent out-of-bounds read (embedding_47_krnl.cpp:927-933)
+                bad |= oob;
+                r = oob ? 0u : r;
+                if constexpr (PREC == 1) {
+                    typedef const unsigned __attribute__((ext_vector_type(2))) __attribute__((address_space(1))) * gptr2_t;
+                    const auto q = *(gptr2_t)(base + (uint64_t)r * stride);
+                    v[t][i] = make_uint2(q.x, q.y);
+                } else {
+                    typedef const unsigned __attribute__((address_space(1))) * gptr1_t;
+                    v[t][i] = *(gptr1_t)(base + (uint64_t)r * stride);
+                }
+            }
+    }
+    const int il = threadIdx.x & 31, ws = threadIdx.x >> 5;  // phase 2: lanes along items, 16 element slots
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int m0 = (mg * NT + t) * FR_GT_ITEMS;
+        if (m0 >= st.ldm) break;  // workgroup-uniform: the last group of an odd tile count
+        if (t > 0) __syncthreads();   // the previous tile has been read out
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool keep = w_live && (m0 + 4 * ig + i < st.batch);
+            if constexpr (PREC == 1) tile[at(4 * ig + i, wl)] = keep ? v[t][i] : make_uint2(0u, 0u);
+            else tile[at(4 * ig + i, wl)] = keep ? v[t][i] : 0u;
+        }
+        __syncthreads();
+        const int m = m0 + il;
+        auto put = [&](size_t elem_row, const uint4 &x) {   // image element row (pair / quad index) of item m
+            const size_t row0 = (size_t)(w0 / EW);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(st.out) + row0 * st.ldm * 16, 0, 0xffffffffu, 0x00020000);
+            u32x4_t q;
+            q.x = x.x, q.y = x.y, q.z = x.z, q.w = x.w;
+            __builtin_amdgcn_raw_buffer_store_b128(q, rs, (unsigned)(((elem_row - row0) * st.ldm + m) * 16), 0, AUX);
+        };
+        if constexpr (PREC == 2) {
+            const int KE = (st.K + 63) / 64 * 4;
+            const int e = (w0 >> 2) + ws;              // 16 quads of the block x 32 items = one element per thread
+            if (e < KE) put((size_t)e, *reinterpret_cast<const uint4 *>(&tile[at(il, 4 * ws)]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {              // 32 pairs of the block x 32 items = two elements per thread
+                const int pl = ws + 16 * j, w2 = w0 + 2 * pl;
+                if (w2 < a.n_words) put((size_t)(w2 >> 1), *reinterpret_cast<const uint4 *>(&tile[at(il, 2 * pl)]));
+            }
+        }
+    }
+    if (bad) atomicOr_system(a.err_flag, 1);
+}
+
 // 2 = gather_tr_stream_body (two tiles per workgroup, write-through image stores: Model-C batch 4096 chain 55 -> 58 M inf/s in fp8,
 // 35.7 -> 37 M in bf16, profiles/r02_gather_tr_variants.txt); 1 = gather_tr_body (FR_GATHER_TR_VARIANT=1, and index buffers >= 4000 MiB)
 int frk_gather_tr_variant(int batch, int idx_stride) {
@@ -858,7 +966,12 @@ __global__ void __launch_bounds__(FR_PIPE_THREADS) fr_pipeline_kernel(const FrPi
     if (s == 0 && st.variant == 1) {
         gather_tr_body<PREC>(a, st, local, smem);
     } else if (s == 0 && st.variant == 2) {
-        gather_tr_stream_body<PREC, 2, 16>(a, st, local, smem);
+        if constexpr (PREC != 0) {
+            if (a.src_lp) gather_tr_stream_lp_body<PREC, 2, 16>(a, st, local, smem);
+            else gather_tr_stream_body<PREC, 2, 16>(a, st, local, smem);
+        } else {
+            gather_tr_stream_body<PREC, 2, 16>(a, st, local, smem);
+        }
     } else if constexpr (PREC == 1) {
         if (s == 0) gather_h_body(a, st, local);
         else if (s == 4) fc_out_h_body(st, local, red);
@@ -905,7 +1018,12 @@ __global__ void __launch_bounds__(FR_PIPE_THREADS) __attribute__((amdgpu_num_vgp
     float *red = reinterpret_cast<float *>(smem);
     const int b = blockIdx.x;
     if (b < a.st[1].block_begin) {   // stage 0 (stages 1-3 are empty in this launch: their begins equal stage 4's)
-        gather_tr_stream_body<PREC, 2, 16>(a, a.st[0], b - a.st[0].block_begin, smem);
+        if constexpr (PREC != 0) {
+            if (a.src_lp) gather_tr_stream_lp_body<PREC, 2, 16>(a, a.st[0], b - a.st[0].block_begin, smem);   // rows already in the operand type
+            else gather_tr_stream_body<PREC, 2, 16>(a, a.st[0], b - a.st[0].block_begin, smem);
+        } else {
+            gather_tr_stream_body<PREC, 2, 16>(a, a.st[0], b - a.st[0].block_begin, smem);
+        }
     } else {
         const FrStageArgs &st = a.st[4];
         const int local = b - st.block_begin;
@@ -956,3 +1074,40 @@ int frk_stage_blocks(int stage, int n_words, int K, int N, int ldm, int nsplit) 
     return pad8(fc_q_blocks(N, ldm, nsplit));
 }
 
+
+
+// ---- operand-type bank image: rows of an fp32 region -> the same rows as bf16 / e4m3 (fr_api.cpp lp_ensure_image) ------------------------
+// One thread per (row, 16-byte fp32 word): the rounding functions are the gather's own (pack_bf16x2: RNE; pack_fp8_word: x 2^e_x,
+// saturated, e4m3), so a row converted here and gathered as it is equals the fp32 row gathered and converted then, bit for bit.
+template <int PREC>
+__global__ void __launch_bounds__(256) convert_rows_lp_kernel(const char *src, size_t src_stride, char *dst, size_t dst_stride, long long rows, int words, float scale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long r = i / words;
+    const int w = (int)(i - r * words);
+    if (r >= rows) return;
+    const uint4 v = *reinterpret_cast<const uint4 *>(src + (size_t)r * src_stride + (size_t)w * 16);
+    if constexpr (PREC == 1) {
+        *reinterpret_cast<uint2 *>(dst + (size_t)r * dst_stride + (size_t)w * 8) =
+            make_uint2(pack_bf16x2(__uint_as_float(v.x), __uint_as_float(v.y)), pack_bf16x2(__uint_as_float(v.z), __uint_as_float(v.w)));
+    } else {
+        *reinterpret_cast<uint32_t *>(dst + (size_t)r * dst_stride + (size_t)w * 4) = pack_fp8_word(v, scale);
+    }
+}
+
+int frk_convert_rows_lp(int precision, const void *src, size_t src_stride, void *dst, size_t dst_stride, int64_t rows, int floats, int e_x, hipStream_t s) {
+    if (rows <= 0 || floats <= 0) return FR_OK;
+    if (floats % 4) FR_FAIL(FR_ERR_INVALID, "internal: a table row of %d floats is not whole 16-byte words", floats);
+    const int words = floats / 4;
+    const long long total = (long long)rows * words;
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) FR_FAIL(FR_ERR_INVALID, "internal: %lld rows x %d words exceed one conversion launch", (long long)rows, words);
+    if (precision == FR_FC_BF16)
+        convert_rows_lp_kernel<1><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(static_cast<const char *>(src), src_stride, static_cast<char *>(dst), dst_stride, rows, words, 1.0f);
+    else if (precision == FR_FC_FP8)
+        convert_rows_lp_kernel<2><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(static_cast<const char *>(src), src_stride, static_cast<char *>(dst), dst_stride, rows, words,
+                                                                                  ldexpf(1.0f, e_x));
+    else
+        FR_FAIL(FR_ERR_INVALID, "internal: no operand-type rows for precision %d", precision);
+    KCHECK();
+    return FR_OK;
+}

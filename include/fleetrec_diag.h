@@ -63,6 +63,14 @@ float *fr_worker_records_dptr(fr_worker *w);
  * xq[((k/4)*ld + m)*4 + k%4] with ld = round_up(batch, 32).  Lets tests check the pipeline's own gather bit-exactly. */
 float *fr_worker_features_dptr(fr_worker *w, int *ld_max);
 
+/* Operand-type bank image: a FR_INDEX_PER_BANK context running the bf16 / fp8 chain keeps its reachable bank rows a
+ * second time in the chain's operand type (bf16; e4m3 at the calibrated X exponent), made from the fp32 tables with the gather's own
+ * rounding and rebuilt by itself whenever precision, calibration or table contents change; the in-chain gather of a large batch reads THAT
+ * (82 lines per Model-C item instead of 142, nothing to convert).  Scores are bit-identical either way.  on = 0 makes the gather read the
+ * fp32 rows and convert them itself (the A/B and parity hook; default 1).  fr_ctx_lp_bank_image_bytes: HBM the image holds now (0: none). */
+int fr_ctx_set_lp_bank_image(fr_ctx *ctx, int on);
+size_t fr_ctx_lp_bank_image_bytes(const fr_ctx *ctx);
+
 /* Failure-injection hook for the table-sharded step's failure protocol (fleetrec.h, kind (2)): the FC chains of this worker's next `steps`
  * fr_worker_submit_sharded calls are reported as failed (FR_ERR_STATE) AFTER they ran -- the rank still joins both collectives, its score
  * chunk travels as NaN and its status word makes every rank's fr_worker_sync return FR_ERR_COMM naming it.  steps = 0 disarms.  A test hook:

@@ -2317,6 +2317,93 @@ def test_part_chip_tiles_follow_the_chain_width_not_the_worker_count(fr, O, ctxs
         ctx.set_fc_precision(fr.FC_FP32)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp8"])
+def test_operand_type_bank_image_is_bit_identical_to_converting_at_gather(fr, O, gpu, prec):
+    """VERDICT r05 item 2.  A per-bank context on the bf16 / fp8 chain keeps its reachable bank rows once more in the chain's operand type
+    (bf16; e4m3 at the calibrated X exponent) and the in-chain gather of a large batch reads THOSE rows -- 82 lines per Model-C item
+    instead of 142, nothing converted.  RNE of the fp32 row at fill = RNE at gather, so every score must be bit-identical to the same
+    chain gathering the fp32 rows (fr_ctx_set_lp_bank_image(0)): full-size Model-C (82 banks, bank rows of 112-256 bytes, lone tables,
+    the request's dense block converted in flight), batches 4096 / 4000 (ragged) / 512 incl. index 0 and the last row of every bank;
+    the image follows the table contents (refill with another seed), the precision and -- fp8 -- a recalibration with other exponents;
+    an out-of-range bank index is still reported; and the image is checked against the oracle on one batch."""
+    m = fr.Model.builtin(fr.MODEL_C).clone(index_mode=fr.INDEX_PER_BANK)
+    om = O.OracleModel("C")
+    ctx = fr.Context(m, device=gpu)
+    ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    bot, brows = m.bank_map()
+    rng = np.random.default_rng(606)
+    enum = {"bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[prec]
+    sizes = [4096, 4000, 512]
+    reqs = []
+    for b in sizes:
+        idx = uniform_idx(rng, brows, b)
+        idx[0] = 0
+        idx[1] = brows - 1
+        reqs.append((idx, rng.uniform(-1, 1, (b, m.dense_len)).astype(np.float32)))
+    ctx.set_fc_precision(enum)
+    wk = fr.Worker(ctx, 4096)
+    try:
+        def run_all(which_reqs):
+            out = []
+            for idx, dense in which_reqs:
+                b = len(idx)
+                d_i, d_d, d_s = fr.DeviceBuffer.from_numpy(ctx, idx), fr.DeviceBuffer.from_numpy(ctx, dense), fr.DeviceBuffer(ctx, b * 4)
+                for _ in range(2):                       # streamed: the chain's own gather launch (fr_gather_out_kernel)
+                    wk.push_device(b, d_i, d_d, d_s)
+                wk.sync()
+                out.append(d_s.download(np.float32, b))
+                for x in (d_i, d_d, d_s):
+                    x.free()
+            return out
+        if prec == "fp8":
+            wk.calibrate_fp8(*reqs[0])
+        assert ctx.lp_bank_image_bytes() == 0            # nothing is built before the first large-batch launch needs it
+        ctx.set_lp_bank_image(1)
+        with_image = run_all(reqs)
+        nbytes = ctx.lp_bank_image_bytes()
+        fp32_bytes = m.table_bytes()
+        assert 0 < nbytes <= 0.56 * fp32_bytes / (1 if prec == "bf16" else 2), (nbytes, fp32_bytes)   # half / a quarter of the tables + row padding
+        ctx.set_lp_bank_image(0)
+        without = run_all(reqs)
+        for a_, b_, sz in zip(with_image, without, sizes):
+            assert np.array_equal(a_, b_), (prec, sz, rel_err(a_, b_))
+        # against the oracle (tolerances of the chains as everywhere else)
+        rec = om.gather(reqs[2][0], dense=reqs[2][1], content_mode=O.FILL_HASH, seed=SEED_TABLES, per_bank=True).view(np.float32)
+        ref = om.fc_chain(rec, [ctx.get_weights(l) for l in range(4)], acc64=True)
+        assert rel_err(with_image[2], ref) <= {"bf16": 3e-2, "fp8": 0.15}[prec]
+        # the image follows the table contents ...
+        ctx.fill_tables(fr.FILL_HASH, SEED_TABLES + 1)
+        ctx.set_lp_bank_image(1)
+        a2 = run_all(reqs[:1])[0]
+        ctx.set_lp_bank_image(0)
+        b2 = run_all(reqs[:1])[0]
+        assert np.array_equal(a2, b2) and not np.array_equal(a2, with_image[0])
+        # ... and, in fp8, the X exponent of a new calibration (a batch of 8 x larger dense features moves it)
+        if prec == "fp8":
+            e_before = ctx.fp8_exponents()
+            big = (reqs[0][0], reqs[0][1] * 64.0)
+            wk.calibrate_fp8(*big)
+            assert ctx.fp8_exponents() != e_before
+            ctx.set_lp_bank_image(1)
+            a3 = run_all([big])[0]
+            ctx.set_lp_bank_image(0)
+            b3 = run_all([big])[0]
+            assert np.array_equal(a3, b3)
+        # an out-of-range bank index is reported through the image path as through the other
+        ctx.set_lp_bank_image(1)
+        bad = reqs[0][0].copy()
+        bad[7, 3] = brows[3]
+        d_i, d_d, d_s = fr.DeviceBuffer.from_numpy(ctx, bad), fr.DeviceBuffer.from_numpy(ctx, reqs[0][1]), fr.DeviceBuffer(ctx, 4096 * 4)
+        wk.push_device(4096, d_i, d_d, d_s)
+        with pytest.raises(fr.FleetRecError) as e:
+            wk.sync()
+        assert e.value.status == fr.FR_ERR_INDEX_RANGE
+    finally:
+        wk.close()
+        ctx.close()
+
+
 def test_diagnostic_and_calibration_launches_do_not_freeze_the_chain_width(fr, ctxs):
     """"create one worker, calibrate / probe, then create the other three" must not pin W = 1 by accident.  Calibration batches
     (fp32 stages) and fleetrec_diag.h's single-layer launches leave the context undecided; the first submit freezes it at the workers alive
