@@ -79,6 +79,8 @@ static unsigned long long *g_stamp_buffer = nullptr;  // diagnostics (tools/expe
 extern "C" __attribute__((visibility("default"))) void fr_debug_set_stamp_buffer(void *dptr) { g_stamp_buffer = (unsigned long long *)dptr; }
 
 static int fused_group_initial();
+static bool lp_image_applies_hs(const fr_ctx *c);
+static int lp_ensure_image(fr_ctx *c, int prec);
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -1022,8 +1024,14 @@ extern "C" int fr_ctx_set_chain_width(fr_ctx *ctx, int width) {
 extern "C" int fr_ctx_chain_width(const fr_ctx *ctx) { return ctx ? ctx->chain_width.load(std::memory_order_relaxed) : FR_ERR_INVALID; }
 
 // ---- operand-type bank image (fr_internal.h, fr_ctx::lp_arena) ------------------------------------------------------------------------
-// Which contexts have one: FR_INDEX_PER_BANK, unsharded or sharded, SEMANTIC layout, bf16 / fp8 chain.  (Per-table contexts gain nothing: a
-// row is one 128-byte line whatever its element type -- the gather is bound by the fabric's REQUEST rate)
+// Which launches read one.  (a) The large-batch gather of a chain model (Model-C) on a FR_INDEX_PER_BANK context, bf16 / fp8 chain: fewer lines
+// per item.  (Per-table chain contexts gain nothing there: a row is one 128-byte line whatever its element type -- that gather is bound by
+// the fabric's REQUEST rate)  (b) EXPERIMENTS build only (FR_FUSED_LP_ROWS=1): the persistent bf16 fused kernel
+// (fr_fused_tile_hs_kernel, any index mode) -- 8-byte row words are twice the row sets in flight in its producers' registers; measured
+// slower (profiles/r06_experiments.md section 3), so frk_fused_hk_takes_lp_rows() is false in the product.
+static bool lp_image_applies_hs(const fr_ctx *c) {
+    return !c->cpu && c->fc_precision == FR_FC_BF16 && c->n_words > 0 && c->lp_image_on.load(std::memory_order_relaxed) != 0;
+}
 static bool lp_image_applies(const fr_ctx *c, int prec) {
     return !c->cpu && c->model.index_mode == FR_INDEX_PER_BANK && (prec == FR_FC_BF16 || prec == FR_FC_FP8) && c->n_words > 0 &&
            c->lp_image_on.load(std::memory_order_relaxed) != 0;
@@ -1045,21 +1053,29 @@ static int lp_ensure_image(fr_ctx *c, int prec) {
     if (c->lp_prec == prec && c->lp_e_x == e_x && c->lp_tables_gen == c->tables_gen && c->d_words_lp) return FR_OK;
     const fr_model_desc &m = c->model;
     const size_t esz = prec == FR_FC_BF16 ? 2 : 1;
+    // a "bank" of the image = the tables one index addresses: a memory bank of a FR_INDEX_PER_BANK context (rows: the bank's common range),
+    // a single table otherwise (rows: its own)
+    const bool per_bank = m.index_mode == FR_INDEX_PER_BANK;
     struct Bank { std::vector<int> members; size_t payload_floats = 0, lp_off = 0, lp_stride = 0; uint64_t rows = 0; };
-    std::vector<Bank> banks(c->n_banks);
-    for (int t = 0; t < m.n_tables; t++)
+    const int n_groups = per_bank ? c->n_banks : m.n_tables;
+    std::vector<int> group_of(m.n_tables, 0);
+    std::vector<Bank> banks(n_groups);
+    for (int t = 0; t < m.n_tables; t++) {
+        group_of[t] = per_bank ? c->bank_of_table[t] : t;
         if (c->table_mem[t].resident) {
-            Bank &b = banks[c->bank_of_table[t]];
+            Bank &b = banks[group_of[t]];
             b.members.push_back(t);
             b.payload_floats += (size_t)m.tables[t].dim;
+            b.rows = per_bank ? (uint64_t)c->bank_rows[group_of[t]] : (uint64_t)m.tables[t].rows;
         }
+    }
     auto lines_x128 = [](size_t stride, size_t bytes) {  // expected 128-byte lines per row, x128 (exact over one period) -- as for the fp32 bank rows
         size_t acc = 0;
         for (size_t r = 0; r < 128; r++) acc += ((r * stride) % 128 + bytes + 127) / 128;
         return acc;
     };
     size_t off = 0;
-    for (int bi = 0; bi < c->n_banks; bi++) {
+    for (int bi = 0; bi < n_groups; bi++) {
         Bank &b = banks[bi];
         if (b.members.empty()) continue;
         const size_t payload = b.payload_floats * esz;
@@ -1067,7 +1083,6 @@ static int lp_ensure_image(fr_ctx *c, int prec) {
         for (size_t cand : {align_up(payload, 16), align_up(payload, 32), align_up(payload, 64), align_up(payload, 128)})
             if (lines_x128(cand, payload) < lines_x128(best, payload)) best = cand;
         b.lp_stride = best;
-        b.rows = (uint64_t)c->bank_rows[bi];
         b.lp_off = align_up(off, 256);
         off = b.lp_off + (size_t)b.rows * best;
     }
@@ -1102,7 +1117,7 @@ static int lp_ensure_image(fr_ctx *c, int prec) {
         const int t = c->h_word_table[i];
         if (t < 0) continue;   // dense words come from the request, in fp32
         lw[i].src = (uint64_t)(uintptr_t)(c->lp_arena + lp_base[t]) + (uint64_t)c->h_word_col[i] * esz;
-        lw[i].stride = (uint32_t)banks[c->bank_of_table[t]].lp_stride;
+        lw[i].stride = (uint32_t)banks[group_of[t]].lp_stride;
     }
     if (!c->d_words_lp) FR_HIP(hipMalloc((void **)&c->d_words_lp, sizeof(FrWordDesc) * c->n_words));
     FR_HIP(hipMemcpyAsync(c->d_words_lp, lw.data(), sizeof(FrWordDesc) * c->n_words, hipMemcpyHostToDevice, c->setup_stream));
@@ -1507,6 +1522,12 @@ static int fused_flush(fr_worker *w) {
             a.blist = db;
             a.n_batches = n_all;
             a.tiles_per_batch = max_tiles;
+            if (bf16 && frk_fused_hk_takes_lp_rows(a.K) && lp_image_applies_hs(c)) {   // rows already bf16: twice the row sets in flight in the producers' registers
+                const int irc = lp_ensure_image(c, FR_FC_BF16);
+                if (irc) return irc;
+                a.words = c->d_words_lp;
+                a.src_lp = 1;
+            }
             if (bf16 && FR_KNOB_ONCE("FUSED_HS_ABLATE", 0)) a.e_act[3] = -776 - FR_KNOB_ONCE("FUSED_HS_ABLATE", 0);   // experiments build: the kernel's timing ablations (1: no row loads, 2: every row load reads row 0)
             if (fp8) {  // the "q16h" copies of the weights (the non-scaled fp8 MFMA's operand layout)
                 a.w1q = reinterpret_cast<const float4 *>(c->d_w_fp8h[0]);

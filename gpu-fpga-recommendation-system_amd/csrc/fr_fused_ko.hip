@@ -111,8 +111,13 @@ __device__ __forceinline__ void hk_mma(f32x16 &acc, const uint4 &a4, const uint4
 // NSL + D + 1 gather events run under FC2, E3 under FC3, the rest under FC1's first slices (one per slice barrier) -- with the bf16
 // schedule (every event under FC1) the fp8 consumers, whose operand stream is half as long, waited for the gather in every slice
 // (340 M inf/s against the chunked kernel's 398 M, profiles/r03_fused_hs_fp8_ab.txt).
-template <int PREC, int KG, int KGS, int LW, int D, int R1D, int E2 = 0, int E3 = 0>
+// SRC = 1 (bf16, round 6): a.words address the OPERAND-TYPE row image (fr_ctx::lp_arena: every table / bank row once more as bf16, made with
+// the rounding W_op applies) -- a row word is 8 bytes, a row set costs half the registers, so D = 4 sets ride where 2 did; W_op stores the
+// words as they come.  Dense words (the request's fp32 features) are converted by the lane that loads them.  Same X image, bit for bit.
+template <int PREC, int KG, int KGS, int LW, int D, int R1D, int E2 = 0, int E3 = 0, int SRC = 0>
 __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs a) {
+    static_assert(SRC == 0 || PREC == 1, "operand-type rows: the bf16 form only");
+    using row_t = typename std::conditional<SRC == 1, uint2, uint4>::type;
     extern __shared__ uint4 lds[];
     constexpr int WPG = PREC == 2 ? 8 : 4;             // record words (4 floats each) per k-group
     constexpr int KPG = 4 * WPG;                       // k per k-group
@@ -223,7 +228,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
         // =========================================== PRODUCERS: the gather ===========================================
         int wl = 0, it0 = 0;                        // word of the slice this thread moves; first of its IPT items inside the tile
         uint32_t idxr[IPT];                         // index values of the slice whose rows are loaded next
-        uint4 rows[D][IPT];                         // row words in flight: D slices
+        row_t rows[D][IPT];                         // row words in flight: D slices
         unsigned bad = 0u;                          // out-of-range index seen (a lane flag, OR-ed: no compare mask is kept)
         uint2 *Xh2 = reinterpret_cast<uint2 *>(Xr);
         uint32_t *Xw = reinterpret_cast<uint32_t *>(Xr);
@@ -250,7 +255,7 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
         constexpr bool no_rows = false;
         constexpr uint32_t zero_above = 0u;
 #endif
-        auto R_op = [&](const HkTile &t, int s, uint4 (&r)[IPT]) {  // row loads of slice s (its indices are in idxr)
+        auto R_op = [&](const HkTile &t, int s, row_t (&r)[IPT]) {  // row loads of slice s (its indices are in idxr)
             const uint4 d = Dsc[slice_word(s)];
             const bool dense = (d.w >> 31) != 0;
             const uint64_t base = (((uint64_t)(d.y & 0xFFFFu) << 32) | d.x) + (dense ? (uint64_t)reinterpret_cast<uintptr_t>(t.dense) : 0ull);
@@ -264,23 +269,38 @@ __global__ void __launch_bounds__(768) fr_fused_tile_hs_kernel(const FrFusedArgs
                 x = oob ? 0u : x;
                 x = dense ? (m < (unsigned)t.batch ? m : 0u) : x;
                 if (zero_above && nrows >= zero_above) x = 0u;
-                if (no_rows) {
-                    r[i] = make_uint4(x, x, x, x);
-                    continue;
+                if constexpr (SRC == 1) {
+                    if (dense) {   // the request's fp32 features: converted here, with W_op's rounding
+                        typedef const u32x4_t __attribute__((address_space(1))) * gptr_t;
+                        const u32x4_t q = *(gptr_t)(base + (uint64_t)x * stride);
+                        r[i] = make_uint2(pack_bf16x2(__uint_as_float(q.x), __uint_as_float(q.y)), pack_bf16x2(__uint_as_float(q.z), __uint_as_float(q.w)));
+                    } else {
+                        typedef const unsigned __attribute__((ext_vector_type(2))) __attribute__((address_space(1))) * gptr2_t;
+                        const auto q = *(gptr2_t)(base + (uint64_t)x * stride);
+                        r[i] = make_uint2(q.x, q.y);
+                    }
+                } else {
+                    if (no_rows) {
+                        r[i] = make_uint4(x, x, x, x);
+                        continue;
+                    }
+                    typedef const u32x4_t __attribute__((address_space(1))) * gptr_t;
+                    const u32x4_t q = *(gptr_t)(base + (uint64_t)x * stride);
+                    r[i] = make_uint4(q.x, q.y, q.z, q.w);
                 }
-                typedef const u32x4_t __attribute__((address_space(1))) * gptr_t;
-                const u32x4_t q = *(gptr_t)(base + (uint64_t)x * stride);
-                r[i] = make_uint4(q.x, q.y, q.z, q.w);
             }
         };
-        auto W_op = [&](const HkTile &t, int s, const uint4 (&r)[IPT]) {  // slice s: fp32 rows -> bf16 / e4m3 -> X ring buffer s % 2
+        auto W_op = [&](const HkTile &t, int s, const row_t (&r)[IPT]) {  // slice s: fp32 rows -> bf16 / e4m3 (SRC = 1: as they are) -> X ring buffer s % 2
             const int nw = WPG * (KG - KGS * s < KGS ? KG - KGS * s : KGS);  // words of this slice
             if (wl < nw) {
                 const uint32_t real = 0u - (uint32_t)(WPG * KGS * s + wl < a.n_words);  // fp8: words past the record are the zero pad of its last k-group
 #pragma unroll
                 for (int i = 0; i < IPT; i++) {
                     const uint32_t in = (0u - (uint32_t)(t.m0 + it0 + i < t.batch)) & real;  // all ones / zero: items past the batch are zero rows, branch-free
-                    if constexpr (PREC == 1) {
+                    if constexpr (SRC == 1) {
+                        uint2 *xb = Xh2 + (size_t)(FULLX ? s : (s & 1)) * (XROWS * HK_LDX * 2);
+                        xb[((size_t)(wl >> 1) * HK_LDX + it0 + i) * 2 + (wl & 1)] = make_uint2(r[i].x & in, r[i].y & in);
+                    } else if constexpr (PREC == 1) {
                         uint2 *xb = Xh2 + (size_t)(FULLX ? s : (s & 1)) * (XROWS * HK_LDX * 2);
                         uint2 hv;
                         hv.x = pack_bf16x2(__uint_as_float(r[i].x), __uint_as_float(r[i].y)) & in;
@@ -656,17 +676,26 @@ bool frk_fused_hk_ok(int K, int H1, int H2, int H3, const FrWordDesc *h_words, i
     return true;
 }
 
-template <int PREC, int KG, int KGS, int LW, int D, int R1D, int E2 = 0, int E3 = 0>
+bool frk_fused_hk_takes_lp_rows(int K) {   // experiments build, opt-in: see frk_fused_hk_launch
+#ifdef FR_EXPERIMENTS
+    return FR_KNOB_ONCE("FUSED_LP_ROWS", 0) == 1 && K % 16 == 0 && K > 704 && K <= 880;
+#else
+    (void)K;
+    return false;
+#endif
+}
+
+template <int PREC, int KG, int KGS, int LW, int D, int R1D, int E2 = 0, int E3 = 0, int SRC = 0>
 static int fused_hk_launch_inst(const FrFusedArgs &a, int n_cu, hipStream_t s) {
     static FrLdsAttrOnce lds_once;  // per instantiation, per device
-    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, D, R1D, E2, E3>, lds_once)) return rc_;
+    if (int rc_ = fr_allow_full_lds(&fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, D, R1D, E2, E3, SRC>, lds_once)) return rc_;
     const size_t r1_rows = 2 * (HK_H1 / (PREC == 2 ? 32 : 16));
     const size_t x_bufs = PREC == 2 ? (KG + KGS - 1) / KGS : 2;   // fp8: the X image of a whole tile; bf16: a ring of two slices
     const size_t lds = (r1_rows * HK_LD + x_bufs * 2 * KGS * HK_LDX + (size_t)a.n_words) * 16;
     if (lds > 160 * 1024) FR_FAIL(FR_ERR_INVALID, "internal: the K-outer fused kernel needs %zu bytes of LDS", lds);
     const int tiles = a.n_batches * a.tiles_per_batch;
-    fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, D, R1D, E2, E3><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(768), lds, s>>>(a);
-    fr_note_kernel("fr_fused_tile_hs_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", PREC, KG, KGS, LW, D, R1D, E2, E3);   // as rocprofv3 prints it
+    fr_fused_tile_hs_kernel<PREC, KG, KGS, LW, D, R1D, E2, E3, SRC><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(768), lds, s>>>(a);
+    fr_note_kernel("fr_fused_tile_hs_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", PREC, KG, KGS, LW, D, R1D, E2, E3, SRC);   // as rocprofv3 prints it
     KCHECK();
     return FR_OK;
 }
@@ -696,6 +725,17 @@ int frk_fused_hk_launch(const FrFusedArgs &a, int n_cu, int precision, hipStream
 #ifdef FR_EXPERIMENTS
     if (a.K == 880 && FR_KNOB_ONCE("FUSED_R1D", 6) == 4) return fused_hk_launch_inst<1, 55, 7, 32, 2, 4>(a, n_cu, s);
 #endif
+    if (a.src_lp) {
+        // Rows already bf16 (fr_ctx::lp_arena, SRC = 1): 8-byte row words, so FOUR row sets ride in the producers' registers where two did -- 168
+        // registers, no scratch: the depth round 5 could not reach (r05_experiments.md section 10).  MEASURED SLOWER (profiles/r06_experiments.md
+        // section 3: Model-B 1024, per table 324 -> 319 M inf/s, per bank 357 -> 341 M; with two row sets of 8-byte words 314 / 336 M): the producers
+        // are not short of rows in flight, and 8-byte row loads cost more than 16-byte ones.  EXPERIMENTS build only (FR_FUSED_LP_ROWS=1).
+#ifdef FR_EXPERIMENTS
+        if (a.K > 704 && a.K <= 880 && FR_KNOB_ONCE("FUSED_LP_D", 4) == 2) return fused_hk_launch_inst<1, 55, 7, 32, 2, 6, 0, 0, 1>(a, n_cu, s);   // the bytes alone: 8-byte rows, still two row sets
+        if (a.K > 704 && a.K <= 880) return fused_hk_launch_inst<1, 55, 7, 32, 4, 6, 0, 0, 1>(a, n_cu, s);   // Model-B: 8 slices, 4 row sets
+#endif
+        FR_FAIL(FR_ERR_INVALID, "internal: no operand-type-rows instantiation of the K-outer fused kernel for K=%d in this build", a.K);
+    }
     if (a.K % 16 == 0 && a.K >= 64) {
         if (a.K <= 352) return fused_hk_launch_inst<1, 22, 4, 16, 3, 4>(a, n_cu, s);   // Model-A: 6 slices of 4 (2) k-groups, 3 row sets in flight, 4 FC1 fragments
         if (a.K <= 528) return fused_hk_launch_inst<1, 33, 6, 32, 3, 4>(a, n_cu, s);   // 6 slices of 6 (3) k-groups, 3 row sets

@@ -380,6 +380,7 @@ int frk_pack_weights_q8_bf16(const float *W, uint16_t *Wh, int K, int H, hipStre
 bool frk_fc_lp_gemm_ok(int precision, int K, int N, int ldm);
 // width: the context's chain width (fr_ctx::chain_width) -> the larger tile already when it covers 1 / width of the chip (lp_gemm_mu)
 int frk_fc_lp_gemm(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, int width, bool minor, hipStream_t s);
+bool frk_fused_hk_takes_lp_rows(int K);   // the persistent bf16 fused kernel has an instantiation that reads operand-type (bf16) rows for this record length
 bool frk_fc_gemm_gather_ok(int precision, int K, int N, int ldm);   // FC1 of batch L - 1 + the gather of batch L in one launch (fc_gemm_gather_kernel)
 int frk_fc_gemm_gather(int precision, const void *Wp, const void *Xp, void *Yp, int K, int N, int ldm, int e_w, int e_in, int e_out, const FrWordDesc *words, int n_words,
                        int idx_stride, const int32_t *idx, const float *dense, int g_batch, int g_ldm, int g_K, void *g_out, int g_e_x, int *err_flag, hipStream_t s);

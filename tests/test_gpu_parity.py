@@ -2317,6 +2317,61 @@ def test_part_chip_tiles_follow_the_chain_width_not_the_worker_count(fr, O, ctxs
         ctx.set_fc_precision(fr.FC_FP32)
 
 
+@pytest.mark.parametrize("mode", ["table", "bank"])
+def test_persistent_bf16_kernel_on_operand_type_rows_is_bit_identical(fr, O, gpu, ctxs, mode):
+    """VERDICT r05 item 3, by another route than LDS-DMA: the persistent bf16 fused kernel's producers hold their rows in flight in
+    registers, and rows that are ALREADY bf16 (the operand-type image, made with W_op's own rounding) are 8-byte row words -- four row sets
+    in flight where two were, at the same 168 registers, no scratch.  Model-B 1024 x 40 batches (many tiles per workgroup, ragged ones
+    among them), per-table and per-bank contexts: every score bit-identical to the same kernel family on the fp32 rows
+    (fr_ctx_set_lp_bank_image(0)), the instantiation that ran is the SRC = 1 one, and one batch is checked against the oracle.
+    The form is correct and SLOWER (profiles/r06_experiments.md section 3: the producers are not short of rows in flight), so it lives in the
+    EXPERIMENTS library only: run with FR_LIB=.../libfleetrec_exp.so FR_FUSED_LP_ROWS=1."""
+    if os.path.basename(fr.LIB_PATH) != "libfleetrec_exp.so" or os.environ.get("FR_FUSED_LP_ROWS") != "1":
+        pytest.skip("operand-type rows under the persistent bf16 kernel: experiments library only (FR_LIB=.../libfleetrec_exp.so FR_FUSED_LP_ROWS=1)")
+    if mode == "bank":
+        m = fr.Model.builtin(fr.MODEL_B).clone(index_mode=fr.INDEX_PER_BANK)
+        ctx = fr.Context(m, device=gpu)
+        ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+        ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    else:
+        m, ctx = ctxs(1)
+    om = O.OracleModel("B")
+    rng = np.random.default_rng(1024)
+    sizes = [1024] * 36 + [1000, 77, 1024, 513]
+    reqs = [uniform_idx(rng, m.index_ranges(), b) for b in sizes]
+    ctx.set_fc_precision(fr.FC_BF16)
+    old_group = ctx.stream_group()
+    try:
+        ctx.set_stream_group(len(sizes))
+        wk = fr.Worker(ctx, 1024)
+        d_i = [fr.DeviceBuffer.from_numpy(ctx, a) for a in reqs]
+        d_s = [fr.DeviceBuffer(ctx, 1024 * 4) for _ in reqs]
+        got = {}
+        for on in (1, 0):
+            ctx.set_lp_bank_image(on)
+            for a, di, ds in zip(reqs, d_i, d_s):
+                wk.push_device(len(a), di, None, ds)
+            wk.sync()
+            kern = wk.last_kernel()
+            assert "fr_fused_tile_hs_kernel<1, 55, 7, 32, %s>" % ("4, 6, 0, 0, 1" if on else "2, 6, 0, 0, 0") in kern, (on, kern)
+            got[on] = [ds.download(np.float32, len(a)) for a, ds in zip(reqs, d_s)]
+        for k, (x, y) in enumerate(zip(got[1], got[0])):
+            assert np.array_equal(x, y), (mode, k, sizes[k], rel_err(x, y))
+        assert ctx.lp_bank_image_bytes() > 0
+        rec = om.gather(reqs[37], content_mode=O.FILL_HASH, seed=SEED_TABLES, per_bank=(mode == "bank")).view(np.float32)
+        ref = om.fc_chain(rec, [ctx.get_weights(l) for l in range(4)], acc64=True)
+        assert rel_err(got[1][37], ref) <= 3e-2
+        wk.close()
+        for x in d_i + d_s:
+            x.free()
+    finally:
+        ctx.set_lp_bank_image(1)
+        ctx.set_stream_group(old_group)
+        ctx.set_fc_precision(fr.FC_FP32)
+        if mode == "bank":
+            ctx.close()
+
+
 @pytest.mark.parametrize("prec", ["bf16", "fp8"])
 def test_operand_type_bank_image_is_bit_identical_to_converting_at_gather(fr, O, gpu, prec):
     """VERDICT r05 item 2.  A per-bank context on the bf16 / fp8 chain keeps its reachable bank rows once more in the chain's operand type
