@@ -79,6 +79,7 @@ static unsigned long long *g_stamp_buffer = nullptr;  // diagnostics (tools/expe
 extern "C" __attribute__((visibility("default"))) void fr_debug_set_stamp_buffer(void *dptr) { g_stamp_buffer = (unsigned long long *)dptr; }
 
 static int fused_group_initial();
+static bool fused_eligible(const fr_ctx *c);
 static bool lp_image_applies_hs(const fr_ctx *c);
 static int lp_ensure_image(fr_ctx *c, int prec);
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -737,6 +738,14 @@ extern "C" int fr_ctx_set_fc_precision(fr_ctx *ctx, int precision) {
         }
         FR_HIP(hipStreamSynchronize(ctx->setup_stream));
     }
+    // fp8 on a model that streams through the fused item-tile kernels (Models A / B) is accepted and CORRECT, but it is not
+    // where the e4m3 peak is: the chunked fr_fused_tile_f8_kernel gathers with the matrix pipes idle and then streams weights at the rate
+    // the bf16 kernel does -- 0.19 of the fp8 peak, 14-19 % above the bf16 chain.  The caller is told instead of finding out from a profile:
+    // the call succeeds and fr_last_error() carries the note (fleetrec.h, fr_fc_precision).
+    if (precision == FR_FC_FP8 && fused_eligible(ctx))
+        fr_set_error("note: FR_FC_FP8 on a fused-kernel model (record of %d floats) runs fr_fused_tile_f8_kernel at ~0.19 of the fp8 MFMA peak, 14-19 %% above FR_FC_BF16 "
+                     "(the 64-item tile is bound by its gather phase and its weight stream, not by the matrix pipes); the scaled-MFMA chain that reaches 0.55 of the fp8 peak "
+                     "is the GEMM path of chain models (Model-C shapes at batch >= 1024)", ctx->model.fc[0]);
     return FR_OK;
 }
 
@@ -863,6 +872,10 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
         // k = how many workers the context has EVER created (one fetch_add: two threads creating workers at once cannot draw the same k, and a
         // destroy + create keeps alternating -- ADVICE r04: the live count did neither)
         const int k = ctx->worker_seq.fetch_add(1, std::memory_order_relaxed);
+        // (Round 6 tried to CHECK the outcome -- handshake kernels between a new worker's stream and its peers' -- and to keep the first streams in
+        // a pool: neither helps.  After some stream churn in the process one pair of a context's four workers takes turns (four Model-C chains
+        // 48 -> 37-45 M inf/s) although handshake kernels on the two streams see each other resident, and pooled streams pair up just the same:
+        // profiles/r06_experiments.md section 4.  What the library controls is what it does here.)
         if (lo > hi) W_HIP(hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, spread == 2 ? hi + k % (lo - hi + 1) : (k % 2 ? lo : hi)));
         else W_HIP(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
     }
@@ -1022,6 +1035,7 @@ extern "C" int fr_ctx_set_chain_width(fr_ctx *ctx, int width) {
 }
 
 extern "C" int fr_ctx_chain_width(const fr_ctx *ctx) { return ctx ? ctx->chain_width.load(std::memory_order_relaxed) : FR_ERR_INVALID; }
+
 
 // ---- operand-type bank image (fr_internal.h, fr_ctx::lp_arena) ------------------------------------------------------------------------
 // Which launches read one.  (a) The large-batch gather of a chain model (Model-C) on a FR_INDEX_PER_BANK context, bf16 / fp8 chain: fewer lines

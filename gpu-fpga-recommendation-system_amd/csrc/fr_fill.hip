@@ -419,3 +419,4 @@ int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, 
     return FR_OK;
 }
 
+

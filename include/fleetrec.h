@@ -158,7 +158,10 @@ typedef enum fr_fc_precision {
     FR_FC_FP32 = 0, /* fp32 in, fp32 accumulate: CUBLAS_COMPUTE_32F + CUDA_R_32F (cuda_server.c:211) */
     FR_FC_BF16 = 1, /* bf16 operands on MFMA, fp32 accumulate (BASELINE configs 3/4) */
     FR_FC_FP8 = 2   /* OCP e4m3 operands on the CDNA4 scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4), per-tensor
-                       power-of-two scales, fp32 accumulate; output layer in fp32 (BASELINE configs[4]) */
+                       power-of-two scales, fp32 accumulate; output layer in fp32 (BASELINE configs[4]).  Where it pays: the GEMM
+                       chain of Model-C shapes (0.55 of the fp8 peak per layer).  On the fused-kernel models (A, B) it is correct
+                       but runs the chunked 64-item-tile kernel at ~0.19 of the fp8 peak, 14-19 % above FR_FC_BF16:
+                       fr_ctx_set_fc_precision succeeds there and leaves a "note:" saying so in fr_last_error(). */
 } fr_fc_precision;
 
 typedef struct fr_ctx fr_ctx;       /* device + model + tables + weights; shared by all workers,

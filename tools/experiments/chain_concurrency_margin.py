@@ -16,12 +16,12 @@ dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
 ctx.set_fc_precision(fr.FC_BF16); ctx.set_chain_width(4)
 wks = [fr.Worker(ctx, B) for _ in range(4)]
 for w in wks: w.infer(idx, dense)
-def per_launch_ms(act, reps=60):
-    for w in act: w.fc_layer_repeat(B, 0, 10)
+def per_launch_ms(act, reps=60, layer=0):
+    for w in act: w.fc_layer_repeat(B, layer, 10)
     for w in act: w.sync()
     stops = [None]*len(act)
     def run_one(i, w):
-        w.timer_start(); w.fc_layer_repeat(B, 0, reps); stops[i] = w.timer_stop_ms()
+        w.timer_start(); w.fc_layer_repeat(B, layer, reps); stops[i] = w.timer_stop_ms()
     th = [threading.Thread(target=run_one, args=(i, w)) for i, w in enumerate(act)]
     [t.start() for t in th]; [t.join() for t in th]
     return float(np.mean(stops))/reps
@@ -38,4 +38,6 @@ rate(wks)
 for rep in range(4):
     a, p = per_launch_ms(wks[:1]), per_launch_ms(wks[:2])
     r4, r1 = rate(wks), rate(wks[:1])
+    f1, f4 = per_launch_ms(wks[:1], layer=1), per_launch_ms(wks, layer=1)
+    print("FC2 per launch: alone %.1f us, four workers at once %.1f us -> %.2f kernels resident on average" % (1e3 * f1, 1e3 * f4, 4 * f1 / f4))
     print("FC1 per launch: alone %.1f us, beside a second worker %.1f us (ratio %.3f)   chains: four %.1f M inf/s, one %.1f M (gain %.2f)" % (1e3*a, 1e3*p, p/a, r4/1e6, r1/1e6, r4/r1))
