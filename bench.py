@@ -42,8 +42,8 @@ MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0}   # dense MFMA peak
 SEED_TABLES, SEED_IDX, SEED_WEIGHTS = 0xF1EE7, 1234, 99
 N_IDX_BUFFERS = 64           # distinct index buffers rotated through (>= 32), so caches are not re-hit artificially
 STEADY_S = 2.2               # minimum wall clock of the timed region behind `value`
-PROFILE_ROUND = "r05"       # prefix of the committed rocprofv3 summaries the roofline objects quote (profiles/<round>_*_kernel_stats.csv)
-PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json")]   # newest first, entry by entry (see pmc())
+PROFILE_ROUND = "r06"       # prefix of the committed rocprofv3 summaries the roofline objects quote (profiles/<round>_*_kernel_stats.csv)
+PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json")]   # newest first, entry by entry (see pmc())
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -288,7 +288,7 @@ def pmc(key, field=None):
 
 def find_profile(suffix):
     """Newest committed rocprofv3 summary profiles/rNN_<suffix> (this round's, else an earlier round's for legs whose kernel did not change)."""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         if os.path.exists(os.path.join(ROOT, "profiles", "%s_%s" % (rnd, suffix))):
             return "%s_%s" % (rnd, suffix)
     return "%s_%s" % (PROFILE_ROUND, suffix)
@@ -1695,8 +1695,16 @@ def main():
                     dik = [fr.DeviceBuffer.from_numpy(cbk, a) for a in ihk]
                     ddk = [fr.DeviceBuffer.from_numpy(cbk, a) for a in dhk]
                     for prec in ("bf16", "fp8"):
-                        result["configs"].append(leg_config(fr, cbk, mcb, BC, prec, dik, ddk, ihk[0], dhk[0], args.threads, args.depth,
-                                                            "Model-C batch=4096, %s FC chain end to end, ONE index per bank (FR_INDEX_PER_BANK, 82 banks)" % prec, tag="C4096_%s_per_bank" % prec))
+                        leg = leg_config(fr, cbk, mcb, BC, prec, dik, ddk, ihk[0], dhk[0], args.threads, args.depth,
+                                         "Model-C batch=4096, %s FC chain end to end, ONE index per bank (FR_INDEX_PER_BANK, 82 banks); the in-chain gather reads the "
+                                         "operand-type bank image (bank rows already %s: 82 lines per item instead of 142)" % (prec, "bf16" if prec == "bf16" else "e4m3"),
+                                         tag="C4096_%s_per_bank" % prec)
+                        # round 6: what the image costs in HBM, and the committed kernel-level A/B of the chain's gather launch (image on / off)
+                        leg["lp_bank_image"] = {"bytes": cbk.lp_bank_image_bytes(), "fp32_table_bytes": int(mcb.table_bytes()),
+                                                "gather_kernel_us_image_on": profiled_avg_us("r06_lp_image_%s_img1_lone_kernel_stats.csv" % prec, "fr_pipeline_kernel<0, %d>" % (1 if prec == "bf16" else 2)),
+                                                "gather_kernel_us_image_off": profiled_avg_us("r06_lp_image_%s_img0_lone_kernel_stats.csv" % prec, "fr_pipeline_kernel<0, %d>" % (1 if prec == "bf16" else 2)),
+                                                "profiles": "profiles/r06_lp_image_%s_img{0,1}_{lone,chains}_kernel_stats.csv" % prec}
+                        result["configs"].append(leg)
                 cbk.close()
         except Exception as ex:  # the main metric must still be reported
             result.setdefault("gather", {})["error"] = repr(ex)
