@@ -26,7 +26,7 @@ LAYOUT_SEMANTIC, LAYOUT_BLOCKED = 0, 1
 INDEX_PER_TABLE, INDEX_PER_ITEM, INDEX_PER_BANK = 0, 1, 2
 SEG_TABLE, SEG_COPY, SEG_DENSE = 0, 1, 2
 GATHER_WORD_MAJOR, GATHER_ITEM_TILE, GATHER_ITEM_TILE_DEDUP, GATHER_ITEM_TILE_DEDUP_COUNT, GATHER_WORD_MAJOR_ONE_CHUNK = 0, 1, 2, 3, 4
-ABI_VERSION = 5   # include/fleetrec.h FR_ABI_VERSION this binding was written against
+ABI_VERSION = 6   # include/fleetrec.h FR_ABI_VERSION this binding was written against
 MEM_CLASS_NAMES = {0: "HBM", 1: "DDR", 2: "PLRAM"}
 
 

@@ -33,7 +33,10 @@ extern "C" {
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 #endif
 
-/* 5 (round 5): fr_ctx_create(device = -1) = the CPU back-end, fr_cpu_set_threads; fr_ctx_set_chain_width / fr_ctx_chain_width (the GEMM tile
+/* 6 (round 6): fr_comm_init_all over CPU shard contexts = the in-process host exchange (the table-sharded step with G > 1 ranks without G GPUs);
+ * fleetrec_diag.h gains fr_worker_inject_fc_failure, fr_ctx_set_lp_bank_image / fr_ctx_lp_bank_image_bytes (the operand-type bank image);
+ * fr_ctx_set_fc_precision / fr_worker_create may succeed with a "note:" in fr_last_error().
+ * 5 (round 5): fr_ctx_create(device = -1) = the CPU back-end, fr_cpu_set_threads; fr_ctx_set_chain_width / fr_ctx_chain_width (the GEMM tile
  * shape of a chain model no longer follows the number of live workers).
  * 4 (round 4): the surface is three headers -- this one (the three spans of thread_consume() that SURVEY section 8(b) cuts, the request
  * driver core and the table-sharded mode), fleetrec_serving.h (host-fed streaming / serving extensions) and fleetrec_diag.h (measurement
@@ -41,7 +44,7 @@ extern "C" {
  * the collectives.  3 (round 3): fr_ctx_set_stream_group is per context (1..256), groups below 12 ride the stage pipeline;
  * FR_INDEX_PER_BANK stores bank-interleaved tables; the library reads no environment variable.  A binding must refuse a library whose
  * fr_abi_version() differs from the header it was written against (the Python binding does, also for a build loaded through FR_LIB). */
-#define FR_ABI_VERSION 5
+#define FR_ABI_VERSION 6
 
 typedef enum fr_status {
     FR_OK = 0,
