@@ -43,7 +43,7 @@ SEED_TABLES, SEED_IDX, SEED_WEIGHTS = 0xF1EE7, 1234, 99
 N_IDX_BUFFERS = 64           # distinct index buffers rotated through (>= 32), so caches are not re-hit artificially
 STEADY_S = 2.2               # minimum wall clock of the timed region behind `value`
 PROFILE_ROUND = "r06"       # prefix of the committed rocprofv3 summaries the roofline objects quote (profiles/<round>_*_kernel_stats.csv)
-PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json")]   # newest first, entry by entry (see pmc())
+PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r06_pmc.json", "r05_pmc.json", "archive/r04_pmc.json", "archive/r03_pmc.json", "archive/r02_pmc.json")]   # newest first, entry by entry (see pmc())
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -273,7 +273,7 @@ def fc_flops_per_inference(fc):
 
 
 def pmc(key, field=None):
-    """Committed PMC summary (tools/pmc_passes.sh -> profiles/r02_pmc.json): separate rocprofv3 --pmc passes of this script's legs,
+    """Committed PMC summary (tools/pmc_passes.sh -> profiles/archive/r02_pmc.json): separate rocprofv3 --pmc passes of this script's legs,
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md.  -> the entry, one field of it, or None."""
     for path in PMC_FILES:
         try:
@@ -281,14 +281,14 @@ def pmc(key, field=None):
         except Exception:
             e = None
         if e is not None:
-            e = dict(e, pmc_file="profiles/" + os.path.basename(path))
+            e = dict(e, pmc_file=os.path.relpath(path, ROOT))
             return e if field is None else e.get(field)
     return None
 
 
 def find_profile(suffix):
     """Newest committed rocprofv3 summary profiles/rNN_<suffix> (this round's, else an earlier round's for legs whose kernel did not change)."""
-    for rnd in ("r06", "r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "archive/r04", "archive/r03", "archive/r02"):   # (rounds 1-4 live under profiles/archive/)
         if os.path.exists(os.path.join(ROOT, "profiles", "%s_%s" % (rnd, suffix))):
             return "%s_%s" % (rnd, suffix)
     return "%s_%s" % (PROFILE_ROUND, suffix)
@@ -335,7 +335,7 @@ def steady_run(run_fn, min_s, n_first=4096, env=None, quantum=256):
 def bf16_launch_group(B):
     """Batches per launch of the bf16 rows (fr_ctx_set_stream_group; the context's default is 64): 131072 items, at most 256 batches -- Model-B
     batch 1024: 128 (8 tiles per persistent workgroup: 340 M inf/s against 330 M at 64), Model-A batch 256: 256 (489 against 435 M);
-    profiles/r03_fused_hs_items_ab.txt, profiles/r03_group_above_64_ab.txt.  Every row says which group it ran at."""
+    profiles/archive/r03_fused_hs_items_ab.txt, profiles/archive/r03_group_above_64_ab.txt.  Every row says which group it ran at."""
     return max(64, min(256, 131072 // B))
 
 
@@ -1446,7 +1446,7 @@ def main():
         # ---- PCIe-inclusive rates (index rows start in HOST memory, scores end in HOST memory; reported, never `value`) ----
         # host threads of these legs = the reference's THREAD_NUM = 4 (constant.h:42): every pushed batch is first copied into pinned
         # staging by its driver thread (the counterpart of the reference's read() into pinned memory), and two threads cannot stage
-        # 13 GB/s of index rows (measured: 2 x 2 workers 60.7 M inf/s, 4 x 2 workers 67.1 M, profiles/r02_experiments.md section 5)
+        # 13 GB/s of index rows (measured: 2 x 2 workers 60.7 M inf/s, 4 x 2 workers 67.1 M, profiles/archive/r02_experiments.md section 5)
         ht = max(args.threads, 4)
         hd = fr.Driver(ctx, ht, 4, B)
         hd.run_host(B, 200, idx_host)
@@ -1621,7 +1621,7 @@ def main():
             for prec in ("bf16", "fp8"):
                 # bf16: a launch group of 256 batches = four 64-item tiles per compute unit per launch, which is what the persistent kernel
                 # (fr_fused_tile_hs_kernel) needs to overlap one tile's gather with another's FC phases; at the default 64 (one tile per compute
-                # unit, the chunked kernel) the same leg gives 434-436 M inf/s against 489 M (profiles/r03_group_above_64_ab.txt)
+                # unit, the chunked kernel) the same leg gives 434-436 M inf/s against 489 M (profiles/archive/r03_group_above_64_ab.txt)
                 ga = bf16_launch_group(B) if prec == "bf16" else 64
                 ca.set_stream_group(ga)
                 cfgs.append(leg_config(fr, ca, ma, B, prec, dia, None, iha[0], None, args.threads, args.depth,

@@ -233,7 +233,7 @@ class Model:
     def placement_report(self, l2_bytes=4 << 20, mall_bytes=256 << 20):
         """Where each table will live on MI355X when accessed uniformly, and what the gather costs per item: the
         MicroRec/FleetRec placement question (on-chip PLRAM vs HBM vs DDR banks) mapped onto L2 / Infinity Cache / HBM.
-        A row costs one 128-byte line beyond L2 whatever its size (profiles/r01_experiments.md)."""
+        A row costs one 128-byte line beyond L2 whatever its size (profiles/archive/r01_experiments.md)."""
         tabs = self.tables()
         order = sorted(range(len(tabs)), key=lambda t: tabs[t].rows * tabs[t].dim * 4)
         cum, out = 0, []

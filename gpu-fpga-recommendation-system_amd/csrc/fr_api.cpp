@@ -251,7 +251,7 @@ static int build_words(fr_ctx *c) {
         // Bank-interleaved regions: the resident tables of one bank share "bank rows" -- row r of every table side by side -- for the
         // rows every one of them has (r < min rows = the valid range of the bank's index); one bank costs one contiguous fetch per
         // item.  The bank-row stride is padded when that lowers the expected number of 128-byte lines a row touches (112 -> 128,
-        // 224 -> 256 bytes: a fetch beyond L2 costs whole lines, profiles/r01_experiments.md).
+        // 224 -> 256 bytes: a fetch beyond L2 costs whole lines, profiles/archive/r01_experiments.md).
         for (int b = 0; b < c->n_banks; b++) {
             std::vector<int> members;
             size_t payload = 0;
@@ -855,12 +855,12 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
     {
         // A model that runs the stage pipeline (several launches per step: Model-C, sharded contexts) gives its workers hardware queues of
         // their own: the HIP runtime keeps one pool of hardware queues per stream priority, four equal-priority streams share two queues
-        // (profiles/r04_C4096_chain_trace_bf16.txt), and there a small launch of one worker waits behind the other's FC1.  The workers
+        // (profiles/archive/r04_C4096_chain_trace_bf16.txt), and there a small launch of one worker waits behind the other's FC1.  The workers
         // alternate between the HIGHEST and the LOWEST priority, never the default one: those two pools are this library's alone, so the
         // first four workers get four consecutively created queues = one per compute pipe of the command processor (queue id mod 4;
-        // two workers whose queues share a pipe run 10 % behind the others: profiles/r04_stream_queues_after_other_contexts.txt -- with
+        // two workers whose queues share a pipe run 10 % behind the others: profiles/archive/r04_stream_queues_after_other_contexts.txt -- with
         // the default priority in the rotation, a context served earlier in the process had that effect).  Model-C 4096, four workers:
-        // bf16 41.9 -> 43.1 M inf/s, fp8 65.5 -> 68.9 M = what GPU_MAX_HW_QUEUES=8 buys (profiles/r04_stream_priorities_ab.txt).
+        // bf16 41.9 -> 43.1 M inf/s, fp8 65.5 -> 68.9 M = what GPU_MAX_HW_QUEUES=8 buys (profiles/archive/r04_stream_priorities_ab.txt).
         // Fused-kernel models (one launch per group) gain nothing from it and keep the default streams.
         // (a model no fused kernel of any precision serves -- the decision must not depend on the precision the context happens to have now)
         const bool any_fused = frk_fused_ok(m.fc[0], m.fc[1], m.fc[2], m.fc[3]) || frk_fused_h_ok(m.fc[0], m.fc[1], m.fc[2], m.fc[3]) ||
@@ -1307,7 +1307,7 @@ static int pipeline_step(fr_worker *w) {
         // The gather of batch L on the aux stream, enqueued AFTER this step's FC1 launch (batch L - 1, main stream): FC1's 256 workgroups
         // (one per CU: 120 KiB of LDS) take their CUs first and one 56-register gather workgroup fits beside each of them, so the two
         // kernels share every CU for the length of the gather instead of two gathers (or two FC1s) of different workers meeting each other
-        // (kernel trace of round 3's chain, profiles/r04_experiments.md section 1).
+        // (kernel trace of round 3's chain, profiles/archive/r04_experiments.md section 1).
         if (!w->aux) {
             if (FR_KNOB_ONCE("GATHER_AUX_PRIO", 0)) {   // experiment: the gather's stream at the lowest priority
                 int lo = 0, hi = 0;
@@ -1514,7 +1514,7 @@ static int fused_flush(fr_worker *w) {
             if (t_ > max_tiles) max_tiles = t_;
         }
         const int hk = FR_KNOB_ONCE("FUSED_HK", -1);  // experiments build: 0 = never, 1 = whenever it applies
-        // Where the persistent kernel starts to pay (re-measured in round 4, after its scratch was removed: profiles/r04_fused_hs_threshold.txt):
+        // Where the persistent kernel starts to pay (re-measured in round 4, after its scratch was removed: profiles/archive/r04_fused_hs_threshold.txt):
         // K <= 352 (Model-A) level with the chunked kernel at ONE tile per compute unit (451 vs 452 M inf/s, the kernel alone 46.4 vs 49.0 us)
         // and 10-30 % ahead from 1.25 on; K = 880 (Model-B) 5 % behind at one tile (305 vs 320 M), 5 % ahead at 1.25, level at 1.5, 6 % ahead at 2.
         const int hs_from = a.K <= 352 ? c->n_cu : c->n_cu + c->n_cu / 4;
@@ -1793,7 +1793,7 @@ extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_i
     FR_SET_DEVICE(c);
     // Launch groups below FR_FUSED_MIN_GROUP ride the stage pipeline even on a fused-eligible context: a fused launch of g batches takes
     // one item tile's time (~130 us for Model-A) whatever g is, so small groups give 7 M (g = 1) .. 35 M inferences/s (g = 8) at 145 us,
-    // where the pipelined stage launches give 43 M at 36 us (profiles/r02_launch_group_paths.txt).
+    // where the pipelined stage launches give 43 M at 36 us (profiles/archive/r02_launch_group_paths.txt).
     // the fused kernels read the index rows through a buffer resource with 32-bit offsets (out-of-range items come back as 0 without a
     // branch): an index buffer of 4000 MiB or more rides the stage pipeline, whose gather stage has a 64-bit fallback
     const bool idx_fits = (size_t)batch * idx_cols(c) * sizeof(int32_t) < ((size_t)4000 << 20);
@@ -1820,7 +1820,7 @@ extern "C" int fr_worker_push_device(fr_worker *w, int batch, const int32_t *d_i
         // a launch carries at most 16384 items (one 64-item tile per compute unit) -- in the bf16 chain, whose persistent kernel's workgroups
         // overlap the gather of their next tile with the FC phases of the current one, as many as the launch group allows (up to 256 batches
         // of 1024 items): every launch exposes its first tile's gather once (13-14 us), so more tiles per workgroup amortise it -- Model-B
-        // 1024: 330 M inf/s at 4 tiles per workgroup (group 64), 340 M at 8 (group 128), 342 M at 16 (profiles/r03_fused_hs_items_ab.txt)
+        // 1024: 330 M inf/s at 4 tiles per workgroup (group 64), 340 M at 8 (group 128), 342 M at 16 (profiles/archive/r03_fused_hs_items_ab.txt)
         const bool big = c->fc_precision == FR_FC_BF16 || (c->fc_precision == FR_FC_FP8 && FR_KNOB_ONCE("FUSED_HK", -1) == 1);
         const int64_t max_items = FR_KNOB_ONCE("FUSED_ITEMS", 0) ? FR_KNOB_ONCE("FUSED_ITEMS", 0) : (big ? 4096 * 64 : 256 * 64);
         return (w->n_pending >= fused_group(c) || w->pending_items >= max_items || w->n_pending >= FR_FUSED_MAX_QUEUE) ? fused_flush(w) : FR_OK;
@@ -1870,7 +1870,7 @@ extern "C" int fr_worker_submit(fr_worker *w, int batch) {
     // pinned host buffers over PCIe and the output layer writes the scores straight into the pinned score buffer.  Against the
     // reference's H2D / D2H commands (cuda_server.c:460-461,494-495; FR_SUBMIT_ZEROCOPY=0 keeps them) that takes 4-8 us off a submit +
     // sync at every batch size (batch 256: 46.1 -> 38.4 us p50) and costs 5 % of the rate of 16 workers submitting at once
-    // (profiles/r02_submit_latency.txt): this entry point is the latency path, the streaming entry points are the throughput path.
+    // (profiles/archive/r02_submit_latency.txt): this entry point is the latency path, the streaming entry points are the throughput path.
     const int zero_copy = FR_KNOB_ONCE("SUBMIT_ZEROCOPY", 1);
     if (zero_copy) {
         rc = launch_pipeline(w, batch, w->h_idx, c->model.dense_len ? w->h_dense : nullptr, w->h_score);

@@ -743,7 +743,7 @@ __global__ void __launch_bounds__(512) fr_fused_tile_h_kernel(const FrFusedArgs 
     // n tile t) in slot (e + OFF2) % RD with OFF2 = KG % RD -- the slot FC1's tail frees first.  Every index is a compile-time
     // constant (the bodies are unrolled), so the ring stays in registers and hipcc counts the vmcnt waits.  The order of the sums does
     // not depend on RD: scores are bit-identical for every depth.  Depths of 8, 12 and 16 take the same time (the weight stream is not
-    // latency-bound, profiles/r02_experiments.md section 5.4); 12 leaves the registers for the B-fragment ring below.
+    // latency-bound, profiles/archive/r02_experiments.md section 5.4); 12 leaves the registers for the B-fragment ring below.
     static_assert(T2W == 2 && KG >= RD && RD >= 8 && RD <= 32 && RD % 2 == 0, "the stream ring assumes two n tiles per wave in FC2 (32 elements per chunk) and at least RD k groups in FC1");
     constexpr int OFF2 = KG % RD;
     uint4 ring[RD];
@@ -912,7 +912,7 @@ static int fused_h_launch_inst(const FrFusedArgs &a, dim3 grid, size_t lds, hipS
 int frk_fused_h_launch(const FrFusedArgs &a, hipStream_t s) {
     dim3 grid(a.n_batches * a.tiles_per_batch);
     // weight ring 16 (Model-A: 22 k groups per chunk) / 12 (Model-B) fragments, B fragments two groups ahead.  Ring depths 8 / 12 / 16 and
-    // B-ring depths 1 / 2 / 4 take the same time on the chip and return the same bits (profiles/r02_experiments.md section 5.4).
+    // B-ring depths 1 / 2 / 4 take the same time on the chip and return the same bits (profiles/archive/r02_experiments.md section 5.4).
     if (a.K == 352) return fused_h_launch_inst<2, 2, 22, true, 16, 2>(a, grid, fused_h_lds_bytes(a.K, a.H2, a.H3, 2, true), s);
     if (a.K == 880) return fused_h_launch_inst<2, 2, 55, false, 12, 2>(a, grid, fused_h_lds_bytes(a.K, a.H2, a.H3, 2, false), s);
     FR_FAIL(FR_ERR_INVALID, "no bf16 fused instantiation for K=%d", a.K);

@@ -9,7 +9,7 @@
 // A workgroup is 12 waves: 8 CONSUMERS (MFMA) and 4 PRODUCERS (gather), three per SIMD (two consumers + one producer), 168 registers
 // each.  Why separate waves: a wave's vector-memory operations return IN ORDER (one vmcnt), so a wave that streams weights from L2
 // through a register ring AND has HBM-latency row loads outstanding waits for the rows every time it waits for a weight fragment --
-// the 8-symmetric-wave form of this kernel (round 3, profiles/r03_fused_hk_8wave_stamps.txt) spent 31-36 us in an FC1 whose MFMA
+// the 8-symmetric-wave form of this kernel (round 3, profiles/archive/r03_fused_hk_8wave_stamps.txt) spent 31-36 us in an FC1 whose MFMA
 // work is 11.7 us.  The producers have nothing but the gather in their queue, and their registers ARE the in-flight window: 4 row
 // sets x 8 items x 16 B per thread = 128 KiB of rows on their way per CU, all the time, through every phase of the consumers.
 //
@@ -110,7 +110,7 @@ __device__ __forceinline__ void hk_mma(f32x16 &acc, const uint4 &a4, const uint4
 // slice buffers instead of a ring of two), and the producers gather tile t + 1 while the consumers are anywhere in tile t: E2 of a tile's
 // NSL + D + 1 gather events run under FC2, E3 under FC3, the rest under FC1's first slices (one per slice barrier) -- with the bf16
 // schedule (every event under FC1) the fp8 consumers, whose operand stream is half as long, waited for the gather in every slice
-// (340 M inf/s against the chunked kernel's 398 M, profiles/r03_fused_hs_fp8_ab.txt).
+// (340 M inf/s against the chunked kernel's 398 M, profiles/archive/r03_fused_hs_fp8_ab.txt).
 // SRC = 1 (bf16, round 6): a.words address the OPERAND-TYPE row image (fr_ctx::lp_arena: every table / bank row once more as bf16, made with
 // the rounding W_op applies) -- a row word is 8 bytes, a row set costs half the registers, so D = 4 sets ride where 2 did; W_op stores the
 // words as they come.  Dense words (the request's fp32 features) are converted by the lane that loads them.  Same X image, bit for bit.
@@ -705,9 +705,9 @@ static int fused_hk_launch_inst(const FrFusedArgs &a, int n_cu, hipStream_t s) {
 // workgroup per CU
 int frk_fused_hk_launch(const FrFusedArgs &a, int n_cu, int precision, hipStream_t s) {
     if (precision == FR_FC_FP8) {
-        // The fp8 form is built into the EXPERIMENTS library only: it is correct (tests/test_gpu_parity.py::test_fp8_persistent_fused_kernel_many_tiles
+        // The fp8 form is built into the EXPERIMENTS library only: it is correct (tests/test_gpu_lowprec.py::test_fp8_persistent_fused_kernel_many_tiles
         // under FR_LIB=libfleetrec_exp.so FR_FUSED_HK=1) and SLOWER than the chunked fr_fused_tile_f8_kernel (Model-B 1024: 340 vs
-        // 398-400 M inf/s, profiles/r03_fused_hs_fp8_ab.txt) -- with the consumers twice as fast as in bf16, the gather, which only runs
+        // 398-400 M inf/s, profiles/archive/r03_fused_hs_fp8_ab.txt) -- with the consumers twice as fast as in bf16, the gather, which only runs
         // under FC1, is what a tile waits for.
 #ifdef FR_EXPERIMENTS
         if (a.K == 880) {   // Model-B: K 880 -> 896 = 28 k-groups of 32, 14 slices of 2; 4 row sets in flight; 19 gather events per tile

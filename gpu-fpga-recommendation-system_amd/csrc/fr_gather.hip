@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) gather_pack_kernel(const FrWordDesc *__re
 // round-robin over the 8 XCDs; a speed assumption only), and each group owns a fixed contiguous run of the record words for
 // ALL items (FrGatherGroups: cut on source-row boundaries, so no table row / bank row is fetched by two XCDs).  Every table is then
 // touched from ONE XCD only, so the 8 x 4 MiB L2s cache 8 different table sets instead of 8 copies of the same hottest 4 MiB --
-// rows served by L2 cost ~5 cycles/CU instead of ~12 from the fabric (profiles/r01_experiments.md, ta_cost2).
+// rows served by L2 cost ~5 cycles/CU instead of ~12 from the fabric (profiles/archive/r01_experiments.md, ta_cost2).
 template <int ITEMS, int TP, int AUX = 0>
 __global__ void __launch_bounds__(256) gather_pack_xcd_kernel(const FrWordDesc *__restrict__ words, const FrGatherGroups groups,
                                                               const int32_t *__restrict__ idx, int idx_stride,
@@ -247,7 +247,7 @@ static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &grou
     (void)n_rec_bytes;
     if constexpr (ITEMS == 4 || ITEMS == 2) {
         // default: the software-pipelined form, 2 chunks per workgroup, write-through record stores while the records fit the Infinity
-        // Cache with room to spare (profiles/r02_gather_stream_sweep.txt: Model-C batch 4096 per-bank 25.2 -> 22.0 us; beyond ~200 MB of
+        // Cache with room to spare (profiles/archive/r02_gather_stream_sweep.txt: Model-C batch 4096 per-bank 25.2 -> 22.0 us; beyond ~200 MB of
         // records write-back stores are as fast or 1-2 % faster).  Experiments build only: FR_GATHER_STREAM = chunks per workgroup,
         // FR_GATHER_STORE = 0 write-back / 16 write-through, both read per launch.
         const int nstep = FR_KNOB("GATHER_STREAM", stream_form);
@@ -257,7 +257,7 @@ static int gather_launch_xcd(const FrWordDesc *words, const FrGatherGroups &grou
             const int st_knob = FR_KNOB("GATHER_STORE", -1);
             const bool wt = st_knob >= 0 ? st_knob == 16 : out_bytes <= ((size_t)200 << 20);
             const bool lead = FR_KNOB("GATHER_LEAD", 0) != 0;   // experiments build: one index load per run of lanes sharing an index column (slower: 22.3 -> 22.9 us)
-#ifdef FR_EXPERIMENTS   /* the LEAD instantiations exist in the experiments build only (measured slower: profiles/r03_experiments.md) */
+#ifdef FR_EXPERIMENTS   /* the LEAD instantiations exist in the experiments build only (measured slower: profiles/archive/r03_experiments.md) */
 #define FR_G_LEAD(NS)                                                                                                                       \
             if (wt) gather_pack_stream_kernel<ITEMS, NS, TP, 16, true><<<g2, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, (unsigned)out_bytes); \
             else gather_pack_stream_kernel<ITEMS, NS, TP, 0, true><<<g2, dim3(bx), 0, s>>>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, (unsigned)out_bytes);
@@ -325,7 +325,7 @@ static int gather_launch(const FrWordDesc *words, int n_words, const FrGatherGro
             groups.max_words = wpg;
         }
         if (groups.max_words <= 256) {
-            switch (FR_KNOB("GATHER_ITEMS", 4)) {  // 4 items per thread: fastest in the r02 sweep (profiles/r02_gather_sweep.txt)
+            switch (FR_KNOB("GATHER_ITEMS", 4)) {  // 4 items per thread: fastest in the r02 sweep (profiles/archive/r02_gather_sweep.txt)
 #ifdef FR_EXPERIMENTS
                 case 1: return gather_launch_xcd<1, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words, stream_form);
                 case 2: return gather_launch_xcd<2, TP>(words, groups, idx, idx_stride, dense, out, batch, err_flag, scale, s, n_words, out_words, stream_form);

@@ -17,7 +17,7 @@ constexpr int FR_GN = 128, FR_GR = 8, FR_GSTAGES = 2;
 // MU = m tiles per wave: 2 -> block tile 128 x 256 (64 x 64 wave tiles), 1 -> 128 x 128 (64 x 32 wave tiles) for layers with too few
 // 128 x 256 tiles to cover the chip (Model-C FC2 / FC3 at batch 4096).  Two K steps in LDS (64 / 96 KiB): the loads of step s+1 are in
 // flight during the MFMAs of step s, and a 32 KiB stage-pipeline workgroup of another stream still fits beside the workgroup.
-// (Three steps, 144 KiB, were 10 % faster alone and slower overall: profiles/r01_experiments.md.)
+// (Three steps, 144 KiB, were 10 % faster alone and slower overall: profiles/archive/r01_experiments.md.)
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(512) fc_pp_gemm_n128_kernel(const uint4 *__res
 // fc_gemm_gather_kernel<PREC>: north_star's "fused concat + first FC" for the model whose record does not fit a CU (Model-C, batch 4096,
 // bf16 / fp8): the FC1 GEMM of batch L - 1 (fc_lp_gemm_kernel's 128 x 256 tile body, 8 consumer waves) and the GATHER of batch L (4
 // producer waves, one per SIMD) in ONE workgroup, so the two share every CU for the length of the kernel by construction -- the
-// separately launched gather met another stream's gather, not a GEMM (profiles/r04_experiments.md section 1).  A 128 x 256 tile cannot
+// separately launched gather met another stream's gather, not a GEMM (profiles/archive/r04_experiments.md section 1).  A 128 x 256 tile cannot
 // gather its own operand (16 n tiles share an item tile: 16 x the row fetches), hence the stage pipeline's shift by one batch: the
 // producers write the q8 / q16 operand image of the NEXT launch's FC1 to HBM.
 //   producers: the batch is cut into half-tiles of 16 items x 64 record words; producer wave p of workgroup b owns half-tiles
@@ -623,7 +623,7 @@ __device__ __forceinline__ void gg_producer(const FrGatherJob &g, uint4 *patch, 
     // Word descriptors: fetched ONE EVENT AHEAD (raw, q0 / q1) and decoded when the half-tile's index event runs -- fetched inside the
     // event, the dependent chain descriptor -> index address put an s_waitcnt vmcnt(0) behind the 16 row loads the same event had just
     // issued (a wave's loads return in order), and every such wait held all 12 waves at the next s_barrier: the fused kernel took as
-    // long as the GEMM and the gather one after the other (profiles/r04_experiments.md section 1.6).
+    // long as the GEMM and the gather one after the other (profiles/archive/r04_experiments.md section 1.6).
     uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0;
     uint64_t d_base = 0;   // decoded descriptor of the half-tile whose rows are requested next
     uint32_t d_stride = 0, d_rows = 0;
@@ -911,7 +911,7 @@ __global__ void __launch_bounds__(512) fc_gemm_pipe_kernel(const uint4 *__restri
     // STAGGER (order 1, default): the two waves of a SIMD (w and w + 4) would otherwise do the same thing at the same time -- issue
     // DMAs (expensive beside other memory instructions), read fragments, and only then both want the matrix pipe.  Waves 0-3 issue and
     // read first and multiply afterwards, waves 4-7 multiply the moment the barrier opens and read / issue afterwards: one partner's
-    // memory instructions hide behind the other's MFMAs (Model-C FC1 bf16: 57.5 -> 52.9 us; profiles/r02_gemm_experiments.md).
+    // memory instructions hide behind the other's MFMAs (Model-C FC1 bf16: 57.5 -> 52.9 us; profiles/archive/r02_gemm_experiments.md).
     const int order = (ablate >> 4) & 15;  // experiment knob FR_GEMM_ORDER: 0 = every wave multiplies first, 1 = stagger, 2 = every wave issues + reads first
     const bool early = order == 2 || (order == 1 && wave < 4);
     int rd_grp = 1;                      // group to prefetch next, counted inside the ring of NS * G groups
@@ -1251,14 +1251,14 @@ static int lp_gemm_mu(int precision, int K, int N, int ldm, int width = 1, bool 
     // EXPERIMENTS build only (FR_LP_GEMM_SPLITK=1): measured on Model-C 4096 with four streams, the split-K kernels are no faster end to
     // end in bf16 (37.0 vs 37.2 M inf/s) and slower in fp8 (55 vs 58-60 M): alone on the chip they would stream a layer's bytes once, but
     // one wave per SIMD with 320-490 registers shares a CU with nothing, and this chain lives on four streams' kernels sharing CUs
-    // (profiles/r03_experiments.md section 4)
+    // (profiles/archive/r03_experiments.md section 4)
     if (FR_KNOB_ONCE("LP_GEMM_SPLITK", 0)) {
         if (s128 >= 192 && s128 <= 512) return 4;
         if (s64 >= 128 && s64 <= 512) return 5;
     }
     // 256 (n) x 256 (m) tiles when THEY cover the chip (batch 8192 of Model-C's FC1: 8 x 32): a third fewer operand bytes per output through
     // the CU's vector-memory return path, which is what the 128 x 256 kernel keeps busy (texture data return busy 0.73, MFMA busy 0.50:
-    // profiles/r04_pmc_gemm_bf16.json); bf16 / fp8 only (the fp32 kernel is MFMA-bound)
+    // profiles/archive/r04_pmc_gemm_bf16.json); bf16 / fp8 only (the fp32 kernel is MFMA-bound)
     const long t256sq = (N % 256 || ldm % 256) ? 0 : (long)(N / 256) * (ldm / 256);
     // `width` = the context's chain width W (fr_ctx_set_chain_width; frozen at min(live workers, 4) by the context's first low-precision
     // GEMM-layer launch otherwise).  The larger tile is taken as soon as it covers 1 / W
@@ -1266,7 +1266,7 @@ static int lp_gemm_mu(int precision, int K, int N, int ldm, int width = 1, bool 
     // part-chip launches of the cheaper tile (fewer operand bytes per output through the CU's vector-memory path) share the chip where W
     // full-chip launches time-share every CU.  Model-C batch 4096, four workers: FC1 8 x 16 tiles of 256 x 256 (for 256 of 128 x 256), FC2
     // 4 x 16 of 128 x 256 (for 256 of 64 x 128), FC3 2 x 32 of 128 x 128: bf16 38.4 -> 44.5 M inf/s, fp8 62.6 -> 69.0 M; a lone worker on
-    // half-chip tiles would lose 15-18 % (profiles/r04_C4096_half_chip_tiles_ab.txt).  bf16 / fp8 only (the fp32 kernel is MFMA-bound).
+    // half-chip tiles would lose 15-18 % (profiles/archive/r04_C4096_half_chip_tiles_ab.txt).  bf16 / fp8 only (the fp32 kernel is MFMA-bound).
     const int part_knob = FR_KNOB_ONCE("LP_GEMM_PART", -1);   // experiment knob: the divisor (1 = full-chip tiles only, 2, 4), whatever the worker count
     const int part = precision == FR_FC_FP32 ? 1 : (part_knob > 0 ? part_knob : (width < 1 ? 1 : (width > 4 ? 4 : width)));
     const long full = 192 / part;
@@ -1393,11 +1393,11 @@ static int lp_gemm_tile(int mu, const void *Wp, const void *Xp, void *Yp, int KE
 // FC1 of one batch + the gather of the next in one launch (fc_gemm_gather_kernel): for layers the 128 x 256 tile takes, bf16 / fp8
 bool frk_fc_gemm_gather_ok(int precision, int K, int N, int ldm) {
     if (precision != FR_FC_BF16 && precision != FR_FC_FP8) return false;
-    // EXPERIMENTS build only (FR_GEMM_GATHER=1).  Correct (tests/test_gpu_parity.py::test_model_c_streaming_gather_inside_fc1: operand image and
+    // EXPERIMENTS build only (FR_GEMM_GATHER=1).  Correct (tests/test_gpu_lowprec.py::test_model_c_streaming_gather_inside_fc1: operand image and
     // fp8 scores bit for bit) and SLOWER: alone on one stream the fused launch takes as long as the GEMM and the gather one after the other
     // (bf16 102.7 us against 63.1 + 37.7; fp8 66.3 against 32.8 + 35.8), in the four-stream chain bf16 38.1 -> 33.7 M inf/s, fp8 60.6 -> 50.1 M.
     // The two do not overlap inside a CU: the GEMM's operand DMA and the gather's row fetches go through the same vector-memory path, and a
-    // wave-private producer still gates all 12 waves at every s_barrier (profiles/r04_experiments.md section 1.2).
+    // wave-private producer still gates all 12 waves at every s_barrier (profiles/archive/r04_experiments.md section 1.2).
     if (FR_KNOB_ONCE("GEMM_GATHER", 0) == 0) return false;
     return lp_gemm_mu(precision, K, N, ldm) == 2;
 }

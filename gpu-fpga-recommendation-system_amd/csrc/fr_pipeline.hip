@@ -387,7 +387,7 @@ __device__ __forceinline__ void gather_tr_stream_lp_body(const FrPipeArgs &a, co
 }
 
 // 2 = gather_tr_stream_body (two tiles per workgroup, write-through image stores: Model-C batch 4096 chain 55 -> 58 M inf/s in fp8,
-// 35.7 -> 37 M in bf16, profiles/r02_gather_tr_variants.txt); 1 = gather_tr_body (FR_GATHER_TR_VARIANT=1, and index buffers >= 4000 MiB)
+// 35.7 -> 37 M in bf16, profiles/archive/r02_gather_tr_variants.txt); 1 = gather_tr_body (FR_GATHER_TR_VARIANT=1, and index buffers >= 4000 MiB)
 int frk_gather_tr_variant(int batch, int idx_stride) {
     const int v = FR_KNOB_ONCE("GATHER_TR_VARIANT", 2);  // experiment knob
     return (v == 1 || (size_t)batch * (size_t)idx_stride * 4 >= ((size_t)4000 << 20)) ? 1 : 2;

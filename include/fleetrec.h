@@ -244,11 +244,11 @@ int fr_ctx_set_fp8_act_exponents(fr_ctx *ctx, const int act_exp[4]);
  * its own -- the k-th worker EVER created on the context takes the highest (k even) or the lowest (k odd) stream priority, never the
  * default one.  Side effect across contexts of one process: a lowest-priority worker can be held back by default-priority streams of
  * other contexts or of a host framework, a highest-priority one runs ahead of them (measured on this chip: the priority only selects the
- * queue pool, profiles/r04_experiments.md section 6.7); fused-kernel models (A, B) keep default-priority streams. */
+ * queue pool, profiles/archive/r04_experiments.md section 6.7); fused-kernel models (A, B) keep default-priority streams. */
 int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out);
 /* Chain width W (1..4) of a chain model: its bf16 / fp8 GEMM layers use tiles that cover 1 / W of the chip, so that W workers' chains run
  * side by side on part-chip tiles (fewer operand bytes per output) instead of time-sharing every compute unit: Model-C batch 4096, W = 4:
- * bf16 +16 %, fp8 +10 %; a lone busy worker at W = 4 loses 15-18 % (profiles/r04_C4096_half_chip_tiles_ab.txt).  CONTRACT: the width is
+ * bf16 +16 %, fp8 +10 %; a lone busy worker at W = 4 loses 15-18 % (profiles/archive/r04_C4096_half_chip_tiles_ab.txt).  CONTRACT: the width is
  * decided ONCE per context -- by this call, or else by the context's first low-precision GEMM-layer launch of a submit / push path, which
  * freezes it at min(workers alive at that moment, 4) (calibration batches and fleetrec_diag.h's single-layer launches freeze nothing; a
  * fr_worker_create that makes the workers outnumber a width frozen that way succeeds and leaves a note in fr_last_error()) -- and never
@@ -256,7 +256,7 @@ int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out);
  * change because an unrelated worker was created or destroyed.  Call it again only on purpose: it takes effect from the next launch on,
  * and in bf16 the tile shape fixes the summation order (<= 1e-2 relative between widths; fp8 and fp32 scores are bit-identical for every
  * width; width = 0 makes the context undecided again).  fr_ctx_chain_width: the current value, 0 while undecided.  Set W = 1 if a runtime update should ever stop giving the
- * workers hardware queues of their own (tests/test_gpu_parity.py::test_chain_workers_run_their_layers_side_by_side guards that). */
+ * workers hardware queues of their own (tests/test_gpu_chain.py::test_chain_workers_run_their_layers_side_by_side guards that). */
 int fr_ctx_set_chain_width(fr_ctx *ctx, int width);
 int fr_ctx_chain_width(const fr_ctx *ctx);
 void fr_worker_destroy(fr_worker *w);

@@ -56,7 +56,7 @@ int fr_worker_flush(fr_worker *w);
  * the whole chip per layer -- instead of the fused item-tile kernel (133 us for any number of batches up to a chip-full).  Such batches
  * get fr_worker_submit's scores bit for bit (the fused kernel sums in another order: equal to ~1e-6, not bit for bit).
  * fleetrec_server --stream --reply sets 8 (4 requests in flight per connection: 18 M inferences/s at 185 us request -> reply, against
- * 14 M at 245 us with five launches per batch; profiles/r02_tcp_reply_small_blocks.txt). */
+ * 14 M at 245 us with five launches per batch; profiles/archive/r02_tcp_reply_small_blocks.txt). */
 int fr_ctx_set_small_block(fr_ctx *ctx, int max_batches);
 int fr_worker_host_poll(fr_worker *w, long long *delivered);
 /* Host-fed batches queued in the block being filled (not launched yet) / launched and not delivered yet, and the number of launched

@@ -36,6 +36,27 @@ def gpu(fr):
     return 0
 
 
+@pytest.fixture(scope="session")
+def ctxs(fr, gpu):
+    """Full-size Model A / B / C contexts (1.4 / 15.1 / 63.2 GB of tables), created lazily, shared by every tests/test_gpu_*.py module of the
+    session (a test that changes a context's precision, chain width or tables puts them back in a `finally`)."""
+    from gpu_helpers import SEED_TABLES, SEED_WEIGHTS
+    cache = {}
+
+    def get(which):
+        if which not in cache:
+            m = fr.Model.builtin(which)
+            c = fr.Context(m, device=gpu)
+            c.fill_tables(fr.FILL_HASH, SEED_TABLES)
+            c.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+            cache[which] = (m, c)
+        return cache[which]
+
+    yield get
+    for m, c in cache.values():
+        c.close()
+
+
 def free_port_block(n=1):
     """A base port such that base .. base+n-1 could all be bound right now (the GPU host's network namespace may be shared with
     other jobs, so fixed port numbers are not safe)."""

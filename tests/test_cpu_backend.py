@@ -1,6 +1,6 @@
 """The CPU back-end behind the same symbols (fr_ctx_create(..., device = -1); SURVEY section 8(b), BASELINE configs[0]): the library's
 own host code (csrc/fr_cpu.cpp) against the oracle.  Runs without a GPU.  Bar: records bit-exact; fp32 scores within 2e-6 of the
-fp64-accumulating oracle (max-abs over max|ref|, as in tests/test_gpu_parity.py: a k-ordered fp32 chain over K = 3968 terms carries ~1e-6
+fp64-accumulating oracle (max-abs over max|ref|, as in tests/test_gpu_*.py: a k-ordered fp32 chain over K = 3968 terms carries ~1e-6
 of rounding by itself -- the oracle's own fp32 chain sits at 0.8e-6 from its fp64 one); the reference's known answers exact."""
 import ctypes
 import os
@@ -329,10 +329,7 @@ def test_random_custom_models(fr, seed):
     """User-defined models (the run-time counterpart of the reference's generated constants.hpp) on the CPU back-end: random tables,
     an optional dense block, COPY pads, random FC widths; tables and weights uploaded from the host.  The record against its semantic
     definition (concatenate the segments), bit for bit; the scores against an fp64 chain of the same weights."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("gpu_parity_helpers", os.path.join(ROOT, "tests", "test_gpu_parity.py"))
-    helpers = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(helpers)
+    import gpu_helpers as helpers     # (the random-model generator the GPU suite uses: tests/gpu_helpers.py)
     rng = np.random.default_rng(1000 + seed)
     m, segs, fcw = helpers._random_model(fr, rng, 64 if seed % 2 == 0 else 32)
     ctx = fr.Context(m, device=CPU)

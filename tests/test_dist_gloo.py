@@ -205,7 +205,7 @@ def test_compact_line_of_a_full_result_stays_under_4k():
     spec = importlib.util.spec_from_file_location("bench_for_line_test", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_line_driver_cmd.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "archive", "r03_bench_line_driver_cmd.json")))
     assert len(json.dumps(full)) > 20000
     for i, c in enumerate(full["configs"]):
         c["tag"] = "row%d_%s" % (i, c["dtype"])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The two figures tests/test_gpu_parity.py::test_chain_workers_run_their_layers_side_by_side asserts on, printed (Model-C 4096 bf16, chain width 4):
+"""The two figures tests/test_gpu_chain.py::test_chain_workers_run_their_layers_side_by_side asserts on, printed (Model-C 4096 bf16, chain width 4):
 (1) an FC1 launch's time per stream with a second worker launching beside it / alone; (2) four chains' rate / one chain's rate."""
 import sys, threading, time
 import numpy as np

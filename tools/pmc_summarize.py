@@ -3,7 +3,7 @@
 
 Averages the PMC passes of tools/pmc_passes.sh over the launches of ONE kernel and applies the gfx950 corrections of
 MI355X_MICROARCH.md (HBM): FETCH_SIZE (KB) = TCC_EA0_RDREQ x 64 B counts 128-byte requests at 64 B -> doubled for the read side;
-WRITE_SIZE (KB) is exact for 16-byte-per-lane stores.  The result is merged into the JSON under <key> (profiles/r02_pmc.json is a
+WRITE_SIZE (KB) is exact for 16-byte-per-lane stores.  The result is merged into the JSON under <key> (profiles/archive/r02_pmc.json is a
 committed copy of it; bench.py reads `traffic_bytes_per_launch`, `l2_hit_rate`, `mfma_busy_fraction` from there)."""
 import collections
 import csv
