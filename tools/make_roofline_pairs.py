@@ -1,18 +1,18 @@
 #!/usr/bin/env python3
-"""Builds profiles/rNN_roofline_pairs.json from one evidence job (tools/jobs/r05_evidence.sh): for every profiled leg, the HIP-event launch
+"""Builds profiles/rNN_roofline_pairs.json from one evidence job (tools/jobs/r06_evidence.sh): for every profiled leg, the HIP-event launch
 time the profiled run printed on its own JSON line (stats_<leg>.log) beside the rocprofv3 figures of the same kernel in that run: the
 kernel-stats CSV's average (<leg>_kernel_stats.csv) and, from the same run's kernel trace (<leg>_kernel_durations.json, made by
 tools/trace_kernel_median.py), the MEDIAN duration and the span per launch of the back-to-back run -- the profiler's own equivalent of the
 HIP-event figure.  tools/check_evidence.py checks the same-run pairs.
-usage: python tools/make_roofline_pairs.py [gpurun_out/r05_evidence] [profiles/r05_roofline_pairs.json]"""
+usage: python tools/make_roofline_pairs.py [gpurun_out/r06_evidence] [profiles/r06_roofline_pairs.json]"""
 import csv
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r05_evidence")
-dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r05_roofline_pairs.json")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r06_evidence")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r06_roofline_pairs.json")
 
 
 def line_of(leg):
@@ -35,7 +35,7 @@ def roof_of(leg, d):
 
 
 out = {}
-for leg in ("roofline", "gather_per_table_uniform", "gather_per_bank_uniform", "C4096_f32", "C4096_bf16", "C4096_fp8", "B1024_bf16", "B1024_bf16_per_bank", "B1024_f32",
+for leg in ("roofline", "gather_per_table_uniform", "gather_per_bank_uniform", "C4096_f32", "C4096_bf16", "C4096_fp8", "C4096_bf16_per_bank", "C4096_fp8_per_bank", "B1024_bf16", "B1024_bf16_per_bank", "B1024_f32",
             "A256_bf16", "A256_fp8"):
     if not os.path.exists(os.path.join(src, "stats_%s.log" % leg)):
         continue
