@@ -11,7 +11,7 @@ the span is what HIP events around those launches measure, so THAT pair must agr
 widened the average's tolerance to 6 % to pass two legs -- ADVICE r04).  Median vs HIP events may differ by more where consecutive
 launches overlap (a kernel whose last workgroups trail lets its successor start: span < duration) or where several launches run side by
 side (the Model-C GEMM rows): reported, and checked at 8 %.  Exit status 1 on any violation or when a CSV lacks the kernel.
-usage: python tools/check_evidence.py [profiles/r05_bench_detail_driver_cmd.json]"""
+usage: python tools/check_evidence.py [profiles/r06_bench_detail_driver_cmd.json]"""
 import csv
 import json
 import os
@@ -19,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # round 4: the stdout line is a compact summary; the roofline objects of every leg are in the DETAIL file written beside it
-line = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_bench_detail_driver_cmd.json")
+line = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r06_bench_detail_driver_cmd.json")
 txt = open(line).read().strip()
 d = json.loads(txt) if txt.startswith("{\n") or "\n" in txt[:3] else json.loads(txt.splitlines()[-1])
 
@@ -49,7 +49,7 @@ for k in ("gather", "gather_per_bank"):
             rows.append((k + " zipf", g["zipf_1.05"], g["zipf_1.05"]["profile"]))
 import re
 m_ = re.search(r"(r\d\d)_", os.path.basename(line))
-rnd = m_.group(1) if m_ else "r05"
+rnd = m_.group(1) if m_ else "r06"
 pairs_path = os.path.join(ROOT, "profiles", rnd + "_roofline_pairs.json")
 pairs_by_csv = {}
 if os.path.exists(pairs_path):
