@@ -498,7 +498,14 @@ extern "C" int fr_model_shard_plan(const fr_model_desc *m, int n_shards, int *sl
 }
 
 extern "C" int fr_ctx_create(const fr_model_desc *m, int device, fr_ctx **out) { return fr_ctx_create_sharded(m, device, 0, 1, out); }
-extern "C" void fr_ctx_destroy(fr_ctx *ctx) { ctx_free(ctx); }
+void fr_ctx_ref(fr_ctx *c) {
+    if (c) c->life.fetch_add(1, std::memory_order_relaxed);
+}
+void fr_ctx_unref(fr_ctx *c) {
+    if (c && c->life.fetch_sub(1, std::memory_order_acq_rel) == 1) ctx_free(c);
+}
+// Workers and communicators that are still alive keep the context (its tables, weights, descriptors) until the last of them is destroyed.
+extern "C" void fr_ctx_destroy(fr_ctx *ctx) { fr_ctx_unref(ctx); }
 extern "C" const fr_model_desc *fr_ctx_model(const fr_ctx *ctx) { return ctx ? &ctx->model : nullptr; }
 
 extern "C" int fr_ctx_shard_info(const fr_ctx *ctx, int *shard_rank, int *n_shards, int *slice_offset, int *slice_len,
@@ -757,7 +764,9 @@ extern "C" void fr_worker_destroy(fr_worker *w) {
         if (w->counted) w->ctx->n_workers.fetch_sub(1, std::memory_order_relaxed);
         void *host[] = {w->h_idx, w->h_dense, w->h_score, w->d_records, w->c_scratch, w->c_x, w->d_slice, w->d_gathered, w->d_score_part, w->d_score_all, w->h_sh_status};
         for (void *p : host) free(p);
+        fr_ctx *held = w->counted ? w->ctx : nullptr;
         delete w;
+        fr_ctx_unref(held);   // (the last worker of a context that was already destroyed releases it)
         return;
     }
     if (w->ctx) (void)hipSetDevice(w->ctx->device);
@@ -799,7 +808,9 @@ extern "C" void fr_worker_destroy(fr_worker *w) {
     if (w->ev_start) (void)hipEventDestroy(w->ev_start);
     if (w->ev_stop) (void)hipEventDestroy(w->ev_stop);
     if (w->stream) (void)hipStreamDestroy(w->stream);
+    fr_ctx *held = w->counted ? w->ctx : nullptr;
     delete w;
+    fr_ctx_unref(held);   // (the last worker of a context that was already destroyed releases it)
 }
 
 static size_t idx_cols(const fr_ctx *c) {
@@ -848,6 +859,7 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
         }
         w->h_err = w->d_err = &w->c_err;
         w->counted = true;
+        fr_ctx_ref(ctx);
         ctx->n_workers.fetch_add(1, std::memory_order_relaxed);
         *out = w;
         return FR_OK;
@@ -901,6 +913,7 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
     W_HIP(hipEventCreate(&w->ev_start));
     W_HIP(hipEventCreate(&w->ev_stop));
     w->counted = true;
+    fr_ctx_ref(ctx);
     const int live = ctx->n_workers.fetch_add(1, std::memory_order_relaxed) + 1;
     // A width frozen by an early launch is kept (scores in flight must not change), but the caller is told once per worker that outnumbers
     // it: the call succeeds and fr_last_error() carries the note.

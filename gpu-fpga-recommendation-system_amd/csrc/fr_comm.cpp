@@ -302,11 +302,13 @@ extern "C" int fr_comm_init_rank(fr_ctx *ctx, const void *id128, fr_comm **out) 
     c->rank = ctx->shard_rank;
     c->n_ranks = ctx->n_shards;
     c->ctx = ctx;
+    fr_ctx_ref(ctx);   // (dropped by comm_release: a communicator destroyed after its context touches no freed memory)
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, c->n_ranks, id, c->rank);
     if (r != ncclSuccess) {
         delete c;
+        fr_ctx_unref(ctx);
         FR_FAIL(FR_ERR_COMM, "ncclCommInitRank(rank %d of %d) failed: %s", ctx->shard_rank, ctx->n_shards, g_rccl.GetErrorString(r));
     }
     *out = c;
@@ -358,6 +360,7 @@ extern "C" int fr_comm_init_all(fr_ctx *const *ctxs, int n, fr_comm **out) {
         c->rank = r;
         c->n_ranks = n;
         c->ctx = ctxs[r];
+        fr_ctx_ref(ctxs[r]);
         out[r] = c;
     }
     return FR_OK;
@@ -376,7 +379,9 @@ static void comm_release(fr_comm *c) {
         (void)g_rccl.CommDestroy(c->comm);
     }
     if (c->grp && c->grp->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete c->grp;   // the last of the G handles takes the group along
+    fr_ctx *held = c->ctx;
     delete c;
+    fr_ctx_unref(held);
 }
 
 extern "C" void fr_comm_destroy(fr_comm *c) {

@@ -45,7 +45,9 @@ extern "C" void fr_driver_destroy(fr_driver *d) {
         if (p && d->ctx->cpu) free(p);
         else if (p) (void)hipFree(p);
     }
+    fr_ctx *held = d->ctx;
     delete d;
+    fr_ctx_unref(held);   // the driver's own reference (fr_driver_create): a driver destroyed after its context releases it last
 }
 
 extern "C" int fr_driver_create(fr_ctx *ctx, int n_threads, int depth, int max_batch, fr_driver **out) {
@@ -55,6 +57,7 @@ extern "C" int fr_driver_create(fr_ctx *ctx, int n_threads, int depth, int max_b
     fr_driver *d = new (std::nothrow) fr_driver();
     if (!d) FR_FAIL(FR_ERR_OOM, "out of host memory");
     d->ctx = ctx;
+    fr_ctx_ref(ctx);   // (dropped by fr_driver_destroy, also on the failure paths below, which all go through it)
     d->n_threads = n_threads;
     d->depth = depth;
     d->max_batch = max_batch;

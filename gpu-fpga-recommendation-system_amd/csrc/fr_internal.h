@@ -239,6 +239,10 @@ struct fr_ctx {
     std::atomic<int> small_block{0};
     int n_cu = 0;                          // compute units of the device (grid of the persistent fused kernel); set at creation
     int hk_ok = 0;                         // the persistent K-outer fused kernel applies to this context's descriptors; set at creation
+    // Lifetime (round 6): one reference for the handle fr_ctx_create gave out, one per live worker and per communicator handle.  fr_ctx_destroy
+    // drops the handle's; the context is released by whoever drops the last -- a worker or communicator destroyed AFTER its context no longer
+    // walks freed memory (a failed test's teardown did exactly that: "corrupted double-linked list").
+    std::atomic<int> life{1};
     std::atomic<int> n_workers{0};         // live workers of the context
     std::atomic<int> worker_seq{0};        // workers ever created on the context: a chain model's k-th worker takes the highest (k even) / lowest (k odd) stream priority
     // chain width W (fr_ctx_set_chain_width): the bf16 / fp8 GEMM layers of a chain model take tiles that cover 1 / W of the chip (lp_gemm_mu).
@@ -334,6 +338,9 @@ struct fr_worker {
     char last_kernel[96] = "";  // fr_worker_last_kernel: the dominant kernel of the most recent launch this worker enqueued
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
+
+void fr_ctx_ref(fr_ctx *c);     // + 1 reference (a worker, a communicator handle)
+void fr_ctx_unref(fr_ctx *c);   // - 1; the last one releases the context
 
 // ---- table-sharded exchange (fr_comm.cpp) ------------------------------------------------------------
 int fr_comm_wait(fr_worker *w);  // bounded wait for the sharded step in flight + the ranks' status words; FR_OK when none is in flight

@@ -215,6 +215,8 @@ int fr_model_bank_map(const fr_model_desc *m, int32_t *bank_of_table, int64_t *b
  * fleetrec_diag.h that name kernels.  Records are bit-identical to the device's; fp32 scores agree to ~1e-6 (another summation order). */
 int fr_ctx_create(const fr_model_desc *m, int device, fr_ctx **out);
 int fr_ctx_create_sharded(const fr_model_desc *m, int device, int shard_rank, int n_shards, fr_ctx **out);
+/* Workers, drivers and communicator handles that are still alive keep the context (tables, weights) until the last of them is destroyed:
+ * destroying a context first is allowed and leaves nothing dangling. */
 void fr_ctx_destroy(fr_ctx *ctx);
 const fr_model_desc *fr_ctx_model(const fr_ctx *ctx);
 

@@ -601,3 +601,43 @@ def test_server_shards_model_c_over_cpu_shard_contexts(fr):
     val = 3968.0 * 2 ** 28
     for r in rows:
         assert [float(x) for x in r.split()] == [0.0, 0.0, val, val, 0.0], (r, out)
+
+
+def test_a_context_destroyed_before_its_workers_and_communicators_leaves_nothing_dangling(fr):
+    """Lifetime (round 6): live workers and communicator handles hold the context; fr_ctx_destroy first is allowed -- the workers keep working
+    and the last object to go releases the tables.  (Before: the worker's destructor walked a freed context; a failed GPU test's teardown
+    ended in glibc's "corrupted double-linked list".)  Runs under ASan in tools/run_sanitizers.sh."""
+    m = fr.Model.builtin(fr.MODEL_A).clone(max_rows=2000)
+    ctx = fr.Context(m, device=CPU)
+    ctx.fill_tables(fr.FILL_HASH, 1)
+    ctx.fill_weights(fr.WEIGHTS_UNIFORM, 2)
+    wks = [fr.Worker(ctx, 32) for _ in range(3)]
+    idx = np.zeros((32, m.n_tables), np.int32)
+    want = wks[0].infer(idx)
+    ctx.close()                                   # the handle goes first
+    for w in wks:
+        assert np.array_equal(w.infer(idx), want)  # ... and the workers still have their context
+        w.close()
+    # sharded: contexts destroyed before their communicator handles and workers
+    mc = fr.Model.builtin(fr.MODEL_C).clone(max_rows=500)
+    ctxs = [fr.Context(mc, device=CPU, shard_rank=r, n_shards=2) for r in range(2)]
+    for c in ctxs:
+        c.fill_tables(fr.FILL_HASH, 1)
+        c.fill_weights(fr.WEIGHTS_UNIFORM, 2)
+    w2 = [fr.Worker(c, 16) for c in ctxs]
+    comms = fr.Comm.init_all(ctxs)
+    for c in ctxs:
+        c.close()
+    rng = np.random.default_rng(1)
+    ix = uniform_idx(rng, mc.rows(), 16)
+    de = rng.uniform(-1, 1, (16, mc.dense_len)).astype(np.float32)
+    _load_request(w2, ix, de)
+    for r in range(2):
+        w2[r].submit_sharded(comms[r], 16)
+    for r in range(2):
+        w2[r].sync()
+    assert np.array_equal(w2[0].score[:16], w2[1].score[:16])
+    for cm in comms:
+        cm.close()
+    for w in w2:
+        w.close()
