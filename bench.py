@@ -32,6 +32,16 @@ import sys
 import threading
 import time
 
+if "--cpu-child" in sys.argv:   # a helper process of the all-cores CPU baseline (cpu_child_main): pin to its slice of the cores and size the BLAS /
+    _k, _P = (int(v) for v in sys.argv[sys.argv.index("--cpu-child") + 1].split("/")[:2])   # OpenMP pools BEFORE numpy loads its OpenBLAS
+    _cpus = sorted(os.sched_getaffinity(0))
+    _per = max(len(_cpus) // _P, 1)
+    _mine = _cpus[_k * _per:(_k + 1) * _per] or _cpus
+    os.sched_setaffinity(0, _mine)
+    os.environ["OMP_NUM_THREADS"] = str(len(_mine))
+    os.environ["OPENBLAS_NUM_THREADS"] = str(min(len(_mine), 64))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -138,6 +148,8 @@ def compact_line(result):
     if cb:
         line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "gather_only", "fc_only", "end_to_end", "gather_threads", "fc_threads", "host_cpus_usable",
                                           "blas", "sample", "error"))
+        if isinstance(cb.get("all_cores"), dict):   # the same sample as P pinned processes on every usable core (detail file: per process)
+            line["cpu_baseline"]["all_cores"] = _pick(cb["all_cores"], ("processes", "cores", "end_to_end", "fc_only", "error"))
         for k, n in (("blas", 56), ("sample", 230)):   # the long forms are in the detail file
             if isinstance(line["cpu_baseline"].get(k), str) and len(line["cpu_baseline"][k]) > n:
                 line["cpu_baseline"][k] = line["cpu_baseline"][k][:n - 3] + "..."
@@ -450,6 +462,80 @@ def cpu_fc_chain(blas, X, ws, fc, bufs):
     return bufs[3]
 
 
+def cpu_child_main(spec):
+    """`bench.py --cpu-child K/P/BUDGET`: one of P host processes of the all-cores CPU baseline (leg_cpu_baseline).  Pinned to the K-th slice of
+    the usable cores BEFORE any BLAS / OpenMP pool exists, it runs the SAME sample as the parent -- Model-A, 16 384 items per call, bank images in
+    host RAM, OpenMP gather + 4 chained sgemm calls -- for BUDGET seconds and prints one JSON line.  Never touches a GPU: the weights come from
+    the library's CPU back-end (same content function as the device's)."""
+    k, P, budget = spec.split("/")
+    k, P, budget = int(k), int(P), float(budget)
+    mine = sorted(os.sched_getaffinity(0))   # (pinned at the top of this file, before numpy's OpenBLAS sized its pool)
+    import __graft_entry__ as graft
+    fr = graft.load_package()
+    O = graft.load_oracle()
+    O.lib().oracle_set_num_threads(len(mine))
+    model = fr.Model.builtin(fr.MODEL_A)
+    cctx = fr.Context(model.clone(max_rows=64), device=fr.DEVICE_CPU)       # weights only (the tables used below are the oracle's bank images)
+    cctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    ws = [cctx.get_weights(l) for l in range(4)]
+    cctx.close()
+    om = O.OracleModel("A")
+    h = om.halves[0]
+    imgs = h.bank_images_native(O.FILL_HASH, SEED_TABLES)
+    fc = model.fc
+    n = 64 * 256
+    rng_c = np.random.default_rng(SEED_IDX + 1000 * (k + 1))
+    groups = []
+    for _ in range(4):
+        src = uniform_idx(rng_c, model.rows(), n)
+        hi_ = np.empty_like(src)
+        hi_[:, h.wire_to_round] = src
+        groups.append(hi_)
+    rec = np.empty((n, h.record_len), dtype=np.uint32)
+    bufs = [np.empty((n, fc[l + 1]), dtype=np.float32) for l in range(4)]
+    blas = load_blas()
+    X = rec.view(np.float32)
+
+    def timed(fn):
+        fn(0)
+        reps, t_begin = 0, time.perf_counter()
+        while True:
+            fn(reps)
+            reps += 1
+            el = time.perf_counter() - t_begin
+            if el >= budget and reps >= 2:
+                return n * reps / el, reps
+    h.gather_direct(groups[0], True, imgs, out=rec)
+    f_rate, f_reps = timed(lambda i: cpu_fc_chain(blas, X, ws, fc, bufs))
+    e_rate, e_reps = timed(lambda i: (h.gather_direct(groups[i % 4], True, imgs, out=rec), cpu_fc_chain(blas, X, ws, fc, bufs)))
+    print(json.dumps({"cpu_child": k, "cpus": len(mine), "fc_only": f_rate, "end_to_end": e_rate, "calls": [f_reps, e_reps],
+                      "blas_threads": blas["threads"] if blas else None}), flush=True)
+
+
+def cpu_all_cores(usable, per_proc, budget_s):
+    """The same sample on EVERY usable core: P = usable / per_proc processes side by side, each pinned to its own slice (one BLAS build caps at 64
+    threads).  -> summed rates, or an {"error": ...} that leaves the single-process figures standing."""
+    P = max(usable // max(per_proc, 1), 1)
+    if P < 2:
+        return None
+    try:
+        env = dict(os.environ)
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-child", "%d/%d/%g" % (k, P, budget_s)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+                 for k in range(P)]
+        outs = []
+        for pr in procs:
+            o, e = pr.communicate(timeout=120)
+            if pr.returncode != 0:
+                return {"error": "child exited %d: %s" % (pr.returncode, e.decode(errors="replace")[-300:])}
+            outs.append(json.loads([ln for ln in o.decode().splitlines() if ln.startswith("{")][-1]))
+        return {"processes": P, "threads_per_process": per_proc, "cores": sum(o_["cpus"] for o_ in outs), "fc_only": sum(o_["fc_only"] for o_ in outs),
+                "end_to_end": sum(o_["end_to_end"] for o_ in outs), "per_process_end_to_end": [o_["end_to_end"] for o_ in outs],
+                "what": "P processes side by side, each pinned to its own slice of the usable cores, each running the same sample (own index rows, same tables / "
+                        "weights law) for the same wall time: the rates are summed"}
+    except Exception as ex:
+        return {"error": repr(ex)[:300]}
+
+
 def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=2.5):
     """Model-A on the node's host cores: tables materialised in host RAM exactly as host.cpp lays out the card's banks (1.4 GB),
     OpenMP gather that READS them, sgemm chain through OpenBLAS over the same 64 x 256 = 16384-item grouping one GPU launch
@@ -548,10 +634,17 @@ def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=
     err = float(np.abs(cpu_scores - gpu_scores_first).max() / max(np.abs(cpu_scores).max(), 1e-30)) if gpu_scores_first is not None else None
     gbytes = 1408 + 188 + 1408
     fc_threads = (alt or {}).get("threads") if blas_used is None else blas["threads"]
+    # ... and on EVERY usable core: the single-process figure above leaves three quarters of a 256-thread host idle in its FC phase (one OpenBLAS
+    # build = 64 threads); P pinned processes side by side do not.  `value` = the better of the two, `cores` = what that one used.
+    # (Measured on the GPU boxes of this pool: 4 x 64 pinned threads run the sample at a THIRD of the one 64-thread process's rate -- the 256 "usable" CPUs
+    # are a scheduler view, the box's CPU share is far smaller -- so the single process stays the baseline there; the line carries both.)
+    allc = cpu_all_cores(usable, max(fc_threads or 64, 1), min(budget_s, 1.0)) if os.environ.get("FR_BENCH_CPU_ALL_CORES", "1") != "0" else None
     # `cores` = the most host threads any phase of the end-to-end figure ran on: the gather's OpenMP team (`gather_threads`, the fastest of the
     # probe above -- all cores is not the fastest: hyper-threads / cgroup quotas) and the FC engine's pool (`fc_threads`: OpenBLAS builds cap
     # at 64, torch.mm takes its own default) run one after the other, never at the same time
-    return {"value": e_rate, "unit": "inferences/s", "cores": max(threads, fc_threads or 0), "gather_threads": threads, "fc_threads": fc_threads,
+    best_all = bool(allc and allc.get("end_to_end", 0) > e_rate)
+    return {"value": allc["end_to_end"] if best_all else e_rate, "unit": "inferences/s", "cores": allc["cores"] if best_all else max(threads, fc_threads or 0),
+            "gather_threads": threads, "fc_threads": fc_threads, "all_cores": allc, "single_process_end_to_end": e_rate,
             "kind": "port",
             "gather_only": g_rate, "fc_only": f_rate, "end_to_end": e_rate,
             "gather_GBps_algorithmic": g_rate * gbytes / 1e9, "fc_GFLOPs": f_rate * fc_flops_per_inference(fc) / 1e9,
@@ -562,7 +655,8 @@ def leg_cpu_baseline(graft, ctx, model, idx_host, B, gpu_scores_first, budget_s=
             "gpu_vs_cpu_max_rel_err_first_batch": err, "host_table_bytes": int(sum(im.nbytes for im in imgs)), "host_table_fill_s": t_fill,
             "sample": "Model-A, %d items per call (64 batches of 256 = one fused GPU launch), gather-only %d calls, FC-only %d, end-to-end %d (>= %.1f s each); "
                       "same seeded tables / weights / index law, 8 index groups rotated (the first = the GPU run's buffers); gather = OpenMP over items reading "
-                      "bank images in host RAM (oracle_gather_banks_direct), FC = 4 chained column-major sgemm calls" % (n, g_reps, f_reps, e_reps, budget_s)}
+                      "bank images in host RAM (oracle_gather_banks_direct), FC = 4 chained column-major sgemm calls; `all_cores` = the same sample as P processes "
+                      "side by side on every usable core, `value` = the better of the two" % (n, g_reps, f_reps, e_reps, budget_s)}
 
 
 def leg_cpu_backend(fr, idx_host, B, gpu_scores_first):
@@ -1303,9 +1397,12 @@ def main():
     ap.add_argument("--no-multi-sharded", action="store_true", help="N > 1: skip the table-sharded legs (`sharded`, `sharded_inflated_fp8`) of the default line")
     ap.add_argument("--fail-rank", type=int, default=-1, help="--plumbing-only: this rank exits with status 3 before the first barrier (launcher fail-fast test)")
     ap.add_argument("--fail-sharded-rank", type=int, default=-1, help="--plumbing-only: this rank raises inside a guarded collective leg (line + non-zero exit status test)")
+    ap.add_argument("--cpu-child", default=None, help=argparse.SUPPRESS)   # K/P/BUDGET: one process of the all-cores CPU baseline (cpu_child_main)
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch / rendezvous / timing-rule check without touching a GPU or the library (CPU test of the multi-GPU launcher)")
     args = ap.parse_args()
+    if args.cpu_child:   # a host-only helper process of leg_cpu_baseline: before anything could touch a GPU
+        return cpu_child_main(args.cpu_child)
 
     # ---- rank processes: torchrun supplies WORLD_SIZE; otherwise start them ourselves, before anything touches the GPU ----
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
