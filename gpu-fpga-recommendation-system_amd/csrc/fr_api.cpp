@@ -770,14 +770,16 @@ extern "C" void fr_worker_destroy(fr_worker *w) {
         return;
     }
     if (w->ctx) (void)hipSetDevice(w->ctx->device);
+    fr_comm_worker_release(w);   // a sharded step still being issued by the worker's host stream (staged exchange) is waited for (bounded); the communicator is let go
     if (w->stream) (void)hipStreamSynchronize(w->stream);
-    fr_comm_forget(w);   // a sharded step that was never synchronised lets go of its communicator
     if (w->counted) w->ctx->n_workers.fetch_sub(1, std::memory_order_relaxed);
     if (w->h_idx) (void)hipHostFree(w->h_idx);
     if (w->h_dense) (void)hipHostFree(w->h_dense);
     if (w->h_score) (void)hipHostFree(w->h_score);
     if (w->h_err) (void)hipHostFree(w->h_err);
     if (w->h_sh_status) (void)hipHostFree(w->h_sh_status);
+    if (w->h_stage_send) (void)hipHostFree(w->h_stage_send);
+    if (w->h_stage_recv) (void)hipHostFree(w->h_stage_recv);
     void *dev[] = {w->d_idx, w->d_dense, w->d_records, w->d_act[0], w->d_act[1], w->d_score, w->d_slice, w->d_gathered, w->d_score_part, w->d_score_all};
     for (void *p : dev)
         if (p) (void)hipFree(p);
@@ -2260,6 +2262,15 @@ extern "C" int fr_worker_sync(fr_worker *w) {
         return FR_OK;
     }
     FR_SET_DEVICE(w->ctx);
+    if (w->sh_comm && w->sh_host_stream) {
+        // a sharded step of a STAGED exchange is issued by the worker's host stream (it blocks in rendezvous): nothing below may touch the worker's
+        // pipeline state while that thread still runs the FC chain's launches -- the bounded wait comes first
+        const int crc0 = fr_comm_wait(w);
+        if (crc0) {
+            w->in_flight = false;
+            return crc0;
+        }
+    }
     int frc = host_ring_drain(w);  // host-fed blocks: launch the partial one, deliver every block's scores
     if (!frc) frc = fused_flush(w);  // launch batches still queued by fr_worker_push_device
     if (!frc) frc = pipeline_flush(w);  // drain the stage pipeline

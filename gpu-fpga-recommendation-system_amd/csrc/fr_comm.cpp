@@ -15,8 +15,13 @@
 //     worker that executes the posted step in order -- what a HIP stream is to a GPU worker), so fr_worker_submit_sharded returns at once and
 //     fr_worker_sync polls that stream with the same bounded loop.  Like an RCCL collective, the rendezvous itself waits without a bound and is
 //     released by an abort; the bound lives in fr_worker_sync.
-// The host exchange exists so that the protocol meets ranks 1 .. G-1 on machines without G GPUs (tests/test_cpu_backend.py, TSan build) and
-// as the exchange of `fleetrec_server --shards G --device -1`.
+//   * the same host exchange, STAGED, for GPU shard contexts that share a device (fr_comm_init_all over contexts of which two sit on one GPU --
+//     RCCL wants one device per rank): every all-gather is D2H into the worker's pinned staging, the rendezvous, H2D of all G parts; the step runs
+//     on a host stream as a CPU worker's does (the rendezvous blocks), the kernels and copies on the worker's HIP stream.  It is how the WHOLE
+//     step -- slice gathers in the chain's operand type, the uneven split on the device, NaN poisoning, status words through hipMemcpy2DAsync,
+//     the bf16 / fp8 chains on all-gathered slices, the sharded fp8 calibration -- runs with G = 2 .. 8 ranks on a one-GPU box.
+// The host exchange exists so that the protocol meets ranks 1 .. G-1 on machines without G GPUs (tests/test_cpu_backend.py, TSan build;
+// tests/test_gpu_sharded.py on one GPU) and as the exchange of `fleetrec_server --shards G --device -1`.
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: the functions are resolved through dlsym
 
@@ -320,6 +325,7 @@ extern "C" int fr_comm_init_all(fr_ctx *const *ctxs, int n, fr_comm **out) {
     for (int r = 0; r < n; r++) out[r] = nullptr;
     int rc;
     int devs[64];
+    bool shared_device = false;
     for (int r = 0; r < n; r++) {
         rc = comm_check_ctx(ctxs[r]);
         if (rc) return rc;
@@ -327,10 +333,11 @@ extern "C" int fr_comm_init_all(fr_ctx *const *ctxs, int n, fr_comm **out) {
         if (ctxs[r]->cpu != ctxs[0]->cpu) FR_FAIL(FR_ERR_INVALID, "ctxs[%d]: CPU and GPU shard contexts cannot share a communicator", r);
         devs[r] = ctxs[r]->device;
         if (!ctxs[r]->cpu)
-            for (int q = 0; q < r; q++)
-                if (devs[q] == devs[r]) FR_FAIL(FR_ERR_INVALID, "shards %d and %d share device %d: RCCL needs one device per rank", q, r, devs[r]);
+            for (int q = 0; q < r; q++) shared_device |= devs[q] == devs[r];
     }
-    const bool host = ctxs[0]->cpu;
+    // CPU contexts: the in-process host exchange.  GPU contexts of which two share a device (RCCL needs one device per rank): the same
+    // exchange, staged through pinned host memory.  One device per rank: RCCL.
+    const bool host = ctxs[0]->cpu || shared_device;
     ncclComm_t comms[64];
     HostGroup *grp = nullptr;
     if (host) {   // the in-process host exchange: nothing of RCCL is touched (or loaded)
@@ -395,7 +402,9 @@ void fr_comm_forget(fr_worker *w) {
     if (comm) comm_release(comm);
 }
 
-// fr_worker_destroy of a CPU worker: a step still running on the host stream is given its communicator's bound, then the exchange is
+bool fr_comm_step_on_host_stream(const fr_worker *w) { return w->sh_host_stream && !static_cast<const HostStream *>(w->sh_host_stream)->done(); }
+
+// fr_worker_destroy of a worker with a host stream (CPU workers; GPU workers of a staged exchange): a step still running on the host stream is given its communicator's bound, then the exchange is
 // aborted (which releases a step parked in a rendezvous); the stream thread is joined, the step's reference dropped.
 void fr_comm_worker_release(fr_worker *w) {
     if (w->sh_host_stream) {
@@ -461,8 +470,17 @@ static int step_fill_ff(fr_worker *w, void *dst, size_t bytes) {   // NaN in eve
 // ONE all-gather of `bytes` per rank through the communicator's transport
 static int step_all_gather(fr_worker *w, fr_comm *comm, const void *send, void *recv, size_t bytes) {
     if (comm->grp) {
-        if (comm->grp->all_gather(comm->rank, send, recv, bytes) != FR_OK)
+        const void *h_send = send;
+        void *h_recv = recv;
+        if (!w->ctx->cpu) {   // staged: this rank's part comes off the device first (everything the step enqueued so far has then run)
+            FR_HIP(hipMemcpyAsync(w->h_stage_send, send, bytes, hipMemcpyDeviceToHost, w->stream));
+            FR_HIP(hipStreamSynchronize(w->stream));
+            h_send = w->h_stage_send;
+            h_recv = w->h_stage_recv;
+        }
+        if (comm->grp->all_gather(comm->rank, h_send, h_recv, bytes) != FR_OK)
             FR_FAIL(FR_ERR_COMM, "host exchange: the all-gather of %zu bytes per rank was aborted (a peer failed, never arrived, or sent another size)", bytes);
+        if (!w->ctx->cpu) FR_HIP(hipMemcpyAsync(recv, w->h_stage_recv, bytes * (size_t)comm->n_ranks, hipMemcpyHostToDevice, w->stream));
         return FR_OK;
     }
     ncclResult_t r = g_rccl.AllGather(send, recv, bytes, ncclChar, comm->comm, w->stream);
@@ -471,7 +489,8 @@ static int step_all_gather(fr_worker *w, fr_comm *comm, const void *send, void *
 }
 // -> 0 the step's stream is idle, 1 still working, < 0 the stream itself failed
 static int step_query(fr_worker *w) {
-    if (w->ctx->cpu) return (!w->sh_host_stream || static_cast<HostStream *>(w->sh_host_stream)->done()) ? 0 : 1;
+    if (w->sh_host_stream && !static_cast<HostStream *>(w->sh_host_stream)->done()) return 1;   // the step is still being issued (host exchange, plain or staged)
+    if (w->ctx->cpu) return 0;
     hipError_t q = hipStreamQuery(w->stream);
     if (q == hipSuccess) return 0;
     if (q == hipErrorNotReady) return 1;
@@ -494,8 +513,8 @@ static bool step_async_error(fr_comm *comm) {
 }
 
 // exchange buffers of a worker: slice [max_batch][F] and gathered [G][max_batch][F] sized for fp32 elements, score chunks
-static int shard_buffers(fr_worker *w, int G) {
-    if (w->sh_ranks == G && w->d_slice) return FR_OK;
+static int shard_buffers(fr_worker *w, int G, bool staged) {
+    if (w->sh_ranks == G && w->d_slice && (!staged || w->ctx->cpu || w->h_stage_send)) return FR_OK;
     fr_ctx *c = w->ctx;
     const size_t slice = (size_t)w->max_batch * (size_t)c->slice_padded * sizeof(float);
     const size_t chunk = ((size_t)w->max_batch + G - 1) / G + 1;  // + the rank's status word (failure protocol, kind (2))
@@ -515,6 +534,14 @@ static int shard_buffers(fr_worker *w, int G) {
     w->d_score_part = static_cast<float *>(step_alloc(w, chunk * sizeof(float)));
     w->d_score_all = static_cast<float *>(step_alloc(w, chunk * G * sizeof(float)));
     if (!w->d_slice || !w->d_gathered || !w->d_score_part || !w->d_score_all) FR_FAIL(FR_ERR_OOM, "exchange buffers for %d ranks x batch %d: out of memory", G, w->max_batch);
+    if (staged && !c->cpu) {   // the staged exchange of GPU contexts that share a device: one part out, G parts in, through pinned host memory
+        if (w->h_stage_send) (void)hipHostFree(w->h_stage_send);
+        if (w->h_stage_recv) (void)hipHostFree(w->h_stage_recv);
+        w->h_stage_send = w->h_stage_recv = nullptr;
+        const size_t part = slice > chunk * sizeof(float) ? slice : chunk * sizeof(float);
+        FR_HIP(hipHostMalloc(&w->h_stage_send, part, hipHostMallocDefault));
+        FR_HIP(hipHostMalloc(&w->h_stage_recv, part * G, hipHostMallocDefault));
+    }
     w->sh_ranks = G;
     return FR_OK;
 }
@@ -535,7 +562,7 @@ static int sharded_check_args(fr_worker *w, fr_comm *comm, int batch) {
 static int sharded_prologue(fr_worker *w, fr_comm *comm, int batch, const int32_t **idx, const float **dense) {
     fr_ctx *c = w->ctx;
     if (!c->cpu) FR_HIP(hipSetDevice(c->device));
-    int rc = shard_buffers(w, comm->n_ranks);
+    int rc = shard_buffers(w, comm->n_ranks, comm->grp != nullptr);
     if (rc) return rc;
     if (c->cpu) {
         *idx = w->h_idx;

@@ -331,6 +331,7 @@ struct fr_worker {
     struct fr_comm *sh_comm = nullptr;  // a sharded step is in flight through this communicator (fr_worker_sync -> fr_comm_wait)
     int sh_ranks = 0;
     std::atomic<int> sh_inject_fc_fail{0};   // fr_worker_inject_fc_failure (fleetrec_diag.h): sharded steps left whose FC chain is reported as failed
+    void *h_stage_send = nullptr, *h_stage_recv = nullptr;   // pinned staging of the STAGED host exchange (GPU shard contexts that share a device)
     void *sh_host_stream = nullptr;  // CPU workers: the host stream their sharded steps run on (fr_comm.cpp HostStream), made on first use
     int *h_err = nullptr;  // sticky index-range flag: pinned host word ...
     int *d_err = nullptr;  // ... and its device-side alias
@@ -344,6 +345,7 @@ void fr_ctx_unref(fr_ctx *c);   // - 1; the last one releases the context
 
 // ---- table-sharded exchange (fr_comm.cpp) ------------------------------------------------------------
 int fr_comm_wait(fr_worker *w);  // bounded wait for the sharded step in flight + the ranks' status words; FR_OK when none is in flight
+bool fr_comm_step_on_host_stream(const fr_worker *w);   // a sharded step of this worker is being issued by its host stream right now
 void fr_comm_worker_release(fr_worker *w);  // fr_worker_destroy of a CPU worker: stop its host stream (bounded), then fr_comm_forget
 void fr_comm_forget(fr_worker *w);  // drop the step's hold on its communicator without waiting (fr_worker_sync leaving early)
 

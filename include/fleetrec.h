@@ -396,7 +396,11 @@ int fr_worker_fc_from_slices_lp(fr_worker *w, int batch_total, int item0, int n_
  * instead -- the same step, status words, reference counts and bounded wait above another transport (a rendezvous of the ranks' host
  * streams; librccl.so is not touched).  A CPU worker's step runs on a host stream of its own behind fr_worker_submit_sharded, so one thread
  * may submit on all G workers and then synchronise them, or G threads may drive one rank each.  fp32 only; fr_comm_init_rank /
- * fr_comm_unique_id (ranks in different processes) remain RCCL-only. */
+ * fr_comm_unique_id (ranks in different processes) remain RCCL-only.
+ * GPU shard contexts of which two SHARE a device (RCCL wants one device per rank): fr_comm_init_all gives them the same host exchange, STAGED
+ * (every all-gather = D2H into pinned staging, the rendezvous, H2D of all G parts; the step is issued by a host stream per worker, the
+ * kernels run on the worker's HIP stream) -- every precision, every entry point; PCIe-bound, meant for rehearsing a G-rank job on fewer
+ * GPUs.  fr_worker_calibrate_fp8_sharded stays a synchronous collective there: one thread per rank. */
 typedef struct fr_comm fr_comm;
 int fr_comm_unique_id(void *id128);
 int fr_comm_init_rank(fr_ctx *ctx, const void *id128, fr_comm **out);

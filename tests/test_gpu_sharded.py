@@ -379,6 +379,113 @@ def test_submit_sharded_through_rccl_two_ranks(fr, O, gpu, prec):
         c_.close()
 
 
+@pytest.mark.parametrize("G,prec", [(2, "f32"), (3, "bf16"), (8, "fp8"), (8, "f32")])
+def test_submit_sharded_with_several_ranks_on_one_gpu_through_the_staged_exchange(fr, O, gpu, G, prec):
+    """Round 6: fr_comm_init_all over GPU shard contexts that SHARE a device builds the staged host exchange (D2H -> rendezvous -> H2D; RCCL
+    wants one device per rank), so the WHOLE step of fr_worker_submit_sharded runs with G = 2, 3, 8 ranks on the one GPU a test box has: slice
+    gathers in the chain's operand type (fp32 / bf16 / e4m3 transport), the uneven item split (B = 301) and batches smaller than G on the
+    device, the status words through the strided copy, the bf16 / fp8 chains on all-gathered slices, the sharded fp8 calibration (a
+    synchronous collective: one thread per rank), submit on all ranks from ONE thread followed by the syncs (the step is issued by each
+    worker's host stream).  Every rank ends with the same B scores; against the oracle within the chain's tolerance, in fp32 within 1e-5 of an
+    unsharded context.  Then the failure protocol on the device: an injected FC failure on rank q -> every rank's sync names q, q's items are
+    NaN (the device-side poisoning), the others right; a rank that never arrives trips the bounded wait."""
+    import threading
+    import time
+    m = fr.Model.builtin(fr.MODEL_C).clone(max_rows=20000)
+    om = O.OracleModel("C")
+    P = {"f32": fr.FC_FP32, "bf16": fr.FC_BF16, "fp8": fr.FC_FP8}[prec]
+    tol = {"f32": 1e-3, "bf16": 3e-2, "fp8": 0.15}[prec]
+    ctxs_, wks = [], []
+    for r in range(G):
+        c = fr.Context(m, device=gpu, shard_rank=r, n_shards=G)
+        c.fill_tables(fr.FILL_HASH, SEED_TABLES)
+        c.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+        c.set_fc_precision(P)
+        ctxs_.append(c)
+        wks.append(fr.Worker(c, 1024))
+    comms = fr.Comm.init_all(ctxs_)
+    whole = fr.Context(m, device=gpu)
+    whole.fill_tables(fr.FILL_HASH, SEED_TABLES)
+    whole.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+    w0 = fr.Worker(whole, 1024)
+    rng = np.random.default_rng(60 + G)
+    try:
+        def load(idx, dense):
+            for w in wks:
+                w.idx[:len(idx)] = idx
+                w.dense[:len(idx)] = dense
+        if prec == "fp8":                                   # every rank calibrates on the same all-gathered fp32 slices: identical exponents
+            idx_c = uniform_idx(rng, m.rows(), 1024)
+            dense_c = rng.uniform(-1, 1, (1024, m.dense_len)).astype(np.float32)
+            th = [threading.Thread(target=lambda r=r: wks[r].calibrate_fp8_sharded(comms[r], idx_c, dense_c)) for r in range(G)]
+            [t.start() for t in th]
+            [t.join(120) for t in th]
+            assert not any(t.is_alive() for t in th)
+            assert all(c.fp8_exponents() == ctxs_[0].fp8_exponents() for c in ctxs_)
+        for B in (301, 5, 1024):
+            idx = uniform_idx(rng, m.rows(), B)
+            dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+            load(idx, dense)
+            for r in range(G):                              # one driving thread: the submits return at once
+                wks[r].submit_sharded(comms[r], B)
+            got = []
+            for r in reversed(range(G)):
+                wks[r].sync()
+                got.append(wks[r].score[:B].copy())
+            for g_ in got[1:]:
+                assert np.array_equal(g_, got[0]), (G, prec, B)
+            rec = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES).view(np.float32)
+            ref = om.fc_chain(rec, [ctxs_[0].get_weights(l) for l in range(4)], acc64=True)
+            assert rel_err(got[0], ref) <= tol, (G, prec, B, rel_err(got[0], ref))
+            if prec == "f32":
+                assert rel_err(got[0], w0.infer(idx, dense)) <= 1e-5
+        # kind (2): the FC chain of rank q "fails"
+        B, q = 301, G - 1
+        idx = uniform_idx(rng, m.rows(), B)
+        dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+        load(idx, dense)
+        for r in range(G):
+            wks[r].submit_sharded(comms[r], B)
+        for r in range(G):
+            wks[r].sync()
+        good = wks[0].score[:B].copy()
+        wks[q].inject_fc_failure(1)
+        for r in range(G):
+            wks[r].submit_sharded(comms[r], B)
+        base, rem = B // G, B % G
+        lo = q * base + min(q, rem)
+        hi = lo + base + (1 if q < rem else 0)
+        for r in range(G):
+            with pytest.raises(fr.FleetRecError) as e:
+                wks[r].sync()
+            assert e.value.status == fr.FR_ERR_COMM and "shard rank %d reported a failed FC chain" % q in str(e.value), (r, str(e.value))
+            sc = wks[r].score[:B]
+            assert np.isnan(sc[lo:hi]).all() and np.array_equal(sc[:lo], good[:lo]) and np.array_equal(sc[hi:], good[hi:]), r
+        # kind (3): the last rank never arrives
+        for cm in comms:
+            cm.set_wait_ms(400)
+        t0 = time.time()
+        for r in range(G - 1):
+            wks[r].submit_sharded(comms[r], B)
+        for r in range(G - 1):
+            with pytest.raises(fr.FleetRecError) as e:
+                wks[r].sync()
+            assert e.value.status == fr.FR_ERR_COMM, str(e.value)
+        assert time.time() - t0 < 30
+        with pytest.raises(fr.FleetRecError) as e:
+            wks[G - 1].submit_sharded(comms[G - 1], B)
+        assert e.value.status == fr.FR_ERR_COMM
+    finally:
+        for w in wks:
+            w.close()
+        for cm in comms:
+            cm.close()
+        for c in ctxs_:
+            c.close()
+        w0.close()
+        whole.close()
+
+
 @pytest.mark.parametrize("rank", [1, 6])
 def test_config5_inflated_shard_gather(fr, O, gpu, rank):
     """BASELINE configs[4] on one GPU: one of the 8 table-ID shards of Model-C inflated 5x (316 GB in total, 30-60 GB per shard).
