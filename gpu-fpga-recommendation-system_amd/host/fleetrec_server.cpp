@@ -13,7 +13,7 @@
 // Usage: fleetrec_server --model A|B|C [--batch 256] [--threads 4] [--port 8080] [--total 1024] [--device 0]
 //        [--stream [--reply [--flush-us 50] [--flush-min 32]]]: streaming with score replies and adaptive batching -- see thread_consume
 //                        [--tables evenodd|hash] [--weights ones|uniform] [--per-item | --per-bank] [--reply] [--row-cap N]
-//                        [--shards G [--precision f32|bf16|fp8]]
+//                        [--shards G [--one-device] [--precision f32|bf16|fp8]]
 // --shards G: BASELINE configs[3]/[4] -- the tables are sharded by table-ID over GPUs device .. device + G - 1 of this node, or with
 // --device -1 over G CPU shard contexts of this process exchanging through the library's in-process host exchange (one
 // context and one worker per shard, fr_comm_init_all); every batch goes through fr_worker_submit_sharded on all shards (slices
@@ -48,6 +48,7 @@ struct Options {
     int tables = FR_FILL_EVEN_ODD, weights = FR_WEIGHTS_ONES;
     bool per_item = false, per_bank = false, reply = false;
     int shards = 0;            // > 0: table-sharded over `shards` GPUs
+    bool one_device = false;   // --shards G --one-device: all G shard contexts on GPU `device` (the library's staged host exchange: a G-rank job rehearsed on one GPU)
     int precision = FR_FC_FP32;
     bool stream = false;   // throughput mode: fr_worker_push_host (blocks of batches per launch) instead of submit + sync per batch
     long flush_us = 50;    // --stream --reply: how long the socket must stay dry before a partial block is launched
@@ -406,6 +407,7 @@ int main(int argc, char **argv) {
         else if (a == "--per-item") o.per_item = true;
         else if (a == "--per-bank") o.per_bank = true;
         else if (a == "--shards") o.shards = atoi(next());
+        else if (a == "--one-device") o.one_device = true;
         else if (a == "--precision") { std::string v = next(); o.precision = v == "bf16" ? FR_FC_BF16 : v == "fp8" ? FR_FC_FP8 : FR_FC_FP32; }
         else if (a == "--reply") o.reply = true;
         else if (a == "--latency") o.latency = true;
@@ -431,7 +433,7 @@ int main(int argc, char **argv) {
         engine.workers.assign(o.shards, nullptr);
         for (int r = 0; r < o.shards; r++) {
             // GPUs device .. device + G - 1, or (--device -1) G CPU shard contexts exchanging in process (fr_comm_init_all picks the transport)
-            if (fr_ctx_create_sharded(model, o.device < 0 ? -1 : o.device + r, r, o.shards, &engine.ctxs[r]) != FR_OK || fr_ctx_fill_tables(engine.ctxs[r], o.tables, 0xF1EE7) != FR_OK ||
+            if (fr_ctx_create_sharded(model, o.device < 0 ? -1 : (o.one_device ? o.device : o.device + r), r, o.shards, &engine.ctxs[r]) != FR_OK || fr_ctx_fill_tables(engine.ctxs[r], o.tables, 0xF1EE7) != FR_OK ||
                 fr_ctx_fill_weights(engine.ctxs[r], o.weights, 99) != FR_OK || fr_ctx_set_fc_precision(engine.ctxs[r], o.precision) != FR_OK ||
                 fr_worker_create(engine.ctxs[r], o.batch, &engine.workers[r]) != FR_OK) {
                 fprintf(stderr, "shard %d set-up failed: %s\n", r, fr_last_error());
@@ -448,6 +450,7 @@ int main(int argc, char **argv) {
         g_engine = &engine;
         ctx = engine.ctxs[0];
         if (o.device < 0) printf("table-sharded over %d CPU shard contexts (in-process host exchange of the looked-up slices)\n", o.shards);
+        else if (o.one_device) printf("table-sharded over %d shard contexts on GPU %d (staged host exchange of the looked-up slices)\n", o.shards, o.device);
         else printf("table-sharded over %d GPUs (RCCL all-gather of the looked-up slices)\n", o.shards);
     } else if (fr_ctx_create(model, o.device, &ctx) != FR_OK || fr_ctx_fill_tables(ctx, o.tables, 0xF1EE7) != FR_OK ||
                fr_ctx_fill_weights(ctx, o.weights, 99) != FR_OK || fr_ctx_set_fc_precision(ctx, o.precision) != FR_OK) {

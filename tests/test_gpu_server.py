@@ -17,7 +17,8 @@ HOST = os.path.join(ROOT, "gpu-fpga-recommendation-system_amd", "host")
                                              ("A", 352.0 * 2 ** 27, ["--stream"]),
                                              ("A", 352.0 * 2 ** 27, ["--stream", "--reply"]),   # scores back over the socket, sender window 64
                                              ("B", 880.0 * 2 ** 27, ["--per-bank", "--row-cap", "200"]),          # the kernel's own index contract on the wire
-                                             ("C", 3968.0 * 2 ** 28, ["--row-cap", "200", "--shards", "1"])])     # sharded engine + RCCL (one-rank communicator)
+                                             ("C", 3968.0 * 2 ** 28, ["--row-cap", "200", "--shards", "1"]),      # sharded engine + RCCL (one-rank communicator)
+                                             ("C", 3968.0 * 2 ** 28, ["--row-cap", "200", "--shards", "3", "--one-device"])])   # three shard contexts on one GPU: the staged exchange
 def test_server_and_sender_known_answer(fr, gpu, model, val, extra):
     """Reference data end to end: even/odd tables, the 32 fixed indices, all-ones weights -> the first five scores of the
     last batch are 0 0 K*H1*H2*H3 K*H1*H2*H3 0 (indices 3, 99, 38, 72, 29), as the reference prints them (cuda_server.c:499-502)."""
@@ -30,7 +31,7 @@ def test_server_and_sender_known_answer(fr, gpu, model, val, extra):
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     time.sleep(0.5)
     snd = subprocess.Popen([os.path.join(HOST, "fleetrec_sender"), "--model", model, "--batch", "128", "--threads", str(threads),
-                            "--port", str(port), "--indices", "reference"] + [e_ for e_ in extra if e_ not in ("--stream", "--shards", "1")]
+                            "--port", str(port), "--indices", "reference"] + [e_ for e_ in extra if e_ not in ("--stream", "--shards", "1", "3", "--one-device")]
                            + (["--window", "64"] if "--reply" in extra else []),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     try:
@@ -53,7 +54,7 @@ def test_server_and_sender_known_answer(fr, gpu, model, val, extra):
     if "--stream" not in extra and "--shards" not in extra:
         assert "Average time from batch received to enqueued" in out
     if "--shards" in extra:
-        assert "table-sharded over 1 GPUs" in out
+        assert ("table-sharded over 3 shard contexts on GPU" if "--one-device" in extra else "table-sharded over 1 GPUs") in out
     assert "blocks sent" in sout.decode()
     if "--reply" in extra:      # every request the server took was answered, and the sender timed the round trips
         m_ = re.search(r"latency request sent -> scores received  n=(\d+) avg ([0-9.]+) us", sout.decode())
