@@ -1229,9 +1229,15 @@ static int pipeline_step(fr_worker *w) {
                     st.variant = trv;
                     if (trv == 2 && lp_image_applies(c, prec)) {   // ... of bank rows that are already in the chain's operand type
                         const int irc = lp_ensure_image(c, prec);
-                        if (irc) return irc;
-                        a.words = c->d_words_lp;
-                        a.src_lp = 1;
+                        if (irc == FR_ERR_OOM) {
+                            // no HBM left for the image: the gather reads the fp32 rows and converts them itself -- the same scores, bit for bit
+                            c->lp_image_on.store(0, std::memory_order_relaxed);
+                        } else if (irc) {
+                            return irc;
+                        } else {
+                            a.words = c->d_words_lp;
+                            a.src_lp = 1;
+                        }
                     }
                     blocks += (trb + 7) / 8 * 8;
                     n_stages++;
