@@ -67,7 +67,8 @@ float *fr_worker_features_dptr(fr_worker *w, int *ld_max);
  * second time in the chain's operand type (bf16; e4m3 at the calibrated X exponent), made from the fp32 tables with the gather's own
  * rounding and rebuilt by itself whenever precision, calibration or table contents change; the in-chain gather of a large batch reads THAT
  * (82 lines per Model-C item instead of 142, nothing to convert).  Scores are bit-identical either way.  on = 0 makes the gather read the
- * fp32 rows and convert them itself (the A/B and parity hook; default 1).  fr_ctx_lp_bank_image_bytes: HBM the image holds now (0: none). */
+ * fp32 rows and convert them itself (the A/B and parity hook; default 1; a context that finds no HBM for the image switches to 0 by itself: same
+ * scores).  fr_ctx_lp_bank_image_bytes: HBM the image holds now (0: none). */
 int fr_ctx_set_lp_bank_image(fr_ctx *ctx, int on);
 size_t fr_ctx_lp_bank_image_bytes(const fr_ctx *ctx);
 
