@@ -3,7 +3,9 @@
 its real neighbours: four workers on four host threads push device-resident batches for `seconds`; every delivered score vector is compared BIT FOR
 BIT with the one a lone worker computed for the same rows before the soak.  A DMA that lands late, a stage overwritten early or a barrier that
 does not cover a read shows as a flipped score (such races come and go with what else runs on the CU).  workers = 1: chain width 1, the lone worker's
-full-chip tiles (fc_pp_gemm_n128_kernel).  Usage: soak_chain.py [seconds] [bf16|fp8] [workers: 4] [batch: 4096]"""
+full-chip tiles (fc_pp_gemm_n128_kernel).  `bank` (round 6): a FR_INDEX_PER_BANK context -- the reference scores are computed with the gather reading
+the fp32 rows (fr_ctx_set_lp_bank_image(0)), the soak runs over the operand-type bank image: a race in gather_tr_stream_lp_body's LDS tile AND any
+difference between the two row sources show as a flipped score.  Usage: soak_chain.py [seconds] [bf16|fp8] [workers: 4] [batch: 4096] [table|bank]"""
 import os
 import sys
 import threading
@@ -19,7 +21,10 @@ fr = g.load_package()
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 n_workers = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+per_bank = len(sys.argv) > 5 and sys.argv[5] == "bank"
 m = fr.Model.builtin(fr.MODEL_C)
+if per_bank:
+    m = m.clone(index_mode=fr.INDEX_PER_BANK)
 ctx = fr.Context(m, device=0)
 ctx.fill_tables(fr.FILL_HASH, 0xF1EE7)
 ctx.fill_weights(fr.WEIGHTS_UNIFORM, 99)
@@ -31,12 +36,17 @@ NP = 6
 pool, d_pool = [], []
 ref_wk = fr.Worker(ctx, B)
 for j in range(NP):
-    idx = (rng0.random((B, m.n_tables)) * m.rows()[None, :]).astype(np.int32)
+    rr = m.index_ranges()
+    idx = (rng0.random((B, len(rr))) * rr[None, :]).astype(np.int32)
     dense = rng0.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
     if prec == "fp8" and j == 0:
         ref_wk.calibrate_fp8(idx, dense)
+    if per_bank:
+        ctx.set_lp_bank_image(0)   # the references: fp32 rows, converted by the gather
     pool.append(ref_wk.infer(idx, dense).copy())
     d_pool.append((fr.DeviceBuffer.from_numpy(ctx, idx), fr.DeviceBuffer.from_numpy(ctx, dense)))
+if per_bank:
+    ctx.set_lp_bank_image(1)       # the soak: rows already in the operand type
 ref_wk.fc_layer_only(B, 0)
 k0 = ref_wk.last_kernel()
 ref_wk.sync()
@@ -71,7 +81,7 @@ for t_ in th:
     t_.start()
 for t_ in th:
     t_.join()
-print("soak_chain %s: FC1 = %s, %d batches of %d in %.0f s on %d worker(s), %d mismatches" % (prec, k0, sum(counts), B, secs, n_workers, len(errors)))
+print("soak_chain %s%s: FC1 = %s, %d batches of %d in %.0f s on %d worker(s), %d mismatches" % (prec, " per bank (operand-type image %.2f GB)" % (ctx.lp_bank_image_bytes() / 1e9) if per_bank else "", k0, sum(counts), B, secs, n_workers, len(errors)))
 for e in errors[:5]:
     print("  ", e)
 sys.exit(1 if errors else 0)
