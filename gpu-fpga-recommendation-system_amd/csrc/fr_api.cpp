@@ -886,10 +886,11 @@ extern "C" int fr_worker_create(fr_ctx *ctx, int max_batch, fr_worker **out) {
         // k = how many workers the context has EVER created (one fetch_add: two threads creating workers at once cannot draw the same k, and a
         // destroy + create keeps alternating -- ADVICE r04: the live count did neither)
         const int k = ctx->worker_seq.fetch_add(1, std::memory_order_relaxed);
-        // (Round 6 tried to CHECK the outcome -- handshake kernels between a new worker's stream and its peers' -- and to keep the first streams in
-        // a pool: neither helps.  After some stream churn in the process one pair of a context's four workers takes turns (four Model-C chains
-        // 48 -> 37-45 M inf/s) although handshake kernels on the two streams see each other resident, and pooled streams pair up just the same:
-        // profiles/r06_experiments.md section 4.  What the library controls is what it does here.)
+        // (Round 6 tried to CHECK and REPAIR the outcome, and kept none of it -- profiles/r06_experiments.md section 4: after some stream churn in the
+        // process one pair of a context's four workers takes turns (four Model-C chains 48 -> 37-45 M inf/s).  Handshake kernels on the two streams
+        // see each other resident; a BURST of part-chip spin launches on both does expose the pair (0.8-1.2 kernels resident of 2 against 1.95-2.0)
+        // -- but a stream that probes clean at creation pairs up again when the next queue is created, a pool of streams pairs up all the same,
+        // and replacing streams after all workers exist does not converge.  What the library controls is what it does here.)
         if (lo > hi) W_HIP(hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, spread == 2 ? hi + k % (lo - hi + 1) : (k % 2 ? lo : hi)));
         else W_HIP(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
     }
@@ -1048,6 +1049,51 @@ extern "C" int fr_ctx_set_chain_width(fr_ctx *ctx, int width) {
     ctx->chain_width_auto.store(false, std::memory_order_relaxed);
     return FR_OK;
 }
+
+#ifdef FR_EXPERIMENTS
+int frk_spin_probe(hipStream_t s, int wgs, int lds_bytes, unsigned ticks);
+// experiments build only (no header): n spin launches on wa's stream alone, then n on each of wa's and wb's streams interleaved -> microseconds per launch
+extern "C" __attribute__((visibility("default"))) int fr_exp_burst_probe(fr_worker *wa, fr_worker *wb, int n, int wgs, int lds_bytes, int ticks, float *us_alone, float *us_pair) {
+    if (!wa || !wb || !us_alone || !us_pair) FR_FAIL(FR_ERR_INVALID, "bad argument");
+    FR_SET_DEVICE(wa->ctx);
+    hipEvent_t e[4];
+    for (auto &x : e) FR_HIP(hipEventCreate(&x));
+    for (int i = 0; i < 3; i++) {   // warm both
+        int rc = frk_spin_probe(wa->stream, wgs, lds_bytes, (unsigned)ticks);
+        if (!rc) rc = frk_spin_probe(wb->stream, wgs, lds_bytes, (unsigned)ticks);
+        if (rc) return rc;
+    }
+    FR_HIP(hipStreamSynchronize(wa->stream));
+    FR_HIP(hipStreamSynchronize(wb->stream));
+    FR_HIP(hipEventRecord(e[0], wa->stream));
+    for (int i = 0; i < n; i++) {
+        int rc = frk_spin_probe(wa->stream, wgs, lds_bytes, (unsigned)ticks);
+        if (rc) return rc;
+    }
+    FR_HIP(hipEventRecord(e[1], wa->stream));
+    FR_HIP(hipStreamSynchronize(wa->stream));
+    float ms = 0;
+    FR_HIP(hipEventElapsedTime(&ms, e[0], e[1]));
+    *us_alone = 1e3f * ms / n;
+    FR_HIP(hipEventRecord(e[0], wa->stream));
+    FR_HIP(hipEventRecord(e[2], wb->stream));
+    for (int i = 0; i < n; i++) {
+        int rc = frk_spin_probe(wa->stream, wgs, lds_bytes, (unsigned)ticks);
+        if (!rc) rc = frk_spin_probe(wb->stream, wgs, lds_bytes, (unsigned)ticks);
+        if (rc) return rc;
+    }
+    FR_HIP(hipEventRecord(e[1], wa->stream));
+    FR_HIP(hipEventRecord(e[3], wb->stream));
+    FR_HIP(hipStreamSynchronize(wa->stream));
+    FR_HIP(hipStreamSynchronize(wb->stream));
+    float ma = 0, mb = 0;
+    FR_HIP(hipEventElapsedTime(&ma, e[0], e[1]));
+    FR_HIP(hipEventElapsedTime(&mb, e[2], e[3]));
+    *us_pair = 1e3f * (ma > mb ? ma : mb) / n;
+    for (auto &x : e) (void)hipEventDestroy(x);
+    return FR_OK;
+}
+#endif
 
 extern "C" int fr_ctx_chain_width(const fr_ctx *ctx) { return ctx ? ctx->chain_width.load(std::memory_order_relaxed) : FR_ERR_INVALID; }
 

@@ -420,3 +420,29 @@ int frk_records_to_q8_bf16(const float *X, void *Xh, int batch, int K, int ldm, 
 }
 
 
+
+
+#ifdef FR_EXPERIMENTS
+// experiments build: a spin kernel shaped like a part-chip GEMM launch of a chain model (workgroups x 512 threads, dynamic LDS) for the queue-pairing
+// probe of tools/experiments/queue_aging.py (fr_exp_burst_probe).  Every wave exits: bounded by the 100 MHz clock and an iteration count.
+__global__ void __launch_bounds__(512) spin_probe_kernel(unsigned ticks, unsigned *sink) {
+    extern __shared__ unsigned spin_lds[];
+    if (threadIdx.x == 0) spin_lds[0] = ticks;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned n = 0;
+    for (int it = 0; it < 4000000; it++) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)spin_lds[0]) break;
+        __builtin_amdgcn_s_sleep(8);
+        n++;
+    }
+    if (n == 0xffffffffu && sink) sink[0] = n;
+}
+int frk_spin_probe(hipStream_t s, int wgs, int lds_bytes, unsigned ticks) {
+    static FrLdsAttrOnce once;
+    if (int rc_ = fr_allow_full_lds(&spin_probe_kernel, once)) return rc_;
+    spin_probe_kernel<<<dim3(wgs), dim3(512), lds_bytes, s>>>(ticks, nullptr);
+    KCHECK();
+    return FR_OK;
+}
+#endif

@@ -41,6 +41,18 @@ def measure(tag):
     rate(8)
     r = max(rate() for _ in range(3))
     print("%-28s FC2 resident %.2f of 4; pairs (01 02 03 12 13 23) %s; four chains %.1f M inf/s" % (tag, res, " ".join("%.2f" % p for p in pair), r), flush=True)
+    import ctypes, os
+    if os.path.basename(fr.LIB_PATH) == "libfleetrec_exp.so":   # does a generic spin burst see the pair that takes turns?
+        L = ctypes.CDLL(fr.LIB_PATH)
+        L.fr_exp_burst_probe.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_float)] * 2
+        for wgs, lds, ticks in ((32, 131072, 3000), (32, 0, 3000), (1, 0, 3000)):
+            out = []
+            for i in range(4):
+                for j in range(i + 1, 4):
+                    a, b = ctypes.c_float(), ctypes.c_float()
+                    L.fr_exp_burst_probe(wks[i]._h, wks[j]._h, 12, wgs, lds, ticks, ctypes.byref(a), ctypes.byref(b))
+                    out.append("%.2f" % (2 * a.value / b.value))
+            print("    spin burst (%d wgs, %d KiB LDS, %d us): pair residency %s" % (wgs, lds // 1024, ticks // 100, " ".join(out)), flush=True)
     for w in wks: w.close()
     for x in d_s: x.free()
 measure("fresh process")
