@@ -486,6 +486,61 @@ def test_submit_sharded_with_several_ranks_on_one_gpu_through_the_staged_exchang
         whole.close()
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_config4_shape_full_size_eight_ranks_through_the_c_abi_step(fr, O, gpu, ctxs, prec):
+    """BASELINE configs[3] as the C-ABI runs it -- Model-C FULL SIZE (63.2 GB of tables cut into eight table-ID shards), batch 4096, eight ranks,
+    fr_worker_submit_sharded on every rank -- on the one GPU of a test box through the staged exchange: every rank ends with the same 4096 scores;
+    fp32 within 1e-5 of the unsharded full-size context, bf16 within 3e-2 of the fp64-accumulating oracle on EVERY item and within 1e-2 of the
+    unsharded bf16 chain.  (What stays unmeasured is the transport -- RCCL over xGMI -- not the step.)"""
+    G, B = 8, 4096
+    m, whole = ctxs(2)
+    om = O.OracleModel("C")
+    P = {"f32": fr.FC_FP32, "bf16": fr.FC_BF16}[prec]
+    ctxs_, wks = [], []
+    comms = []
+    rng = np.random.default_rng(4096)
+    idx = uniform_idx(rng, m.rows(), B)
+    dense = rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)
+    whole.set_fc_precision(P)
+    try:
+        w0 = fr.Worker(whole, B)
+        unsharded = w0.infer(idx, dense)
+        w0.close()
+        for r in range(G):
+            c = fr.Context(m, device=gpu, shard_rank=r, n_shards=G)
+            c.fill_tables(fr.FILL_HASH, SEED_TABLES)
+            c.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+            c.set_fc_precision(P)
+            ctxs_.append(c)
+            wks.append(fr.Worker(c, B))
+        comms = fr.Comm.init_all(ctxs_)
+        for w in wks:
+            w.idx[:B] = idx
+            w.dense[:B] = dense
+        for r in range(G):
+            wks[r].submit_sharded(comms[r], B)
+        got = []
+        for r in range(G):
+            wks[r].sync()
+            got.append(wks[r].score[:B].copy())
+        for g_ in got[1:]:
+            assert np.array_equal(g_, got[0])
+        rec = om.gather(idx, dense=dense, content_mode=O.FILL_HASH, seed=SEED_TABLES).view(np.float32)
+        ref = om.fc_chain(rec, [whole.get_weights(l) for l in range(4)], acc64=True)
+        assert rel_err(got[0], ref) <= {"f32": 1e-3, "bf16": 3e-2}[prec], rel_err(got[0], ref)
+        assert rel_err(got[0], unsharded) <= {"f32": 1e-5, "bf16": 1e-2}[prec], rel_err(got[0], unsharded)
+        if prec == "f32":
+            assert rel_err_each(got[0], ref) <= 1e-3
+    finally:
+        whole.set_fc_precision(fr.FC_FP32)
+        for w in wks:
+            w.close()
+        for cm in comms:
+            cm.close()
+        for c in ctxs_:
+            c.close()
+
+
 @pytest.mark.parametrize("rank", [1, 6])
 def test_config5_inflated_shard_gather(fr, O, gpu, rank):
     """BASELINE configs[4] on one GPU: one of the 8 table-ID shards of Model-C inflated 5x (316 GB in total, 30-60 GB per shard).
