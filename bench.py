@@ -1463,7 +1463,10 @@ def main():
     ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
     rng = np.random.default_rng(dist_mod.replica_seed(SEED_IDX, rank))
     rows = model.bank_map()[1] if args.per_bank else model.rows()
-    n_bufs = N_IDX_BUFFERS if args.model == "A" else 16
+    # rotating index buffers: enough that a launch group does not re-hit its own rows in the 256 MB Infinity Cache (Model-B: 16 buffers x 1024
+    # items x 98 rows = 205 MB of lines FIT there, and the single-configuration runs read 353 M inf/s / 390 us per launch where the default
+    # line's 32 buffers give 330 M / 411 us -- round 6 found the profiled runs flattered by that; SURVEY 8(d): ">= 32 rotating")
+    n_bufs = N_IDX_BUFFERS if args.model == "A" else (32 if args.model == "B" else 16)
     idx_host = [uniform_idx(rng, rows, B) for _ in range(n_bufs)]
     d_idx = [fr.DeviceBuffer.from_numpy(ctx, a) for a in idx_host]
     dense_host = [rng.uniform(-1, 1, (B, model.dense_len)).astype(np.float32) for _ in range(n_bufs)] if model.dense_len else None
