@@ -89,7 +89,7 @@ int rccl_load() {
 // ---- transport 2: the in-process host exchange --------------------------------------------------------------------------------------
 namespace {
 constexpr int FR_HOST_MAX_RANKS = 64;
-// One per fr_comm_init_all over CPU contexts, shared by its G handles.  all_gather: every rank publishes its send buffer and waits for the
+// One per fr_comm_init_all over CPU contexts (or over GPU contexts that share a device: the staged form), shared by its G handles.  all_gather: every rank publishes its send buffer and waits for the
 // others (barrier 1), copies all G buffers into its own receive buffer, and waits until everybody has copied (barrier 2: only then may a
 // send buffer be reused).  Barrier 1 ends early when the group is aborted; barrier 2 never does -- every rank that left barrier 1 is copying
 // from its peers' buffers and will count itself in, and no buffer may go away under a peer's memcpy.
@@ -160,7 +160,8 @@ struct HostGroup {
     }
 };
 
-// The host stream of a CPU worker: one thread, one posted step at a time (a worker has at most one sharded step in flight).
+// The host stream of a worker whose exchange is the host group (CPU workers; GPU workers of the staged form): one thread, one posted step at a
+// time (a worker has at most one sharded step in flight).
 struct HostStream {
     std::mutex m;
     std::condition_variable cv;
@@ -228,7 +229,7 @@ HostStream *host_stream(fr_worker *w) {
 
 struct fr_comm {
     ncclComm_t comm = nullptr;   // transport 1: RCCL (GPU contexts)
-    HostGroup *grp = nullptr;    // transport 2: the in-process host exchange (CPU contexts); exactly one of the two is set
+    HostGroup *grp = nullptr;    // transport 2: the in-process host exchange (CPU contexts; staged: GPU contexts sharing a device); exactly one of the two is set
     int rank = 0, n_ranks = 1;
     fr_ctx *ctx = nullptr;
     // a collective step failed on this rank: the communicator was aborted, every later call returns FR_ERR_COMM (atomic: a CPU worker's step
@@ -579,7 +580,7 @@ static int sharded_prologue(fr_worker *w, fr_comm *comm, int batch, const int32_
 
 // THE STEP, on either transport: slice gather -> all-gather of the slices -> FC chain on this rank's items -> all-gather of the score
 // chunks (each followed by its rank's status word) -> every rank's pinned score buffer.  A GPU worker's fr_worker_submit_sharded calls it
-// inline (every line enqueues on the worker's stream); a CPU worker's posts it to the worker's host stream.  *enqueued is set once the
+// inline (every line enqueues on the worker's stream); a host-exchange worker's (CPU, or staged GPU) posts it to the worker's host stream.  *enqueued is set once the
 // second collective is on its way: from then on fr_worker_sync has something to wait for, whatever this function returns.
 static int sharded_step(fr_worker *w, fr_comm *comm, int batch, bool *enqueued) {
     *enqueued = false;
@@ -645,7 +646,7 @@ extern "C" int fr_worker_submit_sharded(fr_worker *w, fr_comm *comm, int batch) 
     if (rc) return rc;
     w->sh_comm = comm;  // fr_worker_sync waits through fr_comm_wait and reads the G status words
     comm->refs.fetch_add(1, std::memory_order_relaxed);
-    if (comm->grp) {   // a CPU worker: the step runs behind this call on the worker's host stream, as a GPU worker's runs on its HIP stream
+    if (comm->grp) {   // the host exchange (CPU worker, or staged GPU worker): the step runs behind this call on the worker's host stream -- its rendezvous blocks
         host_stream(w)->post([w, comm, batch] {
             bool enqueued = false;
             return sharded_step(w, comm, batch, &enqueued);
@@ -675,7 +676,7 @@ int fr_comm_wait(fr_worker *w) {
     return rc;
 }
 
-// a CPU worker's step has left its host stream: what it returned (kind (3) failures surface here; a kind (2) return is told by the status words)
+// a host-exchange worker's step has left its host stream: what it returned (kind (3) failures surface here; a kind (2) return is told by the status words)
 static int host_step_result(fr_worker *w, fr_comm *comm) {
     HostStream *hs = static_cast<HostStream *>(w->sh_host_stream);
     if (!hs) return FR_OK;
