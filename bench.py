@@ -178,6 +178,10 @@ def compact_line(result):
                           # pipelined form, the sharded scores against an unsharded context's, bit for bit
                           "ok": bool(c_.get("pipelined_equals_stepwise")) if c_.get("pipelined_equals_stepwise") is not None
                                 else (bool(c_["sharded_vs_unsharded_context"].get("bit_identical")) if c_.get("sharded_vs_unsharded_context") else None)}, 5)   # None: nothing was compared
+    if result.get("sharded_cabi_rccl"):   # the C-ABI's own RCCL step with G = N ranks (child processes): ok / rate / ranks, or the error
+        line["sharded_cabi_rccl"] = _r(_pick(result["sharded_cabi_rccl"], ("ok", "ranks_ok", "world", "inferences_per_s", "ms_per_step", "fp32_max_rel_err_vs_unsharded_first_512", "error")), 5)
+        if isinstance(line["sharded_cabi_rccl"].get("error"), str):
+            line["sharded_cabi_rccl"]["error"] = line["sharded_cabi_rccl"]["error"][:160]
     line["detail"] = os.path.relpath(DETAIL_FILE, ROOT)
     line = _r(line)
     s = json.dumps(line, separators=(",", ":"))
@@ -1060,6 +1064,93 @@ def leg_gather(fr, ctx, model, B, law, reps=200, nbuf=32, seed=SEED_IDX, variant
 # ------------------------------------------------------------------------------------------------------------------
 # sharded mode (BASELINE configs[3] / [4])
 # ------------------------------------------------------------------------------------------------------------------
+def cabi_child_main(spec):
+    """`bench.py --cabi-child RANK/WORLD/DEVICE/IDHEX/OUT`: one rank of the C-ABI's OWN table-sharded step over RCCL (fr_comm_init_rank +
+    fr_worker_submit_sharded, csrc/fr_comm.cpp) -- the path no one-GPU box can run with G > 1.  Started by every rank of an N > 1 bench run
+    as a child process of its own (leg_cabi_rccl): whatever happens here -- an RCCL set-up that hangs, a failed step -- stays in the child,
+    the parent's line is never at stake.  Model-C, batch 4096: fp32 steps checked on rank 0 against an unsharded full-size context
+    (first 512 items, 1e-5), then bf16 steps timed.  Writes one JSON object to OUT."""
+    r, G, dev, idhex, out_path = spec.split("/", 4)
+    r, G, dev = int(r), int(G), int(dev)
+    import __graft_entry__ as graft
+    fr = graft.load_package()
+    res = {"rank": r, "world": G}
+    try:
+        B = 4096
+        m = fr.Model.builtin(fr.MODEL_C)
+        ctx = fr.Context(m, device=dev, shard_rank=r, n_shards=G)
+        ctx.fill_tables(fr.FILL_HASH, SEED_TABLES)
+        ctx.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+        wk = fr.Worker(ctx, B)
+        comm = fr.Comm.init_rank(ctx, bytes.fromhex(idhex))
+        comm.set_wait_ms(20000)
+        rng = np.random.default_rng(SEED_IDX)                       # every rank draws the SAME request batches
+        reqs = [(uniform_idx(rng, m.rows(), B), rng.uniform(-1, 1, (B, m.dense_len)).astype(np.float32)) for _ in range(4)]
+        first = wk.infer_sharded(comm, *reqs[0])                     # fp32
+        res["fp32_scores_sha1"] = __import__("hashlib").sha1(first.tobytes()).hexdigest()
+        if r == 0:
+            whole = fr.Context(m, device=dev)
+            whole.fill_tables(fr.FILL_HASH, SEED_TABLES)
+            whole.fill_weights(fr.WEIGHTS_UNIFORM, SEED_WEIGHTS)
+            w0 = fr.Worker(whole, 512)
+            ref = w0.infer(reqs[0][0][:512], reqs[0][1][:512])
+            res["fp32_max_rel_err_vs_unsharded_first_512"] = float(np.abs(first[:512] - ref).max() / max(np.abs(ref).max(), 1e-30))
+            w0.close()
+            whole.close()
+        ctx.set_fc_precision(fr.FC_BF16)
+        for i in range(5):
+            wk.infer_sharded(comm, *reqs[i % 4])
+        steps = 40
+        t0 = time.perf_counter()
+        for i in range(steps):
+            wk.idx[:B] = reqs[i % 4][0]
+            wk.dense[:B] = reqs[i % 4][1]
+            wk.submit_sharded(comm, B)
+            wk.sync()
+        dt = time.perf_counter() - t0
+        res.update({"ok": True, "dtype": "bf16", "steps": steps, "ms_per_step": 1e3 * dt / steps, "inferences_per_s": B * steps / dt,
+                    "what": "fr_worker_submit_sharded + fr_worker_sync per step through the C-ABI's own RCCL communicator (host-buffer form: the request's "
+                            "H2D and the scores' D2H inside), Model-C batch 4096, %d table-ID shards, bf16 slice transport" % G})
+        wk.close()
+        comm.close()
+        ctx.close()
+    except BaseException as ex:   # noqa: BLE001
+        res.update({"ok": False, "error": repr(ex)[:400]})
+    with open(out_path + ".tmp", "w") as f:
+        json.dump(res, f)
+    os.replace(out_path + ".tmp", out_path)
+
+
+def leg_cabi_rccl(fr, env, local_rank, limit_s=150.0):
+    """N > 1, real devices: the C-ABI's own RCCL step (fr_comm_init_rank / fr_worker_submit_sharded) with G = N ranks, each rank in a CHILD process
+    (cabi_child_main) so that nothing it does can cost the line.  Rank 0 draws the RCCL unique id and broadcasts it through the process group.
+    -> rank 0: the child's result object (or why there is none); other ranks: None."""
+    import tempfile
+    idhex = [fr.Comm.unique_id().hex() if env.rank == 0 else None]
+    env.dist.broadcast_object_list(idhex, src=0)
+    out = os.path.join(tempfile.gettempdir(), "fr_cabi_%s_%d_%d.json" % (os.environ.get("MASTER_PORT", "0"), os.getpid(), env.rank))
+    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cabi-child", "%d/%d/%d/%s/%s" % (env.rank, env.world, local_rank, idhex[0], out)],
+                             stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    try:
+        _, err = child.communicate(timeout=limit_s)
+        why = None if child.returncode == 0 else "child exited %s: %s" % (child.returncode, err.decode(errors="replace")[-300:])
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.communicate()
+        why = "no result within %.0f s (child killed)" % limit_s
+    res = None
+    if os.path.exists(out):
+        try:
+            res = json.load(open(out))
+        finally:
+            os.unlink(out)
+    if res is None:
+        res = {"ok": False, "error": why or "the child wrote no result"}
+    ok_all = env.sum_over_ranks(1.0 if res.get("ok") else 0.0)      # (the parents' own process group: every rank reports its child)
+    res["ranks_ok"] = int(ok_all)
+    return res if env.rank == 0 else None
+
+
 def main_sharded(args, graft):
     """`--mode sharded`: the table-sharded configuration alone (see run_sharded); prints its own JSON line."""
     import importlib
@@ -1397,12 +1488,15 @@ def main():
     ap.add_argument("--no-multi-sharded", action="store_true", help="N > 1: skip the table-sharded legs (`sharded`, `sharded_inflated_fp8`) of the default line")
     ap.add_argument("--fail-rank", type=int, default=-1, help="--plumbing-only: this rank exits with status 3 before the first barrier (launcher fail-fast test)")
     ap.add_argument("--fail-sharded-rank", type=int, default=-1, help="--plumbing-only: this rank raises inside a guarded collective leg (line + non-zero exit status test)")
+    ap.add_argument("--cabi-child", default=None, help=argparse.SUPPRESS)  # RANK/WORLD/DEVICE/IDHEX/OUT: one rank of the C-ABI RCCL leg (cabi_child_main)
     ap.add_argument("--cpu-child", default=None, help=argparse.SUPPRESS)   # K/P/BUDGET: one process of the all-cores CPU baseline (cpu_child_main)
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch / rendezvous / timing-rule check without touching a GPU or the library (CPU test of the multi-GPU launcher)")
     args = ap.parse_args()
     if args.cpu_child:   # a host-only helper process of leg_cpu_baseline: before anything could touch a GPU
         return cpu_child_main(args.cpu_child)
+    if args.cabi_child:  # one rank of the C-ABI RCCL leg, in a process of its own
+        return cabi_child_main(args.cabi_child)
 
     # ---- rank processes: torchrun supplies WORLD_SIZE; otherwise start them ourselves, before anything touches the GPU ----
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -1944,6 +2038,17 @@ def main():
                 result[keys[name]] = res
             leg_done(keys[name])
         guard.close()
+        # ... and the C-ABI's OWN RCCL step (fr_comm_init_rank + fr_worker_submit_sharded) with G = N ranks -- the one piece of the product no
+        # one-GPU box can execute -- each rank in a child process, so that it cannot cost the line (a failure is a string in `sharded_cabi_rccl`)
+        cabi_env = os.environ.get("FR_BENCH_CABI_RCCL", "1")   # 0: skip; force: also with --share-device (two ranks on one GPU: RCCL refuses -> exercises the failure path)
+        if not cpu and (not args.share_device or cabi_env == "force") and env.dist is not None and cabi_env != "0":
+            try:
+                cres = leg_cabi_rccl(fr, env, local_rank)
+            except Exception as ex:   # noqa: BLE001
+                cres = {"ok": False, "error": repr(ex)[:300]} if rank == 0 else None
+            if rank == 0:
+                result["sharded_cabi_rccl"] = cres
+            leg_done("sharded_cabi_rccl")
 
     if rank == 0:
         result["leg_seconds_total"] = round(sum(leg_s.values()), 1)

@@ -471,3 +471,32 @@ def test_bench_tcp_leg_fails_cleanly_without_a_gpu():
     r = bench.leg_tcp(256, 0, threads=2, total=64)
     assert ("error" in r or "skipped" in r) and "value" not in r, r
     assert time.time() - t0 < 60
+
+
+@pytest.mark.gpu
+def test_bench_cabi_rccl_leg_child_and_failure_path(gpu, tmp_path):
+    """Round 6: at N > 1 the bench line also runs the C-ABI's OWN table-sharded step over RCCL (fr_comm_init_rank + fr_worker_submit_sharded with
+    G = N ranks) -- the one piece of the product a one-GPU box cannot execute with G > 1 -- each rank in a CHILD process, so that an RCCL set-up
+    that fails or hangs is a string in `sharded_cabi_rccl`, never a lost line.  Here: (1) the child itself with a one-rank communicator whose unique
+    id is drawn by this (living) process, as the bench parent does: fp32 within 1e-5 of the unsharded context, bf16 steps timed; (2) the parent's
+    integration with two ranks SHARING the one GPU (FR_BENCH_CABI_RCCL=force): RCCL refuses two ranks on one device, the line carries that
+    error, `ranks_ok` 0, and the job still exits 0 with its headline and its torch.distributed sharded leg intact."""
+    import json
+    import __graft_entry__ as g
+    fr = g.load_package()
+    out = str(tmp_path / "child.json")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cabi-child", "0/1/%d/%s/%s" % (gpu, fr.Comm.unique_id().hex(), out)],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    res = json.load(open(out))
+    assert res["ok"] is True and res["world"] == 1 and res["fp32_max_rel_err_vs_unsharded_first_512"] <= 1e-5 and res["inferences_per_s"] > 1e5, res
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["FR_BENCH_CABI_RCCL"] = "force"
+    env["FR_BENCH_DETAIL"] = str(tmp_path / "detail.json")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--legs", "none", "--steps", "300", "--warmup", "100"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = _the_line(p.stdout.decode())
+    c = line["sharded_cabi_rccl"]
+    assert c["ok"] is False and c["ranks_ok"] == 0 and c["world"] == 2 and "ncclCommInitRank" in c["error"], c
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["sharded"]["ok"] is True
