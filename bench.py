@@ -50,7 +50,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0}   # dense MFMA peaks (same guide; no 2:1 sparsity)
 SEED_TABLES, SEED_IDX, SEED_WEIGHTS = 0xF1EE7, 1234, 99
-N_IDX_BUFFERS = 64           # distinct index buffers rotated through (>= 32), so caches are not re-hit artificially
+N_IDX_BUFFERS = 1024         # distinct index buffers rotated through (>= 32), so caches are not re-hit artificially.  Round 6: 64 of them
+                             # (770 k distinct Model-A rows = 98 MB of lines) sit INSIDE the 256 MB Infinity Cache and read 0.9 % high (71.05 vs 70.4 M
+                             # inf/s; the kernel's own time does not move: profiles/r06_headline_index_buffers.txt); 1024 = 1.6 GB of lines do not
 STEADY_S = 2.2               # minimum wall clock of the timed region behind `value`
 PROFILE_ROUND = "r06"       # prefix of the committed rocprofv3 summaries the roofline objects quote (profiles/<round>_*_kernel_stats.csv)
 PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r06_pmc.json", "r05_pmc.json", "archive/r04_pmc.json", "archive/r03_pmc.json", "archive/r02_pmc.json")]   # newest first, entry by entry (see pmc())
